@@ -1,0 +1,409 @@
+"""Run the reference's OWN GLSL (read from /root/reference at run time) on CPU llvmpipe.
+
+TEST INFRASTRUCTURE ONLY — the product never imports this (see oracle/README.md).
+
+This is the strongest oracle available for the path: the three.js/postprocessing runtime is
+not installable here (no network, Node 12), but the fragment shaders — where ALL of the
+arithmetic lives — compile unmodified on Mesa llvmpipe.  This module
+
+  1. assembles each pass's final fragment source exactly the way the reference's JS does
+     (string surgery cited per function), with the three.js prefix of SURVEY.md Appendix E and
+     the two restated three.js chunks `<packing>` / `<common>`;
+  2. drives the passes with the uniform values the reference's JS drivers would set
+     (SSGIPass.js:68-95, TemporalReprojectPass.js:162-214, PoissonDenoisePass.js:135-149,
+     DenoiserComposePass.js:129-135), including ping-pong, history wiring, keepData and the
+     "discard keeps previous contents" behaviour;
+  3. returns every stage's render target as numpy arrays.
+
+It is used (a) here in the build container to generate tests/golden/*.npz
+(tests/golden/make_golden.py) and to validate the C restatement oracle/rfx_oracle.c, and
+(b) optionally on the GPU box as the "reference" CPU baseline, from the assembled shader files
+that `make -C oracle ref` drops into oracle/_ref/shaders/ (build products, git-ignored).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_OUT = os.path.join(HERE, "..", "_ref")
+REFERENCE_SRC = "/root/reference/src/"
+
+FMT_RGBA32F, FMT_RGBA16F, FMT_R32F, FMT_RGBA8 = 0, 1, 2, 3
+
+# ------------------------------------------------------------------ three.js chunks (restated)
+# three@0.151.3 is an un-vendored peer dependency (package.json:52-55).  Only these pieces of
+# its ShaderChunks are reached by the path:
+CHUNK_COMMON = """
+#define PI 3.141592653589793
+#define PI2 6.283185307179586
+#define PI_HALF 1.5707963267948966
+#define RECIPROCAL_PI 0.3183098861837907
+#define RECIPROCAL_PI2 0.15915494309189535
+#define EPSILON 1e-6
+#ifndef saturate
+#define saturate( a ) clamp( a, 0.0, 1.0 )
+#endif
+"""
+CHUNK_PACKING = """
+float viewZToOrthographicDepth( const in float viewZ, const in float near, const in float far ) { return ( viewZ + near ) / ( near - far ); }
+float orthographicDepthToViewZ( const in float depth, const in float near, const in float far ) { return depth * ( near - far ) - near; }
+float viewZToPerspectiveDepth( const in float viewZ, const in float near, const in float far ) { return ( ( near + viewZ ) * far ) / ( ( far - near ) * viewZ ); }
+float perspectiveDepthToViewZ( const in float depth, const in float near, const in float far ) { return ( near * far ) / ( ( far - near ) * depth - far ); }
+"""
+
+
+def _rd(rel):
+    with open(REFERENCE_SRC + rel, encoding="utf-8-sig") as f:
+        return f.read()
+
+
+def unroll_loops(s: str) -> str:
+    """src/ssgi/utils/Utils.js:71-89 (three's WebGLProgram loop unroller)."""
+    pat = re.compile(
+        r"#pragma unroll_loop_start\s+for\s*\(\s*int\s+i\s*=\s*(\d+)\s*;\s*i\s*<\s*(\d+)\s*;\s*i\s*\+\+\s*\)\s*{([\s\S]+?)}\s+#pragma unroll_loop_end")
+
+    def rep(m):
+        out = ""
+        for i in range(int(m.group(1)), int(m.group(2))):
+            out += re.sub(r"\[\s*i\s*\]", "[ %d ]" % i, m.group(3)).replace("UNROLLED_LOOP_INDEX", str(i))
+        return out
+
+    return pat.sub(rep, s)
+
+
+def three_prefix(defines: dict, glsl3: bool) -> str:
+    """WebGLProgram fragment prefix for a non-raw ShaderMaterial on WebGL2."""
+    p = "#version 300 es\n#define varying in\n"
+    if not glsl3:
+        p += "layout(location = 0) out highp vec4 pc_fragColor;\n#define gl_FragColor pc_fragColor\n"
+    p += ("#define texture2D texture\n#define textureCube texture\n"
+          "precision highp float;\nprecision highp int;\nprecision highp sampler2D;\n")
+    for k, v in defines.items():
+        p += "#define %s %s\n" % (k, v)
+    p += "uniform mat4 viewMatrix;\nuniform vec3 cameraPosition;\nuniform bool isOrthographic;\n"
+    return p
+
+
+def _with_blue_noise(src: str) -> str:
+    """src/utils/BlueNoiseUtils.js:35 — inserted after the first `uniform vec2 resolution;`."""
+    return src.replace("uniform vec2 resolution;", "uniform vec2 resolution;\n" + _rd("utils/shader/blue_noise.glsl"), 1)
+
+
+def assemble_ssgi(steps=20, refine_steps=5, mode=0, use_direct_light=True, missed_rays=False) -> str:
+    """SSGIMaterial.js:44-56 + SSGIPass.js:38-40 + SSGIEffect.js:143-151,203-221."""
+    gb = _rd("gbuffer/shader/gbuffer_packing.glsl")
+    s = (_rd("ssgi/shader/ssgi.frag").replace("#include <ssgi_utils>", _rd("ssgi/shader/ssgi_utils.frag"))
+         .replace("#include <gbuffer_packing>", gb).replace("#include <packing>", CHUNK_PACKING))
+    s = _with_blue_noise(s)
+    d = {"steps": int(steps), "refineSteps": int(refine_steps), "CUBEUV_TEXEL_WIDTH": 0, "CUBEUV_TEXEL_HEIGHT": 0,
+         "CUBEUV_MAX_MIP": 0, "vWorldPosition": "worldPos", "PERSPECTIVE_CAMERA": "", "mode": int(mode)}
+    if use_direct_light:
+        d["useDirectLight"] = ""
+    if missed_rays:
+        d["missedRays"] = ""
+    return three_prefix(d, False) + s
+
+
+def assemble_temporal(texture_count=2, input_type=0, confidence_power=0.75, reproject_specular=(False, True),
+                      neighborhood_clamp=(False, True), log_transform=True, neighborhood_clamp_radius=2) -> str:
+    """TemporalReprojectMaterial.js:11-41 + TemporalReprojectPass.js:76-117."""
+    gb = _rd("gbuffer/shader/gbuffer_packing.glsl")
+    s = (_rd("temporal-reproject/shader/temporal_reproject.frag")
+         .replace("#include <reproject>", _rd("temporal-reproject/shader/reproject.frag"))
+         .replace("#include <gbuffer_packing>", gb))
+    d = "".join("uniform sampler2D accumulatedTexture%d;\nlayout(location = %d) out vec4 gOutput%d;\n" % (i, i, i)
+                for i in range(texture_count))
+    s = unroll_loops(d + s.replace("textureCount", str(texture_count)))
+    s = re.sub(r"accumulatedTexture\[\s*(\d+)\s*\]", r"accumulatedTexture\1", s)
+    s = re.sub(r"gOutput\[\s*(\d+)\s*\]", r"gOutput\1", s)
+    s = s.replace("#include <packing>", CHUNK_PACKING)
+
+    def boolarr(v):
+        # TemporalReprojectPass.js:109-116: `typeof value !== "array"` is always true -> the
+        # option (already an array) is wrapped in Array(textureCount).fill(value) and joined.
+        v = list(v) if isinstance(v, (list, tuple)) else [v]
+        flat = [("true" if x else "false") for _ in range(texture_count) for x in v]
+        if len(v) > 1:  # JS join of nested arrays: "false,true, false,true"
+            return "bool[](" + ", ".join(",".join("true" if x else "false" for x in v) for _ in range(texture_count)) + ")"
+        return "bool[](" + ", ".join(flat) + ")"
+
+    defines = {"textureCount": texture_count, "PERSPECTIVE_CAMERA": "", "neighborhoodClampRadius": int(neighborhood_clamp_radius),
+               "depthDistance": "2.0000", "worldDistance": "4.0000", "inputType": int(input_type)}
+    if log_transform:
+        defines["logTransform"] = ""
+    # (:79 first sets neighborhoodClamp as a flag; :115 overwrites it with the array form below)
+    defines["reprojectSpecular"] = boolarr(reproject_specular)
+    defines["neighborhoodClamp"] = boolarr(neighborhood_clamp)
+    defines["confidencePower"] = _to_precision5(confidence_power)
+    return three_prefix(defines, True) + s
+
+
+def _to_precision5(x: float) -> str:
+    """JS Number.prototype.toPrecision(5) for the values used (0.75 -> '0.75000', 4 -> '4.0000')."""
+    s = "%.5g" % x
+    if "e" in s:
+        return s
+    digits = len(s.replace("-", "").replace(".", "").lstrip("0"))
+    if "." not in s:
+        s += "."
+    return s + "0" * max(0, 5 - digits)
+
+
+def assemble_denoise(texture_count=2, is_texture_specular=(False, True)) -> str:
+    """PoissonDenoisePass.js:14,43-71,108-117."""
+    gb = _rd("gbuffer/shader/gbuffer_packing.glsl")
+    s = _rd("denoise/shader/poisson_denoise.frag").replace("#include <gbuffer_packing>", gb).replace("textureCount", str(texture_count))
+    s = unroll_loops(s).replace("#include <common>", CHUNK_COMMON)
+    s = _with_blue_noise(s)
+    d = {"isTextureSpecular": "bool[2](" + ",".join("true" if x else "false" for x in is_texture_specular) + ")",
+         "GBUFFER_TEXTURE": ""}
+    return three_prefix(d, True) + s
+
+
+def assemble_compose(input_type=0) -> str:
+    """DenoiserComposePass.js:35-110 (inline template literal)."""
+    js = _rd("denoise/pass/DenoiserComposePass.js")
+    m = re.search(r"fragmentShader:\s*/\* glsl \*/\s*`([\s\S]*?)`,\s*vertexShader", js)
+    s = m.group(1)
+    s = s.replace("${gbuffer_packing}", _rd("gbuffer/shader/gbuffer_packing.glsl"))
+    s = s.replace("${ssgi_poisson_compose_functions}", _rd("denoise/shader/denoiser_compose_functions.glsl"))
+    s = s.replace("#include <common>", CHUNK_COMMON).replace("#include <packing>", CHUNK_PACKING)
+    return three_prefix({"inputType": int(input_type), "PERSPECTIVE_CAMERA": ""}, False) + s
+
+
+def write_assembled(outdir: str, **kw):
+    """Build products for the GPU box (no /root/reference there): oracle/_ref/shaders/*.frag."""
+    os.makedirs(outdir, exist_ok=True)
+    for name, src in (("ssgi_20_5", assemble_ssgi(20, 5)), ("ssgi_8_2", assemble_ssgi(8, 2)), ("ssgi_40_5", assemble_ssgi(40, 5)),
+                      ("temporal", assemble_temporal()), ("denoise", assemble_denoise()), ("compose", assemble_compose())):
+        with open(os.path.join(outdir, name + ".frag"), "w") as f:
+            f.write(src)
+
+
+# ------------------------------------------------------------------ ctypes layer
+
+
+class GL:
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            os.environ.setdefault("glsl_zero_init", "true")  # WebGL zero-init (Appendix C-6)
+            os.environ.setdefault("LP_NUM_THREADS", str(os.cpu_count() or 1))
+            path = os.path.join(REF_OUT, "libglref.so")
+            L = ctypes.CDLL(path)
+            L.glref_info.restype = ctypes.c_char_p
+            L.glref_last_ms.restype = ctypes.c_double
+            rc = L.glref_init()
+            if rc != 0:
+                raise RuntimeError("glref_init failed %d: %s" % (rc, L.glref_info()))
+            cls._lib = L
+        return cls._lib
+
+    @classmethod
+    def info(cls):
+        return cls.lib().glref_info().decode()
+
+
+class Tex:
+    def __init__(self, w, h, fmt, linear=False, repeat=False, data=None):
+        self.w, self.h, self.fmt = w, h, fmt
+        ptr = None
+        if data is not None:
+            data = np.ascontiguousarray(data)
+            ptr = data.ctypes.data_as(ctypes.c_void_p)
+        self.id = GL.lib().glref_texture(w, h, fmt, int(linear), int(repeat), ptr)
+        assert self.id > 0
+
+    def upload(self, data):
+        data = np.ascontiguousarray(data)
+        rc = GL.lib().glref_tex_upload(self.id, data.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, rc
+
+    def read(self) -> np.ndarray:
+        out = np.empty((self.h, self.w, 4), np.float32)
+        rc = GL.lib().glref_read(self.id, out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, hex(rc)
+        return out
+
+    def free(self):
+        GL.lib().glref_tex_free(self.id)
+
+
+class Program:
+    def __init__(self, src: str):
+        log = ctypes.create_string_buffer(16384)
+        self.id = GL.lib().glref_program(src.encode(), log, 16384)
+        if self.id <= 0:
+            raise RuntimeError("GLSL compile/link failed (%d): %s" % (self.id, log.value.decode(errors="replace")))
+        self.last_ms = 0.0
+
+    def sampler(self, name, tex: Tex):
+        GL.lib().glref_bind_sampler(self.id, name.encode(), tex.id)
+
+    def set(self, name, value):
+        L = GL.lib()
+        if isinstance(value, (bool, np.bool_)) or isinstance(value, (int, np.integer)):
+            L.glref_uniform_int(self.id, name.encode(), int(value))
+            return
+        v = np.atleast_1d(np.asarray(value, np.float32)).ravel()
+        kind = {1: 1, 2: 2, 3: 3, 16: 4}[v.size]
+        L.glref_uniform(self.id, name.encode(), kind, v.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+
+    def draw(self, targets):
+        arr = (ctypes.c_int * len(targets))(*[t.id for t in targets])
+        rc = GL.lib().glref_draw(self.id, arr, len(targets))
+        assert rc == 0, "glref_draw failed: %x" % (rc & 0xffffffff)
+        self.last_ms = GL.lib().glref_last_ms()
+
+
+# ------------------------------------------------------------------ the chain
+
+
+DEFAULTS = dict(  # src/ssgi/SSGIOptions.js:26-48
+    distance=10.0, thickness=10.0, denoiseIterations=1, radius=3.0, phi=0.5, lumaPhi=5.0, depthPhi=2.0, normalPhi=50.0,
+    roughnessPhi=50.0, specularPhi=50.0, envBlur=0.5, steps=20, refineSteps=5, missedRays=False)
+
+
+class GLRefChain:
+    """SSGIEffect's K1->K2->K3->K4 chain (denoiseMode "full", inputType "diffuseSpecular") on llvmpipe.
+
+    Persistent state mirrors the reference objects: K2 targets, K3 ping-pong A/B, K4 target,
+    prev-camera uniforms, keepData flag, per-material blue-noise index (passed in explicitly).
+    """
+
+    def __init__(self, width, height, blue_noise_table: np.ndarray, **options):
+        self.W, self.H = width, height
+        self.o = dict(DEFAULTS)
+        self.o.update(options)
+        self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 0, True, self.o["missedRays"]))
+        self.p_temporal = Program(assemble_temporal())
+        self.p_denoise = Program(assemble_denoise())
+        self.p_compose = Program(assemble_compose())
+        W, H = width, height
+        self.t_depth = Tex(W, H, FMT_R32F)
+        self.t_gbuffer = Tex(W, H, FMT_RGBA32F)
+        self.t_velocity = Tex(W, H, FMT_RGBA32F)
+        self.t_direct = Tex(W, H, FMT_RGBA32F)
+        self.t_blue = Tex(128, 128, FMT_RGBA8, repeat=True, data=blue_noise_table)
+        self.t_empty = Tex(1, 1, FMT_RGBA8, data=np.zeros(4, np.uint8))  # three's empty texture (Appendix D-1)
+        self.t_ssgi = Tex(W, H, FMT_RGBA32F)
+        self.t_temporal = [Tex(W, H, FMT_RGBA32F), Tex(W, H, FMT_RGBA32F)]
+        self.t_A = [Tex(W, H, FMT_RGBA16F, linear=True), Tex(W, H, FMT_RGBA16F, linear=True)]
+        self.t_B = [Tex(W, H, FMT_RGBA16F, linear=True), Tex(W, H, FMT_RGBA16F, linear=True)]
+        self.t_compose = Tex(W, H, FMT_RGBA32F)
+        self.keep_data = 0.0  # SSGIEffect's ctor setters call reset() (SSGIEffect.js:264)
+        self.prev = None
+        self.ms = {}
+
+    def upload_frame(self, frame):
+        self.t_depth.upload(frame.depth)
+        self.t_gbuffer.upload(frame.gbuffer.view(np.float32))
+        self.t_velocity.upload(frame.velocity.view(np.float32))
+        self.t_direct.upload(frame.direct)
+
+    # -- K1: SSGIPass.render (src/ssgi/pass/SSGIPass.js:68-95)
+    def ssgi(self, cam, blue_noise_index: int):
+        p, o = self.p_ssgi, self.o
+        near, far = float(cam.near), float(cam.far)
+        p.sampler("accumulatedTexture", self.t_compose)
+        p.sampler("gBufferTexture", self.t_gbuffer)
+        p.sampler("depthTexture", self.t_depth)
+        p.sampler("velocityTexture", self.t_empty)  # SSGIPass.js:89 reads an undefined property
+        p.sampler("directLightTexture", self.t_direct)
+        p.sampler("blueNoiseTexture", self.t_blue)
+        p.set("cameraMatrixWorld", cam.matrixWorld)
+        p.set("viewMatrix", cam.matrixWorldInverse)
+        p.set("projectionMatrix", cam.projectionMatrix)
+        p.set("projectionMatrixInverse", cam.projectionMatrixInverse)
+        p.set("cameraNear", near)
+        p.set("cameraFar", far)
+        p.set("nearMinusFar", near - far)
+        p.set("farMinusNear", far - near)
+        p.set("nearMulFar", near * far)
+        p.set("rayDistance", float(o["distance"]))
+        p.set("thickness", float(o["thickness"]))
+        p.set("envBlur", float(o["envBlur"]))
+        p.set("maxEnvMapMipLevel", 0.0)
+        p.set("backgroundColor", [0.0, 0.0, 0.0])
+        p.set("resolution", [float(self.W), float(self.H)])
+        p.set("blueNoiseSize", [128.0, 128.0])
+        p.set("blueNoiseIndex", int(blue_noise_index))
+        p.draw([self.t_ssgi])
+        self.ms["ssgi"] = p.last_ms
+
+    # -- K2: TemporalReprojectPass.render (src/temporal-reproject/TemporalReprojectPass.js:162-214)
+    def temporal(self, cam, camera_moved: bool = True, full_accumulate_option=True, max_blend=1.0, nci=0.5):
+        p = self.p_temporal
+        prev = self.prev if self.prev is not None else cam  # ctor clones the current matrices (:95-104)
+        p.sampler("inputTexture", self.t_ssgi)
+        p.sampler("velocityTexture", self.t_velocity)
+        p.sampler("accumulatedTexture0", self.t_B[0])  # Denoiser.js:51 overrideAccumulatedTextures
+        p.sampler("accumulatedTexture1", self.t_B[1])
+        p.set("projectionMatrix", cam.projectionMatrix)
+        p.set("projectionMatrixInverse", cam.projectionMatrixInverse)
+        p.set("cameraMatrixWorld", cam.matrixWorld)
+        p.set("viewMatrix", cam.matrixWorldInverse)
+        p.set("cameraPos", cam.position)
+        p.set("prevViewMatrix", prev.matrixWorldInverse)
+        p.set("prevCameraMatrixWorld", prev.matrixWorld)
+        p.set("prevProjectionMatrix", prev.projectionMatrix)
+        p.set("prevProjectionMatrixInverse", prev.projectionMatrixInverse)
+        p.set("prevCameraPos", prev.position)
+        p.set("fullAccumulate", bool(full_accumulate_option and not camera_moved))
+        p.set("keepData", float(self.keep_data))
+        p.set("invTexSize", [1.0 / self.W, 1.0 / self.H])
+        p.set("cameraNear", float(cam.near))
+        p.set("cameraFar", float(cam.far))
+        p.set("maxBlend", float(max_blend))
+        p.set("neighborhoodClampIntensity", float(nci))
+        p.draw(self.t_temporal)
+        self.ms["temporal"] = p.last_ms
+        self.keep_data = 1.0
+        self.prev = cam
+
+    # -- K3: PoissonDenoisePass.render (src/denoise/pass/PoissonDenoisePass.js:135-149)
+    def denoise(self, cam, blue_noise_indices):
+        p, o = self.p_denoise, self.o
+        p.sampler("depthTexture", self.t_depth)
+        p.sampler("gBufferTexture", self.t_gbuffer)
+        p.sampler("blueNoiseTexture", self.t_blue)
+        for k in ("radius", "phi", "lumaPhi", "depthPhi", "normalPhi", "roughnessPhi", "specularPhi"):
+            p.set(k, float(o[k]))
+        p.set("projectionMatrix", cam.projectionMatrix)
+        p.set("projectionMatrixInverse", cam.projectionMatrixInverse)
+        p.set("cameraMatrixWorld", cam.matrixWorld)
+        p.set("viewMatrix", cam.matrixWorldInverse)
+        p.set("resolution", [float(self.W), float(self.H)])
+        p.set("blueNoiseSize", [128.0, 128.0])
+        self.ms["denoise"] = []
+        for i in range(2 * int(o["denoiseIterations"])):
+            horizontal = i % 2 == 0
+            src = self.t_temporal if i == 0 else (self.t_B if horizontal else self.t_A)
+            dst = self.t_A if horizontal else self.t_B
+            p.sampler("inputTexture", src[0])
+            p.sampler("inputTexture2", src[1])
+            p.set("blueNoiseIndex", int(blue_noise_indices[i]))
+            p.draw(dst)
+            self.ms["denoise"].append(p.last_ms)
+
+    # -- K4: DenoiserComposePass.render (src/denoise/pass/DenoiserComposePass.js:129-135)
+    def compose(self, cam):
+        p = self.p_compose
+        p.sampler("depthTexture", self.t_depth)
+        p.sampler("gBufferTexture", self.t_gbuffer)
+        p.sampler("diffuseGiTexture", self.t_B[0])
+        p.sampler("specularGiTexture", self.t_B[1])
+        p.set("viewMatrix", cam.matrixWorldInverse)
+        p.set("cameraMatrixWorld", cam.matrixWorld)
+        p.set("projectionMatrix", cam.projectionMatrix)
+        p.set("projectionMatrixInverse", cam.projectionMatrixInverse)
+        p.set("cameraNear", float(cam.near))
+        p.set("cameraFar", float(cam.far))
+        p.draw([self.t_compose])
+        self.ms["compose"] = p.last_ms
