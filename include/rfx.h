@@ -1,0 +1,174 @@
+/*
+ * rfx.h — C ABI of librfx_hip.so: the MI355X-native SSGI hot path
+ * (SSGI ray-march -> TemporalReprojectPass -> PoissonDenoisePass -> DenoiserComposePass).
+ *
+ * Drop-in boundary.  In the reference every pass is a postprocessing `Pass` whose only
+ * device-side operation is
+ *      renderer.setRenderTarget(rt); renderer.render(this.scene, this.camera)
+ * with the arithmetic defined by the pass's `fullscreenMaterial` (GLSL + uniforms + defines):
+ *      src/ssgi/pass/SSGIPass.js:93-94                          -> rfx_ssgi_march
+ *      src/temporal-reproject/TemporalReprojectPass.js:192-193  -> rfx_temporal_reproject
+ *      src/denoise/pass/PoissonDenoisePass.js:146-147           -> rfx_poisson_denoise
+ *      src/denoise/pass/DenoiserComposePass.js:133-134          -> rfx_compose
+ * Each entry point below replaces exactly one of those draw calls.  The `*_params` structs
+ * carry what the material's `uniforms` (run-time values) and `defines` (shader variants)
+ * carried; textures are addressed by slot id (`rfx_tex`), the analogue of the
+ * `WebGLRenderTarget.texture` objects the passes share by reference (Denoiser.js:45,51).
+ *
+ * Conventions
+ *   - plain C, no exceptions: every call returns 0 (RFX_OK) or a negative RFX_E* code;
+ *     rfx_last_error(ctx) gives the message (the reference signals nothing, GL errors only
+ *     surface on the console).
+ *   - images are row-major, row 0 = BOTTOM (GL / `vUv` convention), tightly packed.
+ *   - matrices are column-major float[16], i.e. three.js `Matrix4.elements`.
+ *   - one context per device; calls enqueue on the context's HIP stream and return;
+ *     rfx_sync() blocks.  A context may own only a horizontal band ("tile") of the frame:
+ *     rows [tile_y0, tile_y0 + tile_rows) are written, textures additionally hold
+ *     `halo_rows` rows above and below (clipped to the frame) for the gathers
+ *     (SURVEY.md §8e).  Row indices in every call are FRAME rows.
+ *   - device buffers are owned by the library unless bound with rfx_bind_external().
+ */
+#ifndef RFX_H
+#define RFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFX_ABI_VERSION 1
+
+enum {
+    RFX_OK = 0,
+    RFX_EINVAL = -1,   /* bad argument / unsupported option combination */
+    RFX_ENOMEM = -2,   /* device allocation failed */
+    RFX_EDEVICE = -3,  /* HIP runtime error (no device, launch failure, ...) */
+    RFX_ESTATE = -4,   /* texture not uploaded / wrong size */
+    RFX_EUNSUPPORTED = -5
+};
+
+/* Texture slots.  Formats follow SURVEY.md Appendix B (the reference's render-target formats,
+ * which parity dictates for every intermediate). */
+typedef enum rfx_tex {
+    RFX_TEX_DEPTH = 0,      /* R32F      GBufferPass depth texture (GBufferPass.js:42-44)           */
+    RFX_TEX_GBUFFER,        /* RGBA32F   packed material (gbuffer_packing.glsl:166-178)             */
+    RFX_TEX_VELOCITY,       /* RGBA32F   VelocityDepthNormalPass output (…Material.js:76-83,186-188)*/
+    RFX_TEX_DIRECT_LIGHT,   /* RGBA32F   composer input buffer = direct lighting (SSGIEffect.js:396)*/
+    RFX_TEX_BLUE_NOISE,     /* RGBA8 128x128, repeat (BlueNoiseUtils.js:9-15), already flipY'd      */
+    RFX_TEX_SSGI,           /* RGBA32F   K1 out: 8 halfs {diffuse.rgb,roughness | specular.rgb,rayLength} */
+    RFX_TEX_TEMPORAL0,      /* RGBA32F   K2 out 0 (diffuse), .a = age                               */
+    RFX_TEX_TEMPORAL1,      /* RGBA32F   K2 out 1 (specular)                                        */
+    RFX_TEX_DENOISE_A0,     /* RGBA16F   K3 ping-pong target A                                      */
+    RFX_TEX_DENOISE_A1,
+    RFX_TEX_DENOISE_B0,     /* RGBA16F   K3 ping-pong target B = K2 history = K4 input              */
+    RFX_TEX_DENOISE_B1,
+    RFX_TEX_COMPOSE,        /* RGBA32F   K4 out = next frame's K1 `accumulatedTexture`              */
+    RFX_TEX_COUNT
+} rfx_tex;
+
+/* What the passes read from `this._camera` each frame. */
+typedef struct rfx_camera {
+    float projectionMatrix[16];
+    float projectionMatrixInverse[16];
+    float matrixWorld[16];        /* cameraMatrixWorld */
+    float matrixWorldInverse[16]; /* viewMatrix        */
+    float position[3];            /* cameraPos (TemporalReprojectPass.js:98) */
+    float near_, far_;
+    int32_t isPerspective;        /* only the PERSPECTIVE_CAMERA variant is built (1) */
+} rfx_camera;
+
+/* K1 — SSGIMaterial uniforms/defines (src/ssgi/material/SSGIMaterial.js:15-51,
+ * SSGIPass.js:38-40,82-91, SSGIEffect.js:143-151,203-226,254-258). */
+typedef struct rfx_ssgi_params {
+    rfx_camera camera;
+    int32_t steps;            /* #define steps        (default 20) */
+    int32_t refineSteps;      /* #define refineSteps  (default 5)  */
+    int32_t mode;             /* #define mode: 0 = MODE_SSGI, 1 = MODE_SSR (only 0 built: RFX_EUNSUPPORTED otherwise) */
+    int32_t useDirectLight;   /* #define useDirectLight */
+    int32_t missedRays;       /* #define missedRays   */
+    int32_t importanceSampling; /* needs an env map: must be 0 (SURVEY.md §8f "next") */
+    float rayDistance;        /* uniform rayDistance = options.distance */
+    float thickness;
+    float envBlur;            /* env only; accepted, unused without USE_ENVMAP */
+    int32_t blueNoiseIndex;   /* uniform blueNoiseIndex (BlueNoiseUtils.js:24-32 recurrence, host side) */
+} rfx_ssgi_params;
+
+/* K2 — TemporalReprojectMaterial uniforms/defines (TemporalReprojectPass.js:76-117,162-214). */
+typedef struct rfx_temporal_params {
+    rfx_camera camera;
+    rfx_camera prevCamera;        /* prevViewMatrix, prevCameraMatrixWorld, prevProjectionMatrix(+Inverse), prevCameraPos */
+    int32_t textureCount;         /* 2 (diffuseSpecular) or 1 */
+    int32_t inputType;            /* 0 DIFFUSE_SPECULAR, 1 DIFFUSE, 2 SPECULAR */
+    int32_t reprojectSpecular[2]; /* define bool[] */
+    int32_t neighborhoodClamp[2]; /* define bool[]; accepted, the shader never reads it (Appendix D-6) */
+    int32_t logTransform;
+    int32_t fullAccumulate;       /* uniform: option && !didCameraMove */
+    float confidencePower;        /* define, toPrecision(5) */
+    float neighborhoodClampIntensity;
+    float maxBlend;
+    float keepData;               /* 0 for the first frame after reset(), else 1 */
+} rfx_temporal_params;
+
+/* K3 — PoissonDenoisePass uniforms/defines (PoissonDenoisePass.js:43-71, SSGIEffect.js:175-190). */
+typedef struct rfx_denoise_params {
+    float radius, phi, lumaPhi, depthPhi, normalPhi, roughnessPhi, specularPhi;
+    int32_t textureCount;          /* 2 or 1 */
+    int32_t isTextureSpecular[2];  /* define bool[2] */
+    int32_t blueNoiseIndex;        /* advances once per draw */
+    int32_t inputIsTemporal;       /* 1: inputs = RFX_TEX_TEMPORAL* (RGBA32F, nearest) — pass 0;
+                                      0: inputs = the other ping-pong target (RGBA16F, linear)   */
+    int32_t writeToB;              /* 0: render into A (even pass index), 1: into B (odd)       */
+    int32_t halfStoreRTZ;          /* 1: RGBA16F stores truncate like llvmpipe's colour-buffer
+                                         store (parity with the oracle); 0: round-to-nearest-even
+                                         like GPU ROPs                                          */
+} rfx_denoise_params;
+
+/* K4 — DenoiserComposePass uniforms/defines (DenoiserComposePass.js:87-110). */
+typedef struct rfx_compose_params {
+    rfx_camera camera;
+    int32_t inputType; /* 0 TYPE_DIFFUSE_SPECULAR (only variant built) */
+} rfx_compose_params;
+
+typedef struct rfx_ctx rfx_ctx;
+
+/* ---- lifetime (Pass ctor / setSize / dispose) */
+int rfx_abi_version(void);
+rfx_ctx *rfx_create(int device, int width, int height, int tile_y0, int tile_rows, int halo_rows);
+void rfx_destroy(rfx_ctx *);
+const char *rfx_last_error(const rfx_ctx *);
+/* Run the context's kernels on a caller-provided hipStream_t (e.g. the framework's current
+ * stream); NULL restores the context's own stream. */
+int rfx_set_stream(rfx_ctx *, void *hip_stream);
+
+/* ---- textures.  `row0`/`rows` are FRAME rows of the band being transferred; the band must lie
+ * inside the rows the context holds: [max(0,tile_y0-halo), min(H,tile_y0+tile_rows+halo)).
+ * Read-only full-frame inputs of K1 (depth, compose history) are always held whole. */
+size_t rfx_tex_texel_bytes(rfx_tex id);
+int rfx_tex_held_rows(const rfx_ctx *, rfx_tex id, int *row0, int *rows);
+int rfx_upload(rfx_ctx *, rfx_tex id, const void *host, int row0, int rows);
+int rfx_download(rfx_ctx *, rfx_tex id, void *host, int row0, int rows);
+int rfx_clear(rfx_ctx *, rfx_tex id); /* zero-fill (render targets start zeroed) */
+/* Device pointer of the first HELD row of a slot (for halo exchange / zero-copy interop). */
+void *rfx_tex_device_ptr(rfx_ctx *, rfx_tex id);
+/* Use caller-owned device memory (held-rows x width x texel bytes) for a slot. */
+int rfx_bind_external(rfx_ctx *, rfx_tex id, void *device_ptr);
+
+/* ---- the four draws */
+int rfx_ssgi_march(rfx_ctx *, const rfx_ssgi_params *);
+int rfx_temporal_reproject(rfx_ctx *, const rfx_temporal_params *);
+int rfx_poisson_denoise(rfx_ctx *, const rfx_denoise_params *);
+int rfx_compose(rfx_ctx *, const rfx_compose_params *);
+
+int rfx_sync(rfx_ctx *);
+
+/* Timing helper: run `fn`-selected kernel `iters` times between two hipEvents on the context's
+ * stream and return the mean milliseconds (used by bench.py for the roofline line). */
+int rfx_time_begin(rfx_ctx *);
+int rfx_time_end(rfx_ctx *, float *elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFX_H */

@@ -1,0 +1,957 @@
+/*
+ * rfx_oracle.c — CPU restatement of the reference's SSGI hot path (K1..K4).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this.  The product (librfx_hip.so and the host packages) never links, imports or
+ * falls back to it.
+ *
+ * What it is: a scalar, per-fragment restatement in plain C of the arithmetic in the
+ * reference's fragment shaders, written from the GLSL (each function cites the file:line it
+ * follows), with the execution semantics of the GL implementation the golden vectors were
+ * produced on (Mesa llvmpipe):
+ *   - fine 2x2-quad derivatives aligned to even pixels (dFdx/dFdy/fwidth),
+ *   - nearest CLAMP_TO_EDGE fetch = clamp(cvttss2si(u*W), 0, W-1) (NaN/out-of-int-range -> 0),
+ *   - bilinear fetch of the RGBA16F targets as llvmpipe computes it,
+ *   - packHalf2x16 = round-to-nearest-even; RGBA16F colour-buffer store = round-toward-zero
+ *     saturating at 65504,
+ *   - min/max are NaN-suppressing, uninitialised locals are zero (WebGL),
+ *   - `discard` leaves the render target's previous contents.
+ * Parity pin: the reference has no tests / golden vectors of its own; this
+ * restatement is pinned against the reference GLSL executed on llvmpipe (oracle/glref),
+ * see tests/golden/ and tests/test_oracle_vs_glref.py.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off, OpenMP over rows)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include "../include/rfx.h"
+
+/* ------------------------------------------------------------------ small vector helpers */
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } v4;
+
+static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 add3(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub3(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 mul3(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 neg3(v3 a) { return V3(-a.x, -a.y, -a.z); }
+static inline float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline v3 cross3(v3 a, v3 b) { return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+/* GLSL normalize: v * inversesqrt(dot(v,v)); llvmpipe's rsq is 1/sqrt (full precision) */
+static inline v3 normalize3(v3 a) { float s = 1.0f / sqrtf(dot3(a, a)); return mul3(a, s); }
+static inline float length3(v3 a) { return sqrtf(dot3(a, a)); }
+static inline float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+static inline v3 mix3(v3 x, v3 y, float a) { return V3(mixf(x.x, y.x, a), mixf(x.y, y.y, a), mixf(x.z, y.z, a)); }
+static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+static inline float lum(v3 c) { return 0.2125f * c.x + 0.7154f * c.y + 0.0721f * c.z; } /* dot(vec3(0.2125,0.7154,0.0721), c) */
+
+/* column-major mat4: M[c*4+r].  M * vec4(p, w): ((M0*x + M1*y) + M2*z) + M3*w */
+static inline v4 mat_mul_v4(const float *M, float x, float y, float z, float w) {
+    v4 r;
+    r.x = ((M[0] * x + M[4] * y) + M[8] * z) + M[12] * w;
+    r.y = ((M[1] * x + M[5] * y) + M[9] * z) + M[13] * w;
+    r.z = ((M[2] * x + M[6] * y) + M[10] * z) + M[14] * w;
+    r.w = ((M[3] * x + M[7] * y) + M[11] * z) + M[15] * w;
+    return r;
+}
+/* vec4(v, w) * M  ->  (dot(v4, M[0]), dot(v4, M[1]), dot(v4, M[2])) */
+static inline v3 v4_mul_mat_xyz(const float *M, v3 v, float w) {
+    v3 r;
+    r.x = ((v.x * M[0] + v.y * M[1]) + v.z * M[2]) + w * M[3];
+    r.y = ((v.x * M[4] + v.y * M[5]) + v.z * M[6]) + w * M[7];
+    r.z = ((v.x * M[8] + v.y * M[9]) + v.z * M[10]) + w * M[11];
+    return r;
+}
+
+/* ------------------------------------------------------------------ half floats */
+static inline float half_to_float(uint16_t h) {
+    uint32_t s = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu, u;
+    if (e == 0) {
+        if (m == 0) u = s;
+        else { /* subnormal */
+            int sh = 0;
+            while (!(m & 0x400u)) { m <<= 1; sh++; }
+            m &= 0x3ffu;
+            u = s | ((uint32_t)(113 - sh) << 23) | (m << 13);
+        }
+    } else if (e == 31) u = s | 0x7f800000u | (m << 13);
+    else u = s | ((e + 112) << 23) | (m << 13);
+    float f; memcpy(&f, &u, 4); return f;
+}
+/* packHalf2x16 conversion: round-to-nearest-even, overflow -> inf (Appendix C-2) */
+static inline uint16_t float_to_half_rne(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    uint32_t s = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return (uint16_t)(s | 0x7c00u | ((a > 0x7f800000u) ? 0x200u : 0));
+    if (a >= 0x477ff000u) return (uint16_t)(s | 0x7c00u); /* rounds to >= 65520 -> inf */
+    if (a < 0x38800000u) { /* half subnormal or zero */
+        if (a < 0x33000000u) return (uint16_t)s; /* < 2^-25 -> 0 */
+        int e = (int)(a >> 23);
+        uint32_t m = (a & 0x7fffffu) | 0x800000u;
+        int shift = 126 - e; /* 14..24 */
+        uint32_t r = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1))) r++;
+        return (uint16_t)(s | r);
+    }
+    uint32_t r = (a - 0x38000000u) >> 13, rem = a & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) r++;
+    return (uint16_t)(s | r);
+}
+/* RGBA16F render-target store on llvmpipe: vcvtps2ph with imm=3 (truncate); finite overflow
+ * saturates at 65504 (Appendix C-3) */
+static inline uint16_t float_to_half_rtz(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    uint32_t s = (u >> 16) & 0x8000u, a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return (uint16_t)(s | 0x7c00u | ((a > 0x7f800000u) ? 0x200u : 0));
+    if (a >= 0x47800000u) return (uint16_t)(s | 0x7bffu);
+    if (a < 0x38800000u) {
+        if (a < 0x33800000u) return (uint16_t)s; /* < 2^-24 -> 0 */
+        int e = (int)(a >> 23);
+        uint32_t m = (a & 0x7fffffu) | 0x800000u;
+        return (uint16_t)(s | (m >> (126 - e)));
+    }
+    return (uint16_t)(s | ((a - 0x38000000u) >> 13));
+}
+
+/* ------------------------------------------------------------------ texture fetch */
+/* nearest CLAMP_TO_EDGE index: clamp(cvttss2si(u*size), 0, size-1); cvttss2si returns INT_MIN
+ * for NaN and anything outside int range (Appendix C-4) */
+static inline int nearest_idx(float u, int size) {
+    float c = u * (float)size;
+    int i;
+    if (!(c > -2147483904.0f && c < 2147483648.0f)) i = INT_MIN;
+    else i = (int)c;
+    if (i < 0) i = 0;
+    if (i > size - 1) i = size - 1;
+    return i;
+}
+typedef struct { int W, H; } dims;
+
+static inline float fetch_r32f(const float *t, dims d, float u, float v) {
+    return t[(size_t)nearest_idx(v, d.H) * d.W + nearest_idx(u, d.W)];
+}
+static inline const uint32_t *fetch_u4(const uint32_t *t, dims d, float u, float v) {
+    return t + 4 * ((size_t)nearest_idx(v, d.H) * d.W + nearest_idx(u, d.W));
+}
+static inline v4 fetch_f4(const float *t, dims d, float u, float v) {
+    const float *p = t + 4 * ((size_t)nearest_idx(v, d.H) * d.W + nearest_idx(u, d.W));
+    v4 r = {p[0], p[1], p[2], p[3]}; return r;
+}
+/* llvmpipe bilinear, CLAMP_TO_EDGE, normalised coords (lp_bld_sample_soa.c):
+ * c = min(u*size, size) - 0.5; c = max(c, 0); i0 = floor(c); w = fract(c); i1 = min(i0+1, size-1)
+ * texel = lerp(wy, lerp(wx, t00, t10), lerp(wx, t01, t11)), lerp(w,a,b) = a + w*(b-a) */
+static inline void linear_coord(float u, int size, int *i0, int *i1, float *w) {
+    float c = u * (float)size;
+    c = fminf(c, (float)size); /* NaN -> size */
+    c = c - 0.5f;
+    c = fmaxf(c, 0.0f);
+    float fl = floorf(c);
+    *i0 = (int)fl;
+    *w = c - fl;
+    *i1 = *i0 + 1 > size - 1 ? size - 1 : *i0 + 1;
+}
+static inline float lerpf(float w, float a, float b) { return a + w * (b - a); }
+static inline v4 fetch_h4_linear(const uint16_t *t, dims d, float u, float v) {
+    int x0, x1, y0, y1; float wx, wy;
+    linear_coord(u, d.W, &x0, &x1, &wx);
+    linear_coord(v, d.H, &y0, &y1, &wy);
+    const uint16_t *p00 = t + 4 * ((size_t)y0 * d.W + x0), *p10 = t + 4 * ((size_t)y0 * d.W + x1);
+    const uint16_t *p01 = t + 4 * ((size_t)y1 * d.W + x0), *p11 = t + 4 * ((size_t)y1 * d.W + x1);
+    float o[4];
+    for (int c = 0; c < 4; c++) {
+        float a = lerpf(wx, half_to_float(p00[c]), half_to_float(p10[c]));
+        float b = lerpf(wx, half_to_float(p01[c]), half_to_float(p11[c]));
+        o[c] = lerpf(wy, a, b);
+    }
+    v4 r = {o[0], o[1], o[2], o[3]}; return r;
+}
+
+/* ------------------------------------------------------------------ codec (gbuffer_packing.glsl) */
+typedef struct { v3 diffuse; float alpha; v3 normal; float roughness, metalness; v3 emissive; } material;
+
+static inline void unpack_half2(uint32_t u, float *a, float *b) { *a = half_to_float((uint16_t)(u & 0xffffu)); *b = half_to_float((uint16_t)(u >> 16)); }
+static inline uint32_t pack_half2(float a, float b) { return (uint32_t)float_to_half_rne(a) | ((uint32_t)float_to_half_rne(b) << 16); }
+
+/* decodeOctWrap + unpackNormal, gbuffer_packing.glsl:52-63 */
+static inline v3 unpack_normal(uint32_t bits) {
+    float fx, fy; unpack_half2(bits, &fx, &fy);
+    fx = fx * 2.0f - 1.0f; fy = fy * 2.0f - 1.0f;
+    v3 n = V3(fx, fy, 1.0f - fabsf(fx) - fabsf(fy));
+    float t = fmaxf(-n.z, 0.0f);
+    n.x += n.x >= 0.0f ? -t : t;
+    n.y += n.y >= 0.0f ? -t : t;
+    return normalize3(n);
+}
+/* floatToVec4, gbuffer_packing.glsl:151-164 */
+static inline v4 float_to_vec4(uint32_t value) {
+    v4 v;
+    v.x = fmaxf((float)(value & 0xffu) / 255.0f - 0.0001f, 0.0f);
+    v.y = fmaxf((float)((value >> 8) & 0xffu) / 255.0f - 0.0001f, 0.0f);
+    v.z = fmaxf((float)((value >> 16) & 0xffu) / 255.0f - 0.0001f, 0.0f);
+    v.w = fmaxf((float)((value >> 24) & 0xffu) / 255.0f - 0.0001f, 0.0f);
+    return v;
+}
+static inline float glsl_mod(float x, float y) { return x - y * floorf(x / y); }
+/* getMaterial, gbuffer_packing.glsl:181-196 */
+static inline material get_material(const uint32_t *g) {
+    material m;
+    v4 d = float_to_vec4(g[0]);
+    m.diffuse = V3(d.x, d.y, d.z); m.alpha = d.w;
+    m.normal = unpack_normal(g[1]);
+    float value; memcpy(&value, &g[2], 4);
+    /* float2color :24-34 : r = mod(v,257)/256, g = floor(v/(257*257))/256 ; -1e-4 ; max 0 */
+    const float p1 = 257.0f;
+    float cr = glsl_mod(value, p1) / 256.0f;
+    float cg = floorf(value / (p1 * p1)) / 256.0f;
+    m.roughness = fmaxf(cr - 0.0001f, 0.0f);
+    m.metalness = fmaxf(cg - 0.0001f, 0.0f);
+    v4 e = float_to_vec4(g[3]);
+    float fexp = e.w * 255.0f - 128.0f; /* decodeRGBE8 :136-141 */
+    float sc = exp2f(fexp);
+    m.emissive = V3(e.x * sc, e.y * sc, e.z * sc);
+    return m;
+}
+/* packTwoVec4 :65-83 */
+static inline void pack_two_vec4(v4 a, v4 b, uint32_t *out) {
+    const float o = 0.0001f;
+    out[0] = pack_half2(a.x + o, a.y + o);
+    out[1] = pack_half2(a.z + o, a.w + o);
+    out[2] = pack_half2(b.x + o, b.y + o);
+    out[3] = pack_half2(b.z + o, b.w + o);
+}
+/* unpackTwoVec4 :85-98 */
+static inline void unpack_two_vec4(const uint32_t *e, v4 *a, v4 *b) {
+    const float o = 0.0001f;
+    unpack_half2(e[0], &a->x, &a->y); unpack_half2(e[1], &a->z, &a->w);
+    unpack_half2(e[2], &b->x, &b->y); unpack_half2(e[3], &b->z, &b->w);
+    a->x -= o; a->y -= o; a->z -= o; a->w -= o;
+    b->x -= o; b->y -= o; b->z -= o; b->w -= o;
+}
+
+/* ------------------------------------------------------------------ blue noise (blue_noise.glsl) */
+static inline void pcg4d(uint32_t *v) { /* :17-28 */
+    for (int i = 0; i < 4; i++) v[i] = v[i] * 1664525u + 1013904223u;
+    v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+    for (int i = 0; i < 4; i++) v[i] ^= v[i] >> 16;
+    v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+}
+/* blueNoise() :37-47 with index != 0; px,py = ivec2(vUv * resolution).
+ * index == 0 takes the textureLod(uv*resolution/128) path (repeat wrap, nearest). */
+static inline v4 blue_noise(const uint8_t *table, int px, int py, int index, float u, float v, dims d) {
+    int sx, sy;
+    if (index == 0) {
+        float cu = u * (float)d.W / 128.0f, cv = v * (float)d.H / 128.0f;
+        /* nearest REPEAT: ifloor(coord*size) & (size-1) */
+        sx = ((int)floorf(cu * 128.0f)) & 127; sy = ((int)floorf(cv * 128.0f)) & 127;
+    } else {
+        uint32_t i = (uint32_t)index;
+        uint32_t s[4] = {i, i * 15843u, i * 31u + 4566u, i * 2345u + 58585u};
+        pcg4d(s);
+        sx = (px + (int)(s[0] % 0x0fffffffu)) % 128;
+        sy = (py + (int)(s[1] % 0x0fffffffu)) % 128;
+    }
+    const uint8_t *t = table + 4 * (sy * 128 + sx);
+    /* llvmpipe unorm8 -> float: float(byte) * (1.0/255.0) */
+    const float k = (float)(1.0 / 255.0);
+    v4 r = {t[0] * k, t[1] * k, t[2] * k, t[3] * k};
+    return r;
+}
+
+/* ------------------------------------------------------------------ quad derivatives */
+/* fine derivatives on 2x2 quads aligned to even pixels (Appendix C-1):
+ * dFdx(f)(x,y) = f(x|1, y) - f(x&~1, y);  dFdy(f)(x,y) = f(x, y|1) - f(x, y&~1).
+ * The partner fragment may lie outside the target (odd sizes): it still executes, its nearest
+ * CLAMP_TO_EDGE fetch lands on the edge texel. */
+static inline int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+
+/* ==================================================================== K1: ssgi.frag */
+#define M_PIf 3.1415926535897932384626433832795f
+
+static inline float pow5(float x) { return powf(x, 5.0f); }
+/* F_Schlick(vec3 f0, theta) ssgi_utils.frag:108 */
+static inline v3 f_schlick3(v3 f0, float theta) {
+    float p = pow5(1.0f - theta);
+    return V3(f0.x + (1.0f - f0.x) * p, f0.y + (1.0f - f0.y) * p, f0.z + (1.0f - f0.z) * p);
+}
+static inline float f_schlick1(float f0, float f90, float theta) { return f0 + (f90 - f0) * pow5(1.0f - theta); } /* :110 */
+static inline float d_gtr2(float roughness, float NoH) { /* D_GTR(roughness, NoH, 2.) :112-115 */
+    float a2 = roughness * roughness; /* pow(x, 2.) -> x*x */
+    float t = (NoH * NoH) * (a2 * a2 - 1.0f) + 1.0f;
+    return a2 / (M_PIf * (t * t));
+}
+static inline float smith_g(float NDotV, float alphaG) { /* :117-121 */
+    float a = alphaG * alphaG, b = NDotV * NDotV;
+    return (2.0f * NDotV) / (NDotV + sqrtf(a + b - a * b));
+}
+static inline float ggx_vndf_pdf(float NoH, float NoV, float roughness) { /* :123-127 */
+    float D = d_gtr2(roughness, NoH);
+    float G1 = smith_g(NoV, roughness * roughness);
+    return (D * G1) / fmaxf(0.00001f, 4.0f * NoV);
+}
+static inline float eval_disney_diffuse(float NoL, float NoV, float LoH, float roughness, float metalness) { /* :136-142 */
+    float FD90 = 0.5f + 2.0f * roughness * (LoH * LoH);
+    float a = f_schlick1(1.0f, FD90, NoL), b = f_schlick1(1.0f, FD90, NoV);
+    return (a * b / M_PIf) * (1.0f - metalness);
+}
+static inline float eval_disney_specular(float roughness, float NoH, float NoV, float NoL) { /* :144-151 */
+    float D = d_gtr2(roughness, NoH);
+    float r2 = 0.5f + roughness * 0.5f; r2 = r2 * r2;
+    float a2 = r2 * r2; /* GeometryTerm: a2 = roughness*roughness, SmithG(.., a2) */
+    float G = smith_g(NoV, a2) * smith_g(NoL, a2);
+    return D * G / (4.0f * NoL * NoV);
+}
+/* SampleGGXVNDF :153-170 */
+static inline v3 sample_ggx_vndf(v3 V, float ax, float ay, float r1, float r2) {
+    v3 Vh = normalize3(V3(ax * V.x, ay * V.y, V.z));
+    float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    v3 T1;
+    if (lensq > 0.0f) { float is = 1.0f / sqrtf(lensq); T1 = V3(-Vh.y * is, Vh.x * is, 0.0f * is); }
+    else T1 = V3(1.0f, 0.0f, 0.0f);
+    v3 T2 = cross3(Vh, T1);
+    float r = sqrtf(r1);
+    float phi = 2.0f * M_PIf * r2;
+    float t1 = r * cosf(phi), t2 = r * sinf(phi);
+    float s = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
+    float k = sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2));
+    v3 Nh = add3(add3(mul3(T1, t1), mul3(T2, t2)), mul3(Vh, k));
+    return normalize3(V3(ax * Nh.x, ay * Nh.y, fmaxf(0.0f, Nh.z)));
+}
+static inline void onb(v3 N, v3 *T, v3 *B) { /* :172-176 */
+    v3 up = fabsf(N.z) < 0.9999999f ? V3(0, 0, 1) : V3(1, 0, 0);
+    *T = normalize3(cross3(up, N));
+    *B = cross3(N, *T);
+}
+static inline v3 cosine_sample_hemisphere(v3 n, float ux, float uy) { /* :183-191 */
+    float r = sqrtf(ux), theta = 2.0f * M_PIf * uy;
+    v3 b = normalize3(cross3(n, V3(0.0f, 1.0f, 1.0f)));
+    v3 t = cross3(b, n);
+    v3 s = add3(add3(mul3(b, r * sinf(theta)), mul3(n, sqrtf(1.0f - ux))), mul3(t, r * cosf(theta)));
+    return normalize3(s);
+}
+
+typedef struct {
+    int W, H;
+    const float *depth; const uint32_t *gbuffer; const float *direct; const float *history; const uint8_t *blue;
+    const rfx_ssgi_params *p;
+    float nearMulFar, farMinusNear, cameraFar;
+} k1_ctx;
+
+static inline float k1_view_z(const k1_ctx *c, float depth) { /* getViewZ ssgi_utils.frag:7-13 (PERSPECTIVE_CAMERA) */
+    return c->nearMulFar / (c->farMinusNear * depth - c->cameraFar);
+}
+static inline void k1_project(const k1_ctx *c, v3 pos, float *u, float *v) { /* viewSpaceToScreenSpace :26-33 */
+    v4 pc = mat_mul_v4(c->p->camera.projectionMatrix, pos.x, pos.y, pos.z, 1.0f);
+    *u = (pc.x / pc.w) * 0.5f + 0.5f;
+    *v = (pc.y / pc.w) * 0.5f + 0.5f;
+}
+/* BinarySearch ssgi.frag:477-503 */
+static void k1_binary_search(const k1_ctx *c, v3 *dir, v3 *hitPos, float *u, float *v) {
+    dims d = {c->W, c->H};
+    *dir = mul3(*dir, 0.5f);
+    *hitPos = sub3(*hitPos, *dir);
+    for (int i = 0; i < c->p->refineSteps; i++) {
+        k1_project(c, *hitPos, u, v);
+        float z = k1_view_z(c, fetch_r32f(c->depth, d, *u, *v));
+        float diff = z - hitPos->z;
+        *dir = mul3(*dir, 0.5f);
+        if (diff >= 0.0f) *hitPos = sub3(*hitPos, *dir); else *hitPos = add3(*hitPos, *dir);
+    }
+    k1_project(c, *hitPos, u, v);
+}
+/* RayMarch ssgi.frag:441-475 */
+static void k1_ray_march(const k1_ctx *c, v3 *dir, v3 *hitPos, float random_b, float *u, float *v) {
+    dims d = {c->W, c->H};
+    *dir = mul3(*dir, c->p->rayDistance / (float)c->p->steps);
+    *u = 0.0f; *v = 0.0f;
+    for (int i = 1; i < c->p->steps; i++) {
+        float m = (float)i + random_b - 0.5f;
+        float cs = 1.0f - expf(-0.25f * (m * m));
+        *hitPos = add3(*hitPos, mul3(*dir, cs));
+        k1_project(c, *hitPos, u, v);
+        float z = k1_view_z(c, fetch_r32f(c->depth, d, *u, *v));
+        float diff = z - hitPos->z;
+        if (diff >= 0.0f && diff < c->p->thickness) {
+            if (c->p->refineSteps == 0) return;
+            k1_binary_search(c, dir, hitPos, u, v);
+            return;
+        }
+    }
+    *hitPos = V3(10.0e9f, 10.0e9f, 10.0e9f);
+}
+static inline float smoothstepf(float e0, float e1, float x) {
+    float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+/* doSample ssgi.frag:362-439 (no env map: getEnvColor == vec3(0)) */
+static v3 k1_do_sample(const k1_ctx *c, const material *mat, v3 viewPos, v3 viewNormal, float metalness, float roughness,
+                       int isDiffuseSample, float NoV, float NoL, float NoH, float LoH, float VoH, v4 random,
+                       v3 *l, v3 *hitPos, float *brdf, float *pdf) {
+    (void)VoH;
+    dims d = {c->W, c->H};
+    float cosTheta = fmaxf(0.0f, dot3(viewNormal, *l));
+    if (isDiffuseSample) {
+        *brdf = eval_disney_diffuse(NoL, NoV, LoH, roughness, metalness);
+        *pdf = NoL / M_PIf;
+    } else {
+        *brdf = eval_disney_specular(roughness, NoH, NoV, NoL);
+        *pdf = ggx_vndf_pdf(NoH, NoV, roughness);
+    }
+    *brdf *= cosTheta;
+    *pdf = fmaxf(0.00001f, *pdf);
+    *hitPos = viewPos;
+    float cu, cv;
+    k1_ray_march(c, l, hitPos, random.z, &cu, &cv);
+    int allowMissed = c->p->missedRays != 0;
+    int isMissed = hitPos->x == 10.0e9f;
+    v3 env = V3(0, 0, 0);
+    if (isMissed && !allowMissed) return env;
+    /* velocityTexture is never wired (SSGIPass.js:89) -> three's empty texture -> velocity = 0 */
+    float ru = cu - 0.0f, rv = cv - 0.0f;
+    v3 ssgi;
+    if (ru >= 0.0f && ru <= 1.0f && rv >= 0.0f && rv <= 1.0f) {
+        v4 h = fetch_f4(c->history, d, ru, rv);
+        v3 gi = V3(h.x, h.y, h.z);
+        /* getSaturation :348-360 */
+        float mx = fmaxf(fmaxf(mat->diffuse.x, mat->diffuse.y), mat->diffuse.z);
+        float mn = fminf(fminf(mat->diffuse.x, mat->diffuse.y), mat->diffuse.z);
+        float sat = (mx == mn) ? 0.0f : (mx - mn) / mx;
+        float L = lum(gi);
+        gi = mix3(gi, V3(L, L, L), (1.0f - roughness) * sat * 0.4f);
+        const float border = 0.15f;
+        float bf = smoothstepf(0.0f, border, cu) * smoothstepf(1.0f, 1.0f - border, cu) * smoothstepf(0.0f, border, cv) *
+                   smoothstepf(1.0f, 1.0f - border, cv);
+        bf = sqrtf(bf);
+        ssgi = mix3(env, gi, bf);
+    } else {
+        return env;
+    }
+    if (allowMissed) { /* :430-436, envMapSample is vec3(0) */
+        if (0.0f > lum(ssgi)) ssgi = V3(0, 0, 0);
+    }
+    return ssgi;
+}
+static inline void calc_angles(v3 l, v3 v, v3 n, float *NoL, float *NoH, float *LoH, float *VoH) { /* :93-100 */
+    const float E = 0.00001f, OME = 1.0f - 0.00001f;
+    v3 h = normalize3(add3(v, l));
+    *NoL = clampf(dot3(n, l), E, OME);
+    *NoH = clampf(dot3(n, h), E, OME);
+    *LoH = clampf(dot3(l, h), E, OME);
+    *VoH = clampf(dot3(v, h), E, OME);
+}
+
+static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
+    const rfx_ssgi_params *p = c->p;
+    const float *C = p->camera.matrixWorld, *Vw = p->camera.matrixWorldInverse;
+    const float *P = p->camera.projectionMatrix, *Pi = p->camera.projectionMatrixInverse;
+    dims d = {c->W, c->H};
+    float u = ((float)x + 0.5f) / (float)c->W, v = ((float)y + 0.5f) / (float)c->H;
+    float depth = fetch_r32f(c->depth, d, u, v);
+    if (depth == 1.0f) { /* :109-113 */
+        v4 dl = fetch_f4(c->direct, d, u, v);
+        pack_two_vec4(dl, dl, out);
+        return;
+    }
+    material mat = get_material(fetch_u4(c->gbuffer, d, u, v));
+    float roughnessSq = clampf(mat.roughness * mat.roughness, 0.000001f, 1.0f);
+    float viewZ = k1_view_z(c, depth);
+    /* getViewPosition ssgi_utils.frag:17-24 */
+    float clipW = P[2 * 4 + 3] * viewZ + P[3 * 4 + 3];
+    float cx = ((u - 0.5f) * 2.0f) * clipW, cy = ((v - 0.5f) * 2.0f) * clipW, cz = ((viewZ - 0.5f) * 2.0f) * clipW, cw = 1.0f * clipW;
+    v4 pp = mat_mul_v4(Pi, cx, cy, cz, cw);
+    v3 viewPos = V3(pp.x, pp.y, viewZ);
+    v3 viewDir = normalize3(viewPos);
+    v3 worldNormal = mat.normal;
+    v3 viewNormal = normalize3(v4_mul_mat_xyz(C, worldNormal, 0.0f));
+    v3 n = viewNormal, vv = neg3(viewDir);
+    float NoV = fmaxf(0.00001f, dot3(n, vv));
+    v3 V = v4_mul_mat_xyz(Vw, vv, 0.0f);
+    v3 N = worldNormal, T, B;
+    onb(N, &T, &B);
+    V = V3(dot3(V, T), dot3(V, B), dot3(V, N)); /* ToLocal */
+    v3 f0 = mix3(V3(0.04f, 0.04f, 0.04f), mat.diffuse, mat.metalness);
+    v4 random = blue_noise(c->blue, x, y, p->blueNoiseIndex, u, v, d);
+    v3 Hh = sample_ggx_vndf(V, roughnessSq, roughnessSq, random.x, random.y);
+    if (Hh.z < 0.0f) Hh = neg3(Hh);
+    /* reflect(-V, H) = I - 2*dot(N,I)*N with I=-V */
+    v3 I = neg3(V);
+    float dNI = dot3(Hh, I);
+    v3 l = normalize3(sub3(I, mul3(Hh, 2.0f * dNI)));
+    l = add3(add3(mul3(T, l.x), mul3(B, l.y)), mul3(N, l.z)); /* ToWorld */
+    l = normalize3(v4_mul_mat_xyz(C, l, 0.0f));
+    float NoL, NoH, LoH, VoH;
+    calc_angles(l, vv, n, &NoL, &NoH, &LoH, &VoH);
+    int isDiffuseSample = 0;
+    if (p->mode == 0) { /* :169-186 */
+        v3 F = f_schlick3(f0, VoH);
+        float diffW = (1.0f - mat.metalness) * lum(mat.diffuse);
+        float specW = lum(F);
+        diffW = fmaxf(diffW, 0.00001f);
+        specW = fmaxf(specW, 0.00001f);
+        float invW = 1.0f / (diffW + specW);
+        diffW *= invW;
+        isDiffuseSample = random.z < diffW;
+    }
+    v3 diffuseRay = cosine_sample_hemisphere(viewNormal, random.x, random.y);
+    v3 specularRay = l;
+    v3 diffuseGI = V3(0, 0, 0), specularGI = V3(0, 0, 0), hitPos = V3(0, 0, 0);
+    float diffuseSamples = 0.0f;
+    float brdf, pdf;
+    if (p->mode == 0 && isDiffuseSample) { /* :222-242 */
+        l = diffuseRay;
+        calc_angles(l, vv, n, &NoL, &NoH, &LoH, &VoH);
+        v3 gi = k1_do_sample(c, &mat, viewPos, viewNormal, mat.metalness, roughnessSq, isDiffuseSample, NoV, NoL, NoH, LoH, VoH, random,
+                             &l, &hitPos, &brdf, &pdf);
+        gi = mul3(gi, brdf);
+        gi = V3(gi.x / pdf, gi.y / pdf, gi.z / pdf);
+        gi = V3(gi.x / 1.0f, gi.y / 1.0f, gi.z / 1.0f); /* ems.pdf = 1 */
+        diffuseSamples += 1.0f;
+        diffuseGI = gi; /* mix(0, gi, 1/1) */
+    }
+    l = specularRay; /* :246-265 */
+    calc_angles(l, vv, n, &NoL, &NoH, &LoH, &VoH);
+    {
+        v3 gi = k1_do_sample(c, &mat, viewPos, viewNormal, mat.metalness, roughnessSq, isDiffuseSample, NoV, NoL, NoH, LoH, VoH, random,
+                             &l, &hitPos, &brdf, &pdf);
+        gi = mul3(gi, brdf);
+        gi = V3(gi.x / pdf, gi.y / pdf, gi.z / pdf);
+        specularGI = gi;
+    }
+    v3 specularHitPos = hitPos;
+    if (p->useDirectLight) { /* :267-272 */
+        v4 dl = fetch_f4(c->direct, d, u, v);
+        diffuseGI = add3(diffuseGI, V3(dl.x, dl.y, dl.z));
+        specularGI = add3(specularGI, V3(dl.x, dl.y, dl.z));
+    }
+    if (diffuseSamples == 0.0f) diffuseGI = V3(-1.0f, -1.0f, -1.0f); /* :277-278 */
+    float rayLength = 0.0f; /* :284-296 */
+    int missed = hitPos.x > 10.0e8f;
+    if (!missed) {
+        v4 hw = mat_mul_v4(C, specularHitPos.x, specularHitPos.y, specularHitPos.z, 1.0f);
+        v3 camPos = V3(C[12], C[13], C[14]);
+        rayLength = length3(sub3(camPos, V3(hw.x, hw.y, hw.z)));
+    }
+    v4 gD = {diffuseGI.x, diffuseGI.y, diffuseGI.z, mat.roughness};
+    v4 gS = {specularGI.x, specularGI.y, specularGI.z, rayLength};
+    pack_two_vec4(gD, gS, out);
+}
+
+int rfxo_ssgi(int W, int H, int y0, int y1, const float *depth, const uint32_t *gbuffer, const float *direct, const float *history,
+              const uint8_t *blue, const rfx_ssgi_params *p, uint32_t *out) {
+    if (p->mode != 0 || p->importanceSampling) return RFX_EUNSUPPORTED;
+    k1_ctx c = {W, H, depth, gbuffer, direct, history, blue, p, 0, 0, 0};
+    /* SSGIPass.js:84-87: JS doubles rounded to float uniforms */
+    c.nearMulFar = (float)((double)p->camera.near_ * (double)p->camera.far_);
+    c.farMinusNear = (float)((double)p->camera.far_ - (double)p->camera.near_);
+    c.cameraFar = p->camera.far_;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < W; x++) k1_pixel(&c, x, y, out + 4 * ((size_t)y * W + x));
+    return 0;
+}
+
+/* ==================================================================== K2: temporal_reproject.frag */
+typedef struct {
+    int W, H;
+    const uint32_t *ssgi, *velocity; const uint16_t *hist[2];
+    const rfx_temporal_params *p;
+    float invW, invH;
+} k2_ctx;
+
+static inline float perspective_depth_to_view_z(float depth, float n, float f) { return (n * f) / ((f - n) * depth - f); }
+
+/* getVelocityNormalDepth reproject.frag:97-105 */
+static inline void k2_vnd(const k2_ctx *c, float u, float v, float *vx, float *vy, v3 *normal, float *depth) {
+    dims d = {c->W, c->H};
+    const uint32_t *t = fetch_u4(c->velocity, d, u, v);
+    memcpy(vx, &t[0], 4); memcpy(vy, &t[1], 4);
+    *normal = unpack_normal(t[2]);
+    memcpy(depth, &t[3], 4);
+}
+/* screenSpaceToWorldSpace reproject.frag:21-28 */
+static inline v3 ss_to_ws(float u, float v, float depth, const float *matWorld, const float *projInv) {
+    v4 clip = mat_mul_v4(projInv, (u - 0.5f) * 2.0f, (v - 0.5f) * 2.0f, (depth - 0.5f) * 2.0f, 1.0f);
+    v4 view = mat_mul_v4(matWorld, clip.x / clip.w, clip.y / clip.w, clip.z / clip.w, clip.w / clip.w);
+    return V3(view.x, view.y, view.z);
+}
+/* validateReprojectedUV reproject.frag:130-167 (angleMix/lastViewAngle are dead) */
+static float k2_validate(const k2_ctx *c, float ru, float rv, v3 worldPos, v3 worldNormal, float depth) {
+    if (ru > 1.0f || ru < 0.0f || rv > 1.0f || rv < 0.0f) return 0.0f;
+    float lvx, lvy, lastDepth; v3 lastN;
+    k2_vnd(c, ru, rv, &lvx, &lvy, &lastN, &lastDepth); /* samples the CURRENT velocity texture */
+    v3 lastWorldPos = ss_to_ws(ru, rv, lastDepth, c->p->prevCamera.matrixWorld, c->p->prevCamera.projectionMatrixInverse);
+    float viewZ = fabsf(perspective_depth_to_view_z(depth, c->p->camera.near_, c->p->camera.far_));
+    float distFactor = 1.0f + 1.0f / (viewZ + 1.0f);
+    float disoccl = 0.0f;
+    v3 dp = sub3(worldPos, lastWorldPos);
+    disoccl += length3(dp) / 10.0f * distFactor;                     /* worldDistanceDisocclusionCheck */
+    disoccl += fabsf(dot3(dp, worldNormal)) / 20.0f * distFactor;    /* planeDistanceDisocclusionCheck */
+    disoccl += fminf(1.0f - dot3(worldNormal, lastN), 1.0f) / 1.0f * distFactor; /* normalDisocclusionCheck */
+    float conf = 1.0f - fminf(disoccl, 1.0f);
+    conf = fmaxf(conf, 0.0f);
+    return powf(conf, c->p->confidencePower);
+}
+/* BiCubicCatmullRom5Tap reproject.frag:212-255 on a linear-filtered RGBA16F texture */
+static v4 k2_bicubic(const k2_ctx *c, const uint16_t *tex, float pu, float pv) {
+    dims d = {c->W, c->H};
+    float its[2] = {c->invW, c->invH}, P[2] = {pu, pv};
+    float w0[2], w1[2], w2[2], w3[2], W0[2], W1[2], W2[2], S0[2], S1[2], S2[2];
+    for (int k = 0; k < 2; k++) {
+        float UV = P[k] / its[k];
+        float tc = floorf(UV - 0.5f) + 0.5f;
+        float f = UV - tc, f2 = f * f, f3 = f2 * f;
+        w0[k] = f2 - 0.5f * (f3 + f);
+        w1[k] = 1.5f * f3 - 2.5f * f2 + 1.0f;
+        w3[k] = 0.5f * (f3 - f2);
+        w2[k] = 1.0f - w0[k] - w1[k] - w3[k];
+        W0[k] = w0[k]; W1[k] = w1[k] + w2[k]; W2[k] = w3[k];
+        S0[k] = (tc - 1.0f) * its[k];
+        S1[k] = (tc + w2[k] / W1[k]) * its[k];
+        S2[k] = (tc + 2.0f) * its[k];
+    }
+    float sw[5] = {W1[0] * W0[1], W0[0] * W1[1], W1[0] * W1[1], W2[0] * W1[1], W1[0] * W2[1]};
+    v4 Ct = fetch_h4_linear(tex, d, S1[0], S0[1]);
+    v4 Cl = fetch_h4_linear(tex, d, S0[0], S1[1]);
+    v4 Cc = fetch_h4_linear(tex, d, S1[0], S1[1]);
+    v4 Cr = fetch_h4_linear(tex, d, S2[0], S1[1]);
+    v4 Cb = fetch_h4_linear(tex, d, S1[0], S2[1]);
+    float wm = 1.0f / (sw[0] + sw[1] + sw[2] + sw[3] + sw[4]);
+    v4 r;
+    r.x = fmaxf(((((Ct.x * sw[0] + Cl.x * sw[1]) + Cc.x * sw[2]) + Cr.x * sw[3]) + Cb.x * sw[4]) * wm, 0.0f);
+    r.y = fmaxf(((((Ct.y * sw[0] + Cl.y * sw[1]) + Cc.y * sw[2]) + Cr.y * sw[3]) + Cb.y * sw[4]) * wm, 0.0f);
+    r.z = fmaxf(((((Ct.z * sw[0] + Cl.z * sw[1]) + Cc.z * sw[2]) + Cr.z * sw[3]) + Cb.z * sw[4]) * wm, 0.0f);
+    r.w = fmaxf(((((Ct.w * sw[0] + Cl.w * sw[1]) + Cc.w * sw[2]) + Cr.w * sw[3]) + Cb.w * sw[4]) * wm, 0.0f);
+    return r;
+}
+static inline v3 log1p3(v3 c, int on) { return on ? V3(logf(c.x + 1.0f), logf(c.y + 1.0f), logf(c.z + 1.0f)) : c; } /* transformColor */
+static inline v3 expm13(v3 c, int on) { return on ? V3(expf(c.x) - 1.0f, expf(c.y) - 1.0f, expf(c.z) - 1.0f) : c; } /* undoColorTransform */
+
+/* input texel i at (u,v) after unpack (DIFFUSE_SPECULAR) or raw */
+static inline v4 k2_input_texel(const k2_ctx *c, float u, float v, int idx) {
+    dims d = {c->W, c->H};
+    const uint32_t *t = fetch_u4(c->ssgi, d, u, v);
+    if (c->p->inputType == 0) {
+        v4 a, b; unpack_two_vec4(t, &a, &b);
+        return idx ? b : a;
+    }
+    v4 r; memcpy(&r, t, 16); return r;
+}
+
+static void k2_pixel(const k2_ctx *c, int x, int y, float *out0, float *out1) {
+    const rfx_temporal_params *p = c->p;
+    const int tc = p->textureCount, lt = p->logTransform;
+    float u = ((float)x + 0.5f) / (float)c->W, v = ((float)y + 0.5f) / (float)c->H;
+    float velx, vely, depth; v3 worldNormal;
+    k2_vnd(c, u, v, &velx, &vely, &worldNormal, &depth);
+    /* getTexels + preprocessInput temporal_reproject.frag:124-145 */
+    v4 inp[2]; int sampled[2];
+    for (int i = 0; i < tc; i++) {
+        inp[i] = k2_input_texel(c, u, v, i);
+        sampled[i] = inp[i].x >= 0.0f;
+        v3 rgb = V3(fmaxf(inp[i].x, 0.0f), fmaxf(inp[i].y, 0.0f), fmaxf(inp[i].z, 0.0f));
+        rgb = log1p3(rgb, lt);
+        inp[i].x = rgb.x; inp[i].y = rgb.y; inp[i].z = rgb.z;
+    }
+    /* quad partners for fwidth */
+    int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
+    float fx0 = ((float)qx0 + 0.5f) / (float)c->W, fx1 = ((float)qx1 + 0.5f) / (float)c->W;
+    float fy0 = ((float)qy0 + 0.5f) / (float)c->H, fy1 = ((float)qy1 + 0.5f) / (float)c->H;
+    float tvx, tvy, dxa, dxb, dya, dyb; v3 nxa, nxb, nya, nyb;
+    k2_vnd(c, fx0, v, &tvx, &tvy, &nxa, &dxa); k2_vnd(c, fx1, v, &tvx, &tvy, &nxb, &dxb);
+    k2_vnd(c, u, fy0, &tvx, &tvy, &nya, &dya); k2_vnd(c, u, fy1, &tvx, &tvy, &nyb, &dyb);
+    if (p->inputType != 1) { /* :188-193 */
+        float fw = fabsf(dxb - dxa) + fabsf(dyb - dya);
+        if (depth == 1.0f && fw == 0.0f) return; /* discard */
+    }
+    v3 fwn = V3(fabsf(nxb.x - nxa.x) + fabsf(nyb.x - nya.x), fabsf(nxb.y - nxa.y) + fabsf(nyb.y - nya.y), fabsf(nxb.z - nxa.z) + fabsf(nyb.z - nya.z));
+    float curvature = length3(fwn); /* getCurvature reproject.frag:265-269 */
+    v3 worldPos = ss_to_ws(u, v, depth, p->camera.matrixWorld, p->camera.projectionMatrixInverse);
+    float rayLength = 0.0f, roughness = 1.0f; /* globals: roughness = 1. (reproject.frag:6) */
+    if (p->inputType == 0) { rayLength = inp[1].w; roughness = clampf(inp[0].w, 0.0f, 1.0f); }
+    else if (p->inputType == 2) { uint32_t b; memcpy(&b, &inp[0].w, 4); float rl, ro; unpack_half2(b, &rl, &ro); rayLength = rl; roughness = clampf(ro, 0.0f, 1.0f); }
+    /* computeReprojectedUv temporal_reproject.frag:155-165 */
+    float rd[3], rs[3] = {-1.0f, -1.0f, -1.0f};
+    rd[0] = u - velx; rd[1] = v - vely;
+    rd[2] = k2_validate(c, rd[0], rd[1], worldPos, worldNormal, depth);
+    if (p->inputType == 0 || p->inputType == 2) {
+        /* reprojectHitPoint reproject.frag:169-193 */
+        float hu, hv;
+        if (curvature > 0.05f || rayLength < 0.01f) { hu = -1.0f; hv = -1.0f; }
+        else {
+            v3 camPos = V3(p->camera.position[0], p->camera.position[1], p->camera.position[2]);
+            v3 cameraRay = normalize3(sub3(worldPos, camPos));
+            v3 hp = add3(camPos, mul3(cameraRay, rayLength));
+            /* prevProjectionMatrix * prevViewMatrix * vec4(hp, 1): GLSL evaluates (A*B)*v */
+            float PV[16];
+            const float *A = p->prevCamera.projectionMatrix, *Bm = p->prevCamera.matrixWorldInverse;
+            for (int col = 0; col < 4; col++)
+                for (int row = 0; row < 4; row++)
+                    PV[col * 4 + row] = ((A[0 * 4 + row] * Bm[col * 4 + 0] + A[1 * 4 + row] * Bm[col * 4 + 1]) + A[2 * 4 + row] * Bm[col * 4 + 2]) +
+                                        A[3 * 4 + row] * Bm[col * 4 + 3];
+            v4 r = mat_mul_v4(PV, hp.x, hp.y, hp.z, 1.0f);
+            hu = (r.x / r.w) * 0.5f + 0.5f; hv = (r.y / r.w) * 0.5f + 0.5f;
+        }
+        rs[0] = hu; rs[1] = hv;
+        rs[2] = k2_validate(c, hu, hv, worldPos, worldNormal, depth);
+        if (rs[0] == -1.0f) { rs[0] = rd[0]; rs[1] = rd[1]; rs[2] = rd[2]; }
+    }
+    float moveFactor = fminf((velx * velx + vely * vely) * 10000.0f, 1.0f);
+    for (int i = 0; i < tc; i++) {
+        int spec = p->reprojectSpecular[i] != 0;
+        const float *uvc = spec ? rs : rd;
+        /* reproject() temporal_reproject.frag:83-122 */
+        v4 acc = k2_bicubic(c, c->hist[i], uvc[0], uvc[1]);
+        v3 accrgb = log1p3(V3(acc.x, acc.y, acc.z), lt);
+        float acca = acc.w;
+        v3 inrgb = V3(inp[i].x, inp[i].y, inp[i].z);
+        if (!sampled[i]) {
+            inrgb = accrgb;
+        } else {
+            acca += 1.0f;
+            v3 clamped = accrgb;
+            int cr = (spec && roughness < 0.25f) ? 1 : 2;
+            /* clampNeighborhood reproject.frag:83-95 + getNeighborhoodAABB :53-81 */
+            v3 ic = expm13(inrgb, lt);
+            v3 mn = ic, mx = ic;
+            for (int ox = -cr; ox <= cr; ox++)
+                for (int oy = -cr; oy <= cr; oy++) {
+                    float nu = u + (float)ox * c->invW, nv = v + (float)oy * c->invH;
+                    v4 t = k2_input_texel(c, nu, nv, (p->inputType == 0) ? spec : 0);
+                    if (t.x >= 0.0f) {
+                        mn = V3(fminf(t.x, mn.x), fminf(t.y, mn.y), fminf(t.z, mn.z));
+                        mx = V3(fmaxf(t.x, mx.x), fmaxf(t.y, mx.y), fmaxf(t.z, mx.z));
+                    }
+                }
+            mn = log1p3(mn, lt); mx = log1p3(mx, lt);
+            clamped = V3(clampf(clamped.x, mn.x, mx.x), clampf(clamped.y, mn.y, mx.y), clampf(clamped.z, mn.z, mx.z));
+            float r = spec ? roughness : 1.0f;
+            float aggr = fminf(1.0f, uvc[2] * r);
+            float ci = mixf(0.0f, fminf(1.0f, moveFactor * 50.0f + p->neighborhoodClampIntensity), aggr);
+            v3 nc = mix3(accrgb, clamped, ci);
+            float cd = fminf(length3(sub3(nc, accrgb)), 1.0f);
+            acca *= 1.0f - cd;
+            accrgb = nc;
+        }
+        /* accumulate() temporal_reproject.frag:42-79 */
+        float conf = powf(uvc[2], p->confidencePower);
+        float accumBlend = 1.0f - 1.0f / (acca + 1.0f);
+        accumBlend = mixf(0.0f, accumBlend, conf);
+        float maxValue = (p->fullAccumulate ? 1.0f : p->maxBlend) * p->keepData;
+        if (p->inputType != 1) {
+            const float rmax = 0.1f;
+            if (spec && roughness >= 0.0f && roughness < rmax) {
+                float mrv = mixf(0.0f, maxValue, roughness / rmax);
+                maxValue = mixf(maxValue, mrv, fminf(100.0f * moveFactor, 1.0f));
+            }
+        }
+        float m = fminf(accumBlend, maxValue);
+        acca = 1.0f / (1.0f - m) - 1.0f;
+        acca = fminf(65536.0f, acca);
+        v3 o = expm13(mix3(inrgb, accrgb, m), lt);
+        float *dst = i ? out1 : out0;
+        dst[0] = o.x; dst[1] = o.y; dst[2] = o.z; dst[3] = acca;
+    }
+}
+
+int rfxo_temporal(int W, int H, int y0, int y1, const uint32_t *ssgi, const uint32_t *velocity, const uint16_t *hist0, const uint16_t *hist1,
+                  const rfx_temporal_params *p, float *out0, float *out1) {
+    k2_ctx c = {W, H, ssgi, velocity, {hist0, hist1}, p, 0, 0};
+    /* TemporalReprojectPass.js:135: invTexSize.set(1 / width, 1 / height) — JS doubles -> float */
+    c.invW = (float)(1.0 / (double)W); c.invH = (float)(1.0 / (double)H);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < W; x++) {
+            size_t o = 4 * ((size_t)y * W + x);
+            k2_pixel(&c, x, y, out0 + o, out1 ? out1 + o : NULL);
+        }
+    return 0;
+}
+
+/* ==================================================================== K3: poisson_denoise.frag */
+typedef struct {
+    int W, H;
+    const float *depth; const uint32_t *gbuffer;
+    const void *in[2]; int in_half; /* in_half: RGBA16F linear, else RGBA32F nearest */
+    const uint8_t *blue; const rfx_denoise_params *p;
+} k3_ctx;
+
+static inline v4 k3_input(const k3_ctx *c, int idx, float u, float v) {
+    dims d = {c->W, c->H};
+    if (c->in_half) return fetch_h4_linear((const uint16_t *)c->in[idx], d, u, v);
+    return fetch_f4((const float *)c->in[idx], d, u, v);
+}
+static inline float k3_lum(v3 a) { return powf(lum(a), 0.125f); } /* #define luminance(a) pow(dot(..), 0.125) :28 */
+
+static void k3_pixel(const k3_ctx *c, int x, int y, uint16_t *out0, uint16_t *out1) {
+    const rfx_denoise_params *p = c->p;
+    dims d = {c->W, c->H};
+    const int tc = p->textureCount;
+    float u = ((float)x + 0.5f) / (float)c->W, v = ((float)y + 0.5f) / (float)c->H;
+    float depth = fetch_r32f(c->depth, d, u, v);
+    int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
+    float fx0 = ((float)qx0 + 0.5f) / (float)c->W, fx1 = ((float)qx1 + 0.5f) / (float)c->W;
+    float fy0 = ((float)qy0 + 0.5f) / (float)c->H, fy1 = ((float)qy1 + 0.5f) / (float)c->H;
+    {
+        float fw = fabsf(fetch_r32f(c->depth, d, fx1, v) - fetch_r32f(c->depth, d, fx0, v)) +
+                   fabsf(fetch_r32f(c->depth, d, u, fy1) - fetch_r32f(c->depth, d, u, fy0));
+        if (depth == 1.0f && fw == 0.0f) return; /* discard :129-132 */
+    }
+    v3 rgb[2]; float a[2], L[2], w_age[2], tw[2]; int isSpec[2];
+    for (int i = 0; i < tc; i++) { /* :137-165 */
+        isSpec[i] = p->isTextureSpecular[i] != 0;
+        v4 t = k3_input(c, isSpec[i] ? 1 : 0, u, v);
+        float age = 1.0f / powf(t.w + 1.0f, 1.2f * p->phi);
+        v3 col = V3(t.x * 1.0003f, t.y * 1.0003f, t.z * 1.0003f);
+        col = V3(logf(col.x + 1.0f), logf(col.y + 1.0f), logf(col.z + 1.0f));
+        rgb[i] = col; a[i] = t.w; L[i] = k3_lum(col); w_age[i] = age; tw[i] = 1.0f;
+    }
+    material mat = get_material(fetch_u4(c->gbuffer, d, u, v));
+    v3 normal = mat.normal;
+    float glossiness = fmaxf(0.0f, 4.0f * (1.0f - mat.roughness / 0.25f));
+    float specularFactor = expf(-glossiness * p->specularPhi);
+    /* fwidth(normal) over the quad */
+    v3 nxa = get_material(fetch_u4(c->gbuffer, d, fx0, v)).normal, nxb = get_material(fetch_u4(c->gbuffer, d, fx1, v)).normal;
+    v3 nya = get_material(fetch_u4(c->gbuffer, d, u, fy0)).normal, nyb = get_material(fetch_u4(c->gbuffer, d, u, fy1)).normal;
+    v3 fwn = V3(fabsf(nxb.x - nxa.x) + fabsf(nyb.x - nya.x), fabsf(nxb.y - nxa.y) + fabsf(nyb.y - nya.y), fabsf(nxb.z - nxa.z) + fabsf(nyb.z - nya.z));
+    float flatness = 1.0f - fminf(length3(fwn), 1.0f);
+    flatness = (flatness * flatness) * 0.75f + 0.25f;
+    v4 random = blue_noise(c->blue, x, y, p->blueNoiseIndex, u, v, d);
+    float r = p->radius;
+    float angle = random.x * 2.0f * 3.141592653589793f;
+    float s = sinf(angle), co = cosf(angle);
+    /* mat2 rm = r * flatness * mat2(c, -s, s, c): columns (c,-s), (s,c) */
+    float rf = r * flatness;
+    float m00 = rf * co, m01 = rf * -s, m10 = rf * s, m11 = rf * co; /* m<col><row> */
+    static const float SQ = 0.25f * 1.41421356237f;
+    const float POI[8][2] = {{-1, 0}, {0, -1}, {1, 0}, {0, 1}, {-SQ, -SQ}, {SQ, -SQ}, {SQ, SQ}, {-SQ, SQ}};
+    for (int k = 0; k < 8; k++) {
+        float ox = POI[k][0] / (float)c->W, oy = POI[k][1] / (float)c->H;
+        float nu = u + (m00 * ox + m10 * oy), nv = v + (m01 * ox + m11 * oy);
+        /* getBasicNeighborWeight :52-78 */
+        float wBasic;
+        {
+            material nm = get_material(fetch_u4(c->gbuffer, d, nu, nv));
+            float nd = fetch_r32f(c->depth, d, nu, nv);
+            if (nd == 1.0f) wBasic = 0.0f;
+            else {
+                float normalDiff = 1.0f - fmaxf(dot3(normal, nm.normal), 0.0f);
+                float depthDiff = 10000.0f * fabsf(depth - nd);
+                float roughDiff = fabsf(mat.roughness - nm.roughness);
+                wBasic = expf(-normalDiff * p->normalPhi - depthDiff * p->depthPhi - roughDiff * p->roughnessPhi);
+            }
+        }
+        for (int i = 0; i < tc; i++) { /* applyWeight :102-124 */
+            float w = wBasic;
+            v4 t = k3_input(c, isSpec[i] ? 1 : 0, nu, nv);
+            if (isSpec[i]) w *= specularFactor;
+            v3 tl = V3(logf(t.x + 1.0f), logf(t.y + 1.0f), logf(t.z + 1.0f));
+            float disocclW = powf(w, 0.1f);
+            float lumaDiff = fminf(fabsf(L[i] - k3_lum(tl)), 0.5f);
+            float lumaFactor = expf(-lumaDiff * p->lumaPhi);
+            w = mixf(w * lumaFactor, disocclW, w_age[i]) * w_age[i];
+            w *= (w < 0.0001f) ? 0.0f : 1.0f; /* step(0.0001, w) */
+            rgb[i] = add3(rgb[i], mul3(tl, w));
+            tw[i] += w;
+        }
+    }
+    for (int i = 0; i < tc; i++) { /* outputTexel :94-100 */
+        v3 o = V3(rgb[i].x / tw[i], rgb[i].y / tw[i], rgb[i].z / tw[i]);
+        o = V3(expf(o.x) - 1.0f, expf(o.y) - 1.0f, expf(o.z) - 1.0f);
+        uint16_t *dst = i ? out1 : out0;
+        if (p->halfStoreRTZ) { dst[0] = float_to_half_rtz(o.x); dst[1] = float_to_half_rtz(o.y); dst[2] = float_to_half_rtz(o.z); dst[3] = float_to_half_rtz(a[i]); }
+        else { dst[0] = float_to_half_rne(o.x); dst[1] = float_to_half_rne(o.y); dst[2] = float_to_half_rne(o.z); dst[3] = float_to_half_rne(a[i]); }
+    }
+}
+
+int rfxo_denoise(int W, int H, int y0, int y1, const float *depth, const uint32_t *gbuffer, const void *in0, const void *in1, int in_is_half,
+                 const uint8_t *blue, const rfx_denoise_params *p, uint16_t *out0, uint16_t *out1) {
+    k3_ctx c = {W, H, depth, gbuffer, {in0, in1}, in_is_half, blue, p};
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < W; x++) {
+            size_t o = 4 * ((size_t)y * W + x);
+            k3_pixel(&c, x, y, out0 + o, out1 ? out1 + o : NULL);
+        }
+    return 0;
+}
+
+/* ==================================================================== K4: DenoiserComposePass */
+int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_t *gbuffer, const uint16_t *gi0, const uint16_t *gi1,
+                 const rfx_compose_params *p, float *out) {
+    if (p->inputType != 0) return RFX_EUNSUPPORTED;
+    const float *C = p->camera.matrixWorld, *Vw = p->camera.matrixWorldInverse, *P = p->camera.projectionMatrix, *Pi = p->camera.projectionMatrixInverse;
+    dims d = {W, H};
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < W; x++) {
+            float u = ((float)x + 0.5f) / (float)W, v = ((float)y + 0.5f) / (float)H;
+            float dep = fetch_r32f(depth, d, u, v);
+            int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
+            float fx0 = ((float)qx0 + 0.5f) / (float)W, fx1 = ((float)qx1 + 0.5f) / (float)W;
+            float fy0 = ((float)qy0 + 0.5f) / (float)H, fy1 = ((float)qy1 + 0.5f) / (float)H;
+            float fw = fabsf(fetch_r32f(depth, d, fx1, v) - fetch_r32f(depth, d, fx0, v)) + fabsf(fetch_r32f(depth, d, u, fy1) - fetch_r32f(depth, d, u, fy0));
+            if (dep == 1.0f && fw == 0.0f) continue; /* discard DenoiserComposePass.js:61-64 */
+            material mat = get_material(fetch_u4(gbuffer, d, u, v));
+            v3 viewNormal = v4_mul_mat_xyz(C, mat.normal, 0.0f); /* :71, not normalised */
+            float viewZ = -perspective_depth_to_view_z(dep, p->camera.near_, p->camera.far_); /* :73 */
+            /* getViewPosition denoiser_compose_functions.glsl:13-20 */
+            float clipW = P[2 * 4 + 3] * viewZ + P[3 * 4 + 3];
+            v4 pp = mat_mul_v4(Pi, ((u - 0.5f) * 2.0f) * clipW, ((v - 0.5f) * 2.0f) * clipW, ((viewZ - 0.5f) * 2.0f) * clipW, 1.0f * clipW);
+            v3 viewPos = V3(pp.x, pp.y, -viewZ);
+            v3 viewDir = normalize3(viewPos);
+            v4 dgi = fetch_h4_linear(gi0, d, u, v), sgi = fetch_h4_linear(gi1, d, u, v);
+            /* constructGlobalIllumination :53-108 */
+            float roughness = mat.roughness * mat.roughness;
+            v3 normal = v4_mul_mat_xyz(Vw, viewNormal, 0.0f);
+            v3 vv = neg3(viewDir);
+            v3 V = v4_mul_mat_xyz(Vw, vv, 0.0f);
+            v3 N = normal, T, B;
+            onb(N, &T, &B);
+            V = V3(dot3(V, T), dot3(V, B), dot3(V, N));
+            v3 Hh = sample_ggx_vndf(V, roughness, roughness, 0.25f, 0.25f);
+            if (Hh.z < 0.0f) Hh = neg3(Hh);
+            v3 I = neg3(V);
+            v3 l = normalize3(sub3(I, mul3(Hh, 2.0f * dot3(Hh, I))));
+            l = add3(add3(mul3(T, l.x), mul3(B, l.y)), mul3(N, l.z));
+            l = normalize3(v4_mul_mat_xyz(C, l, 1.0f)); /* vec4(l, 1.) quirk :81 */
+            if (dot3(viewNormal, l) < 0.0f) l = neg3(l);
+            v3 h = normalize3(add3(vv, l));
+            float VoH = fmaxf(1e-6f, dot3(vv, h)); /* EPSILON from <common> */
+            v3 f0 = mix3(V3(0.04f, 0.04f, 0.04f), mat.diffuse, mat.metalness);
+            v3 F = f_schlick3(f0, VoH);
+            float om = 1.0f - mat.metalness;
+            v3 diffuseC = V3(mat.diffuse.x * om * (1.0f - F.x) * dgi.x, mat.diffuse.y * om * (1.0f - F.y) * dgi.y, mat.diffuse.z * om * (1.0f - F.z) * dgi.z);
+            v3 specC = V3(sgi.x * F.x, sgi.y * F.y, sgi.z * F.z);
+            float *o = out + 4 * ((size_t)y * W + x);
+            o[0] = diffuseC.x + specC.x + mat.emissive.x;
+            o[1] = diffuseC.y + specC.y + mat.emissive.y;
+            o[2] = diffuseC.z + specC.z + mat.emissive.z;
+            o[3] = 1.0f;
+        }
+    return 0;
+}
+
+/* exported helpers for unit tests of the codec / conversions */
+uint16_t rfxo_f2h_rne(float f) { return float_to_half_rne(f); }
+uint16_t rfxo_f2h_rtz(float f) { return float_to_half_rtz(f); }
+float rfxo_h2f(uint16_t h) { return half_to_float(h); }
+int rfxo_nearest_idx(float u, int size) { return nearest_idx(u, size); }
+void rfxo_get_material(const uint32_t *g, float *out12) {
+    material m = get_material(g);
+    out12[0] = m.diffuse.x; out12[1] = m.diffuse.y; out12[2] = m.diffuse.z; out12[3] = m.alpha;
+    out12[4] = m.normal.x; out12[5] = m.normal.y; out12[6] = m.normal.z;
+    out12[7] = m.roughness; out12[8] = m.metalness;
+    out12[9] = m.emissive.x; out12[10] = m.emissive.y; out12[11] = m.emissive.z;
+}
+void rfxo_blue_noise(const uint8_t *table, int px, int py, int index, float *out4) {
+    dims d = {128, 128};
+    v4 r = blue_noise(table, px, py, index, 0, 0, d);
+    out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w;
+}
+void rfxo_pack_two_vec4(const float *a, const float *b, uint32_t *out) {
+    v4 A = {a[0], a[1], a[2], a[3]}, Bv = {b[0], b[1], b[2], b[3]};
+    pack_two_vec4(A, Bv, out);
+}

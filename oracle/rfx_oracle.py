@@ -1,0 +1,109 @@
+"""ctypes wrapper around oracle/_ref/librfx_oracle.so (the C restatement, oracle/rfx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY — importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never from the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "realism-effects_amd"))
+from rfx_amd import abi  # noqa: E402  (struct layouts of include/rfx.h only)
+
+LIB = os.path.join(HERE, "_ref", "librfx_oracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE, "_ref/librfx_oracle.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "rfx_oracle.c")):
+            build()
+        _lib = C.CDLL(LIB)
+        _lib.rfxo_h2f.restype = C.c_float
+        _lib.rfxo_h2f.argtypes = [C.c_uint16]
+        _lib.rfxo_f2h_rne.restype = C.c_uint16
+        _lib.rfxo_f2h_rne.argtypes = [C.c_float]
+        _lib.rfxo_f2h_rtz.restype = C.c_uint16
+        _lib.rfxo_f2h_rtz.argtypes = [C.c_float]
+        _lib.rfxo_nearest_idx.argtypes = [C.c_float, C.c_int]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _chk(a, dtype, shape=None):
+    assert a.dtype == dtype and a.flags["C_CONTIGUOUS"], (a.dtype, dtype)
+    if shape is not None:
+        assert a.shape == shape, (a.shape, shape)
+    return a
+
+
+def ssgi(depth, gbuffer, direct, history, blue, params: abi.SsgiParams, out=None, rows=None):
+    H, W = depth.shape
+    y0, y1 = rows or (0, H)
+    if out is None:
+        out = np.zeros((H, W, 4), np.uint32)
+    rc = lib().rfxo_ssgi(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gbuffer, np.uint32, (H, W, 4))), _p(_chk(direct, np.float32, (H, W, 4))),
+                         _p(_chk(history, np.float32, (H, W, 4))), _p(_chk(blue, np.uint8)), C.byref(params), _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def temporal(ssgi_tex, velocity, hist0, hist1, params: abi.TemporalParams, out0=None, out1=None, rows=None):
+    H, W = ssgi_tex.shape[:2]
+    y0, y1 = rows or (0, H)
+    out0 = np.zeros((H, W, 4), np.float32) if out0 is None else out0
+    out1 = np.zeros((H, W, 4), np.float32) if out1 is None else out1
+    rc = lib().rfxo_temporal(W, H, y0, y1, _p(_chk(ssgi_tex, np.uint32, (H, W, 4))), _p(_chk(velocity, np.uint32, (H, W, 4))),
+                             _p(_chk(hist0, np.uint16, (H, W, 4))), _p(_chk(hist1, np.uint16, (H, W, 4))), C.byref(params), _p(out0), _p(out1))
+    assert rc == 0, rc
+    return out0, out1
+
+
+def denoise(depth, gbuffer, in0, in1, blue, params: abi.DenoiseParams, out0, out1, rows=None):
+    """in0/in1: float32 (H,W,4) [pass 0] or uint16 half bits (H,W,4) [later passes]; out0/out1 are
+    updated IN PLACE (discarded fragments keep their previous contents)."""
+    H, W = depth.shape
+    y0, y1 = rows or (0, H)
+    is_half = in0.dtype == np.uint16
+    _chk(in0, np.uint16 if is_half else np.float32, (H, W, 4))
+    rc = lib().rfxo_denoise(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gbuffer, np.uint32, (H, W, 4))), _p(in0), _p(in1), int(is_half),
+                            _p(_chk(blue, np.uint8)), C.byref(params), _p(_chk(out0, np.uint16, (H, W, 4))), _p(_chk(out1, np.uint16, (H, W, 4))))
+    assert rc == 0, rc
+    return out0, out1
+
+
+def compose(depth, gbuffer, gi0, gi1, params: abi.ComposeParams, out=None, rows=None):
+    H, W = depth.shape
+    y0, y1 = rows or (0, H)
+    out = np.zeros((H, W, 4), np.float32) if out is None else out
+    rc = lib().rfxo_compose(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gbuffer, np.uint32, (H, W, 4))), _p(_chk(gi0, np.uint16, (H, W, 4))),
+                            _p(_chk(gi1, np.uint16, (H, W, 4))), C.byref(params), _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def half_bits_to_float(h: np.ndarray) -> np.ndarray:
+    return h.view(np.float16).astype(np.float32)
+
+
+def unpack_ssgi(packed: np.ndarray):
+    """unpackTwoVec4 (gbuffer_packing.glsl:85-98) of a K1 output -> (diffuse+roughness, specular+rayLength) float32."""
+    lo = (packed & np.uint32(0xffff)).astype(np.uint16).view(np.float16).astype(np.float32)
+    hi = (packed >> np.uint32(16)).astype(np.uint16).view(np.float16).astype(np.float32)
+    a = np.stack([lo[..., 0], hi[..., 0], lo[..., 1], hi[..., 1]], axis=-1) - np.float32(1e-4)
+    b = np.stack([lo[..., 2], hi[..., 2], lo[..., 3], hi[..., 3]], axis=-1) - np.float32(1e-4)
+    return a, b
