@@ -163,6 +163,11 @@ int rfx_compose(rfx_ctx *, const rfx_compose_params *);
 
 int rfx_sync(rfx_ctx *);
 
+/* Number of texel fetches that fell outside the rows a tile context holds since creation
+ * (they are clamped into the band, i.e. the halo was too small for the frame's motion/radius).
+ * 0 on a correct configuration; always 0 for a whole-frame context. */
+unsigned int rfx_halo_violations(rfx_ctx *);
+
 /* Timing helper: run `fn`-selected kernel `iters` times between two hipEvents on the context's
  * stream and return the mean milliseconds (used by bench.py for the roofline line). */
 int rfx_time_begin(rfx_ctx *);

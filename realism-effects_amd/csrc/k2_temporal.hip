@@ -1,0 +1,241 @@
+// K2 — TemporalReprojectPass: velocity / hit-point reprojection, disocclusion confidence,
+// neighbourhood clamp and age-driven accumulation.  Replaces `renderer.render` of
+// src/temporal-reproject/TemporalReprojectPass.js:192-193 with the fragment program
+// src/temporal-reproject/shader/temporal_reproject.frag (+ reproject.frag), PERSPECTIVE_CAMERA.
+#include "rfx_device.h"
+#include "rfx_kernels.h"
+
+namespace {
+
+struct VND {
+    float vx, vy, depth;
+    float3 normal;
+};
+// getVelocityNormalDepth reproject.frag:97-105
+RFX_DEV VND k2_vnd(uint4 t) {
+    VND r;
+    r.vx = __uint_as_float(t.x);
+    r.vy = __uint_as_float(t.y);
+    r.normal = rfx_unpack_normal(t.z);
+    r.depth = __uint_as_float(t.w);
+    return r;
+}
+// screenSpaceToWorldSpace reproject.frag:21-28
+RFX_DEV float3 k2_ss_to_ws(float u, float v, float depth, const float *matWorld, const float *projInv) {
+    float4 clip = rfx_mat_mul(projInv, (u - 0.5f) * 2.0f, (v - 0.5f) * 2.0f, (depth - 0.5f) * 2.0f, 1.0f);
+    float4 w = rfx_mat_mul(matWorld, clip.x / clip.w, clip.y / clip.w, clip.z / clip.w, clip.w / clip.w);
+    return make_float3(w.x, w.y, w.z);
+}
+// validateReprojectedUV reproject.frag:130-167 (the angleMix / lastViewAngle computation is dead code)
+RFX_DEV float k2_validate(const K2Args &A, const FrameDims &d, float ru, float rv, float3 worldPos, float3 worldNormal, float distFactor) {
+    if (ru > 1.0f || ru < 0.0f || rv > 1.0f || rv < 0.0f) return 0.0f;
+    const VND last = k2_vnd(rfx_fetch_u4(A.velocity, d, ru, rv));  // NB: the CURRENT velocity texture
+    const float3 lastWorldPos = k2_ss_to_ws(ru, rv, last.depth, A.p.prevCamera.matrixWorld, A.p.prevCamera.projectionMatrixInverse);
+    const float3 dp = worldPos - lastWorldPos;
+    float disoccl = 0.0f;
+    disoccl += rfx_length(dp) / 10.0f * distFactor;                              // worldDistanceDisocclusionCheck
+    disoccl += fabsf(rfx_dot(dp, worldNormal)) / 20.0f * distFactor;              // planeDistanceDisocclusionCheck
+    disoccl += fminf(1.0f - rfx_dot(worldNormal, last.normal), 1.0f) / 1.0f * distFactor;  // normalDisocclusionCheck
+    float conf = fmaxf(1.0f - fminf(disoccl, 1.0f), 0.0f);
+    return rfx_pow(conf, A.p.confidencePower);
+}
+
+// BiCubicCatmullRom5Tap reproject.frag:212-255 — five hardware-bilinear taps of the RGBA16F history
+RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &tex, float pu, float pv) {
+    float Wa[2], Wb[2], Wc[2], S0[2], S1[2], S2[2];
+    const float its[2] = {A.invW, A.invH}, P[2] = {pu, pv};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float UV = P[k] / its[k];
+        const float tc = floorf(UV - 0.5f) + 0.5f;
+        const float f = UV - tc, f2 = f * f, f3 = f2 * f;
+        const float w0 = f2 - 0.5f * (f3 + f);
+        const float w1 = 1.5f * f3 - 2.5f * f2 + 1.0f;
+        const float w3 = 0.5f * (f3 - f2);
+        const float w2 = 1.0f - w0 - w1 - w3;
+        Wa[k] = w0;
+        Wb[k] = w1 + w2;
+        Wc[k] = w3;
+        S0[k] = (tc - 1.0f) * its[k];
+        S1[k] = (tc + w2 / Wb[k]) * its[k];
+        S2[k] = (tc + 2.0f) * its[k];
+    }
+    const float sw0 = Wb[0] * Wa[1], sw1 = Wa[0] * Wb[1], sw2 = Wb[0] * Wb[1], sw3 = Wc[0] * Wb[1], sw4 = Wb[0] * Wc[1];
+    const float4 Ct = rfx_fetch_h4_linear(tex, d, S1[0], S0[1]);
+    const float4 Cl = rfx_fetch_h4_linear(tex, d, S0[0], S1[1]);
+    const float4 Cc = rfx_fetch_h4_linear(tex, d, S1[0], S1[1]);
+    const float4 Cr = rfx_fetch_h4_linear(tex, d, S2[0], S1[1]);
+    const float4 Cb = rfx_fetch_h4_linear(tex, d, S1[0], S2[1]);
+    const float wm = 1.0f / ((((sw0 + sw1) + sw2) + sw3) + sw4);
+    float4 r;
+    r.x = fmaxf(((((Ct.x * sw0 + Cl.x * sw1) + Cc.x * sw2) + Cr.x * sw3) + Cb.x * sw4) * wm, 0.0f);
+    r.y = fmaxf(((((Ct.y * sw0 + Cl.y * sw1) + Cc.y * sw2) + Cr.y * sw3) + Cb.y * sw4) * wm, 0.0f);
+    r.z = fmaxf(((((Ct.z * sw0 + Cl.z * sw1) + Cc.z * sw2) + Cr.z * sw3) + Cb.z * sw4) * wm, 0.0f);
+    r.w = fmaxf(((((Ct.w * sw0 + Cl.w * sw1) + Cc.w * sw2) + Cr.w * sw3) + Cb.w * sw4) * wm, 0.0f);
+    return r;
+}
+
+template <bool LOGT>
+RFX_DEV float3 k2_to_log(float3 c) {  // transformColor reproject.frag:42
+    return LOGT ? make_float3(rfx_log(c.x + 1.0f), rfx_log(c.y + 1.0f), rfx_log(c.z + 1.0f)) : c;
+}
+template <bool LOGT>
+RFX_DEV float3 k2_from_log(float3 c) {  // undoColorTransform :43
+    return LOGT ? make_float3(rfx_exp(c.x) - 1.0f, rfx_exp(c.y) - 1.0f, rfx_exp(c.z) - 1.0f) : c;
+}
+
+// input texel `idx` of the packed K1 output (DIFFUSE_SPECULAR) or the raw texel
+template <int INPUT_TYPE>
+RFX_DEV float4 k2_unpack(uint4 t, int idx) {
+    if (INPUT_TYPE == 0) return idx ? rfx_unpack_vec4(t.z, t.w) : rfx_unpack_vec4(t.x, t.y);
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+}
+
+template <int INPUT_TYPE, int TC, bool LOGT>
+__global__ __launch_bounds__(256) void k2_temporal_reproject(K2Args A) {
+    const FrameDims d = A.dims;
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = A.y0 + blockIdx.y * 4 + threadIdx.y;
+    if (x >= d.W || y >= A.y1) return;
+    const rfx_temporal_params &p = A.p;
+    const float u = ((float)x + 0.5f) / d.fW, v = ((float)y + 0.5f) / d.fH;
+    const uint4 *velp = (const uint4 *)A.velocity.ptr;
+    const uint4 *inp_p = (const uint4 *)A.ssgi.ptr;
+
+    const VND cur = k2_vnd(velp[rfx_xy_index(d, A.velocity.row0, A.velocity.rows, x, y)]);
+    const uint4 packed = inp_p[rfx_xy_index(d, A.ssgi.row0, A.ssgi.rows, x, y)];
+
+    // 2x2 quad partners for fwidth(depth) / fwidth(worldNormal)
+    const int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
+    const VND xa = k2_vnd(velp[rfx_xy_index(d, A.velocity.row0, A.velocity.rows, qx0, y)]);
+    const VND xb = k2_vnd(velp[rfx_xy_index(d, A.velocity.row0, A.velocity.rows, qx1, y)]);
+    const VND ya = k2_vnd(velp[rfx_xy_index(d, A.velocity.row0, A.velocity.rows, x, qy0)]);
+    const VND yb = k2_vnd(velp[rfx_xy_index(d, A.velocity.row0, A.velocity.rows, x, qy1)]);
+    if (INPUT_TYPE != 1) {  // temporal_reproject.frag:188-193
+        const float fw = fabsf(xb.depth - xa.depth) + fabsf(yb.depth - ya.depth);
+        if (cur.depth == 1.0f && fw == 0.0f) return;  // discard
+    }
+    const float3 fwn = make_float3(fabsf(xb.normal.x - xa.normal.x) + fabsf(yb.normal.x - ya.normal.x),
+                                   fabsf(xb.normal.y - xa.normal.y) + fabsf(yb.normal.y - ya.normal.y),
+                                   fabsf(xb.normal.z - xa.normal.z) + fabsf(yb.normal.z - ya.normal.z));
+    const float curvature = rfx_length(fwn);  // getCurvature reproject.frag:265-269
+
+    // getTexels + preprocessInput :124-145
+    float4 inp[TC];
+    bool sampled[TC];
+#pragma unroll
+    for (int i = 0; i < TC; i++) {
+        inp[i] = k2_unpack<INPUT_TYPE>(packed, i);
+        sampled[i] = inp[i].x >= 0.0f;
+        const float3 c = k2_to_log<LOGT>(make_float3(fmaxf(inp[i].x, 0.0f), fmaxf(inp[i].y, 0.0f), fmaxf(inp[i].z, 0.0f)));
+        inp[i].x = c.x; inp[i].y = c.y; inp[i].z = c.z;
+    }
+    const float3 worldNormal = cur.normal;
+    const float3 worldPos = k2_ss_to_ws(u, v, cur.depth, p.camera.matrixWorld, p.camera.projectionMatrixInverse);
+    float rayLength = 0.0f, roughness = 1.0f;  // getRoughnessRayLength :167-176
+    if (INPUT_TYPE == 0) {
+        rayLength = inp[TC - 1].w;
+        roughness = rfx_clamp(inp[0].w, 0.0f, 1.0f);
+    } else if (INPUT_TYPE == 2) {
+        float rl, ro;
+        rfx_unpack_half2(__float_as_uint(inp[0].w), rl, ro);
+        rayLength = rl;
+        roughness = rfx_clamp(ro, 0.0f, 1.0f);
+    }
+    const float n_ = p.camera.near_, f_ = p.camera.far_;
+    const float viewZ = fabsf((n_ * f_) / ((f_ - n_) * cur.depth - f_));
+    const float distFactor = 1.0f + 1.0f / (viewZ + 1.0f);
+
+    // computeReprojectedUv :155-165
+    float3 rd, rs;
+    rd.x = u - cur.vx;
+    rd.y = v - cur.vy;
+    rd.z = k2_validate(A, d, rd.x, rd.y, worldPos, worldNormal, distFactor);
+    rs = rd;
+    if (INPUT_TYPE != 1) {
+        if (!(curvature > 0.05f || rayLength < 0.01f)) {  // reprojectHitPoint reproject.frag:169-193
+            const float3 camPos = make_float3(p.camera.position[0], p.camera.position[1], p.camera.position[2]);
+            const float3 cameraRay = rfx_normalize(worldPos - camPos);
+            const float3 hp = camPos + cameraRay * rayLength;
+            const float4 r = rfx_mat_mul(A.prevPV, hp.x, hp.y, hp.z, 1.0f);
+            const float hu = (r.x / r.w) * 0.5f + 0.5f, hv = (r.y / r.w) * 0.5f + 0.5f;
+            const float conf = k2_validate(A, d, hu, hv, worldPos, worldNormal, distFactor);
+            if (hu != -1.0f) rs = make_float3(hu, hv, conf);  // :161-163 falls back to the diffuse triple
+        }
+    }
+    const float moveFactor = fminf((cur.vx * cur.vx + cur.vy * cur.vy) * 10000.0f, 1.0f);
+    const size_t oi = (size_t)rfx_local_row(d, A.out0.row0, A.out0.rows, y) * d.W + x;
+
+#pragma unroll
+    for (int i = 0; i < TC; i++) {
+        const bool spec = p.reprojectSpecular[i] != 0;
+        const float3 uvc = spec ? rs : rd;
+        // reproject() :83-122
+        const float4 acc = k2_bicubic(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
+        float3 accrgb = k2_to_log<LOGT>(make_float3(acc.x, acc.y, acc.z));
+        float acca = acc.w;
+        float3 inrgb = make_float3(inp[i].x, inp[i].y, inp[i].z);
+        if (!sampled[i]) {
+            inrgb = accrgb;
+        } else {
+            acca += 1.0f;
+            const int cr = (spec && roughness < 0.25f) ? 1 : 2;
+            // clampNeighborhood reproject.frag:83-95 / getNeighborhoodAABB :53-81 (raw neighbour texels)
+            const float3 ic = k2_from_log<LOGT>(inrgb);
+            float3 mn = ic, mx = ic;
+            for (int ox = -cr; ox <= cr; ox++)
+                for (int oy = -cr; oy <= cr; oy++) {
+                    const float nu = u + (float)ox * A.invW, nv = v + (float)oy * A.invH;
+                    const float4 t = k2_unpack<INPUT_TYPE>(rfx_fetch_u4(A.ssgi, d, nu, nv), (INPUT_TYPE == 0 && spec) ? 1 : 0);
+                    if (t.x >= 0.0f) {
+                        mn = make_float3(fminf(t.x, mn.x), fminf(t.y, mn.y), fminf(t.z, mn.z));
+                        mx = make_float3(fmaxf(t.x, mx.x), fmaxf(t.y, mx.y), fmaxf(t.z, mx.z));
+                    }
+                }
+            mn = k2_to_log<LOGT>(mn);
+            mx = k2_to_log<LOGT>(mx);
+            const float3 clamped = make_float3(rfx_clamp(accrgb.x, mn.x, mx.x), rfx_clamp(accrgb.y, mn.y, mx.y), rfx_clamp(accrgb.z, mn.z, mx.z));
+            const float r = spec ? roughness : 1.0f;
+            const float aggr = fminf(1.0f, uvc.z * r);
+            const float ci = rfx_mix(0.0f, fminf(1.0f, moveFactor * 50.0f + p.neighborhoodClampIntensity), aggr);
+            const float3 nc = rfx_mix(accrgb, clamped, ci);
+            const float cd = fminf(rfx_length(nc - accrgb), 1.0f);
+            acca *= 1.0f - cd;
+            accrgb = nc;
+        }
+        // accumulate() :42-79
+        const float conf = rfx_pow(uvc.z, p.confidencePower);  // second power on purpose (Appendix D-6)
+        float accumBlend = 1.0f - 1.0f / (acca + 1.0f);
+        accumBlend = rfx_mix(0.0f, accumBlend, conf);
+        float maxValue = (p.fullAccumulate ? 1.0f : p.maxBlend) * p.keepData;
+        if (INPUT_TYPE != 1) {
+            const float rmax = 0.1f;
+            if (spec && roughness >= 0.0f && roughness < rmax) {
+                const float mrv = rfx_mix(0.0f, maxValue, roughness / rmax);
+                maxValue = rfx_mix(maxValue, mrv, fminf(100.0f * moveFactor, 1.0f));
+            }
+        }
+        const float mixv = fminf(accumBlend, maxValue);
+        acca = fminf(65536.0f, 1.0f / (1.0f - mixv) - 1.0f);
+        const float3 o = k2_from_log<LOGT>(rfx_mix(inrgb, accrgb, mixv));
+        ((float4 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = make_float4(o.x, o.y, o.z, acca);
+    }
+}
+
+}  // namespace
+
+hipError_t rfx_launch_k2(const K2Args &A, hipStream_t stream) {
+    dim3 block(64, 4), grid((A.dims.W + 63) / 64, (A.y1 - A.y0 + 3) / 4);
+    const bool lt = A.p.logTransform != 0;
+#define K2_LAUNCH(IT, TC)                                                                                          \
+    do {                                                                                                           \
+        if (lt) hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, true>), grid, block, 0, stream, A);              \
+        else hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, false>), grid, block, 0, stream, A);               \
+    } while (0)
+    if (A.p.inputType == 0 && A.p.textureCount == 2) K2_LAUNCH(0, 2);
+    else if (A.p.inputType == 1 && A.p.textureCount == 1) K2_LAUNCH(1, 1);
+    else if (A.p.inputType == 2 && A.p.textureCount == 1) K2_LAUNCH(2, 1);
+    else return hipErrorInvalidValue;
+#undef K2_LAUNCH
+    return hipGetLastError();
+}

@@ -1,0 +1,68 @@
+// K4 — DenoiserComposePass: gi = diffuse*(1-metal)*(1-F)*diffuseGi + specularGi*F + emissive.
+// Replaces `renderer.render` of src/denoise/pass/DenoiserComposePass.js:133-134; arithmetic from
+// the inline shader :36-86 and src/denoise/shader/denoiser_compose_functions.glsl:53-108.
+// Pure streaming kernel: 52 B/px (4 depth + 16 gbuffer + 2x8 GI in, 16 out).
+#include "rfx_brdf.h"
+#include "rfx_kernels.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k4_compose(K4Args A) {
+    const FrameDims d = A.dims;
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = A.y0 + blockIdx.y * 4 + threadIdx.y;
+    if (x >= d.W || y >= A.y1) return;
+    const float *C = A.p.camera.matrixWorld, *Vw = A.p.camera.matrixWorldInverse;
+    const float *P = A.p.camera.projectionMatrix, *Pi = A.p.camera.projectionMatrixInverse;
+    const float u = ((float)x + 0.5f) / d.fW, v = ((float)y + 0.5f) / d.fH;
+    const float *depthp = (const float *)A.depth.ptr;
+    const float depth = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, y)];
+    {
+        const int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
+        float dxa = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, qx0, y)], dxb = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, qx1, y)];
+        float dya = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, qy0)], dyb = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, qy1)];
+        if (depth == 1.0f && (fabsf(dxb - dxa) + fabsf(dyb - dya)) == 0.0f) return;  // discard :61-64
+    }
+    const Material mat = rfx_get_material<true>(((const uint4 *)A.gbuffer.ptr)[rfx_xy_index(d, A.gbuffer.row0, A.gbuffer.rows, x, y)]);
+    const float3 viewNormal = rfx_vec_mul_mat(C, mat.normal, 0.0f);  // :71 (not normalised)
+    const float n_ = A.p.camera.near_, f_ = A.p.camera.far_;
+    const float viewZ = -((n_ * f_) / ((f_ - n_) * depth - f_));  // -perspectiveDepthToViewZ :73
+    const float clipW = P[2 * 4 + 3] * viewZ + P[3 * 4 + 3];
+    const float4 pp = rfx_mat_mul(Pi, ((u - 0.5f) * 2.0f) * clipW, ((v - 0.5f) * 2.0f) * clipW, ((viewZ - 0.5f) * 2.0f) * clipW, 1.0f * clipW);
+    const float3 viewDir = rfx_normalize(make_float3(pp.x, pp.y, -viewZ));
+    const float4 dgi = rfx_fetch_h4_linear(A.gi0, d, u, v), sgi = rfx_fetch_h4_linear(A.gi1, d, u, v);
+
+    // constructGlobalIllumination
+    const float roughness = mat.roughness * mat.roughness;
+    const float3 normal = rfx_vec_mul_mat(Vw, viewNormal, 0.0f);
+    const float3 vv = -viewDir;
+    float3 V = rfx_vec_mul_mat(Vw, vv, 0.0f);
+    float3 T, B;
+    rfx_onb(normal, T, B);
+    V = rfx_to_local(T, B, normal, V);
+    float3 H = rfx_sample_ggx_vndf(V, roughness, roughness, 0.25f, 0.25f);
+    if (H.z < 0.0f) H = -H;
+    float3 l = rfx_normalize(rfx_reflect(-V, H));
+    l = rfx_to_world(T, B, normal, l);
+    l = rfx_normalize(rfx_vec_mul_mat(C, l, 1.0f));  // vec4(l, 1.) quirk :81
+    if (rfx_dot(viewNormal, l) < 0.0f) l = -l;
+    const float3 h = rfx_normalize(vv + l);
+    const float VoH = fmaxf(1e-6f, rfx_dot(vv, h));
+    const float3 f0 = rfx_mix(make_float3(0.04f, 0.04f, 0.04f), mat.diffuse, mat.metalness);
+    const float3 F = rfx_f_schlick(f0, VoH);
+    const float om = 1.0f - mat.metalness;
+    float4 o;
+    o.x = (mat.diffuse.x * om * (1.0f - F.x) * dgi.x + sgi.x * F.x) + mat.emissive.x;
+    o.y = (mat.diffuse.y * om * (1.0f - F.y) * dgi.y + sgi.y * F.y) + mat.emissive.y;
+    o.z = (mat.diffuse.z * om * (1.0f - F.z) * dgi.z + sgi.z * F.z) + mat.emissive.z;
+    o.w = 1.0f;
+    ((float4 *)A.out.ptr)[(size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x] = o;
+}
+
+}  // namespace
+
+hipError_t rfx_launch_k4(const K4Args &A, hipStream_t stream) {
+    dim3 block(64, 4), grid((A.dims.W + 63) / 64, (A.y1 - A.y0 + 3) / 4);
+    hipLaunchKernelGGL(k4_compose, grid, block, 0, stream, A);
+    return hipGetLastError();
+}

@@ -1,0 +1,388 @@
+// rfx_api.hip — the C ABI of librfx_hip.so (include/rfx.h): context, texture slots, the four
+// draw entry points.  Host side only; kernels live in k1..k4_*.hip.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include "../../include/rfx.h"
+#include "rfx_kernels.h"
+
+struct Slot {
+    void *ptr = nullptr;
+    bool owned = false;
+    int row0 = 0, rows = 0;  // held band (frame rows)
+    size_t texel = 0;
+    int width = 0;
+    bool uploaded = false;
+};
+
+struct rfx_ctx {
+    int device = 0;
+    int W = 0, H = 0, tile_y0 = 0, tile_rows = 0, halo = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned int *halo_violations = nullptr;
+    Slot slots[RFX_TEX_COUNT];
+    std::string err;
+};
+
+static thread_local std::string g_create_err;
+
+static size_t texel_bytes(int id) {
+    switch (id) {
+    case RFX_TEX_DEPTH: return 4;
+    case RFX_TEX_BLUE_NOISE: return 4;
+    case RFX_TEX_DENOISE_A0: case RFX_TEX_DENOISE_A1: case RFX_TEX_DENOISE_B0: case RFX_TEX_DENOISE_B1: return 8;
+    default: return 16;
+    }
+}
+
+static int fail(rfx_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    if (c) c->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+#define HIPCHK(c, call)                                              \
+    do {                                                             \
+        hipError_t e__ = (call);                                     \
+        if (e__ != hipSuccess) return fail(c, RFX_EDEVICE, #call, e__); \
+    } while (0)
+
+extern "C" {
+
+int rfx_abi_version(void) { return RFX_ABI_VERSION; }
+
+size_t rfx_tex_texel_bytes(rfx_tex id) { return (id >= 0 && id < RFX_TEX_COUNT) ? texel_bytes(id) : 0; }
+
+rfx_ctx *rfx_create(int device, int width, int height, int tile_y0, int tile_rows, int halo_rows) {
+    if (width <= 0 || height <= 0 || tile_y0 < 0 || tile_rows <= 0 || tile_y0 + tile_rows > height || halo_rows < 0) {
+        fail(nullptr, RFX_EINVAL, "rfx_create: bad geometry");
+        return nullptr;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || device < 0 || device >= ndev) {
+        fail(nullptr, RFX_EDEVICE, "rfx_create: no such HIP device", e);
+        return nullptr;
+    }
+    rfx_ctx *c = new rfx_ctx();
+    c->device = device;
+    c->W = width; c->H = height; c->tile_y0 = tile_y0; c->tile_rows = tile_rows; c->halo = halo_rows;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc((void **)&c->halo_violations, sizeof(unsigned int)) != hipSuccess) {
+        fail(nullptr, RFX_EDEVICE, "rfx_create: stream/event creation failed");
+        delete c;
+        return nullptr;
+    }
+    hipMemset(c->halo_violations, 0, sizeof(unsigned int));
+    c->stream = c->own_stream;
+    const int b0 = tile_y0 - halo_rows < 0 ? 0 : tile_y0 - halo_rows;
+    const int b1 = tile_y0 + tile_rows + halo_rows > height ? height : tile_y0 + tile_rows + halo_rows;
+    for (int i = 0; i < RFX_TEX_COUNT; i++) {
+        Slot &s = c->slots[i];
+        s.texel = texel_bytes(i);
+        s.width = width;
+        // K1 gathers depth and last frame's composed GI anywhere on screen -> held whole
+        const bool whole = (i == RFX_TEX_DEPTH || i == RFX_TEX_COMPOSE);
+        s.row0 = whole ? 0 : b0;
+        s.rows = whole ? height : b1 - b0;
+        if (i == RFX_TEX_BLUE_NOISE) { s.row0 = 0; s.rows = 128; s.width = 128; }
+    }
+    return c;
+}
+
+void rfx_destroy(rfx_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (int i = 0; i < RFX_TEX_COUNT; i++)
+        if (c->slots[i].owned && c->slots[i].ptr) hipFree(c->slots[i].ptr);
+    if (c->halo_violations) hipFree(c->halo_violations);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char *rfx_last_error(const rfx_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int rfx_set_stream(rfx_ctx *c, void *hip_stream) {
+    if (!c) return RFX_EINVAL;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return RFX_OK;
+}
+
+int rfx_tex_held_rows(const rfx_ctx *c, rfx_tex id, int *row0, int *rows) {
+    if (!c || id < 0 || id >= RFX_TEX_COUNT) return RFX_EINVAL;
+    if (row0) *row0 = c->slots[id].row0;
+    if (rows) *rows = c->slots[id].rows;
+    return RFX_OK;
+}
+
+static int ensure(rfx_ctx *c, int id) {
+    Slot &s = c->slots[id];
+    if (s.ptr) return RFX_OK;
+    hipSetDevice(c->device);
+    const size_t bytes = (size_t)s.rows * s.width * s.texel;
+    hipError_t e = hipMalloc(&s.ptr, bytes);
+    if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(texture)", e);
+    s.owned = true;
+    // render targets start zeroed: `discard`ed fragments expose the initial contents (Appendix D-10)
+    e = hipMemsetAsync(s.ptr, 0, bytes, c->stream);
+    if (e != hipSuccess) return fail(c, RFX_EDEVICE, "hipMemsetAsync", e);
+    return RFX_OK;
+}
+
+static int band_check(rfx_ctx *c, int id, int row0, int rows) {
+    if (id < 0 || id >= RFX_TEX_COUNT) return fail(c, RFX_EINVAL, "bad texture id");
+    const Slot &s = c->slots[id];
+    if (rows <= 0 || row0 < s.row0 || row0 + rows > s.row0 + s.rows) return fail(c, RFX_EINVAL, "row band outside the rows this context holds");
+    return RFX_OK;
+}
+
+int rfx_upload(rfx_ctx *c, rfx_tex id, const void *host, int row0, int rows) {
+    if (!c || !host) return RFX_EINVAL;
+    int rc = band_check(c, id, row0, rows);
+    if (rc) return rc;
+    if ((rc = ensure(c, id))) return rc;
+    Slot &s = c->slots[id];
+    const size_t pitch = (size_t)s.width * s.texel;
+    HIPCHK(c, hipMemcpyAsync((char *)s.ptr + (size_t)(row0 - s.row0) * pitch, host, (size_t)rows * pitch, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller may free `host` as soon as we return
+    s.uploaded = true;
+    return RFX_OK;
+}
+
+int rfx_download(rfx_ctx *c, rfx_tex id, void *host, int row0, int rows) {
+    if (!c || !host) return RFX_EINVAL;
+    int rc = band_check(c, id, row0, rows);
+    if (rc) return rc;
+    if ((rc = ensure(c, id))) return rc;
+    Slot &s = c->slots[id];
+    const size_t pitch = (size_t)s.width * s.texel;
+    HIPCHK(c, hipMemcpyAsync(host, (char *)s.ptr + (size_t)(row0 - s.row0) * pitch, (size_t)rows * pitch, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RFX_OK;
+}
+
+int rfx_clear(rfx_ctx *c, rfx_tex id) {
+    if (!c || id < 0 || id >= RFX_TEX_COUNT) return RFX_EINVAL;
+    int rc = ensure(c, id);
+    if (rc) return rc;
+    Slot &s = c->slots[id];
+    HIPCHK(c, hipMemsetAsync(s.ptr, 0, (size_t)s.rows * s.width * s.texel, c->stream));
+    return RFX_OK;
+}
+
+void *rfx_tex_device_ptr(rfx_ctx *c, rfx_tex id) {
+    if (!c || id < 0 || id >= RFX_TEX_COUNT) return nullptr;
+    if (ensure(c, id)) return nullptr;
+    return c->slots[id].ptr;
+}
+
+int rfx_bind_external(rfx_ctx *c, rfx_tex id, void *device_ptr) {
+    if (!c || id < 0 || id >= RFX_TEX_COUNT || !device_ptr) return RFX_EINVAL;
+    Slot &s = c->slots[id];
+    if (s.owned && s.ptr) { hipSetDevice(c->device); hipFree(s.ptr); }
+    s.ptr = device_ptr;
+    s.owned = false;
+    s.uploaded = true;
+    return RFX_OK;
+}
+
+static TexView view(rfx_ctx *c, int id) {
+    TexView v;
+    v.ptr = c->slots[id].ptr; v.row0 = c->slots[id].row0; v.rows = c->slots[id].rows;
+    return v;
+}
+static TexViewW wview(rfx_ctx *c, int id) {
+    TexViewW v;
+    v.ptr = c->slots[id].ptr; v.row0 = c->slots[id].row0; v.rows = c->slots[id].rows;
+    return v;
+}
+static FrameDims dims(rfx_ctx *c) {
+    FrameDims d;
+    d.W = c->W; d.H = c->H; d.fW = (float)c->W; d.fH = (float)c->H;
+    d.halo_violations = c->halo_violations;
+    return d;
+}
+static int need(rfx_ctx *c, const int *ids, int n) {
+    for (int i = 0; i < n; i++) {
+        int rc = ensure(c, ids[i]);
+        if (rc) return rc;
+    }
+    return RFX_OK;
+}
+
+// blue_noise.glsl:9-34: one pcg4d round of the per-draw seed; the toroidal shift is pixel-independent
+static void blue_noise_shift(int index, int *sx, int *sy) {
+    if (index == 0) { *sx = 0; *sy = 0; return; }  // :38-39 texture-coordinate path == unshifted table
+    uint32_t i = (uint32_t)index;
+    uint32_t v[4] = {i, i * 15843u, i * 31u + 4566u, i * 2345u + 58585u};
+    for (int k = 0; k < 4; k++) v[k] = v[k] * 1664525u + 1013904223u;
+    v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+    for (int k = 0; k < 4; k++) v[k] ^= v[k] >> 16;
+    v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+    *sx = (int)((v[0] % 0x0fffffffu) % 128u);
+    *sy = (int)((v[1] % 0x0fffffffu) % 128u);
+}
+
+// Rows a launch produces: the tile, widened by `extra` rows on each side (clipped to what the
+// output slot holds).
+static void launch_rows(rfx_ctx *c, int out_id, int extra, int *y0, int *y1) {
+    const Slot &s = c->slots[out_id];
+    int a = c->tile_y0 - extra, b = c->tile_y0 + c->tile_rows + extra;
+    if (a < s.row0) a = s.row0;
+    if (b > s.row0 + s.rows) b = s.row0 + s.rows;
+    *y0 = a; *y1 = b;
+}
+
+int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
+    if (!c || !p) return RFX_EINVAL;
+    if (p->mode != 0) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: only mode \"ssgi\" (MODE_SSGI) is built");
+    if (p->importanceSampling) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: importanceSampling needs an env map (not built)");
+    if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: only PERSPECTIVE_CAMERA is built");
+    if (p->steps < 1 || p->refineSteps < 0) return fail(c, RFX_EINVAL, "rfx_ssgi_march: steps/refineSteps");
+    hipSetDevice(c->device);
+    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, RFX_TEX_DIRECT_LIGHT, RFX_TEX_COMPOSE, RFX_TEX_BLUE_NOISE, RFX_TEX_SSGI};
+    int rc = need(c, ids, 6);
+    if (rc) return rc;
+    if (!c->slots[RFX_TEX_DEPTH].uploaded || !c->slots[RFX_TEX_GBUFFER].uploaded || !c->slots[RFX_TEX_BLUE_NOISE].uploaded)
+        return fail(c, RFX_ESTATE, "rfx_ssgi_march: depth / gbuffer / blue-noise not uploaded");
+    K1Args A;
+    A.dims = dims(c);
+    // K2's neighbourhood clamp reads +-2 rows of K1's output: produce them redundantly in the halo
+    launch_rows(c, RFX_TEX_SSGI, c->halo < 2 ? c->halo : 2, &A.y0, &A.y1);
+    A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER); A.direct = view(c, RFX_TEX_DIRECT_LIGHT);
+    A.history = view(c, RFX_TEX_COMPOSE);
+    A.blue = c->slots[RFX_TEX_BLUE_NOISE].ptr;
+    blue_noise_shift(p->blueNoiseIndex, &A.shift_x, &A.shift_y);
+    A.out = wview(c, RFX_TEX_SSGI);
+    A.p = *p;
+    // SSGIPass.js:84-87: computed in JS doubles, then rounded to float uniforms
+    A.nearMulFar = (float)((double)p->camera.near_ * (double)p->camera.far_);
+    A.farMinusNear = (float)((double)p->camera.far_ - (double)p->camera.near_);
+    HIPCHK(c, rfx_launch_k1(A, c->stream));
+    return RFX_OK;
+}
+
+int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
+    if (!c || !p) return RFX_EINVAL;
+    if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_temporal_reproject: only PERSPECTIVE_CAMERA is built");
+    if (!((p->inputType == 0 && p->textureCount == 2) || ((p->inputType == 1 || p->inputType == 2) && p->textureCount == 1)))
+        return fail(c, RFX_EINVAL, "rfx_temporal_reproject: inputType/textureCount combination");
+    hipSetDevice(c->device);
+    const int ids[] = {RFX_TEX_SSGI, RFX_TEX_VELOCITY, RFX_TEX_DENOISE_B0, RFX_TEX_DENOISE_B1, RFX_TEX_TEMPORAL0, RFX_TEX_TEMPORAL1};
+    int rc = need(c, ids, 6);
+    if (rc) return rc;
+    if (!c->slots[RFX_TEX_VELOCITY].uploaded) return fail(c, RFX_ESTATE, "rfx_temporal_reproject: velocity not uploaded");
+    K2Args A;
+    A.dims = dims(c);
+    launch_rows(c, RFX_TEX_TEMPORAL0, 0, &A.y0, &A.y1);
+    A.ssgi = view(c, RFX_TEX_SSGI); A.velocity = view(c, RFX_TEX_VELOCITY);
+    A.hist0 = view(c, RFX_TEX_DENOISE_B0);
+    // with one texture the reference binds the same history to every index (TemporalReprojectPass.js:148-151)
+    A.hist1 = view(c, p->textureCount == 2 ? RFX_TEX_DENOISE_B1 : RFX_TEX_DENOISE_B0);
+    A.out0 = wview(c, RFX_TEX_TEMPORAL0); A.out1 = wview(c, RFX_TEX_TEMPORAL1);
+    A.p = *p;
+    // TemporalReprojectPass.js:135: invTexSize.set(1 / width, 1 / height) in doubles
+    A.invW = (float)(1.0 / (double)c->W); A.invH = (float)(1.0 / (double)c->H);
+    // prevProjectionMatrix * prevViewMatrix (reproject.frag:183), fp32, column by column like GLSL
+    const float *Pm = p->prevCamera.projectionMatrix, *Vm = p->prevCamera.matrixWorldInverse;
+    for (int col = 0; col < 4; col++)
+        for (int row = 0; row < 4; row++) {
+            volatile float acc = Pm[0 * 4 + row] * Vm[col * 4 + 0];
+            volatile float t1 = Pm[1 * 4 + row] * Vm[col * 4 + 1]; acc = acc + t1;
+            volatile float t2 = Pm[2 * 4 + row] * Vm[col * 4 + 2]; acc = acc + t2;
+            volatile float t3 = Pm[3 * 4 + row] * Vm[col * 4 + 3]; acc = acc + t3;
+            A.prevPV[col * 4 + row] = acc;
+        }
+    HIPCHK(c, rfx_launch_k2(A, c->stream));
+    return RFX_OK;
+}
+
+int rfx_poisson_denoise(rfx_ctx *c, const rfx_denoise_params *p) {
+    if (!c || !p) return RFX_EINVAL;
+    if (p->textureCount != 1 && p->textureCount != 2) return fail(c, RFX_EINVAL, "rfx_poisson_denoise: textureCount");
+    hipSetDevice(c->device);
+    const int in0 = p->inputIsTemporal ? RFX_TEX_TEMPORAL0 : (p->writeToB ? RFX_TEX_DENOISE_A0 : RFX_TEX_DENOISE_B0);
+    const int in1 = p->inputIsTemporal ? RFX_TEX_TEMPORAL1 : (p->writeToB ? RFX_TEX_DENOISE_A1 : RFX_TEX_DENOISE_B1);
+    const int out0 = p->writeToB ? RFX_TEX_DENOISE_B0 : RFX_TEX_DENOISE_A0;
+    const int out1 = p->writeToB ? RFX_TEX_DENOISE_B1 : RFX_TEX_DENOISE_A1;
+    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, RFX_TEX_BLUE_NOISE, in0, in1, out0, out1};
+    int rc = need(c, ids, 7);
+    if (rc) return rc;
+    if (!c->slots[RFX_TEX_DEPTH].uploaded || !c->slots[RFX_TEX_GBUFFER].uploaded || !c->slots[RFX_TEX_BLUE_NOISE].uploaded)
+        return fail(c, RFX_ESTATE, "rfx_poisson_denoise: depth / gbuffer / blue-noise not uploaded");
+    K3Args A;
+    A.dims = dims(c);
+    launch_rows(c, out0, 0, &A.y0, &A.y1);
+    A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER);
+    A.in0 = view(c, in0);
+    A.in1 = view(c, p->textureCount == 2 ? in1 : in0);  // `#define inputTexture2 inputTexture` (poisson_denoise.frag:30-32)
+    A.blue = c->slots[RFX_TEX_BLUE_NOISE].ptr;
+    blue_noise_shift(p->blueNoiseIndex, &A.shift_x, &A.shift_y);
+    A.out0 = wview(c, out0); A.out1 = wview(c, out1);
+    A.p = *p;
+    HIPCHK(c, rfx_launch_k3(A, c->stream));
+    return RFX_OK;
+}
+
+int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
+    if (!c || !p) return RFX_EINVAL;
+    if (p->inputType != 0) return fail(c, RFX_EUNSUPPORTED, "rfx_compose: only inputType diffuseSpecular is built");
+    if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_compose: only PERSPECTIVE_CAMERA is built");
+    hipSetDevice(c->device);
+    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, RFX_TEX_DENOISE_B0, RFX_TEX_DENOISE_B1, RFX_TEX_COMPOSE};
+    int rc = need(c, ids, 5);
+    if (rc) return rc;
+    K4Args A;
+    A.dims = dims(c);
+    launch_rows(c, RFX_TEX_COMPOSE, 0, &A.y0, &A.y1);
+    if (A.y0 < c->tile_y0) A.y0 = c->tile_y0;  // COMPOSE is held whole: write only the tile
+    if (A.y1 > c->tile_y0 + c->tile_rows) A.y1 = c->tile_y0 + c->tile_rows;
+    A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER);
+    A.gi0 = view(c, RFX_TEX_DENOISE_B0); A.gi1 = view(c, RFX_TEX_DENOISE_B1);
+    A.out = wview(c, RFX_TEX_COMPOSE);
+    A.p = *p;
+    HIPCHK(c, rfx_launch_k4(A, c->stream));
+    return RFX_OK;
+}
+
+int rfx_sync(rfx_ctx *c) {
+    if (!c) return RFX_EINVAL;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RFX_OK;
+}
+
+int rfx_time_begin(rfx_ctx *c) {
+    if (!c) return RFX_EINVAL;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    return RFX_OK;
+}
+int rfx_time_end(rfx_ctx *c, float *elapsed_ms) {
+    if (!c || !elapsed_ms) return RFX_EINVAL;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    return RFX_OK;
+}
+
+unsigned int rfx_halo_violations(rfx_ctx *c) {
+    unsigned int v = 0;
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(&v, c->halo_violations, sizeof v, hipMemcpyDeviceToHost);
+    return v;
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+// rfx_device.h — device-side building blocks shared by the four kernels (gfx950 only).
+//
+// Everything here is the GPU statement of semantics the reference's GLSL relies on:
+// texel codecs (src/gbuffer/shader/gbuffer_packing.glsl), the blue-noise RNG
+// (src/utils/shader/blue_noise.glsl), texture addressing rules (nearest / bilinear,
+// CLAMP_TO_EDGE) and the half-float rounding modes of packHalf2x16 and RGBA16F stores.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rfx.h"
+
+#define RFX_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- texture views
+// A view addresses rows [row0, row0+rows) of a W x H frame held contiguously in HBM.
+// Fetch coordinates are FRAME coordinates: CLAMP_TO_EDGE happens against the frame, then the
+// row is rebased into the held band.  A row outside the band is a halo violation: the access
+// is clamped into the band (memory-safe) and counted.
+struct TexView {
+    const void *ptr;
+    int row0, rows;
+};
+struct TexViewW {
+    void *ptr;
+    int row0, rows;
+};
+struct FrameDims {
+    int W, H;
+    float fW, fH;
+    unsigned int *halo_violations; // device counter (may be null)
+};
+
+RFX_DEV int rfx_local_row(const FrameDims &d, int row0, int rows, int y) {
+    int l = y - row0;
+    if (l < 0 || l >= rows) {
+        if (d.halo_violations) atomicAdd(d.halo_violations, 1u);
+        l = l < 0 ? 0 : rows - 1;
+    }
+    return l;
+}
+
+// nearest CLAMP_TO_EDGE index as x86 cvttss2si + clamp computes it:
+// NaN and |c| >= 2^31 give INT_MIN -> texel 0 (AMD's v_cvt_i32_f32 would saturate to size-1).
+RFX_DEV int rfx_nearest_idx(float u, float fsize, int size) {
+    float c = u * fsize;
+    int i = (c < 2147483648.0f) ? max((int)c, 0) : 0; // NaN compares false -> 0
+    return min(i, size - 1);
+}
+
+RFX_DEV size_t rfx_texel_index(const FrameDims &d, int row0, int rows, float u, float v) {
+    int x = rfx_nearest_idx(u, d.fW, d.W);
+    int y = rfx_nearest_idx(v, d.fH, d.H);
+    return (size_t)rfx_local_row(d, row0, rows, y) * d.W + x;
+}
+
+RFX_DEV float rfx_fetch_r32f(const TexView &t, const FrameDims &d, float u, float v) {
+    return ((const float *)t.ptr)[rfx_texel_index(d, t.row0, t.rows, u, v)];
+}
+RFX_DEV uint4 rfx_fetch_u4(const TexView &t, const FrameDims &d, float u, float v) {
+    return ((const uint4 *)t.ptr)[rfx_texel_index(d, t.row0, t.rows, u, v)];
+}
+RFX_DEV float4 rfx_fetch_f4(const TexView &t, const FrameDims &d, float u, float v) {
+    return ((const float4 *)t.ptr)[rfx_texel_index(d, t.row0, t.rows, u, v)];
+}
+// integer-addressed variants (pixel centres: the nearest fetch at vUv is the texel itself)
+RFX_DEV size_t rfx_xy_index(const FrameDims &d, int row0, int rows, int x, int y) {
+    x = min(max(x, 0), d.W - 1);
+    y = min(max(y, 0), d.H - 1);
+    return (size_t)rfx_local_row(d, row0, rows, y) * d.W + x;
+}
+
+// ---------------------------------------------------------------- half floats
+RFX_DEV float rfx_h2f(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+RFX_DEV uint32_t rfx_f2h_rne(float f) { return (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)f); }  // v_cvt_f16_f32, RNE
+// packHalf2x16: round-to-nearest-even
+RFX_DEV uint32_t rfx_pack_half2(float a, float b) {
+    return rfx_f2h_rne(a) | (rfx_f2h_rne(b) << 16);
+}
+RFX_DEV void rfx_unpack_half2(uint32_t u, float &a, float &b) {
+    a = rfx_h2f((unsigned short)(u & 0xffffu));
+    b = rfx_h2f((unsigned short)(u >> 16));
+}
+// RGBA16F render-target store.  RTZ = what the llvmpipe oracle does (vcvtps2ph imm 3,
+// Appendix C-3): v_cvt_pkrtz_f16_f32 truncates and saturates finite overflow at 65504.
+typedef __fp16 rfx_half2_t __attribute__((ext_vector_type(2)));
+RFX_DEV uint2 rfx_store_half4(float x, float y, float z, float w, bool rtz) {
+    uint2 r;
+    if (rtz) {
+        rfx_half2_t a = __builtin_amdgcn_cvt_pkrtz(x, y);
+        rfx_half2_t b = __builtin_amdgcn_cvt_pkrtz(z, w);
+        r.x = __builtin_bit_cast(uint32_t, a);
+        r.y = __builtin_bit_cast(uint32_t, b);
+    } else {
+        r.x = rfx_pack_half2(x, y);
+        r.y = rfx_pack_half2(z, w);
+    }
+    return r;
+}
+RFX_DEV float4 rfx_load_half4(uint2 t) {
+    float4 r;
+    rfx_unpack_half2(t.x, r.x, r.y);
+    rfx_unpack_half2(t.y, r.z, r.w);
+    return r;
+}
+
+// bilinear fetch of an RGBA16F target, CLAMP_TO_EDGE, as the llvmpipe sampler computes it:
+//   c = min(u*size, size) - 0.5;  c = max(c, 0);  i0 = floor(c);  w = c - i0;  i1 = min(i0+1, size-1)
+//   texel = lerp(wy, lerp(wx, t00, t10), lerp(wx, t01, t11)),  lerp(w,a,b) = a + w*(b-a)
+RFX_DEV void rfx_linear_coord(float u, float fsize, int size, int &i0, int &i1, float &w) {
+    float c = u * fsize;
+    c = fminf(c, fsize);
+    c = c - 0.5f;
+    c = fmaxf(c, 0.0f);
+    float fl = floorf(c);
+    i0 = (int)fl;
+    w = c - fl;
+    i1 = min(i0 + 1, size - 1);
+}
+RFX_DEV float rfx_lerp(float w, float a, float b) { return a + w * (b - a); }
+RFX_DEV float4 rfx_fetch_h4_linear(const TexView &t, const FrameDims &d, float u, float v) {
+    int x0, x1, y0, y1;
+    float wx, wy;
+    rfx_linear_coord(u, d.fW, d.W, x0, x1, wx);
+    rfx_linear_coord(v, d.fH, d.H, y0, y1, wy);
+    const uint2 *p = (const uint2 *)t.ptr;
+    size_t r0 = (size_t)rfx_local_row(d, t.row0, t.rows, y0) * d.W, r1 = (size_t)rfx_local_row(d, t.row0, t.rows, y1) * d.W;
+    float4 t00 = rfx_load_half4(p[r0 + x0]), t10 = rfx_load_half4(p[r0 + x1]);
+    float4 t01 = rfx_load_half4(p[r1 + x0]), t11 = rfx_load_half4(p[r1 + x1]);
+    float4 r;
+    r.x = rfx_lerp(wy, rfx_lerp(wx, t00.x, t10.x), rfx_lerp(wx, t01.x, t11.x));
+    r.y = rfx_lerp(wy, rfx_lerp(wx, t00.y, t10.y), rfx_lerp(wx, t01.y, t11.y));
+    r.z = rfx_lerp(wy, rfx_lerp(wx, t00.z, t10.z), rfx_lerp(wx, t01.z, t11.z));
+    r.w = rfx_lerp(wy, rfx_lerp(wx, t00.w, t10.w), rfx_lerp(wx, t01.w, t11.w));
+    return r;
+}
+
+// ---------------------------------------------------------------- float3 helpers
+RFX_DEV float3 operator+(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RFX_DEV float3 operator-(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RFX_DEV float3 operator*(float3 a, float s) { return make_float3(a.x * s, a.y * s, a.z * s); }
+RFX_DEV float3 operator-(float3 a) { return make_float3(-a.x, -a.y, -a.z); }
+RFX_DEV float rfx_dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RFX_DEV float3 rfx_cross(float3 a, float3 b) { return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RFX_DEV float3 rfx_normalize(float3 a) { return a * (1.0f / sqrtf(rfx_dot(a, a))); }
+RFX_DEV float rfx_length(float3 a) { return sqrtf(rfx_dot(a, a)); }
+RFX_DEV float rfx_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+RFX_DEV float3 rfx_mix(float3 x, float3 y, float a) { return make_float3(rfx_mix(x.x, y.x, a), rfx_mix(x.y, y.y, a), rfx_mix(x.z, y.z, a)); }
+RFX_DEV float rfx_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+RFX_DEV float rfx_lum(float3 c) { return 0.2125f * c.x + 0.7154f * c.y + 0.0721f * c.z; }
+// transcendental set: hardware v_exp/v_log/v_sin/v_cos paths (<= ~1e-6 rel. error, far inside the
+// 1e-3 parity budget; the llvmpipe oracle's own exp/log/pow are polynomial approximations too)
+RFX_DEV float rfx_exp(float x) { return __expf(x); }
+RFX_DEV float rfx_log(float x) { return __logf(x); }
+RFX_DEV float rfx_pow(float x, float y) { return __powf(x, y); }
+
+// column-major mat4 (three.js Matrix4.elements).  M * vec4(x,y,z,w)
+RFX_DEV float4 rfx_mat_mul(const float *M, float x, float y, float z, float w) {
+    float4 r;
+    r.x = ((M[0] * x + M[4] * y) + M[8] * z) + M[12] * w;
+    r.y = ((M[1] * x + M[5] * y) + M[9] * z) + M[13] * w;
+    r.z = ((M[2] * x + M[6] * y) + M[10] * z) + M[14] * w;
+    r.w = ((M[3] * x + M[7] * y) + M[11] * z) + M[15] * w;
+    return r;
+}
+// (vec4(v, w) * M).xyz
+RFX_DEV float3 rfx_vec_mul_mat(const float *M, float3 v, float w) {
+    float3 r;
+    r.x = ((v.x * M[0] + v.y * M[1]) + v.z * M[2]) + w * M[3];
+    r.y = ((v.x * M[4] + v.y * M[5]) + v.z * M[6]) + w * M[7];
+    r.z = ((v.x * M[8] + v.y * M[9]) + v.z * M[10]) + w * M[11];
+    return r;
+}
+
+// ---------------------------------------------------------------- G-buffer codec (decode side)
+struct Material {
+    float3 diffuse;
+    float3 normal;
+    float roughness, metalness;
+    float3 emissive;
+};
+// unpackNormal / decodeOctWrap, gbuffer_packing.glsl:52-63
+RFX_DEV float3 rfx_unpack_normal(uint32_t bits) {
+    float fx, fy;
+    rfx_unpack_half2(bits, fx, fy);
+    fx = fx * 2.0f - 1.0f;
+    fy = fy * 2.0f - 1.0f;
+    float3 n = make_float3(fx, fy, 1.0f - fabsf(fx) - fabsf(fy));
+    float t = fmaxf(-n.z, 0.0f);
+    n.x += n.x >= 0.0f ? -t : t;
+    n.y += n.y >= 0.0f ? -t : t;
+    return rfx_normalize(n);
+}
+// floatToVec4, gbuffer_packing.glsl:151-164 (one byte)
+RFX_DEV float rfx_byte_unorm(uint32_t b) { return fmaxf((float)b / 255.0f - 0.0001f, 0.0f); }
+// float2color .r (roughness), gbuffer_packing.glsl:24-34
+RFX_DEV float rfx_decode_roughness(uint32_t bits) {
+    float value = __uint_as_float(bits);
+    float q = value / 257.0f;
+    float cr = (value - 257.0f * floorf(q)) / 256.0f; // mod(value, 257) / 256
+    return fmaxf(cr - 0.0001f, 0.0f);
+}
+RFX_DEV float rfx_decode_metalness(uint32_t bits) {
+    float value = __uint_as_float(bits);
+    float cg = floorf(value / (257.0f * 257.0f)) / 256.0f;
+    return fmaxf(cg - 0.0001f, 0.0f);
+}
+template <bool WITH_EMISSIVE>
+RFX_DEV Material rfx_get_material(uint4 g) {
+    Material m;
+    m.diffuse = make_float3(rfx_byte_unorm(g.x & 0xffu), rfx_byte_unorm((g.x >> 8) & 0xffu), rfx_byte_unorm((g.x >> 16) & 0xffu));
+    m.normal = rfx_unpack_normal(g.y);
+    m.roughness = rfx_decode_roughness(g.z);
+    m.metalness = rfx_decode_metalness(g.z);
+    if (WITH_EMISSIVE) {
+        float ex = rfx_byte_unorm(g.w & 0xffu), ey = rfx_byte_unorm((g.w >> 8) & 0xffu), ez = rfx_byte_unorm((g.w >> 16) & 0xffu);
+        float ea = rfx_byte_unorm(g.w >> 24);
+        float sc = exp2f(ea * 255.0f - 128.0f); // decodeRGBE8 :136-141
+        m.emissive = make_float3(ex * sc, ey * sc, ez * sc);
+    } else {
+        m.emissive = make_float3(0.f, 0.f, 0.f);
+    }
+    return m;
+}
+// packTwoVec4 / unpackTwoVec4, gbuffer_packing.glsl:65-98
+RFX_DEV uint4 rfx_pack_two_vec4(float4 a, float4 b) {
+    const float o = 0.0001f;
+    return make_uint4(rfx_pack_half2(a.x + o, a.y + o), rfx_pack_half2(a.z + o, a.w + o), rfx_pack_half2(b.x + o, b.y + o),
+                      rfx_pack_half2(b.z + o, b.w + o));
+}
+RFX_DEV float4 rfx_unpack_vec4(uint32_t rg, uint32_t ba) {
+    float4 v;
+    rfx_unpack_half2(rg, v.x, v.y);
+    rfx_unpack_half2(ba, v.z, v.w);
+    const float o = 0.0001f;
+    v.x -= o; v.y -= o; v.z -= o; v.w -= o;
+    return v;
+}
+
+// ---------------------------------------------------------------- blue noise (blue_noise.glsl:9-48)
+// One pcg4d round seeded by the draw's blueNoiseIndex gives the per-draw toroidal shift; it is
+// identical for every pixel, so the host-independent part is hoisted: the kernels receive the
+// shift (sx, sy) computed once per launch by rfx_blue_noise_shift().
+RFX_DEV void rfx_pcg4d(uint32_t &x, uint32_t &y, uint32_t &z, uint32_t &w) {
+    x = x * 1664525u + 1013904223u; y = y * 1664525u + 1013904223u;
+    z = z * 1664525u + 1013904223u; w = w * 1664525u + 1013904223u;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+}
+// RGBA8 -> float as the sampler does it: float(byte) * (1/255)
+RFX_DEV float4 rfx_blue_noise(const uchar4 *table, int px, int py, int shift_x, int shift_y) {
+    int sx = (px + shift_x) & 127, sy = (py + shift_y) & 127; // (pixel + shift) % 128, operands >= 0
+    uchar4 t = table[sy * 128 + sx];
+    const float k = (float)(1.0 / 255.0);
+    return make_float4(t.x * k, t.y * k, t.z * k, t.w * k);
+}

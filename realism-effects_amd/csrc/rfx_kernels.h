@@ -1,0 +1,51 @@
+// rfx_kernels.h — launch-argument blocks and launcher prototypes of the four kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rfx_device.h"
+
+// Rows [y0, y1) of the frame are produced by a launch (the context's tile, plus whatever extra
+// rows the host asks for, e.g. K1's +-2 rows that K2's neighbourhood clamp reads).
+
+struct K1Args {
+    FrameDims dims;
+    int y0, y1;
+    TexView depth, gbuffer, direct, history;  // history = K4 output of the previous frame (RGBA32F, nearest)
+    const void *blue;
+    int shift_x, shift_y;
+    TexViewW out;  // RGBA32F holding 8 halfs
+    rfx_ssgi_params p;
+    float nearMulFar, farMinusNear;
+};
+
+struct K2Args {
+    FrameDims dims;
+    int y0, y1;
+    TexView ssgi, velocity, hist0, hist1;  // hist* = K3 target B of the previous frame (RGBA16F, linear)
+    TexViewW out0, out1;
+    rfx_temporal_params p;
+    float invW, invH;
+    float prevPV[16];  // prevProjectionMatrix * prevViewMatrix, multiplied in fp32 like the shader does per fragment
+};
+
+struct K3Args {
+    FrameDims dims;
+    int y0, y1;
+    TexView depth, gbuffer, in0, in1;
+    const void *blue;
+    int shift_x, shift_y;
+    TexViewW out0, out1;
+    rfx_denoise_params p;
+};
+
+struct K4Args {
+    FrameDims dims;
+    int y0, y1;
+    TexView depth, gbuffer, gi0, gi1;
+    TexViewW out;
+    rfx_compose_params p;
+};
+
+hipError_t rfx_launch_k1(const K1Args &, hipStream_t);
+hipError_t rfx_launch_k2(const K2Args &, hipStream_t);
+hipError_t rfx_launch_k3(const K3Args &, hipStream_t);
+hipError_t rfx_launch_k4(const K4Args &, hipStream_t);

@@ -75,7 +75,7 @@ class ComposeParams(C.Structure):
 EXPORTS = [
     "rfx_abi_version", "rfx_create", "rfx_destroy", "rfx_last_error", "rfx_set_stream", "rfx_tex_texel_bytes", "rfx_tex_held_rows",
     "rfx_upload", "rfx_download", "rfx_clear", "rfx_tex_device_ptr", "rfx_bind_external", "rfx_ssgi_march", "rfx_temporal_reproject",
-    "rfx_poisson_denoise", "rfx_compose", "rfx_sync", "rfx_time_begin", "rfx_time_end",
+    "rfx_poisson_denoise", "rfx_compose", "rfx_sync", "rfx_halo_violations", "rfx_time_begin", "rfx_time_end",
 ]
 
 _lib = None
@@ -115,6 +115,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rfx_poisson_denoise.argtypes = [vp, C.POINTER(DenoiseParams)]
     lib.rfx_compose.argtypes = [vp, C.POINTER(ComposeParams)]
     lib.rfx_sync.argtypes = [vp]
+    lib.rfx_halo_violations.argtypes = [vp]
+    lib.rfx_halo_violations.restype = C.c_uint
     lib.rfx_time_begin.argtypes = [vp]
     lib.rfx_time_end.argtypes = [vp, C.POINTER(f)]
     if lib.rfx_abi_version() != RFX_ABI_VERSION:

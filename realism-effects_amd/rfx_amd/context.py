@@ -1,0 +1,137 @@
+"""Thin object wrapper over the C ABI (include/rfx.h): one `Context` = one `rfx_ctx` =
+the device-side state of the pass chain on one GPU (or one row tile of it)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "data")
+
+
+class RfxError(RuntimeError):
+    pass
+
+
+def load_blue_noise_table() -> np.ndarray:
+    """128x128 RGBA8 table, decoded once from the reference's PNG asset, already flipY'd
+    (tools/make_blue_noise_table.py; src/utils/BlueNoiseUtils.js:9-15)."""
+    t = np.fromfile(os.path.join(DATA_DIR, "blue_noise_128_rgba8.bin"), np.uint8)
+    assert t.size == 128 * 128 * 4
+    return t.reshape(128, 128, 4)
+
+
+class Context:
+    def __init__(self, width: int, height: int, device: int = 0, tile_y0: int = 0, tile_rows: int | None = None, halo_rows: int = 0):
+        self.lib = abi.load_library()
+        self.W, self.H = int(width), int(height)
+        self.tile_y0 = int(tile_y0)
+        self.tile_rows = int(tile_rows if tile_rows is not None else height - tile_y0)
+        self.halo = int(halo_rows)
+        self._h = self.lib.rfx_create(int(device), self.W, self.H, self.tile_y0, self.tile_rows, self.halo)
+        if not self._h:
+            raise RfxError("rfx_create failed: %s" % self.lib.rfx_last_error(None).decode())
+        self.upload(abi.TEX_BLUE_NOISE, load_blue_noise_table(), 0, 128)
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.rfx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RfxError("%s failed (%d): %s" % (what, rc, self.lib.rfx_last_error(self._h).decode()))
+
+    # -- textures
+    def held_rows(self, tex: int):
+        r0, n = C.c_int(), C.c_int()
+        self._chk(self.lib.rfx_tex_held_rows(self._h, tex, C.byref(r0), C.byref(n)), "rfx_tex_held_rows")
+        return r0.value, n.value
+
+    def upload(self, tex: int, array: np.ndarray, row0: int | None = None, rows: int | None = None):
+        """Upload rows [row0, row0+rows) (FRAME rows; default = everything the context holds).
+        `array` holds exactly those rows."""
+        dtype, ch = abi.TEX_FORMAT[tex]
+        h0, hn = self.held_rows(tex)
+        row0 = h0 if row0 is None else row0
+        rows = hn if rows is None else rows
+        a = np.ascontiguousarray(array)
+        if a.dtype != dtype:
+            if a.dtype.itemsize == np.dtype(dtype).itemsize:
+                a = a.view(dtype)
+            else:
+                raise TypeError("texture %s wants %s, got %s" % (abi.TEX_NAMES[tex], np.dtype(dtype), a.dtype))
+        width = 128 if tex == abi.TEX_BLUE_NOISE else self.W
+        if a.size != rows * width * ch:
+            raise ValueError("texture %s: expected %d x %d x %d elements, got %s" % (abi.TEX_NAMES[tex], rows, width, ch, a.shape))
+        self._chk(self.lib.rfx_upload(self._h, tex, a.ctypes.data_as(C.c_void_p), row0, rows), "rfx_upload")
+
+    def download(self, tex: int, row0: int | None = None, rows: int | None = None) -> np.ndarray:
+        dtype, ch = abi.TEX_FORMAT[tex]
+        h0, hn = self.held_rows(tex)
+        row0 = h0 if row0 is None else row0
+        rows = hn if rows is None else rows
+        width = 128 if tex == abi.TEX_BLUE_NOISE else self.W
+        out = np.empty((rows, width, ch) if ch > 1 else (rows, width), dtype)
+        self._chk(self.lib.rfx_download(self._h, tex, out.ctypes.data_as(C.c_void_p), row0, rows), "rfx_download")
+        return out
+
+    def clear(self, tex: int):
+        self._chk(self.lib.rfx_clear(self._h, tex), "rfx_clear")
+
+    def device_ptr(self, tex: int) -> int:
+        p = self.lib.rfx_tex_device_ptr(self._h, tex)
+        if not p:
+            raise RfxError("rfx_tex_device_ptr: %s" % self.lib.rfx_last_error(self._h).decode())
+        return p
+
+    def bind_external(self, tex: int, device_ptr: int):
+        self._chk(self.lib.rfx_bind_external(self._h, tex, C.c_void_p(device_ptr)), "rfx_bind_external")
+
+    def set_stream(self, hip_stream: int | None):
+        self._chk(self.lib.rfx_set_stream(self._h, C.c_void_p(hip_stream or 0)), "rfx_set_stream")
+
+    def upload_frame(self, frame):
+        """Upload a dumped frame (rfx_amd.scene.Frame or any object with depth/gbuffer/velocity/direct)
+        whose planes cover the FULL frame; each slot takes the band it holds."""
+        for tex, plane in ((abi.TEX_DEPTH, frame.depth), (abi.TEX_GBUFFER, frame.gbuffer), (abi.TEX_VELOCITY, frame.velocity),
+                           (abi.TEX_DIRECT_LIGHT, frame.direct)):
+            r0, n = self.held_rows(tex)
+            self.upload(tex, plane[r0:r0 + n], r0, n)
+
+    # -- the four draws
+    def ssgi_march(self, p: abi.SsgiParams):
+        self._chk(self.lib.rfx_ssgi_march(self._h, C.byref(p)), "rfx_ssgi_march")
+
+    def temporal_reproject(self, p: abi.TemporalParams):
+        self._chk(self.lib.rfx_temporal_reproject(self._h, C.byref(p)), "rfx_temporal_reproject")
+
+    def poisson_denoise(self, p: abi.DenoiseParams):
+        self._chk(self.lib.rfx_poisson_denoise(self._h, C.byref(p)), "rfx_poisson_denoise")
+
+    def compose(self, p: abi.ComposeParams):
+        self._chk(self.lib.rfx_compose(self._h, C.byref(p)), "rfx_compose")
+
+    def sync(self):
+        self._chk(self.lib.rfx_sync(self._h), "rfx_sync")
+
+    def time_begin(self):
+        self._chk(self.lib.rfx_time_begin(self._h), "rfx_time_begin")
+
+    def time_end(self) -> float:
+        ms = C.c_float()
+        self._chk(self.lib.rfx_time_end(self._h, C.byref(ms)), "rfx_time_end")
+        return ms.value
+
+    def halo_violations(self) -> int:
+        return int(self.lib.rfx_halo_violations(self._h))

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Per-kernel timing of the HIP chain on one GPU (development helper; bench.py is the contract)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "realism-effects_amd"))
+import numpy as np
+from rfx_amd import abi
+from rfx_amd.context import Context
+from rfx_amd.scene import synthetic_frame
+
+W, H = int(sys.argv[1]), int(sys.argv[2])
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+t = time.time(); f = synthetic_frame(W, H, 1); print("scene gen %.1fs" % (time.time() - t), flush=True)
+ctx = Context(W, H)
+ctx.upload_frame(f)
+cam = abi.Camera.from_scene(f.camera); pc = abi.Camera.from_scene(f.prev_camera)
+sp = abi.SsgiParams(camera=cam, steps=20, refineSteps=5, mode=0, useDirectLight=1, rayDistance=10, thickness=10, envBlur=0.5, blueNoiseIndex=77)
+tp = abi.TemporalParams(camera=cam, prevCamera=pc, textureCount=2, inputType=0, logTransform=1, fullAccumulate=0, confidencePower=0.75,
+                        neighborhoodClampIntensity=0.5, maxBlend=1.0, keepData=1.0)
+tp.reprojectSpecular[:] = [0, 1]; tp.neighborhoodClamp[:] = [0, 1]
+dp = abi.DenoiseParams(radius=3, phi=0.5, lumaPhi=5, depthPhi=2, normalPhi=50, roughnessPhi=50, specularPhi=50, textureCount=2, blueNoiseIndex=5,
+                       inputIsTemporal=1, writeToB=0, halfStoreRTZ=1)
+dp.isTextureSpecular[:] = [0, 1]
+cp = abi.ComposeParams(camera=cam, inputType=0)
+def d0(): dp.inputIsTemporal, dp.writeToB = 1, 0; ctx.poisson_denoise(dp)
+def d1(): dp.inputIsTemporal, dp.writeToB = 0, 1; ctx.poisson_denoise(dp)
+stages = [("K1 ssgi", lambda: ctx.ssgi_march(sp), 68), ("K2 temporal", lambda: ctx.temporal_reproject(tp), 80), ("K3 pass0", d0, 68), ("K3 pass1", d1, 52),
+          ("K4 compose", lambda: ctx.compose(cp), 52)]
+# two warm frames so the history textures are populated
+for _ in range(2):
+    for _, fn, _b in stages: fn()
+ctx.sync()
+tot = 0
+for name, fn, bpp in stages:
+    ctx.time_begin()
+    for _ in range(iters): fn()
+    ms = ctx.time_end() / iters
+    gbs = bpp * W * H / (ms * 1e-3) / 1e9
+    print("%-12s %8.3f ms  %8.1f Mpix/s  algorithmic %6.1f GB/s (%.1f%% of 8 TB/s)" % (name, ms, W * H / ms / 1e3, gbs, gbs / 80), flush=True)
+    if not name.startswith("K4"): tot += ms
+print("K1+K2+2xK3: %.3f ms  -> %.1f Mpix/s; 268 B/px -> %.1f GB/s (%.1f%% of 8 TB/s)" % (tot, W * H / tot / 1e3, 268 * W * H / tot / 1e6, 268 * W * H / tot / 1e6 / 80))
+print("halo violations", ctx.halo_violations())
