@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path's headline metric on MI355X: Mpixels/s of the SSGI chain at 4K.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one frame through SSGIEffect.update(): K1 SSGI march (steps 20 / refineSteps 5) ->
+K2 temporal reprojection -> 2 x K3 Poisson denoise (denoiseIterations 1) -> K4 compose, over a
+3840x2160 synthetic G-buffer dump (seed 1234) that is ALREADY RESIDENT in HBM when the timed
+region starts.  N > 1: weak scaling — the frame is 3840 x (2160*N), rank r owns rows
+[2160 r, 2160 (r+1)) and exchanges halo rows with its neighbours over RCCL after K2 and after
+every K3 pass, plus an all-gather of the composed GI (rfx_amd/tiling.py).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (largest share of the
+step), measured live with hipEvents on the stream the kernels run on; `cpu_baseline` is the
+oracle (the C restatement, OpenMP) timed on this box's host cores on the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "realism-effects_amd"))
+
+import numpy as np  # noqa: E402
+
+from rfx_amd import abi, tiling  # noqa: E402
+from rfx_amd.context import Context  # noqa: E402
+from rfx_amd.effect import SSGIEffect  # noqa: E402
+from rfx_amd.scene import AnalyticScene  # noqa: E402
+
+W4K, H4K = 3840, 2160
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+# algorithmic bytes per pixel per launch, reference texel formats (SURVEY.md §8d / DESIGN.md)
+BYTES_PER_PX = {"k1_ssgi_march": 68, "k2_temporal_reproject": 80, "k3_poisson_denoise_pass0": 68, "k3_poisson_denoise_pass1": 52, "k4_compose": 52}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=W4K)
+    ap.add_argument("--height", type=int, default=H4K, help="rows per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame the CPU baseline processes (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W, Ht = args.width, args.height
+    H = Ht * world  # weak scaling: the frame grows with the number of GPUs
+    tiles = [(r * Ht, Ht) for r in range(world)]
+    y0, rows = tiles[rank]
+
+    # ---- synthetic dump: every rank ray-casts the band it holds (+ halo); depth is gathered whole
+    t0 = time.time()
+    scene_gen = AnalyticScene(1234)
+    opts = dict(width=W, height=H, steps=20, refineSteps=5, denoiseIterations=1)
+    # frame 1 of the orbit: non-zero velocity (camera moved 0.5 deg since frame 0)
+    probe = scene_gen.render(W, 8, 1, row0=y0 + rows // 2, rows=8, frame_height=H, vfov_rows=Ht)
+    vmax = float(np.abs(probe.velocity[..., 1].view(np.float32)).max()) * 1.5 + 1e-4
+    halo = 0 if world == 1 else tiling.required_halo(3.0, vmax, H)
+    b0, b1 = max(0, y0 - halo), min(H, y0 + rows + halo)
+    band = scene_gen.render(W, b1 - b0, 1, row0=b0, rows=b1 - b0, frame_height=H, vfov_rows=Ht)
+    log("[rank %d] dump band rows [%d,%d) of %dx%d generated in %.1fs (halo %d)" % (rank, b0, b1, W, H, time.time() - t0, halo))
+
+    ctx = Context(W, H, device=local_rank, tile_y0=y0, tile_rows=rows, halo_rows=halo)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # kernels, RCCL ops and torch's sync share one stream
+    ctx.uses_torch_stream = True
+    renderer = ctx
+    depth_full = band.depth
+    if world > 1:
+        tensors = tiling.bind_torch_buffers(ctx, dev)
+        renderer = tiling.TiledRenderer(ctx, tensors, rank, world)
+        mine = torch.from_numpy(np.ascontiguousarray(band.depth[y0 - b0:y0 - b0 + rows])).to(dev)
+        full = torch.empty((H, W), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(full, mine)
+        depth_full = full.cpu().numpy()
+    frame = types.SimpleNamespace(depth=depth_full, gbuffer=band.gbuffer, velocity=band.velocity, direct=band.direct, camera=band.camera)
+    scene = types.SimpleNamespace(frame=frame)
+    cam = band.camera
+    fx = SSGIEffect(None, scene, cam, opts, seeds=dict(ssgi=1, denoise=2), half_store_rtz=True)
+
+    def step():
+        fx.update(renderer, None)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    step()  # first frame: uploads the dump (not timed), keepData = 0
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = W * H * args.steps / dt / 1e6  # Mpixels/s, whole job
+    viol = ctx.halo_violations()
+
+    # ---- per-kernel durations (hipEvents on the kernels' stream), this rank's tile
+    sp, tp = fx.ssgiPass.uniforms, fx.denoiser.temporalReprojectPass.uniforms
+    dp, cp = fx.denoiser.denoisePass.uniforms, fx.denoiser.denoiserComposePass.uniforms
+
+    def k3(pass_i):
+        dp.inputIsTemporal, dp.writeToB = (1, 0) if pass_i == 0 else (0, 1)
+        ctx.poisson_denoise(dp)
+
+    kernels = [("k1_ssgi_march", lambda: ctx.ssgi_march(sp)), ("k2_temporal_reproject", lambda: ctx.temporal_reproject(tp)),
+               ("k3_poisson_denoise_pass0", lambda: k3(0)), ("k3_poisson_denoise_pass1", lambda: k3(1)), ("k4_compose", lambda: ctx.compose(cp))]
+    iters = max(5, min(args.steps, 20))
+    kms = {}
+    for name, fn in kernels:
+        fn()
+        ctx.time_begin()
+        for _ in range(iters):
+            fn()
+        kms[name] = ctx.time_end() / iters
+    barrier()
+
+    if rank == 0:
+        px_tile = W * rows
+        dom = max(kms, key=kms.get)
+        achieved = BYTES_PER_PX[dom] * px_tile / (kms[dom] * 1e-3) / 1e9
+        chain_bytes = sum(BYTES_PER_PX[k] for k in kms)
+        chain_ms = sum(kms.values())
+        out = {
+            "metric": "Mpixels/s SSGI+denoise @4K steps=20; achieved HBM GB/s vs peak",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: %dx%d per GPU, steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step" % (W, Ht),
+                       "frame": "%dx%d" % (W, H), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz",
+                       "parallelism": "row-tiles x%d, RCCL halo send/recv + compose all-gather" % world if world > 1 else "single GPU"},
+            "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
+            "chain": {"algorithmic_bytes_per_px": chain_bytes, "sum_kernel_ms": round(chain_ms, 4),
+                      "achieved_GBs": round(chain_bytes * px_tile / (chain_ms * 1e-3) / 1e9, 1),
+                      "frac_of_peak": round(chain_bytes * px_tile / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": BYTES_PER_PX[dom] * px_tile, "avg_launch_ms": round(kms[dom], 4)},
+            "halo_violations": viol,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(frame, fx, W, H, args.cpu_sample_rows)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def cpu_baseline(frame, fx, W, H, sample_rows):
+    """The oracle (oracle/rfx_oracle.c, kind "port": scalar C restatement, OpenMP over rows) on the
+    host cores of this box: the same chain on a bounded band of the same 4K frame."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import rfx_oracle as O
+    from rfx_amd.context import load_blue_noise_table
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    blue = load_blue_noise_table()
+    rows = sample_rows or H
+    y0 = max(0, (H - rows) // 2) & ~1
+    band = (y0, y0 + rows)
+    z16 = lambda: np.zeros((H, W, 4), np.uint16)  # noqa: E731
+    z32 = lambda: np.zeros((H, W, 4), np.float32)  # noqa: E731
+    sp, tp = fx.ssgiPass.uniforms, fx.denoiser.temporalReprojectPass.uniforms
+    dp, cp = fx.denoiser.denoisePass.uniforms, fx.denoiser.denoiserComposePass.uniforms
+    hist, ssgi, T0, T1, A0, A1, B0, B1, comp = z32(), np.zeros((H, W, 4), np.uint32), z32(), z32(), z16(), z16(), z16(), z16(), z32()
+
+    def chain():
+        O.ssgi(frame.depth, frame.gbuffer, frame.direct, hist, blue, sp, out=ssgi, rows=band)
+        O.temporal(ssgi, frame.velocity, B0, B1, tp, T0, T1, rows=band)
+        dp.inputIsTemporal, dp.writeToB = 1, 0
+        O.denoise(frame.depth, frame.gbuffer, T0, T1, blue, dp, A0, A1, rows=band)
+        dp.inputIsTemporal, dp.writeToB = 0, 1
+        O.denoise(frame.depth, frame.gbuffer, A0, A1, blue, dp, B0, B1, rows=band)
+        O.compose(frame.depth, frame.gbuffer, B0, B1, cp, out=comp, rows=band)
+
+    chain()  # warm (page faults, OpenMP team)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        chain()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or n >= 20:
+            break
+    return {"value": round(W * rows * n / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "%d x (K1+K2+2xK3+K4) over rows [%d,%d) of the same %dx%d frame, %.1f s of wall time, OMP threads=%s" % (
+                n, band[0], band[1], W, H, dt, os.environ.get("OMP_NUM_THREADS"))}
+
+
+if __name__ == "__main__":
+    main()

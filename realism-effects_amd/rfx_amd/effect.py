@@ -1,0 +1,499 @@
+"""Host-side mirror of the reference's operator interface for the hot path (Python flavour; the
+Node flavour with the same surface lives in ../js).
+
+Same class names, constructor signatures, option names, defaults and frame logic as the
+reference's JS drivers; the device work each `render()` did through
+`renderer.setRenderTarget(rt); renderer.render(scene, camera)` is one C-ABI call on a
+`Context` (librfx_hip.so).  `scene` / `camera` are plain dumped-state objects (no three.js):
+
+  camera  : rfx_amd.scene.Camera-like (projectionMatrix[Inverse], matrixWorld[Inverse], position,
+            quaternion, near, far, isPerspectiveCamera) — updated by the caller every frame
+  scene   : anything; only `scene.frame` (a dumped rfx_amd.scene.Frame) is read, by the
+            raster shims (GBufferPass / VelocityDepthNormalPass) that stand where the
+            reference rasterises
+  renderer: an rfx_amd.context.Context (the device), passed to update()/render() like
+            three's WebGLRenderer is.
+
+Reference files mirrored (file:line in each class):
+  src/ssgi/SSGIEffect.js, src/ssgi/SSGIOptions.js, src/ssgi/pass/SSGIPass.js,
+  src/denoise/Denoiser.js, src/denoise/pass/PoissonDenoisePass.js,
+  src/denoise/pass/DenoiserComposePass.js, src/temporal-reproject/TemporalReprojectPass.js,
+  src/temporal-reproject/pass/VelocityDepthNormalPass.js, src/traa/TRAAEffect.js,
+  src/utils/BlueNoiseUtils.js, src/utils/SceneUtils.js
+"""
+from __future__ import annotations
+
+import math
+import random
+
+import numpy as np
+
+from . import abi
+
+# src/ssgi/SSGIOptions.js:26-48
+defaultSSGIOptions = dict(
+    mode="ssgi", distance=10, thickness=10, denoiseIterations=1, denoiseKernel=2, denoiseDiffuse=10, denoiseSpecular=10, radius=3,
+    phi=0.5, lumaPhi=5, depthPhi=2, normalPhi=50, roughnessPhi=50, specularPhi=50, envBlur=0.5, importanceSampling=True, steps=20,
+    refineSteps=5, resolutionScale=1, missedRays=False, outputTexture=None)
+
+# src/temporal-reproject/TemporalReprojectPass.js:17-32
+defaultTemporalReprojectPassOptions = dict(
+    dilation=False, fullAccumulate=False, neighborhoodClamp=False, neighborhoodClampRadius=1, neighborhoodClampIntensity=1, maxBlend=1,
+    logTransform=False, depthDistance=2, worldDistance=4, reprojectSpecular=False, renderTarget=None, copyTextures=True,
+    confidencePower=0.75, inputType="diffuse")
+
+# src/denoise/pass/PoissonDenoisePass.js:16-24
+defaultPoissonBlurOptions = dict(iterations=1, radius=3, phi=0.5, lumaPhi=5, depthPhi=2, normalPhi=3.25, inputType="diffuseSpecular")
+
+# src/denoise/Denoiser.js:6-11
+defaultDenoiserOptions = dict(denoiseMode="full", inputType="diffuseSpecular", gBufferPass=None, velocityDepthNormalPass=None)
+
+_INPUT_TYPES = ["diffuseSpecular", "diffuse", "specular"]
+HIGHEST_SIGNED_INT = 0x7FFFFFFF
+
+
+class BlueNoiseIndex:
+    """The `blueNoiseIndex` uniform getter of src/utils/BlueNoiseUtils.js:17-33: every READ (one
+    per draw of the material) advances `(startIndex + idx + 1) % 0x7fffffff`; `startIndex` is
+    random per material unless pinned for reproducible runs."""
+
+    def __init__(self, start_index: int | None = None):
+        self.start_index = int(start_index) if start_index is not None else int(math.floor(random.random() * HIGHEST_SIGNED_INT))
+        self._idx = 0
+
+    @property
+    def value(self) -> int:
+        self._idx = (self.start_index + self._idx + 1) % HIGHEST_SIGNED_INT
+        return self._idx
+
+    @value.setter
+    def value(self, v: int):
+        self._idx = int(v)
+
+
+def didCameraMove(camera, last_position, last_quaternion) -> bool:
+    """src/utils/SceneUtils.js:17-27."""
+    p = np.asarray(camera.position, np.float64)
+    if float(((p - last_position) ** 2).sum()) > 0.000001:
+        return True
+    q = np.asarray(getattr(camera, "quaternion", (0, 0, 0, 1)), np.float64)
+    d = abs(float(np.clip(np.dot(q, last_quaternion), -1, 1)))
+    return 2 * math.acos(d) > 0.001  # Quaternion.angleTo
+
+
+def _upload_plane(renderer, tex, plane):
+    """Hand one dumped full-frame plane to the device (the slot takes the band it holds).  A plane
+    object that is already resident (same ndarray as last time) is not sent again — the dump is
+    the "render" of the raster passes, re-rendering an unchanged scene changes nothing."""
+    cache = renderer.__dict__.setdefault("_resident_planes", {})
+    if cache.get(tex) is plane:
+        return
+    r0, n = renderer.held_rows(tex)
+    if plane.shape[0] == n:  # the caller dumped exactly the band this tile holds
+        renderer.upload(tex, plane, r0, n)
+    else:
+        renderer.upload(tex, plane[r0:r0 + n], r0, n)
+    cache[tex] = plane
+
+
+class GBufferPass:
+    """Stand-in for src/gbuffer/GBufferPass.js: the rasteriser is out of scope;
+    `render` uploads the pre-dumped packed G-buffer + depth planes of `scene.frame`."""
+
+    def __init__(self, scene, camera):
+        self._scene, self._camera = scene, camera
+        self.texture, self.depthTexture = abi.TEX_GBUFFER, abi.TEX_DEPTH
+
+    def setSize(self, width, height):
+        self.width, self.height = width, height
+
+    def render(self, renderer):
+        f = self._scene.frame
+        for tex, plane in ((abi.TEX_DEPTH, f.depth), (abi.TEX_GBUFFER, f.gbuffer)):
+            _upload_plane(renderer, tex, plane)
+
+    def dispose(self):
+        pass
+
+
+class VelocityDepthNormalPass:
+    """src/temporal-reproject/pass/VelocityDepthNormalPass.js:66 — kept as a loader shim: the
+    class, its (scene, camera) signature and `texture`/`renderTarget` accessors survive, the
+    raster work is replaced by uploading the dumped RGBA32F plane (format :186-188)."""
+
+    def __init__(self, scene, camera):
+        self._scene, self._camera = scene, camera
+        self.renderTarget = self
+        self.texture = abi.TEX_VELOCITY
+        self.depthTexture = abi.TEX_VELOCITY
+        self.lastVelocityTexture = None  # declared by the reference, never read by K2 (Appendix D-6)
+
+    def setSize(self, width, height):
+        self.width, self.height = width, height
+
+    def render(self, renderer):
+        _upload_plane(renderer, abi.TEX_VELOCITY, self._scene.frame.velocity)
+
+    def dispose(self):
+        pass
+
+
+class TemporalReprojectPass:
+    """src/temporal-reproject/TemporalReprojectPass.js:38-225."""
+
+    def __init__(self, scene, camera, velocityDepthNormalPass, texture, textureCount, options=None):
+        self._scene, self._camera = scene, camera
+        self.textureCount = textureCount
+        o = dict(defaultTemporalReprojectPassOptions)
+        o.update(options or {})
+        self.options = o
+        self.velocityDepthNormalPass = velocityDepthNormalPass
+        self.frame = 0
+        self.overrideAccumulatedTextures = []
+        self.lastCameraTransform = dict(position=np.zeros(3), quaternion=np.array([0.0, 0, 0, 1]))
+        it = _INPUT_TYPES.index(o["inputType"]) if o["inputType"] in _INPUT_TYPES else 1
+        p = abi.TemporalParams(textureCount=textureCount, inputType=it, logTransform=1 if o["logTransform"] else 0,
+                               confidencePower=float(o["confidencePower"]), neighborhoodClampIntensity=float(o["neighborhoodClampIntensity"]),
+                               maxBlend=float(o["maxBlend"]), keepData=1.0)
+        for name in ("reprojectSpecular", "neighborhoodClamp"):  # :109-116 — arrays of (arrays of) bools; indices 0,1 matter
+            v = o[name]
+            v = list(v) if isinstance(v, (list, tuple)) else [v] * 2
+            getattr(p, name)[:] = [1 if x else 0 for x in (v + v)[:2]]
+        self.uniforms = p
+        # :95-104 the ctor clones the current camera state into the prev* uniforms
+        self._prev = abi.Camera.from_scene(camera)
+
+    def setSize(self, width, height):
+        self.width, self.height = width, height
+
+    @property
+    def texture(self):
+        return abi.TEX_TEMPORAL0
+
+    def reset(self):
+        self.uniforms.keepData = 0.0  # :158-160
+
+    def render(self, renderer):
+        self.frame = (self.frame + 1) % 4096
+        cam = self._camera
+        self.uniforms.camera = abi.Camera.from_scene(cam)
+        self.uniforms.prevCamera = self._prev
+        moved = didCameraMove(cam, self.lastCameraTransform["position"], self.lastCameraTransform["quaternion"])
+        self.uniforms.fullAccumulate = 1 if (self.options["fullAccumulate"] and not moved) else 0  # :178-180
+        self.lastCameraTransform["position"] = np.asarray(cam.position, np.float64).copy()
+        self.lastCameraTransform["quaternion"] = np.asarray(getattr(cam, "quaternion", (0, 0, 0, 1)), np.float64).copy()
+        renderer.temporal_reproject(self.uniforms)  # :192-193
+        self.uniforms.keepData = 1.0  # :195
+        self._prev = abi.Camera.from_scene(cam)  # :203-213
+
+    def dispose(self):
+        pass
+
+
+class PoissonDenoisePass:
+    """src/denoise/pass/PoissonDenoisePass.js:26-152."""
+
+    DefaultOptions = defaultPoissonBlurOptions
+
+    def __init__(self, camera, textures, options=None, blue_noise_start=None, half_store_rtz=True):
+        o = dict(defaultPoissonBlurOptions)
+        o.update(options or {})
+        self.iterations = defaultPoissonBlurOptions["iterations"]
+        self.textures = textures
+        spec = [0, 1]
+        if o["inputType"] == "diffuse":
+            spec = [0, 0]
+        if o["inputType"] == "specular":
+            spec = [1, 1]
+        tc = 2 if o["inputType"] == "diffuseSpecular" else 1
+        d = defaultPoissonBlurOptions
+        # :48-66 — roughnessPhi/specularPhi start `undefined` until SSGIEffect's setters write them
+        self.uniforms = abi.DenoiseParams(radius=d["radius"], phi=d["phi"], lumaPhi=d["lumaPhi"], depthPhi=float(o["depthPhi"]),
+                                          normalPhi=float(o["normalPhi"]), roughnessPhi=float("nan"), specularPhi=float("nan"),
+                                          textureCount=tc, halfStoreRTZ=1 if half_store_rtz else 0)
+        self.uniforms.isTextureSpecular[:] = spec
+        self.blueNoiseIndex = BlueNoiseIndex(blue_noise_start)
+
+    def setSize(self, width, height):
+        self.width, self.height = width, height
+
+    @property
+    def texture(self):
+        return (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1)
+
+    def render(self, renderer):
+        for i in range(2 * int(self.iterations)):  # :135-149
+            horizontal = i % 2 == 0
+            self.uniforms.inputIsTemporal = 1 if i == 0 else 0
+            self.uniforms.writeToB = 0 if horizontal else 1
+            self.uniforms.blueNoiseIndex = self.blueNoiseIndex.value
+            renderer.poisson_denoise(self.uniforms)
+            hook = getattr(renderer, "after_denoise_pass", None)
+            if hook:
+                hook(i, self.uniforms)  # multi-GPU: halo exchange of the target just written
+
+    def dispose(self):
+        pass
+
+
+class DenoiserComposePass:
+    """src/denoise/pass/DenoiserComposePass.js:8-136."""
+
+    def __init__(self, camera, textures, gBufferTexture, depthTexture, options=None):
+        self._camera = camera
+        o = options or {}
+        it = _INPUT_TYPES.index(o.get("inputType", "diffuseSpecular")) if o.get("inputType", "diffuseSpecular") in _INPUT_TYPES else 0
+        self.uniforms = abi.ComposeParams(inputType=it)
+
+    def setSize(self, width, height):
+        self.width, self.height = width, height
+
+    @property
+    def texture(self):
+        return abi.TEX_COMPOSE
+
+    def render(self, renderer):
+        self.uniforms.camera = abi.Camera.from_scene(self._camera)
+        renderer.compose(self.uniforms)
+
+    def dispose(self):
+        pass
+
+
+class Denoiser:
+    """src/denoise/Denoiser.js:16-108 — temporal + spatial + compose chain."""
+
+    def __init__(self, scene, camera, texture, options=None, blue_noise_start=None, half_store_rtz=True):
+        o = dict(defaultDenoiserOptions)
+        o.update(options or {})
+        self.options = o
+        self.velocityDepthNormalPass = o["velocityDepthNormalPass"] or VelocityDepthNormalPass(scene, camera)
+        self.isOwnVelocityDepthNormalPass = not o["velocityDepthNormalPass"]
+        textureCount = 2 if o["inputType"] == "diffuseSpecular" else 1
+        topt = dict(fullAccumulate=True, logTransform=True, copyTextures=not o.get("denoise"), reprojectSpecular=[False, True],
+                    neighborhoodClamp=[True, True], neighborhoodClampRadius=2, neighborhoodClampIntensity=0.5)
+        topt.update({k: v for k, v in o.items() if k in defaultTemporalReprojectPassOptions})
+        self.temporalReprojectPass = TemporalReprojectPass(scene, camera, self.velocityDepthNormalPass, texture, textureCount, topt)
+        self.denoisePass = None
+        self.denoiserComposePass = None
+        if o["denoiseMode"] in ("full", "denoised"):
+            popt = {k: v for k, v in o.items() if k in defaultPoissonBlurOptions}
+            self.denoisePass = PoissonDenoisePass(camera, (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1), popt, blue_noise_start, half_store_rtz)
+            self.temporalReprojectPass.overrideAccumulatedTextures = list(self.denoisePass.texture)
+        if o["denoiseMode"].startswith("full"):
+            if self.denoisePass is None:
+                raise NotImplementedError('denoiseMode "full_temporal": K2 history from a framebuffer copy is not built (Appendix D-11)')
+            self.denoiserComposePass = DenoiserComposePass(camera, self.denoisePass.texture, abi.TEX_GBUFFER, abi.TEX_DEPTH, o)
+        if o["denoiseMode"] == "temporal":
+            raise NotImplementedError('denoiseMode "temporal": framebuffer-copy history is not built (Appendix D-11)')
+
+    @property
+    def texture(self):
+        m = self.options["denoiseMode"]
+        if m in ("full", "full_temporal"):
+            return self.denoiserComposePass.texture
+        if m == "denoised":
+            return self.denoisePass.texture
+        return self.temporalReprojectPass.texture
+
+    def reset(self):
+        self.temporalReprojectPass.reset()
+
+    def setSize(self, width, height):
+        for p in (self.velocityDepthNormalPass, self.temporalReprojectPass, self.denoisePass, self.denoiserComposePass):
+            if p:
+                p.setSize(width, height)
+
+    def dispose(self):
+        pass
+
+    def render(self, renderer, inputBuffer=None):
+        if self.isOwnVelocityDepthNormalPass:
+            self.velocityDepthNormalPass.render(renderer)
+        self.temporalReprojectPass.render(renderer)
+        hook = getattr(renderer, "after_temporal_pass", None)
+        if hook:
+            hook()
+        if self.denoisePass:
+            self.denoisePass.render(renderer)
+        if self.denoiserComposePass:
+            self.denoiserComposePass.render(renderer)
+            hook = getattr(renderer, "after_compose_pass", None)
+            if hook:
+                hook()
+
+
+class SSGIPass:
+    """src/ssgi/pass/SSGIPass.js:7-96."""
+
+    def __init__(self, ssgiEffect, options, blue_noise_start=None):
+        self.ssgiEffect = ssgiEffect
+        self._scene, self._camera = ssgiEffect._scene, ssgiEffect._camera
+        self.frame = 21483
+        mode = ["ssgi", "ssr"].index(options["mode"])
+        self.uniforms = abi.SsgiParams(steps=20, refineSteps=5, mode=mode, useDirectLight=0, missedRays=0, importanceSampling=0)
+        self.blueNoiseIndex = BlueNoiseIndex(blue_noise_start)
+        self.gBufferPass = GBufferPass(self._scene, self._camera)
+
+    @property
+    def texture(self):
+        return abi.TEX_SSGI
+
+    def setSize(self, width, height):
+        if self.ssgiEffect.resolutionScale != 1:
+            raise NotImplementedError("resolutionScale != 1 (SSGIPass.js:53) is not built yet (SURVEY.md §8f-4)")
+        self.gBufferPass.setSize(width, height)
+
+    def render(self, renderer):
+        self.frame = (self.frame + 1) % 4096
+        self.gBufferPass.render(renderer)
+        self.uniforms.camera = abi.Camera.from_scene(self._camera)
+        self.uniforms.blueNoiseIndex = self.blueNoiseIndex.value
+        renderer.ssgi_march(self.uniforms)  # :93-94
+
+    def dispose(self):
+        pass
+
+
+class SSGIEffect:
+    """src/ssgi/SSGIEffect.js:27-439 — owns SSGIPass + Denoiser, reactive options."""
+
+    DefaultOptions = defaultSSGIOptions
+
+    def __init__(self, composer, scene, camera, options=None, seeds=None, half_store_rtz=True):
+        options = dict(defaultSSGIOptions, **(options or {}))
+        self._scene, self._camera, self.composer = scene, camera, composer
+        self.isUsingRenderPass = True
+        if options["mode"] == "ssr":
+            raise NotImplementedError('mode "ssr" (MODE_SSR) is not built yet (SURVEY.md §8f-2)')
+        elif options["mode"] == "ssgi":  # :74-77
+            options["reprojectSpecular"] = [False, True]
+            options["neighborhoodClamp"] = [False, True]
+        preset = options.get("preset")
+        if isinstance(preset, str):  # :79-99 (the second `case "medium"` is unreachable)
+            if preset == "low":
+                options.update(steps=10, refineSteps=2, denoiseMode="full_temporal")
+            elif preset == "medium":
+                options.update(steps=20, refineSteps=4, denoiseMode="full")
+        seeds = seeds or {}
+        self._options = options
+        self.ssgiPass = SSGIPass(self, options, seeds.get("ssgi"))
+        dopt = dict(gBufferPass=self.ssgiPass.gBufferPass, velocityDepthNormalPass=options.get("velocityDepthNormalPass"))
+        dopt.update(options)
+        self.denoiser = Denoiser(scene, camera, self.ssgiPass.texture, dopt, seeds.get("denoise"), half_store_rtz)
+        self.lastSize = dict(width=options.get("width"), height=options.get("height"), resolutionScale=options["resolutionScale"])
+        self.setSize(options.get("width"), options.get("height"))
+        self._reactive = False
+        for key in list(options.keys()):  # makeOptionsReactive :157-268 — apply every option once
+            self._apply(key, options[key])
+        self._reactive = True
+        self.outputTexture = self.denoiser.texture
+        # the composer's RenderPass has run before update(): direct light is available (:124-138,143-151)
+        self.updateUsingRenderPass()
+
+    # reactive option surface: effect.<option> reads/writes go through _apply like the JS setters
+    def __getattr__(self, key):
+        o = self.__dict__.get("_options")
+        if o is not None and key in o:
+            return o[key]
+        raise AttributeError(key)
+
+    def __setattr__(self, key, value):
+        o = self.__dict__.get("_options")
+        if o is not None and key in o and self.__dict__.get("_reactive"):
+            if o[key] == value:
+                return
+            o[key] = value
+            self._apply(key, value)
+        else:
+            object.__setattr__(self, key, value)
+
+    def _apply(self, key, value):
+        dp = self.denoiser.denoisePass
+        if key == "denoiseIterations":
+            if dp:
+                dp.iterations = value
+        elif key in ("radius", "phi", "lumaPhi", "depthPhi", "normalPhi", "roughnessPhi", "specularPhi"):
+            if dp:
+                setattr(dp.uniforms, key, float(value))
+                self.reset()
+        elif key == "resolutionScale":
+            self.setSize(self.lastSize["width"], self.lastSize["height"])
+            self.reset()
+        elif key in ("steps", "refineSteps"):
+            setattr(self.ssgiPass.uniforms, key, int(value))
+            self.reset()
+        elif key == "importanceSampling":
+            # only effective with an env map (SSGIEffect.js:344-354); no env map in the dumps -> define stays unset
+            self.reset()
+        elif key == "missedRays":
+            self.ssgiPass.uniforms.missedRays = 1 if value else 0
+            self.reset()
+        elif key == "distance":
+            self.ssgiPass.uniforms.rayDistance = float(value)
+            self.reset()
+        elif key in ("thickness", "envBlur"):  # default branch: a uniform of the same name
+            setattr(self.ssgiPass.uniforms, key, float(value))
+            self.reset()
+        # denoiseKernel / denoiseDiffuse / denoiseSpecular: accepted, no consumer (Appendix D-3)
+
+    def updateUsingRenderPass(self):
+        self.ssgiPass.uniforms.useDirectLight = 1 if self.isUsingRenderPass else 0
+
+    def reset(self):
+        self.denoiser.reset()
+
+    def setSize(self, width, height, force=False):
+        if width is None and height is None:
+            return
+        self.ssgiPass.setSize(width, height)
+        self.denoiser.setSize(width, height)
+        self.lastSize = dict(width=width, height=height, resolutionScale=self._options["resolutionScale"])
+
+    @property
+    def depthTexture(self):
+        return self.ssgiPass.gBufferPass.depthTexture
+
+    def initialize(self, renderer=None, *args):
+        pass
+
+    def dispose(self):
+        self.ssgiPass.dispose()
+        self.denoiser.dispose()
+
+    def update(self, renderer, inputBuffer=None):
+        """:372-436.  `inputBuffer` = the composer's input buffer (direct lighting) as an (H,W,4)
+        float32 array covering the frame, or None to take `scene.frame.direct`."""
+        direct = inputBuffer if inputBuffer is not None else self._scene.frame.direct
+        _upload_plane(renderer, abi.TEX_DIRECT_LIGHT, direct)
+        self.ssgiPass.render(renderer)
+        self.denoiser.render(renderer, inputBuffer)
+
+
+class TRAAEffect:
+    """src/traa/TRAAEffect.js:10-78 — option surface + K2 parameter mapping only (camera jitter
+    needs the rasteriser)."""
+
+    DefaultOptions = defaultTemporalReprojectPassOptions
+
+    def __init__(self, scene, camera, velocityDepthNormalPass, options=None):
+        self._scene, self._camera = scene, camera
+        self.velocityDepthNormalPass = velocityDepthNormalPass
+        o = dict(options or defaultTemporalReprojectPassOptions)
+        o.update(maxBlend=0.9, neighborhoodClamp=True, neighborhoodClampIntensity=1, neighborhoodClampRadius=1, logTransform=True,
+                 confidencePower=4)  # :21-31
+        self.options = dict(defaultTemporalReprojectPassOptions, **o)
+        self.temporalReprojectPass = None
+
+    def reset(self):
+        self.temporalReprojectPass.reset()
+
+    def setSize(self, width, height):
+        if self.temporalReprojectPass:
+            self.temporalReprojectPass.setSize(width, height)
+
+    def temporal_params(self):
+        """The K2 launch parameters this effect would draw with (textureCount 1, inputType DIFFUSE)."""
+        if self.temporalReprojectPass is None:
+            self.temporalReprojectPass = TemporalReprojectPass(self._scene, self._camera, self.velocityDepthNormalPass, None, 1, self.options)
+        return self.temporalReprojectPass.uniforms

@@ -269,14 +269,20 @@ class AnalyticScene:
         return t_best, mat, nrm
 
     def render(self, width: int, height: int, frame_index: int = 0, row0: int = 0, rows: int | None = None,
-               frame_height: int | None = None) -> Frame:
+               frame_height: int | None = None, vfov_rows: int | None = None) -> Frame:
         """Dump frame `frame_index`.  (row0, rows, frame_height) select a horizontal band of a
-        taller frame — used by the row-tiled multi-GPU path; default = the whole frame."""
+        taller frame — used by the row-tiled multi-GPU path; default = the whole frame.
+        `vfov_rows`: number of rows that span the nominal 40 deg vertical fov; a taller frame
+        (weak scaling: N stacked 4K tiles) widens the vertical fov instead of squeezing the
+        horizontal one."""
         fh = frame_height or height
         rows = rows if rows is not None else height
         aspect = width / fh
-        cam = Camera.orbit(frame_index, aspect)
-        prev = Camera.orbit(frame_index - 1, aspect) if frame_index > 0 else cam
+        fov = 40.0
+        if vfov_rows and vfov_rows != fh:
+            fov = min(160.0, 2.0 * math.degrees(math.atan(math.tan(math.radians(20.0)) * fh / vfov_rows)))
+        cam = Camera.orbit(frame_index, aspect, fov=fov)
+        prev = Camera.orbit(frame_index - 1, aspect, fov=fov) if frame_index > 0 else cam
         P, Pi, C, V = cam._m("projectionMatrix"), cam._m("projectionMatrixInverse"), cam._m("matrixWorld"), cam._m("matrixWorldInverse")
         Pp, Vp = prev._m("projectionMatrix"), prev._m("matrixWorldInverse")
 

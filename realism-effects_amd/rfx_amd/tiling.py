@@ -1,0 +1,136 @@
+"""Row tiling of a frame over the GPUs of one node, one process per GPU.
+
+Rank r owns frame rows [r*H/N, (r+1)*H/N).  Pixels are independent inside every kernel; the
+coupling is only through gathers from previous-stage textures, so the tile holds `halo` extra
+rows above and below and three exchange steps keep them current:
+
+  after K2 and after every K3 pass : neighbour Send/Recv of `halo` rows of the textures just
+                                     written (RCCL over xGMI; message = halo*W*texel bytes per
+                                     texture and direction — latency-bound)
+  after K4                         : all-gather of the composed GI tile rows (next frame's K1
+                                     gathers it anywhere on screen)
+
+K1 needs no exchange: it recomputes the +-2 rows K2's neighbourhood clamp reads, from the
+read-only dump planes every rank holds for its band, and reads depth / last frame's composed GI
+whole-frame.  The tiled result is bit-identical to the single-GPU result as long as the halo
+covers the gather footprints: `required_halo()`.
+
+The exchanger is written against torch tensors so the same code runs over RCCL on device
+memory (the rfx contexts' buffers, bound with rfx_bind_external) and over gloo on CPU tensors
+(tests/test_tiling_gloo.py).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import abi
+
+EXCHANGED = (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1, abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1)
+
+
+def split_rows(height: int, world: int):
+    """Even split; tile boundaries on EVEN rows so the 2x2 derivative quads never straddle tiles."""
+    base = (height // world) & ~1
+    starts = [r * base for r in range(world)]
+    rows = [base] * world
+    rows[-1] = height - starts[-1]
+    return list(zip(starts, rows))
+
+
+def required_halo(radius: float, max_abs_velocity_y: float, frame_height: int) -> int:
+    """Rows of halo that make the tiled result exact:
+       K3: taps within radius*flatness <= radius px, +1 for the bilinear footprint, +1 for rounding
+       K2: history bicubic at vUv - velocity: |v_y|*H rows + 2 texels of Catmull-Rom + 1 bilinear;
+           K1 output neighbourhood +-2 rows (recomputed locally)."""
+    k3 = int(math.ceil(radius)) + 2
+    k2 = int(math.ceil(abs(max_abs_velocity_y) * frame_height)) + 4
+    return max(k3, k2, 2)
+
+
+class TiledRenderer:
+    """Wraps the per-tile renderer (an rfx Context, or the oracle double in tests) and performs the
+    exchange steps through torch.distributed.  `tensors[tex]` is a torch tensor over the rows the
+    tile holds of that texture (first dim = held rows)."""
+
+    def __init__(self, inner, tensors: dict, rank: int, world: int, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.inner, self.tensors, self.rank, self.world, self.group = inner, tensors, rank, world, group
+        self.W, self.H = inner.W, inner.H
+        self.tile_y0, self.tile_rows, self.halo = inner.tile_y0, inner.tile_rows, inner.halo
+        self.exchange_count = 0
+
+    def __getattr__(self, name):  # everything else (upload, the four draws, ...) goes to the tile's renderer
+        return getattr(self.inner, name)
+
+    # ---- hooks called by rfx_amd.effect
+    def after_temporal_pass(self):
+        self.exchange((abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1))
+
+    def after_denoise_pass(self, i, uniforms):
+        self.exchange((abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1) if uniforms.writeToB else (abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1))
+
+    def after_compose_pass(self):
+        self.allgather_compose()
+
+    # ---- halo Send/Recv with the row neighbours
+    def exchange(self, texs):
+        if self.world == 1 or self.halo == 0:
+            return
+        dist = self._dist
+        ops = []
+        up, down = self.rank + 1, self.rank - 1  # up = higher frame rows
+        for tex in texs:
+            t = self.tensors[tex]
+            b0, _ = self.inner.held_rows(tex)
+            lo = self.tile_y0 - b0  # first tile row inside the held band
+            hi = lo + self.tile_rows
+            h = self.halo
+            if up < self.world:
+                ops.append(dist.P2POp(dist.isend, t[hi - h:hi], up, self.group))
+                ops.append(dist.P2POp(dist.irecv, t[hi:hi + h], up, self.group))
+            if down >= 0:
+                ops.append(dist.P2POp(dist.isend, t[lo:lo + h], down, self.group))
+                ops.append(dist.P2POp(dist.irecv, t[lo - h:lo], down, self.group))
+        self._sync_before_comm()
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        self.exchange_count += 1
+
+    def allgather_compose(self):
+        if self.world == 1:
+            return
+        dist = self._dist
+        full = self.tensors[abi.TEX_COMPOSE]  # whole frame
+        mine = full[self.tile_y0:self.tile_y0 + self.tile_rows]
+        self._sync_before_comm()
+        parts = [full[y0:y0 + n] for (y0, n) in split_rows(self.H, self.world)]
+        if all(p.shape == mine.shape for p in parts) and full.is_cuda:
+            dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group)
+        else:  # ragged last tile, or a backend without all_gather_into_tensor: one broadcast per owner
+            for r, p in enumerate(parts):
+                dist.broadcast(p, src=r, group=self.group)
+
+    def _sync_before_comm(self):
+        # kernels run on the context's stream; when that is torch's current stream (bench.py binds it)
+        # the collectives are ordered after them automatically.  A context on its own stream syncs here.
+        if getattr(self.inner, "uses_torch_stream", True):
+            return
+        self.inner.sync()
+
+
+def bind_torch_buffers(ctx, device):
+    """Allocate the exchanged textures as torch tensors on `device` and bind them into the rfx
+    context (rfx_bind_external), so torch.distributed can send/receive their rows in place."""
+    import torch
+    tensors = {}
+    for tex in EXCHANGED + (abi.TEX_COMPOSE,):
+        r0, n = ctx.held_rows(tex)
+        dtype, ch = abi.TEX_FORMAT[tex]
+        nbytes = np.dtype(dtype).itemsize * ch * ctx.W
+        t = torch.zeros((n, nbytes), dtype=torch.uint8, device=device)
+        ctx.bind_external(tex, t.data_ptr())
+        tensors[tex] = t
+    return tensors

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own GLSL on CPU llvmpipe.
+
+Build-container only: needs /root/reference (the shaders are read from there at run time and are
+never copied into this repository) and Mesa's swrast_dri.so.  Usage:
+
+    make -C oracle && python tests/golden/make_golden.py
+
+Each .npz holds, for a short frame sequence of the synthetic dump (seed 1234), the INPUT planes
+and the render target of every pass (K1 ssgi, K2 temporal x2, K3 A/B x2, K4 compose) as produced
+by oracle/glref/chain.py — i.e. by src/ssgi/shader/ssgi.frag,
+src/temporal-reproject/shader/temporal_reproject.frag, src/denoise/shader/poisson_denoise.frag and
+the DenoiserComposePass shader, unmodified, under the uniform values of the reference's JS drivers.
+The blue-noise indices follow src/utils/BlueNoiseUtils.js:24-32 from pinned start indices.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, os.path.join(ROOT, "realism-effects_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "glref"))
+
+from rfx_amd.scene import synthetic_frame  # noqa: E402  (input generator only)
+import chain  # noqa: E402
+
+M = 0x7FFFFFFF
+
+
+def cam_arrays(cam, prefix):
+    return {prefix + k: np.asarray(getattr(cam, k)) for k in
+            ("projectionMatrix", "projectionMatrixInverse", "matrixWorld", "matrixWorldInverse", "position", "quaternion")}
+
+
+def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_start=2000):
+    bn = np.fromfile(os.path.join(ROOT, "realism-effects_amd", "data", "blue_noise_128_rgba8.bin"), np.uint8).reshape(128, 128, 4)
+    c = chain.GLRefChain(W, H, bn, steps=steps, refineSteps=refine, denoiseIterations=iterations)
+    out = dict(width=W, height=H, frames=frames, steps=steps, refineSteps=refine, denoiseIterations=iterations, ssgi_start=ssgi_start,
+               denoise_start=denoise_start, gl_info=chain.GL.info())
+    si = di = 0
+    for fi in range(frames):
+        f = synthetic_frame(W, H, fi)
+        c.upload_frame(f)
+        k = "f%d_" % fi
+        out[k + "depth"], out[k + "gbuffer"], out[k + "velocity"], out[k + "direct"] = f.depth, f.gbuffer, f.velocity, f.direct
+        out.update(cam_arrays(f.camera, k + "cam_"))
+        out[k + "near"], out[k + "far"] = f.camera.near, f.camera.far
+        si = (ssgi_start + si + 1) % M
+        c.ssgi(f.camera, si)
+        out[k + "ssgi"] = c.t_ssgi.read().view(np.uint32)
+        out[k + "ssgi_index"] = si
+        c.temporal(f.camera, camera_moved=True)
+        out[k + "temporal0"], out[k + "temporal1"] = c.t_temporal[0].read(), c.t_temporal[1].read()
+        idx = []
+        for _ in range(2 * iterations):
+            di = (denoise_start + di + 1) % M
+            idx.append(di)
+        c.denoise(f.camera, idx)
+        out[k + "denoise_index"] = np.array(idx, np.int64)
+        for j in range(2):
+            # RGBA16F targets read back as float32 are exactly representable in half
+            out[k + "A%d" % j] = c.t_A[j].read().astype(np.float16).view(np.uint16)
+            out[k + "B%d" % j] = c.t_B[j].read().astype(np.float16).view(np.uint16)
+        c.compose(f.camera)
+        out[k + "compose"] = c.t_compose.read()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    run("chain_160x90_s20r5_it1", 160, 90, frames=3, steps=20, refine=5, iterations=1)
+    run("chain_97x55_s8r2_it2", 97, 55, frames=2, steps=8, refine=2, iterations=2)

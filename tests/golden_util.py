@@ -1,0 +1,27 @@
+"""Helpers to read tests/golden/*.npz (reference GLSL on llvmpipe, see make_golden.py)."""
+import os
+import types
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDENS = ["chain_160x90_s20r5_it1", "chain_97x55_s8r2_it2"]
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+
+
+def camera(g, fi):
+    k = "f%d_cam_" % fi
+    return types.SimpleNamespace(projectionMatrix=g[k + "projectionMatrix"], projectionMatrixInverse=g[k + "projectionMatrixInverse"],
+                                 matrixWorld=g[k + "matrixWorld"], matrixWorldInverse=g[k + "matrixWorldInverse"], position=g[k + "position"],
+                                 quaternion=g[k + "quaternion"], near=float(g["f%d_near" % fi]), far=float(g["f%d_far" % fi]),
+                                 isPerspectiveCamera=True)
+
+
+def frame(g, fi):
+    k = "f%d_" % fi
+    return types.SimpleNamespace(depth=np.ascontiguousarray(g[k + "depth"]), gbuffer=np.ascontiguousarray(g[k + "gbuffer"]),
+                                 velocity=np.ascontiguousarray(g[k + "velocity"]), direct=np.ascontiguousarray(g[k + "direct"]),
+                                 camera=camera(g, fi), width=int(g["width"]), height=int(g["height"]))

@@ -1,0 +1,95 @@
+"""Test double: the `Context` interface (rfx_amd.context.Context) implemented on the CPU oracle.
+
+TESTS ONLY.  It lets the host-side logic (rfx_amd.effect: option plumbing, ping-pong, history
+wiring, blue-noise recurrence, keepData, tiling/halo hooks) be exercised without a GPU, and it is
+the checker the -m gpu tests compare the HIP path against.  It is never importable from the
+product package."""
+import numpy as np
+
+import rfx_oracle as O
+from rfx_amd import abi
+from rfx_amd.context import load_blue_noise_table
+
+
+class OracleRenderer:
+    def __init__(self, width, height, tile_y0=0, tile_rows=None, halo_rows=0):
+        self.W, self.H = width, height
+        self.tile_y0 = tile_y0
+        self.tile_rows = tile_rows if tile_rows is not None else height - tile_y0
+        self.halo = halo_rows
+        self.tex = {}
+        for t, (dtype, ch) in abi.TEX_FORMAT.items():
+            if t == abi.TEX_BLUE_NOISE:
+                self.tex[t] = load_blue_noise_table().copy()
+            else:
+                # the oracle addresses FULL frames; rows outside the held band simply stay zero
+                self.tex[t] = np.zeros((height, width, ch) if ch > 1 else (height, width), dtype)
+        self.calls = []
+
+    def held_rows(self, tex):
+        if tex in (abi.TEX_DEPTH, abi.TEX_COMPOSE):
+            return 0, self.H
+        if tex == abi.TEX_BLUE_NOISE:
+            return 0, 128
+        b0 = max(0, self.tile_y0 - self.halo)
+        b1 = min(self.H, self.tile_y0 + self.tile_rows + self.halo)
+        return b0, b1 - b0
+
+    def upload(self, tex, array, row0=None, rows=None):
+        h0, hn = self.held_rows(tex)
+        row0 = h0 if row0 is None else row0
+        rows = hn if rows is None else rows
+        assert h0 <= row0 and row0 + rows <= h0 + hn, "band outside held rows"
+        dtype, ch = abi.TEX_FORMAT[tex]
+        a = np.ascontiguousarray(array)
+        if a.dtype != dtype:
+            a = a.view(dtype)
+        self.tex[tex][row0:row0 + rows] = a.reshape(self.tex[tex][row0:row0 + rows].shape)
+
+    def download(self, tex, row0=None, rows=None):
+        h0, hn = self.held_rows(tex)
+        row0 = h0 if row0 is None else row0
+        rows = hn if rows is None else rows
+        return self.tex[tex][row0:row0 + rows].copy()
+
+    def _rows(self, extra=0):
+        b0, n = self.held_rows(abi.TEX_SSGI)
+        return max(b0, self.tile_y0 - extra), min(b0 + n, self.tile_y0 + self.tile_rows + extra)
+
+    def ssgi_march(self, p):
+        self.calls.append(("ssgi", p.blueNoiseIndex))
+        t = self.tex
+        O.ssgi(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[abi.TEX_DIRECT_LIGHT], t[abi.TEX_COMPOSE], t[abi.TEX_BLUE_NOISE], p,
+               out=t[abi.TEX_SSGI], rows=self._rows(min(2, self.halo)))
+
+    def temporal_reproject(self, p):
+        self.calls.append(("temporal", p.keepData, p.fullAccumulate))
+        t = self.tex
+        h1 = t[abi.TEX_DENOISE_B1] if p.textureCount == 2 else t[abi.TEX_DENOISE_B0]
+        O.temporal(t[abi.TEX_SSGI], t[abi.TEX_VELOCITY], t[abi.TEX_DENOISE_B0], h1, p, t[abi.TEX_TEMPORAL0], t[abi.TEX_TEMPORAL1],
+                   rows=self._rows())
+
+    def poisson_denoise(self, p):
+        self.calls.append(("denoise", p.blueNoiseIndex, p.inputIsTemporal, p.writeToB))
+        t = self.tex
+        if p.inputIsTemporal:
+            i0, i1 = t[abi.TEX_TEMPORAL0], t[abi.TEX_TEMPORAL1]
+        elif p.writeToB:
+            i0, i1 = t[abi.TEX_DENOISE_A0], t[abi.TEX_DENOISE_A1]
+        else:
+            i0, i1 = t[abi.TEX_DENOISE_B0], t[abi.TEX_DENOISE_B1]
+        o0, o1 = (t[abi.TEX_DENOISE_B0], t[abi.TEX_DENOISE_B1]) if p.writeToB else (t[abi.TEX_DENOISE_A0], t[abi.TEX_DENOISE_A1])
+        if p.textureCount == 1:
+            i1 = i0
+        O.denoise(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], i0, i1, t[abi.TEX_BLUE_NOISE], p, o0, o1, rows=self._rows())
+
+    def compose(self, p):
+        self.calls.append(("compose",))
+        t = self.tex
+        O.compose(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[abi.TEX_DENOISE_B0], t[abi.TEX_DENOISE_B1], p, out=t[abi.TEX_COMPOSE], rows=self._rows())
+
+    def sync(self):
+        pass
+
+    def halo_violations(self):
+        return 0

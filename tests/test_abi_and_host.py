@@ -1,0 +1,171 @@
+"""CPU (-m "not gpu"): the C-ABI library loads and exports every symbol include/rfx.h declares,
+struct layouts agree between the header and the ctypes mirror, and the host-side mirror of the
+reference's JS drivers behaves like the JS (option surface, blue-noise recurrence, keepData,
+ping-pong order).  No compute calls: there is no GPU here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import types
+
+import numpy as np
+import pytest
+
+from rfx_amd import abi, effect
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "rfx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rfx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = abi.load_library()
+    declared = header_functions()
+    assert set(declared) == set(abi.EXPORTS), (sorted(set(declared) ^ set(abi.EXPORTS)))
+    for name in declared:
+        assert hasattr(lib, name), "librfx_hip.so does not export %s" % name
+    assert lib.rfx_abi_version() == abi.RFX_ABI_VERSION
+
+
+def test_no_gpu_fails_loudly_not_silently():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rfx_amd.context import Context, RfxError
+    with pytest.raises(RfxError, match="no such HIP device|no ROCm"):
+        Context(64, 64)
+
+
+def test_struct_sizes_match_header(tmp_path):
+    """Compile a tiny C program against include/rfx.h and compare sizeof/offsetof with ctypes."""
+    c = tmp_path / "sz.c"
+    c.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rfx.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %d\\n",'
+                 "sizeof(rfx_camera),sizeof(rfx_ssgi_params),sizeof(rfx_temporal_params),sizeof(rfx_denoise_params),sizeof(rfx_compose_params),"
+                 "offsetof(rfx_ssgi_params,blueNoiseIndex),offsetof(rfx_temporal_params,keepData),offsetof(rfx_denoise_params,halfStoreRTZ),"
+                 "(int)RFX_TEX_COUNT);return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(abi.Camera), C.sizeof(abi.SsgiParams), C.sizeof(abi.TemporalParams), C.sizeof(abi.DenoiseParams), C.sizeof(abi.ComposeParams),
+            abi.SsgiParams.blueNoiseIndex.offset, abi.TemporalParams.keepData.offset, abi.DenoiseParams.halfStoreRTZ.offset, abi.TEX_COUNT]
+    assert got == want
+
+
+def test_texel_bytes():
+    lib = abi.load_library()
+    for tex, (dtype, ch) in abi.TEX_FORMAT.items():
+        assert lib.rfx_tex_texel_bytes(tex) == np.dtype(dtype).itemsize * ch
+
+
+def test_blue_noise_index_recurrence():
+    """src/utils/BlueNoiseUtils.js:24-32."""
+    b = effect.BlueNoiseIndex(start_index=123456)
+    seq = [b.value for _ in range(4)]
+    want, idx = [], 0
+    for _ in range(4):
+        idx = (123456 + idx + 1) % 0x7FFFFFFF
+        want.append(idx)
+    assert seq == want
+    b2 = effect.BlueNoiseIndex(start_index=0x7FFFFFF0)
+    assert all(0 <= b2.value < 0x7FFFFFFF for _ in range(50))
+
+
+class RecordingRenderer:
+    """records the C-ABI call sequence the host mirror issues"""
+
+    def __init__(self, W, H):
+        self.W, self.H, self.calls = W, H, []
+
+    def held_rows(self, tex):
+        return (0, 128) if tex == abi.TEX_BLUE_NOISE else (0, self.H)
+
+    def upload(self, tex, a, row0=None, rows=None):
+        self.calls.append(("upload", tex))
+
+    def ssgi_march(self, p):
+        self.calls.append(("ssgi", p.steps, p.refineSteps, p.useDirectLight, p.rayDistance, p.thickness, p.blueNoiseIndex))
+
+    def temporal_reproject(self, p):
+        self.calls.append(("temporal", p.keepData, p.fullAccumulate, p.textureCount, p.inputType, list(p.reprojectSpecular), p.logTransform,
+                           round(p.confidencePower, 5), p.neighborhoodClampIntensity, p.maxBlend))
+
+    def poisson_denoise(self, p):
+        self.calls.append(("denoise", p.inputIsTemporal, p.writeToB, p.radius, p.normalPhi, p.roughnessPhi, p.specularPhi, list(p.isTextureSpecular)))
+
+    def compose(self, p):
+        self.calls.append(("compose", p.inputType))
+
+
+def _scene(W=32, H=16):
+    from rfx_amd.scene import synthetic_frame
+    f = synthetic_frame(W, H, 0)
+    return types.SimpleNamespace(frame=f), f.camera
+
+
+def test_ssgi_effect_call_sequence_and_defaults():
+    scene, cam = _scene()
+    fx = effect.SSGIEffect(None, scene, cam, dict(width=32, height=16), seeds=dict(ssgi=10, denoise=20))
+    assert effect.SSGIEffect.DefaultOptions["normalPhi"] == 50 and fx.steps == 20 and fx.refineSteps == 5
+    r = RecordingRenderer(32, 16)
+    fx.update(r, None)
+    kinds = [c[0] for c in r.calls if c[0] != "upload"]
+    assert kinds == ["ssgi", "temporal", "denoise", "denoise", "compose"]  # SSGIEffect.js:398-400, Denoiser.js:97-107
+    ssgi = [c for c in r.calls if c[0] == "ssgi"][0]
+    assert ssgi[1:6] == (20, 5, 1, 10.0, 10.0)
+    t = [c for c in r.calls if c[0] == "temporal"][0]
+    # keepData 0 on the first frame (the ctor's setters call reset()), fullAccumulate false because the camera "moved" from the origin
+    assert t[1] == 0.0 and t[2] == 0 and t[3:] == (2, 0, [0, 1], 1, 0.75, 0.5, 1.0)
+    d = [c for c in r.calls if c[0] == "denoise"]
+    assert [(x[1], x[2]) for x in d] == [(1, 0), (0, 1)]  # pass 0: temporal -> A, pass 1: A -> B  (PoissonDenoisePass.js:135-149)
+    assert d[0][3:] == (3.0, 50.0, 50.0, 50.0, [0, 1])
+    # second frame, camera unchanged: keepData 1, fullAccumulate = option(true in Denoiser.js:32) && !moved
+    r.calls.clear()
+    fx.update(r, None)
+    t = [c for c in r.calls if c[0] == "temporal"][0]
+    assert t[1] == 1.0 and t[2] == 1
+    # planes already resident: nothing is uploaded again
+    assert not [c for c in r.calls if c[0] == "upload"]
+
+
+def test_reactive_options_reset_and_iterations():
+    scene, cam = _scene()
+    fx = effect.SSGIEffect(None, scene, cam, dict(width=32, height=16))
+    r = RecordingRenderer(32, 16)
+    fx.update(r, None)
+    fx.radius = 5  # SSGIEffect.js:179-190: uniform write + reset()
+    fx.denoiseIterations = 2
+    fx.steps = "8"  # parseInt
+    fx.denoiseKernel = 3  # accepted, no consumer (Appendix D-3)
+    r.calls.clear()
+    fx.update(r, None)
+    kinds = [c[0] for c in r.calls if c[0] != "upload"]
+    assert kinds == ["ssgi", "temporal"] + ["denoise"] * 4 + ["compose"]
+    assert [c for c in r.calls if c[0] == "temporal"][0][1] == 0.0  # reset() -> keepData 0 for one frame
+    assert [c for c in r.calls if c[0] == "ssgi"][0][1] == 8
+    d = [c for c in r.calls if c[0] == "denoise"]
+    assert [(x[1], x[2]) for x in d] == [(1, 0), (0, 1), (0, 0), (0, 1)] and d[0][3] == 5.0
+
+
+def test_presets_and_unsupported_modes():
+    scene, cam = _scene()
+    fx = effect.SSGIEffect(None, scene, cam, dict(preset="medium", width=32, height=16))
+    assert (fx.steps, fx.refineSteps) == (20, 4)
+    with pytest.raises(NotImplementedError):
+        effect.SSGIEffect(None, scene, cam, dict(mode="ssr"))
+    with pytest.raises(NotImplementedError):
+        effect.SSGIEffect(None, scene, cam, dict(preset="low"))  # denoiseMode full_temporal: framebuffer-copy history
+
+
+def test_traa_option_mapping():
+    scene, cam = _scene()
+    v = effect.VelocityDepthNormalPass(scene, cam)
+    fx = effect.TRAAEffect(scene, cam, v, dict(fullAccumulate=True, maxBlend=0.5))
+    p = fx.temporal_params()
+    # TRAAEffect.js:21-31 overrides user options
+    assert (p.textureCount, p.inputType, p.logTransform) == (1, 1, 1)
+    assert abs(p.maxBlend - 0.9) < 1e-7 and p.confidencePower == 4.0 and p.neighborhoodClampIntensity == 1.0
+    assert effect.TRAAEffect.DefaultOptions["confidencePower"] == 0.75

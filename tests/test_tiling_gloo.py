@@ -1,0 +1,91 @@
+"""CPU, world_size 2 over gloo: the row-tiled chain (halo Send/Recv after K2 and every K3 pass,
+all-gather of the composed GI) must be BIT-IDENTICAL to the single-tile chain.  The per-tile
+compute is the oracle double (tests only); the exchange code is the product's (rfx_amd.tiling)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+W, H, FRAMES = 96, 64, 2
+
+
+def _chain(renderer, scene, cam, frames):
+    from rfx_amd.effect import SSGIEffect
+    fx = SSGIEffect(None, scene, cam, dict(width=W, height=H, denoiseIterations=1), seeds=dict(ssgi=5, denoise=9))
+    for f in frames:
+        scene.frame = f
+        for k, v in vars(f.camera).items():
+            setattr(cam, k, v)
+        fx.update(renderer, None)
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, HERE)
+    import conftest  # noqa: F401  (sys.path setup)
+    from oracle_renderer import OracleRenderer
+    from rfx_amd import abi, tiling
+    from rfx_amd.scene import synthetic_frame
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
+    vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
+    halo = tiling.required_halo(3.0, vmax, H)
+    y0, rows = tiling.split_rows(H, world)[rank]
+    inner = OracleRenderer(W, H, y0, rows, halo)
+    tensors = {}
+    for tex in tiling.EXCHANGED + (abi.TEX_COMPOSE,):
+        b0, n = inner.held_rows(tex)
+        tensors[tex] = torch.from_numpy(inner.tex[tex][b0:b0 + n])  # shares memory with the renderer's planes
+    r = tiling.TiledRenderer(inner, tensors, rank, world)
+    scene = types.SimpleNamespace(frame=None)
+    _chain(r, scene, frames[0].camera, frames)
+    assert r.exchange_count == FRAMES * 3  # after K2, after K3 pass 0, after K3 pass 1
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), y0=y0, rows=rows, halo=halo,
+             **{abi.TEX_NAMES[t]: inner.tex[t][y0:y0 + rows] for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0,
+                                                                     abi.TEX_DENOISE_B1)},
+             compose_full=inner.tex[abi.TEX_COMPOSE])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_tiled_chain_is_bit_identical(tmp_path):
+    import socket
+    from oracle_renderer import OracleRenderer
+    from rfx_amd import abi
+    from rfx_amd.scene import synthetic_frame
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+
+    frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
+    ref = OracleRenderer(W, H)
+    _chain(ref, types.SimpleNamespace(frame=None), frames[0].camera, frames)
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        y0, rows = int(z["y0"]), int(z["rows"])
+        for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1):
+            assert np.array_equal(z[abi.TEX_NAMES[t]], ref.tex[t][y0:y0 + rows]), "rank %d %s differs" % (rank, abi.TEX_NAMES[t])
+        # every rank ends with the WHOLE composed frame (next frame's K1 gathers it anywhere)
+        assert np.array_equal(z["compose_full"], ref.tex[abi.TEX_COMPOSE]), "rank %d compose differs" % rank
+
+
+def test_split_rows_even_boundaries_and_halo():
+    from rfx_amd import tiling
+    for Hh, n in ((2160, 8), (2160, 4), (1080, 8), (90, 4), (4320, 8)):
+        tiles = tiling.split_rows(Hh, n)
+        assert sum(r for _, r in tiles) == Hh and all(y % 2 == 0 for y, _ in tiles)
+        assert tiles[0][0] == 0 and all(tiles[i][0] + tiles[i][1] == tiles[i + 1][0] for i in range(n - 1))
+    assert tiling.required_halo(3.0, 0.0, 2160) == 5
+    assert tiling.required_halo(3.0, 0.005, 2160) == 15
