@@ -138,6 +138,8 @@ int rfx_abi_version(void);
 rfx_ctx *rfx_create(int device, int width, int height, int tile_y0, int tile_rows, int halo_rows);
 void rfx_destroy(rfx_ctx *);
 const char *rfx_last_error(const rfx_ctx *);
+/* Geometry the context was created with (any out pointer may be NULL). */
+int rfx_get_geometry(const rfx_ctx *, int *width, int *height, int *tile_y0, int *tile_rows, int *halo_rows);
 /* Run the context's kernels on a caller-provided hipStream_t (e.g. the framework's current
  * stream); NULL restores the context's own stream. */
 int rfx_set_stream(rfx_ctx *, void *hip_stream);

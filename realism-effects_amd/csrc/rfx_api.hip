@@ -111,6 +111,16 @@ void rfx_destroy(rfx_ctx *c) {
 
 const char *rfx_last_error(const rfx_ctx *c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
+int rfx_get_geometry(const rfx_ctx *c, int *width, int *height, int *tile_y0, int *tile_rows, int *halo_rows) {
+    if (!c) return RFX_EINVAL;
+    if (width) *width = c->W;
+    if (height) *height = c->H;
+    if (tile_y0) *tile_y0 = c->tile_y0;
+    if (tile_rows) *tile_rows = c->tile_rows;
+    if (halo_rows) *halo_rows = c->halo;
+    return RFX_OK;
+}
+
 int rfx_set_stream(rfx_ctx *c, void *hip_stream) {
     if (!c) return RFX_EINVAL;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;

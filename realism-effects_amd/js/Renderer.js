@@ -1,0 +1,132 @@
+"use strict"
+// Renderer — the device.  Stands where three's WebGLRenderer stands in the reference's
+// `pass.render(renderer)` calls: one Renderer = one rfx context (librfx_hip.so) on one GPU, or on one
+// row tile of the frame (tileY0 / tileRows / haloRows).  Thin wrapper over the N-API addon
+// (../napi/rfx_napi.node); there is NO software fallback: loading fails if the addon or the HIP
+// library is missing, and creation fails without an MI355X.
+const fs = require("fs")
+const path = require("path")
+const addon = require("../napi/rfx_napi.node")
+
+// texture slots — include/rfx.h `rfx_tex`
+const TEX = {
+	DEPTH: 0,
+	GBUFFER: 1,
+	VELOCITY: 2,
+	DIRECT_LIGHT: 3,
+	BLUE_NOISE: 4,
+	SSGI: 5,
+	TEMPORAL0: 6,
+	TEMPORAL1: 7,
+	DENOISE_A0: 8,
+	DENOISE_A1: 9,
+	DENOISE_B0: 10,
+	DENOISE_B1: 11,
+	COMPOSE: 12
+}
+// [TypedArray constructor, elements per texel]
+const FORMAT = {
+	0: [Float32Array, 1],
+	1: [Uint32Array, 4],
+	2: [Uint32Array, 4],
+	3: [Float32Array, 4],
+	4: [Uint8Array, 4],
+	5: [Uint32Array, 4],
+	6: [Float32Array, 4],
+	7: [Float32Array, 4],
+	8: [Uint16Array, 4],
+	9: [Uint16Array, 4],
+	10: [Uint16Array, 4],
+	11: [Uint16Array, 4],
+	12: [Float32Array, 4]
+}
+
+// 128x128 RGBA8 blue-noise table: decoded once from the reference's PNG asset, already flipY'd
+// (tools/make_blue_noise_table.py; src/utils/BlueNoiseUtils.js:9-15)
+function loadBlueNoiseTable() {
+	const buf = fs.readFileSync(path.join(__dirname, "..", "data", "blue_noise_128_rgba8.bin"))
+	if (buf.length !== 128 * 128 * 4) throw new Error("blue noise table: unexpected size")
+	return new Uint8Array(buf.buffer, buf.byteOffset, buf.length)
+}
+
+class Renderer {
+	constructor(width, height, options) {
+		options = options || {}
+		this.width = width
+		this.height = height
+		this.tileY0 = options.tileY0 || 0
+		this.tileRows = options.tileRows === undefined ? height - this.tileY0 : options.tileRows
+		this.haloRows = options.haloRows || 0
+		this._h = addon.create(options.device || 0, width, height, this.tileY0, this.tileRows, this.haloRows)
+		this._resident = {}
+		this.upload(TEX.BLUE_NOISE, loadBlueNoiseTable(), 0, 128)
+	}
+
+	heldRows(tex) {
+		return addon.heldRows(this._h, tex)
+	}
+
+	// rows [row0, row0+rows) in FRAME rows; `array` holds exactly those rows
+	upload(tex, array, row0, rows) {
+		const held = this.heldRows(tex)
+		if (row0 === undefined) row0 = held[0]
+		if (rows === undefined) rows = held[1]
+		addon.upload(this._h, tex, array, row0, rows)
+	}
+
+	// a dumped FULL-FRAME plane: the slot takes the band it holds; an already resident plane is not re-sent
+	uploadPlane(tex, plane) {
+		if (this._resident[tex] === plane) return
+		const held = this.heldRows(tex)
+		const per = FORMAT[tex][1] * this.width
+		const band = plane.length === held[1] * per ? plane : plane.subarray(held[0] * per, (held[0] + held[1]) * per)
+		this.upload(tex, band, held[0], held[1])
+		this._resident[tex] = plane
+	}
+
+	download(tex, row0, rows) {
+		const held = this.heldRows(tex)
+		if (row0 === undefined) row0 = held[0]
+		if (rows === undefined) rows = held[1]
+		const f = FORMAT[tex]
+		const out = new f[0](rows * (tex === TEX.BLUE_NOISE ? 128 : this.width) * f[1])
+		addon.download(this._h, tex, out, row0, rows)
+		return out
+	}
+
+	clear(tex) {
+		addon.clear(this._h, tex)
+	}
+
+	// the four draws (include/rfx.h)
+	ssgiMarch(uniforms) {
+		addon.ssgiMarch(this._h, uniforms)
+	}
+	temporalReproject(uniforms) {
+		addon.temporalReproject(this._h, uniforms)
+	}
+	poissonDenoise(uniforms) {
+		addon.poissonDenoise(this._h, uniforms)
+	}
+	compose(uniforms) {
+		addon.compose(this._h, uniforms)
+	}
+
+	sync() {
+		addon.sync(this._h)
+	}
+	haloViolations() {
+		return addon.haloViolations(this._h)
+	}
+	timeBegin() {
+		addon.timeBegin(this._h)
+	}
+	timeEnd() {
+		return addon.timeEnd(this._h)
+	}
+	dispose() {
+		this._h = null // the context is destroyed by the handle's finalizer
+	}
+}
+
+module.exports = { Renderer, TEX, FORMAT, loadBlueNoiseTable, abiVersion: addon.abiVersion }

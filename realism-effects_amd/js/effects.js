@@ -1,0 +1,594 @@
+"use strict"
+// Host side of the hot path in the reference's own language: the reference's class names,
+// constructor signatures, option names, defaults and per-frame logic, with every
+// `renderer.setRenderTarget(rt); renderer.render(scene, camera)` replaced by one call into
+// librfx_hip.so through the N-API addon (Renderer.js).  Node-12 syntax (no ?. ?? class fields).
+//
+// `scene` / `camera` are plain dumped-state objects (no three.js):
+//   camera : { projectionMatrix, projectionMatrixInverse, matrixWorld, matrixWorldInverse (16 numbers, column-major =
+//              three's Matrix4.elements), position [3], quaternion [4], near, far, isPerspectiveCamera }
+//   scene  : { frame: { depth, gbuffer, velocity, direct } } — the pre-dumped planes (dump.js)
+//
+// Mirrors: src/ssgi/SSGIEffect.js, src/ssgi/SSGIOptions.js, src/ssgi/pass/SSGIPass.js, src/denoise/Denoiser.js,
+// src/denoise/pass/PoissonDenoisePass.js, src/denoise/pass/DenoiserComposePass.js,
+// src/temporal-reproject/TemporalReprojectPass.js, src/temporal-reproject/pass/VelocityDepthNormalPass.js,
+// src/traa/TRAAEffect.js, src/utils/BlueNoiseUtils.js, src/utils/SceneUtils.js
+const { TEX } = require("./Renderer")
+
+// src/ssgi/SSGIOptions.js:26-48
+const defaultSSGIOptions = {
+	mode: "ssgi",
+	distance: 10,
+	thickness: 10,
+	denoiseIterations: 1,
+	denoiseKernel: 2,
+	denoiseDiffuse: 10,
+	denoiseSpecular: 10,
+	radius: 3,
+	phi: 0.5,
+	lumaPhi: 5,
+	depthPhi: 2,
+	normalPhi: 50,
+	roughnessPhi: 50,
+	specularPhi: 50,
+	envBlur: 0.5,
+	importanceSampling: true,
+	steps: 20,
+	refineSteps: 5,
+	resolutionScale: 1,
+	missedRays: false,
+	outputTexture: null
+}
+
+// src/temporal-reproject/TemporalReprojectPass.js:17-32
+const defaultTemporalReprojectPassOptions = {
+	dilation: false,
+	fullAccumulate: false,
+	neighborhoodClamp: false,
+	neighborhoodClampRadius: 1,
+	neighborhoodClampIntensity: 1,
+	maxBlend: 1,
+	logTransform: false,
+	depthDistance: 2,
+	worldDistance: 4,
+	reprojectSpecular: false,
+	renderTarget: null,
+	copyTextures: true,
+	confidencePower: 0.75,
+	inputType: "diffuse"
+}
+
+// src/denoise/pass/PoissonDenoisePass.js:16-24
+const defaultPoissonBlurOptions = {
+	iterations: 1,
+	radius: 3,
+	phi: 0.5,
+	lumaPhi: 5,
+	depthPhi: 2,
+	normalPhi: 3.25,
+	inputType: "diffuseSpecular"
+}
+
+// src/denoise/Denoiser.js:6-11
+const defaultDenosierOptions = {
+	denoiseMode: "full",
+	inputType: "diffuseSpecular",
+	gBufferPass: null,
+	velocityDepthNormalPass: null
+}
+
+const INPUT_TYPES = ["diffuseSpecular", "diffuse", "specular"]
+const highestSignedInt = 0x7fffffff
+
+// src/utils/BlueNoiseUtils.js:17-33 — the uniform is a getter: every read (one per draw) advances the index
+function makeBlueNoiseIndex(startIndex) {
+	let blueNoiseIndex = 0
+	if (startIndex === undefined || startIndex === null) startIndex = Math.floor(Math.random() * highestSignedInt)
+	return {
+		startIndex,
+		get value() {
+			blueNoiseIndex = (startIndex + blueNoiseIndex + 1) % highestSignedInt
+			return blueNoiseIndex
+		},
+		set value(v) {
+			blueNoiseIndex = v
+		}
+	}
+}
+
+// src/utils/SceneUtils.js:17-27
+function didCameraMove(camera, lastPosition, lastQuaternion) {
+	let d2 = 0
+	for (let i = 0; i < 3; i++) d2 += (camera.position[i] - lastPosition[i]) * (camera.position[i] - lastPosition[i])
+	if (d2 > 0.000001) return true
+	const q = camera.quaternion || [0, 0, 0, 1]
+	let dot = 0
+	for (let i = 0; i < 4; i++) dot += q[i] * lastQuaternion[i]
+	const angle = 2 * Math.acos(Math.abs(Math.max(-1, Math.min(1, dot))))
+	return angle > 0.001
+}
+
+function cloneCamera(camera) {
+	return {
+		projectionMatrix: Float32Array.from(camera.projectionMatrix),
+		projectionMatrixInverse: Float32Array.from(camera.projectionMatrixInverse),
+		matrixWorld: Float32Array.from(camera.matrixWorld),
+		matrixWorldInverse: Float32Array.from(camera.matrixWorldInverse),
+		position: Float32Array.from(camera.position),
+		near: camera.near,
+		far: camera.far,
+		isPerspectiveCamera: camera.isPerspectiveCamera === undefined ? true : camera.isPerspectiveCamera
+	}
+}
+
+// Stand-in for src/gbuffer/GBufferPass.js: the rasteriser is out of scope; render() hands the pre-dumped
+// packed G-buffer + depth planes to the device.
+class GBufferPass {
+	constructor(scene, camera) {
+		this._scene = scene
+		this._camera = camera
+		this.texture = TEX.GBUFFER
+		this.depthTexture = TEX.DEPTH
+	}
+	setSize(width, height) {
+		this.width = width
+		this.height = height
+	}
+	render(renderer) {
+		renderer.uploadPlane(TEX.DEPTH, this._scene.frame.depth)
+		renderer.uploadPlane(TEX.GBUFFER, this._scene.frame.gbuffer)
+	}
+	dispose() {}
+}
+
+// src/temporal-reproject/pass/VelocityDepthNormalPass.js:66 — loader shim with the reference's signature
+class VelocityDepthNormalPass {
+	constructor(scene, camera) {
+		this._scene = scene
+		this._camera = camera
+		this.renderTarget = this
+		this.texture = TEX.VELOCITY
+		this.depthTexture = TEX.VELOCITY
+		this.lastVelocityTexture = null
+	}
+	setSize(width, height) {
+		this.width = width
+		this.height = height
+	}
+	render(renderer) {
+		renderer.uploadPlane(TEX.VELOCITY, this._scene.frame.velocity)
+	}
+	dispose() {}
+}
+
+// src/temporal-reproject/TemporalReprojectPass.js:38-225
+class TemporalReprojectPass {
+	constructor(scene, camera, velocityDepthNormalPass, texture, textureCount, options) {
+		this._scene = scene
+		this._camera = camera
+		this.textureCount = textureCount
+		options = Object.assign({}, defaultTemporalReprojectPassOptions, options || {})
+		this.options = options
+		this.velocityDepthNormalPass = velocityDepthNormalPass
+		this.frame = 0
+		this.overrideAccumulatedTextures = []
+		this.lastCameraTransform = { position: [0, 0, 0], quaternion: [0, 0, 0, 1] }
+		const it = INPUT_TYPES.indexOf(options.inputType)
+		const flags = name => {
+			let v = options[name]
+			if (!Array.isArray(v)) v = [v, v]
+			return [v[0] ? 1 : 0, (v.length > 1 ? v[1] : v[0]) ? 1 : 0]
+		}
+		this.uniforms = {
+			camera: null,
+			prevCamera: cloneCamera(camera), // :95-104 the ctor clones the current camera state
+			textureCount,
+			inputType: it < 0 ? 1 : it,
+			reprojectSpecular: flags("reprojectSpecular"),
+			neighborhoodClamp: flags("neighborhoodClamp"),
+			logTransform: options.logTransform ? 1 : 0,
+			fullAccumulate: 0,
+			confidencePower: options.confidencePower,
+			neighborhoodClampIntensity: options.neighborhoodClampIntensity,
+			maxBlend: options.maxBlend,
+			keepData: 1
+		}
+	}
+	setSize(width, height) {
+		this.width = width
+		this.height = height
+	}
+	get texture() {
+		return TEX.TEMPORAL0
+	}
+	reset() {
+		this.uniforms.keepData = 0 // :158-160
+	}
+	render(renderer) {
+		this.frame = (this.frame + 1) % 4096
+		const cam = this._camera
+		this.uniforms.camera = cloneCamera(cam)
+		const moved = didCameraMove(cam, this.lastCameraTransform.position, this.lastCameraTransform.quaternion)
+		this.uniforms.fullAccumulate = this.options.fullAccumulate && !moved ? 1 : 0 // :178-180
+		this.lastCameraTransform.position = Array.from(cam.position)
+		this.lastCameraTransform.quaternion = Array.from(cam.quaternion || [0, 0, 0, 1])
+		renderer.temporalReproject(this.uniforms) // :192-193
+		this.uniforms.keepData = 1 // :195
+		this.uniforms.prevCamera = cloneCamera(cam) // :203-213
+	}
+	dispose() {}
+}
+
+// src/denoise/pass/PoissonDenoisePass.js:26-152
+class PoissonDenoisePass {
+	constructor(camera, textures, options, blueNoiseStart, halfStoreRTZ) {
+		options = Object.assign({}, defaultPoissonBlurOptions, options || {})
+		this.iterations = defaultPoissonBlurOptions.iterations
+		this.textures = textures
+		let isTextureSpecular = [0, 1]
+		if (options.inputType === "diffuse") isTextureSpecular = [0, 0]
+		if (options.inputType === "specular") isTextureSpecular = [1, 1]
+		this.uniforms = {
+			radius: defaultPoissonBlurOptions.radius,
+			phi: defaultPoissonBlurOptions.phi,
+			lumaPhi: defaultPoissonBlurOptions.lumaPhi,
+			depthPhi: options.depthPhi,
+			normalPhi: options.normalPhi,
+			roughnessPhi: undefined, // :63-64 start undefined until SSGIEffect's setters write them
+			specularPhi: undefined,
+			textureCount: options.inputType === "diffuseSpecular" ? 2 : 1,
+			isTextureSpecular,
+			blueNoiseIndex: 0,
+			inputIsTemporal: 1,
+			writeToB: 0,
+			halfStoreRTZ: halfStoreRTZ ? 1 : 0
+		}
+		this.blueNoiseIndex = makeBlueNoiseIndex(blueNoiseStart)
+	}
+	setSize(width, height) {
+		this.width = width
+		this.height = height
+	}
+	get texture() {
+		return [TEX.DENOISE_B0, TEX.DENOISE_B1]
+	}
+	render(renderer) {
+		for (let i = 0; i < 2 * this.iterations; i++) {
+			const horizontal = i % 2 === 0
+			this.uniforms.inputIsTemporal = i === 0 ? 1 : 0
+			this.uniforms.writeToB = horizontal ? 0 : 1
+			this.uniforms.blueNoiseIndex = this.blueNoiseIndex.value
+			renderer.poissonDenoise(this.uniforms)
+			if (renderer.afterDenoisePass) renderer.afterDenoisePass(i, this.uniforms)
+		}
+	}
+	dispose() {}
+}
+PoissonDenoisePass.DefaultOptions = defaultPoissonBlurOptions
+
+// src/denoise/pass/DenoiserComposePass.js:8-136
+class DenoiserComposePass {
+	constructor(camera, textures, gBufferTexture, depthTexture, options) {
+		options = options || {}
+		this._camera = camera
+		const it = INPUT_TYPES.indexOf(options.inputType)
+		this.uniforms = { camera: null, inputType: it < 0 ? 0 : it }
+	}
+	setSize(width, height) {
+		this.width = width
+		this.height = height
+	}
+	get texture() {
+		return TEX.COMPOSE
+	}
+	render(renderer) {
+		this.uniforms.camera = cloneCamera(this._camera)
+		renderer.compose(this.uniforms)
+	}
+	dispose() {}
+}
+
+// src/denoise/Denoiser.js:16-108
+class Denoiser {
+	constructor(scene, camera, texture, options, blueNoiseStart, halfStoreRTZ) {
+		options = Object.assign({}, defaultDenosierOptions, options || {})
+		this.options = options
+		this.velocityDepthNormalPass = options.velocityDepthNormalPass || new VelocityDepthNormalPass(scene, camera)
+		this.isOwnVelocityDepthNormalPass = !options.velocityDepthNormalPass
+		const textureCount = options.inputType === "diffuseSpecular" ? 2 : 1
+		const topt = {
+			fullAccumulate: true,
+			logTransform: true,
+			copyTextures: !options.denoise,
+			reprojectSpecular: [false, true],
+			neighborhoodClamp: [true, true],
+			neighborhoodClampRadius: 2,
+			neighborhoodClampIntensity: 0.5
+		}
+		for (const k of Object.keys(defaultTemporalReprojectPassOptions)) if (k in options) topt[k] = options[k]
+		this.temporalReprojectPass = new TemporalReprojectPass(scene, camera, this.velocityDepthNormalPass, texture, textureCount, topt)
+		this.denoisePass = null
+		this.denoiserComposePass = null
+		if (options.denoiseMode === "full" || options.denoiseMode === "denoised") {
+			const popt = {}
+			for (const k of Object.keys(defaultPoissonBlurOptions)) if (k in options) popt[k] = options[k]
+			this.denoisePass = new PoissonDenoisePass(camera, [TEX.TEMPORAL0, TEX.TEMPORAL1], popt, blueNoiseStart, halfStoreRTZ)
+			this.temporalReprojectPass.overrideAccumulatedTextures = this.denoisePass.texture
+		}
+		if (options.denoiseMode.startsWith("full")) {
+			if (!this.denoisePass)
+				throw new Error('denoiseMode "full_temporal": K2 history from a framebuffer copy is not built (SURVEY.md Appendix D-11)')
+			this.denoiserComposePass = new DenoiserComposePass(camera, this.denoisePass.texture, TEX.GBUFFER, TEX.DEPTH, options)
+		}
+		if (options.denoiseMode === "temporal") throw new Error('denoiseMode "temporal" is not built (SURVEY.md Appendix D-11)')
+	}
+	get texture() {
+		switch (this.options.denoiseMode) {
+			case "full":
+			case "full_temporal":
+				return this.denoiserComposePass.texture
+			case "denoised":
+				return this.denoisePass.texture
+			default:
+				return this.temporalReprojectPass.texture
+		}
+	}
+	reset() {
+		this.temporalReprojectPass.reset()
+	}
+	setSize(width, height) {
+		for (const p of [this.velocityDepthNormalPass, this.temporalReprojectPass, this.denoisePass, this.denoiserComposePass])
+			if (p) p.setSize(width, height)
+	}
+	dispose() {}
+	render(renderer, inputBuffer) {
+		if (this.isOwnVelocityDepthNormalPass) this.velocityDepthNormalPass.render(renderer)
+		this.temporalReprojectPass.render(renderer)
+		if (renderer.afterTemporalPass) renderer.afterTemporalPass()
+		if (this.denoisePass) this.denoisePass.render(renderer)
+		if (this.denoiserComposePass) {
+			this.denoiserComposePass.render(renderer)
+			if (renderer.afterComposePass) renderer.afterComposePass()
+		}
+	}
+}
+
+// src/ssgi/pass/SSGIPass.js:7-96
+class SSGIPass {
+	constructor(ssgiEffect, options, blueNoiseStart) {
+		this.ssgiEffect = ssgiEffect
+		this._scene = ssgiEffect._scene
+		this._camera = ssgiEffect._camera
+		this.frame = 21483
+		this.uniforms = {
+			camera: null,
+			steps: 20,
+			refineSteps: 5,
+			mode: ["ssgi", "ssr"].indexOf(options.mode),
+			useDirectLight: 0,
+			missedRays: 0,
+			importanceSampling: 0,
+			rayDistance: 0,
+			thickness: 0,
+			envBlur: 0,
+			blueNoiseIndex: 0
+		}
+		this.blueNoiseIndex = makeBlueNoiseIndex(blueNoiseStart)
+		this.gBufferPass = new GBufferPass(this._scene, this._camera)
+	}
+	get texture() {
+		return TEX.SSGI
+	}
+	setSize(width, height) {
+		if (this.ssgiEffect._options.resolutionScale !== 1) throw new Error("resolutionScale != 1 (SSGIPass.js:53) is not built yet")
+		this.gBufferPass.setSize(width, height)
+	}
+	render(renderer) {
+		this.frame = (this.frame + 1) % 4096
+		this.gBufferPass.render(renderer)
+		this.uniforms.camera = cloneCamera(this._camera)
+		this.uniforms.blueNoiseIndex = this.blueNoiseIndex.value
+		renderer.ssgiMarch(this.uniforms) // :93-94
+	}
+	dispose() {}
+}
+
+// src/ssgi/SSGIEffect.js:27-439
+class SSGIEffect {
+	// `seeds` ({ ssgi, denoise } blue-noise start indices) and `halfStoreRTZ` are additions for reproducible offline runs
+	constructor(composer, scene, camera, options, seeds, halfStoreRTZ) {
+		options = Object.assign({}, defaultSSGIOptions, options || {})
+		this._scene = scene
+		this._camera = camera
+		this.composer = composer
+		this.isUsingRenderPass = true
+		if (options.mode === "ssr") {
+			throw new Error('mode "ssr" (MODE_SSR) is not built yet (SURVEY.md §8f-2)')
+		} else if (options.mode === "ssgi") {
+			options.reprojectSpecular = [false, true] // :74-77
+			options.neighborhoodClamp = [false, true]
+		}
+		if (typeof options.preset === "string") {
+			// :79-99 (the second `case "medium"` in the reference is unreachable)
+			switch (options.preset) {
+				case "low":
+					options.steps = 10
+					options.refineSteps = 2
+					options.denoiseMode = "full_temporal"
+					break
+				case "medium":
+					options.steps = 20
+					options.refineSteps = 4
+					options.denoiseMode = "full"
+					break
+			}
+		}
+		seeds = seeds || {}
+		this._options = options
+		this.ssgiPass = new SSGIPass(this, options, seeds.ssgi)
+		this.denoiser = new Denoiser(
+			scene,
+			camera,
+			this.ssgiPass.texture,
+			Object.assign({ gBufferPass: this.ssgiPass.gBufferPass, velocityDepthNormalPass: options.velocityDepthNormalPass }, options),
+			seeds.denoise,
+			halfStoreRTZ
+		)
+		this.lastSize = { width: options.width, height: options.height, resolutionScale: options.resolutionScale }
+		this.setSize(options.width, options.height)
+		this.makeOptionsReactive(options)
+		this.outputTexture = this.denoiser.texture
+		this.updateUsingRenderPass() // the composer's RenderPass ran before update(): direct light is available
+	}
+
+	updateUsingRenderPass() {
+		this.ssgiPass.uniforms.useDirectLight = this.isUsingRenderPass ? 1 : 0 // :143-151
+	}
+
+	reset() {
+		this.denoiser.reset()
+	}
+
+	// :157-268
+	makeOptionsReactive(options) {
+		let needsUpdate = false
+		const ssgiUniforms = this.ssgiPass.uniforms
+		for (const key of Object.keys(options)) {
+			if (key === "outputTexture") continue
+			Object.defineProperty(this, key, {
+				configurable: true,
+				get() {
+					return options[key]
+				},
+				set(value) {
+					if (options[key] === value && needsUpdate) return
+					options[key] = value
+					const dp = this.denoiser.denoisePass
+					switch (key) {
+						case "denoiseIterations":
+							if (dp) dp.iterations = value
+							break
+						case "radius":
+						case "phi":
+						case "lumaPhi":
+						case "depthPhi":
+						case "normalPhi":
+						case "roughnessPhi":
+						case "specularPhi":
+							if (dp) {
+								dp.uniforms[key] = value
+								this.reset()
+							}
+							break
+						case "resolutionScale":
+							this.setSize(this.lastSize.width, this.lastSize.height)
+							this.reset()
+							break
+						case "steps":
+						case "refineSteps":
+							ssgiUniforms[key] = parseInt(value)
+							this.reset()
+							break
+						case "importanceSampling":
+							// only effective with an env map (SSGIEffect.js:344-354); the dumps carry none
+							this.reset()
+							break
+						case "missedRays":
+							ssgiUniforms.missedRays = value ? 1 : 0
+							this.reset()
+							break
+						case "distance":
+							ssgiUniforms.rayDistance = value
+							this.reset()
+							break
+						default:
+							// must be a uniform (:254-258); denoiseKernel/denoiseDiffuse/denoiseSpecular have no consumer
+							if (key === "thickness" || key === "envBlur") {
+								ssgiUniforms[key] = value
+								this.reset()
+							}
+					}
+				}
+			})
+			this[key] = options[key]
+		}
+		needsUpdate = true
+	}
+
+	setSize(width, height, force) {
+		if (width === undefined && height === undefined) return
+		this.ssgiPass.setSize(width, height)
+		this.denoiser.setSize(width, height)
+		this.lastSize = { width, height, resolutionScale: this._options.resolutionScale }
+	}
+
+	get depthTexture() {
+		return this.ssgiPass.gBufferPass.depthTexture
+	}
+
+	initialize() {}
+
+	dispose() {
+		this.ssgiPass.dispose()
+		this.denoiser.dispose()
+	}
+
+	// :372-436.  inputBuffer: the composer's input buffer (direct lighting) as a Float32Array RGBA plane, or null to
+	// take scene.frame.direct.
+	update(renderer, inputBuffer) {
+		const direct = inputBuffer || this._scene.frame.direct
+		renderer.uploadPlane(TEX.DIRECT_LIGHT, direct)
+		this.ssgiPass.render(renderer)
+		this.denoiser.render(renderer, inputBuffer)
+	}
+}
+SSGIEffect.DefaultOptions = defaultSSGIOptions
+
+// src/traa/TRAAEffect.js:10-78 — option surface + K2 parameter mapping (camera jitter needs the rasteriser)
+class TRAAEffect {
+	constructor(scene, camera, velocityDepthNormalPass, options) {
+		this._scene = scene
+		this._camera = camera
+		this.velocityDepthNormalPass = velocityDepthNormalPass
+		options = Object.assign({}, options || defaultTemporalReprojectPassOptions, {
+			maxBlend: 0.9,
+			neighborhoodClamp: true,
+			neighborhoodClampIntensity: 1,
+			neighborhoodClampRadius: 1,
+			logTransform: true,
+			confidencePower: 4
+		})
+		this.options = Object.assign({}, defaultTemporalReprojectPassOptions, options)
+		this.temporalReprojectPass = null
+	}
+	setSize(width, height) {
+		if (this.temporalReprojectPass) this.temporalReprojectPass.setSize(width, height)
+	}
+	reset() {
+		this.temporalReprojectPass.reset()
+	}
+	temporalParams() {
+		if (!this.temporalReprojectPass)
+			this.temporalReprojectPass = new TemporalReprojectPass(this._scene, this._camera, this.velocityDepthNormalPass, null, 1, this.options)
+		return this.temporalReprojectPass.uniforms
+	}
+	dispose() {}
+}
+TRAAEffect.DefaultOptions = defaultTemporalReprojectPassOptions
+
+module.exports = {
+	SSGIEffect,
+	TRAAEffect,
+	VelocityDepthNormalPass,
+	TemporalReprojectPass,
+	PoissonDenoisePass,
+	DenoiserComposePass,
+	Denoiser,
+	SSGIPass,
+	GBufferPass,
+	defaultSSGIOptions,
+	defaultTemporalReprojectPassOptions,
+	defaultPoissonBlurOptions,
+	makeBlueNoiseIndex,
+	didCameraMove
+}

@@ -1,0 +1,44 @@
+#!/usr/bin/env node
+"use strict"
+// node run_dump.js <dumpdir0> [<dumpdir1> ...] --out <dir> [--steps N --refineSteps N --denoiseIterations N]
+// Runs SSGIEffect.update() over a sequence of dumped frames on GPU 0 and writes compose.bin / denoise_b0.bin /
+// denoise_b1.bin / temporal0.bin / ssgi.bin of the LAST frame into --out.
+const fs = require("fs")
+const path = require("path")
+const rfx = require("./index")
+
+const args = process.argv.slice(2)
+const dumps = []
+const opt = {}
+let out = "."
+for (let i = 0; i < args.length; i++) {
+	if (args[i] === "--out") out = args[++i]
+	else if (args[i].startsWith("--")) opt[args[i].slice(2)] = JSON.parse(args[++i])
+	else dumps.push(args[i])
+}
+if (!dumps.length) {
+	console.error("usage: run_dump.js <dumpdir>... --out <dir> [--steps N ...]")
+	process.exit(2)
+}
+const seeds = { ssgi: opt.ssgiSeed === undefined ? 11 : opt.ssgiSeed, denoise: opt.denoiseSeed === undefined ? 22 : opt.denoiseSeed }
+delete opt.ssgiSeed
+delete opt.denoiseSeed
+const first = rfx.readDump(dumps[0])
+const scene = { frame: first }
+const camera = Object.assign({}, first.camera)
+const renderer = new rfx.Renderer(first.width, first.height)
+const effect = new rfx.SSGIEffect(null, scene, camera, Object.assign({ width: first.width, height: first.height }, opt), seeds, true)
+for (const d of dumps) {
+	const f = d === dumps[0] ? first : rfx.readDump(d)
+	scene.frame = f
+	Object.assign(camera, f.camera)
+	effect.update(renderer, null)
+}
+renderer.sync()
+fs.mkdirSync(out, { recursive: true })
+const T = rfx.TEX
+for (const [name, tex] of [["compose", T.COMPOSE], ["denoise_b0", T.DENOISE_B0], ["denoise_b1", T.DENOISE_B1], ["temporal0", T.TEMPORAL0], ["ssgi", T.SSGI]]) {
+	const a = renderer.download(tex)
+	fs.writeFileSync(path.join(out, name + ".bin"), Buffer.from(a.buffer, a.byteOffset, a.byteLength))
+}
+console.log(JSON.stringify({ frames: dumps.length, width: first.width, height: first.height, haloViolations: renderer.haloViolations() }))

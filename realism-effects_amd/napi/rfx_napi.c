@@ -1,0 +1,356 @@
+/*
+ * rfx_napi.c — raw N-API addon (node_api.h, no node-gyp / C++ wrappers) that binds the C ABI of
+ * librfx_hip.so (include/rfx.h) for the Node host in ../js.
+ *
+ * Every export is a 1:1 wrapper of one rfx_* entry point; TypedArrays are passed zero-copy
+ * (napi_get_typedarray_info).  Pass parameter blocks are plain JS objects whose property names
+ * are the reference's uniform / define names (see include/rfx.h for the mapping to the
+ * reference files).  Errors become JS exceptions carrying rfx_last_error().
+ *
+ * All calls are made on the JS main thread; asynchrony comes from the HIP stream inside the
+ * context (calls enqueue and return, `sync` blocks), not from JS threads — the same model as the
+ * reference, whose draws are asynchronous on the GL command queue.
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/rfx.h"
+
+#define NAPI_CALL(env, call)                                          \
+    do {                                                              \
+        napi_status s__ = (call);                                     \
+        if (s__ != napi_ok) {                                         \
+            napi_throw_error((env), NULL, "N-API call failed: " #call); \
+            return NULL;                                              \
+        }                                                             \
+    } while (0)
+
+static napi_value throw_rfx(napi_env env, rfx_ctx *c, const char *what, int rc) {
+    char buf[640];
+    snprintf(buf, sizeof buf, "%s failed (%d): %s", what, rc, rfx_last_error(c));
+    napi_throw_error(env, NULL, buf);
+    return NULL;
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv) {
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+        napi_throw_type_error(env, NULL, "wrong number of arguments");
+        return 0;
+    }
+    return 1;
+}
+
+static rfx_ctx *get_ctx(napi_env env, napi_value v) {
+    void *p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+        napi_throw_type_error(env, NULL, "expected an rfx context handle");
+        return NULL;
+    }
+    return (rfx_ctx *)p;
+}
+
+static int get_int(napi_env env, napi_value v, int32_t *out) {
+    napi_valuetype t;
+    if (napi_typeof(env, v, &t) != napi_ok) return 0;
+    if (t == napi_boolean) { bool b; napi_get_value_bool(env, v, &b); *out = b ? 1 : 0; return 1; }
+    if (t != napi_number) return 0;
+    double d;
+    napi_get_value_double(env, v, &d);
+    *out = (int32_t)d;
+    return 1;
+}
+
+/* obj[name] as double; missing/undefined -> default */
+static double prop_num(napi_env env, napi_value obj, const char *name, double def) {
+    napi_value v;
+    napi_valuetype t;
+    if (napi_get_named_property(env, obj, name, &v) != napi_ok || napi_typeof(env, v, &t) != napi_ok) return def;
+    if (t == napi_boolean) { bool b; napi_get_value_bool(env, v, &b); return b ? 1.0 : 0.0; }
+    if (t != napi_number) return def;
+    double d;
+    napi_get_value_double(env, v, &d);
+    return d;
+}
+
+/* obj[name] = Float32Array | Float64Array | Array of n numbers -> out[n] */
+static int prop_floats(napi_env env, napi_value obj, const char *name, float *out, size_t n) {
+    napi_value v;
+    bool is_ta = false, is_arr = false;
+    if (napi_get_named_property(env, obj, name, &v) != napi_ok) return 0;
+    napi_is_typedarray(env, v, &is_ta);
+    if (is_ta) {
+        napi_typedarray_type ty; size_t len; void *data;
+        if (napi_get_typedarray_info(env, v, &ty, &len, &data, NULL, NULL) != napi_ok || len < n) return 0;
+        if (ty == napi_float32_array) { memcpy(out, data, n * sizeof(float)); return 1; }
+        if (ty == napi_float64_array) { for (size_t i = 0; i < n; i++) out[i] = (float)((double *)data)[i]; return 1; }
+        return 0;
+    }
+    napi_is_array(env, v, &is_arr);
+    if (!is_arr) return 0;
+    for (size_t i = 0; i < n; i++) {
+        napi_value e; double d;
+        if (napi_get_element(env, v, (uint32_t)i, &e) != napi_ok || napi_get_value_double(env, e, &d) != napi_ok) return 0;
+        out[i] = (float)d;
+    }
+    return 1;
+}
+
+static int prop_bool2(napi_env env, napi_value obj, const char *name, int32_t *out) {
+    napi_value v, e;
+    bool is_arr = false;
+    out[0] = out[1] = 0;
+    if (napi_get_named_property(env, obj, name, &v) != napi_ok) return 0;
+    napi_is_array(env, v, &is_arr);
+    if (!is_arr) { int32_t x = 0; if (get_int(env, v, &x)) { out[0] = out[1] = x; return 1; } return 0; }
+    for (uint32_t i = 0; i < 2; i++)
+        if (napi_get_element(env, v, i, &e) == napi_ok) get_int(env, e, &out[i]);
+    return 1;
+}
+
+/* camera object: the fields the reference passes read from three's camera */
+static int read_camera(napi_env env, napi_value obj, const char *name, rfx_camera *c) {
+    napi_value cam;
+    napi_valuetype t;
+    if (napi_get_named_property(env, obj, name, &cam) != napi_ok || napi_typeof(env, cam, &t) != napi_ok || t != napi_object) {
+        napi_throw_type_error(env, NULL, "params.camera / params.prevCamera must be an object");
+        return 0;
+    }
+    if (!prop_floats(env, cam, "projectionMatrix", c->projectionMatrix, 16) || !prop_floats(env, cam, "projectionMatrixInverse", c->projectionMatrixInverse, 16) ||
+        !prop_floats(env, cam, "matrixWorld", c->matrixWorld, 16) || !prop_floats(env, cam, "matrixWorldInverse", c->matrixWorldInverse, 16) ||
+        !prop_floats(env, cam, "position", c->position, 3)) {
+        napi_throw_type_error(env, NULL, "camera needs projectionMatrix, projectionMatrixInverse, matrixWorld, matrixWorldInverse (16 numbers) and position (3)");
+        return 0;
+    }
+    c->near_ = (float)prop_num(env, cam, "near", 0.1);
+    c->far_ = (float)prop_num(env, cam, "far", 1000.0);
+    c->isPerspective = (int32_t)prop_num(env, cam, "isPerspectiveCamera", 1.0);
+    return 1;
+}
+
+static void destroy_ctx(napi_env env, void *data, void *hint) { (void)env; (void)hint; rfx_destroy((rfx_ctx *)data); }
+
+/* create(device, width, height, tileY0, tileRows, haloRows) -> handle */
+static napi_value n_create(napi_env env, napi_callback_info info) {
+    napi_value a[6], out;
+    int32_t v[6];
+    if (!get_args(env, info, 6, a)) return NULL;
+    for (int i = 0; i < 6; i++) if (!get_int(env, a[i], &v[i])) { napi_throw_type_error(env, NULL, "create: integers expected"); return NULL; }
+    rfx_ctx *c = rfx_create(v[0], v[1], v[2], v[3], v[4], v[5]);
+    if (!c) return throw_rfx(env, NULL, "rfx_create", RFX_EDEVICE);
+    NAPI_CALL(env, napi_create_external(env, c, destroy_ctx, NULL, &out));
+    return out;
+}
+
+static napi_value n_abi_version(napi_env env, napi_callback_info info) {
+    (void)info;
+    napi_value out;
+    NAPI_CALL(env, napi_create_int32(env, rfx_abi_version(), &out));
+    return out;
+}
+
+/* heldRows(ctx, tex) -> [row0, rows] */
+static napi_value n_held_rows(napi_env env, napi_callback_info info) {
+    napi_value a[2], arr, e;
+    int32_t tex;
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[1], &tex)) return NULL;
+    int r0 = 0, n = 0;
+    int rc = rfx_tex_held_rows(c, (rfx_tex)tex, &r0, &n);
+    if (rc) return throw_rfx(env, c, "rfx_tex_held_rows", rc);
+    NAPI_CALL(env, napi_create_array_with_length(env, 2, &arr));
+    napi_create_int32(env, r0, &e); napi_set_element(env, arr, 0, e);
+    napi_create_int32(env, n, &e); napi_set_element(env, arr, 1, e);
+    return arr;
+}
+
+/* upload(ctx, tex, typedArray, row0, rows) / download(ctx, tex, typedArray, row0, rows) */
+static napi_value xfer(napi_env env, napi_callback_info info, int up) {
+    napi_value a[5];
+    int32_t tex, row0, rows;
+    if (!get_args(env, info, 5, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[1], &tex) || !get_int(env, a[3], &row0) || !get_int(env, a[4], &rows)) return NULL;
+    bool is_ta = false;
+    napi_is_typedarray(env, a[2], &is_ta);
+    if (!is_ta) { napi_throw_type_error(env, NULL, "upload/download: TypedArray expected"); return NULL; }
+    napi_typedarray_type ty; size_t len; void *data; napi_value ab; size_t off;
+    NAPI_CALL(env, napi_get_typedarray_info(env, a[2], &ty, &len, &data, &ab, &off));
+    static const size_t esz[] = {1, 1, 1, 2, 2, 4, 4, 4, 8, 8, 8};
+    const size_t bytes = len * esz[ty];
+    int width = 0;
+    rfx_get_geometry(c, &width, NULL, NULL, NULL, NULL);
+    if (tex == RFX_TEX_BLUE_NOISE) width = 128;
+    const size_t need = (size_t)rows * (size_t)width * rfx_tex_texel_bytes((rfx_tex)tex);
+    if (rows <= 0 || need == 0 || bytes != need) {
+        napi_throw_range_error(env, NULL, "upload/download: TypedArray byte length != rows * width * texel bytes");
+        return NULL;
+    }
+    int rc = up ? rfx_upload(c, (rfx_tex)tex, data, row0, rows) : rfx_download(c, (rfx_tex)tex, data, row0, rows);
+    if (rc) return throw_rfx(env, c, up ? "rfx_upload" : "rfx_download", rc);
+    return NULL;
+}
+static napi_value n_upload(napi_env env, napi_callback_info info) { return xfer(env, info, 1); }
+static napi_value n_download(napi_env env, napi_callback_info info) { return xfer(env, info, 0); }
+
+static napi_value n_clear(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    int32_t tex;
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[1], &tex)) return NULL;
+    int rc = rfx_clear(c, (rfx_tex)tex);
+    if (rc) return throw_rfx(env, c, "rfx_clear", rc);
+    return NULL;
+}
+
+/* ssgiMarch(ctx, {camera, steps, refineSteps, mode, useDirectLight, missedRays, importanceSampling,
+ *                 rayDistance, thickness, envBlur, blueNoiseIndex}) */
+static napi_value n_ssgi(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    rfx_ssgi_params p;
+    memset(&p, 0, sizeof p);
+    if (!read_camera(env, a[1], "camera", &p.camera)) return NULL;
+    p.steps = (int32_t)prop_num(env, a[1], "steps", 20);
+    p.refineSteps = (int32_t)prop_num(env, a[1], "refineSteps", 5);
+    p.mode = (int32_t)prop_num(env, a[1], "mode", 0);
+    p.useDirectLight = (int32_t)prop_num(env, a[1], "useDirectLight", 0);
+    p.missedRays = (int32_t)prop_num(env, a[1], "missedRays", 0);
+    p.importanceSampling = (int32_t)prop_num(env, a[1], "importanceSampling", 0);
+    p.rayDistance = (float)prop_num(env, a[1], "rayDistance", 10);
+    p.thickness = (float)prop_num(env, a[1], "thickness", 10);
+    p.envBlur = (float)prop_num(env, a[1], "envBlur", 0.5);
+    p.blueNoiseIndex = (int32_t)prop_num(env, a[1], "blueNoiseIndex", 0);
+    int rc = rfx_ssgi_march(c, &p);
+    if (rc) return throw_rfx(env, c, "rfx_ssgi_march", rc);
+    return NULL;
+}
+
+/* temporalReproject(ctx, {camera, prevCamera, textureCount, inputType, reprojectSpecular[2], neighborhoodClamp[2],
+ *                         logTransform, fullAccumulate, confidencePower, neighborhoodClampIntensity, maxBlend, keepData}) */
+static napi_value n_temporal(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    rfx_temporal_params p;
+    memset(&p, 0, sizeof p);
+    if (!read_camera(env, a[1], "camera", &p.camera) || !read_camera(env, a[1], "prevCamera", &p.prevCamera)) return NULL;
+    p.textureCount = (int32_t)prop_num(env, a[1], "textureCount", 2);
+    p.inputType = (int32_t)prop_num(env, a[1], "inputType", 0);
+    prop_bool2(env, a[1], "reprojectSpecular", p.reprojectSpecular);
+    prop_bool2(env, a[1], "neighborhoodClamp", p.neighborhoodClamp);
+    p.logTransform = (int32_t)prop_num(env, a[1], "logTransform", 0);
+    p.fullAccumulate = (int32_t)prop_num(env, a[1], "fullAccumulate", 0);
+    p.confidencePower = (float)prop_num(env, a[1], "confidencePower", 0.75);
+    p.neighborhoodClampIntensity = (float)prop_num(env, a[1], "neighborhoodClampIntensity", 1);
+    p.maxBlend = (float)prop_num(env, a[1], "maxBlend", 1);
+    p.keepData = (float)prop_num(env, a[1], "keepData", 1);
+    int rc = rfx_temporal_reproject(c, &p);
+    if (rc) return throw_rfx(env, c, "rfx_temporal_reproject", rc);
+    return NULL;
+}
+
+/* poissonDenoise(ctx, {radius, phi, lumaPhi, depthPhi, normalPhi, roughnessPhi, specularPhi, textureCount,
+ *                      isTextureSpecular[2], blueNoiseIndex, inputIsTemporal, writeToB, halfStoreRTZ}) */
+static napi_value n_denoise(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    rfx_denoise_params p;
+    memset(&p, 0, sizeof p);
+    p.radius = (float)prop_num(env, a[1], "radius", 3);
+    p.phi = (float)prop_num(env, a[1], "phi", 0.5);
+    p.lumaPhi = (float)prop_num(env, a[1], "lumaPhi", 5);
+    p.depthPhi = (float)prop_num(env, a[1], "depthPhi", 2);
+    p.normalPhi = (float)prop_num(env, a[1], "normalPhi", 3.25);
+    p.roughnessPhi = (float)prop_num(env, a[1], "roughnessPhi", 0.0 / 0.0);
+    p.specularPhi = (float)prop_num(env, a[1], "specularPhi", 0.0 / 0.0);
+    p.textureCount = (int32_t)prop_num(env, a[1], "textureCount", 2);
+    prop_bool2(env, a[1], "isTextureSpecular", p.isTextureSpecular);
+    p.blueNoiseIndex = (int32_t)prop_num(env, a[1], "blueNoiseIndex", 0);
+    p.inputIsTemporal = (int32_t)prop_num(env, a[1], "inputIsTemporal", 1);
+    p.writeToB = (int32_t)prop_num(env, a[1], "writeToB", 0);
+    p.halfStoreRTZ = (int32_t)prop_num(env, a[1], "halfStoreRTZ", 0);
+    int rc = rfx_poisson_denoise(c, &p);
+    if (rc) return throw_rfx(env, c, "rfx_poisson_denoise", rc);
+    return NULL;
+}
+
+/* compose(ctx, {camera, inputType}) */
+static napi_value n_compose(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    rfx_compose_params p;
+    memset(&p, 0, sizeof p);
+    if (!read_camera(env, a[1], "camera", &p.camera)) return NULL;
+    p.inputType = (int32_t)prop_num(env, a[1], "inputType", 0);
+    int rc = rfx_compose(c, &p);
+    if (rc) return throw_rfx(env, c, "rfx_compose", rc);
+    return NULL;
+}
+
+static napi_value n_sync(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    int rc = rfx_sync(c);
+    if (rc) return throw_rfx(env, c, "rfx_sync", rc);
+    return NULL;
+}
+
+static napi_value n_halo_violations(napi_env env, napi_callback_info info) {
+    napi_value a[1], out;
+    if (!get_args(env, info, 1, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    NAPI_CALL(env, napi_create_uint32(env, rfx_halo_violations(c), &out));
+    return out;
+}
+
+/* timeBegin(ctx) / timeEnd(ctx) -> ms */
+static napi_value n_time_begin(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    int rc = rfx_time_begin(c);
+    if (rc) return throw_rfx(env, c, "rfx_time_begin", rc);
+    return NULL;
+}
+static napi_value n_time_end(napi_env env, napi_callback_info info) {
+    napi_value a[1], out;
+    if (!get_args(env, info, 1, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    float ms = 0;
+    int rc = rfx_time_end(c, &ms);
+    if (rc) return throw_rfx(env, c, "rfx_time_end", rc);
+    NAPI_CALL(env, napi_create_double(env, ms, &out));
+    return out;
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+    static const struct { const char *name; napi_callback fn; } fns[] = {
+        {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
+        {"clear", n_clear}, {"ssgiMarch", n_ssgi}, {"temporalReproject", n_temporal}, {"poissonDenoise", n_denoise}, {"compose", n_compose},
+        {"sync", n_sync}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
+    };
+    for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
+        napi_value f;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+        napi_set_named_property(env, exports, fns[i].name, f);
+    }
+    return exports;
+}
+
+NAPI_MODULE(rfx_napi, init)

@@ -73,7 +73,7 @@ class ComposeParams(C.Structure):
 
 
 EXPORTS = [
-    "rfx_abi_version", "rfx_create", "rfx_destroy", "rfx_last_error", "rfx_set_stream", "rfx_tex_texel_bytes", "rfx_tex_held_rows",
+    "rfx_abi_version", "rfx_create", "rfx_destroy", "rfx_last_error", "rfx_get_geometry", "rfx_set_stream", "rfx_tex_texel_bytes", "rfx_tex_held_rows",
     "rfx_upload", "rfx_download", "rfx_clear", "rfx_tex_device_ptr", "rfx_bind_external", "rfx_ssgi_march", "rfx_temporal_reproject",
     "rfx_poisson_denoise", "rfx_compose", "rfx_sync", "rfx_halo_violations", "rfx_time_begin", "rfx_time_end",
 ]
@@ -100,6 +100,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rfx_destroy.restype = None
     lib.rfx_last_error.argtypes = [vp]
     lib.rfx_last_error.restype = C.c_char_p
+    lib.rfx_get_geometry.argtypes = [vp] + [C.POINTER(i)] * 5
     lib.rfx_set_stream.argtypes = [vp, vp]
     lib.rfx_tex_texel_bytes.argtypes = [i]
     lib.rfx_tex_texel_bytes.restype = C.c_size_t

@@ -92,3 +92,107 @@ def test_chain_stagewise_vs_oracle(blue_noise, size, steps, refine):
         assert_close("compose f%d" % fi, ctx.download(abi.TEX_COMPOSE), comp, FLIP["compose"])
     assert ctx.halo_violations() == 0
     ctx.close()
+
+
+class _LocalTiles:
+    """N row-tile contexts on ONE device with host-staged halos: the single-process stand-in for
+    rfx_amd.tiling.TiledRenderer (which needs one process per GPU).  Exercises the kernels' tile
+    addressing: held bands, frame-space clamping, K1's +-2 redundant rows."""
+
+    def __init__(self, W, H, n, halo):
+        from rfx_amd import tiling
+        from rfx_amd.context import Context
+        self.W, self.H = W, H
+        self.tiles = tiling.split_rows(H, n)
+        self.ctxs = [Context(W, H, tile_y0=y0, tile_rows=rows, halo_rows=halo) for (y0, rows) in self.tiles]
+        self.halo = halo
+
+    def _exchange(self, texs):
+        from rfx_amd import abi  # noqa: F401
+        for tex in texs:
+            rows = [c.download(tex, y0, n) for c, (y0, n) in zip(self.ctxs, self.tiles)]
+            for i, c in enumerate(self.ctxs):
+                y0, n = self.tiles[i]
+                if i + 1 < len(self.ctxs):
+                    c.upload(tex, rows[i + 1][:self.halo], y0 + n, self.halo)
+                if i > 0:
+                    c.upload(tex, rows[i - 1][-self.halo:], y0 - self.halo, self.halo)
+
+    # the renderer interface used by rfx_amd.effect
+    def held_rows(self, tex):
+        return (0, 128) if tex == 4 else (0, self.H)
+
+    def upload(self, tex, array, row0=None, rows=None):
+        for c in self.ctxs:
+            r0, n = c.held_rows(tex)
+            c.upload(tex, array[r0:r0 + n], r0, n)
+
+    def ssgi_march(self, p):
+        for c in self.ctxs:
+            c.ssgi_march(p)
+
+    def temporal_reproject(self, p):
+        for c in self.ctxs:
+            c.temporal_reproject(p)
+
+    def poisson_denoise(self, p):
+        for c in self.ctxs:
+            c.poisson_denoise(p)
+
+    def compose(self, p):
+        for c in self.ctxs:
+            c.compose(p)
+
+    def after_temporal_pass(self):
+        from rfx_amd import abi
+        self._exchange((abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1))
+
+    def after_denoise_pass(self, i, u):
+        from rfx_amd import abi
+        self._exchange((abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1) if u.writeToB else (abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1))
+
+    def after_compose_pass(self):
+        from rfx_amd import abi
+        parts = [c.download(abi.TEX_COMPOSE, y0, n) for c, (y0, n) in zip(self.ctxs, self.tiles)]
+        full = np.concatenate(parts, axis=0)
+        for c in self.ctxs:
+            c.upload(abi.TEX_COMPOSE, full)
+
+    def gather(self, tex):
+        return np.concatenate([c.download(tex, y0, n) for c, (y0, n) in zip(self.ctxs, self.tiles)], axis=0)
+
+
+@pytest.mark.parametrize("ntiles", [2, 3])
+def test_row_tiled_chain_is_bit_identical_to_single_context(ntiles):
+    import types
+    from rfx_amd import abi, tiling
+    from rfx_amd.context import Context
+    from rfx_amd.effect import SSGIEffect
+    from rfx_amd.scene import synthetic_frame
+
+    W, H, NF = 200, 132, 3
+    frames = [synthetic_frame(W, H, i) for i in range(NF)]
+    vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
+    halo = tiling.required_halo(3.0, vmax, H)
+
+    def run(renderer):
+        scene = types.SimpleNamespace(frame=None)
+        cam = types.SimpleNamespace(**vars(frames[0].camera))
+        fx = SSGIEffect(None, scene, cam, dict(width=W, height=H), seeds=dict(ssgi=3, denoise=4))
+        for f in frames:
+            scene.frame = f
+            for k, v in vars(f.camera).items():
+                setattr(cam, k, v)
+            fx.update(renderer, None)
+
+    single = Context(W, H)
+    run(single)
+    tiled = _LocalTiles(W, H, ntiles, halo)
+    run(tiled)
+    for tex in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1, abi.TEX_COMPOSE):
+        assert np.array_equal(tiled.gather(tex).view(np.uint8), single.download(tex).view(np.uint8)), abi.TEX_NAMES[tex]
+    assert all(c.halo_violations() == 0 for c in tiled.ctxs)
+    # an undersized halo is detected, not silently wrong
+    bad = _LocalTiles(W, H, 2, 1)
+    run(bad)
+    assert sum(c.halo_violations() for c in bad.ctxs) > 0

@@ -1,0 +1,135 @@
+"""The Node host (realism-effects_amd/js, N-API addon) against the Python host.
+
+CPU: same option surface / defaults, and the SAME C-ABI call sequence with the same parameter
+values for a 3-frame run (a recording renderer on both sides).
+GPU (-m gpu): run_dump.js drives the real library over dumped frames; its outputs must be
+bit-identical to the Python host's (both are thin drivers of the same librfx_hip.so)."""
+import json
+import os
+import shutil
+import subprocess
+import types
+
+import numpy as np
+import pytest
+
+from rfx_amd import abi, effect
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JS = os.path.join(ROOT, "realism-effects_amd", "js")
+node = shutil.which("node")
+pytestmark = pytest.mark.skipif(node is None, reason="node not installed")
+
+RECORDER = r"""
+const fx = require(process.argv[1] + "/effects")
+const cam = JSON.parse(process.argv[2])
+const calls = []
+const r5 = x => Math.round(x * 1e5) / 1e5
+const R = {
+  uploadPlane() {},
+  ssgiMarch(u) { calls.push(["ssgi", u.steps, u.refineSteps, u.useDirectLight, u.rayDistance, u.thickness, u.blueNoiseIndex]) },
+  temporalReproject(u) { calls.push(["temporal", u.keepData, u.fullAccumulate, u.textureCount, u.inputType, u.reprojectSpecular, u.logTransform, r5(u.confidencePower), u.neighborhoodClampIntensity, u.maxBlend]) },
+  poissonDenoise(u) { calls.push(["denoise", u.inputIsTemporal, u.writeToB, u.radius, u.normalPhi, u.roughnessPhi, u.specularPhi, u.isTextureSpecular, u.blueNoiseIndex]) },
+  compose(u) { calls.push(["compose", u.inputType]) }
+}
+const e = new fx.SSGIEffect(null, { frame: {} }, cam, { width: 32, height: 16 }, { ssgi: 10, denoise: 20 })
+e.update(R, null); e.update(R, null)
+e.radius = 5; e.denoiseIterations = 2; e.steps = "8"; e.denoiseKernel = 3
+e.update(R, null)
+const t = new fx.TRAAEffect({}, cam, new fx.VelocityDepthNormalPass({}, cam), { fullAccumulate: true, maxBlend: 0.5 }).temporalParams()
+console.log(JSON.stringify({ calls, defaults: fx.SSGIEffect.DefaultOptions, traa: [t.textureCount, t.inputType, t.logTransform, t.maxBlend, t.confidencePower, t.neighborhoodClampIntensity] }))
+"""
+
+
+class Rec:
+    def __init__(self):
+        self.calls = []
+        self.W, self.H = 32, 16
+
+    def held_rows(self, tex):
+        return 0, 16
+
+    def upload(self, *a, **k):
+        pass
+
+    def ssgi_march(self, p):
+        self.calls.append(["ssgi", p.steps, p.refineSteps, p.useDirectLight, p.rayDistance, p.thickness, p.blueNoiseIndex])
+
+    def temporal_reproject(self, p):
+        self.calls.append(["temporal", p.keepData, p.fullAccumulate, p.textureCount, p.inputType, list(p.reprojectSpecular), p.logTransform,
+                           round(p.confidencePower, 5), p.neighborhoodClampIntensity, p.maxBlend])
+
+    def poisson_denoise(self, p):
+        self.calls.append(["denoise", p.inputIsTemporal, p.writeToB, p.radius, p.normalPhi, p.roughnessPhi, p.specularPhi, list(p.isTextureSpecular),
+                           p.blueNoiseIndex])
+
+    def compose(self, p):
+        self.calls.append(["compose", p.inputType])
+
+
+def test_js_and_python_hosts_issue_the_same_calls():
+    from rfx_amd.scene import synthetic_frame
+    f = synthetic_frame(32, 16, 0)
+    camd = {k: [float(x) for x in np.asarray(getattr(f.camera, k)).ravel()] for k in
+            ("projectionMatrix", "projectionMatrixInverse", "matrixWorld", "matrixWorldInverse", "position", "quaternion")}
+    camd.update(near=f.camera.near, far=f.camera.far)
+    out = subprocess.check_output([node, "-e", RECORDER, JS, json.dumps(camd)], cwd=JS)
+    js = json.loads(out)
+
+    scene = types.SimpleNamespace(frame=f)
+    fx = effect.SSGIEffect(None, scene, f.camera, dict(width=32, height=16), seeds=dict(ssgi=10, denoise=20))
+    r = Rec()
+    fx.update(r, None)
+    fx.update(r, None)
+    fx.radius = 5
+    fx.denoiseIterations = 2
+    fx.steps = "8"
+    fx.denoiseKernel = 3
+    fx.update(r, None)
+    assert js["calls"] == json.loads(json.dumps(r.calls))
+    assert js["defaults"] == json.loads(json.dumps(effect.defaultSSGIOptions))
+    t = effect.TRAAEffect(scene, f.camera, effect.VelocityDepthNormalPass(scene, f.camera), dict(fullAccumulate=True, maxBlend=0.5)).temporal_params()
+    assert js["traa"] == [t.textureCount, t.inputType, t.logTransform, pytest.approx(t.maxBlend), t.confidencePower, t.neighborhoodClampIntensity]
+
+
+def test_addon_loads_and_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = subprocess.run([node, "-e", "const r=require('./index'); console.log(r.abiVersion()); new r.Renderer(64,64)"], cwd=JS, capture_output=True,
+                       text=True)
+    assert p.stdout.strip() == str(abi.RFX_ABI_VERSION)
+    assert p.returncode != 0 and "rfx_create failed" in p.stderr
+
+
+@pytest.mark.gpu
+def test_node_host_drives_the_gpu_bit_identically(tmp_path):
+    from rfx_amd.context import Context
+    from rfx_amd.dump import write_dump
+    from rfx_amd.scene import synthetic_frame
+    W, H = 160, 96
+    frames = [synthetic_frame(W, H, i) for i in range(2)]
+    dirs = []
+    for i, f in enumerate(frames):
+        d = str(tmp_path / ("dump%d" % i))
+        write_dump(d, f)
+        dirs.append(d)
+    out = str(tmp_path / "js_out")
+    res = subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", out, "--steps", "12", "--refineSteps", "3"], text=True)
+    assert json.loads(res.strip().splitlines()[-1])["frames"] == 2
+
+    scene = types.SimpleNamespace(frame=None)
+    cam = types.SimpleNamespace(**vars(frames[0].camera))
+    fx = effect.SSGIEffect(None, scene, cam, dict(width=W, height=H, steps=12, refineSteps=3), seeds=dict(ssgi=11, denoise=22), half_store_rtz=True)
+    ctx = Context(W, H)
+    for f in frames:
+        scene.frame = f
+        for k, v in vars(f.camera).items():
+            setattr(cam, k, v)
+        fx.update(ctx, None)
+    for name, tex in (("compose", abi.TEX_COMPOSE), ("denoise_b0", abi.TEX_DENOISE_B0), ("denoise_b1", abi.TEX_DENOISE_B1), ("temporal0", abi.TEX_TEMPORAL0),
+                      ("ssgi", abi.TEX_SSGI)):
+        py = ctx.download(tex)
+        js = np.fromfile(os.path.join(out, name + ".bin"), py.dtype).reshape(py.shape)
+        assert np.array_equal(py.view(np.uint8), js.view(np.uint8)), name
+    ctx.close()
