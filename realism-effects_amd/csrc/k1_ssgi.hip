@@ -112,7 +112,7 @@ RFX_DEV float3 k1_do_sample(const MarchCtx &m, const FrameDims &d, const K1Args 
         const float border = 0.15f;
         float bf = k1_smoothstep(0.0f, border, coords.x) * k1_smoothstep(1.0f, 1.0f - border, coords.x) * k1_smoothstep(0.0f, border, coords.y) *
                    k1_smoothstep(1.0f, 1.0f - border, coords.y);
-        bf = sqrtf(bf);
+        bf = rfx_sqrt(bf);
         ssgi = rfx_mix(make_float3(0.f, 0.f, 0.f), gi, bf);
         if (allowMissed && 0.0f > rfx_lum(ssgi)) ssgi = make_float3(0.f, 0.f, 0.f);  // :430-436 with envMapSample == 0
     }

@@ -339,6 +339,8 @@ int rfx_poisson_denoise(rfx_ctx *c, const rfx_denoise_params *p) {
     blue_noise_shift(p->blueNoiseIndex, &A.shift_x, &A.shift_y);
     A.out0 = wview(c, out0); A.out1 = wview(c, out1);
     A.p = *p;
+    static const int force_generic = getenv("RFX_K3_GENERIC") ? atoi(getenv("RFX_K3_GENERIC")) : 0;
+    A.force_generic = force_generic;
     HIPCHK(c, rfx_launch_k3(A, c->stream));
     return RFX_OK;
 }

@@ -23,7 +23,7 @@ RFX_DEV float rfx_d_gtr2(float roughness, float NoH) {
 // SmithG  :117-121
 RFX_DEV float rfx_smith_g(float NDotV, float alphaG) {
     float a = alphaG * alphaG, b = NDotV * NDotV;
-    return (2.0f * NDotV) / (NDotV + sqrtf(a + b - a * b));
+    return (2.0f * NDotV) / (NDotV + rfx_sqrt(a + b - a * b));
 }
 // GGXVNDFPdf  :123-127
 RFX_DEV float rfx_ggx_vndf_pdf(float NoH, float NoV, float roughness) {
@@ -52,20 +52,20 @@ RFX_DEV float3 rfx_sample_ggx_vndf(float3 V, float ax, float ay, float r1, float
     float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
     float3 T1;
     if (lensq > 0.0f) {
-        float is = 1.0f / sqrtf(lensq);
+        float is = rfx_rsqrt(lensq);
         T1 = make_float3(-Vh.y * is, Vh.x * is, 0.0f * is);
     } else {
         T1 = make_float3(1.0f, 0.0f, 0.0f);
     }
     float3 T2 = rfx_cross(Vh, T1);
-    float r = sqrtf(r1);
+    float r = rfx_sqrt(r1);
     float phi = 2.0f * RFX_PI * r2;
     float sp, cp;
-    __sincosf(phi, &sp, &cp);
+    rfx_sincos(phi, sp, cp);
     float t1 = r * cp, t2 = r * sp;
     float s = 0.5f * (1.0f + Vh.z);
-    t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
-    float k = sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2));
+    t2 = (1.0f - s) * rfx_sqrt(1.0f - t1 * t1) + s * t2;
+    float k = rfx_sqrt(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2));
     float3 Nh = (T1 * t1 + T2 * t2) + Vh * k;
     return rfx_normalize(make_float3(ax * Nh.x, ay * Nh.y, fmaxf(0.0f, Nh.z)));
 }
@@ -80,10 +80,10 @@ RFX_DEV float3 rfx_to_world(float3 X, float3 Y, float3 Z, float3 V) { return (X 
 RFX_DEV float3 rfx_reflect(float3 I, float3 N) { return I - N * (2.0f * rfx_dot(N, I)); }
 // cosineSampleHemisphere  :183-191
 RFX_DEV float3 rfx_cosine_sample_hemisphere(float3 n, float ux, float uy) {
-    float r = sqrtf(ux), theta = 2.0f * RFX_PI * uy;
+    float r = rfx_sqrt(ux), theta = 2.0f * RFX_PI * uy;
     float st, ct;
-    __sincosf(theta, &st, &ct);
+    rfx_sincos(theta, st, ct);
     float3 b = rfx_normalize(rfx_cross(n, make_float3(0.0f, 1.0f, 1.0f)));
     float3 t = rfx_cross(b, n);
-    return rfx_normalize((b * (r * st) + n * sqrtf(1.0f - ux)) + t * (r * ct));
+    return rfx_normalize((b * (r * st) + n * rfx_sqrt(1.0f - ux)) + t * (r * ct));
 }

@@ -141,17 +141,30 @@ RFX_DEV float3 operator*(float3 a, float s) { return make_float3(a.x * s, a.y * 
 RFX_DEV float3 operator-(float3 a) { return make_float3(-a.x, -a.y, -a.z); }
 RFX_DEV float rfx_dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RFX_DEV float3 rfx_cross(float3 a, float3 b) { return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-RFX_DEV float3 rfx_normalize(float3 a) { return a * (1.0f / sqrtf(rfx_dot(a, a))); }
-RFX_DEV float rfx_length(float3 a) { return sqrtf(rfx_dot(a, a)); }
+// Hardware transcendental set (v_exp_f32 / v_log_f32 / v_sqrt_f32 / v_rsq_f32 / v_rcp_f32: 1 ulp).  The libm-grade
+// expf/logf/powf/sqrtf that hipcc emits by default cost 10-100x more VALU issue slots (range reduction, denormal
+// scaling, Newton fix-ups) for accuracy the 1e-3 parity budget cannot see; the llvmpipe oracle's own exp/log/pow are
+// polynomial approximations of similar accuracy.
+RFX_DEV float rfx_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+RFX_DEV float rfx_log2(float x) { return __builtin_amdgcn_logf(x); }
+RFX_DEV float rfx_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+RFX_DEV float rfx_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+RFX_DEV float rfx_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+RFX_DEV float3 rfx_normalize(float3 a) { return a * rfx_rsqrt(rfx_dot(a, a)); }
+RFX_DEV float rfx_length(float3 a) { return rfx_sqrt(rfx_dot(a, a)); }
 RFX_DEV float rfx_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 RFX_DEV float3 rfx_mix(float3 x, float3 y, float a) { return make_float3(rfx_mix(x.x, y.x, a), rfx_mix(x.y, y.y, a), rfx_mix(x.z, y.z, a)); }
 RFX_DEV float rfx_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 RFX_DEV float rfx_lum(float3 c) { return 0.2125f * c.x + 0.7154f * c.y + 0.0721f * c.z; }
-// transcendental set: hardware v_exp/v_log/v_sin/v_cos paths (<= ~1e-6 rel. error, far inside the
-// 1e-3 parity budget; the llvmpipe oracle's own exp/log/pow are polynomial approximations too)
-RFX_DEV float rfx_exp(float x) { return __expf(x); }
-RFX_DEV float rfx_log(float x) { return __logf(x); }
-RFX_DEV float rfx_pow(float x, float y) { return __powf(x, y); }
+RFX_DEV float rfx_exp(float x) { return rfx_exp2(x * 1.4426950408889634f); }
+RFX_DEV float rfx_log(float x) { return rfx_log2(x) * 0.6931471805599453f; }
+RFX_DEV float rfx_pow(float x, float y) { return rfx_exp2(y * rfx_log2(x)); }  // GLSL pow: undefined for x < 0
+// sin/cos of an angle in [0, 2pi]: v_sin_f32 / v_cos_f32 take revolutions
+RFX_DEV void rfx_sincos(float a, float &s, float &c) {
+    const float r = a * 0.15915494309189535f;
+    s = __builtin_amdgcn_sinf(r);
+    c = __builtin_amdgcn_cosf(r);
+}
 
 // column-major mat4 (three.js Matrix4.elements).  M * vec4(x,y,z,w)
 RFX_DEV float4 rfx_mat_mul(const float *M, float x, float y, float z, float w) {
@@ -214,7 +227,7 @@ RFX_DEV Material rfx_get_material(uint4 g) {
     if (WITH_EMISSIVE) {
         float ex = rfx_byte_unorm(g.w & 0xffu), ey = rfx_byte_unorm((g.w >> 8) & 0xffu), ez = rfx_byte_unorm((g.w >> 16) & 0xffu);
         float ea = rfx_byte_unorm(g.w >> 24);
-        float sc = exp2f(ea * 255.0f - 128.0f); // decodeRGBE8 :136-141
+        float sc = rfx_exp2(ea * 255.0f - 128.0f); // decodeRGBE8 :136-141
         m.emissive = make_float3(ex * sc, ey * sc, ez * sc);
     } else {
         m.emissive = make_float3(0.f, 0.f, 0.f);

@@ -35,6 +35,9 @@ struct K3Args {
     int shift_x, shift_y;
     TexViewW out0, out1;
     rfx_denoise_params p;
+    int force_generic;  // development switch (env RFX_K3_GENERIC=1): use the untiled kernel for any radius
+    struct { int Rx, Ry, LW, LH; } tile;  // filled by the launcher
+    float tap_ox[8], tap_oy[8];           // POISSON[k] / resolution, filled by the launcher
 };
 
 struct K4Args {

@@ -39,12 +39,15 @@ def split_rows(height: int, world: int):
     return list(zip(starts, rows))
 
 
-def required_halo(radius: float, max_abs_velocity_y: float, frame_height: int) -> int:
+def required_halo(radius: float, max_abs_velocity_y: float, frame_height: int, frame_width: int | None = None) -> int:
     """Rows of halo that make the tiled result exact:
-       K3: taps within radius*flatness <= radius px, +1 for the bilinear footprint, +1 for rounding
+       K3: the reference rotates the Poisson offsets in UV space (`rm * (offset / resolution)`,
+           poisson_denoise.frag:183-189), so the tap footprint is radius*max(1, H/W) ROWS high
+           (and radius*max(1, W/H) columns wide), +1 for the bilinear footprint, +1 for rounding
        K2: history bicubic at vUv - velocity: |v_y|*H rows + 2 texels of Catmull-Rom + 1 bilinear;
            K1 output neighbourhood +-2 rows (recomputed locally)."""
-    k3 = int(math.ceil(radius)) + 2
+    aspect_rows = max(1.0, frame_height / frame_width) if frame_width else 1.0
+    k3 = int(math.ceil(radius * aspect_rows)) + 2
     k2 = int(math.ceil(abs(max_abs_velocity_y) * frame_height)) + 4
     return max(k3, k2, 2)
 

@@ -173,7 +173,7 @@ def test_row_tiled_chain_is_bit_identical_to_single_context(ntiles):
     W, H, NF = 200, 132, 3
     frames = [synthetic_frame(W, H, i) for i in range(NF)]
     vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
-    halo = tiling.required_halo(3.0, vmax, H)
+    halo = tiling.required_halo(3.0, vmax, H, W)
 
     def run(renderer):
         scene = types.SimpleNamespace(frame=None)

@@ -36,7 +36,7 @@ def _worker(rank, world, port, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
     vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
-    halo = tiling.required_halo(3.0, vmax, H)
+    halo = tiling.required_halo(3.0, vmax, H, W)
     y0, rows = tiling.split_rows(H, world)[rank]
     inner = OracleRenderer(W, H, y0, rows, halo)
     tensors = {}
@@ -87,5 +87,6 @@ def test_split_rows_even_boundaries_and_halo():
         tiles = tiling.split_rows(Hh, n)
         assert sum(r for _, r in tiles) == Hh and all(y % 2 == 0 for y, _ in tiles)
         assert tiles[0][0] == 0 and all(tiles[i][0] + tiles[i][1] == tiles[i + 1][0] for i in range(n - 1))
-    assert tiling.required_halo(3.0, 0.0, 2160) == 5
-    assert tiling.required_halo(3.0, 0.005, 2160) == 15
+    assert tiling.required_halo(3.0, 0.0, 2160, 3840) == 5
+    assert tiling.required_halo(3.0, 0.005, 2160, 3840) == 15
+    assert tiling.required_halo(3.0, 0.0, 3840, 2160) == 8  # portrait: the UV-space rotation stretches the tap footprint vertically
