@@ -120,8 +120,7 @@ RFX_DEV float3 k1_do_sample(const MarchCtx &m, const FrameDims &d, const K1Args 
     return make_float3(ssgi.x / pdf, ssgi.y / pdf, ssgi.z / pdf);
 }
 
-__global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
-    const FrameDims d = A.dims;
+RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = A.y0 + blockIdx.y * 4 + threadIdx.y;
     if (x >= d.W || y >= A.y1) return;
@@ -216,6 +215,13 @@ __global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
     }
     *outp = rfx_pack_two_vec4(make_float4(diffuseGI.x, diffuseGI.y, diffuseGI.z, mat.roughness),
                               make_float4(specularGI.x, specularGI.y, specularGI.z, rayLength));
+}
+
+__global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
+    FrameDims d = A.dims;
+    d.viol = 0;
+    k1_ssgi_march_body(A, d);
+    rfx_flush_violations(d);
 }
 
 }  // namespace

@@ -2,10 +2,21 @@
 // neighbourhood clamp and age-driven accumulation.  Replaces `renderer.render` of
 // src/temporal-reproject/TemporalReprojectPass.js:192-193 with the fragment program
 // src/temporal-reproject/shader/temporal_reproject.frag (+ reproject.frag), PERSPECTIVE_CAMERA.
+//
+// A 64x8-pixel workgroup tile with a 2-texel apron is staged through LDS once: the packed K1 output
+// is unpacked (8 halfs -> two float4) and the velocity texel is decoded (normal + depth) ONE time per
+// texel, so the (2r+1)^2 neighbourhood AABB of both textures (up to 50 taps per pixel) and the 2x2-quad
+// derivatives read LDS instead of re-fetching and re-unpacking global texels.  The history taps
+// (5 bilinear taps x 2 textures at the reprojected uv) and the validation fetch stay global gathers:
+// their position is data dependent.
 #include "rfx_device.h"
 #include "rfx_kernels.h"
 
 namespace {
+
+constexpr int TW = 64, TH = 8, AP = 2;            // tile, apron (neighbourhood radius <= 2)
+constexpr int LW = TW + 2 * AP, LH = TH + 2 * AP;  // 68 x 12 staged texels
+constexpr int NT = TW * TH;
 
 struct VND {
     float vx, vy, depth;
@@ -22,8 +33,9 @@ RFX_DEV VND k2_vnd(uint4 t) {
 }
 // screenSpaceToWorldSpace reproject.frag:21-28
 RFX_DEV float3 k2_ss_to_ws(float u, float v, float depth, const float *matWorld, const float *projInv) {
-    float4 clip = rfx_mat_mul(projInv, (u - 0.5f) * 2.0f, (v - 0.5f) * 2.0f, (depth - 0.5f) * 2.0f, 1.0f);
-    float4 w = rfx_mat_mul(matWorld, clip.x / clip.w, clip.y / clip.w, clip.z / clip.w, clip.w / clip.w);
+    const float4 clip = rfx_mat_mul(projInv, (u - 0.5f) * 2.0f, (v - 0.5f) * 2.0f, (depth - 0.5f) * 2.0f, 1.0f);
+    const float iw = rfx_rcp(clip.w);
+    const float4 w = rfx_mat_mul(matWorld, clip.x * iw, clip.y * iw, clip.z * iw, clip.w * iw);
     return make_float3(w.x, w.y, w.z);
 }
 // validateReprojectedUV reproject.frag:130-167 (the angleMix / lastViewAngle computation is dead code)
@@ -33,10 +45,10 @@ RFX_DEV float k2_validate(const K2Args &A, const FrameDims &d, float ru, float r
     const float3 lastWorldPos = k2_ss_to_ws(ru, rv, last.depth, A.p.prevCamera.matrixWorld, A.p.prevCamera.projectionMatrixInverse);
     const float3 dp = worldPos - lastWorldPos;
     float disoccl = 0.0f;
-    disoccl += rfx_length(dp) / 10.0f * distFactor;                              // worldDistanceDisocclusionCheck
-    disoccl += fabsf(rfx_dot(dp, worldNormal)) / 20.0f * distFactor;              // planeDistanceDisocclusionCheck
-    disoccl += fminf(1.0f - rfx_dot(worldNormal, last.normal), 1.0f) / 1.0f * distFactor;  // normalDisocclusionCheck
-    float conf = fmaxf(1.0f - fminf(disoccl, 1.0f), 0.0f);
+    disoccl += rfx_length(dp) * 0.1f * distFactor;                                 // worldDistanceDisocclusionCheck (/ 10.)
+    disoccl += fabsf(rfx_dot(dp, worldNormal)) * 0.05f * distFactor;                // planeDistanceDisocclusionCheck (/ 20.)
+    disoccl += fminf(1.0f - rfx_dot(worldNormal, last.normal), 1.0f) * distFactor;  // normalDisocclusionCheck (/ 1.)
+    const float conf = fmaxf(1.0f - fminf(disoccl, 1.0f), 0.0f);
     return rfx_pow(conf, A.p.confidencePower);
 }
 
@@ -46,7 +58,7 @@ RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &te
     const float its[2] = {A.invW, A.invH}, P[2] = {pu, pv};
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const float UV = P[k] / its[k];
+        const float UV = P[k] * rfx_rcp(its[k]);
         const float tc = floorf(UV - 0.5f) + 0.5f;
         const float f = UV - tc, f2 = f * f, f3 = f2 * f;
         const float w0 = f2 - 0.5f * (f3 + f);
@@ -57,7 +69,7 @@ RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &te
         Wb[k] = w1 + w2;
         Wc[k] = w3;
         S0[k] = (tc - 1.0f) * its[k];
-        S1[k] = (tc + w2 / Wb[k]) * its[k];
+        S1[k] = (tc + w2 * rfx_rcp(Wb[k])) * its[k];
         S2[k] = (tc + 2.0f) * its[k];
     }
     const float sw0 = Wb[0] * Wa[1], sw1 = Wa[0] * Wb[1], sw2 = Wb[0] * Wb[1], sw3 = Wc[0] * Wb[1], sw4 = Wb[0] * Wc[1];
@@ -66,7 +78,7 @@ RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &te
     const float4 Cc = rfx_fetch_h4_linear(tex, d, S1[0], S1[1]);
     const float4 Cr = rfx_fetch_h4_linear(tex, d, S2[0], S1[1]);
     const float4 Cb = rfx_fetch_h4_linear(tex, d, S1[0], S2[1]);
-    const float wm = 1.0f / ((((sw0 + sw1) + sw2) + sw3) + sw4);
+    const float wm = rfx_rcp((((sw0 + sw1) + sw2) + sw3) + sw4);
     float4 r;
     r.x = fmaxf(((((Ct.x * sw0 + Cl.x * sw1) + Cc.x * sw2) + Cr.x * sw3) + Cb.x * sw4) * wm, 0.0f);
     r.y = fmaxf(((((Ct.y * sw0 + Cl.y * sw1) + Cc.y * sw2) + Cr.y * sw3) + Cb.y * sw4) * wm, 0.0f);
@@ -91,33 +103,50 @@ RFX_DEV float4 k2_unpack(uint4 t, int idx) {
     return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
 }
 
+struct Tile {
+    float4 tex[2][LH * LW];  // unpacked input texels: [0] = diffuse (or the raw single texture), [1] = specular
+    float4 vn[LH * LW];      // velocity texel: world normal.xyz, depth
+    float2 vel[LH * LW];     // velocity.xy
+};
+
 template <int INPUT_TYPE, int TC, bool LOGT>
-__global__ __launch_bounds__(256) void k2_temporal_reproject(K2Args A) {
-    const FrameDims d = A.dims;
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = A.y0 + blockIdx.y * 4 + threadIdx.y;
-    if (x >= d.W || y >= A.y1) return;
+RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
+    __shared__ Tile s;
     const rfx_temporal_params &p = A.p;
-    const float u = ((float)x + 0.5f) / d.fW, v = ((float)y + 0.5f) / d.fH;
-    const uint4 *velp = (const uint4 *)A.velocity.ptr;
-    const uint4 *inp_p = (const uint4 *)A.ssgi.ptr;
+    const int tx0 = blockIdx.x * TW, ty0 = A.y0 + blockIdx.y * TH;
+    const int tid = threadIdx.y * TW + threadIdx.x;
 
-    const VND cur = k2_vnd(velp[rfx_xy_index(d, A.velocity.row0, A.velocity.rows, x, y)]);
-    const uint4 packed = inp_p[rfx_xy_index(d, A.ssgi.row0, A.ssgi.rows, x, y)];
-
-    // 2x2 quad partners for fwidth(depth) / fwidth(worldNormal)
-    const int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
-    const VND xa = k2_vnd(velp[rfx_xy_index(d, A.velocity.row0, A.velocity.rows, qx0, y)]);
-    const VND xb = k2_vnd(velp[rfx_xy_index(d, A.velocity.row0, A.velocity.rows, qx1, y)]);
-    const VND ya = k2_vnd(velp[rfx_xy_index(d, A.velocity.row0, A.velocity.rows, x, qy0)]);
-    const VND yb = k2_vnd(velp[rfx_xy_index(d, A.velocity.row0, A.velocity.rows, x, qy1)]);
-    if (INPUT_TYPE != 1) {  // temporal_reproject.frag:188-193
-        const float fw = fabsf(xb.depth - xa.depth) + fabsf(yb.depth - ya.depth);
-        if (cur.depth == 1.0f && fw == 0.0f) return;  // discard
+    // ---- stage tile + apron (out-of-frame texels are never addressed: CLAMP_TO_EDGE is applied first)
+    for (int i = tid; i < LW * LH; i += NT) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gx = tx0 - AP + lx, gy = ty0 - AP + ly;
+        if (gx < 0 || gx >= d.W || gy < 0 || gy >= d.H || gy > A.y1 - 1 + AP) continue;
+        const uint4 t = ((const uint4 *)A.ssgi.ptr)[(size_t)rfx_local_row(d, A.ssgi.row0, A.ssgi.rows, gy) * d.W + gx];
+        s.tex[0][i] = k2_unpack<INPUT_TYPE>(t, 0);
+        if (INPUT_TYPE == 0) s.tex[1][i] = k2_unpack<INPUT_TYPE>(t, 1);
+        const VND vd = k2_vnd(((const uint4 *)A.velocity.ptr)[(size_t)rfx_local_row(d, A.velocity.row0, A.velocity.rows, gy) * d.W + gx]);
+        s.vn[i] = make_float4(vd.normal.x, vd.normal.y, vd.normal.z, vd.depth);
+        s.vel[i] = make_float2(vd.vx, vd.vy);
     }
-    const float3 fwn = make_float3(fabsf(xb.normal.x - xa.normal.x) + fabsf(yb.normal.x - ya.normal.x),
-                                   fabsf(xb.normal.y - xa.normal.y) + fabsf(yb.normal.y - ya.normal.y),
-                                   fabsf(xb.normal.z - xa.normal.z) + fabsf(yb.normal.z - ya.normal.z));
+    __syncthreads();
+
+    const int x = tx0 + threadIdx.x, y = ty0 + threadIdx.y;
+    if (x >= d.W || y >= A.y1) return;
+    const int cx = threadIdx.x + AP, cy = threadIdx.y + AP, ci = cy * LW + cx;
+    const float u = ((float)x + 0.5f) / d.fW, v = ((float)y + 0.5f) / d.fH;
+
+    const float4 cvn = s.vn[ci];
+    const float2 cvel = s.vel[ci];
+    const float depth = cvn.w;
+    // 2x2 quad partners for fwidth(depth) / fwidth(worldNormal) (SURVEY.md Appendix C-1)
+    const int qx0 = cy * LW + min(x & ~1, d.W - 1) - tx0 + AP, qx1 = cy * LW + min(x | 1, d.W - 1) - tx0 + AP;
+    const int qy0 = (min(y & ~1, d.H - 1) - ty0 + AP) * LW + cx, qy1 = (min(y | 1, d.H - 1) - ty0 + AP) * LW + cx;
+    const float4 xa = s.vn[qx0], xb = s.vn[qx1], ya = s.vn[qy0], yb = s.vn[qy1];
+    if (INPUT_TYPE != 1) {  // temporal_reproject.frag:188-193
+        const float fw = fabsf(xb.w - xa.w) + fabsf(yb.w - ya.w);
+        if (depth == 1.0f && fw == 0.0f) return;  // discard
+    }
+    const float3 fwn = make_float3(fabsf(xb.x - xa.x) + fabsf(yb.x - ya.x), fabsf(xb.y - xa.y) + fabsf(yb.y - ya.y), fabsf(xb.z - xa.z) + fabsf(yb.z - ya.z));
     const float curvature = rfx_length(fwn);  // getCurvature reproject.frag:265-269
 
     // getTexels + preprocessInput :124-145
@@ -125,13 +154,13 @@ __global__ __launch_bounds__(256) void k2_temporal_reproject(K2Args A) {
     bool sampled[TC];
 #pragma unroll
     for (int i = 0; i < TC; i++) {
-        inp[i] = k2_unpack<INPUT_TYPE>(packed, i);
+        inp[i] = s.tex[i][ci];
         sampled[i] = inp[i].x >= 0.0f;
         const float3 c = k2_to_log<LOGT>(make_float3(fmaxf(inp[i].x, 0.0f), fmaxf(inp[i].y, 0.0f), fmaxf(inp[i].z, 0.0f)));
         inp[i].x = c.x; inp[i].y = c.y; inp[i].z = c.z;
     }
-    const float3 worldNormal = cur.normal;
-    const float3 worldPos = k2_ss_to_ws(u, v, cur.depth, p.camera.matrixWorld, p.camera.projectionMatrixInverse);
+    const float3 worldNormal = make_float3(cvn.x, cvn.y, cvn.z);
+    const float3 worldPos = k2_ss_to_ws(u, v, depth, p.camera.matrixWorld, p.camera.projectionMatrixInverse);
     float rayLength = 0.0f, roughness = 1.0f;  // getRoughnessRayLength :167-176
     if (INPUT_TYPE == 0) {
         rayLength = inp[TC - 1].w;
@@ -143,13 +172,13 @@ __global__ __launch_bounds__(256) void k2_temporal_reproject(K2Args A) {
         roughness = rfx_clamp(ro, 0.0f, 1.0f);
     }
     const float n_ = p.camera.near_, f_ = p.camera.far_;
-    const float viewZ = fabsf((n_ * f_) / ((f_ - n_) * cur.depth - f_));
-    const float distFactor = 1.0f + 1.0f / (viewZ + 1.0f);
+    const float viewZ = fabsf((n_ * f_) * rfx_rcp((f_ - n_) * depth - f_));
+    const float distFactor = 1.0f + rfx_rcp(viewZ + 1.0f);
 
     // computeReprojectedUv :155-165
     float3 rd, rs;
-    rd.x = u - cur.vx;
-    rd.y = v - cur.vy;
+    rd.x = u - cvel.x;
+    rd.y = v - cvel.y;
     rd.z = k2_validate(A, d, rd.x, rd.y, worldPos, worldNormal, distFactor);
     rs = rd;
     if (INPUT_TYPE != 1) {
@@ -158,13 +187,22 @@ __global__ __launch_bounds__(256) void k2_temporal_reproject(K2Args A) {
             const float3 cameraRay = rfx_normalize(worldPos - camPos);
             const float3 hp = camPos + cameraRay * rayLength;
             const float4 r = rfx_mat_mul(A.prevPV, hp.x, hp.y, hp.z, 1.0f);
+            // IEEE divisions: this uv addresses a NEAREST fetch (the validation texel)
             const float hu = (r.x / r.w) * 0.5f + 0.5f, hv = (r.y / r.w) * 0.5f + 0.5f;
             const float conf = k2_validate(A, d, hu, hv, worldPos, worldNormal, distFactor);
             if (hu != -1.0f) rs = make_float3(hu, hv, conf);  // :161-163 falls back to the diffuse triple
         }
     }
-    const float moveFactor = fminf((cur.vx * cur.vx + cur.vy * cur.vy) * 10000.0f, 1.0f);
+    const float moveFactor = fminf((cvel.x * cvel.x + cvel.y * cvel.y) * 10000.0f, 1.0f);
     const size_t oi = (size_t)rfx_local_row(d, A.out0.row0, A.out0.rows, y) * d.W + x;
+
+    // neighbourhood columns/rows with CLAMP_TO_EDGE, as LDS offsets
+    int nxo[5], nyo[5];
+#pragma unroll
+    for (int o = -2; o <= 2; o++) {
+        nxo[o + 2] = min(max(x + o, 0), d.W - 1) - tx0 + AP;
+        nyo[o + 2] = (min(max(y + o, 0), d.H - 1) - ty0 + AP) * LW;
+    }
 
 #pragma unroll
     for (int i = 0; i < TC; i++) {
@@ -180,13 +218,16 @@ __global__ __launch_bounds__(256) void k2_temporal_reproject(K2Args A) {
         } else {
             acca += 1.0f;
             const int cr = (spec && roughness < 0.25f) ? 1 : 2;
-            // clampNeighborhood reproject.frag:83-95 / getNeighborhoodAABB :53-81 (raw neighbour texels)
+            // clampNeighborhood reproject.frag:83-95 / getNeighborhoodAABB :53-81 (raw neighbour texels, centre included)
             const float3 ic = k2_from_log<LOGT>(inrgb);
             float3 mn = ic, mx = ic;
-            for (int ox = -cr; ox <= cr; ox++)
-                for (int oy = -cr; oy <= cr; oy++) {
-                    const float nu = u + (float)ox * A.invW, nv = v + (float)oy * A.invH;
-                    const float4 t = k2_unpack<INPUT_TYPE>(rfx_fetch_u4(A.ssgi, d, nu, nv), (INPUT_TYPE == 0 && spec) ? 1 : 0);
+            const float4 *nt = s.tex[(INPUT_TYPE == 0 && spec) ? 1 : 0];
+#pragma unroll
+            for (int oy = 0; oy < 5; oy++)
+#pragma unroll
+                for (int ox = 0; ox < 5; ox++) {
+                    if (cr == 1 && (ox == 0 || ox == 4 || oy == 0 || oy == 4)) continue;
+                    const float4 t = nt[nyo[oy] + nxo[ox]];
                     if (t.x >= 0.0f) {
                         mn = make_float3(fminf(t.x, mn.x), fminf(t.y, mn.y), fminf(t.z, mn.z));
                         mx = make_float3(fmaxf(t.x, mx.x), fmaxf(t.y, mx.y), fmaxf(t.z, mx.z));
@@ -197,35 +238,43 @@ __global__ __launch_bounds__(256) void k2_temporal_reproject(K2Args A) {
             const float3 clamped = make_float3(rfx_clamp(accrgb.x, mn.x, mx.x), rfx_clamp(accrgb.y, mn.y, mx.y), rfx_clamp(accrgb.z, mn.z, mx.z));
             const float r = spec ? roughness : 1.0f;
             const float aggr = fminf(1.0f, uvc.z * r);
-            const float ci = rfx_mix(0.0f, fminf(1.0f, moveFactor * 50.0f + p.neighborhoodClampIntensity), aggr);
-            const float3 nc = rfx_mix(accrgb, clamped, ci);
+            const float ci2 = rfx_mix(0.0f, fminf(1.0f, moveFactor * 50.0f + p.neighborhoodClampIntensity), aggr);
+            const float3 nc = rfx_mix(accrgb, clamped, ci2);
             const float cd = fminf(rfx_length(nc - accrgb), 1.0f);
             acca *= 1.0f - cd;
             accrgb = nc;
         }
         // accumulate() :42-79
         const float conf = rfx_pow(uvc.z, p.confidencePower);  // second power on purpose (Appendix D-6)
-        float accumBlend = 1.0f - 1.0f / (acca + 1.0f);
+        float accumBlend = 1.0f - rfx_rcp(acca + 1.0f);
         accumBlend = rfx_mix(0.0f, accumBlend, conf);
         float maxValue = (p.fullAccumulate ? 1.0f : p.maxBlend) * p.keepData;
         if (INPUT_TYPE != 1) {
             const float rmax = 0.1f;
             if (spec && roughness >= 0.0f && roughness < rmax) {
-                const float mrv = rfx_mix(0.0f, maxValue, roughness / rmax);
+                const float mrv = rfx_mix(0.0f, maxValue, roughness * 10.0f);
                 maxValue = rfx_mix(maxValue, mrv, fminf(100.0f * moveFactor, 1.0f));
             }
         }
         const float mixv = fminf(accumBlend, maxValue);
-        acca = fminf(65536.0f, 1.0f / (1.0f - mixv) - 1.0f);
+        acca = fminf(65536.0f, rfx_rcp(1.0f - mixv) - 1.0f);
         const float3 o = k2_from_log<LOGT>(rfx_mix(inrgb, accrgb, mixv));
         ((float4 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = make_float4(o.x, o.y, o.z, acca);
     }
 }
 
+template <int INPUT_TYPE, int TC, bool LOGT>
+__global__ __launch_bounds__(NT) void k2_temporal_reproject(K2Args A) {
+    FrameDims d = A.dims;
+    d.viol = 0;
+    k2_body<INPUT_TYPE, TC, LOGT>(A, d);
+    rfx_flush_violations(d);
+}
+
 }  // namespace
 
 hipError_t rfx_launch_k2(const K2Args &A, hipStream_t stream) {
-    dim3 block(64, 4), grid((A.dims.W + 63) / 64, (A.y1 - A.y0 + 3) / 4);
+    dim3 block(TW, TH), grid((A.dims.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH);
     const bool lt = A.p.logTransform != 0;
 #define K2_LAUNCH(IT, TC)                                                                                          \
     do {                                                                                                           \

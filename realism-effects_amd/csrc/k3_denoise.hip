@@ -56,7 +56,7 @@ RFX_DEV void k3_apply(CenterTexel &c, float w, float3 tl, float tapLuma, float l
 RFX_DEV size_t k3_lds_bytes(int n, bool temporal) { return (size_t)n * (16 + 4 + 2 * (temporal ? 16 : 8)); }
 
 template <bool IN_TEMPORAL, int TC>
-__global__ __launch_bounds__(NT) void k3_tiled(K3Args A) {
+RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     extern __shared__ float4 lds[];
     const int Rx = A.tile.Rx, Ry = A.tile.Ry, LW = A.tile.LW, LH = A.tile.LH;
     const int ntex = (LW * LH + 3) & ~3;
@@ -64,7 +64,6 @@ __global__ __launch_bounds__(NT) void k3_tiled(K3Args A) {
     float4 *s_in0 = lds + ntex;                                   // pass 0 view
     uint2 *s_inN = reinterpret_cast<uint2 *>(lds + ntex);         // pass >= 1 view
     float *s_depth = reinterpret_cast<float *>(lds + ntex) + (IN_TEMPORAL ? 8 : 4) * (size_t)ntex;
-    const FrameDims d = A.dims;
     const rfx_denoise_params &p = A.p;
     const int tx0 = blockIdx.x * TW, ty0 = A.y0 + blockIdx.y * TH;
     const int tid = threadIdx.y * TW + threadIdx.x;
@@ -222,8 +221,7 @@ RFX_DEV float4 k3_input(const TexView &t, const FrameDims &d, float u, float v) 
 }
 
 template <bool IN_TEMPORAL, int TC>
-__global__ __launch_bounds__(256) void k3_generic(K3Args A) {
-    const FrameDims d = A.dims;
+RFX_DEV void k3_generic_body(const K3Args &A, const FrameDims &d) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = A.y0 + blockIdx.y * 4 + threadIdx.y;
     if (x >= d.W || y >= A.y1) return;
@@ -303,6 +301,21 @@ __global__ __launch_bounds__(256) void k3_generic(K3Args A) {
         o = make_float3(rfx_exp(o.x) - 1.0f, rfx_exp(o.y) - 1.0f, rfx_exp(o.z) - 1.0f);
         ((uint2 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = rfx_store_half4(o.x, o.y, o.z, c[i].a, p.halfStoreRTZ != 0);
     }
+}
+
+template <bool IN_TEMPORAL, int TC>
+__global__ __launch_bounds__(NT) void k3_tiled(K3Args A) {
+    FrameDims d = A.dims;
+    d.viol = 0;
+    k3_tiled_body<IN_TEMPORAL, TC>(A, d);
+    rfx_flush_violations(d);
+}
+template <bool IN_TEMPORAL, int TC>
+__global__ __launch_bounds__(256) void k3_generic(K3Args A) {
+    FrameDims d = A.dims;
+    d.viol = 0;
+    k3_generic_body<IN_TEMPORAL, TC>(A, d);
+    rfx_flush_violations(d);
 }
 
 }  // namespace

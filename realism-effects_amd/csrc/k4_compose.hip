@@ -7,8 +7,7 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void k4_compose(K4Args A) {
-    const FrameDims d = A.dims;
+RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = A.y0 + blockIdx.y * 4 + threadIdx.y;
     if (x >= d.W || y >= A.y1) return;
@@ -57,6 +56,13 @@ __global__ __launch_bounds__(256) void k4_compose(K4Args A) {
     o.z = (mat.diffuse.z * om * (1.0f - F.z) * dgi.z + sgi.z * F.z) + mat.emissive.z;
     o.w = 1.0f;
     ((float4 *)A.out.ptr)[(size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x] = o;
+}
+
+__global__ __launch_bounds__(256) void k4_compose(K4Args A) {
+    FrameDims d = A.dims;
+    d.viol = 0;
+    k4_compose_body(A, d);
+    rfx_flush_violations(d);
 }
 
 }  // namespace

@@ -27,16 +27,19 @@ struct TexViewW {
 struct FrameDims {
     int W, H;
     float fW, fH;
-    unsigned int *halo_violations; // device counter (may be null)
+    unsigned int *halo_violations;  // device counter (may be null)
+    mutable unsigned int viol;      // per-lane sticky flag, flushed once by rfx_flush_violations()
 };
 
+// branch-free: clamp into the held band and remember that a clamp happened
 RFX_DEV int rfx_local_row(const FrameDims &d, int row0, int rows, int y) {
-    int l = y - row0;
-    if (l < 0 || l >= rows) {
-        if (d.halo_violations) atomicAdd(d.halo_violations, 1u);
-        l = l < 0 ? 0 : rows - 1;
-    }
-    return l;
+    const int l = y - row0;
+    const int c = min(max(l, 0), rows - 1);
+    d.viol |= (unsigned int)(l != c);
+    return c;
+}
+RFX_DEV void rfx_flush_violations(const FrameDims &d) {
+    if (d.viol && d.halo_violations) atomicAdd(d.halo_violations, 1u);
 }
 
 // nearest CLAMP_TO_EDGE index as x86 cvttss2si + clamp computes it:
