@@ -3,58 +3,162 @@
 // RayMarch :441-475, BinarySearch :477-503) in the MODE_SSGI / PERSPECTIVE_CAMERA /
 // no-env-map variant (the configs carry no env map).
 //
-// One pixel per lane, 64x4-pixel workgroups: the G-buffer/direct-light/output planes are read
-// and written as coalesced 16 B/lane rows; the depth taps of the march are data-dependent
-// gathers into the (L2/MALL-resident) R32F depth plane.
+// One pixel per lane, 64x4-pixel workgroups: the G-buffer / direct-light / output planes are read and
+// written as coalesced 16 B/lane rows.  The march's depth taps are data-dependent gathers anywhere on
+// screen; three things keep them off the HBM/fabric path:
+//   * k1_prepare (one streaming pre-pass per draw) converts the depth plane to VIEW-SPACE Z once per texel
+//     (the same IEEE expression every tap would evaluate, ssgi_utils.frag:9) and reduces it to an 8x8-cell
+//     (min, max) table that stays resident in every XCD's L2 (1 MiB at 4K);
+//   * every tap first consults its cell: when the cell's range proves the texel cannot satisfy
+//     `0 <= z - hitPos.z < thickness` (RayMarch :463) — or fixes the sign BinarySearch tests (:493) — the
+//     exact texel is never fetched.  The decision is exact, not approximate: fp subtraction is monotonic,
+//     so the cell bounds bound the per-texel difference;
+//   * workgroups are mapped to XCDs by image band, so an XCD's L2 holds the neighbourhood its rays visit.
 #include "rfx_brdf.h"
 #include "rfx_kernels.h"
 
 namespace {
 
+constexpr int CELL = 8;  // coarse cell edge in texels
+
 struct MarchCtx {
-    const float *P;  // projectionMatrix
-    const float *depth;
-    int depth_row0, depth_rows;
-    float nearMulFar, farMinusNear, cameraFar;
+    const float *P;            // projectionMatrix (column-major)
+    const float *viewz;        // full-frame view-space Z plane (k1_prepare)
+    const float2 *coarse;      // (min, max) view Z per CELL x CELL block
+    int coarse_w;
     float rayDistance, thickness;
     int steps, refineSteps;
+    bool use_coarse;
 };
 
-RFX_DEV float k1_view_z(const MarchCtx &m, float depth) {  // getViewZ ssgi_utils.frag:7-13
-    return m.nearMulFar / (m.farMinusNear * depth - m.cameraFar);
+// viewSpaceToScreenSpace ssgi_utils.frag:26-33.  PERSP: the projection matrix has the sparsity of a (possibly
+// off-centre / jittered) perspective matrix — P[1,2,3,4,6,7,12,13,15] == 0, P[11] == -1 — so the general
+// mat4*vec4 collapses to the same values (only exact zeros are dropped): x' = P0 x + P8 z, y' = P5 y + P9 z, w = -z.
+// The two quotients share one v_rcp_f32 and get one fused Newton step each (the residual x - w*q is exact in an
+// fma), i.e. they are correctly rounded except in rare double-rounding cases — 7 VALU ops instead of the ~24 of
+// two full IEEE division sequences.  The quotient addresses a NEAREST fetch, so this matters for parity: measured
+// K1 stays >99.9 % bit-identical to the oracle.
+RFX_DEV float k1_div(float x, float w, float r) {
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-w, q, x), r, q);
 }
-RFX_DEV float2 k1_project(const MarchCtx &m, float3 p) {  // viewSpaceToScreenSpace :26-33
-    float4 pc = rfx_mat_mul(m.P, p.x, p.y, p.z, 1.0f);
-    return make_float2((pc.x / pc.w) * 0.5f + 0.5f, (pc.y / pc.w) * 0.5f + 0.5f);
+template <bool PERSP>
+RFX_DEV float2 k1_project(const MarchCtx &m, float3 p) {
+    float px, py, pw;
+    if (PERSP) {
+        px = m.P[0] * p.x + m.P[8] * p.z;
+        py = m.P[5] * p.y + m.P[9] * p.z;
+        pw = -p.z;
+    } else {
+        const float4 pc = rfx_mat_mul(m.P, p.x, p.y, p.z, 1.0f);
+        px = pc.x; py = pc.y; pw = pc.w;
+    }
+    const float r = rfx_rcp(pw);
+    return make_float2(k1_div(px, pw, r) * 0.5f + 0.5f, k1_div(py, pw, r) * 0.5f + 0.5f);
 }
-RFX_DEV float k1_depth_tap(const MarchCtx &m, const FrameDims &d, float2 uv) {
-    return m.depth[rfx_texel_index(d, m.depth_row0, m.depth_rows, uv.x, uv.y)];
+
+struct Tap {
+    int idx;     // texel index into the view-Z plane
+    int cell;    // index into the coarse table
+};
+RFX_DEV Tap k1_tap(const MarchCtx &m, const FrameDims &d, float2 uv) {
+    const int xi = rfx_nearest_idx(uv.x, d.fW, d.W), yi = rfx_nearest_idx(uv.y, d.fH, d.H);
+    Tap t;
+    t.idx = yi * d.W + xi;
+    t.cell = (yi / CELL) * m.coarse_w + (xi / CELL);
+    return t;
+}
+// BinarySearch only tests the sign of z_tap - h (:493)
+RFX_DEV bool k1_behind(const MarchCtx &m, const FrameDims &d, float2 uv, float h) {
+    const Tap t = k1_tap(m, d, uv);
+    if (m.use_coarse) {
+        const float2 mm = m.coarse[t.cell];
+        if (mm.y - h < 0.0f) return false;  // every texel of the cell: z - h < 0
+        if (mm.x - h >= 0.0f) return true;
+    }
+    return m.viewz[t.idx] - h >= 0.0f;
 }
 
 // RayMarch + BinarySearch.  Returns the hit uv; hitPos.x == 1e10 marks a miss.
+// The march positions do not depend on the taps (hitPos_i = origin + dir * sum cs_j), so the taps of NB consecutive
+// steps are issued together: first the NB coarse-cell lookups, then the exact texels of the cells that cannot rule a hit
+// out — two memory round trips per NB steps instead of up to 2*NB dependent ones.  The first hit in step order wins,
+// exactly as in the sequential loop; taps issued past it are discarded.
+template <bool PERSP>
 RFX_DEV float2 k1_ray_march(const MarchCtx &m, const FrameDims &d, float3 dir, float3 &hitPos, float random_b) {
+#ifndef RFX_K1_NB
+#define RFX_K1_NB 2
+#endif
+    constexpr int NB = RFX_K1_NB;
     dir = dir * (m.rayDistance / (float)m.steps);
     float2 uv = make_float2(0.f, 0.f);
-    for (int i = 1; i < m.steps; i++) {
-        const float t = (float)i + random_b - 0.5f;
-        const float cs = 1.0f - rfx_exp(-0.25f * (t * t));
-        hitPos = hitPos + dir * cs;
-        uv = k1_project(m, hitPos);
-        const float z = k1_view_z(m, k1_depth_tap(m, d, uv));
-        const float diff = z - hitPos.z;
-        if (diff >= 0.0f && diff < m.thickness) {
+    for (int i0 = 1; i0 < m.steps; i0 += NB) {
+        float3 pos[NB];
+        float2 uvs[NB];
+        Tap taps[NB];
+        float2 mm[NB];
+        float3 hp = hitPos;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const float t = (float)(i0 + j) + random_b - 0.5f;
+            const float cs = 1.0f - rfx_exp(-0.25f * (t * t));
+            hp = hp + dir * cs;
+            pos[j] = hp;
+            uvs[j] = k1_project<PERSP>(m, hp);
+            taps[j] = k1_tap(m, d, uvs[j]);
+        }
+        bool need[NB];
+        if (m.use_coarse) {
+#pragma unroll
+            for (int j = 0; j < NB; j++) mm[j] = m.coarse[taps[j].cell];
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const float h = pos[j].z;
+                // a hit needs 0 <= z - h < thickness for the texel; the cell range rules it out when max - h < 0 or min - h >= thickness
+                need[j] = !((mm[j].y - h < 0.0f) || (mm[j].x - h >= m.thickness));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; j++) need[j] = true;
+        }
+        float z[NB];
+#pragma unroll
+        for (int j = 0; j < NB; j++) z[j] = need[j] ? m.viewz[taps[j].idx] : 0.0f;
+        int hit = -1;
+#pragma unroll
+        for (int j = NB - 1; j >= 0; j--) {
+            const float diff = z[j] - pos[j].z;
+            if (need[j] && i0 + j < m.steps && diff >= 0.0f && diff < m.thickness) hit = j;
+        }
+        if (hit >= 0) {
+            float3 hpos = pos[0];
+            float2 huv = uvs[0];
+#pragma unroll
+            for (int j = 1; j < NB; j++)
+                if (hit == j) { hpos = pos[j]; huv = uvs[j]; }
+            hitPos = hpos;
+            uv = huv;
             if (m.refineSteps == 0) return uv;
+            // dir was scaled only once; BinarySearch halves it (:481-482)
             dir = dir * 0.5f;
             hitPos = hitPos - dir;
             for (int k = 0; k < m.refineSteps; k++) {
-                uv = k1_project(m, hitPos);
-                const float zz = k1_view_z(m, k1_depth_tap(m, d, uv));
-                const float dd = zz - hitPos.z;
+                uv = k1_project<PERSP>(m, hitPos);
+                const bool behind = k1_behind(m, d, uv, hitPos.z);
                 dir = dir * 0.5f;
-                hitPos = (dd >= 0.0f) ? hitPos - dir : hitPos + dir;
+                hitPos = behind ? hitPos - dir : hitPos + dir;
             }
-            return k1_project(m, hitPos);
+            return k1_project<PERSP>(m, hitPos);
         }
+        // no hit in this batch: continue from the last VALID step of the batch
+        const int last = min(NB, m.steps - i0) - 1;
+        float3 lpos = pos[0];
+        float2 luv = uvs[0];
+#pragma unroll
+        for (int j = 1; j < NB; j++)
+            if (last == j) { lpos = pos[j]; luv = uvs[j]; }
+        hitPos = lpos;
+        uv = luv;
     }
     hitPos = make_float3(10.0e9f, 10.0e9f, 10.0e9f);
     return uv;
@@ -80,6 +184,7 @@ RFX_DEV Angles k1_angles(float3 l, float3 v, float3 n) {  // calculateAngles :93
 }
 
 // doSample :362-439 without env map (getEnvColor == 0).  Returns gi * brdf / pdf.
+template <bool PERSP>
 RFX_DEV float3 k1_do_sample(const MarchCtx &m, const FrameDims &d, const K1Args &A, const Material &mat, float3 viewPos, float3 viewNormal,
                             float roughness, bool isDiffuseSample, float NoV, const Angles &an, float random_b, float3 l, float3 &hitPos) {
     const float cosTheta = fmaxf(0.0f, rfx_dot(viewNormal, l));
@@ -94,7 +199,7 @@ RFX_DEV float3 k1_do_sample(const MarchCtx &m, const FrameDims &d, const K1Args 
     brdf *= cosTheta;
     pdf = fmaxf(0.00001f, pdf);
     hitPos = viewPos;
-    const float2 coords = k1_ray_march(m, d, l, hitPos, random_b);
+    const float2 coords = k1_ray_march<PERSP>(m, d, l, hitPos, random_b);
     const bool allowMissed = A.p.missedRays != 0;
     const bool isMissed = hitPos.x == 10.0e9f;
     float3 ssgi = make_float3(0.f, 0.f, 0.f);
@@ -120,9 +225,16 @@ RFX_DEV float3 k1_do_sample(const MarchCtx &m, const FrameDims &d, const K1Args 
     return make_float3(ssgi.x / pdf, ssgi.y / pdf, ssgi.z / pdf);
 }
 
+template <bool PERSP>
 RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = A.y0 + blockIdx.y * 4 + threadIdx.y;
+    // XCD-aware mapping: hardware block b runs on XCD b % 8 (observed, used for speed only); give XCD k the k-th
+    // contiguous eighth of the row-major tile list, i.e. an image band, so its L2 sees a compact part of the depth plane
+    const int nbx = (d.W + 63) / 64, nblocks = gridDim.x;
+    const int per = (nblocks + 7) / 8;
+    const int lb = A.xcd_map ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
+    if (lb >= nblocks) return;
+    const int x = (lb % nbx) * 64 + threadIdx.x;
+    const int y = A.y0 + (lb / nbx) * 4 + threadIdx.y;
     if (x >= d.W || y >= A.y1) return;
     const rfx_ssgi_params &p = A.p;
     const float *C = p.camera.matrixWorld, *Vw = p.camera.matrixWorldInverse;
@@ -142,18 +254,16 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
 
     MarchCtx m;
     m.P = P;
-    m.depth = (const float *)A.depth.ptr;
-    m.depth_row0 = A.depth.row0;
-    m.depth_rows = A.depth.rows;
-    m.nearMulFar = A.nearMulFar;
-    m.farMinusNear = A.farMinusNear;
-    m.cameraFar = p.camera.far_;
+    m.viewz = A.viewz;
+    m.coarse = A.coarse;
+    m.coarse_w = A.coarse_w;
     m.rayDistance = p.rayDistance;
     m.thickness = p.thickness;
     m.steps = p.steps;
     m.refineSteps = p.refineSteps;
+    m.use_coarse = A.use_coarse != 0;
 
-    const float viewZ = k1_view_z(m, depth);
+    const float viewZ = A.viewz[(size_t)y * d.W + x];  // getViewZ(depth) ssgi_utils.frag:7-13, from the pre-pass
     // getViewPosition ssgi_utils.frag:17-24
     const float clipW = P[2 * 4 + 3] * viewZ + P[3 * 4 + 3];
     const float4 pp = rfx_mat_mul(Pi, ((u - 0.5f) * 2.0f) * clipW, ((v - 0.5f) * 2.0f) * clipW, ((viewZ - 0.5f) * 2.0f) * clipW, 1.0f * clipW);
@@ -200,12 +310,12 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     if (isDiffuseSample) {  // :222-242
         const float3 diffuseRay = rfx_cosine_sample_hemisphere(viewNormal, rnd.x, rnd.y);
         const Angles ad = k1_angles(diffuseRay, vv, n);
-        diffuseGI = k1_do_sample(m, d, A, mat, viewPos, viewNormal, roughnessSq, true, NoV, ad, rnd.z, diffuseRay, hitPos);
+        diffuseGI = k1_do_sample<PERSP>(m, d, A, mat, viewPos, viewNormal, roughnessSq, true, NoV, ad, rnd.z, diffuseRay, hitPos);
         diffuseGI = diffuseGI + dl;
     }
     // specular ray, traced every frame — evaluated with the SAME isDiffuseSample flag (:246-265)
     an = k1_angles(specularRay, vv, n);
-    float3 specularGI = k1_do_sample(m, d, A, mat, viewPos, viewNormal, roughnessSq, isDiffuseSample, NoV, an, rnd.z, specularRay, hitPos);
+    float3 specularGI = k1_do_sample<PERSP>(m, d, A, mat, viewPos, viewNormal, roughnessSq, isDiffuseSample, NoV, an, rnd.z, specularRay, hitPos);
     specularGI = specularGI + dl;
 
     float rayLength = 0.0f;  // :284-296
@@ -217,17 +327,66 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
                               make_float4(specularGI.x, specularGI.y, specularGI.z, rayLength));
 }
 
+template <bool PERSP>
 __global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-    k1_ssgi_march_body(A, d);
+    k1_ssgi_march_body<PERSP>(A, d);
     rfx_flush_violations(d);
+}
+
+// Pre-pass: view-space Z per texel (getViewZ, ssgi_utils.frag:9: nearMulFar / (farMinusNear * depth - cameraFar), IEEE)
+// and its (min, max) per 8x8 cell.  64x8-pixel workgroups = 8 cells; 8-lane shuffles reduce a row segment, LDS the rows.
+__global__ __launch_bounds__(512) void k1_prepare(const float *depth, float *viewz, float2 *coarse, int W, int H, int coarse_w, float nearMulFar,
+                                                  float farMinusNear, float cameraFar) {
+    __shared__ float s_min[8][8], s_max[8][8];
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 8 + threadIdx.y;
+    float z = 0.0f;
+    const bool in = x < W && y < H;
+    if (in) {
+        z = nearMulFar / (farMinusNear * depth[(size_t)y * W + x] - cameraFar);
+        viewz[(size_t)y * W + x] = z;
+    }
+    float mn = in ? z : INFINITY, mx = in ? z : -INFINITY;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o));
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    if ((threadIdx.x & 7) == 0) {
+        s_min[threadIdx.y][threadIdx.x >> 3] = mn;
+        s_max[threadIdx.y][threadIdx.x >> 3] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.y == 0 && threadIdx.x < 8) {
+        float a = s_min[0][threadIdx.x], b = s_max[0][threadIdx.x];
+#pragma unroll
+        for (int r = 1; r < 8; r++) {
+            a = fminf(a, s_min[r][threadIdx.x]);
+            b = fmaxf(b, s_max[r][threadIdx.x]);
+        }
+        const int cx = blockIdx.x * 8 + threadIdx.x;
+        if (cx < coarse_w) coarse[(size_t)blockIdx.y * coarse_w + cx] = make_float2(a, b);
+    }
 }
 
 }  // namespace
 
+hipError_t rfx_launch_k1_prepare(const K1Args &A, hipStream_t stream) {
+    dim3 block(64, 8), grid((A.dims.W + 63) / 64, (A.dims.H + 7) / 8);
+    hipLaunchKernelGGL(k1_prepare, grid, block, 0, stream, (const float *)A.depth.ptr, A.viewz, A.coarse, A.dims.W, A.dims.H, A.coarse_w, A.nearMulFar,
+                       A.farMinusNear, A.p.camera.far_);
+    return hipGetLastError();
+}
+
 hipError_t rfx_launch_k1(const K1Args &A, hipStream_t stream) {
-    dim3 block(64, 4), grid((A.dims.W + 63) / 64, (A.y1 - A.y0 + 3) / 4);
-    hipLaunchKernelGGL(k1_ssgi_march, grid, block, 0, stream, A);
+    const int nbx = (A.dims.W + 63) / 64, nby = (A.y1 - A.y0 + 3) / 4;
+    const int nblocks = nbx * nby;
+    dim3 block(64, 4), grid(((nblocks + 7) / 8) * 8);
+    const float *P = A.p.camera.projectionMatrix;
+    const bool persp = P[1] == 0.f && P[2] == 0.f && P[3] == 0.f && P[4] == 0.f && P[6] == 0.f && P[7] == 0.f && P[12] == 0.f && P[13] == 0.f &&
+                       P[15] == 0.f && P[11] == -1.f;
+    if (persp) hipLaunchKernelGGL(k1_ssgi_march<true>, grid, block, 0, stream, A);
+    else hipLaunchKernelGGL(k1_ssgi_march<false>, grid, block, 0, stream, A);
     return hipGetLastError();
 }

@@ -23,6 +23,8 @@ struct rfx_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned int *halo_violations = nullptr;
+    float *viewz = nullptr;    // K1 scratch: view-space Z plane (full frame)
+    float2 *coarse = nullptr;  // K1 scratch: (min,max) view Z per 8x8 cell
     Slot slots[RFX_TEX_COUNT];
     std::string err;
 };
@@ -103,6 +105,8 @@ void rfx_destroy(rfx_ctx *c) {
     for (int i = 0; i < RFX_TEX_COUNT; i++)
         if (c->slots[i].owned && c->slots[i].ptr) hipFree(c->slots[i].ptr);
     if (c->halo_violations) hipFree(c->halo_violations);
+    if (c->viewz) hipFree(c->viewz);
+    if (c->coarse) hipFree(c->coarse);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -277,6 +281,22 @@ int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
     // SSGIPass.js:84-87: computed in JS doubles, then rounded to float uniforms
     A.nearMulFar = (float)((double)p->camera.near_ * (double)p->camera.far_);
     A.farMinusNear = (float)((double)p->camera.far_ - (double)p->camera.near_);
+    A.coarse_w = (c->W + 7) / 8;
+    A.coarse_h = (c->H + 7) / 8;
+    if (!c->viewz) {
+        hipError_t e = hipMalloc((void **)&c->viewz, (size_t)c->W * c->H * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->coarse, (size_t)A.coarse_w * A.coarse_h * sizeof(float2));
+        if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(K1 scratch)", e);
+    }
+    A.viewz = c->viewz;
+    A.coarse = c->coarse;
+    static const int no_coarse = getenv("RFX_K1_NO_COARSE") ? atoi(getenv("RFX_K1_NO_COARSE")) : 0;
+    A.use_coarse = !no_coarse;
+    // band-per-XCD mapping measured SLOWER (1.33 vs 0.99 ms at 4K): sky bands finish early and idle their XCD
+    static const int xcd = getenv("RFX_K1_XCD") ? atoi(getenv("RFX_K1_XCD")) : 0;
+    A.xcd_map = xcd;
+    // the pre-pass runs on EVERY draw: the depth plane is an input that changes every frame
+    HIPCHK(c, rfx_launch_k1_prepare(A, c->stream));
     HIPCHK(c, rfx_launch_k1(A, c->stream));
     return RFX_OK;
 }

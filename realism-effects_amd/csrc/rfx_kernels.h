@@ -15,6 +15,11 @@ struct K1Args {
     TexViewW out;  // RGBA32F holding 8 halfs
     rfx_ssgi_params p;
     float nearMulFar, farMinusNear;
+    float *viewz;    // full-frame view-space Z (context scratch, filled by k1_prepare)
+    float2 *coarse;  // (min, max) view Z per 8x8 cell
+    int coarse_w, coarse_h;
+    int use_coarse;
+    int xcd_map;  // band-per-XCD block mapping (development switch RFX_K1_NO_XCD=1 turns it off)
 };
 
 struct K2Args {
@@ -48,6 +53,7 @@ struct K4Args {
     rfx_compose_params p;
 };
 
+hipError_t rfx_launch_k1_prepare(const K1Args &, hipStream_t);
 hipError_t rfx_launch_k1(const K1Args &, hipStream_t);
 hipError_t rfx_launch_k2(const K2Args &, hipStream_t);
 hipError_t rfx_launch_k3(const K3Args &, hipStream_t);
