@@ -8,9 +8,10 @@
 One "step" = one frame through SSGIEffect.update(): K1 SSGI march (steps 20 / refineSteps 5) ->
 K2 temporal reprojection -> 2 x K3 Poisson denoise (denoiseIterations 1) -> K4 compose, over a
 3840x2160 synthetic G-buffer dump (seed 1234) that is ALREADY RESIDENT in HBM when the timed
-region starts.  N > 1: weak scaling — the frame is 3840 x (2160*N), rank r owns rows
-[2160 r, 2160 (r+1)) and exchanges halo rows with its neighbours over RCCL after K2 and after
-every K3 pass, plus an all-gather of the composed GI (rfx_amd/tiling.py).
+region starts.  N > 1: weak scaling — the frame keeps its 16:9 aspect and grows to N x 8.29 Mpixel
+(e.g. 7680x4320 for N = 4), is cut into N row tiles (one per GPU, 8.29 Mpixel each) which exchange
+halo rows with their neighbours over RCCL after K2 and after every K3 pass, plus an all-gather of
+the composed GI (rfx_amd/tiling.py).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (largest share of the
 step), measured live with hipEvents on the stream the kernels run on; `cpu_baseline` is the
@@ -68,8 +69,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    W, Ht = args.width, args.height
-    H = Ht * world  # weak scaling: the frame grows with the number of GPUs
+    # weak scaling: the frame grows with the number of GPUs at constant aspect, so that the per-pixel work (tap
+    # footprints, ray lengths in pixels) stays what it is on one GPU; every rank owns W*Ht = const pixels
+    W1, H1 = args.width, args.height
+    if world == 1:
+        W, H, Ht = W1, H1, H1
+    else:
+        W = int(round(W1 * world ** 0.5 / 64.0)) * 64
+        Ht = int(W1 * H1 / W) & ~1
+        H = Ht * world
     tiles = [(r * Ht, Ht) for r in range(world)]
     y0, rows = tiles[rank]
 
@@ -78,11 +86,11 @@ def main():
     scene_gen = AnalyticScene(1234)
     opts = dict(width=W, height=H, steps=20, refineSteps=5, denoiseIterations=1)
     # frame 1 of the orbit: non-zero velocity (camera moved 0.5 deg since frame 0)
-    probe = scene_gen.render(W, 8, 1, row0=y0 + rows // 2, rows=8, frame_height=H, vfov_rows=Ht)
+    probe = scene_gen.render(W, 8, 1, row0=y0 + rows // 2, rows=8, frame_height=H)
     vmax = float(np.abs(probe.velocity[..., 1].view(np.float32)).max()) * 1.5 + 1e-4
     halo = 0 if world == 1 else tiling.required_halo(3.0, vmax, H, W)
     b0, b1 = max(0, y0 - halo), min(H, y0 + rows + halo)
-    band = scene_gen.render(W, b1 - b0, 1, row0=b0, rows=b1 - b0, frame_height=H, vfov_rows=Ht)
+    band = scene_gen.render(W, b1 - b0, 1, row0=b0, rows=b1 - b0, frame_height=H)
     log("[rank %d] dump band rows [%d,%d) of %dx%d generated in %.1fs (halo %d)" % (rank, b0, b1, W, H, time.time() - t0, halo))
 
     ctx = Context(W, H, device=local_rank, tile_y0=y0, tile_rows=rows, halo_rows=halo)
@@ -159,7 +167,7 @@ def main():
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: %dx%d per GPU, steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step" % (W, Ht),
+            "config": {"workload": "configs[2]: %dx%d (%.2f Mpixel) per GPU, steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step" % (W, Ht, W * Ht / 1e6),
                        "frame": "%dx%d" % (W, H), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz",
                        "parallelism": "row-tiles x%d, RCCL halo send/recv + compose all-gather" % world if world > 1 else "single GPU"},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
@@ -180,9 +188,53 @@ def main():
     ctx.close()
 
 
+def cpu_baseline_llvmpipe(frame, W, H):
+    """kind "reference": the reference's OWN fragment shaders (assembled by `make -C oracle ref` into
+    oracle/_ref/shaders/, build products) executed by Mesa llvmpipe on this box's host cores through
+    oracle/glref — K1+K2+2xK3+K4 on the same 4K frame, per-draw glFinish-fenced wall time, after two
+    warm-up frames (llvmpipe JIT-compiles on the first draw and re-specialises on the second)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "glref"))
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("LP_NUM_THREADS", str(min(cores, 32)))  # llvmpipe caps its rasteriser threads (LP_MAX_THREADS)
+    import chain
+    from rfx_amd.context import load_blue_noise_table
+    c = chain.GLRefChain(W, H, load_blue_noise_table(), steps=20, refineSteps=5, denoiseIterations=1)
+    c.upload_frame(frame)
+
+    def one(i):
+        c.ssgi(frame.camera, 100 + i)
+        c.temporal(frame.camera)
+        c.denoise(frame.camera, [200 + 2 * i, 201 + 2 * i])
+        c.compose(frame.camera)
+        return c.ms["ssgi"] + c.ms["temporal"] + sum(c.ms["denoise"]) + c.ms["compose"]
+
+    one(0)
+    one(1)
+    ms, n, t0 = [], 0, time.perf_counter()
+    while n < 5 and (time.perf_counter() - t0 < 20.0 or n == 0):
+        ms.append(one(2 + n))
+        n += 1
+    med = sorted(ms)[len(ms) // 2]
+    return {"value": round(W * H / med / 1e3, 3), "unit": "Mpixels/s", "cores": int(os.environ["LP_NUM_THREADS"]), "kind": "reference",
+            "sample": "median of %d frames of the reference GLSL (ssgi/temporal/2x denoise/compose) on llvmpipe over the same %dx%d frame, "
+                      "%.0f ms per frame; %s; box has %d cores, LP_NUM_THREADS=%s" % (n, W, H, med, chain.GL.info(), cores, os.environ["LP_NUM_THREADS"])}
+
+
 def cpu_baseline(frame, fx, W, H, sample_rows):
-    """The oracle (oracle/rfx_oracle.c, kind "port": scalar C restatement, OpenMP over rows) on the
-    host cores of this box: the same chain on a bounded band of the same 4K frame."""
+    """Preferred: the reference GLSL on llvmpipe (kind "reference").  Fallback / second line: the oracle
+    (oracle/rfx_oracle.c, kind "port": scalar C restatement, OpenMP over rows) on the host cores of
+    this box: the same chain on a bounded band of the same 4K frame."""
+    port = cpu_baseline_port(frame, fx, W, H, sample_rows)
+    try:
+        ref = cpu_baseline_llvmpipe(frame, W, H)
+        ref["port"] = {k: port[k] for k in ("value", "unit", "cores", "sample")}
+        return ref
+    except Exception as e:  # no swrast_dri.so / no prebuilt shaders on this box
+        port["llvmpipe_unavailable"] = repr(e)[:200]
+        return port
+
+
+def cpu_baseline_port(frame, fx, W, H, sample_rows):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import rfx_oracle as O
     from rfx_amd.context import load_blue_noise_table

@@ -277,14 +277,25 @@ class GLRefChain:
     prev-camera uniforms, keepData flag, per-material blue-noise index (passed in explicitly).
     """
 
-    def __init__(self, width, height, blue_noise_table: np.ndarray, **options):
+    def __init__(self, width, height, blue_noise_table: np.ndarray, shader_dir: str | None = None, **options):
         self.W, self.H = width, height
         self.o = dict(DEFAULTS)
         self.o.update(options)
-        self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 0, True, self.o["missedRays"]))
-        self.p_temporal = Program(assemble_temporal())
-        self.p_denoise = Program(assemble_denoise())
-        self.p_compose = Program(assemble_compose())
+        if shader_dir is None and not os.path.isdir(REFERENCE_SRC):
+            shader_dir = os.path.join(REF_OUT, "shaders")  # build products of `make -C oracle ref` (GPU box: no /root/reference)
+        if shader_dir is not None:
+            def rd(name):
+                with open(os.path.join(shader_dir, name + ".frag")) as f:
+                    return f.read()
+            if self.o["missedRays"]:
+                raise RuntimeError("prebuilt shaders cover missedRays=false only")
+            self.p_ssgi = Program(rd("ssgi_%d_%d" % (self.o["steps"], self.o["refineSteps"])))
+            self.p_temporal, self.p_denoise, self.p_compose = Program(rd("temporal")), Program(rd("denoise")), Program(rd("compose"))
+        else:
+            self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 0, True, self.o["missedRays"]))
+            self.p_temporal = Program(assemble_temporal())
+            self.p_denoise = Program(assemble_denoise())
+            self.p_compose = Program(assemble_compose())
         W, H = width, height
         self.t_depth = Tex(W, H, FMT_R32F)
         self.t_gbuffer = Tex(W, H, FMT_RGBA32F)
