@@ -79,89 +79,80 @@ RFX_DEV bool k1_behind(const MarchCtx &m, const FrameDims &d, float2 uv, float h
     return m.viewz[t.idx] - h >= 0.0f;
 }
 
-// RayMarch + BinarySearch.  Returns the hit uv; hitPos.x == 1e10 marks a miss.
-// The march positions do not depend on the taps (hitPos_i = origin + dir * sum cs_j), so the taps of NB consecutive
-// steps are issued together: first the NB coarse-cell lookups, then the exact texels of the cells that cannot rule a hit
-// out — two memory round trips per NB steps instead of up to 2*NB dependent ones.  The first hit in step order wins,
-// exactly as in the sequential loop; taps issued past it are discarded.
+// RayMarch (:441-475) + BinarySearch (:477-503) for the pixel's TWO rays at once (slot 0 = optional diffuse ray,
+// slot 1 = specular ray), restructured for the SIMT machine without changing any per-ray arithmetic:
+//   * both rays advance in the same loop iteration (they share cs(i), and their taps are in flight together);
+//   * a ray that finds a hit only RECORDS it and stops marching; the binary search runs ONCE after the march loop for
+//     every ray that hit.  In the GLSL the search is nested in the march loop, so a wavefront whose lanes hit at k
+//     different steps executes the 5-step search k times with mostly idle lanes — here it is 19 + 5 iterations, always.
+struct Ray {
+    float3 pos, dir;
+    float2 uv;
+    bool active, hit;
+};
 template <bool PERSP>
-RFX_DEV float2 k1_ray_march(const MarchCtx &m, const FrameDims &d, float3 dir, float3 &hitPos, float random_b) {
-#ifndef RFX_K1_NB
-#define RFX_K1_NB 2
-#endif
-    constexpr int NB = RFX_K1_NB;
-    dir = dir * (m.rayDistance / (float)m.steps);
-    float2 uv = make_float2(0.f, 0.f);
-    for (int i0 = 1; i0 < m.steps; i0 += NB) {
-        float3 pos[NB];
-        float2 uvs[NB];
-        Tap taps[NB];
-        float2 mm[NB];
-        float3 hp = hitPos;
-#pragma unroll
-        for (int j = 0; j < NB; j++) {
-            const float t = (float)(i0 + j) + random_b - 0.5f;
-            const float cs = 1.0f - rfx_exp(-0.25f * (t * t));
-            hp = hp + dir * cs;
-            pos[j] = hp;
-            uvs[j] = k1_project<PERSP>(m, hp);
-            taps[j] = k1_tap(m, d, uvs[j]);
-        }
-        bool need[NB];
-        if (m.use_coarse) {
-#pragma unroll
-            for (int j = 0; j < NB; j++) mm[j] = m.coarse[taps[j].cell];
-#pragma unroll
-            for (int j = 0; j < NB; j++) {
-                const float h = pos[j].z;
-                // a hit needs 0 <= z - h < thickness for the texel; the cell range rules it out when max - h < 0 or min - h >= thickness
-                need[j] = !((mm[j].y - h < 0.0f) || (mm[j].x - h >= m.thickness));
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NB; j++) need[j] = true;
-        }
-        float z[NB];
-#pragma unroll
-        for (int j = 0; j < NB; j++) z[j] = need[j] ? m.viewz[taps[j].idx] : 0.0f;
-        int hit = -1;
-#pragma unroll
-        for (int j = NB - 1; j >= 0; j--) {
-            const float diff = z[j] - pos[j].z;
-            if (need[j] && i0 + j < m.steps && diff >= 0.0f && diff < m.thickness) hit = j;
-        }
-        if (hit >= 0) {
-            float3 hpos = pos[0];
-            float2 huv = uvs[0];
-#pragma unroll
-            for (int j = 1; j < NB; j++)
-                if (hit == j) { hpos = pos[j]; huv = uvs[j]; }
-            hitPos = hpos;
-            uv = huv;
-            if (m.refineSteps == 0) return uv;
-            // dir was scaled only once; BinarySearch halves it (:481-482)
-            dir = dir * 0.5f;
-            hitPos = hitPos - dir;
-            for (int k = 0; k < m.refineSteps; k++) {
-                uv = k1_project<PERSP>(m, hitPos);
-                const bool behind = k1_behind(m, d, uv, hitPos.z);
-                dir = dir * 0.5f;
-                hitPos = behind ? hitPos - dir : hitPos + dir;
-            }
-            return k1_project<PERSP>(m, hitPos);
-        }
-        // no hit in this batch: continue from the last VALID step of the batch
-        const int last = min(NB, m.steps - i0) - 1;
-        float3 lpos = pos[0];
-        float2 luv = uvs[0];
-#pragma unroll
-        for (int j = 1; j < NB; j++)
-            if (last == j) { lpos = pos[j]; luv = uvs[j]; }
-        hitPos = lpos;
-        uv = luv;
+RFX_DEV bool k1_step_hits(const MarchCtx &m, const FrameDims &d, const Ray &r) {
+    const Tap t = k1_tap(m, d, r.uv);
+    const float h = r.pos.z;
+    if (m.use_coarse) {
+        const float2 mm = m.coarse[t.cell];
+        // a hit needs 0 <= z - h < thickness for the texel; the cell's range rules it out when max - h < 0 or min - h >= thickness
+        if ((mm.y - h < 0.0f) || (mm.x - h >= m.thickness)) return false;
     }
-    hitPos = make_float3(10.0e9f, 10.0e9f, 10.0e9f);
-    return uv;
+    const float diff = m.viewz[t.idx] - h;
+    return diff >= 0.0f && diff < m.thickness;
+}
+template <bool PERSP>
+RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2], float random_b) {
+    const float scale = m.rayDistance / (float)m.steps;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        rays[r].dir = rays[r].dir * scale;
+        rays[r].uv = make_float2(0.f, 0.f);
+        rays[r].hit = false;
+    }
+    for (int i = 1; i < m.steps && (rays[0].active || rays[1].active); i++) {
+        const float t = (float)i + random_b - 0.5f;
+        const float cs = 1.0f - rfx_exp(-0.25f * (t * t));
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            if (rays[r].active) {
+                rays[r].pos = rays[r].pos + rays[r].dir * cs;
+                rays[r].uv = k1_project<PERSP>(m, rays[r].pos);
+            }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            if (rays[r].active && k1_step_hits<PERSP>(m, d, rays[r])) {
+                rays[r].active = false;
+                rays[r].hit = true;
+            }
+    }
+    if (m.refineSteps > 0) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            if (rays[r].hit) {
+                rays[r].dir = rays[r].dir * 0.5f;
+                rays[r].pos = rays[r].pos - rays[r].dir;
+            }
+        for (int k = 0; k < m.refineSteps; k++) {
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                if (rays[r].hit) rays[r].uv = k1_project<PERSP>(m, rays[r].pos);
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                if (rays[r].hit) {
+                    const bool behind = k1_behind(m, d, rays[r].uv, rays[r].pos.z);
+                    rays[r].dir = rays[r].dir * 0.5f;
+                    rays[r].pos = behind ? rays[r].pos - rays[r].dir : rays[r].pos + rays[r].dir;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            if (rays[r].hit) rays[r].uv = k1_project<PERSP>(m, rays[r].pos);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+        if (!rays[r].hit) rays[r].pos = make_float3(10.0e9f, 10.0e9f, 10.0e9f);  // :472
 }
 
 RFX_DEV float k1_smoothstep(float e0, float e1, float x) {
@@ -183,12 +174,11 @@ RFX_DEV Angles k1_angles(float3 l, float3 v, float3 n) {  // calculateAngles :93
     return a;
 }
 
-// doSample :362-439 without env map (getEnvColor == 0).  Returns gi * brdf / pdf.
-template <bool PERSP>
-RFX_DEV float3 k1_do_sample(const MarchCtx &m, const FrameDims &d, const K1Args &A, const Material &mat, float3 viewPos, float3 viewNormal,
-                            float roughness, bool isDiffuseSample, float NoV, const Angles &an, float random_b, float3 l, float3 &hitPos) {
+// doSample :362-439 without env map (getEnvColor == 0), split around the march: the BRDF/pdf factor first ...
+RFX_DEV float k1_brdf_over_pdf_parts(const Material &mat, float3 viewNormal, float roughness, bool isDiffuseSample, float NoV, const Angles &an, float3 l,
+                                      float &pdf) {
     const float cosTheta = fmaxf(0.0f, rfx_dot(viewNormal, l));
-    float brdf, pdf;
+    float brdf;
     if (isDiffuseSample) {
         brdf = rfx_eval_disney_diffuse(an.NoL, NoV, an.LoH, roughness, mat.metalness);
         pdf = an.NoL / RFX_PI;
@@ -198,13 +188,16 @@ RFX_DEV float3 k1_do_sample(const MarchCtx &m, const FrameDims &d, const K1Args 
     }
     brdf *= cosTheta;
     pdf = fmaxf(0.00001f, pdf);
-    hitPos = viewPos;
-    const float2 coords = k1_ray_march<PERSP>(m, d, l, hitPos, random_b);
+    return brdf;
+}
+// ... and the shading of the marched ray: gi * brdf / pdf
+RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat, float roughness, const Ray &ray, float brdf, float pdf) {
     const bool allowMissed = A.p.missedRays != 0;
-    const bool isMissed = hitPos.x == 10.0e9f;
+    const bool isMissed = ray.pos.x == 10.0e9f;
     float3 ssgi = make_float3(0.f, 0.f, 0.f);
     if (isMissed && !allowMissed) return ssgi;
     // velocityTexture is never wired in the reference (SSGIPass.js:89) -> velocity == 0
+    const float2 coords = ray.uv;
     const float ru = coords.x, rv = coords.y;
     if (ru >= 0.0f && ru <= 1.0f && rv >= 0.0f && rv <= 1.0f) {
         const float4 h = rfx_fetch_f4(A.history, d, ru, rv);
@@ -300,23 +293,34 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
         isDiffuseSample = rnd.z < diffW;
     }
     const float3 specularRay = l;
-    float3 diffuseGI = make_float3(-1.0f, -1.0f, -1.0f);  // "not sampled this frame" marker :277-278
-    float3 hitPos;
     float3 dl = make_float3(0.f, 0.f, 0.f);
     if (p.useDirectLight) {
         const float4 t = ((const float4 *)A.direct.ptr)[gi_idx];
         dl = make_float3(t.x, t.y, t.z);
     }
+    Ray rays[2];
+    float brdfD = 0.f, pdfD = 1.f, brdfS, pdfS;
+    rays[0].active = isDiffuseSample;
+    rays[0].pos = viewPos;
+    rays[0].dir = make_float3(0.f, 0.f, 0.f);
     if (isDiffuseSample) {  // :222-242
         const float3 diffuseRay = rfx_cosine_sample_hemisphere(viewNormal, rnd.x, rnd.y);
         const Angles ad = k1_angles(diffuseRay, vv, n);
-        diffuseGI = k1_do_sample<PERSP>(m, d, A, mat, viewPos, viewNormal, roughnessSq, true, NoV, ad, rnd.z, diffuseRay, hitPos);
-        diffuseGI = diffuseGI + dl;
+        brdfD = k1_brdf_over_pdf_parts(mat, viewNormal, roughnessSq, true, NoV, ad, diffuseRay, pdfD);
+        rays[0].dir = diffuseRay;
     }
     // specular ray, traced every frame — evaluated with the SAME isDiffuseSample flag (:246-265)
     an = k1_angles(specularRay, vv, n);
-    float3 specularGI = k1_do_sample<PERSP>(m, d, A, mat, viewPos, viewNormal, roughnessSq, isDiffuseSample, NoV, an, rnd.z, specularRay, hitPos);
-    specularGI = specularGI + dl;
+    brdfS = k1_brdf_over_pdf_parts(mat, viewNormal, roughnessSq, isDiffuseSample, NoV, an, specularRay, pdfS);
+    rays[1].active = true;
+    rays[1].pos = viewPos;
+    rays[1].dir = specularRay;
+    k1_march_rays<PERSP>(m, d, rays, rnd.z);
+
+    float3 diffuseGI = make_float3(-1.0f, -1.0f, -1.0f);  // "not sampled this frame" marker :277-278
+    if (isDiffuseSample) diffuseGI = k1_shade(d, A, mat, roughnessSq, rays[0], brdfD, pdfD) + dl;
+    const float3 specularGI = k1_shade(d, A, mat, roughnessSq, rays[1], brdfS, pdfS) + dl;
+    const float3 hitPos = rays[1].pos;
 
     float rayLength = 0.0f;  // :284-296
     if (!(hitPos.x > 10.0e8f)) {
