@@ -196,3 +196,90 @@ def test_row_tiled_chain_is_bit_identical_to_single_context(ntiles):
     bad = _LocalTiles(W, H, 2, 1)
     run(bad)
     assert sum(c.halo_violations() for c in bad.ctxs) > 0
+
+
+def test_full_size_4k_band_parity_and_determinism(blue_noise):
+    """BASELINE.json configs[2] size (3840x2160, steps 20/5, it 1): (a) the whole chain run twice from the same
+    state is bit-identical (no atomics / races in the data path), (b) a 24-row band in the middle of the frame agrees
+    with the oracle for every stage (the oracle computes only those rows, from full-frame inputs), (c) size-independent
+    structure: background pixels of K1 carry the packed direct light, discarded pixels of K2/K3/K4 keep the target's
+    previous contents."""
+    import types
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.effect import SSGIEffect
+    from rfx_amd.scene import AnalyticScene
+    import rfx_oracle as O
+
+    W, H = 3840, 2160
+    gen = AnalyticScene(1234)
+    frames = [gen.render(W, H, i) for i in range(2)]
+    band = (1068, 1092)
+
+    def run():
+        ctx = Context(W, H)
+        scene = types.SimpleNamespace(frame=None)
+        cam = types.SimpleNamespace(**vars(frames[0].camera))
+        fx = SSGIEffect(None, scene, cam, dict(width=W, height=H), seeds=dict(ssgi=7, denoise=8))
+        state = []
+        for f in frames:
+            scene.frame = f
+            for k, v in vars(f.camera).items():
+                setattr(cam, k, v)
+            if f is frames[-1]:  # state the last frame starts from
+                state = {t: ctx.download(t) for t in (abi.TEX_COMPOSE, abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1, abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1,
+                                                      abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1)}
+            fx.update(ctx, None)
+        out = {t: ctx.download(t) for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1,
+                                            abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1, abi.TEX_COMPOSE)}
+        uni = (fx.ssgiPass.uniforms, fx.denoiser.temporalReprojectPass.uniforms, fx.denoiser.denoisePass.uniforms, fx.denoiser.denoiserComposePass.uniforms)
+        ctx.close()
+        return state, out, uni
+
+    s1, o1, uni = run()
+    s2, o2, _ = run()
+    for t in o1:  # (a)
+        assert np.array_equal(o1[t].view(np.uint8), o2[t].view(np.uint8)), "non-deterministic: " + abi.TEX_NAMES[t]
+
+    f = frames[-1]
+    sp, tp, dp, cp = uni
+    y0, y1 = band
+    sl = np.s_[y0:y1]
+    # (b) stage by stage on the band, each stage fed with the GPU's own previous-stage output of the same run
+    o = O.ssgi(f.depth, f.gbuffer, f.direct, s1[abi.TEX_COMPOSE], blue_noise, sp, rows=band)
+    ga, gb = O.unpack_ssgi(o1[abi.TEX_SSGI][sl])
+    oa, ob = O.unpack_ssgi(o[sl])
+    assert_close("4K ssgi.diffuse", ga, oa, FLIP["ssgi"])
+    assert_close("4K ssgi.specular", gb, ob, FLIP["ssgi"])
+    tp.keepData = 1.0
+    T0, T1 = s1[abi.TEX_TEMPORAL0].copy(), s1[abi.TEX_TEMPORAL1].copy()
+    O.temporal(o1[abi.TEX_SSGI], f.velocity, s1[abi.TEX_DENOISE_B0], s1[abi.TEX_DENOISE_B1], tp, T0, T1, rows=band)
+    assert_close("4K temporal0", o1[abi.TEX_TEMPORAL0][sl], T0[sl], FLIP["temporal"])
+    assert_close("4K temporal1", o1[abi.TEX_TEMPORAL1][sl], T1[sl], FLIP["temporal"])
+    A0, A1 = s1[abi.TEX_DENOISE_A0].copy(), s1[abi.TEX_DENOISE_A1].copy()
+    # dp.blueNoiseIndex holds the index of the LAST pass; pass 0 used the previous value of the recurrence (BlueNoiseUtils.js:24-32)
+    M = 0x7FFFFFFF
+    start = 8
+    last = dp.blueNoiseIndex
+    prev = (last - start - 1) % M
+    dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = prev, 1, 0
+    O.denoise(f.depth, f.gbuffer, o1[abi.TEX_TEMPORAL0], o1[abi.TEX_TEMPORAL1], blue_noise, dp, A0, A1, rows=band)
+    assert_close("4K denoiseA0", O.half_bits_to_float(o1[abi.TEX_DENOISE_A0][sl]), O.half_bits_to_float(A0[sl]), FLIP["denoise"])
+    assert_close("4K denoiseA1", O.half_bits_to_float(o1[abi.TEX_DENOISE_A1][sl]), O.half_bits_to_float(A1[sl]), FLIP["denoise"])
+    B0, B1 = s1[abi.TEX_DENOISE_B0].copy(), s1[abi.TEX_DENOISE_B1].copy()
+    dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = last, 0, 1
+    O.denoise(f.depth, f.gbuffer, o1[abi.TEX_DENOISE_A0], o1[abi.TEX_DENOISE_A1], blue_noise, dp, B0, B1, rows=band)
+    assert_close("4K denoiseB0", O.half_bits_to_float(o1[abi.TEX_DENOISE_B0][sl]), O.half_bits_to_float(B0[sl]), FLIP["denoise"])
+    comp = s1[abi.TEX_COMPOSE].copy()
+    O.compose(f.depth, f.gbuffer, o1[abi.TEX_DENOISE_B0], o1[abi.TEX_DENOISE_B1], cp, comp, rows=band)
+    assert_close("4K compose", o1[abi.TEX_COMPOSE][sl], comp[sl], FLIP["compose"])
+    # (c) structure over the WHOLE frame
+    bg = f.depth == 1.0
+    assert bg.any()
+    pa, pb = O.unpack_ssgi(o1[abi.TEX_SSGI][bg][None])
+    assert np.abs(pa[0, :, :3] - f.direct[bg][:, :3]).max() < 2e-3 * max(1.0, float(f.direct.max()))  # packTwoVec4(directLight, directLight)
+    interior = bg.copy()  # background pixels whose 2x2 quad is all background are discarded by K2/K3/K4
+    q = bg.reshape(H // 2, 2, W // 2, 2).all(axis=(1, 3))
+    interior = np.repeat(np.repeat(q, 2, axis=0), 2, axis=1)
+    for t in (abi.TEX_TEMPORAL0, abi.TEX_DENOISE_B0, abi.TEX_COMPOSE):
+        assert np.array_equal(o1[t][interior], s1[t][interior]), "discarded pixels must keep previous contents: " + abi.TEX_NAMES[t]
