@@ -65,7 +65,7 @@ RFX_DEV Tap k1_tap(const MarchCtx &m, const FrameDims &d, float2 uv) {
     const int xi = rfx_nearest_idx(uv.x, d.fW, d.W), yi = rfx_nearest_idx(uv.y, d.fH, d.H);
     Tap t;
     t.idx = yi * d.W + xi;
-    t.cell = (yi / CELL) * m.coarse_w + (xi / CELL);
+    t.cell = (int)(((unsigned)yi / CELL) * (unsigned)m.coarse_w + ((unsigned)xi / CELL));
     return t;
 }
 // BinarySearch only tests the sign of z_tap - h (:493)
@@ -91,18 +91,6 @@ struct Ray {
     bool active, hit;
 };
 template <bool PERSP>
-RFX_DEV bool k1_step_hits(const MarchCtx &m, const FrameDims &d, const Ray &r) {
-    const Tap t = k1_tap(m, d, r.uv);
-    const float h = r.pos.z;
-    if (m.use_coarse) {
-        const float2 mm = m.coarse[t.cell];
-        // a hit needs 0 <= z - h < thickness for the texel; the cell's range rules it out when max - h < 0 or min - h >= thickness
-        if ((mm.y - h < 0.0f) || (mm.x - h >= m.thickness)) return false;
-    }
-    const float diff = m.viewz[t.idx] - h;
-    return diff >= 0.0f && diff < m.thickness;
-}
-template <bool PERSP>
 RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2], float random_b) {
     const float scale = m.rayDistance / (float)m.steps;
 #pragma unroll
@@ -120,12 +108,36 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
                 rays[r].pos = rays[r].pos + rays[r].dir * cs;
                 rays[r].uv = k1_project<PERSP>(m, rays[r].pos);
             }
+        // taps of both rays in flight together: the two coarse cells first, then the exact texels of the cells that cannot
+        // rule a hit out (a hit needs 0 <= z - h < thickness; the cell range rules it out when max - h < 0 or min - h >= thickness)
+        Tap tap[2];
+        float2 mm[2];
+        bool need[2];
 #pragma unroll
-        for (int r = 0; r < 2; r++)
-            if (rays[r].active && k1_step_hits<PERSP>(m, d, rays[r])) {
+        for (int r = 0; r < 2; r++) tap[r] = k1_tap(m, d, rays[r].uv);
+        if (m.use_coarse) {
+#pragma unroll
+            for (int r = 0; r < 2; r++) mm[r] = m.coarse[tap[r].cell];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const float h = rays[r].pos.z;
+                need[r] = rays[r].active && !((mm[r].y - h < 0.0f) || (mm[r].x - h >= m.thickness));
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; r++) need[r] = rays[r].active;
+        }
+        float z[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) z[r] = need[r] ? m.viewz[tap[r].idx] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const float diff = z[r] - rays[r].pos.z;
+            if (need[r] && diff >= 0.0f && diff < m.thickness) {
                 rays[r].active = false;
                 rays[r].hit = true;
             }
+        }
     }
     if (m.refineSteps > 0) {
 #pragma unroll
@@ -138,12 +150,36 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
 #pragma unroll
             for (int r = 0; r < 2; r++)
                 if (rays[r].hit) rays[r].uv = k1_project<PERSP>(m, rays[r].pos);
+            // BinarySearch only tests the sign of z_tap - h (:493): decided by the cell when max - h < 0 or min - h >= 0
+            Tap tap[2];
+            float2 mm[2];
+            bool need[2], behind[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) tap[r] = k1_tap(m, d, rays[r].uv);
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                need[r] = rays[r].hit;
+                behind[r] = false;
+            }
+            if (m.use_coarse) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) mm[r] = m.coarse[tap[r].cell];
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const float h = rays[r].pos.z;
+                    if (mm[r].y - h < 0.0f) need[r] = false;                               // diff < 0 everywhere in the cell
+                    else if (mm[r].x - h >= 0.0f) { need[r] = false; behind[r] = true; }   // diff >= 0 everywhere
+                }
+            }
+            float z[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) z[r] = need[r] ? m.viewz[tap[r].idx] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 2; r++)
                 if (rays[r].hit) {
-                    const bool behind = k1_behind(m, d, rays[r].uv, rays[r].pos.z);
+                    if (need[r]) behind[r] = z[r] - rays[r].pos.z >= 0.0f;
                     rays[r].dir = rays[r].dir * 0.5f;
-                    rays[r].pos = behind ? rays[r].pos - rays[r].dir : rays[r].pos + rays[r].dir;
+                    rays[r].pos = behind[r] ? rays[r].pos - rays[r].dir : rays[r].pos + rays[r].dir;
                 }
         }
 #pragma unroll

@@ -204,12 +204,21 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
         nyo[o + 2] = (min(max(y + o, 0), d.H - 1) - ty0 + AP) * LW;
     }
 
+    // history taps first: 5 bilinear fetches x TC textures are issued before the LDS neighbourhood loops so their latency
+    // overlaps with that work (sampleReprojectedTexture, reproject.frag:257-263)
+    float4 accv[TC];
+#pragma unroll
+    for (int i = 0; i < TC; i++) {
+        const float3 uvc = (p.reprojectSpecular[i] != 0) ? rs : rd;
+        accv[i] = k2_bicubic(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
+    }
+
 #pragma unroll
     for (int i = 0; i < TC; i++) {
         const bool spec = p.reprojectSpecular[i] != 0;
         const float3 uvc = spec ? rs : rd;
         // reproject() :83-122
-        const float4 acc = k2_bicubic(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
+        const float4 acc = accv[i];
         float3 accrgb = k2_to_log<LOGT>(make_float3(acc.x, acc.y, acc.z));
         float acca = acc.w;
         float3 inrgb = make_float3(inp[i].x, inp[i].y, inp[i].z);
