@@ -68,17 +68,6 @@ RFX_DEV Tap k1_tap(const MarchCtx &m, const FrameDims &d, float2 uv) {
     t.cell = (int)(((unsigned)yi / CELL) * (unsigned)m.coarse_w + ((unsigned)xi / CELL));
     return t;
 }
-// BinarySearch only tests the sign of z_tap - h (:493)
-RFX_DEV bool k1_behind(const MarchCtx &m, const FrameDims &d, float2 uv, float h) {
-    const Tap t = k1_tap(m, d, uv);
-    if (m.use_coarse) {
-        const float2 mm = m.coarse[t.cell];
-        if (mm.y - h < 0.0f) return false;  // every texel of the cell: z - h < 0
-        if (mm.x - h >= 0.0f) return true;
-    }
-    return m.viewz[t.idx] - h >= 0.0f;
-}
-
 // RayMarch (:441-475) + BinarySearch (:477-503) for the pixel's TWO rays at once (slot 0 = optional diffuse ray,
 // slot 1 = specular ray), restructured for the SIMT machine without changing any per-ray arithmetic:
 //   * both rays advance in the same loop iteration (they share cs(i), and their taps are in flight together);

@@ -23,9 +23,6 @@ constexpr int NT = TW * TH;     // 512 threads
 // (`rm * (offset / resolution)`, poisson_denoise.frag:183-189), so on a W x H frame the tap footprint is
 // radius * max(1, W/H) pixels wide and radius * max(1, H/W) pixels high — NOT a circle of `radius` pixels;
 // +1 texel for the bilinear footprint of the RGBA16F passes.
-struct TileGeom {
-    int Rx, Ry, LW, LH;
-};
 
 struct CenterTexel {
     float3 rgb;     // log-space colour accumulator
@@ -53,7 +50,6 @@ RFX_DEV void k3_apply(CenterTexel &c, float w, float3 tl, float tapLuma, float l
 //   float4 geom[n]          normal.xyz, roughness
 //   pass 0 : float4 in[2][n] log(rgb+1), luma^(1/8)     pass >= 1 : uint2 in[2][n] raw RGBA16F
 //   float  depth[n]
-RFX_DEV size_t k3_lds_bytes(int n, bool temporal) { return (size_t)n * (16 + 4 + 2 * (temporal ? 16 : 8)); }
 
 template <bool IN_TEMPORAL, int TC>
 RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
@@ -323,7 +319,7 @@ __global__ __launch_bounds__(256) void k3_generic(K3Args A) {
 hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream) {
     K3Args A = A_in;
     const bool temporal = A.p.inputIsTemporal != 0;
-    // apron of the tap footprint (see TileGeom): anisotropic because the reference rotates in UV space
+    // apron of the tap footprint: anisotropic because the reference rotates in UV space
     const float aspect = A.dims.fW / A.dims.fH;
     const float rx = A.p.radius * fmaxf(1.0f, aspect), ry = A.p.radius * fmaxf(1.0f, 1.0f / aspect);
     {
