@@ -236,11 +236,12 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
 #pragma unroll
                 for (int ox = 0; ox < 5; ox++) {
                     if (cr == 1 && (ox == 0 || ox == 4 || oy == 0 || oy == 4)) continue;
+                    // one 16-byte LDS read per tap, selects instead of a branch: a branch makes the compiler fetch .x first and
+                    // .yz later as 4-byte reads, which are 4-way bank-conflicted at this 16-byte lane stride
                     const float4 t = nt[nyo[oy] + nxo[ox]];
-                    if (t.x >= 0.0f) {
-                        mn = make_float3(fminf(t.x, mn.x), fminf(t.y, mn.y), fminf(t.z, mn.z));
-                        mx = make_float3(fmaxf(t.x, mx.x), fmaxf(t.y, mx.y), fmaxf(t.z, mx.z));
-                    }
+                    const bool ok = t.x >= 0.0f;
+                    mn = make_float3(ok ? fminf(t.x, mn.x) : mn.x, ok ? fminf(t.y, mn.y) : mn.y, ok ? fminf(t.z, mn.z) : mn.z);
+                    mx = make_float3(ok ? fmaxf(t.x, mx.x) : mx.x, ok ? fmaxf(t.y, mx.y) : mx.y, ok ? fmaxf(t.z, mx.z) : mx.z);
                 }
             mn = k2_to_log<LOGT>(mn);
             mx = k2_to_log<LOGT>(mx);
