@@ -66,7 +66,8 @@ def temporal(ssgi_tex, velocity, hist0, hist1, params: abi.TemporalParams, out0=
     H, W = ssgi_tex.shape[:2]
     y0, y1 = rows or (0, H)
     out0 = np.zeros((H, W, 4), np.float32) if out0 is None else out0
-    out1 = np.zeros((H, W, 4), np.float32) if out1 is None else out1
+    if out1 is None and params.textureCount == 2:
+        out1 = np.zeros((H, W, 4), np.float32)
     rc = lib().rfxo_temporal(W, H, y0, y1, _p(_chk(ssgi_tex, np.uint32, (H, W, 4))), _p(_chk(velocity, np.uint32, (H, W, 4))),
                              _p(_chk(hist0, np.uint16, (H, W, 4))), _p(_chk(hist1, np.uint16, (H, W, 4))), C.byref(params), _p(out0), _p(out1))
     assert rc == 0, rc
@@ -81,7 +82,8 @@ def denoise(depth, gbuffer, in0, in1, blue, params: abi.DenoiseParams, out0, out
     is_half = in0.dtype == np.uint16
     _chk(in0, np.uint16 if is_half else np.float32, (H, W, 4))
     rc = lib().rfxo_denoise(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gbuffer, np.uint32, (H, W, 4))), _p(in0), _p(in1), int(is_half),
-                            _p(_chk(blue, np.uint8)), C.byref(params), _p(_chk(out0, np.uint16, (H, W, 4))), _p(_chk(out1, np.uint16, (H, W, 4))))
+                            _p(_chk(blue, np.uint8)), C.byref(params), _p(_chk(out0, np.uint16, (H, W, 4))),
+                            _p(_chk(out1, np.uint16, (H, W, 4))) if out1 is not None else None)
     assert rc == 0, rc
     return out0, out1
 

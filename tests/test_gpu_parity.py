@@ -283,3 +283,84 @@ def test_full_size_4k_band_parity_and_determinism(blue_noise):
     interior = np.repeat(np.repeat(q, 2, axis=0), 2, axis=1)
     for t in (abi.TEX_TEMPORAL0, abi.TEX_DENOISE_B0, abi.TEX_COMPOSE):
         assert np.array_equal(o1[t][interior], s1[t][interior]), "discarded pixels must keep previous contents: " + abi.TEX_NAMES[t]
+
+
+@pytest.mark.parametrize("size,radius", [((200, 120), 5.0), ((120, 200), 3.0), ((333, 77), 2.0), ((64, 64), 0.0)])
+def test_denoise_variants_vs_oracle(blue_noise, size, radius):
+    """K3 outside the default shape: radius 5 (apron too large for the LDS tile -> generic kernel), a portrait frame
+    (the UV-space tap rotation stretches the footprint vertically), odd sizes, radius 0; both the RGBA32F-nearest
+    (pass 0) and the RGBA16F-bilinear (pass >= 1) input paths, RNE and RTZ half stores."""
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_frame
+    import rfx_oracle as O
+
+    W, H = size
+    f = synthetic_frame(W, H, 0)
+    _, _, dp, _ = _params(abi, f, f.camera, 1.0)
+    dp.radius = radius
+    rng = np.random.RandomState(3)
+    T = [(rng.rand(H, W, 4).astype(np.float32) * np.array([2, 2, 2, 6], np.float32)) for _ in range(2)]
+    ctx = Context(W, H)
+    ctx.upload_frame(f)
+    ctx.upload(abi.TEX_TEMPORAL0, T[0])
+    ctx.upload(abi.TEX_TEMPORAL1, T[1])
+    A = [np.zeros((H, W, 4), np.uint16) for _ in range(2)]
+    B = [np.zeros((H, W, 4), np.uint16) for _ in range(2)]
+    for rtz in (1, 0):
+        dp.halfStoreRTZ = rtz
+        dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 31, 1, 0
+        ctx.poisson_denoise(dp)
+        O.denoise(f.depth, f.gbuffer, T[0], T[1], blue_noise, dp, A[0], A[1])
+        for j, tex in enumerate((abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1)):
+            assert_close("A%d r=%g rtz=%d" % (j, radius, rtz), O.half_bits_to_float(ctx.download(tex)), O.half_bits_to_float(A[j]), FLIP["denoise"])
+        ctx.upload(abi.TEX_DENOISE_A0, A[0])
+        ctx.upload(abi.TEX_DENOISE_A1, A[1])
+        dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 32, 0, 1
+        ctx.poisson_denoise(dp)
+        O.denoise(f.depth, f.gbuffer, A[0], A[1], blue_noise, dp, B[0], B[1])
+        for j, tex in enumerate((abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1)):
+            assert_close("B%d r=%g rtz=%d" % (j, radius, rtz), O.half_bits_to_float(ctx.download(tex)), O.half_bits_to_float(B[j]), FLIP["denoise"])
+    ctx.close()
+
+
+def test_single_texture_variants_vs_oracle(blue_noise):
+    """inputType "diffuse" (TRAA's K2 variant: textureCount 1, raw RGBA texel, maxBlend 0.9, confidencePower 4) and
+    textureCount-1 K3 — the other specialisations of the same kernels."""
+    import types
+    from rfx_amd import abi, effect
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_frame
+    import rfx_oracle as O
+
+    W, H = 240, 136
+    f0, f1 = synthetic_frame(W, H, 0), synthetic_frame(W, H, 1)
+    rng = np.random.RandomState(5)
+    raw = rng.rand(H, W, 4).astype(np.float32)
+    hist = (rng.rand(H, W, 4).astype(np.float32) * np.array([1, 1, 1, 9], np.float32)).astype(np.float16).view(np.uint16)
+    scene = types.SimpleNamespace(frame=f1)
+    v = effect.VelocityDepthNormalPass(scene, f1.camera)
+    traa = effect.TRAAEffect(scene, f1.camera, v, dict(fullAccumulate=True))
+    tp = traa.temporal_params()
+    tp.camera = abi.Camera.from_scene(f1.camera)
+    tp.prevCamera = abi.Camera.from_scene(f0.camera)
+    tp.keepData = 1.0
+    ctx = Context(W, H)
+    ctx.upload_frame(f1)
+    ctx.upload(abi.TEX_SSGI, raw.view(np.uint32))
+    ctx.upload(abi.TEX_DENOISE_B0, hist)
+    ctx.temporal_reproject(tp)
+    out0 = np.zeros((H, W, 4), np.float32)
+    O.temporal(np.ascontiguousarray(raw.view(np.uint32)), f1.velocity, hist, hist, tp, out0, None)
+    assert_close("traa temporal", ctx.download(abi.TEX_TEMPORAL0), out0, FLIP["temporal"])
+    # K3 with one (diffuse) texture
+    _, _, dp, _ = _params(abi, f1, f1.camera, 1.0)
+    dp.textureCount = 1
+    dp.isTextureSpecular[:] = [0, 0]
+    dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 9, 1, 0
+    ctx.upload(abi.TEX_TEMPORAL0, out0)
+    ctx.poisson_denoise(dp)
+    A0 = np.zeros((H, W, 4), np.uint16)
+    O.denoise(f1.depth, f1.gbuffer, out0, out0, blue_noise, dp, A0, None)
+    assert_close("tc1 denoise", O.half_bits_to_float(ctx.download(abi.TEX_DENOISE_A0)), O.half_bits_to_float(A0), FLIP["denoise"])
+    ctx.close()
