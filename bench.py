@@ -111,6 +111,10 @@ def main():
     # frame 1 of the orbit: non-zero velocity (camera moved 0.5 deg since frame 0)
     probe = scene_gen.render(W, 8, 1, row0=y0 + rows // 2, rows=8, frame_height=H)
     vmax = float(np.abs(probe.velocity[..., 1].view(np.float32)).max()) * 1.5 + 1e-4
+    if dist is not None:  # every rank must use the SAME halo: the neighbours' send/recv sizes have to match
+        t = torch.tensor([vmax], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        vmax = float(t.item())
     halo = 0 if world == 1 else tiling.required_halo(3.0, vmax, H, W)
     b0, b1 = max(0, y0 - halo), min(H, y0 + rows + halo)
     band = scene_gen.render(W, b1 - b0, 1, row0=b0, rows=b1 - b0, frame_height=H)
