@@ -108,16 +108,23 @@ def main():
     t0 = time.time()
     scene_gen = AnalyticScene(1234)
     opts = dict(width=W, height=H, steps=20, refineSteps=5, denoiseIterations=1)
-    # frame 1 of the orbit: non-zero velocity (camera moved 0.5 deg since frame 0)
-    probe = scene_gen.render(W, 8, 1, row0=y0 + rows // 2, rows=8, frame_height=H)
-    vmax = float(np.abs(probe.velocity[..., 1].view(np.float32)).max()) * 1.5 + 1e-4
+    # frame 1 of the orbit: non-zero velocity (camera moved 0.5 deg since frame 0).  The tile is dumped first, the
+    # velocity bound over ALL tiles fixes the halo width, then the halo rows are dumped and attached.
+    tile = scene_gen.render(W, rows, 1, row0=y0, rows=rows, frame_height=H)
+    vmax = float(np.abs(tile.velocity[..., 1].view(np.float32)).max())
     if dist is not None:  # every rank must use the SAME halo: the neighbours' send/recv sizes have to match
         t = torch.tensor([vmax], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         vmax = float(t.item())
     halo = 0 if world == 1 else tiling.required_halo(3.0, vmax, H, W)
     b0, b1 = max(0, y0 - halo), min(H, y0 + rows + halo)
-    band = scene_gen.render(W, b1 - b0, 1, row0=b0, rows=b1 - b0, frame_height=H)
+    parts = [tile]
+    if b0 < y0:
+        parts.insert(0, scene_gen.render(W, y0 - b0, 1, row0=b0, rows=y0 - b0, frame_height=H))
+    if b1 > y0 + rows:
+        parts.append(scene_gen.render(W, b1 - y0 - rows, 1, row0=y0 + rows, rows=b1 - y0 - rows, frame_height=H))
+    band = types.SimpleNamespace(camera=tile.camera, **{k: np.concatenate([getattr(q, k) for q in parts], axis=0)
+                                                         for k in ("depth", "gbuffer", "velocity", "direct")})
     log("[rank %d] dump band rows [%d,%d) of %dx%d generated in %.1fs (halo %d)" % (rank, b0, b1, W, H, time.time() - t0, halo))
 
     ctx = Context(W, H, device=local_rank, tile_y0=y0, tile_rows=rows, halo_rows=halo)

@@ -241,7 +241,9 @@ class PoissonDenoisePass {
 			blueNoiseIndex: 0,
 			inputIsTemporal: 1,
 			writeToB: 0,
-			halfStoreRTZ: halfStoreRTZ ? 1 : 0
+			// RGBA16F stores: round-toward-zero like the llvmpipe run of the reference (the parity definition); pass false for
+			// round-to-nearest-even like GPU ROPs
+			halfStoreRTZ: halfStoreRTZ === undefined || halfStoreRTZ ? 1 : 0
 		}
 		this.blueNoiseIndex = makeBlueNoiseIndex(blueNoiseStart)
 	}
