@@ -179,7 +179,9 @@ def write_assembled(outdir: str, **kw):
     """Build products for the GPU box (no /root/reference there): oracle/_ref/shaders/*.frag."""
     os.makedirs(outdir, exist_ok=True)
     for name, src in (("ssgi_20_5", assemble_ssgi(20, 5)), ("ssgi_8_2", assemble_ssgi(8, 2)), ("ssgi_40_5", assemble_ssgi(40, 5)),
-                      ("temporal", assemble_temporal()), ("denoise", assemble_denoise()), ("compose", assemble_compose())):
+                      ("temporal", assemble_temporal()), ("denoise", assemble_denoise()), ("compose", assemble_compose()),
+                      ("ssgi_ssr_20_5", assemble_ssgi(20, 5, 1)), ("temporal_ssr", assemble_temporal(texture_count=1, input_type=2, reproject_specular=True, neighborhood_clamp=True)),
+                      ("denoise_ssr", assemble_denoise(texture_count=1, is_texture_specular=(True, True))), ("compose_ssr", assemble_compose(input_type=2))):
         with open(os.path.join(outdir, name + ".frag"), "w") as f:
             f.write(src)
 
@@ -267,7 +269,7 @@ class Program:
 
 DEFAULTS = dict(  # src/ssgi/SSGIOptions.js:26-48
     distance=10.0, thickness=10.0, denoiseIterations=1, radius=3.0, phi=0.5, lumaPhi=5.0, depthPhi=2.0, normalPhi=50.0,
-    roughnessPhi=50.0, specularPhi=50.0, envBlur=0.5, steps=20, refineSteps=5, missedRays=False)
+    roughnessPhi=50.0, specularPhi=50.0, envBlur=0.5, steps=20, refineSteps=5, missedRays=False, mode="ssgi")
 
 
 class GLRefChain:
@@ -283,14 +285,22 @@ class GLRefChain:
         self.o.update(options)
         if shader_dir is None and not os.path.isdir(REFERENCE_SRC):
             shader_dir = os.path.join(REF_OUT, "shaders")  # build products of `make -C oracle ref` (GPU box: no /root/reference)
+        ssr = self.o["mode"] == "ssr"
+        self.tc = 1 if ssr else 2  # SSGIEffect.js:70-77: "ssr" -> inputType "specular", one texture
+        sfx = "_ssr" if ssr else ""
         if shader_dir is not None:
             def rd(name):
                 with open(os.path.join(shader_dir, name + ".frag")) as f:
                     return f.read()
             if self.o["missedRays"]:
                 raise RuntimeError("prebuilt shaders cover missedRays=false only")
-            self.p_ssgi = Program(rd("ssgi_%d_%d" % (self.o["steps"], self.o["refineSteps"])))
-            self.p_temporal, self.p_denoise, self.p_compose = Program(rd("temporal")), Program(rd("denoise")), Program(rd("compose"))
+            self.p_ssgi = Program(rd("ssgi%s_%d_%d" % (sfx, self.o["steps"], self.o["refineSteps"])))
+            self.p_temporal, self.p_denoise, self.p_compose = Program(rd("temporal" + sfx)), Program(rd("denoise" + sfx)), Program(rd("compose" + sfx))
+        elif ssr:
+            self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 1, True, self.o["missedRays"]))
+            self.p_temporal = Program(assemble_temporal(texture_count=1, input_type=2, reproject_specular=True, neighborhood_clamp=True))
+            self.p_denoise = Program(assemble_denoise(texture_count=1, is_texture_specular=(True, True)))
+            self.p_compose = Program(assemble_compose(input_type=2))
         else:
             self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 0, True, self.o["missedRays"]))
             self.p_temporal = Program(assemble_temporal())
@@ -355,7 +365,8 @@ class GLRefChain:
         p.sampler("inputTexture", self.t_ssgi)
         p.sampler("velocityTexture", self.t_velocity)
         p.sampler("accumulatedTexture0", self.t_B[0])  # Denoiser.js:51 overrideAccumulatedTextures
-        p.sampler("accumulatedTexture1", self.t_B[1])
+        if self.tc == 2:
+            p.sampler("accumulatedTexture1", self.t_B[1])
         p.set("projectionMatrix", cam.projectionMatrix)
         p.set("projectionMatrixInverse", cam.projectionMatrixInverse)
         p.set("cameraMatrixWorld", cam.matrixWorld)
@@ -373,7 +384,7 @@ class GLRefChain:
         p.set("cameraFar", float(cam.far))
         p.set("maxBlend", float(max_blend))
         p.set("neighborhoodClampIntensity", float(nci))
-        p.draw(self.t_temporal)
+        p.draw(self.t_temporal[:self.tc])
         self.ms["temporal"] = p.last_ms
         self.keep_data = 1.0
         self.prev = cam
@@ -398,9 +409,10 @@ class GLRefChain:
             src = self.t_temporal if i == 0 else (self.t_B if horizontal else self.t_A)
             dst = self.t_A if horizontal else self.t_B
             p.sampler("inputTexture", src[0])
-            p.sampler("inputTexture2", src[1])
+            if self.tc == 2:
+                p.sampler("inputTexture2", src[1])
             p.set("blueNoiseIndex", int(blue_noise_indices[i]))
-            p.draw(dst)
+            p.draw(dst[:self.tc])
             self.ms["denoise"].append(p.last_ms)
 
     # -- K4: DenoiserComposePass.render (src/denoise/pass/DenoiserComposePass.js:129-135)
@@ -408,8 +420,13 @@ class GLRefChain:
         p = self.p_compose
         p.sampler("depthTexture", self.t_depth)
         p.sampler("gBufferTexture", self.t_gbuffer)
-        p.sampler("diffuseGiTexture", self.t_B[0])
-        p.sampler("specularGiTexture", self.t_B[1])
+        if self.tc == 2:
+            p.sampler("diffuseGiTexture", self.t_B[0])
+            p.sampler("specularGiTexture", self.t_B[1])
+        else:  # DenoiserComposePass.js:26-33 inputType "specular": textures[0] is the specular GI; Denoiser.js:101-103 sceneTexture
+            p.sampler("diffuseGiTexture", self.t_empty)
+            p.sampler("specularGiTexture", self.t_B[0])
+            p.sampler("sceneTexture", self.t_direct)
         p.set("viewMatrix", cam.matrixWorldInverse)
         p.set("cameraMatrixWorld", cam.matrixWorld)
         p.set("projectionMatrix", cam.projectionMatrix)

@@ -526,7 +526,7 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
         diffuseGI = add3(diffuseGI, V3(dl.x, dl.y, dl.z));
         specularGI = add3(specularGI, V3(dl.x, dl.y, dl.z));
     }
-    if (diffuseSamples == 0.0f) diffuseGI = V3(-1.0f, -1.0f, -1.0f); /* :277-278 */
+    if (p->mode == 0 && diffuseSamples == 0.0f) diffuseGI = V3(-1.0f, -1.0f, -1.0f); /* :277-278 */
     float rayLength = 0.0f; /* :284-296 */
     int missed = hitPos.x > 10.0e8f;
     if (!missed) {
@@ -534,14 +534,19 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
         v3 camPos = V3(C[12], C[13], C[14]);
         rayLength = length3(sub3(camPos, V3(hw.x, hw.y, hw.z)));
     }
-    v4 gD = {diffuseGI.x, diffuseGI.y, diffuseGI.z, mat.roughness};
-    v4 gS = {specularGI.x, specularGI.y, specularGI.z, rayLength};
-    pack_two_vec4(gD, gS, out);
+    if (p->mode == 0) { /* :302-304 */
+        v4 gD = {diffuseGI.x, diffuseGI.y, diffuseGI.z, mat.roughness};
+        v4 gS = {specularGI.x, specularGI.y, specularGI.z, rayLength};
+        pack_two_vec4(gD, gS, out);
+    } else { /* MODE_SSR :298-300,306-307: raw vec4(specularGI, uintBitsToFloat(packHalf2x16(rayLength, roughness))) */
+        memcpy(&out[0], &specularGI.x, 4); memcpy(&out[1], &specularGI.y, 4); memcpy(&out[2], &specularGI.z, 4);
+        out[3] = pack_half2(rayLength, mat.roughness);
+    }
 }
 
 int rfxo_ssgi(int W, int H, int y0, int y1, const float *depth, const uint32_t *gbuffer, const float *direct, const float *history,
               const uint8_t *blue, const rfx_ssgi_params *p, uint32_t *out) {
-    if (p->mode != 0 || p->importanceSampling) return RFX_EUNSUPPORTED;
+    if ((p->mode != 0 && p->mode != 1) || p->importanceSampling) return RFX_EUNSUPPORTED;
     k1_ctx c = {W, H, depth, gbuffer, direct, history, blue, p, 0, 0, 0};
     /* SSGIPass.js:84-87: JS doubles rounded to float uniforms */
     c.nearMulFar = (float)((double)p->camera.near_ * (double)p->camera.far_);
@@ -879,9 +884,12 @@ int rfxo_denoise(int W, int H, int y0, int y1, const float *depth, const uint32_
 }
 
 /* ==================================================================== K4: DenoiserComposePass */
+/* gi0/gi1: K3 target B ([0] = diffuse, [1] = specular; inputType "specular": gi0 is the specular GI, gi1 unused);
+ * scene: the composer's input buffer (sceneTexture), only read when inputType == TYPE_SPECULAR */
 int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_t *gbuffer, const uint16_t *gi0, const uint16_t *gi1,
-                 const rfx_compose_params *p, float *out) {
-    if (p->inputType != 0) return RFX_EUNSUPPORTED;
+                 const float *scene, const rfx_compose_params *p, float *out) {
+    if (p->inputType != 0 && p->inputType != 2) return RFX_EUNSUPPORTED;
+    if (p->inputType == 2 && !scene) return RFX_EINVAL;
     const float *C = p->camera.matrixWorld, *Vw = p->camera.matrixWorldInverse, *P = p->camera.projectionMatrix, *Pi = p->camera.projectionMatrixInverse;
     dims d = {W, H};
 #pragma omp parallel for schedule(dynamic, 4)
@@ -902,7 +910,11 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
             v4 pp = mat_mul_v4(Pi, ((u - 0.5f) * 2.0f) * clipW, ((v - 0.5f) * 2.0f) * clipW, ((viewZ - 0.5f) * 2.0f) * clipW, 1.0f * clipW);
             v3 viewPos = V3(pp.x, pp.y, -viewZ);
             v3 viewDir = normalize3(viewPos);
-            v4 dgi = fetch_h4_linear(gi0, d, u, v), sgi = fetch_h4_linear(gi1, d, u, v);
+            /* DenoiserComposePass.js:26-33,78-79: diffuseSpecular -> (textures[0], textures[1]); specular -> specularGi = textures[0],
+               diffuseGiTexture unbound (zeros) */
+            v4 dgi = {0, 0, 0, 0}, sgi;
+            if (p->inputType == 0) { dgi = fetch_h4_linear(gi0, d, u, v); sgi = fetch_h4_linear(gi1, d, u, v); }
+            else sgi = fetch_h4_linear(gi0, d, u, v);
             /* constructGlobalIllumination :53-108 */
             float roughness = mat.roughness * mat.roughness;
             v3 normal = v4_mul_mat_xyz(Vw, viewNormal, 0.0f);
@@ -924,6 +936,10 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
             v3 F = f_schlick3(f0, VoH);
             float om = 1.0f - mat.metalness;
             v3 diffuseC = V3(mat.diffuse.x * om * (1.0f - F.x) * dgi.x, mat.diffuse.y * om * (1.0f - F.y) * dgi.y, mat.diffuse.z * om * (1.0f - F.z) * dgi.z);
+            if (p->inputType == 2) { /* denoiser_compose_functions.glsl:97-101: diffuseComponent = textureLod(sceneTexture, vUv, 0.).rgb */
+                v4 sc = fetch_f4(scene, d, u, v);
+                diffuseC = V3(sc.x, sc.y, sc.z);
+            }
             v3 specC = V3(sgi.x * F.x, sgi.y * F.y, sgi.z * F.z);
             float *o = out + 4 * ((size_t)y * W + x);
             o[0] = diffuseC.x + specC.x + mat.emissive.x;

@@ -88,12 +88,14 @@ def denoise(depth, gbuffer, in0, in1, blue, params: abi.DenoiseParams, out0, out
     return out0, out1
 
 
-def compose(depth, gbuffer, gi0, gi1, params: abi.ComposeParams, out=None, rows=None):
+def compose(depth, gbuffer, gi0, gi1, params: abi.ComposeParams, out=None, rows=None, scene=None):
+    """gi1 may be None for inputType "specular" (then gi0 is the specular GI and `scene` the composer's input buffer)."""
     H, W = depth.shape
     y0, y1 = rows or (0, H)
     out = np.zeros((H, W, 4), np.float32) if out is None else out
     rc = lib().rfxo_compose(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gbuffer, np.uint32, (H, W, 4))), _p(_chk(gi0, np.uint16, (H, W, 4))),
-                            _p(_chk(gi1, np.uint16, (H, W, 4))), C.byref(params), _p(out))
+                            _p(_chk(gi1, np.uint16, (H, W, 4))) if gi1 is not None else None,
+                            _p(_chk(scene, np.float32, (H, W, 4))) if scene is not None else None, C.byref(params), _p(out))
     assert rc == 0, rc
     return out
 

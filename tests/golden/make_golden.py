@@ -34,11 +34,12 @@ def cam_arrays(cam, prefix):
             ("projectionMatrix", "projectionMatrixInverse", "matrixWorld", "matrixWorldInverse", "position", "quaternion")}
 
 
-def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_start=2000):
+def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_start=2000, mode="ssgi"):
     bn = np.fromfile(os.path.join(ROOT, "realism-effects_amd", "data", "blue_noise_128_rgba8.bin"), np.uint8).reshape(128, 128, 4)
-    c = chain.GLRefChain(W, H, bn, steps=steps, refineSteps=refine, denoiseIterations=iterations)
+    c = chain.GLRefChain(W, H, bn, steps=steps, refineSteps=refine, denoiseIterations=iterations, mode=mode)
+    tc = c.tc
     out = dict(width=W, height=H, frames=frames, steps=steps, refineSteps=refine, denoiseIterations=iterations, ssgi_start=ssgi_start,
-               denoise_start=denoise_start, gl_info=chain.GL.info())
+               denoise_start=denoise_start, gl_info=chain.GL.info(), mode=mode, textureCount=tc)
     si = di = 0
     for fi in range(frames):
         f = synthetic_frame(W, H, fi)
@@ -52,14 +53,15 @@ def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_
         out[k + "ssgi"] = c.t_ssgi.read().view(np.uint32)
         out[k + "ssgi_index"] = si
         c.temporal(f.camera, camera_moved=True)
-        out[k + "temporal0"], out[k + "temporal1"] = c.t_temporal[0].read(), c.t_temporal[1].read()
+        for j in range(tc):
+            out[k + "temporal%d" % j] = c.t_temporal[j].read()
         idx = []
         for _ in range(2 * iterations):
             di = (denoise_start + di + 1) % M
             idx.append(di)
         c.denoise(f.camera, idx)
         out[k + "denoise_index"] = np.array(idx, np.int64)
-        for j in range(2):
+        for j in range(tc):
             # RGBA16F targets read back as float32 are exactly representable in half
             out[k + "A%d" % j] = c.t_A[j].read().astype(np.float16).view(np.uint16)
             out[k + "B%d" % j] = c.t_B[j].read().astype(np.float16).view(np.uint16)
@@ -73,3 +75,4 @@ def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_
 if __name__ == "__main__":
     run("chain_160x90_s20r5_it1", 160, 90, frames=3, steps=20, refine=5, iterations=1)
     run("chain_97x55_s8r2_it2", 97, 55, frames=2, steps=8, refine=2, iterations=2)
+    run("chain_ssr_128x72_s20r5_it1", 128, 72, frames=2, steps=20, refine=5, iterations=1, mode="ssr")

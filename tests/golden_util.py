@@ -6,6 +6,7 @@ import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDENS = ["chain_160x90_s20r5_it1", "chain_97x55_s8r2_it2"]
+GOLDEN_SSR = "chain_ssr_128x72_s20r5_it1"
 
 
 def load(name):

@@ -86,7 +86,8 @@ class OracleRenderer:
     def compose(self, p):
         self.calls.append(("compose",))
         t = self.tex
-        O.compose(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[abi.TEX_DENOISE_B0], t[abi.TEX_DENOISE_B1], p, out=t[abi.TEX_COMPOSE], rows=self._rows())
+        O.compose(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[abi.TEX_DENOISE_B0], t[abi.TEX_DENOISE_B1], p, out=t[abi.TEX_COMPOSE], rows=self._rows(),
+                  scene=t[abi.TEX_DIRECT_LIGHT])
 
     def sync(self):
         pass

@@ -104,3 +104,61 @@ def test_full_chain_through_effect(name):
         di = [c[1] for c in r.calls if c[0] == "denoise"]
         assert di == [int(x) for x in g[k + "denoise_index"]]
         r.calls.clear()
+
+
+def ssr_params(g, fi, keep):
+    """mode "ssr" (SSGIEffect.js:70-73): inputType "specular", one texture, reprojectSpecular/neighborhoodClamp true."""
+    cam = abi.Camera.from_scene(G.camera(g, fi))
+    prev = abi.Camera.from_scene(G.camera(g, fi - 1 if fi > 0 else 0))
+    sp = abi.SsgiParams(camera=cam, steps=int(g["steps"]), refineSteps=int(g["refineSteps"]), mode=1, useDirectLight=1, rayDistance=10, thickness=10,
+                        envBlur=0.5, blueNoiseIndex=int(g["f%d_ssgi_index" % fi]))
+    tp = abi.TemporalParams(camera=cam, prevCamera=prev, textureCount=1, inputType=2, logTransform=1, fullAccumulate=0, confidencePower=0.75,
+                            neighborhoodClampIntensity=0.5, maxBlend=1.0, keepData=keep)
+    tp.reprojectSpecular[:] = [1, 1]
+    tp.neighborhoodClamp[:] = [1, 1]
+    dp = abi.DenoiseParams(radius=3, phi=0.5, lumaPhi=5, depthPhi=2, normalPhi=50, roughnessPhi=50, specularPhi=50, textureCount=1, halfStoreRTZ=1)
+    dp.isTextureSpecular[:] = [1, 1]
+    cp = abi.ComposeParams(camera=cam, inputType=2)
+    return sp, tp, dp, cp
+
+
+def ssr_unpack(ssgi_bits):
+    """MODE_SSR K1 texel: raw rgb floats + packHalf2x16(rayLength, roughness) in .a"""
+    rgb = ssgi_bits[..., :3].view(np.float32)
+    a = ssgi_bits[..., 3]
+    ray = (a & np.uint32(0xffff)).astype(np.uint16).view(np.float16).astype(np.float32)
+    rough = (a >> np.uint32(16)).astype(np.uint16).view(np.float16).astype(np.float32)
+    return np.concatenate([rgb, ray[..., None], rough[..., None]], axis=-1)
+
+
+def test_stagewise_ssr_mode(blue_noise):
+    """mode "ssr": K1 MODE_SSR, K2 inputType SPECULAR, K3 with one specular texture, K4 TYPE_SPECULAR (sceneTexture)."""
+    g = G.load(G.GOLDEN_SSR)
+    W, H, nf = int(g["width"]), int(g["height"]), int(g["frames"])
+    z16 = np.zeros((H, W, 4), np.uint16)
+    for fi in range(nf):
+        f = G.frame(g, fi)
+        k, kp = "f%d_" % fi, "f%d_" % (fi - 1)
+        sp, tp, dp, cp = ssr_params(g, fi, 0.0 if fi == 0 else 1.0)
+        hist = np.ascontiguousarray(g[kp + "compose"]) if fi else np.zeros((H, W, 4), np.float32)
+        o = O.ssgi(f.depth, f.gbuffer, f.direct, hist, blue_noise, sp)
+        fg = f.depth < 1.0  # background texels carry packTwoVec4(direct, direct) in both modes (ssgi.frag:109-113)
+        assert_close("ssr ssgi f%d" % fi, ssr_unpack(o)[fg][None], ssr_unpack(g[k + "ssgi"])[fg][None], FLIP["ssgi"])
+        # (raw fp32 output here: no half rounding to hide last-ulp transcendental differences, so no bit-identity claim)
+        B0 = np.ascontiguousarray(g[kp + "B0"]) if fi else z16
+        T0 = np.ascontiguousarray(g[kp + "temporal0"]) if fi else np.zeros((H, W, 4), np.float32)
+        O.temporal(np.ascontiguousarray(g[k + "ssgi"]), f.velocity, B0, B0, tp, T0, None)
+        assert_close("ssr temporal0 f%d" % fi, T0, g[k + "temporal0"], FLIP["temporal"])
+        A0 = np.ascontiguousarray(g[kp + "A0"]) if fi else z16.copy()
+        dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = int(g[k + "denoise_index"][0]), 1, 0
+        t0 = np.ascontiguousarray(g[k + "temporal0"])
+        O.denoise(f.depth, f.gbuffer, t0, t0, blue_noise, dp, A0, None)
+        assert_close("ssr A0 f%d" % fi, O.half_bits_to_float(A0), O.half_bits_to_float(g[k + "A0"]), FLIP["denoise0"])
+        Bn = np.ascontiguousarray(g[kp + "B0"]).copy() if fi else z16.copy()
+        dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = int(g[k + "denoise_index"][1]), 0, 1
+        a0 = np.ascontiguousarray(g[k + "A0"])
+        O.denoise(f.depth, f.gbuffer, a0, a0, blue_noise, dp, Bn, None)
+        assert_close("ssr B0 f%d" % fi, O.half_bits_to_float(Bn), O.half_bits_to_float(g[k + "B0"]), FLIP["denoise"])
+        comp = hist.copy()
+        O.compose(f.depth, f.gbuffer, np.ascontiguousarray(g[k + "B0"]), None, cp, comp, scene=f.direct)
+        assert_close("ssr compose f%d" % fi, comp, g[k + "compose"], FLIP["compose"])
