@@ -85,7 +85,7 @@ typedef struct rfx_ssgi_params {
     rfx_camera camera;
     int32_t steps;            /* #define steps        (default 20) */
     int32_t refineSteps;      /* #define refineSteps  (default 5)  */
-    int32_t mode;             /* #define mode: 0 = MODE_SSGI, 1 = MODE_SSR (only 0 built: RFX_EUNSUPPORTED otherwise) */
+    int32_t mode;             /* #define mode: 0 = MODE_SSGI (two packed vec4 of halfs), 1 = MODE_SSR (raw vec4: specular GI, packHalf2x16(rayLength, roughness)) */
     int32_t useDirectLight;   /* #define useDirectLight */
     int32_t missedRays;       /* #define missedRays   */
     int32_t importanceSampling; /* needs an env map: must be 0 (SURVEY.md §8f "next") */
@@ -128,7 +128,7 @@ typedef struct rfx_denoise_params {
 /* K4 — DenoiserComposePass uniforms/defines (DenoiserComposePass.js:87-110). */
 typedef struct rfx_compose_params {
     rfx_camera camera;
-    int32_t inputType; /* 0 TYPE_DIFFUSE_SPECULAR (only variant built) */
+    int32_t inputType; /* 0 TYPE_DIFFUSE_SPECULAR; 2 TYPE_SPECULAR (diffuse component = sceneTexture = RFX_TEX_DIRECT_LIGHT, specular GI = B0) */
 } rfx_compose_params;
 
 typedef struct rfx_ctx rfx_ctx;

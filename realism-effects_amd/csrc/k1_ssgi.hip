@@ -306,8 +306,8 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     Angles an = k1_angles(l, vv, n);
 
     // diffuse-vs-specular lobe selection :169-186
-    bool isDiffuseSample;
-    {
+    bool isDiffuseSample = false;  // MODE_SSR: never (:187-189)
+    if (p.mode == 0) {
         const float3 F = rfx_f_schlick(f0, an.VoH);
         float diffW = (1.0f - mat.metalness) * rfx_lum(mat.diffuse);
         float specW = rfx_lum(F);
@@ -352,8 +352,12 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
         const float4 hw = rfx_mat_mul(C, hitPos.x, hitPos.y, hitPos.z, 1.0f);
         rayLength = rfx_length(make_float3(C[12], C[13], C[14]) - make_float3(hw.x, hw.y, hw.z));
     }
-    *outp = rfx_pack_two_vec4(make_float4(diffuseGI.x, diffuseGI.y, diffuseGI.z, mat.roughness),
-                              make_float4(specularGI.x, specularGI.y, specularGI.z, rayLength));
+    if (p.mode == 0) {  // :302-304
+        *outp = rfx_pack_two_vec4(make_float4(diffuseGI.x, diffuseGI.y, diffuseGI.z, mat.roughness),
+                                  make_float4(specularGI.x, specularGI.y, specularGI.z, rayLength));
+    } else {  // MODE_SSR :298-300,306-307: raw vec4(specularGI, uintBitsToFloat(packHalf2x16(vec2(rayLength, roughness))))
+        *outp = make_uint4(__float_as_uint(specularGI.x), __float_as_uint(specularGI.y), __float_as_uint(specularGI.z), rfx_pack_half2(rayLength, mat.roughness));
+    }
 }
 
 template <bool PERSP>

@@ -29,7 +29,15 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
     const float clipW = P[2 * 4 + 3] * viewZ + P[3 * 4 + 3];
     const float4 pp = rfx_mat_mul(Pi, ((u - 0.5f) * 2.0f) * clipW, ((v - 0.5f) * 2.0f) * clipW, ((viewZ - 0.5f) * 2.0f) * clipW, 1.0f * clipW);
     const float3 viewDir = rfx_normalize(make_float3(pp.x, pp.y, -viewZ));
-    const float4 dgi = rfx_fetch_h4_linear(A.gi0, d, u, v), sgi = rfx_fetch_h4_linear(A.gi1, d, u, v);
+    // DenoiserComposePass.js:26-33: "diffuseSpecular" -> (textures[0], textures[1]); "specular" -> specularGi = textures[0],
+    // diffuseGiTexture unbound (zeros) and the diffuse component comes from sceneTexture
+    float4 dgi = make_float4(0.f, 0.f, 0.f, 0.f), sgi;
+    if (A.p.inputType == 0) {
+        dgi = rfx_fetch_h4_linear(A.gi0, d, u, v);
+        sgi = rfx_fetch_h4_linear(A.gi1, d, u, v);
+    } else {
+        sgi = rfx_fetch_h4_linear(A.gi0, d, u, v);
+    }
 
     // constructGlobalIllumination
     const float roughness = mat.roughness * mat.roughness;
@@ -50,10 +58,15 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
     const float3 f0 = rfx_mix(make_float3(0.04f, 0.04f, 0.04f), mat.diffuse, mat.metalness);
     const float3 F = rfx_f_schlick(f0, VoH);
     const float om = 1.0f - mat.metalness;
+    float3 dc = make_float3(mat.diffuse.x * om * (1.0f - F.x) * dgi.x, mat.diffuse.y * om * (1.0f - F.y) * dgi.y, mat.diffuse.z * om * (1.0f - F.z) * dgi.z);
+    if (A.p.inputType == 2) {  // denoiser_compose_functions.glsl:97-101: diffuseComponent = textureLod(sceneTexture, vUv, 0.).rgb
+        const float4 sc = ((const float4 *)A.scene.ptr)[rfx_xy_index(d, A.scene.row0, A.scene.rows, x, y)];
+        dc = make_float3(sc.x, sc.y, sc.z);
+    }
     float4 o;
-    o.x = (mat.diffuse.x * om * (1.0f - F.x) * dgi.x + sgi.x * F.x) + mat.emissive.x;
-    o.y = (mat.diffuse.y * om * (1.0f - F.y) * dgi.y + sgi.y * F.y) + mat.emissive.y;
-    o.z = (mat.diffuse.z * om * (1.0f - F.z) * dgi.z + sgi.z * F.z) + mat.emissive.z;
+    o.x = (dc.x + sgi.x * F.x) + mat.emissive.x;
+    o.y = (dc.y + sgi.y * F.y) + mat.emissive.y;
+    o.z = (dc.z + sgi.z * F.z) + mat.emissive.z;
     o.w = 1.0f;
     ((float4 *)A.out.ptr)[(size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x] = o;
 }

@@ -258,7 +258,7 @@ static void launch_rows(rfx_ctx *c, int out_id, int extra, int *y0, int *y1) {
 
 int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
     if (!c || !p) return RFX_EINVAL;
-    if (p->mode != 0) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: only mode \"ssgi\" (MODE_SSGI) is built");
+    if (p->mode != 0 && p->mode != 1) return fail(c, RFX_EINVAL, "rfx_ssgi_march: mode must be 0 (MODE_SSGI) or 1 (MODE_SSR)");
     if (p->importanceSampling) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: importanceSampling needs an env map (not built)");
     if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: only PERSPECTIVE_CAMERA is built");
     if (p->steps < 1 || p->refineSteps < 0) return fail(c, RFX_EINVAL, "rfx_ssgi_march: steps/refineSteps");
@@ -367,11 +367,12 @@ int rfx_poisson_denoise(rfx_ctx *c, const rfx_denoise_params *p) {
 
 int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
     if (!c || !p) return RFX_EINVAL;
-    if (p->inputType != 0) return fail(c, RFX_EUNSUPPORTED, "rfx_compose: only inputType diffuseSpecular is built");
+    if (p->inputType != 0 && p->inputType != 2)
+        return fail(c, RFX_EUNSUPPORTED, "rfx_compose: inputType diffuseSpecular (0) and specular (2) are built");
     if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_compose: only PERSPECTIVE_CAMERA is built");
     hipSetDevice(c->device);
-    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, RFX_TEX_DENOISE_B0, RFX_TEX_DENOISE_B1, RFX_TEX_COMPOSE};
-    int rc = need(c, ids, 5);
+    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, RFX_TEX_DENOISE_B0, RFX_TEX_DENOISE_B1, RFX_TEX_COMPOSE, RFX_TEX_DIRECT_LIGHT};
+    int rc = need(c, ids, 6);
     if (rc) return rc;
     K4Args A;
     A.dims = dims(c);
@@ -380,6 +381,7 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
     if (A.y1 > c->tile_y0 + c->tile_rows) A.y1 = c->tile_y0 + c->tile_rows;
     A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER);
     A.gi0 = view(c, RFX_TEX_DENOISE_B0); A.gi1 = view(c, RFX_TEX_DENOISE_B1);
+    A.scene = view(c, RFX_TEX_DIRECT_LIGHT);  // Denoiser.js:101-103: sceneTexture = the composer's input buffer
     A.out = wview(c, RFX_TEX_COMPOSE);
     A.p = *p;
     HIPCHK(c, rfx_launch_k4(A, c->stream));

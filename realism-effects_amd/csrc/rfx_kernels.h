@@ -49,6 +49,7 @@ struct K4Args {
     FrameDims dims;
     int y0, y1;
     TexView depth, gbuffer, gi0, gi1;
+    TexView scene;  // the composer's input buffer (sceneTexture): read only by inputType "specular"
     TexViewW out;
     rfx_compose_params p;
 };

@@ -405,7 +405,9 @@ class SSGIEffect {
 		this.composer = composer
 		this.isUsingRenderPass = true
 		if (options.mode === "ssr") {
-			throw new Error('mode "ssr" (MODE_SSR) is not built yet (SURVEY.md §8f-2)')
+			options.reprojectSpecular = true // :70-73
+			options.neighborhoodClamp = true
+			options.inputType = "specular"
 		} else if (options.mode === "ssgi") {
 			options.reprojectSpecular = [false, true] // :74-77
 			options.neighborhoodClamp = [false, true]
@@ -546,6 +548,15 @@ class SSGIEffect {
 }
 SSGIEffect.DefaultOptions = defaultSSGIOptions
 
+// src/ssgi/SSREffect.js:3-9
+class SSREffect extends SSGIEffect {
+	constructor(composer, scene, camera, options, seeds, halfStoreRTZ) {
+		options = Object.assign({}, options || {})
+		options.mode = "ssr"
+		super(composer, scene, camera, options, seeds, halfStoreRTZ)
+	}
+}
+
 // src/traa/TRAAEffect.js:10-78 — option surface + K2 parameter mapping (camera jitter needs the rasteriser)
 class TRAAEffect {
 	constructor(scene, camera, velocityDepthNormalPass, options) {
@@ -580,6 +591,7 @@ TRAAEffect.DefaultOptions = defaultTemporalReprojectPassOptions
 
 module.exports = {
 	SSGIEffect,
+	SSREffect,
 	TRAAEffect,
 	VelocityDepthNormalPass,
 	TemporalReprojectPass,

@@ -364,8 +364,10 @@ class SSGIEffect:
         options = dict(defaultSSGIOptions, **(options or {}))
         self._scene, self._camera, self.composer = scene, camera, composer
         self.isUsingRenderPass = True
-        if options["mode"] == "ssr":
-            raise NotImplementedError('mode "ssr" (MODE_SSR) is not built yet (SURVEY.md §8f-2)')
+        if options["mode"] == "ssr":  # :70-73
+            options["reprojectSpecular"] = True
+            options["neighborhoodClamp"] = True
+            options["inputType"] = "specular"
         elif options["mode"] == "ssgi":  # :74-77
             options["reprojectSpecular"] = [False, True]
             options["neighborhoodClamp"] = [False, True]
@@ -468,6 +470,15 @@ class SSGIEffect:
         _upload_plane(renderer, abi.TEX_DIRECT_LIGHT, direct)
         self.ssgiPass.render(renderer)
         self.denoiser.render(renderer, inputBuffer)
+
+
+class SSREffect(SSGIEffect):
+    """src/ssgi/SSREffect.js:3-9."""
+
+    def __init__(self, composer, scene, camera, options=None, **kw):
+        options = dict(options or {})
+        options["mode"] = "ssr"
+        super().__init__(composer, scene, camera, options, **kw)
 
 
 class TRAAEffect:

@@ -155,8 +155,6 @@ def test_presets_and_unsupported_modes():
     fx = effect.SSGIEffect(None, scene, cam, dict(preset="medium", width=32, height=16))
     assert (fx.steps, fx.refineSteps) == (20, 4)
     with pytest.raises(NotImplementedError):
-        effect.SSGIEffect(None, scene, cam, dict(mode="ssr"))
-    with pytest.raises(NotImplementedError):
         effect.SSGIEffect(None, scene, cam, dict(preset="low"))  # denoiseMode full_temporal: framebuffer-copy history
 
 
@@ -169,3 +167,17 @@ def test_traa_option_mapping():
     assert (p.textureCount, p.inputType, p.logTransform) == (1, 1, 1)
     assert abs(p.maxBlend - 0.9) < 1e-7 and p.confidencePower == 4.0 and p.neighborhoodClampIntensity == 1.0
     assert effect.TRAAEffect.DefaultOptions["confidencePower"] == 0.75
+
+
+def test_ssr_effect_parameter_mapping():
+    """SSREffect.js:3-9 + SSGIEffect.js:70-73: mode "ssr" -> MODE_SSR march, one specular texture through K2/K3, TYPE_SPECULAR compose."""
+    scene, cam = _scene()
+    fx = effect.SSREffect(None, scene, cam, dict(width=32, height=16))
+    assert fx.mode == "ssr" and fx.ssgiPass.uniforms.mode == 1
+    r = RecordingRenderer(32, 16)
+    fx.update(r, None)
+    t = [c for c in r.calls if c[0] == "temporal"][0]
+    assert t[3:6] == (1, 2, [1, 1])  # textureCount 1, inputType SPECULAR, reprojectSpecular true
+    d = [c for c in r.calls if c[0] == "denoise"]
+    assert len(d) == 2 and d[0][7] == [1, 1]
+    assert [c for c in r.calls if c[0] == "compose"][0][1] == 2

@@ -364,3 +364,61 @@ def test_single_texture_variants_vs_oracle(blue_noise):
     O.denoise(f1.depth, f1.gbuffer, out0, out0, blue_noise, dp, A0, None)
     assert_close("tc1 denoise", O.half_bits_to_float(ctx.download(abi.TEX_DENOISE_A0)), O.half_bits_to_float(A0), FLIP["denoise"])
     ctx.close()
+
+
+def test_ssr_mode_chain_vs_oracle(blue_noise):
+    """mode "ssr" end to end (SSREffect): K1 MODE_SSR -> K2 inputType SPECULAR -> K3 (one specular texture) -> K4 TYPE_SPECULAR,
+    stage by stage against the oracle, each stage fed with the oracle's previous-stage output."""
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_frame
+    from test_oracle_vs_golden import ssr_unpack
+    import rfx_oracle as O
+
+    W, H = 288, 160
+    ctx = Context(W, H)
+    comp = np.zeros((H, W, 4), np.float32)
+    A0, B0 = np.zeros((H, W, 4), np.uint16), np.zeros((H, W, 4), np.uint16)
+    T0 = np.zeros((H, W, 4), np.float32)
+    prev, keep = None, 0.0
+    for fi in range(2):
+        f = synthetic_frame(W, H, fi)
+        cam = abi.Camera.from_scene(f.camera)
+        sp = abi.SsgiParams(camera=cam, steps=20, refineSteps=5, mode=1, useDirectLight=1, rayDistance=10, thickness=10, envBlur=0.5, blueNoiseIndex=50 + fi)
+        tp = abi.TemporalParams(camera=cam, prevCamera=abi.Camera.from_scene(prev or f.camera), textureCount=1, inputType=2, logTransform=1, fullAccumulate=0,
+                                confidencePower=0.75, neighborhoodClampIntensity=0.5, maxBlend=1.0, keepData=keep)
+        tp.reprojectSpecular[:] = [1, 1]
+        tp.neighborhoodClamp[:] = [1, 1]
+        dp = abi.DenoiseParams(radius=3, phi=0.5, lumaPhi=5, depthPhi=2, normalPhi=50, roughnessPhi=50, specularPhi=50, textureCount=1, halfStoreRTZ=1)
+        dp.isTextureSpecular[:] = [1, 1]
+        cp = abi.ComposeParams(camera=cam, inputType=2)
+        ctx.upload_frame(f)
+        ctx.upload(abi.TEX_COMPOSE, comp)
+        ctx.ssgi_march(sp)
+        o = O.ssgi(f.depth, f.gbuffer, f.direct, comp, blue_noise, sp)
+        fg = f.depth < 1.0
+        assert_close("ssr ssgi f%d" % fi, ssr_unpack(ctx.download(abi.TEX_SSGI))[fg][None], ssr_unpack(o)[fg][None], FLIP["ssgi"])
+        ctx.upload(abi.TEX_SSGI, o)
+        ctx.upload(abi.TEX_DENOISE_B0, B0)
+        ctx.upload(abi.TEX_TEMPORAL0, T0)
+        ctx.temporal_reproject(tp)
+        O.temporal(o, f.velocity, B0, B0, tp, T0, None)
+        assert_close("ssr temporal f%d" % fi, ctx.download(abi.TEX_TEMPORAL0), T0, FLIP["temporal"])
+        keep, prev = 1.0, f.camera
+        ctx.upload(abi.TEX_TEMPORAL0, T0)
+        ctx.upload(abi.TEX_DENOISE_A0, A0)
+        dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 60 + 2 * fi, 1, 0
+        ctx.poisson_denoise(dp)
+        O.denoise(f.depth, f.gbuffer, T0, T0, blue_noise, dp, A0, None)
+        assert_close("ssr A0 f%d" % fi, O.half_bits_to_float(ctx.download(abi.TEX_DENOISE_A0)), O.half_bits_to_float(A0), FLIP["denoise"])
+        ctx.upload(abi.TEX_DENOISE_A0, A0)
+        dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 61 + 2 * fi, 0, 1
+        ctx.poisson_denoise(dp)
+        O.denoise(f.depth, f.gbuffer, A0, A0, blue_noise, dp, B0, None)
+        assert_close("ssr B0 f%d" % fi, O.half_bits_to_float(ctx.download(abi.TEX_DENOISE_B0)), O.half_bits_to_float(B0), FLIP["denoise"])
+        ctx.upload(abi.TEX_DENOISE_B0, B0)
+        ctx.upload(abi.TEX_COMPOSE, comp)
+        ctx.compose(cp)
+        O.compose(f.depth, f.gbuffer, B0, None, cp, comp, scene=f.direct)
+        assert_close("ssr compose f%d" % fi, ctx.download(abi.TEX_COMPOSE), comp, FLIP["compose"])
+    ctx.close()
