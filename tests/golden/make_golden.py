@@ -34,12 +34,12 @@ def cam_arrays(cam, prefix):
             ("projectionMatrix", "projectionMatrixInverse", "matrixWorld", "matrixWorldInverse", "position", "quaternion")}
 
 
-def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_start=2000, mode="ssgi"):
+def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_start=2000, mode="ssgi", missed_rays=False):
     bn = np.fromfile(os.path.join(ROOT, "realism-effects_amd", "data", "blue_noise_128_rgba8.bin"), np.uint8).reshape(128, 128, 4)
-    c = chain.GLRefChain(W, H, bn, steps=steps, refineSteps=refine, denoiseIterations=iterations, mode=mode)
+    c = chain.GLRefChain(W, H, bn, steps=steps, refineSteps=refine, denoiseIterations=iterations, mode=mode, missedRays=missed_rays)
     tc = c.tc
     out = dict(width=W, height=H, frames=frames, steps=steps, refineSteps=refine, denoiseIterations=iterations, ssgi_start=ssgi_start,
-               denoise_start=denoise_start, gl_info=chain.GL.info(), mode=mode, textureCount=tc)
+               denoise_start=denoise_start, gl_info=chain.GL.info(), mode=mode, textureCount=tc, missedRays=int(missed_rays))
     si = di = 0
     for fi in range(frames):
         f = synthetic_frame(W, H, fi)
@@ -76,3 +76,4 @@ if __name__ == "__main__":
     run("chain_160x90_s20r5_it1", 160, 90, frames=3, steps=20, refine=5, iterations=1)
     run("chain_97x55_s8r2_it2", 97, 55, frames=2, steps=8, refine=2, iterations=2)
     run("chain_ssr_128x72_s20r5_it1", 128, 72, frames=2, steps=20, refine=5, iterations=1, mode="ssr")
+    run("chain_missed_96x54_s12r3_it1", 96, 54, frames=2, steps=12, refine=3, iterations=1, missed_rays=True)

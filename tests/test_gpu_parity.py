@@ -12,9 +12,9 @@ pytestmark = pytest.mark.gpu
 FLIP = dict(ssgi=2e-3, temporal=2e-3, denoise=6e-3, compose=1e-3)
 
 
-def _params(abi, frame, prev_cam, keep, steps=20, refine=5):
+def _params(abi, frame, prev_cam, keep, steps=20, refine=5, missed=0):
     cam = abi.Camera.from_scene(frame.camera)
-    sp = abi.SsgiParams(camera=cam, steps=steps, refineSteps=refine, mode=0, useDirectLight=1, missedRays=0, importanceSampling=0,
+    sp = abi.SsgiParams(camera=cam, steps=steps, refineSteps=refine, mode=0, useDirectLight=1, missedRays=missed, importanceSampling=0,
                         rayDistance=10, thickness=10, envBlur=0.5, blueNoiseIndex=0)
     tp = abi.TemporalParams(camera=cam, prevCamera=abi.Camera.from_scene(prev_cam), textureCount=2, inputType=0, logTransform=1, fullAccumulate=0,
                             confidencePower=0.75, neighborhoodClampIntensity=0.5, maxBlend=1.0, keepData=keep)
@@ -27,8 +27,8 @@ def _params(abi, frame, prev_cam, keep, steps=20, refine=5):
     return sp, tp, dp, cp
 
 
-@pytest.mark.parametrize("size,steps,refine", [((320, 180), 20, 5), ((250, 141), 8, 2)])
-def test_chain_stagewise_vs_oracle(blue_noise, size, steps, refine):
+@pytest.mark.parametrize("size,steps,refine,missed", [((320, 180), 20, 5, 0), ((250, 141), 8, 2, 0), ((200, 112), 12, 3, 1)])
+def test_chain_stagewise_vs_oracle(blue_noise, size, steps, refine, missed):
     from rfx_amd import abi
     from rfx_amd.context import Context
     from rfx_amd.scene import synthetic_frame
@@ -43,7 +43,7 @@ def test_chain_stagewise_vs_oracle(blue_noise, size, steps, refine):
     prev_cam, keep = None, 0.0
     for fi in range(3):
         f = synthetic_frame(W, H, fi)
-        sp, tp, dp, cp = _params(abi, f, prev_cam or f.camera, keep, steps, refine)
+        sp, tp, dp, cp = _params(abi, f, prev_cam or f.camera, keep, steps, refine, missed)
         ctx.upload_frame(f)
         # ---- K1
         sp.blueNoiseIndex = 1000 + fi

@@ -16,7 +16,8 @@ def stage_params(g, fi, keep):
     cam = abi.Camera.from_scene(G.camera(g, fi))
     prev = abi.Camera.from_scene(G.camera(g, fi - 1 if fi > 0 else 0))
     sp = abi.SsgiParams(camera=cam, steps=int(g["steps"]), refineSteps=int(g["refineSteps"]), mode=0, useDirectLight=1, rayDistance=10,
-                        thickness=10, envBlur=0.5, blueNoiseIndex=int(g["f%d_ssgi_index" % fi]))
+                        thickness=10, envBlur=0.5, blueNoiseIndex=int(g["f%d_ssgi_index" % fi]),
+                        missedRays=int(g["missedRays"]) if "missedRays" in g.files else 0)
     tp = abi.TemporalParams(camera=cam, prevCamera=prev, textureCount=2, inputType=0, logTransform=1, fullAccumulate=0, confidencePower=0.75,
                             neighborhoodClampIntensity=0.5, maxBlend=1.0, keepData=keep)
     tp.reprojectSpecular[:] = [0, 1]
@@ -86,7 +87,8 @@ def test_full_chain_through_effect(name):
     scene = types.SimpleNamespace(frame=None)
     cam = G.camera(g, 0)
     fx = SSGIEffect(None, scene, cam, dict(steps=int(g["steps"]), refineSteps=int(g["refineSteps"]), denoiseIterations=int(g["denoiseIterations"]),
-                                           width=W, height=H), seeds=dict(ssgi=int(g["ssgi_start"]), denoise=int(g["denoise_start"])))
+                                           missedRays=bool(int(g["missedRays"])) if "missedRays" in g.files else False, width=W, height=H),
+                    seeds=dict(ssgi=int(g["ssgi_start"]), denoise=int(g["denoise_start"])))
     r = OracleRenderer(W, H)
     for fi in range(nf):
         scene.frame = G.frame(g, fi)
