@@ -196,13 +196,10 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
     const float moveFactor = fminf((cvel.x * cvel.x + cvel.y * cvel.y) * 10000.0f, 1.0f);
     const size_t oi = (size_t)rfx_local_row(d, A.out0.row0, A.out0.rows, y) * d.W + x;
 
-    // neighbourhood columns/rows with CLAMP_TO_EDGE, as LDS offsets
-    int nxo[5], nyo[5];
+    // neighbourhood columns with CLAMP_TO_EDGE, as LDS offsets
+    int nxo[5];
 #pragma unroll
-    for (int o = -2; o <= 2; o++) {
-        nxo[o + 2] = min(max(x + o, 0), d.W - 1) - tx0 + AP;
-        nyo[o + 2] = (min(max(y + o, 0), d.H - 1) - ty0 + AP) * LW;
-    }
+    for (int o = -2; o <= 2; o++) nxo[o + 2] = min(max(x + o, 0), d.W - 1) - tx0 + AP;
 
     // history taps first: 5 bilinear fetches x TC textures are issued before the LDS neighbourhood loops so their latency
     // overlaps with that work (sampleReprojectedTexture, reproject.frag:257-263)
@@ -231,18 +228,23 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
             const float3 ic = k2_from_log<LOGT>(inrgb);
             float3 mn = ic, mx = ic;
             const float4 *nt = s.tex[(INPUT_TYPE == 0 && spec) ? 1 : 0];
-#pragma unroll
-            for (int oy = 0; oy < 5; oy++)
+#ifndef RFX_K2_UNROLL_Y
+#define RFX_K2_UNROLL_Y 5
+#endif
+#pragma unroll RFX_K2_UNROLL_Y
+            for (int oy = 0; oy < 5; oy++) {
+                const int nrow = (min(max(y + oy - 2, 0), d.H - 1) - ty0 + AP) * LW;  // CLAMP_TO_EDGE row, as an LDS offset
+                const bool row_in = (cr == 2) || (oy >= 1 && oy <= 3);
 #pragma unroll
                 for (int ox = 0; ox < 5; ox++) {
-                    if (cr == 1 && (ox == 0 || ox == 4 || oy == 0 || oy == 4)) continue;
-                    // one 16-byte LDS read per tap, selects instead of a branch: a branch makes the compiler fetch .x first and
+                    // one 16-byte LDS read per tap and selects instead of branches: a branch makes the compiler fetch .x first and
                     // .yz later as 4-byte reads, which are 4-way bank-conflicted at this 16-byte lane stride
-                    const float4 t = nt[nyo[oy] + nxo[ox]];
-                    const bool ok = t.x >= 0.0f;
+                    const float4 t = nt[nrow + nxo[ox]];
+                    const bool ok = (t.x >= 0.0f) && row_in && ((cr == 2) || (ox >= 1 && ox <= 3));
                     mn = make_float3(ok ? fminf(t.x, mn.x) : mn.x, ok ? fminf(t.y, mn.y) : mn.y, ok ? fminf(t.z, mn.z) : mn.z);
                     mx = make_float3(ok ? fmaxf(t.x, mx.x) : mx.x, ok ? fmaxf(t.y, mx.y) : mx.y, ok ? fmaxf(t.z, mx.z) : mx.z);
                 }
+            }
             mn = k2_to_log<LOGT>(mn);
             mx = k2_to_log<LOGT>(mx);
             const float3 clamped = make_float3(rfx_clamp(accrgb.x, mn.x, mx.x), rfx_clamp(accrgb.y, mn.y, mx.y), rfx_clamp(accrgb.z, mn.z, mx.z));
@@ -274,7 +276,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
 }
 
 template <int INPUT_TYPE, int TC, bool LOGT>
-__global__ __launch_bounds__(NT) void k2_temporal_reproject(K2Args A) {
+__global__ __launch_bounds__(NT, 4) void k2_temporal_reproject(K2Args A) {  // 4 waves/SIMD = two 512-thread tiles per CU (<= 128 VGPRs)
     FrameDims d = A.dims;
     d.viol = 0;
     k2_body<INPUT_TYPE, TC, LOGT>(A, d);

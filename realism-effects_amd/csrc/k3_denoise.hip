@@ -168,7 +168,13 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     const float m00 = rf * co, m01 = rf * -sn, m10 = rf * sn, m11 = rf * co;  // mat2 rm = r*flatness*mat2(c,-s,s,c) :183
 
     // pass 0 taps are cheap LDS reads: unroll fully; the bilinear variant carries 8 half4 texels per tap, keep VGPRs down
-#pragma unroll IN_TEMPORAL ? 8 : 2
+#ifndef RFX_K3_UNROLL_N
+#define RFX_K3_UNROLL_N 1
+#endif
+#ifndef RFX_K3_UNROLL_0
+#define RFX_K3_UNROLL_0 1
+#endif
+#pragma unroll IN_TEMPORAL ? RFX_K3_UNROLL_0 : RFX_K3_UNROLL_N
     for (int k = 0; k < 8; k++) {
         const float ox = A.tap_ox[k], oy = A.tap_oy[k];  // POISSON[k] / resolution (:91-92,:189), divided once on the host
         const float nu = u + (m00 * ox + m10 * oy), nv = v + (m01 * ox + m11 * oy);
