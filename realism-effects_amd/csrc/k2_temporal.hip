@@ -276,7 +276,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
 }
 
 template <int INPUT_TYPE, int TC, bool LOGT>
-__global__ __launch_bounds__(NT, 4) void k2_temporal_reproject(K2Args A) {  // 4 waves/SIMD = two 512-thread tiles per CU (<= 128 VGPRs)
+__global__ __launch_bounds__(NT) void k2_temporal_reproject(K2Args A) {  // (forcing 128 VGPRs for 2 tiles/CU spills 17 registers to scratch: +470 MB of writes, no gain)
     FrameDims d = A.dims;
     d.viol = 0;
     k2_body<INPUT_TYPE, TC, LOGT>(A, d);
