@@ -3,7 +3,7 @@
 // src/temporal-reproject/TemporalReprojectPass.js:192-193 with the fragment program
 // src/temporal-reproject/shader/temporal_reproject.frag (+ reproject.frag), PERSPECTIVE_CAMERA.
 //
-// A 64x8-pixel workgroup tile with a 2-texel apron is staged through LDS once: the packed K1 output
+// A 64x4-pixel workgroup tile (four waves; at 149 VGPRs three such tiles are resident per CU) with a 2-texel apron is staged through LDS once: the packed K1 output
 // is unpacked (8 halfs -> two float4) and the velocity texel is decoded (normal + depth) ONE time per
 // texel, so the (2r+1)^2 neighbourhood AABB of both textures (up to 50 taps per pixel) and the 2x2-quad
 // derivatives read LDS instead of re-fetching and re-unpacking global texels.  The history taps
@@ -14,8 +14,17 @@
 
 namespace {
 
-constexpr int TW = 64, TH = 8, AP = 2;            // tile, apron (neighbourhood radius <= 2)
-constexpr int LW = TW + 2 * AP, LH = TH + 2 * AP;  // 68 x 12 staged texels
+#ifndef RFX_K2_TH
+#define RFX_K2_TH 4
+#endif
+#ifndef RFX_K2_FENCE
+#define RFX_K2_FENCE 0
+#endif
+#ifndef RFX_K2_WAVES
+#define RFX_K2_WAVES 0
+#endif
+constexpr int TW = 64, TH = RFX_K2_TH, AP = 2;    // tile, apron (neighbourhood radius <= 2)
+constexpr int LW = TW + 2 * AP, LH = TH + 2 * AP;  // 68 x 8 staged texels
 constexpr int NT = TW * TH;
 
 struct VND {
@@ -103,6 +112,11 @@ RFX_DEV float4 k2_unpack(uint4 t, int idx) {
     return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
 }
 
+RFX_DEV float4 k2_mask_unsampled(float4 t) {
+    const float qnan = __builtin_nanf("");
+    return (t.x >= 0.0f) ? t : make_float4(qnan, qnan, qnan, t.w);
+}
+
 struct Tile {
     float4 tex[2][LH * LW];  // unpacked input texels: [0] = diffuse (or the raw single texture), [1] = specular
     float4 vn[LH * LW];      // velocity texel: world normal.xyz, depth
@@ -122,8 +136,11 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
         const int gx = tx0 - AP + lx, gy = ty0 - AP + ly;
         if (gx < 0 || gx >= d.W || gy < 0 || gy >= d.H || gy > A.y1 - 1 + AP) continue;
         const uint4 t = ((const uint4 *)A.ssgi.ptr)[(size_t)rfx_local_row(d, A.ssgi.row0, A.ssgi.rows, gy) * d.W + gx];
-        s.tex[0][i] = k2_unpack<INPUT_TYPE>(t, 0);
-        if (INPUT_TYPE == 0) s.tex[1][i] = k2_unpack<INPUT_TYPE>(t, 1);
+        // a texel that was not sampled (`!(t.r >= 0.)`) takes no part in any neighbourhood AABB (reproject.frag:66) and its
+        // colour is never read as a centre texel either: stage its rgb as quiet NaNs, which v_min/v_max skip, so the
+        // 25-tap loops below need no per-tap test.  .a (roughness / ray length) is kept.
+        s.tex[0][i] = k2_mask_unsampled(k2_unpack<INPUT_TYPE>(t, 0));
+        if (INPUT_TYPE == 0) s.tex[1][i] = k2_mask_unsampled(k2_unpack<INPUT_TYPE>(t, 1));
         const VND vd = k2_vnd(((const uint4 *)A.velocity.ptr)[(size_t)rfx_local_row(d, A.velocity.row0, A.velocity.rows, gy) * d.W + gx]);
         s.vn[i] = make_float4(vd.normal.x, vd.normal.y, vd.normal.z, vd.depth);
         s.vel[i] = make_float2(vd.vx, vd.vy);
@@ -201,21 +218,17 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
 #pragma unroll
     for (int o = -2; o <= 2; o++) nxo[o + 2] = min(max(x + o, 0), d.W - 1) - tx0 + AP;
 
-    // history taps first: 5 bilinear fetches x TC textures are issued before the LDS neighbourhood loops so their latency
-    // overlaps with that work (sampleReprojectedTexture, reproject.frag:257-263)
-    float4 accv[TC];
-#pragma unroll
-    for (int i = 0; i < TC; i++) {
-        const float3 uvc = (p.reprojectSpecular[i] != 0) ? rs : rd;
-        accv[i] = k2_bicubic(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
-    }
-
 #pragma unroll
     for (int i = 0; i < TC; i++) {
         const bool spec = p.reprojectSpecular[i] != 0;
         const float3 uvc = spec ? rs : rd;
-        // reproject() :83-122
-        const float4 acc = accv[i];
+        // reproject() :83-122.  The 5 bilinear history fetches of THIS texture (sampleReprojectedTexture, reproject.frag:257-263)
+        // are issued here, ahead of the LDS neighbourhood reduction that hides their latency; fetching both textures' taps
+        // up front held 80 VGPRs of texels and capped the kernel at one workgroup per CU.
+#if RFX_K2_FENCE
+        if (i) asm volatile("" ::: "memory");  // keep texture 1's 20 history texels out of flight while texture 0 is reduced
+#endif
+        const float4 acc = k2_bicubic(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
         float3 accrgb = k2_to_log<LOGT>(make_float3(acc.x, acc.y, acc.z));
         float acca = acc.w;
         float3 inrgb = make_float3(inp[i].x, inp[i].y, inp[i].z);
@@ -226,25 +239,43 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
             const int cr = (spec && roughness < 0.25f) ? 1 : 2;
             // clampNeighborhood reproject.frag:83-95 / getNeighborhoodAABB :53-81 (raw neighbour texels, centre included)
             const float3 ic = k2_from_log<LOGT>(inrgb);
-            float3 mn = ic, mx = ic;
+            // The 3x3 core is always inside the window; the outer ring only when the radius is 2.  min/max are order
+            // independent, so the two sets are reduced separately (three-operand v_min3/v_max3) and joined by one select.
+            const float qnan = __builtin_nanf("");
+            float3 mni = ic, mxi = ic;
+            float3 mno = make_float3(qnan, qnan, qnan), mxo = mno;
             const float4 *nt = s.tex[(INPUT_TYPE == 0 && spec) ? 1 : 0];
 #ifndef RFX_K2_UNROLL_Y
 #define RFX_K2_UNROLL_Y 5
 #endif
 #pragma unroll RFX_K2_UNROLL_Y
-            for (int oy = 0; oy < 5; oy++) {
+            for (int oy = 0; oy < 5; oy++) {  // one row of five 12-byte LDS reads in flight at a time keeps the kernel under 128 VGPRs
                 const int nrow = (min(max(y + oy - 2, 0), d.H - 1) - ty0 + AP) * LW;  // CLAMP_TO_EDGE row, as an LDS offset
-                const bool row_in = (cr == 2) || (oy >= 1 && oy <= 3);
-#pragma unroll
-                for (int ox = 0; ox < 5; ox++) {
-                    // one 16-byte LDS read per tap and selects instead of branches: a branch makes the compiler fetch .x first and
-                    // .yz later as 4-byte reads, which are 4-way bank-conflicted at this 16-byte lane stride
-                    const float4 t = nt[nrow + nxo[ox]];
-                    const bool ok = (t.x >= 0.0f) && row_in && ((cr == 2) || (ox >= 1 && ox <= 3));
-                    mn = make_float3(ok ? fminf(t.x, mn.x) : mn.x, ok ? fminf(t.y, mn.y) : mn.y, ok ? fminf(t.z, mn.z) : mn.z);
-                    mx = make_float3(ok ? fmaxf(t.x, mx.x) : mx.x, ok ? fmaxf(t.y, mx.y) : mx.y, ok ? fmaxf(t.z, mx.z) : mx.z);
+                const float4 t0 = nt[nrow + nxo[0]], t1 = nt[nrow + nxo[1]], t2 = nt[nrow + nxo[2]], t3 = nt[nrow + nxo[3]], t4 = nt[nrow + nxo[4]];
+#define K2_RED3(acc_mn, acc_mx, a, b)                                                                                         \
+    acc_mn = make_float3(rfx_min3_raw(acc_mn.x, a.x, b.x), rfx_min3_raw(acc_mn.y, a.y, b.y), rfx_min3_raw(acc_mn.z, a.z, b.z)); \
+    acc_mx = make_float3(rfx_max3_raw(acc_mx.x, a.x, b.x), rfx_max3_raw(acc_mx.y, a.y, b.y), rfx_max3_raw(acc_mx.z, a.z, b.z))
+#define K2_RED2(acc_mn, acc_mx, a)                                                                                 \
+    acc_mn = make_float3(rfx_min_raw(acc_mn.x, a.x), rfx_min_raw(acc_mn.y, a.y), rfx_min_raw(acc_mn.z, a.z)); \
+    acc_mx = make_float3(rfx_max_raw(acc_mx.x, a.x), rfx_max_raw(acc_mx.y, a.y), rfx_max_raw(acc_mx.z, a.z))
+                if (oy >= 1 && oy <= 3) {
+                    K2_RED3(mni, mxi, t1, t2);
+                    K2_RED2(mni, mxi, t3);
+                    K2_RED3(mno, mxo, t0, t4);
+                } else {
+                    K2_RED3(mno, mxo, t0, t1);
+                    K2_RED3(mno, mxo, t2, t3);
+                    K2_RED2(mno, mxo, t4);
                 }
             }
+            float3 mn, mx;
+            {
+                const bool wide = cr == 2;
+                mn = make_float3(wide ? rfx_min_raw(mni.x, mno.x) : mni.x, wide ? rfx_min_raw(mni.y, mno.y) : mni.y, wide ? rfx_min_raw(mni.z, mno.z) : mni.z);
+                mx = make_float3(wide ? rfx_max_raw(mxi.x, mxo.x) : mxi.x, wide ? rfx_max_raw(mxi.y, mxo.y) : mxi.y, wide ? rfx_max_raw(mxi.z, mxo.z) : mxi.z);
+            }
+#undef K2_RED3
+#undef K2_RED2
             mn = k2_to_log<LOGT>(mn);
             mx = k2_to_log<LOGT>(mx);
             const float3 clamped = make_float3(rfx_clamp(accrgb.x, mn.x, mx.x), rfx_clamp(accrgb.y, mn.y, mx.y), rfx_clamp(accrgb.z, mn.z, mx.z));
@@ -276,7 +307,11 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
 }
 
 template <int INPUT_TYPE, int TC, bool LOGT>
-__global__ __launch_bounds__(NT) void k2_temporal_reproject(K2Args A) {  // (forcing 128 VGPRs for 2 tiles/CU spills 17 registers to scratch: +470 MB of writes, no gain)
+#if RFX_K2_WAVES
+__global__ __launch_bounds__(NT, RFX_K2_WAVES) void k2_temporal_reproject(K2Args A) {
+#else
+__global__ __launch_bounds__(NT) void k2_temporal_reproject(K2Args A) {
+#endif
     FrameDims d = A.dims;
     d.viol = 0;
     k2_body<INPUT_TYPE, TC, LOGT>(A, d);

@@ -35,12 +35,16 @@ struct CenterTexel {
 RFX_DEV float k3_luma(float3 a) { return rfx_pow(rfx_lum(a), 0.125f); }  // poisson_denoise.frag:28
 RFX_DEV float3 k3_log3(float x, float y, float z) { return make_float3(rfx_log(x + 1.0f), rfx_log(y + 1.0f), rfx_log(z + 1.0f)); }
 
-// applyWeight poisson_denoise.frag:102-124 on an already log-transformed tap
-RFX_DEV void k3_apply(CenterTexel &c, float w, float3 tl, float tapLuma, float lumaPhi) {
-    float disocclW = rfx_pow(w, 0.1f);
-    float lumaDiff = fminf(fabsf(c.lumaPow - tapLuma), 0.5f);
-    float lumaFactor = rfx_exp(-lumaDiff * lumaPhi);
-    w = rfx_mix(w * lumaFactor, disocclW, c.w) * c.w;
+// applyWeight poisson_denoise.frag:102-124 on an already log-transformed tap.  The bilateral weight arrives as its base-2
+// LOGARITHM `l2w`: the reference forms w = exp(-a) (getBasicNeighborWeight :52-78) [* exp(-g) for a specular texture], then
+// needs w * exp(-lumaDiff * lumaPhi) and pow(w, 0.1) — i.e. exp2(l2w + l2luma) and exp2(0.1 * l2w): two v_exp_f32 instead of
+// exp, log, exp, exp.  l2w = -inf (background tap, :60) gives 0 for both, as w = 0 does in the reference.
+constexpr float K3_LOG2E = 1.4426950408889634f;
+RFX_DEV void k3_apply(CenterTexel &c, float l2w, float3 tl, float tapLuma, float lumaPhiL2) {
+    const float disocclW = rfx_exp2(0.1f * l2w);
+    const float lumaDiff = fminf(fabsf(c.lumaPow - tapLuma), 0.5f);
+    const float wl = rfx_exp2(l2w - lumaDiff * lumaPhiL2);  // w * lumaFactor
+    float w = rfx_mix(wl, disocclW, c.w) * c.w;
     w = (w < 0.0001f) ? 0.0f : w;  // w *= step(0.0001, w)
     c.rgb = c.rgb + tl * w;
     c.total += w;
@@ -110,7 +114,8 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     const float3 normal = make_float3(gc.x, gc.y, gc.z);
     const float roughness = gc.w;
     const float glossiness = fmaxf(0.0f, 4.0f * (1.0f - roughness / 0.25f));
-    const float specularFactor = rfx_exp(-glossiness * p.specularPhi);
+    const float l2spec = -glossiness * p.specularPhi * K3_LOG2E;  // log2(specularFactor) :169
+    const float lumaPhiL2 = p.lumaPhi * K3_LOG2E;
     float flatness;
     {
         const float4 nxa = s_geom[qx0], nxb = s_geom[qx1], nya = s_geom[qy0], nyb = s_geom[qy1];
@@ -182,26 +187,24 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         const int ny = min(max(rfx_nearest_idx(nv, d.fH, d.H) - ty0 + Ry, 0), LH - 1);
         const int ni = ny * LW + nx;
         // getBasicNeighborWeight :52-78
-        float wBasic = 0.0f;
         const float nd = s_depth[ni];
-        if (nd != 1.0f) {
-            const float4 ng = s_geom[ni];
-            const float normalDiff = 1.0f - fmaxf(rfx_dot(normal, make_float3(ng.x, ng.y, ng.z)), 0.0f);
-            const float depthDiff = 10000.0f * fabsf(depth - nd);
-            const float roughDiff = fabsf(roughness - ng.w);
-            wBasic = rfx_exp(-normalDiff * p.normalPhi - depthDiff * p.depthPhi - roughDiff * p.roughnessPhi);
-        }
+        const float4 ng = s_geom[ni];
+        const float normalDiff = 1.0f - fmaxf(rfx_dot(normal, make_float3(ng.x, ng.y, ng.z)), 0.0f);
+        const float depthDiff = 10000.0f * fabsf(depth - nd);
+        const float roughDiff = fabsf(roughness - ng.w);
+        float l2basic = (-normalDiff * p.normalPhi - depthDiff * p.depthPhi - roughDiff * p.roughnessPhi) * K3_LOG2E;
+        l2basic = (nd != 1.0f) ? l2basic : -__builtin_inff();
 #pragma unroll
         for (int i = 0; i < TC; i++) {
             const int ti = (TC == 2 && isSpec[i]) ? 1 : 0;
-            const float w = isSpec[i] ? wBasic * specularFactor : wBasic;
+            const float l2w = isSpec[i] ? l2basic + l2spec : l2basic;
             if constexpr (IN_TEMPORAL) {
                 const float4 tl = s_in0[ti * ntex + ni];
-                k3_apply(c[i], w, make_float3(tl.x, tl.y, tl.z), tl.w, p.lumaPhi);
+                k3_apply(c[i], l2w, make_float3(tl.x, tl.y, tl.z), tl.w, lumaPhiL2);
             } else {
                 const float4 t = lds_linear(ti, nu, nv);
                 const float3 tl = k3_log3(t.x, t.y, t.z);
-                k3_apply(c[i], w, tl, k3_luma(tl), p.lumaPhi);
+                k3_apply(c[i], l2w, tl, k3_luma(tl), lumaPhiL2);
             }
         }
     }
@@ -255,7 +258,8 @@ RFX_DEV void k3_generic_body(const K3Args &A, const FrameDims &d) {
     const float3 normal = rfx_unpack_normal(g.y);
     const float roughness = rfx_decode_roughness(g.z);
     const float glossiness = fmaxf(0.0f, 4.0f * (1.0f - roughness / 0.25f));
-    const float specularFactor = rfx_exp(-glossiness * p.specularPhi);
+    const float l2spec = -glossiness * p.specularPhi * K3_LOG2E;
+    const float lumaPhiL2 = p.lumaPhi * K3_LOG2E;
     float flatness;
     {
         float3 nxa = rfx_unpack_normal(gbp[rfx_xy_index(d, A.gbuffer.row0, A.gbuffer.rows, qx0, y)].y);
@@ -276,7 +280,7 @@ RFX_DEV void k3_generic_body(const K3Args &A, const FrameDims &d) {
     for (int k = 0; k < 8; k++) {
         const float ox = A.tap_ox[k], oy = A.tap_oy[k];
         const float nu = u + (m00 * ox + m10 * oy), nv = v + (m01 * ox + m11 * oy);
-        float wBasic = 0.0f;
+        float l2basic = -__builtin_inff();
         {
             const uint4 ng = gbp[rfx_texel_index(d, A.gbuffer.row0, A.gbuffer.rows, nu, nv)];
             const float nd = depthp[rfx_texel_index(d, A.depth.row0, A.depth.rows, nu, nv)];
@@ -285,15 +289,15 @@ RFX_DEV void k3_generic_body(const K3Args &A, const FrameDims &d) {
                 float normalDiff = 1.0f - fmaxf(rfx_dot(normal, nn), 0.0f);
                 float depthDiff = 10000.0f * fabsf(depth - nd);
                 float roughDiff = fabsf(roughness - rfx_decode_roughness(ng.z));
-                wBasic = rfx_exp(-normalDiff * p.normalPhi - depthDiff * p.depthPhi - roughDiff * p.roughnessPhi);
+                l2basic = (-normalDiff * p.normalPhi - depthDiff * p.depthPhi - roughDiff * p.roughnessPhi) * K3_LOG2E;
             }
         }
 #pragma unroll
         for (int i = 0; i < TC; i++) {
-            const float w = isSpec[i] ? wBasic * specularFactor : wBasic;
+            const float l2w = isSpec[i] ? l2basic + l2spec : l2basic;
             const float4 t = k3_input<IN_TEMPORAL>(isSpec[i] ? A.in1 : A.in0, d, nu, nv);
             const float3 tl = k3_log3(t.x, t.y, t.z);
-            k3_apply(c[i], w, tl, k3_luma(tl), p.lumaPhi);
+            k3_apply(c[i], l2w, tl, k3_luma(tl), lumaPhiL2);
         }
     }
     const size_t oi = (size_t)rfx_local_row(d, A.out0.row0, A.out0.rows, y) * d.W + x;

@@ -120,15 +120,20 @@ RFX_DEV void rfx_linear_coord(float u, float fsize, int size, int &i0, int &i1, 
     i1 = min(i0 + 1, size - 1);
 }
 RFX_DEV float rfx_lerp(float w, float a, float b) { return a + w * (b - a); }
+// gather with a 32-bit BYTE offset from a wave-uniform base (one plane is < 4 GiB: 8K RGBA32F = 0.53 GB): the
+// compiler keeps the base in SGPRs and the offset in one VGPR instead of a 64-bit add per lane per tap
+template <typename T>
+RFX_DEV T rfx_gather(const void *base, unsigned int texel) {
+    return *(const T *)((const char *)base + (texel * (unsigned int)sizeof(T)));
+}
 RFX_DEV float4 rfx_fetch_h4_linear(const TexView &t, const FrameDims &d, float u, float v) {
     int x0, x1, y0, y1;
     float wx, wy;
     rfx_linear_coord(u, d.fW, d.W, x0, x1, wx);
     rfx_linear_coord(v, d.fH, d.H, y0, y1, wy);
-    const uint2 *p = (const uint2 *)t.ptr;
-    size_t r0 = (size_t)rfx_local_row(d, t.row0, t.rows, y0) * d.W, r1 = (size_t)rfx_local_row(d, t.row0, t.rows, y1) * d.W;
-    float4 t00 = rfx_load_half4(p[r0 + x0]), t10 = rfx_load_half4(p[r0 + x1]);
-    float4 t01 = rfx_load_half4(p[r1 + x0]), t11 = rfx_load_half4(p[r1 + x1]);
+    const unsigned int r0 = (unsigned int)(rfx_local_row(d, t.row0, t.rows, y0) * d.W), r1 = (unsigned int)(rfx_local_row(d, t.row0, t.rows, y1) * d.W);
+    float4 t00 = rfx_load_half4(rfx_gather<uint2>(t.ptr, r0 + x0)), t10 = rfx_load_half4(rfx_gather<uint2>(t.ptr, r0 + x1));
+    float4 t01 = rfx_load_half4(rfx_gather<uint2>(t.ptr, r1 + x0)), t11 = rfx_load_half4(rfx_gather<uint2>(t.ptr, r1 + x1));
     float4 r;
     r.x = rfx_lerp(wy, rfx_lerp(wx, t00.x, t10.x), rfx_lerp(wx, t01.x, t11.x));
     r.y = rfx_lerp(wy, rfx_lerp(wx, t00.y, t10.y), rfx_lerp(wx, t01.y, t11.y));
@@ -158,6 +163,13 @@ RFX_DEV float rfx_length(float3 a) { return rfx_sqrt(rfx_dot(a, a)); }
 RFX_DEV float rfx_mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
 RFX_DEV float3 rfx_mix(float3 x, float3 y, float a) { return make_float3(rfx_mix(x.x, y.x, a), rfx_mix(x.y, y.y, a), rfx_mix(x.z, y.z, a)); }
 RFX_DEV float rfx_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+// v_min/v_max issued as written.  fminf/fmaxf make hipcc canonicalise (v_max_f32 x, x) every operand it cannot prove
+// quiet — one extra VALU per value that comes from memory or LDS.  In the kernel's IEEE mode these return the non-NaN
+// operand when the other is a quiet NaN, the same NaN-suppressing min()/max() the llvmpipe oracle has (Appendix C).
+RFX_DEV float rfx_min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RFX_DEV float rfx_max_raw(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+RFX_DEV float rfx_min3_raw(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+RFX_DEV float rfx_max3_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 RFX_DEV float rfx_lum(float3 c) { return 0.2125f * c.x + 0.7154f * c.y + 0.0721f * c.z; }
 RFX_DEV float rfx_exp(float x) { return rfx_exp2(x * 1.4426950408889634f); }
 RFX_DEV float rfx_log(float x) { return rfx_log2(x) * 0.6931471805599453f; }

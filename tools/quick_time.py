@@ -10,7 +10,19 @@ from rfx_amd.scene import synthetic_frame
 
 W, H = int(sys.argv[1]), int(sys.argv[2])
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-t = time.time(); f = synthetic_frame(W, H, 1); print("scene gen %.1fs" % (time.time() - t), flush=True)
+only = sys.argv[4] if len(sys.argv) > 4 else ""  # e.g. "K1": time only the stages whose name starts with this
+import pickle
+_cache = "/tmp/rfx_frame_%dx%d.pkl" % (W, H)
+t = time.time()
+if os.path.exists(_cache):
+    f = pickle.load(open(_cache, "rb"))
+else:
+    f = synthetic_frame(W, H, 1)
+    try:
+        pickle.dump(f, open(_cache, "wb"), protocol=4)
+    except Exception as e:  # cache is a convenience only
+        print("no cache:", e)
+print("scene %.1fs" % (time.time() - t), flush=True)
 ctx = Context(W, H)
 ctx.upload_frame(f)
 cam = abi.Camera.from_scene(f.camera); pc = abi.Camera.from_scene(f.prev_camera)
@@ -32,6 +44,7 @@ for _ in range(2):
 ctx.sync()
 tot = 0
 for name, fn, bpp in stages:
+    if not name.startswith(only): continue
     ctx.time_begin()
     for _ in range(iters): fn()
     ms = ctx.time_end() / iters
