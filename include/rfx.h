@@ -10,7 +10,10 @@
  *      src/temporal-reproject/TemporalReprojectPass.js:192-193  -> rfx_temporal_reproject
  *      src/denoise/pass/PoissonDenoisePass.js:146-147           -> rfx_poisson_denoise
  *      src/denoise/pass/DenoiserComposePass.js:133-134          -> rfx_compose
- * Each entry point below replaces exactly one of those draw calls.  The `*_params` structs
+ * plus the one non-draw device operation on the path,
+ *      renderer.copyFramebufferToTexture(...)  TemporalReprojectPass.js:198-201  -> rfx_copy_framebuffer
+ *      (the pass's own history when no override textures are set: TRAAEffect, src/traa/TRAAEffect.js:52-75).
+ * Each entry point below replaces exactly one of those calls.  The `*_params` structs
  * carry what the material's `uniforms` (run-time values) and `defines` (shader variants)
  * carried; textures are addressed by slot id (`rfx_tex`), the analogue of the
  * `WebGLRenderTarget.texture` objects the passes share by reference (Denoiser.js:45,51).
@@ -38,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 1
+#define RFX_ABI_VERSION 2
 
 enum {
     RFX_OK = 0,
@@ -65,6 +68,8 @@ typedef enum rfx_tex {
     RFX_TEX_DENOISE_B0,     /* RGBA16F   K3 ping-pong target B = K2 history = K4 input              */
     RFX_TEX_DENOISE_B1,
     RFX_TEX_COMPOSE,        /* RGBA32F   K4 out = next frame's K1 `accumulatedTexture`              */
+    RFX_TEX_FBCOPY_F16,     /* RGBA16F linear   TemporalReprojectPass.framebufferTexture (:137-142) when the pass's    */
+    RFX_TEX_FBCOPY_F32,     /* RGBA32F linear   input / render target is HalfFloatType resp. FloatType (:66,139-140)   */
     RFX_TEX_COUNT
 } rfx_tex;
 
@@ -109,6 +114,14 @@ typedef struct rfx_temporal_params {
     float neighborhoodClampIntensity;
     float maxBlend;
     float keepData;               /* 0 for the first frame after reset(), else 1 */
+    int32_t historySource;        /* which textures `accumulatedTexture[i]` are (TemporalReprojectPass.js:148-151):
+                                     0  overrideAccumulatedTextures = K3's target B, RFX_TEX_DENOISE_B0/B1 (Denoiser.js:51);
+                                     1  the pass's own framebuffer copy RFX_TEX_FBCOPY_F16 (render-target type HalfFloatType);
+                                     2  the same, RFX_TEX_FBCOPY_F32 (FloatType).  1 and 2 need textureCount == 1.          */
+    int32_t targetHalf;           /* render target type = type of the input texture (:63-68): 0 FloatType — texels stored as
+                                     computed; 1 HalfFloatType — every output channel is rounded to half precision on store
+                                     (RFX_TEX_TEMPORAL* then hold half-representable floats)                                 */
+    int32_t halfStoreRTZ;         /* rounding of that store: 1 truncate (llvmpipe, parity with the oracle), 0 nearest-even    */
 } rfx_temporal_params;
 
 /* K3 — PoissonDenoisePass uniforms/defines (PoissonDenoisePass.js:43-71, SSGIEffect.js:175-190). */
@@ -160,6 +173,11 @@ int rfx_bind_external(rfx_ctx *, rfx_tex id, void *device_ptr);
 /* ---- the four draws */
 int rfx_ssgi_march(rfx_ctx *, const rfx_ssgi_params *);
 int rfx_temporal_reproject(rfx_ctx *, const rfx_temporal_params *);
+/* renderer.copyFramebufferToTexture(tmpVec2, this.framebufferTexture), TemporalReprojectPass.js:198-201: the tile rows of
+ * the pass's render target RFX_TEX_TEMPORAL0 become the history the NEXT rfx_temporal_reproject samples (linear filter).
+ * `dst` is RFX_TEX_FBCOPY_F16 (source texels must be half-representable, i.e. drawn with targetHalf = 1: the copy is then
+ * exact, as in the reference where both sides have the same type) or RFX_TEX_FBCOPY_F32. */
+int rfx_copy_framebuffer(rfx_ctx *, rfx_tex dst);
 int rfx_poisson_denoise(rfx_ctx *, const rfx_denoise_params *);
 int rfx_compose(rfx_ctx *, const rfx_compose_params *);
 

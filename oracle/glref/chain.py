@@ -142,6 +142,13 @@ def assemble_temporal(texture_count=2, input_type=0, confidence_power=0.75, repr
     return three_prefix(defines, True) + s
 
 
+def assemble_traa() -> str:
+    """TRAAEffect.js:21-33 over defaultTemporalReprojectPassOptions: one texture, inputType "diffuse", logTransform,
+    confidencePower 4, reprojectSpecular false, neighborhoodClamp true, neighborhoodClampRadius 1 (a define the shader never reads)."""
+    return assemble_temporal(texture_count=1, input_type=1, confidence_power=4, reproject_specular=False, neighborhood_clamp=True,
+                             log_transform=True, neighborhood_clamp_radius=1)
+
+
 def _to_precision5(x: float) -> str:
     """JS Number.prototype.toPrecision(5) for the values used (0.75 -> '0.75000', 4 -> '4.0000')."""
     s = "%.5g" % x
@@ -181,7 +188,8 @@ def write_assembled(outdir: str, **kw):
     for name, src in (("ssgi_20_5", assemble_ssgi(20, 5)), ("ssgi_8_2", assemble_ssgi(8, 2)), ("ssgi_40_5", assemble_ssgi(40, 5)),
                       ("temporal", assemble_temporal()), ("denoise", assemble_denoise()), ("compose", assemble_compose()),
                       ("ssgi_ssr_20_5", assemble_ssgi(20, 5, 1)), ("temporal_ssr", assemble_temporal(texture_count=1, input_type=2, reproject_specular=True, neighborhood_clamp=True)),
-                      ("denoise_ssr", assemble_denoise(texture_count=1, is_texture_specular=(True, True))), ("compose_ssr", assemble_compose(input_type=2))):
+                      ("denoise_ssr", assemble_denoise(texture_count=1, is_texture_specular=(True, True))), ("compose_ssr", assemble_compose(input_type=2)),
+                      ("temporal_traa", assemble_traa())):
         with open(os.path.join(outdir, name + ".frag"), "w") as f:
             f.write(src)
 
@@ -435,3 +443,63 @@ class GLRefChain:
         p.set("cameraFar", float(cam.far))
         p.draw([self.t_compose])
         self.ms["compose"] = p.last_ms
+
+
+class GLRefTRAA:
+    """TRAAEffect's device work (src/traa/TRAAEffect.js:52-75) on llvmpipe: TemporalReprojectPass alone on the composer's
+    input buffer, history = the pass's own framebuffer copy (TemporalReprojectPass.js:137-151,197-201).
+
+    `half` selects the composer's frameBufferType: HalfFloatType (example/main.js:173) -> RGBA16F input buffer, render
+    target and framebuffer copy; FloatType -> RGBA32F throughout.  copyFramebufferToTexture copies between two textures
+    of the same format, i.e. exactly: done here as read-back + upload of the same texel values."""
+
+    def __init__(self, width, height, half=True, shader_dir: str | None = None, full_accumulate=True):
+        self.W, self.H, self.half = width, height, half
+        if shader_dir is None and not os.path.isdir(REFERENCE_SRC):
+            shader_dir = os.path.join(REF_OUT, "shaders")
+        if shader_dir is not None:
+            with open(os.path.join(shader_dir, "temporal_traa.frag")) as f:
+                self.p = Program(f.read())
+        else:
+            self.p = Program(assemble_traa())
+        fmt = FMT_RGBA16F if half else FMT_RGBA32F
+        self.t_input = Tex(width, height, fmt)
+        self.t_velocity = Tex(width, height, FMT_RGBA32F)
+        self.t_out = Tex(width, height, fmt)                # renderTarget: Nearest (:63-68)
+        self.t_fb = Tex(width, height, fmt, linear=True)    # framebufferTexture: LinearFilter (:139-142)
+        self.full_accumulate = full_accumulate
+        self.keep_data = 1.0  # the uniform's initial value (TemporalReprojectMaterial.js); TRAAEffect never resets on its own
+        self.prev = None
+        self.ms = 0.0
+
+    def upload_frame(self, frame):
+        d = frame.direct  # the composer's input buffer = the lit scene
+        self.t_input.upload(d.astype(np.float16) if self.half else d)
+        self.t_velocity.upload(frame.velocity.view(np.float32))
+
+    def render(self, cam, camera_moved: bool = True):
+        p = self.p
+        prev = self.prev if self.prev is not None else cam
+        p.sampler("inputTexture", self.t_input)
+        p.sampler("velocityTexture", self.t_velocity)
+        p.sampler("accumulatedTexture0", self.t_fb)
+        for name, v in (("projectionMatrix", cam.projectionMatrix), ("projectionMatrixInverse", cam.projectionMatrixInverse),
+                        ("cameraMatrixWorld", cam.matrixWorld), ("viewMatrix", cam.matrixWorldInverse), ("cameraPos", cam.position),
+                        ("prevViewMatrix", prev.matrixWorldInverse), ("prevCameraMatrixWorld", prev.matrixWorld),
+                        ("prevProjectionMatrix", prev.projectionMatrix), ("prevProjectionMatrixInverse", prev.projectionMatrixInverse),
+                        ("prevCameraPos", prev.position)):
+            p.set(name, v)
+        p.set("fullAccumulate", bool(self.full_accumulate and not camera_moved))
+        p.set("keepData", float(self.keep_data))
+        p.set("invTexSize", [1.0 / self.W, 1.0 / self.H])
+        p.set("cameraNear", float(cam.near))
+        p.set("cameraFar", float(cam.far))
+        p.set("maxBlend", 0.9)                     # TRAAEffect.js:24
+        p.set("neighborhoodClampIntensity", 1.0)   # :26
+        p.draw([self.t_out])
+        self.ms = p.last_ms
+        self.keep_data = 1.0
+        out = self.t_out.read()
+        self.t_fb.upload(out.astype(np.float16) if self.half else out)  # copyFramebufferToTexture (:197-201)
+        self.prev = cam
+        return out

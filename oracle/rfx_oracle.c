@@ -169,6 +169,18 @@ static inline v4 fetch_h4_linear(const uint16_t *t, dims d, float u, float v) {
     v4 r = {o[0], o[1], o[2], o[3]}; return r;
 }
 
+/* the same sampler over an RGBA32F texture (the FloatType framebuffer copy, TemporalReprojectPass.js:137-142) */
+static inline v4 fetch_f4_linear(const float *t, dims d, float u, float v) {
+    int x0, x1, y0, y1; float wx, wy;
+    linear_coord(u, d.W, &x0, &x1, &wx);
+    linear_coord(v, d.H, &y0, &y1, &wy);
+    const float *p00 = t + 4 * ((size_t)y0 * d.W + x0), *p10 = t + 4 * ((size_t)y0 * d.W + x1);
+    const float *p01 = t + 4 * ((size_t)y1 * d.W + x0), *p11 = t + 4 * ((size_t)y1 * d.W + x1);
+    float o[4];
+    for (int c = 0; c < 4; c++) o[c] = lerpf(wy, lerpf(wx, p00[c], p10[c]), lerpf(wx, p01[c], p11[c]));
+    v4 r = {o[0], o[1], o[2], o[3]}; return r;
+}
+
 /* ------------------------------------------------------------------ codec (gbuffer_packing.glsl) */
 typedef struct { v3 diffuse; float alpha; v3 normal; float roughness, metalness; v3 emissive; } material;
 
@@ -561,7 +573,7 @@ int rfxo_ssgi(int W, int H, int y0, int y1, const float *depth, const uint32_t *
 /* ==================================================================== K2: temporal_reproject.frag */
 typedef struct {
     int W, H;
-    const uint32_t *ssgi, *velocity; const uint16_t *hist[2];
+    const uint32_t *ssgi, *velocity; const void *hist[2];
     const rfx_temporal_params *p;
     float invW, invH;
 } k2_ctx;
@@ -599,8 +611,12 @@ static float k2_validate(const k2_ctx *c, float ru, float rv, v3 worldPos, v3 wo
     conf = fmaxf(conf, 0.0f);
     return powf(conf, c->p->confidencePower);
 }
-/* BiCubicCatmullRom5Tap reproject.frag:212-255 on a linear-filtered RGBA16F texture */
-static v4 k2_bicubic(const k2_ctx *c, const uint16_t *tex, float pu, float pv) {
+/* one LINEAR tap of the history: RGBA16F (K3's target B, or a HalfFloatType framebuffer copy) or RGBA32F (FloatType copy) */
+static inline v4 k2_hist_tap(const k2_ctx *c, const void *tex, dims d, float u, float v) {
+    return c->p->historySource == 2 ? fetch_f4_linear((const float *)tex, d, u, v) : fetch_h4_linear((const uint16_t *)tex, d, u, v);
+}
+/* BiCubicCatmullRom5Tap reproject.frag:212-255 on the linear-filtered history texture */
+static v4 k2_bicubic(const k2_ctx *c, const void *tex, float pu, float pv) {
     dims d = {c->W, c->H};
     float its[2] = {c->invW, c->invH}, P[2] = {pu, pv};
     float w0[2], w1[2], w2[2], w3[2], W0[2], W1[2], W2[2], S0[2], S1[2], S2[2];
@@ -618,11 +634,11 @@ static v4 k2_bicubic(const k2_ctx *c, const uint16_t *tex, float pu, float pv) {
         S2[k] = (tc + 2.0f) * its[k];
     }
     float sw[5] = {W1[0] * W0[1], W0[0] * W1[1], W1[0] * W1[1], W2[0] * W1[1], W1[0] * W2[1]};
-    v4 Ct = fetch_h4_linear(tex, d, S1[0], S0[1]);
-    v4 Cl = fetch_h4_linear(tex, d, S0[0], S1[1]);
-    v4 Cc = fetch_h4_linear(tex, d, S1[0], S1[1]);
-    v4 Cr = fetch_h4_linear(tex, d, S2[0], S1[1]);
-    v4 Cb = fetch_h4_linear(tex, d, S1[0], S2[1]);
+    v4 Ct = k2_hist_tap(c, tex, d, S1[0], S0[1]);
+    v4 Cl = k2_hist_tap(c, tex, d, S0[0], S1[1]);
+    v4 Cc = k2_hist_tap(c, tex, d, S1[0], S1[1]);
+    v4 Cr = k2_hist_tap(c, tex, d, S2[0], S1[1]);
+    v4 Cb = k2_hist_tap(c, tex, d, S1[0], S2[1]);
     float wm = 1.0f / (sw[0] + sw[1] + sw[2] + sw[3] + sw[4]);
     v4 r;
     r.x = fmaxf(((((Ct.x * sw[0] + Cl.x * sw[1]) + Cc.x * sw[2]) + Cr.x * sw[3]) + Cb.x * sw[4]) * wm, 0.0f);
@@ -758,11 +774,14 @@ static void k2_pixel(const k2_ctx *c, int x, int y, float *out0, float *out1) {
         v3 o = expm13(mix3(inrgb, accrgb, m), lt);
         float *dst = i ? out1 : out0;
         dst[0] = o.x; dst[1] = o.y; dst[2] = o.z; dst[3] = acca;
+        if (p->targetHalf) /* HalfFloatType render target (TemporalReprojectPass.js:63-68): the store rounds to half */
+            for (int k = 0; k < 4; k++) dst[k] = half_to_float(p->halfStoreRTZ ? float_to_half_rtz(dst[k]) : float_to_half_rne(dst[k]));
     }
 }
 
-int rfxo_temporal(int W, int H, int y0, int y1, const uint32_t *ssgi, const uint32_t *velocity, const uint16_t *hist0, const uint16_t *hist1,
+int rfxo_temporal(int W, int H, int y0, int y1, const uint32_t *ssgi, const uint32_t *velocity, const void *hist0, const void *hist1,
                   const rfx_temporal_params *p, float *out0, float *out1) {
+    if (p->historySource < 0 || p->historySource > 2 || (p->historySource != 0 && p->textureCount != 1)) return RFX_EINVAL;
     k2_ctx c = {W, H, ssgi, velocity, {hist0, hist1}, p, 0, 0};
     /* TemporalReprojectPass.js:135: invTexSize.set(1 / width, 1 / height) — JS doubles -> float */
     c.invW = (float)(1.0 / (double)W); c.invH = (float)(1.0 / (double)H);

@@ -63,13 +63,15 @@ def ssgi(depth, gbuffer, direct, history, blue, params: abi.SsgiParams, out=None
 
 
 def temporal(ssgi_tex, velocity, hist0, hist1, params: abi.TemporalParams, out0=None, out1=None, rows=None):
+    """hist*: uint16 half bits (H,W,4) [historySource 0/1] or float32 (H,W,4) [historySource 2, the FloatType framebuffer copy]."""
     H, W = ssgi_tex.shape[:2]
     y0, y1 = rows or (0, H)
     out0 = np.zeros((H, W, 4), np.float32) if out0 is None else out0
     if out1 is None and params.textureCount == 2:
         out1 = np.zeros((H, W, 4), np.float32)
+    hdt = np.float32 if params.historySource == 2 else np.uint16
     rc = lib().rfxo_temporal(W, H, y0, y1, _p(_chk(ssgi_tex, np.uint32, (H, W, 4))), _p(_chk(velocity, np.uint32, (H, W, 4))),
-                             _p(_chk(hist0, np.uint16, (H, W, 4))), _p(_chk(hist1, np.uint16, (H, W, 4))), C.byref(params), _p(out0), _p(out1))
+                             _p(_chk(hist0, hdt, (H, W, 4))), _p(_chk(hist1, hdt, (H, W, 4))), C.byref(params), _p(out0), _p(out1))
     assert rc == 0, rc
     return out0, out1
 

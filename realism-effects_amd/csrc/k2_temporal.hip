@@ -61,7 +61,12 @@ RFX_DEV float k2_validate(const K2Args &A, const FrameDims &d, float ru, float r
     return rfx_pow(conf, A.p.confidencePower);
 }
 
-// BiCubicCatmullRom5Tap reproject.frag:212-255 — five hardware-bilinear taps of the RGBA16F history
+// BiCubicCatmullRom5Tap reproject.frag:212-255 — five hardware-bilinear taps of the RGBA16F (or RGBA32F) history
+template <bool HIST_F32>
+RFX_DEV float4 k2_history_tap(const TexView &tex, const FrameDims &d, float u, float v) {
+    return HIST_F32 ? rfx_fetch_f4_linear(tex, d, u, v) : rfx_fetch_h4_linear(tex, d, u, v);
+}
+template <bool HIST_F32>
 RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &tex, float pu, float pv) {
     float Wa[2], Wb[2], Wc[2], S0[2], S1[2], S2[2];
     const float its[2] = {A.invW, A.invH}, P[2] = {pu, pv};
@@ -82,11 +87,11 @@ RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &te
         S2[k] = (tc + 2.0f) * its[k];
     }
     const float sw0 = Wb[0] * Wa[1], sw1 = Wa[0] * Wb[1], sw2 = Wb[0] * Wb[1], sw3 = Wc[0] * Wb[1], sw4 = Wb[0] * Wc[1];
-    const float4 Ct = rfx_fetch_h4_linear(tex, d, S1[0], S0[1]);
-    const float4 Cl = rfx_fetch_h4_linear(tex, d, S0[0], S1[1]);
-    const float4 Cc = rfx_fetch_h4_linear(tex, d, S1[0], S1[1]);
-    const float4 Cr = rfx_fetch_h4_linear(tex, d, S2[0], S1[1]);
-    const float4 Cb = rfx_fetch_h4_linear(tex, d, S1[0], S2[1]);
+    const float4 Ct = k2_history_tap<HIST_F32>(tex, d, S1[0], S0[1]);
+    const float4 Cl = k2_history_tap<HIST_F32>(tex, d, S0[0], S1[1]);
+    const float4 Cc = k2_history_tap<HIST_F32>(tex, d, S1[0], S1[1]);
+    const float4 Cr = k2_history_tap<HIST_F32>(tex, d, S2[0], S1[1]);
+    const float4 Cb = k2_history_tap<HIST_F32>(tex, d, S1[0], S2[1]);
     const float wm = rfx_rcp((((sw0 + sw1) + sw2) + sw3) + sw4);
     float4 r;
     r.x = fmaxf(((((Ct.x * sw0 + Cl.x * sw1) + Cc.x * sw2) + Cr.x * sw3) + Cb.x * sw4) * wm, 0.0f);
@@ -123,7 +128,7 @@ struct Tile {
     float2 vel[LH * LW];     // velocity.xy
 };
 
-template <int INPUT_TYPE, int TC, bool LOGT>
+template <int INPUT_TYPE, int TC, bool LOGT, bool HIST_F32>
 RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
     __shared__ Tile s;
     const rfx_temporal_params &p = A.p;
@@ -228,7 +233,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
 #if RFX_K2_FENCE
         if (i) asm volatile("" ::: "memory");  // keep texture 1's 20 history texels out of flight while texture 0 is reduced
 #endif
-        const float4 acc = k2_bicubic(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
+        const float4 acc = k2_bicubic<HIST_F32>(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
         float3 accrgb = k2_to_log<LOGT>(make_float3(acc.x, acc.y, acc.z));
         float acca = acc.w;
         float3 inrgb = make_float3(inp[i].x, inp[i].y, inp[i].z);
@@ -302,11 +307,13 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
         const float mixv = fminf(accumBlend, maxValue);
         acca = fminf(65536.0f, rfx_rcp(1.0f - mixv) - 1.0f);
         const float3 o = k2_from_log<LOGT>(rfx_mix(inrgb, accrgb, mixv));
-        ((float4 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = make_float4(o.x, o.y, o.z, acca);
+        float4 texel = make_float4(o.x, o.y, o.z, acca);
+        if (p.targetHalf) texel = rfx_round_half4(texel, p.halfStoreRTZ != 0);  // HalfFloatType render target (TemporalReprojectPass.js:63-68)
+        ((float4 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = texel;
     }
 }
 
-template <int INPUT_TYPE, int TC, bool LOGT>
+template <int INPUT_TYPE, int TC, bool LOGT, bool HIST_F32>
 #if RFX_K2_WAVES
 __global__ __launch_bounds__(NT, RFX_K2_WAVES) void k2_temporal_reproject(K2Args A) {
 #else
@@ -314,22 +321,53 @@ __global__ __launch_bounds__(NT) void k2_temporal_reproject(K2Args A) {
 #endif
     FrameDims d = A.dims;
     d.viol = 0;
-    k2_body<INPUT_TYPE, TC, LOGT>(A, d);
+    k2_body<INPUT_TYPE, TC, LOGT, HIST_F32>(A, d);
+    rfx_flush_violations(d);
+}
+
+// renderer.copyFramebufferToTexture(tmpVec2, this.framebufferTexture) (TemporalReprojectPass.js:198-201): the pass's render
+// target becomes its own history.  Both sides have the same type in the reference; here the target always lives in an
+// RGBA32F slot, so the HalfFloatType case narrows texels that are half-representable already (drawn with targetHalf).
+template <bool TO_HALF>
+__global__ __launch_bounds__(256) void k2_copy_framebuffer(FrameDims d, int y0, int y1, TexView src, TexViewW dst) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = y0 + blockIdx.y * 4 + threadIdx.y;
+    d.viol = 0;
+    if (x < d.W && y < y1) {
+        const float4 t = ((const float4 *)src.ptr)[(size_t)rfx_local_row(d, src.row0, src.rows, y) * d.W + x];
+        const size_t o = (size_t)rfx_local_row(d, dst.row0, dst.rows, y) * d.W + x;
+        if (TO_HALF) ((uint2 *)dst.ptr)[o] = rfx_store_half4(t.x, t.y, t.z, t.w, false);
+        else ((float4 *)dst.ptr)[o] = t;
+    }
     rfx_flush_violations(d);
 }
 
 }  // namespace
 
+hipError_t rfx_launch_copy_fb(const FrameDims &d, int y0, int y1, TexView src, TexViewW dst, bool to_half, hipStream_t stream) {
+    dim3 block(64, 4), grid((d.W + 63) / 64, (y1 - y0 + 3) / 4);
+    if (to_half) hipLaunchKernelGGL(k2_copy_framebuffer<true>, grid, block, 0, stream, d, y0, y1, src, dst);
+    else hipLaunchKernelGGL(k2_copy_framebuffer<false>, grid, block, 0, stream, d, y0, y1, src, dst);
+    return hipGetLastError();
+}
+
 hipError_t rfx_launch_k2(const K2Args &A, hipStream_t stream) {
     dim3 block(TW, TH), grid((A.dims.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH);
     const bool lt = A.p.logTransform != 0;
-#define K2_LAUNCH(IT, TC)                                                                                          \
-    do {                                                                                                           \
-        if (lt) hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, true>), grid, block, 0, stream, A);              \
-        else hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, false>), grid, block, 0, stream, A);               \
+#define K2_LAUNCH(IT, TC)                                                                                                   \
+    do {                                                                                                                    \
+        if (A.hist_f32) {                                                                                                   \
+            if (lt) hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, true, true>), grid, block, 0, stream, A);             \
+            else hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, false, true>), grid, block, 0, stream, A);              \
+        } else {                                                                                                            \
+            if (lt) hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, true, false>), grid, block, 0, stream, A);            \
+            else hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, false, false>), grid, block, 0, stream, A);             \
+        }                                                                                                                   \
     } while (0)
-    if (A.p.inputType == 0 && A.p.textureCount == 2) K2_LAUNCH(0, 2);
-    else if (A.p.inputType == 1 && A.p.textureCount == 1) K2_LAUNCH(1, 1);
+    if (A.hist_f32 && A.p.textureCount != 1) return hipErrorInvalidValue;
+    if (A.p.inputType == 0 && A.p.textureCount == 2) {
+        if (lt) hipLaunchKernelGGL((k2_temporal_reproject<0, 2, true, false>), grid, block, 0, stream, A);
+        else hipLaunchKernelGGL((k2_temporal_reproject<0, 2, false, false>), grid, block, 0, stream, A);
+    } else if (A.p.inputType == 1 && A.p.textureCount == 1) K2_LAUNCH(1, 1);
     else if (A.p.inputType == 2 && A.p.textureCount == 1) K2_LAUNCH(2, 1);
     else return hipErrorInvalidValue;
 #undef K2_LAUNCH

@@ -35,7 +35,7 @@ static size_t texel_bytes(int id) {
     switch (id) {
     case RFX_TEX_DEPTH: return 4;
     case RFX_TEX_BLUE_NOISE: return 4;
-    case RFX_TEX_DENOISE_A0: case RFX_TEX_DENOISE_A1: case RFX_TEX_DENOISE_B0: case RFX_TEX_DENOISE_B1: return 8;
+    case RFX_TEX_DENOISE_A0: case RFX_TEX_DENOISE_A1: case RFX_TEX_DENOISE_B0: case RFX_TEX_DENOISE_B1: case RFX_TEX_FBCOPY_F16: return 8;
     default: return 16;
     }
 }
@@ -306,8 +306,14 @@ int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
     if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_temporal_reproject: only PERSPECTIVE_CAMERA is built");
     if (!((p->inputType == 0 && p->textureCount == 2) || ((p->inputType == 1 || p->inputType == 2) && p->textureCount == 1)))
         return fail(c, RFX_EINVAL, "rfx_temporal_reproject: inputType/textureCount combination");
+    if (p->historySource < 0 || p->historySource > 2 || (p->historySource != 0 && p->textureCount != 1))
+        return fail(c, RFX_EINVAL, "rfx_temporal_reproject: historySource (the framebuffer copy serves one texture)");
     hipSetDevice(c->device);
-    const int ids[] = {RFX_TEX_SSGI, RFX_TEX_VELOCITY, RFX_TEX_DENOISE_B0, RFX_TEX_DENOISE_B1, RFX_TEX_TEMPORAL0, RFX_TEX_TEMPORAL1};
+    const int h0 = p->historySource == 0 ? RFX_TEX_DENOISE_B0 : (p->historySource == 1 ? RFX_TEX_FBCOPY_F16 : RFX_TEX_FBCOPY_F32);
+    // with one texture the reference binds the same history to every index (TemporalReprojectPass.js:148-151)
+    const int h1 = (p->historySource == 0 && p->textureCount == 2) ? RFX_TEX_DENOISE_B1 : h0;
+    const int o1 = p->textureCount == 2 ? RFX_TEX_TEMPORAL1 : RFX_TEX_TEMPORAL0;
+    const int ids[] = {RFX_TEX_SSGI, RFX_TEX_VELOCITY, h0, h1, RFX_TEX_TEMPORAL0, o1};
     int rc = need(c, ids, 6);
     if (rc) return rc;
     if (!c->slots[RFX_TEX_VELOCITY].uploaded) return fail(c, RFX_ESTATE, "rfx_temporal_reproject: velocity not uploaded");
@@ -315,10 +321,10 @@ int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
     A.dims = dims(c);
     launch_rows(c, RFX_TEX_TEMPORAL0, 0, &A.y0, &A.y1);
     A.ssgi = view(c, RFX_TEX_SSGI); A.velocity = view(c, RFX_TEX_VELOCITY);
-    A.hist0 = view(c, RFX_TEX_DENOISE_B0);
-    // with one texture the reference binds the same history to every index (TemporalReprojectPass.js:148-151)
-    A.hist1 = view(c, p->textureCount == 2 ? RFX_TEX_DENOISE_B1 : RFX_TEX_DENOISE_B0);
-    A.out0 = wview(c, RFX_TEX_TEMPORAL0); A.out1 = wview(c, RFX_TEX_TEMPORAL1);
+    A.hist0 = view(c, h0);
+    A.hist1 = view(c, h1);
+    A.hist_f32 = p->historySource == 2;
+    A.out0 = wview(c, RFX_TEX_TEMPORAL0); A.out1 = wview(c, o1);
     A.p = *p;
     // TemporalReprojectPass.js:135: invTexSize.set(1 / width, 1 / height) in doubles
     A.invW = (float)(1.0 / (double)c->W); A.invH = (float)(1.0 / (double)c->H);
@@ -333,6 +339,19 @@ int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
             A.prevPV[col * 4 + row] = acc;
         }
     HIPCHK(c, rfx_launch_k2(A, c->stream));
+    return RFX_OK;
+}
+
+int rfx_copy_framebuffer(rfx_ctx *c, rfx_tex dst) {
+    if (!c) return RFX_EINVAL;
+    if (dst != RFX_TEX_FBCOPY_F16 && dst != RFX_TEX_FBCOPY_F32) return fail(c, RFX_EINVAL, "rfx_copy_framebuffer: dst must be RFX_TEX_FBCOPY_F16 or _F32");
+    hipSetDevice(c->device);
+    const int ids[] = {RFX_TEX_TEMPORAL0, (int)dst};
+    int rc = need(c, ids, 2);
+    if (rc) return rc;
+    int y0, y1;
+    launch_rows(c, dst, 0, &y0, &y1);
+    HIPCHK(c, rfx_launch_copy_fb(dims(c), y0, y1, view(c, RFX_TEX_TEMPORAL0), wview(c, dst), dst == RFX_TEX_FBCOPY_F16, c->stream));
     return RFX_OK;
 }
 

@@ -142,6 +142,25 @@ RFX_DEV float4 rfx_fetch_h4_linear(const TexView &t, const FrameDims &d, float u
     return r;
 }
 
+// the same sampler over an RGBA32F texture (FloatType framebuffer copy, TemporalReprojectPass.js:137-142)
+RFX_DEV float4 rfx_fetch_f4_linear(const TexView &t, const FrameDims &d, float u, float v) {
+    int x0, x1, y0, y1;
+    float wx, wy;
+    rfx_linear_coord(u, d.fW, d.W, x0, x1, wx);
+    rfx_linear_coord(v, d.fH, d.H, y0, y1, wy);
+    const unsigned int r0 = (unsigned int)(rfx_local_row(d, t.row0, t.rows, y0) * d.W), r1 = (unsigned int)(rfx_local_row(d, t.row0, t.rows, y1) * d.W);
+    const float4 t00 = rfx_gather<float4>(t.ptr, r0 + x0), t10 = rfx_gather<float4>(t.ptr, r0 + x1);
+    const float4 t01 = rfx_gather<float4>(t.ptr, r1 + x0), t11 = rfx_gather<float4>(t.ptr, r1 + x1);
+    float4 r;
+    r.x = rfx_lerp(wy, rfx_lerp(wx, t00.x, t10.x), rfx_lerp(wx, t01.x, t11.x));
+    r.y = rfx_lerp(wy, rfx_lerp(wx, t00.y, t10.y), rfx_lerp(wx, t01.y, t11.y));
+    r.z = rfx_lerp(wy, rfx_lerp(wx, t00.z, t10.z), rfx_lerp(wx, t01.z, t11.z));
+    r.w = rfx_lerp(wy, rfx_lerp(wx, t00.w, t10.w), rfx_lerp(wx, t01.w, t11.w));
+    return r;
+}
+// value of an RGBA16F render-target texel after the store (rounded to half, read back as float)
+RFX_DEV float4 rfx_round_half4(float4 v, bool rtz) { return rfx_load_half4(rfx_store_half4(v.x, v.y, v.z, v.w, rtz)); }
+
 // ---------------------------------------------------------------- float3 helpers
 RFX_DEV float3 operator+(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
 RFX_DEV float3 operator-(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }

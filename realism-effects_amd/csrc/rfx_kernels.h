@@ -25,7 +25,8 @@ struct K1Args {
 struct K2Args {
     FrameDims dims;
     int y0, y1;
-    TexView ssgi, velocity, hist0, hist1;  // hist* = K3 target B of the previous frame (RGBA16F, linear)
+    TexView ssgi, velocity, hist0, hist1;  // hist* = K3 target B of the previous frame (RGBA16F, linear), or the pass's framebuffer copy
+    int hist_f32;                          // history texels are RGBA32F (FloatType framebuffer copy) instead of RGBA16F
     TexViewW out0, out1;
     rfx_temporal_params p;
     float invW, invH;
@@ -59,3 +60,5 @@ hipError_t rfx_launch_k1(const K1Args &, hipStream_t);
 hipError_t rfx_launch_k2(const K2Args &, hipStream_t);
 hipError_t rfx_launch_k3(const K3Args &, hipStream_t);
 hipError_t rfx_launch_k4(const K4Args &, hipStream_t);
+// rows [y0, y1) of an RGBA32F plane -> the same rows of an RGBA16F (to_half) or RGBA32F plane
+hipError_t rfx_launch_copy_fb(const FrameDims &, int y0, int y1, TexView src, TexViewW dst, bool to_half, hipStream_t);

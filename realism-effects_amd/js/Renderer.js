@@ -22,7 +22,9 @@ const TEX = {
 	DENOISE_A1: 9,
 	DENOISE_B0: 10,
 	DENOISE_B1: 11,
-	COMPOSE: 12
+	COMPOSE: 12,
+	FBCOPY_F16: 13,
+	FBCOPY_F32: 14
 }
 // [TypedArray constructor, elements per texel]
 const FORMAT = {
@@ -38,7 +40,9 @@ const FORMAT = {
 	9: [Uint16Array, 4],
 	10: [Uint16Array, 4],
 	11: [Uint16Array, 4],
-	12: [Float32Array, 4]
+	12: [Float32Array, 4],
+	13: [Uint16Array, 4],
+	14: [Float32Array, 4]
 }
 
 // 128x128 RGBA8 blue-noise table: decoded once from the reference's PNG asset, already flipY'd
@@ -98,12 +102,16 @@ class Renderer {
 		addon.clear(this._h, tex)
 	}
 
-	// the four draws (include/rfx.h)
+	// the four draws + the framebuffer copy (include/rfx.h)
 	ssgiMarch(uniforms) {
 		addon.ssgiMarch(this._h, uniforms)
 	}
 	temporalReproject(uniforms) {
 		addon.temporalReproject(this._h, uniforms)
+	}
+	// renderer.copyFramebufferToTexture of TemporalReprojectPass.js:198-201
+	copyFramebuffer(dstTex) {
+		addon.copyFramebuffer(this._h, dstTex)
 	}
 	poissonDenoise(uniforms) {
 		addon.poissonDenoise(this._h, uniforms)

@@ -161,9 +161,59 @@ class VelocityDepthNormalPass {
 	dispose() {}
 }
 
+// three.js texture `type` constants the path distinguishes (three/src/constants.js)
+const UnsignedByteType = 1009
+const FloatType = 1015
+const HalfFloatType = 1016
+function textureType(texture) {
+	return texture && texture.type !== undefined && texture.type !== null ? texture.type : FloatType // SSGIPass.js:24 targets are FloatType
+}
+
+// value of float16(v) (round to nearest even; overflow -> +-Infinity) as a JS number; Node 12 has no Float16Array
+const _f32 = new Float32Array(1)
+const _u32 = new Uint32Array(_f32.buffer)
+function roundToHalf(v) {
+	_f32[0] = v
+	const bits = _u32[0]
+	const e = (bits >>> 23) & 0xff
+	if (e === 0xff || v === 0) return _f32[0]
+	const a = Math.abs(_f32[0])
+	const q = Math.pow(2, Math.max(e - 127, -14) - 10) // half quantum at this magnitude (subnormals: 2^-24)
+	const t = a / q
+	const f = Math.floor(t)
+	const d = t - f
+	let r = (d < 0.5 ? f : d > 0.5 ? f + 1 : f % 2 === 0 ? f : f + 1) * q
+	if (r > 65504) r = Infinity
+	return bits >>> 31 ? -r : r
+}
+function toHalfPrecision(data) {
+	const out = new Float32Array(data.length)
+	for (let i = 0; i < data.length; i++) out[i] = roundToHalf(data[i])
+	return out
+}
+
+// src/taa/TAAUtils.js:3 + src/temporal-reproject/utils/QuasirandomGenerator.js:12-27
+const r2Sequence = (() => {
+	const g = 1.32471795724474602596090885447809
+	const a1 = 1.0 / g
+	const a2 = 1.0 / (g * g)
+	const base = 1.1127756842787055
+	const points = []
+	for (let n = 0; n < 256; n++) points.push([((base + a1 * n) % 1) - 0.5, ((base + a2 * n) % 1) - 0.5])
+	return points
+})()
+// src/taa/TAAUtils.js:5-11 — `setViewOffset` is three's PerspectiveCamera method: a dumped-state camera that has one
+// records the offset for the raster side, which renders the next dump with it
+function jitter(width, height, camera, frame, jitterScale) {
+	if (jitterScale === undefined) jitterScale = 1
+	const p = r2Sequence[frame % r2Sequence.length]
+	if (camera.setViewOffset) camera.setViewOffset(width, height, p[0] * jitterScale, p[1] * jitterScale, width, height)
+	return [p[0] * jitterScale, p[1] * jitterScale]
+}
+
 // src/temporal-reproject/TemporalReprojectPass.js:38-225
 class TemporalReprojectPass {
-	constructor(scene, camera, velocityDepthNormalPass, texture, textureCount, options) {
+	constructor(scene, camera, velocityDepthNormalPass, texture, textureCount, options, halfStoreRTZ) {
 		this._scene = scene
 		this._camera = camera
 		this.textureCount = textureCount
@@ -173,6 +223,10 @@ class TemporalReprojectPass {
 		this.frame = 0
 		this.overrideAccumulatedTextures = []
 		this.lastCameraTransform = { position: [0, 0, 0], quaternion: [0, 0, 0, 1] }
+		// :63-68 the render target takes the TYPE of the input texture; :137-142 so does the framebuffer copy
+		this.targetType = textureType(texture)
+		if (this.targetType !== FloatType && this.targetType !== HalfFloatType)
+			throw new Error("TemporalReprojectPass: input texture type " + this.targetType + " — only FloatType / HalfFloatType targets are built")
 		const it = INPUT_TYPES.indexOf(options.inputType)
 		const flags = name => {
 			let v = options[name]
@@ -191,7 +245,10 @@ class TemporalReprojectPass {
 			confidencePower: options.confidencePower,
 			neighborhoodClampIntensity: options.neighborhoodClampIntensity,
 			maxBlend: options.maxBlend,
-			keepData: 1
+			keepData: 1,
+			historySource: 0,
+			targetHalf: this.targetType === HalfFloatType ? 1 : 0,
+			halfStoreRTZ: halfStoreRTZ === undefined || halfStoreRTZ ? 1 : 0
 		}
 	}
 	setSize(width, height) {
@@ -201,20 +258,38 @@ class TemporalReprojectPass {
 	get texture() {
 		return TEX.TEMPORAL0
 	}
+	// :137-142 — the slot the pass copies its target into when nothing overrides its history
+	get framebufferTexture() {
+		return this.targetType === HalfFloatType ? TEX.FBCOPY_F16 : TEX.FBCOPY_F32
+	}
 	reset() {
 		this.uniforms.keepData = 0 // :158-160
 	}
 	render(renderer) {
 		this.frame = (this.frame + 1) % 4096
 		const cam = this._camera
-		this.uniforms.camera = cloneCamera(cam)
+		// :168-172,185-187 the pass draws with the UNJITTERED projection (view offset disabled while the uniforms are read)
+		this.uniforms.camera = cloneCamera(cam.unjittered || cam)
 		const moved = didCameraMove(cam, this.lastCameraTransform.position, this.lastCameraTransform.quaternion)
 		this.uniforms.fullAccumulate = this.options.fullAccumulate && !moved ? 1 : 0 // :178-180
 		this.lastCameraTransform.position = Array.from(cam.position)
 		this.lastCameraTransform.quaternion = Array.from(cam.quaternion || [0, 0, 0, 1])
+		const ownHistory = this.overrideAccumulatedTextures.length === 0 // :148-151
+		this.uniforms.historySource = !ownHistory ? 0 : this.targetType === HalfFloatType ? 1 : 2
 		renderer.temporalReproject(this.uniforms) // :192-193
 		this.uniforms.keepData = 1 // :195
-		this.uniforms.prevCamera = cloneCamera(cam) // :203-213
+		if (ownHistory) {
+			renderer.copyFramebuffer(this.framebufferTexture) // :197-201
+			if (renderer.afterCopyFramebuffer) renderer.afterCopyFramebuffer(this.framebufferTexture)
+		}
+		this.uniforms.prevCamera = cloneCamera(cam.unjittered || cam) // :203-213
+	}
+	jitter(jitterScale) {
+		this.unjitter() // :216-220
+		return jitter(this.width, this.height, this._camera, this.frame, jitterScale)
+	}
+	unjitter() {
+		if (this._camera.clearViewOffset) this._camera.clearViewOffset() // :222-224
 	}
 	dispose() {}
 }
@@ -559,7 +634,8 @@ class SSREffect extends SSGIEffect {
 
 // src/traa/TRAAEffect.js:10-78 — option surface + K2 parameter mapping (camera jitter needs the rasteriser)
 class TRAAEffect {
-	constructor(scene, camera, velocityDepthNormalPass, options) {
+	// `halfStoreRTZ` is an addition for parity runs against the llvmpipe oracle (RGBA16F stores truncate there)
+	constructor(scene, camera, velocityDepthNormalPass, options, halfStoreRTZ) {
 		this._scene = scene
 		this._camera = camera
 		this.velocityDepthNormalPass = velocityDepthNormalPass
@@ -573,6 +649,9 @@ class TRAAEffect {
 		})
 		this.options = Object.assign({}, defaultTemporalReprojectPassOptions, options)
 		this.temporalReprojectPass = null
+		this._halfStoreRTZ = halfStoreRTZ
+		this.uniforms = { accumulatedTexture: null }
+		this.unjitteredProjectionMatrix = null
 	}
 	setSize(width, height) {
 		if (this.temporalReprojectPass) this.temporalReprojectPass.setSize(width, height)
@@ -580,12 +659,44 @@ class TRAAEffect {
 	reset() {
 		this.temporalReprojectPass.reset()
 	}
-	temporalParams() {
+	temporalParams(texture) {
 		if (!this.temporalReprojectPass)
-			this.temporalReprojectPass = new TemporalReprojectPass(this._scene, this._camera, this.velocityDepthNormalPass, null, 1, this.options)
+			this.temporalReprojectPass = new TemporalReprojectPass(this._scene, this._camera, this.velocityDepthNormalPass, texture, 1, this.options, this._halfStoreRTZ)
 		return this.temporalReprojectPass.uniforms
 	}
-	dispose() {}
+	// `inputBuffer`: the composer buffer as dumped state — { texture: { type }, width, height, data: Float32Array(H*W*4) }
+	update(renderer, inputBuffer) {
+		if (!this.temporalReprojectPass) {
+			this.temporalParams(inputBuffer.texture) // :53-66
+			this.temporalReprojectPass.setSize(inputBuffer.width, inputBuffer.height)
+			this.uniforms.accumulatedTexture = this.temporalReprojectPass.texture
+		}
+		// the raster shims stand where the composer's earlier passes ran
+		this.velocityDepthNormalPass.render(renderer)
+		let data = inputBuffer.data
+		if (this.temporalReprojectPass.targetType === HalfFloatType) {
+			// a HalfFloatType buffer holds half-precision texels: state that on the way in (exact for a real dump of one)
+			if (this._halfSrc !== data) {
+				this._halfSrc = data
+				this._halfData = toHalfPrecision(data)
+			}
+			data = this._halfData
+		}
+		renderer.uploadPlane(TEX.SSGI, new Uint32Array(data.buffer, data.byteOffset, data.length)) // K2's `inputTexture` (:118)
+		this.temporalReprojectPass.unjitter() // :68-73
+		this.unjitteredProjectionMatrix = Array.from(this._camera.projectionMatrix)
+		this.temporalReprojectPass.jitter()
+		this.temporalReprojectPass.render(renderer) // :75
+	}
+	// traa_compose.frag:3-7 — outputColor = vec4(accumulatedTexel.rgb, 1.)
+	output(renderer, row0, rows) {
+		const t = renderer.download(this.uniforms.accumulatedTexture, row0, rows)
+		for (let i = 3; i < t.length; i += 4) t[i] = 1
+		return t
+	}
+	dispose() {
+		if (this.temporalReprojectPass) this.temporalReprojectPass.dispose()
+	}
 }
 TRAAEffect.DefaultOptions = defaultTemporalReprojectPassOptions
 
@@ -603,6 +714,12 @@ module.exports = {
 	defaultSSGIOptions,
 	defaultTemporalReprojectPassOptions,
 	defaultPoissonBlurOptions,
+	FloatType,
+	HalfFloatType,
+	UnsignedByteType,
+	roundToHalf,
+	r2Sequence,
+	jitter,
 	makeBlueNoiseIndex,
 	didCameraMove
 }

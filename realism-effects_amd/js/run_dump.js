@@ -3,6 +3,8 @@
 // node run_dump.js <dumpdir0> [<dumpdir1> ...] --out <dir> [--steps N --refineSteps N --denoiseIterations N]
 // Runs SSGIEffect.update() over a sequence of dumped frames on GPU 0 and writes compose.bin / denoise_b0.bin /
 // denoise_b1.bin / temporal0.bin / ssgi.bin of the LAST frame into --out.
+// With --traa '"half"' | '"float"': runs TRAAEffect.update() instead, the dump's direct.bin standing for the composer's
+// input buffer (HalfFloatType / FloatType), and writes traa.bin (traa_compose output, RGBA32F) of the last frame.
 const fs = require("fs")
 const path = require("path")
 const rfx = require("./index")
@@ -27,6 +29,22 @@ const first = rfx.readDump(dumps[0])
 const scene = { frame: first }
 const camera = Object.assign({}, first.camera)
 const renderer = new rfx.Renderer(first.width, first.height)
+if (opt.traa) {
+	const half = opt.traa === "half"
+	const traa = new rfx.TRAAEffect(scene, camera, new rfx.VelocityDepthNormalPass(scene, camera), { fullAccumulate: true }, true)
+	for (const d of dumps) {
+		const f = d === dumps[0] ? first : rfx.readDump(d)
+		scene.frame = f
+		Object.assign(camera, f.camera)
+		traa.update(renderer, { texture: { type: half ? rfx.HalfFloatType : rfx.FloatType }, width: f.width, height: f.height, data: f.direct })
+	}
+	renderer.sync()
+	fs.mkdirSync(out, { recursive: true })
+	const a = traa.output(renderer)
+	fs.writeFileSync(path.join(out, "traa.bin"), Buffer.from(a.buffer, a.byteOffset, a.byteLength))
+	console.log(JSON.stringify({ frames: dumps.length, width: first.width, height: first.height, haloViolations: renderer.haloViolations() }))
+	process.exit(0)
+}
 const effect = new rfx.SSGIEffect(null, scene, camera, Object.assign({ width: first.width, height: first.height }, opt), seeds, true)
 for (const d of dumps) {
 	const f = d === dumps[0] ? first : rfx.readDump(d)

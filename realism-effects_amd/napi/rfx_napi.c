@@ -232,7 +232,8 @@ static napi_value n_ssgi(napi_env env, napi_callback_info info) {
 }
 
 /* temporalReproject(ctx, {camera, prevCamera, textureCount, inputType, reprojectSpecular[2], neighborhoodClamp[2],
- *                         logTransform, fullAccumulate, confidencePower, neighborhoodClampIntensity, maxBlend, keepData}) */
+ *                         logTransform, fullAccumulate, confidencePower, neighborhoodClampIntensity, maxBlend, keepData,
+ *                         historySource, targetHalf, halfStoreRTZ}) */
 static napi_value n_temporal(napi_env env, napi_callback_info info) {
     napi_value a[2];
     if (!get_args(env, info, 2, a)) return NULL;
@@ -251,8 +252,23 @@ static napi_value n_temporal(napi_env env, napi_callback_info info) {
     p.neighborhoodClampIntensity = (float)prop_num(env, a[1], "neighborhoodClampIntensity", 1);
     p.maxBlend = (float)prop_num(env, a[1], "maxBlend", 1);
     p.keepData = (float)prop_num(env, a[1], "keepData", 1);
+    p.historySource = (int32_t)prop_num(env, a[1], "historySource", 0);
+    p.targetHalf = (int32_t)prop_num(env, a[1], "targetHalf", 0);
+    p.halfStoreRTZ = (int32_t)prop_num(env, a[1], "halfStoreRTZ", 1);
     int rc = rfx_temporal_reproject(c, &p);
     if (rc) return throw_rfx(env, c, "rfx_temporal_reproject", rc);
+    return NULL;
+}
+
+/* copyFramebuffer(ctx, dstTex) — renderer.copyFramebufferToTexture of TemporalReprojectPass.js:198-201 */
+static napi_value n_copy_framebuffer(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    int32_t tex;
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[1], &tex)) return NULL;
+    int rc = rfx_copy_framebuffer(c, (rfx_tex)tex);
+    if (rc) return throw_rfx(env, c, "rfx_copy_framebuffer", rc);
     return NULL;
 }
 
@@ -342,7 +358,7 @@ static napi_value n_time_end(napi_env env, napi_callback_info info) {
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
-        {"clear", n_clear}, {"ssgiMarch", n_ssgi}, {"temporalReproject", n_temporal}, {"poissonDenoise", n_denoise}, {"compose", n_compose},
+        {"clear", n_clear}, {"ssgiMarch", n_ssgi}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose},
         {"sync", n_sync}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

@@ -109,12 +109,15 @@ class Context:
             r0, n = self.held_rows(tex)
             self.upload(tex, plane[r0:r0 + n], r0, n)
 
-    # -- the four draws
+    # -- the four draws (+ the framebuffer copy)
     def ssgi_march(self, p: abi.SsgiParams):
         self._chk(self.lib.rfx_ssgi_march(self._h, C.byref(p)), "rfx_ssgi_march")
 
     def temporal_reproject(self, p: abi.TemporalParams):
         self._chk(self.lib.rfx_temporal_reproject(self._h, C.byref(p)), "rfx_temporal_reproject")
+
+    def copy_framebuffer(self, dst: int):
+        self._chk(self.lib.rfx_copy_framebuffer(self._h, dst), "rfx_copy_framebuffer")
 
     def poisson_denoise(self, p: abi.DenoiseParams):
         self._chk(self.lib.rfx_poisson_denoise(self._h, C.byref(p)), "rfx_poisson_denoise")

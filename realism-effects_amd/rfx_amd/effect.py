@@ -49,6 +49,36 @@ defaultPoissonBlurOptions = dict(iterations=1, radius=3, phi=0.5, lumaPhi=5, dep
 defaultDenoiserOptions = dict(denoiseMode="full", inputType="diffuseSpecular", gBufferPass=None, velocityDepthNormalPass=None)
 
 _INPUT_TYPES = ["diffuseSpecular", "diffuse", "specular"]
+# three.js texture `type` constants the path distinguishes (three/src/constants.js)
+UnsignedByteType, FloatType, HalfFloatType = 1009, 1015, 1016
+
+
+def _texture_type(texture) -> int:
+    """`texture.type` of an input texture: a three-style object/dict carrying `type`, or a bare slot id / None for the
+    FloatType targets the SSGI chain passes around (SSGIPass.js:24)."""
+    t = getattr(texture, "type", None)
+    if t is None and isinstance(texture, dict):
+        t = texture.get("type")
+    return FloatType if t is None else int(t)
+
+
+# src/taa/TAAUtils.js:3 + src/temporal-reproject/utils/QuasirandomGenerator.js:12-27 (JS doubles)
+def _generate_r2(count):
+    g = 1.32471795724474602596090885447809
+    a1, a2, base = 1.0 / g, 1.0 / (g * g), 1.1127756842787055
+    return [[math.fmod(base + a1 * n, 1.0), math.fmod(base + a2 * n, 1.0)] for n in range(count)]
+
+
+r2Sequence = [[a - 0.5, b - 0.5] for a, b in _generate_r2(256)]
+
+
+def jitter(width, height, camera, frame, jitterScale=1):
+    """src/taa/TAAUtils.js:5-11.  `camera.setViewOffset` is three's PerspectiveCamera method; the dumped-state camera of
+    this host records the offset for the raster side (which renders the next dump with it) when it has one."""
+    x, y = r2Sequence[frame % len(r2Sequence)]
+    if hasattr(camera, "setViewOffset"):
+        camera.setViewOffset(width, height, x * jitterScale, y * jitterScale, width, height)
+    return x * jitterScale, y * jitterScale
 HIGHEST_SIGNED_INT = 0x7FFFFFFF
 
 
@@ -141,7 +171,7 @@ class VelocityDepthNormalPass:
 class TemporalReprojectPass:
     """src/temporal-reproject/TemporalReprojectPass.js:38-225."""
 
-    def __init__(self, scene, camera, velocityDepthNormalPass, texture, textureCount, options=None):
+    def __init__(self, scene, camera, velocityDepthNormalPass, texture, textureCount, options=None, half_store_rtz=True):
         self._scene, self._camera = scene, camera
         self.textureCount = textureCount
         o = dict(defaultTemporalReprojectPassOptions)
@@ -151,10 +181,15 @@ class TemporalReprojectPass:
         self.frame = 0
         self.overrideAccumulatedTextures = []
         self.lastCameraTransform = dict(position=np.zeros(3), quaternion=np.array([0.0, 0, 0, 1]))
+        # :63-68 the render target takes the TYPE of the input texture; :137-142 so does the framebuffer copy
+        self.targetType = _texture_type(texture)
+        if self.targetType not in (FloatType, HalfFloatType):
+            raise ValueError("TemporalReprojectPass: input texture type %r — only FloatType / HalfFloatType targets are built" % (self.targetType,))
         it = _INPUT_TYPES.index(o["inputType"]) if o["inputType"] in _INPUT_TYPES else 1
         p = abi.TemporalParams(textureCount=textureCount, inputType=it, logTransform=1 if o["logTransform"] else 0,
                                confidencePower=float(o["confidencePower"]), neighborhoodClampIntensity=float(o["neighborhoodClampIntensity"]),
-                               maxBlend=float(o["maxBlend"]), keepData=1.0)
+                               maxBlend=float(o["maxBlend"]), keepData=1.0, targetHalf=1 if self.targetType == HalfFloatType else 0,
+                               halfStoreRTZ=1 if half_store_rtz else 0)
         for name in ("reprojectSpecular", "neighborhoodClamp"):  # :109-116 — arrays of (arrays of) bools; indices 0,1 matter
             v = o[name]
             v = list(v) if isinstance(v, (list, tuple)) else [v] * 2
@@ -170,21 +205,42 @@ class TemporalReprojectPass:
     def texture(self):
         return abi.TEX_TEMPORAL0
 
+    @property
+    def framebufferTexture(self):
+        """:137-142 — the slot the pass copies its target into when nothing overrides its history."""
+        return abi.TEX_FBCOPY_F16 if self.targetType == HalfFloatType else abi.TEX_FBCOPY_F32
+
     def reset(self):
         self.uniforms.keepData = 0.0  # :158-160
 
     def render(self, renderer):
         self.frame = (self.frame + 1) % 4096
         cam = self._camera
-        self.uniforms.camera = abi.Camera.from_scene(cam)
+        # :168-172,185-187 the pass draws with the UNJITTERED projection (view offset disabled while the uniforms are read)
+        self.uniforms.camera = abi.Camera.from_scene(getattr(cam, "unjittered", cam))
         self.uniforms.prevCamera = self._prev
         moved = didCameraMove(cam, self.lastCameraTransform["position"], self.lastCameraTransform["quaternion"])
         self.uniforms.fullAccumulate = 1 if (self.options["fullAccumulate"] and not moved) else 0  # :178-180
         self.lastCameraTransform["position"] = np.asarray(cam.position, np.float64).copy()
         self.lastCameraTransform["quaternion"] = np.asarray(getattr(cam, "quaternion", (0, 0, 0, 1)), np.float64).copy()
+        own_history = len(self.overrideAccumulatedTextures) == 0  # :148-151
+        self.uniforms.historySource = 0 if not own_history else (1 if self.targetType == HalfFloatType else 2)
         renderer.temporal_reproject(self.uniforms)  # :192-193
         self.uniforms.keepData = 1.0  # :195
-        self._prev = abi.Camera.from_scene(cam)  # :203-213
+        if own_history:  # :197-201
+            renderer.copy_framebuffer(self.framebufferTexture)
+            hook = getattr(renderer, "after_copy_framebuffer", None)
+            if hook:
+                hook(self.framebufferTexture)  # multi-GPU: halo exchange of the history rows
+        self._prev = abi.Camera.from_scene(getattr(cam, "unjittered", cam))  # :203-213
+
+    def jitter(self, jitterScale=1):  # :216-220
+        self.unjitter()
+        return jitter(self.width, self.height, self._camera, self.frame, jitterScale)
+
+    def unjitter(self):  # :222-224
+        if hasattr(self._camera, "clearViewOffset"):
+            self._camera.clearViewOffset()
 
     def dispose(self):
         pass
@@ -482,12 +538,15 @@ class SSREffect(SSGIEffect):
 
 
 class TRAAEffect:
-    """src/traa/TRAAEffect.js:10-78 — option surface + K2 parameter mapping only (camera jitter
-    needs the rasteriser)."""
+    """src/traa/TRAAEffect.js:10-78.  K2 alone, on the composer's input buffer: one texture, inputType "diffuse",
+    history = the pass's own framebuffer copy.  `inputBuffer` is the composer buffer as dumped state: an object (or
+    dict) with `texture` (anything carrying three's `type`: HalfFloatType for `frameBufferType: HalfFloatType`,
+    example/main.js:173, or FloatType), `width`, `height` and `data` — the H x W x 4 float32 scene colour, which
+    stands where the reference's previous pass rendered into the buffer."""
 
     DefaultOptions = defaultTemporalReprojectPassOptions
 
-    def __init__(self, scene, camera, velocityDepthNormalPass, options=None):
+    def __init__(self, scene, camera, velocityDepthNormalPass, options=None, half_store_rtz=True):
         self._scene, self._camera = scene, camera
         self.velocityDepthNormalPass = velocityDepthNormalPass
         o = dict(options or defaultTemporalReprojectPassOptions)
@@ -495,6 +554,9 @@ class TRAAEffect:
                  confidencePower=4)  # :21-31
         self.options = dict(defaultTemporalReprojectPassOptions, **o)
         self.temporalReprojectPass = None
+        self._half_store_rtz = half_store_rtz
+        self.uniforms = {"accumulatedTexture": None}
+        self.unjitteredProjectionMatrix = None
 
     def reset(self):
         self.temporalReprojectPass.reset()
@@ -503,8 +565,43 @@ class TRAAEffect:
         if self.temporalReprojectPass:
             self.temporalReprojectPass.setSize(width, height)
 
-    def temporal_params(self):
-        """The K2 launch parameters this effect would draw with (textureCount 1, inputType DIFFUSE)."""
+    def dispose(self):
+        if self.temporalReprojectPass:
+            self.temporalReprojectPass.dispose()
+
+    @staticmethod
+    def _field(obj, name):
+        return obj[name] if isinstance(obj, dict) else getattr(obj, name)
+
+    def temporal_params(self, texture=None):
+        """The K2 launch parameters this effect draws with (textureCount 1, inputType DIFFUSE)."""
         if self.temporalReprojectPass is None:
-            self.temporalReprojectPass = TemporalReprojectPass(self._scene, self._camera, self.velocityDepthNormalPass, None, 1, self.options)
+            self.temporalReprojectPass = TemporalReprojectPass(self._scene, self._camera, self.velocityDepthNormalPass, texture, 1, self.options,
+                                                               half_store_rtz=self._half_store_rtz)
         return self.temporalReprojectPass.uniforms
+
+    def update(self, renderer, inputBuffer):
+        if self.temporalReprojectPass is None:  # :53-66
+            self.temporal_params(self._field(inputBuffer, "texture"))
+            self.temporalReprojectPass.setSize(self._field(inputBuffer, "width"), self._field(inputBuffer, "height"))
+            self.uniforms["accumulatedTexture"] = self.temporalReprojectPass.texture
+        # the raster shims stand where the composer's earlier passes ran: velocity/depth/normal plane and the input buffer
+        self.velocityDepthNormalPass.render(renderer)
+        data = self._field(inputBuffer, "data")
+        if self.temporalReprojectPass.targetType == HalfFloatType:
+            # a HalfFloatType buffer holds half-precision texels: state that on the way in (exact for a real dump of one)
+            cache = self.__dict__.setdefault("_half_cache", [None, None])
+            if cache[0] is not data:
+                cache[0], cache[1] = data, np.asarray(data, np.float32).astype(np.float16).astype(np.float32)
+            data = cache[1]
+        _upload_plane(renderer, abi.TEX_SSGI, data)  # K2's `inputTexture` (:118)
+        self.temporalReprojectPass.unjitter()  # :68-73
+        self.unjitteredProjectionMatrix = np.array(self._camera.projectionMatrix, np.float32).copy()
+        self.temporalReprojectPass.jitter()
+        self.temporalReprojectPass.render(renderer)  # :75
+
+    def output(self, renderer, row0=None, rows=None):
+        """traa_compose.frag (src/traa/shader/traa_compose.frag:3-7): outputColor = vec4(accumulatedTexel.rgb, 1.)."""
+        t = renderer.download(self.uniforms["accumulatedTexture"], row0, rows).copy()
+        t[..., 3] = 1.0
+        return t

@@ -9,6 +9,7 @@ rows above and below and three exchange steps keep them current:
                                      texture and direction — latency-bound)
   after K4                         : all-gather of the composed GI tile rows (next frame's K1
                                      gathers it anywhere on screen)
+  after a framebuffer copy (TRAA)  : the same neighbour Send/Recv for the pass's own history
 
 K1 needs no exchange: it recomputes the +-2 rows K2's neighbourhood clamp reads, from the
 read-only dump planes every rank holds for its band, and reads depth / last frame's composed GI
@@ -78,6 +79,9 @@ class TiledRenderer:
     def after_compose_pass(self):
         self.allgather_compose()
 
+    def after_copy_framebuffer(self, tex):
+        self.exchange((tex,))  # TRAA: the pass's own history (TemporalReprojectPass.js:197-201) is gathered at vUv - velocity next frame
+
     # ---- halo Send/Recv with the row neighbours
     def exchange(self, texs):
         if self.world == 1 or self.halo == 0:
@@ -124,12 +128,13 @@ class TiledRenderer:
         self.inner.sync()
 
 
-def bind_torch_buffers(ctx, device):
+def bind_torch_buffers(ctx, device, texs=None):
     """Allocate the exchanged textures as torch tensors on `device` and bind them into the rfx
-    context (rfx_bind_external), so torch.distributed can send/receive their rows in place."""
+    context (rfx_bind_external), so torch.distributed can send/receive their rows in place.
+    `texs` defaults to what the SSGI chain exchanges; a TRAA run binds (TEX_FBCOPY_F16,) or (TEX_FBCOPY_F32,)."""
     import torch
     tensors = {}
-    for tex in EXCHANGED + (abi.TEX_COMPOSE,):
+    for tex in (EXCHANGED + (abi.TEX_COMPOSE,) if texs is None else tuple(texs)):
         r0, n = ctx.held_rows(tex)
         dtype, ch = abi.TEX_FORMAT[tex]
         nbytes = np.dtype(dtype).itemsize * ch * ctx.W

@@ -7,8 +7,8 @@ never copied into this repository) and Mesa's swrast_dri.so.  Usage:
     make -C oracle && python tests/golden/make_golden.py
 
 Each .npz holds, for a short frame sequence of the synthetic dump (seed 1234), the INPUT planes
-and the render target of every pass (K1 ssgi, K2 temporal x2, K3 A/B x2, K4 compose) as produced
-by oracle/glref/chain.py — i.e. by src/ssgi/shader/ssgi.frag,
+and the render target of every pass (K1 ssgi, K2 temporal x2, K3 A/B x2, K4 compose; for the traa_* files the
+TemporalReprojectPass target of TRAAEffect) as produced by oracle/glref/chain.py — i.e. by src/ssgi/shader/ssgi.frag,
 src/temporal-reproject/shader/temporal_reproject.frag, src/denoise/shader/poisson_denoise.frag and
 the DenoiserComposePass shader, unmodified, under the uniform values of the reference's JS drivers.
 The blue-noise indices follow src/utils/BlueNoiseUtils.js:24-32 from pinned start indices.
@@ -72,8 +72,28 @@ def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_
     print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
 
 
+def run_traa(name, W, H, frames, half):
+    """TRAAEffect (src/traa/TRAAEffect.js): temporal_reproject.frag alone with TRAA's defines, its own framebuffer copy as
+    history; composer buffers HalfFloatType (half=True, example/main.js:173) or FloatType."""
+    c = chain.GLRefTRAA(W, H, half=half)
+    out = dict(width=W, height=H, frames=frames, half=int(half), gl_info=chain.GL.info())
+    for fi in range(frames):
+        f = synthetic_frame(W, H, fi)
+        c.upload_frame(f)
+        k = "f%d_" % fi
+        out[k + "velocity"], out[k + "direct"] = f.velocity, f.direct
+        out.update(cam_arrays(f.camera, k + "cam_"))
+        out[k + "near"], out[k + "far"] = f.camera.near, f.camera.far
+        out[k + "out"] = c.render(f.camera, camera_moved=True)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     run("chain_160x90_s20r5_it1", 160, 90, frames=3, steps=20, refine=5, iterations=1)
     run("chain_97x55_s8r2_it2", 97, 55, frames=2, steps=8, refine=2, iterations=2)
     run("chain_ssr_128x72_s20r5_it1", 128, 72, frames=2, steps=20, refine=5, iterations=1, mode="ssr")
     run("chain_missed_96x54_s12r3_it1", 96, 54, frames=2, steps=12, refine=3, iterations=1, missed_rays=True)
+    run_traa("traa_half_128x72", 128, 72, frames=3, half=True)
+    run_traa("traa_float_96x54", 96, 54, frames=3, half=False)

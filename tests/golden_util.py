@@ -7,6 +7,7 @@ import numpy as np
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDENS = ["chain_160x90_s20r5_it1", "chain_97x55_s8r2_it2", "chain_missed_96x54_s12r3_it1"]
 GOLDEN_SSR = "chain_ssr_128x72_s20r5_it1"
+GOLDEN_TRAA = ["traa_half_128x72", "traa_float_96x54"]  # TRAAEffect: composer buffers HalfFloatType / FloatType
 
 
 def load(name):
@@ -25,4 +26,11 @@ def frame(g, fi):
     k = "f%d_" % fi
     return types.SimpleNamespace(depth=np.ascontiguousarray(g[k + "depth"]), gbuffer=np.ascontiguousarray(g[k + "gbuffer"]),
                                  velocity=np.ascontiguousarray(g[k + "velocity"]), direct=np.ascontiguousarray(g[k + "direct"]),
+                                 camera=camera(g, fi), width=int(g["width"]), height=int(g["height"]))
+
+
+def traa_frame(g, fi):
+    """TRAA goldens carry the composer input buffer (`direct`), the velocity/normal/depth plane and the camera."""
+    k = "f%d_" % fi
+    return types.SimpleNamespace(velocity=np.ascontiguousarray(g[k + "velocity"]), direct=np.ascontiguousarray(g[k + "direct"]),
                                  camera=camera(g, fi), width=int(g["width"]), height=int(g["height"]))

@@ -65,9 +65,21 @@ class OracleRenderer:
     def temporal_reproject(self, p):
         self.calls.append(("temporal", p.keepData, p.fullAccumulate))
         t = self.tex
-        h1 = t[abi.TEX_DENOISE_B1] if p.textureCount == 2 else t[abi.TEX_DENOISE_B0]
-        O.temporal(t[abi.TEX_SSGI], t[abi.TEX_VELOCITY], t[abi.TEX_DENOISE_B0], h1, p, t[abi.TEX_TEMPORAL0], t[abi.TEX_TEMPORAL1],
-                   rows=self._rows())
+        if p.historySource == 0:
+            h0 = t[abi.TEX_DENOISE_B0]
+            h1 = t[abi.TEX_DENOISE_B1] if p.textureCount == 2 else h0
+        else:
+            h0 = h1 = t[abi.TEX_FBCOPY_F16 if p.historySource == 1 else abi.TEX_FBCOPY_F32]
+        O.temporal(t[abi.TEX_SSGI], t[abi.TEX_VELOCITY], h0, h1, p, t[abi.TEX_TEMPORAL0], t[abi.TEX_TEMPORAL1], rows=self._rows())
+
+    def copy_framebuffer(self, dst):
+        self.calls.append(("copy_framebuffer", dst))
+        y0, y1 = self._rows()
+        src = self.tex[abi.TEX_TEMPORAL0][y0:y1]
+        if dst == abi.TEX_FBCOPY_F16:
+            self.tex[dst][y0:y1] = src.astype(np.float16).view(np.uint16)  # exact: the target was drawn with targetHalf
+        else:
+            self.tex[dst][y0:y1] = src
 
     def poisson_denoise(self, p):
         self.calls.append(("denoise", p.blueNoiseIndex, p.inputIsTemporal, p.writeToB))

@@ -143,6 +143,16 @@ class _LocalTiles:
         for c in self.ctxs:
             c.compose(p)
 
+    def copy_framebuffer(self, dst):
+        for c in self.ctxs:
+            c.copy_framebuffer(dst)
+
+    def after_copy_framebuffer(self, tex):
+        self._exchange((tex,))
+
+    def download(self, tex, row0=None, rows=None):
+        return self.gather(tex)
+
     def after_temporal_pass(self):
         from rfx_amd import abi
         self._exchange((abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1))
@@ -422,3 +432,75 @@ def test_ssr_mode_chain_vs_oracle(blue_noise):
         O.compose(f.depth, f.gbuffer, B0, None, cp, comp, scene=f.direct)
         assert_close("ssr compose f%d" % fi, ctx.download(abi.TEX_COMPOSE), comp, FLIP["compose"])
     ctx.close()
+
+
+@pytest.mark.parametrize("half", [True, False])
+def test_traa_end_to_end_vs_oracle(half):
+    """TRAAEffect end to end: K2 on the composer's input buffer with its own framebuffer copy as history,
+    HalfFloatType and FloatType composer buffers.  Stage-wise: each frame's K2 is fed the ORACLE's history; the copy is
+    checked bit-exactly; then the whole effect runs on both renderers in lockstep."""
+    import types
+    from oracle_renderer import OracleRenderer
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.effect import FloatType, HalfFloatType, TRAAEffect, VelocityDepthNormalPass
+    from rfx_amd.scene import synthetic_frame
+    import rfx_oracle as O
+
+    W, H, NF = 352, 198, 3
+    frames = [synthetic_frame(W, H, i) for i in range(NF)]
+    fb = abi.TEX_FBCOPY_F16 if half else abi.TEX_FBCOPY_F32
+    ctx = Context(W, H)
+    hist = np.zeros((H, W, 4), np.uint16 if half else np.float32)
+    for fi, f in enumerate(frames):
+        cam = abi.Camera.from_scene(f.camera)
+        tp = abi.TemporalParams(camera=cam, prevCamera=abi.Camera.from_scene(frames[max(fi - 1, 0)].camera), textureCount=1, inputType=1, logTransform=1,
+                                fullAccumulate=0, confidencePower=4, neighborhoodClampIntensity=1, maxBlend=0.9, keepData=1.0,
+                                historySource=1 if half else 2, targetHalf=1 if half else 0, halfStoreRTZ=1)
+        tp.neighborhoodClamp[:] = [1, 1]
+        inp = f.direct.astype(np.float16).astype(np.float32) if half else f.direct
+        ctx.upload(abi.TEX_VELOCITY, f.velocity)
+        ctx.upload(abi.TEX_SSGI, inp.view(np.uint32))
+        ctx.upload(fb, hist)
+        ctx.temporal_reproject(tp)
+        want = np.zeros((H, W, 4), np.float32)
+        O.temporal(np.ascontiguousarray(inp.view(np.uint32)), f.velocity, hist, hist, tp, want, None)
+        got = ctx.download(abi.TEX_TEMPORAL0)
+        assert_close("traa(%s) f%d" % ("half" if half else "float", fi), got, want, FLIP["temporal"])
+        ctx.copy_framebuffer(fb)
+        cp = ctx.download(fb)
+        if half:
+            assert (got.astype(np.float16).astype(np.float32) == got).all()  # the half target stores halfs ...
+            assert np.array_equal(cp, got.astype(np.float16).view(np.uint16))  # ... which the copy narrows exactly
+        else:
+            assert np.array_equal(cp.view(np.uint32), got.view(np.uint32))
+        hist = want.astype(np.float16).view(np.uint16) if half else want
+    ctx.close()
+
+    # the effect on both renderers
+    def run(renderer):
+        scene = types.SimpleNamespace(frame=None)
+        cam = types.SimpleNamespace(**vars(frames[0].camera))
+        fx = TRAAEffect(scene, cam, VelocityDepthNormalPass(scene, cam), dict(fullAccumulate=True))
+        outs = []
+        for f in frames:
+            scene.frame = f
+            for k, v in vars(f.camera).items():
+                setattr(cam, k, v)
+            fx.update(renderer, dict(texture=dict(type=HalfFloatType if half else FloatType), width=W, height=H, data=f.direct))
+            outs.append(fx.output(renderer))
+        return outs
+
+    dev = Context(W, H)
+    a, b = run(dev), run(OracleRenderer(W, H))
+    for fi in range(NF):
+        assert_close("traa effect f%d" % fi, a[fi], b[fi], FLIP["temporal"] * (fi + 1))
+    # row tiles (the multi-GPU decomposition) reproduce the single context bit for bit
+    from rfx_amd import tiling
+    vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
+    tiled = _LocalTiles(W, H, 2, tiling.required_halo(0.0, vmax, H, W))
+    c = run(tiled)
+    for fi in range(NF):
+        assert np.array_equal(c[fi].view(np.uint32), a[fi].view(np.uint32))
+    assert all(x.halo_violations() == 0 for x in tiled.ctxs)
+    dev.close()

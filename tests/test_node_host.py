@@ -37,7 +37,22 @@ e.update(R, null); e.update(R, null)
 e.radius = 5; e.denoiseIterations = 2; e.steps = "8"; e.denoiseKernel = 3
 e.update(R, null)
 const t = new fx.TRAAEffect({}, cam, new fx.VelocityDepthNormalPass({}, cam), { fullAccumulate: true, maxBlend: 0.5 }).temporalParams()
-console.log(JSON.stringify({ calls, defaults: fx.SSGIEffect.DefaultOptions, traa: [t.textureCount, t.inputType, t.logTransform, t.maxBlend, t.confidencePower, t.neighborhoodClampIntensity] }))
+// TRAAEffect.update end to end on a recording renderer, HalfFloatType then FloatType composer buffers
+const traaCalls = []
+const RT = {
+  uploadPlane(tex, plane) { traaCalls.push(["upload", tex, plane.length]) },
+  temporalReproject(u) { traaCalls.push(["temporal", u.keepData, u.fullAccumulate, u.textureCount, u.inputType, u.historySource, u.targetHalf, u.halfStoreRTZ, u.maxBlend, u.confidencePower]) },
+  copyFramebuffer(tex) { traaCalls.push(["copy", tex]) }
+}
+const data = new Float32Array(32 * 16 * 4).fill(0.1)
+for (const type of [fx.HalfFloatType, fx.FloatType]) {
+  const sc = { frame: { velocity: new Uint32Array(32 * 16 * 4) } }
+  const e2 = new fx.TRAAEffect(sc, cam, new fx.VelocityDepthNormalPass(sc, cam), { fullAccumulate: true })
+  e2.update(RT, { texture: { type }, width: 32, height: 16, data }); e2.update(RT, { texture: { type }, width: 32, height: 16, data })
+}
+const halfProbe = JSON.parse(process.argv[3]).map(fx.roundToHalf).map(x => Number.isFinite(x) ? x : String(x))
+console.log(JSON.stringify({ calls, defaults: fx.SSGIEffect.DefaultOptions, traa: [t.textureCount, t.inputType, t.logTransform, t.maxBlend, t.confidencePower, t.neighborhoodClampIntensity],
+                             traaCalls, halfProbe, r2: fx.r2Sequence.slice(0, 3) }))
 """
 
 
@@ -67,13 +82,29 @@ class Rec:
         self.calls.append(["compose", p.inputType])
 
 
+class RecTRAA(Rec):
+    def upload(self, tex, array, row0=None, rows=None):
+        self.calls.append(["upload", tex, int(np.asarray(array).size)])
+
+    def temporal_reproject(self, p):
+        self.calls.append(["temporal", p.keepData, p.fullAccumulate, p.textureCount, p.inputType, p.historySource, p.targetHalf, p.halfStoreRTZ,
+                           round(p.maxBlend, 5), p.confidencePower])
+
+    def copy_framebuffer(self, tex):
+        self.calls.append(["copy", tex])
+
+
+HALF_PROBE = [0.0, 1.0, -1.0, 0.1, 1.0 / 3.0, 65504.0, 65519.9, 65520.0, 1e-8, 5.9604645e-08, 2.9802322e-08, 3.0e-08, 6.1e-05, 6.1035156e-05, 1000.5,
+              2049.0, 2051.0, -0.33333334, 123456.0]
+
+
 def test_js_and_python_hosts_issue_the_same_calls():
     from rfx_amd.scene import synthetic_frame
     f = synthetic_frame(32, 16, 0)
     camd = {k: [float(x) for x in np.asarray(getattr(f.camera, k)).ravel()] for k in
             ("projectionMatrix", "projectionMatrixInverse", "matrixWorld", "matrixWorldInverse", "position", "quaternion")}
     camd.update(near=f.camera.near, far=f.camera.far)
-    out = subprocess.check_output([node, "-e", RECORDER, JS, json.dumps(camd)], cwd=JS)
+    out = subprocess.check_output([node, "-e", RECORDER, JS, json.dumps(camd), json.dumps(HALF_PROBE)], cwd=JS)
     js = json.loads(out)
 
     scene = types.SimpleNamespace(frame=f)
@@ -90,6 +121,23 @@ def test_js_and_python_hosts_issue_the_same_calls():
     assert js["defaults"] == json.loads(json.dumps(effect.defaultSSGIOptions))
     t = effect.TRAAEffect(scene, f.camera, effect.VelocityDepthNormalPass(scene, f.camera), dict(fullAccumulate=True, maxBlend=0.5)).temporal_params()
     assert js["traa"] == [t.textureCount, t.inputType, t.logTransform, pytest.approx(t.maxBlend), t.confidencePower, t.neighborhoodClampIntensity]
+    # TRAAEffect.update: same device calls from both hosts (velocity upload, input-buffer upload, K2, framebuffer copy)
+    rt = RecTRAA()
+    data = np.full((16, 32, 4), 0.1, np.float32)
+    for ttype in (effect.HalfFloatType, effect.FloatType):
+        sc = types.SimpleNamespace(frame=types.SimpleNamespace(velocity=np.zeros((16, 32, 4), np.uint32)))
+        e2 = effect.TRAAEffect(sc, f.camera, effect.VelocityDepthNormalPass(sc, f.camera), dict(fullAccumulate=True))
+        for _ in range(2):
+            e2.update(rt, dict(texture=dict(type=ttype), width=32, height=16, data=data))
+    # the Python host skips re-sending a resident plane (same ndarray), the JS host wraps the buffer in a fresh view per frame
+    py = [c for c in rt.calls if c[0] != "upload"]
+    assert [c for c in js["traaCalls"] if c[0] != "upload"] == json.loads(json.dumps(py))
+    assert [c[:2] for c in js["traaCalls"] if c[0] == "upload"][:2] == [["upload", abi.TEX_VELOCITY], ["upload", abi.TEX_SSGI]]
+    # the JS float->half rounding (no Float16Array in Node 12) against numpy's
+    want = np.array(HALF_PROBE, np.float32).astype(np.float16).astype(np.float32)
+    got = np.array([float(x) for x in js["halfProbe"]], np.float32)
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), (want, got)
+    assert np.allclose(js["r2"], effect.r2Sequence[:3], rtol=0, atol=0)
 
 
 def test_addon_loads_and_fails_loudly_without_gpu():
@@ -133,3 +181,20 @@ def test_node_host_drives_the_gpu_bit_identically(tmp_path):
         js = np.fromfile(os.path.join(out, name + ".bin"), py.dtype).reshape(py.shape)
         assert np.array_equal(py.view(np.uint8), js.view(np.uint8)), name
     ctx.close()
+    # TRAAEffect through both hosts
+    for mode, ttype in (("half", effect.HalfFloatType), ("float", effect.FloatType)):
+        out = str(tmp_path / ("js_traa_" + mode))
+        subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", out, "--traa", json.dumps(mode)], text=True)
+        scene = types.SimpleNamespace(frame=None)
+        cam = types.SimpleNamespace(**vars(frames[0].camera))
+        tx = effect.TRAAEffect(scene, cam, effect.VelocityDepthNormalPass(scene, cam), dict(fullAccumulate=True), half_store_rtz=True)
+        ctx = Context(W, H)
+        for f in frames:
+            scene.frame = f
+            for k, v in vars(f.camera).items():
+                setattr(cam, k, v)
+            tx.update(ctx, dict(texture=dict(type=ttype), width=W, height=H, data=f.direct))
+        py = tx.output(ctx)
+        js = np.fromfile(os.path.join(out, "traa.bin"), np.float32).reshape(py.shape)
+        assert np.array_equal(py.view(np.uint8), js.view(np.uint8)), mode
+        ctx.close()

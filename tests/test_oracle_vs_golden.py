@@ -164,3 +164,67 @@ def test_stagewise_ssr_mode(blue_noise):
         comp = hist.copy()
         O.compose(f.depth, f.gbuffer, np.ascontiguousarray(g[k + "B0"]), None, cp, comp, scene=f.direct)
         assert_close("ssr compose f%d" % fi, comp, g[k + "compose"], FLIP["compose"])
+
+
+def traa_params(g, fi):
+    """TRAAEffect.js:21-33 over defaultTemporalReprojectPassOptions; the example's fullAccumulate option never fires while the camera orbits."""
+    half = bool(int(g["half"]))
+    cam = abi.Camera.from_scene(G.camera(g, fi))
+    prev = abi.Camera.from_scene(G.camera(g, fi - 1 if fi > 0 else 0))
+    tp = abi.TemporalParams(camera=cam, prevCamera=prev, textureCount=1, inputType=1, logTransform=1, fullAccumulate=0, confidencePower=4,
+                            neighborhoodClampIntensity=1, maxBlend=0.9, keepData=1.0, historySource=1 if half else 2, targetHalf=1 if half else 0,
+                            halfStoreRTZ=1)
+    tp.reprojectSpecular[:] = [0, 0]
+    tp.neighborhoodClamp[:] = [1, 1]
+    return tp, half
+
+
+def traa_input(g, fi, half):
+    d = np.ascontiguousarray(g["f%d_direct" % fi])
+    if half:  # a HalfFloatType composer buffer holds half texels
+        d = d.astype(np.float16).astype(np.float32)
+    return d.view(np.uint32)
+
+
+@pytest.mark.parametrize("name", G.GOLDEN_TRAA)
+def test_traa_stagewise(name):
+    """TRAAEffect's TemporalReprojectPass fed with the GOLDEN framebuffer copy of the previous frame."""
+    g = G.load(name)
+    W, H, nf = int(g["width"]), int(g["height"]), int(g["frames"])
+    for fi in range(nf):
+        tp, half = traa_params(g, fi)
+        prev_out = np.ascontiguousarray(g["f%d_out" % (fi - 1)]) if fi else np.zeros((H, W, 4), np.float32)
+        hist = prev_out.astype(np.float16).view(np.uint16) if half else prev_out
+        out = np.zeros((H, W, 4), np.float32)
+        O.temporal(traa_input(g, fi, half), np.ascontiguousarray(g["f%d_velocity" % fi]), hist, hist, tp, out, None)
+        assert_close(name + " out f%d" % fi, out, g["f%d_out" % fi], FLIP["temporal"])
+        if half:  # every stored channel is a half
+            assert (out.astype(np.float16).astype(np.float32) == out).all()
+
+
+@pytest.mark.parametrize("name", G.GOLDEN_TRAA)
+def test_traa_through_effect(name):
+    """rfx_amd.effect.TRAAEffect (target type from the input buffer, own framebuffer copy as history, prev-camera bookkeeping)
+    driving the oracle renderer reproduces the reference sequence."""
+    import types
+    from oracle_renderer import OracleRenderer
+    from rfx_amd.effect import FloatType, HalfFloatType, TRAAEffect, VelocityDepthNormalPass
+
+    g = G.load(name)
+    W, H, nf, half = int(g["width"]), int(g["height"]), int(g["frames"]), bool(int(g["half"]))
+    scene = types.SimpleNamespace(frame=None)
+    cam = G.camera(g, 0)
+    fx = TRAAEffect(scene, cam, VelocityDepthNormalPass(scene, cam), dict(fullAccumulate=True))
+    r = OracleRenderer(W, H)
+    for fi in range(nf):
+        scene.frame = G.traa_frame(g, fi)
+        for kk, vv in vars(G.camera(g, fi)).items():
+            setattr(cam, kk, vv)
+        buf = dict(texture=dict(type=HalfFloatType if half else FloatType), width=W, height=H, data=scene.frame.direct)
+        fx.update(r, buf)
+        assert [c[0] for c in r.calls] == ["temporal", "copy_framebuffer"]
+        assert r.calls[1][1] == (abi.TEX_FBCOPY_F16 if half else abi.TEX_FBCOPY_F32)
+        r.calls.clear()
+        assert_close(name + " effect out f%d" % fi, r.tex[abi.TEX_TEMPORAL0], g["f%d_out" % fi], FLIP["temporal"] * (fi + 1))
+        o = fx.output(r)
+        assert (o[..., 3] == 1.0).all() and (o[..., :3] == r.tex[abi.TEX_TEMPORAL0][..., :3]).all()

@@ -1,5 +1,5 @@
 """CPU, world_size 2 over gloo: the row-tiled chain (halo Send/Recv after K2 and every K3 pass,
-all-gather of the composed GI) must be BIT-IDENTICAL to the single-tile chain.  The per-tile
+all-gather of the composed GI; for TRAAEffect the Send/Recv of its framebuffer copy) must be BIT-IDENTICAL to the single-tile chain.  The per-tile
 compute is the oracle double (tests only); the exchange code is the product's (rfx_amd.tiling)."""
 import os
 import sys
@@ -23,6 +23,16 @@ def _chain(renderer, scene, cam, frames):
         for k, v in vars(f.camera).items():
             setattr(cam, k, v)
         fx.update(renderer, None)
+
+
+def _traa(renderer, scene, cam, frames):
+    from rfx_amd.effect import HalfFloatType, TRAAEffect, VelocityDepthNormalPass
+    fx = TRAAEffect(scene, cam, VelocityDepthNormalPass(scene, cam), dict(fullAccumulate=True))
+    for f in frames:
+        scene.frame = f
+        for k, v in vars(f.camera).items():
+            setattr(cam, k, v)
+        fx.update(renderer, dict(texture=dict(type=HalfFloatType), width=W, height=H, data=f.direct))
 
 
 def _worker(rank, world, port, outdir):
@@ -51,6 +61,13 @@ def _worker(rank, world, port, outdir):
              **{abi.TEX_NAMES[t]: inner.tex[t][y0:y0 + rows] for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0,
                                                                      abi.TEX_DENOISE_B1)},
              compose_full=inner.tex[abi.TEX_COMPOSE])
+    # TRAAEffect on the same tiles: one exchange per frame, of the pass's own history
+    inner2 = OracleRenderer(W, H, y0, rows, tiling.required_halo(0.0, vmax, H, W))
+    b0, n = inner2.held_rows(abi.TEX_FBCOPY_F16)
+    r2 = tiling.TiledRenderer(inner2, {abi.TEX_FBCOPY_F16: torch.from_numpy(inner2.tex[abi.TEX_FBCOPY_F16][b0:b0 + n])}, rank, world)
+    _traa(r2, types.SimpleNamespace(frame=None), types.SimpleNamespace(**vars(frames[0].camera)), frames)
+    assert r2.exchange_count == FRAMES
+    np.save(os.path.join(outdir, "traa%d.npy" % rank), inner2.tex[abi.TEX_TEMPORAL0][y0:y0 + rows])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,6 +96,12 @@ def test_two_rank_tiled_chain_is_bit_identical(tmp_path):
             assert np.array_equal(z[abi.TEX_NAMES[t]], ref.tex[t][y0:y0 + rows]), "rank %d %s differs" % (rank, abi.TEX_NAMES[t])
         # every rank ends with the WHOLE composed frame (next frame's K1 gathers it anywhere)
         assert np.array_equal(z["compose_full"], ref.tex[abi.TEX_COMPOSE]), "rank %d compose differs" % rank
+    ref2 = OracleRenderer(W, H)
+    _traa(ref2, types.SimpleNamespace(frame=None), types.SimpleNamespace(**vars(frames[0].camera)), frames)
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        y0, rows = int(z["y0"]), int(z["rows"])
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "traa%d.npy" % rank)), ref2.tex[abi.TEX_TEMPORAL0][y0:y0 + rows]), "rank %d TRAA differs" % rank
 
 
 def test_split_rows_even_boundaries_and_halo():
