@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 2
+#define RFX_ABI_VERSION 3
 
 enum {
     RFX_OK = 0,
@@ -70,6 +70,7 @@ typedef enum rfx_tex {
     RFX_TEX_COMPOSE,        /* RGBA32F   K4 out = next frame's K1 `accumulatedTexture`              */
     RFX_TEX_FBCOPY_F16,     /* RGBA16F linear   TemporalReprojectPass.framebufferTexture (:137-142) when the pass's    */
     RFX_TEX_FBCOPY_F32,     /* RGBA32F linear   input / render target is HalfFloatType resp. FloatType (:66,139-140)   */
+    RFX_TEX_FINAL,          /* RGBA32F   SSGIEffect's own fragment (ssgi_compose.frag mainImage): the effect's output colour */
     RFX_TEX_COUNT
 } rfx_tex;
 
@@ -144,6 +145,16 @@ typedef struct rfx_compose_params {
     int32_t inputType; /* 0 TYPE_DIFFUSE_SPECULAR; 2 TYPE_SPECULAR (diffuse component = sceneTexture = RFX_TEX_DIRECT_LIGHT, specular GI = B0) */
 } rfx_compose_params;
 
+/* SSGIEffect's own fragment — FinalSSGIMaterial uniforms/defines (SSGIEffect.js:34-66,404-417; src/ssgi/shader/ssgi_compose.frag). */
+typedef struct rfx_final_params {
+    rfx_camera camera;     /* cameraNear / cameraFar / PERSPECTIVE_CAMERA (only read when fog is on) */
+    int32_t isDebug;       /* uniform isDebug: output = inputTexture texel, unmodified */
+    int32_t fogMode;       /* 0: scene.fog unset; 1: THREE.Fog (USE_FOG); 2: THREE.FogExp2 (USE_FOG + FOG_EXP2) */
+    float fogColor[3];
+    float fogNear, fogFar; /* fogMode 1 */
+    float fogDensity;      /* fogMode 2 */
+} rfx_final_params;
+
 typedef struct rfx_ctx rfx_ctx;
 
 /* ---- lifetime (Pass ctor / setSize / dispose) */
@@ -170,7 +181,7 @@ void *rfx_tex_device_ptr(rfx_ctx *, rfx_tex id);
 /* Use caller-owned device memory (held-rows x width x texel bytes) for a slot. */
 int rfx_bind_external(rfx_ctx *, rfx_tex id, void *device_ptr);
 
-/* ---- the four draws */
+/* ---- the four draws (+ the framebuffer copy and the effect's own fragment) */
 int rfx_ssgi_march(rfx_ctx *, const rfx_ssgi_params *);
 int rfx_temporal_reproject(rfx_ctx *, const rfx_temporal_params *);
 /* renderer.copyFramebufferToTexture(tmpVec2, this.framebufferTexture), TemporalReprojectPass.js:198-201: the tile rows of
@@ -180,6 +191,10 @@ int rfx_temporal_reproject(rfx_ctx *, const rfx_temporal_params *);
 int rfx_copy_framebuffer(rfx_ctx *, rfx_tex dst);
 int rfx_poisson_denoise(rfx_ctx *, const rfx_denoise_params *);
 int rfx_compose(rfx_ctx *, const rfx_compose_params *);
+/* The effect's mainImage (src/ssgi/shader/ssgi_compose.frag:20-45), which postprocessing's EffectPass runs after
+ * SSGIEffect.update(): background texels take the scene colour (RFX_TEX_DIRECT_LIGHT = the composer's input buffer),
+ * the rest the composed GI (RFX_TEX_COMPOSE), fogged when the scene has fog; alpha 1.  Writes RFX_TEX_FINAL. */
+int rfx_final_compose(rfx_ctx *, const rfx_final_params *);
 
 int rfx_sync(rfx_ctx *);
 

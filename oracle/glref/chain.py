@@ -182,6 +182,47 @@ def assemble_compose(input_type=0) -> str:
     return three_prefix({"inputType": int(input_type), "PERSPECTIVE_CAMERA": ""}, False) + s
 
 
+# three@0.151 ShaderChunk.fog_pars_fragment / fog_fragment (un-vendored dependency, restated: SURVEY.md Appendix H)
+CHUNK_FOG_PARS = """
+#ifdef USE_FOG
+	uniform vec3 fogColor;
+	varying float vFogDepth;
+	#ifdef FOG_EXP2
+		uniform float fogDensity;
+	#else
+		uniform float fogNear;
+		uniform float fogFar;
+	#endif
+#endif
+"""
+CHUNK_FOG = """
+#ifdef USE_FOG
+	#ifdef FOG_EXP2
+		float fogFactor = 1.0 - exp( - fogDensity * fogDensity * vFogDepth * vFogDepth );
+	#else
+		float fogFactor = smoothstep( fogNear, fogFar, vFogDepth );
+	#endif
+	gl_FragColor.rgb = mix( gl_FragColor.rgb, fogColor, fogFactor );
+#endif
+"""
+
+
+def assemble_final(fog_mode=0) -> str:
+    """SSGIEffect.js:34-66 (FinalSSGIMaterial): ssgi_compose.frag with the fog chunks spliced in as the ctor does
+    (`.replace("varying", "")`, the gl_FragColor line deleted by regex), wrapped the way postprocessing's EffectMaterial
+    calls an Effect's mainImage (harness boundary): mainImage(inputColor, vUv, outputColor)."""
+    s = _rd("ssgi/shader/ssgi_compose.frag")
+    s = s.replace("#include <fog_pars_fragment>", CHUNK_FOG_PARS.replace("varying", ""))
+    s = s.replace("#include <fog_fragment>", re.sub(r".*gl_FragColor.*", "", CHUNK_FOG))
+    d = {"PERSPECTIVE_CAMERA": 1}
+    if fog_mode:
+        d["USE_FOG"] = ""
+    if fog_mode == 2:
+        d["FOG_EXP2"] = ""
+    main = "\nvarying vec2 vUv;\nvoid main() { vec4 c; mainImage(vec4(0.), vUv, c); gl_FragColor = c; }\n"
+    return three_prefix(d, False) + CHUNK_PACKING + s + main
+
+
 def write_assembled(outdir: str, **kw):
     """Build products for the GPU box (no /root/reference there): oracle/_ref/shaders/*.frag."""
     os.makedirs(outdir, exist_ok=True)
@@ -189,7 +230,8 @@ def write_assembled(outdir: str, **kw):
                       ("temporal", assemble_temporal()), ("denoise", assemble_denoise()), ("compose", assemble_compose()),
                       ("ssgi_ssr_20_5", assemble_ssgi(20, 5, 1)), ("temporal_ssr", assemble_temporal(texture_count=1, input_type=2, reproject_specular=True, neighborhood_clamp=True)),
                       ("denoise_ssr", assemble_denoise(texture_count=1, is_texture_specular=(True, True))), ("compose_ssr", assemble_compose(input_type=2)),
-                      ("temporal_traa", assemble_traa())):
+                      ("temporal_traa", assemble_traa()), ("final_fog0", assemble_final(0)), ("final_fog1", assemble_final(1)),
+                      ("final_fog2", assemble_final(2))):
         with open(os.path.join(outdir, name + ".frag"), "w") as f:
             f.write(src)
 
@@ -503,3 +545,35 @@ class GLRefTRAA:
         self.t_fb.upload(out.astype(np.float16) if self.half else out)  # copyFramebufferToTexture (:197-201)
         self.prev = cam
         return out
+
+
+def run_final(width, height, depth, gi, scene, cam, fog_mode=0, fog_color=(0.5, 0.6, 0.7), fog_near=1.0, fog_far=30.0, fog_density=0.05,
+              is_debug=False, shader_dir: str | None = None):
+    """One draw of SSGIEffect's own fragment (FinalSSGIMaterial) on llvmpipe; returns the RGBA32F output."""
+    if shader_dir is None and not os.path.isdir(REFERENCE_SRC):
+        shader_dir = os.path.join(REF_OUT, "shaders")
+    if shader_dir is not None:
+        with open(os.path.join(shader_dir, "final_fog%d.frag" % fog_mode)) as f:
+            p = Program(f.read())
+    else:
+        p = Program(assemble_final(fog_mode))
+    t_depth, t_gi, t_scene = Tex(width, height, FMT_R32F, data=depth), Tex(width, height, FMT_RGBA32F, data=gi), Tex(width, height, FMT_RGBA32F, data=scene)
+    t_out = Tex(width, height, FMT_RGBA32F)
+    p.sampler("inputTexture", t_gi)
+    p.sampler("sceneTexture", t_scene)
+    p.sampler("depthTexture", t_depth)
+    p.set("isDebug", bool(is_debug))
+    if fog_mode:
+        p.set("fogColor", list(fog_color))
+        if fog_mode == 2:
+            p.set("fogDensity", float(fog_density))
+        else:
+            p.set("fogNear", float(fog_near))
+            p.set("fogFar", float(fog_far))
+    p.set("cameraNear", float(cam.near))
+    p.set("cameraFar", float(cam.far))
+    p.draw([t_out])
+    out = t_out.read()
+    for t in (t_depth, t_gi, t_scene, t_out):
+        t.free()
+    return out

@@ -970,6 +970,36 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
 }
 
 /* exported helpers for unit tests of the codec / conversions */
+/* ==================================================================== SSGIEffect's own fragment: ssgi_compose.frag:20-45
+ * gi = the denoiser's texture (K4 output, `inputTexture`), scene = the composer's input buffer (`sceneTexture`).
+ * Fog: three.js fog_fragment (un-vendored, three@0.151: SURVEY.md Appendix H) with its gl_FragColor line removed (SSGIEffect.js:40-44):
+ *   FOG_EXP2: fogFactor = 1.0 - exp( - fogDensity * fogDensity * vFogDepth * vFogDepth );  else smoothstep( fogNear, fogFar, vFogDepth ) */
+int rfxo_final(int W, int H, int y0, int y1, const float *depth, const float *gi, const float *scene, const rfx_final_params *p, float *out) {
+    if (p->fogMode < 0 || p->fogMode > 2) return RFX_EINVAL;
+#pragma omp parallel for schedule(static)
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < W; x++) {
+            size_t i = (size_t)y * W + x;
+            float *o = out + 4 * i;
+            if (p->isDebug) { memcpy(o, gi + 4 * i, 16); continue; }
+            float dep = depth[i];
+            float c[3];
+            if (dep == 1.0f) { c[0] = scene[4 * i]; c[1] = scene[4 * i + 1]; c[2] = scene[4 * i + 2]; }
+            else {
+                c[0] = gi[4 * i]; c[1] = gi[4 * i + 1]; c[2] = gi[4 * i + 2];
+                if (p->fogMode) {
+                    float viewZ = perspective_depth_to_view_z(dep, p->camera.near_, p->camera.far_) * 0.4f;
+                    float fd = -viewZ, ff;
+                    if (p->fogMode == 2) ff = 1.0f - expf(-p->fogDensity * p->fogDensity * fd * fd);
+                    else { float t = fminf(fmaxf((fd - p->fogNear) / (p->fogFar - p->fogNear), 0.0f), 1.0f); ff = t * t * (3.0f - 2.0f * t); }
+                    for (int k = 0; k < 3; k++) c[k] = mixf(c[k], p->fogColor[k], ff);
+                }
+            }
+            o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = 1.0f;
+        }
+    return 0;
+}
+
 uint16_t rfxo_f2h_rne(float f) { return float_to_half_rne(f); }
 uint16_t rfxo_f2h_rtz(float f) { return float_to_half_rtz(f); }
 float rfxo_h2f(uint16_t h) { return half_to_float(h); }

@@ -102,6 +102,17 @@ def compose(depth, gbuffer, gi0, gi1, params: abi.ComposeParams, out=None, rows=
     return out
 
 
+def final(depth, gi, scene, params: abi.FinalParams, out=None, rows=None):
+    """SSGIEffect's own fragment (ssgi_compose.frag): gi = K4 output, scene = the composer's input buffer."""
+    H, W = depth.shape
+    y0, y1 = rows or (0, H)
+    out = np.zeros((H, W, 4), np.float32) if out is None else out
+    rc = lib().rfxo_final(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gi, np.float32, (H, W, 4))), _p(_chk(scene, np.float32, (H, W, 4))),
+                          C.byref(params), _p(out))
+    assert rc == 0, rc
+    return out
+
+
 def half_bits_to_float(h: np.ndarray) -> np.ndarray:
     return h.view(np.float16).astype(np.float32)
 

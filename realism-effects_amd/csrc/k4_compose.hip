@@ -78,7 +78,55 @@ __global__ __launch_bounds__(256) void k4_compose(K4Args A) {
     rfx_flush_violations(d);
 }
 
+// SSGIEffect's own fragment, src/ssgi/shader/ssgi_compose.frag:20-45 (the `mainImage` postprocessing's EffectPass runs
+// after SSGIEffect.update).  Streaming: 4 B depth + 16 B (GI or scene) in, 16 B out.  The fog arithmetic is three.js'
+// fog_fragment chunk (un-vendored dependency): FogExp2 1 - exp(-density^2 * d^2), Fog smoothstep(near, far, d).
+__global__ __launch_bounds__(256) void k5_final_compose(K5Args A) {
+    FrameDims d = A.dims;
+    d.viol = 0;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = A.y0 + blockIdx.y * 4 + threadIdx.y;
+    if (x < d.W && y < A.y1) {
+        const rfx_final_params &p = A.p;
+        float4 o;
+        const float4 gi = ((const float4 *)A.gi.ptr)[rfx_xy_index(d, A.gi.row0, A.gi.rows, x, y)];
+        if (p.isDebug) {
+            o = gi;  // :21-24
+        } else {
+            const float depth = ((const float *)A.depth.ptr)[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, y)];
+            float3 c;
+            if (depth == 1.0f) {
+                const float4 sc = ((const float4 *)A.scene.ptr)[rfx_xy_index(d, A.scene.row0, A.scene.rows, x, y)];
+                c = make_float3(sc.x, sc.y, sc.z);
+            } else {
+                c = make_float3(gi.x, gi.y, gi.z);
+                if (p.fogMode) {
+                    const float n_ = p.camera.near_, f_ = p.camera.far_;
+                    const float viewZ = ((n_ * f_) / ((f_ - n_) * depth - f_)) * 0.4f;  // getViewZ(depth) * 0.4 :36
+                    const float fd = -viewZ;
+                    float ff;
+                    if (p.fogMode == 2) {
+                        ff = 1.0f - rfx_exp(((-p.fogDensity * p.fogDensity) * fd) * fd);
+                    } else {
+                        const float t = rfx_clamp((fd - p.fogNear) / (p.fogFar - p.fogNear), 0.0f, 1.0f);
+                        ff = t * t * (3.0f - 2.0f * t);
+                    }
+                    c = rfx_mix(c, make_float3(p.fogColor[0], p.fogColor[1], p.fogColor[2]), ff);
+                }
+            }
+            o = make_float4(c.x, c.y, c.z, 1.0f);
+        }
+        ((float4 *)A.out.ptr)[(size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x] = o;
+    }
+    rfx_flush_violations(d);
+}
+
 }  // namespace
+
+hipError_t rfx_launch_k5(const K5Args &A, hipStream_t stream) {
+    dim3 block(64, 4), grid((A.dims.W + 63) / 64, (A.y1 - A.y0 + 3) / 4);
+    hipLaunchKernelGGL(k5_final_compose, grid, block, 0, stream, A);
+    return hipGetLastError();
+}
 
 hipError_t rfx_launch_k4(const K4Args &A, hipStream_t stream) {
     dim3 block(64, 4), grid((A.dims.W + 63) / 64, (A.y1 - A.y0 + 3) / 4);

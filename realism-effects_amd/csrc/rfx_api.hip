@@ -407,6 +407,24 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
     return RFX_OK;
 }
 
+int rfx_final_compose(rfx_ctx *c, const rfx_final_params *p) {
+    if (!c || !p) return RFX_EINVAL;
+    if (p->fogMode < 0 || p->fogMode > 2) return fail(c, RFX_EINVAL, "rfx_final_compose: fogMode");
+    if (p->fogMode && !p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_final_compose: only PERSPECTIVE_CAMERA is built");
+    hipSetDevice(c->device);
+    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_COMPOSE, RFX_TEX_DIRECT_LIGHT, RFX_TEX_FINAL};
+    int rc = need(c, ids, 4);
+    if (rc) return rc;
+    K5Args A;
+    A.dims = dims(c);
+    launch_rows(c, RFX_TEX_FINAL, 0, &A.y0, &A.y1);
+    A.depth = view(c, RFX_TEX_DEPTH); A.gi = view(c, RFX_TEX_COMPOSE); A.scene = view(c, RFX_TEX_DIRECT_LIGHT);
+    A.out = wview(c, RFX_TEX_FINAL);
+    A.p = *p;
+    HIPCHK(c, rfx_launch_k5(A, c->stream));
+    return RFX_OK;
+}
+
 int rfx_sync(rfx_ctx *c) {
     if (!c) return RFX_EINVAL;
     hipSetDevice(c->device);

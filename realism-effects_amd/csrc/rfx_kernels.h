@@ -55,6 +55,15 @@ struct K4Args {
     rfx_compose_params p;
 };
 
+struct K5Args {
+    FrameDims dims;
+    int y0, y1;
+    TexView depth, gi, scene;  // gi = K4 output (inputTexture), scene = the composer's input buffer (sceneTexture)
+    TexViewW out;
+    rfx_final_params p;
+};
+
+hipError_t rfx_launch_k5(const K5Args &, hipStream_t);
 hipError_t rfx_launch_k1_prepare(const K1Args &, hipStream_t);
 hipError_t rfx_launch_k1(const K1Args &, hipStream_t);
 hipError_t rfx_launch_k2(const K2Args &, hipStream_t);

@@ -24,7 +24,8 @@ const TEX = {
 	DENOISE_B1: 11,
 	COMPOSE: 12,
 	FBCOPY_F16: 13,
-	FBCOPY_F32: 14
+	FBCOPY_F32: 14,
+	FINAL: 15
 }
 // [TypedArray constructor, elements per texel]
 const FORMAT = {
@@ -42,7 +43,8 @@ const FORMAT = {
 	11: [Uint16Array, 4],
 	12: [Float32Array, 4],
 	13: [Uint16Array, 4],
-	14: [Float32Array, 4]
+	14: [Float32Array, 4],
+	15: [Float32Array, 4]
 }
 
 // 128x128 RGBA8 blue-noise table: decoded once from the reference's PNG asset, already flipY'd
@@ -118,6 +120,11 @@ class Renderer {
 	}
 	compose(uniforms) {
 		addon.compose(this._h, uniforms)
+	}
+
+	// SSGIEffect's own fragment (ssgi_compose.frag mainImage)
+	finalCompose(uniforms) {
+		addon.finalCompose(this._h, uniforms)
 	}
 
 	sync() {

@@ -514,6 +514,8 @@ class SSGIEffect {
 			halfStoreRTZ
 		)
 		this.lastSize = { width: options.width, height: options.height, resolutionScale: options.resolutionScale }
+		// FinalSSGIMaterial uniforms (:47-66)
+		this.uniforms = { camera: cloneCamera(camera), isDebug: 0, fogMode: 0, fogColor: [0, 0, 0], fogNear: 0, fogFar: 0, fogDensity: 0 }
 		this.setSize(options.width, options.height)
 		this.makeOptionsReactive(options)
 		this.outputTexture = this.denoiser.texture
@@ -619,6 +621,23 @@ class SSGIEffect {
 		renderer.uploadPlane(TEX.DIRECT_LIGHT, direct)
 		this.ssgiPass.render(renderer)
 		this.denoiser.render(renderer, inputBuffer)
+		// :400-417 the effect's own uniforms: inputTexture = the denoiser's texture, sceneTexture = the input buffer, fog from the scene
+		const fog = this._scene.fog
+		const u = this.uniforms
+		u.fogMode = !fog ? 0 : fog.isFogExp2 ? 2 : 1
+		if (fog) {
+			u.fogColor = Array.from(fog.color)
+			u.fogNear = fog.near || 0
+			u.fogFar = fog.far || 0
+			u.fogDensity = fog.density || 0
+			u.camera = cloneCamera(this._camera)
+		}
+	}
+	// The effect's own fragment (src/ssgi/shader/ssgi_compose.frag:20-45), which postprocessing's EffectPass runs after update():
+	// scene colour on background texels, composed GI (+ fog) elsewhere, alpha 1 -> TEX.FINAL
+	mainImage(renderer) {
+		renderer.finalCompose(this.uniforms)
+		return TEX.FINAL
 	}
 }
 SSGIEffect.DefaultOptions = defaultSSGIOptions

@@ -2,7 +2,7 @@
 "use strict"
 // node run_dump.js <dumpdir0> [<dumpdir1> ...] --out <dir> [--steps N --refineSteps N --denoiseIterations N]
 // Runs SSGIEffect.update() over a sequence of dumped frames on GPU 0 and writes compose.bin / denoise_b0.bin /
-// denoise_b1.bin / temporal0.bin / ssgi.bin of the LAST frame into --out.
+// denoise_b1.bin / temporal0.bin / ssgi.bin / final.bin (the effect's mainImage output) of the LAST frame into --out.
 // With --traa '"half"' | '"float"': runs TRAAEffect.update() instead, the dump's direct.bin standing for the composer's
 // input buffer (HalfFloatType / FloatType), and writes traa.bin (traa_compose output, RGBA32F) of the last frame.
 const fs = require("fs")
@@ -55,7 +55,8 @@ for (const d of dumps) {
 renderer.sync()
 fs.mkdirSync(out, { recursive: true })
 const T = rfx.TEX
-for (const [name, tex] of [["compose", T.COMPOSE], ["denoise_b0", T.DENOISE_B0], ["denoise_b1", T.DENOISE_B1], ["temporal0", T.TEMPORAL0], ["ssgi", T.SSGI]]) {
+effect.mainImage(renderer) // the effect's own fragment -> final.bin
+for (const [name, tex] of [["final", T.FINAL], ["compose", T.COMPOSE], ["denoise_b0", T.DENOISE_B0], ["denoise_b1", T.DENOISE_B1], ["temporal0", T.TEMPORAL0], ["ssgi", T.SSGI]]) {
 	const a = renderer.download(tex)
 	fs.writeFileSync(path.join(out, name + ".bin"), Buffer.from(a.buffer, a.byteOffset, a.byteLength))
 }

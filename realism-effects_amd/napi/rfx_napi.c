@@ -314,6 +314,35 @@ static napi_value n_compose(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+/* finalCompose(ctx, {camera, isDebug, fogMode, fogColor[3], fogNear, fogFar, fogDensity}) — SSGIEffect's own fragment */
+static napi_value n_final(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    rfx_final_params p;
+    memset(&p, 0, sizeof p);
+    if (!read_camera(env, a[1], "camera", &p.camera)) return NULL;
+    p.isDebug = (int32_t)prop_num(env, a[1], "isDebug", 0);
+    p.fogMode = (int32_t)prop_num(env, a[1], "fogMode", 0);
+    napi_value fc;
+    bool has = false;
+    if (napi_has_named_property(env, a[1], "fogColor", &has) == napi_ok && has && napi_get_named_property(env, a[1], "fogColor", &fc) == napi_ok) {
+        for (uint32_t k = 0; k < 3; k++) {
+            napi_value e;
+            double v = 0;
+            if (napi_get_element(env, fc, k, &e) == napi_ok) napi_get_value_double(env, e, &v);
+            p.fogColor[k] = (float)v;
+        }
+    }
+    p.fogNear = (float)prop_num(env, a[1], "fogNear", 0);
+    p.fogFar = (float)prop_num(env, a[1], "fogFar", 0);
+    p.fogDensity = (float)prop_num(env, a[1], "fogDensity", 0);
+    int rc = rfx_final_compose(c, &p);
+    if (rc) return throw_rfx(env, c, "rfx_final_compose", rc);
+    return NULL;
+}
+
 static napi_value n_sync(napi_env env, napi_callback_info info) {
     napi_value a[1];
     if (!get_args(env, info, 1, a)) return NULL;
@@ -358,7 +387,7 @@ static napi_value n_time_end(napi_env env, napi_callback_info info) {
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
-        {"clear", n_clear}, {"ssgiMarch", n_ssgi}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose},
+        {"clear", n_clear}, {"ssgiMarch", n_ssgi}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
         {"sync", n_sync}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

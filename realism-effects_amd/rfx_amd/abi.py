@@ -13,20 +13,20 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "..", "csrc", "librfx_hip.so")
 
-RFX_ABI_VERSION = 2
+RFX_ABI_VERSION = 3
 RFX_OK, RFX_EINVAL, RFX_ENOMEM, RFX_EDEVICE, RFX_ESTATE, RFX_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 (TEX_DEPTH, TEX_GBUFFER, TEX_VELOCITY, TEX_DIRECT_LIGHT, TEX_BLUE_NOISE, TEX_SSGI, TEX_TEMPORAL0, TEX_TEMPORAL1,
- TEX_DENOISE_A0, TEX_DENOISE_A1, TEX_DENOISE_B0, TEX_DENOISE_B1, TEX_COMPOSE, TEX_FBCOPY_F16, TEX_FBCOPY_F32, TEX_COUNT) = range(16)
+ TEX_DENOISE_A0, TEX_DENOISE_A1, TEX_DENOISE_B0, TEX_DENOISE_B1, TEX_COMPOSE, TEX_FBCOPY_F16, TEX_FBCOPY_F32, TEX_FINAL, TEX_COUNT) = range(17)
 
 TEX_NAMES = ["depth", "gbuffer", "velocity", "direct_light", "blue_noise", "ssgi", "temporal0", "temporal1",
-             "denoise_a0", "denoise_a1", "denoise_b0", "denoise_b1", "compose", "fbcopy_f16", "fbcopy_f32"]
+             "denoise_a0", "denoise_a1", "denoise_b0", "denoise_b1", "compose", "fbcopy_f16", "fbcopy_f32", "final"]
 # (numpy dtype, channels) per slot, matching rfx_tex_texel_bytes()
 TEX_FORMAT = {
     TEX_DEPTH: (np.float32, 1), TEX_GBUFFER: (np.uint32, 4), TEX_VELOCITY: (np.uint32, 4), TEX_DIRECT_LIGHT: (np.float32, 4),
     TEX_BLUE_NOISE: (np.uint8, 4), TEX_SSGI: (np.uint32, 4), TEX_TEMPORAL0: (np.float32, 4), TEX_TEMPORAL1: (np.float32, 4),
     TEX_DENOISE_A0: (np.uint16, 4), TEX_DENOISE_A1: (np.uint16, 4), TEX_DENOISE_B0: (np.uint16, 4), TEX_DENOISE_B1: (np.uint16, 4),
-    TEX_COMPOSE: (np.float32, 4), TEX_FBCOPY_F16: (np.uint16, 4), TEX_FBCOPY_F32: (np.float32, 4),
+    TEX_COMPOSE: (np.float32, 4), TEX_FBCOPY_F16: (np.uint16, 4), TEX_FBCOPY_F32: (np.float32, 4), TEX_FINAL: (np.float32, 4),
 }
 
 M16 = C.c_float * 16
@@ -73,10 +73,15 @@ class ComposeParams(C.Structure):
     _fields_ = [("camera", Camera), ("inputType", C.c_int32)]
 
 
+class FinalParams(C.Structure):
+    _fields_ = [("camera", Camera), ("isDebug", C.c_int32), ("fogMode", C.c_int32), ("fogColor", C.c_float * 3), ("fogNear", C.c_float),
+                ("fogFar", C.c_float), ("fogDensity", C.c_float)]
+
+
 EXPORTS = [
     "rfx_abi_version", "rfx_create", "rfx_destroy", "rfx_last_error", "rfx_get_geometry", "rfx_set_stream", "rfx_tex_texel_bytes", "rfx_tex_held_rows",
     "rfx_upload", "rfx_download", "rfx_clear", "rfx_tex_device_ptr", "rfx_bind_external", "rfx_ssgi_march", "rfx_temporal_reproject",
-    "rfx_copy_framebuffer", "rfx_poisson_denoise", "rfx_compose", "rfx_sync", "rfx_halo_violations", "rfx_time_begin", "rfx_time_end",
+    "rfx_copy_framebuffer", "rfx_poisson_denoise", "rfx_compose", "rfx_final_compose", "rfx_sync", "rfx_halo_violations", "rfx_time_begin", "rfx_time_end",
 ]
 
 _lib = None
@@ -117,6 +122,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rfx_copy_framebuffer.argtypes = [vp, i]
     lib.rfx_poisson_denoise.argtypes = [vp, C.POINTER(DenoiseParams)]
     lib.rfx_compose.argtypes = [vp, C.POINTER(ComposeParams)]
+    lib.rfx_final_compose.argtypes = [vp, C.POINTER(FinalParams)]
     lib.rfx_sync.argtypes = [vp]
     lib.rfx_halo_violations.argtypes = [vp]
     lib.rfx_halo_violations.restype = C.c_uint

@@ -125,6 +125,9 @@ class Context:
     def compose(self, p: abi.ComposeParams):
         self._chk(self.lib.rfx_compose(self._h, C.byref(p)), "rfx_compose")
 
+    def final_compose(self, p: abi.FinalParams):
+        self._chk(self.lib.rfx_final_compose(self._h, C.byref(p)), "rfx_final_compose")
+
     def sync(self):
         self._chk(self.lib.rfx_sync(self._h), "rfx_sync")
 

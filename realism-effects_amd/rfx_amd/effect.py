@@ -441,6 +441,7 @@ class SSGIEffect:
         self.denoiser = Denoiser(scene, camera, self.ssgiPass.texture, dopt, seeds.get("denoise"), half_store_rtz)
         self.lastSize = dict(width=options.get("width"), height=options.get("height"), resolutionScale=options["resolutionScale"])
         self.setSize(options.get("width"), options.get("height"))
+        self.uniforms = abi.FinalParams(camera=abi.Camera.from_scene(camera), isDebug=0, fogMode=0)  # FinalSSGIMaterial :47-66
         self._reactive = False
         for key in list(options.keys()):  # makeOptionsReactive :157-268 — apply every option once
             self._apply(key, options[key])
@@ -526,6 +527,21 @@ class SSGIEffect:
         _upload_plane(renderer, abi.TEX_DIRECT_LIGHT, direct)
         self.ssgiPass.render(renderer)
         self.denoiser.render(renderer, inputBuffer)
+        # :400-417 the effect's own uniforms: inputTexture = the denoiser's texture, sceneTexture = the input buffer, fog from the scene
+        u = self.uniforms
+        fog = getattr(self._scene, "fog", None)
+        u.fogMode = 0 if fog is None else (2 if getattr(fog, "isFogExp2", False) else 1)
+        if fog is not None:
+            u.fogColor[:] = [float(x) for x in fog.color]
+            u.fogNear, u.fogFar = float(getattr(fog, "near", 0.0) or 0.0), float(getattr(fog, "far", 0.0) or 0.0)
+            u.fogDensity = float(getattr(fog, "density", 0.0) or 0.0)
+            u.camera = abi.Camera.from_scene(self._camera)
+
+    def mainImage(self, renderer):
+        """The effect's own fragment (src/ssgi/shader/ssgi_compose.frag:20-45), which postprocessing's EffectPass runs after
+        update(): scene colour on background texels, composed GI (+ fog) elsewhere, alpha 1 -> RFX_TEX_FINAL."""
+        renderer.final_compose(self.uniforms)
+        return abi.TEX_FINAL
 
 
 class SSREffect(SSGIEffect):

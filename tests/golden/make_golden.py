@@ -90,6 +90,28 @@ def run_traa(name, W, H, frames, half):
     print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
 
 
+def run_final(name, W, H):
+    """SSGIEffect's own fragment (ssgi_compose.frag) over the K4 output of a 2-frame chain: no fog / Fog / FogExp2 / isDebug."""
+    bn = np.fromfile(os.path.join(ROOT, "realism-effects_amd", "data", "blue_noise_128_rgba8.bin"), np.uint8).reshape(128, 128, 4)
+    c = chain.GLRefChain(W, H, bn, steps=12, refineSteps=3, denoiseIterations=1)
+    for fi in range(2):
+        f = synthetic_frame(W, H, fi)
+        c.upload_frame(f)
+        c.ssgi(f.camera, 31 + fi)
+        c.temporal(f.camera)
+        c.denoise(f.camera, [41 + 2 * fi, 42 + 2 * fi])
+        c.compose(f.camera)
+    gi = c.t_compose.read()
+    out = dict(width=W, height=H, depth=f.depth, gi=gi, scene=f.direct, near=f.camera.near, far=f.camera.far, gl_info=chain.GL.info(),
+               fogColor=np.array([0.5, 0.6, 0.7], np.float32), fogNear=1.0, fogFar=30.0, fogDensity=0.05)
+    for m in (0, 1, 2):
+        out["final_fog%d" % m] = chain.run_final(W, H, f.depth, gi, f.direct, f.camera, fog_mode=m)
+    out["final_debug"] = chain.run_final(W, H, f.depth, gi, f.direct, f.camera, fog_mode=0, is_debug=True)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     run("chain_160x90_s20r5_it1", 160, 90, frames=3, steps=20, refine=5, iterations=1)
     run("chain_97x55_s8r2_it2", 97, 55, frames=2, steps=8, refine=2, iterations=2)
@@ -97,3 +119,4 @@ if __name__ == "__main__":
     run("chain_missed_96x54_s12r3_it1", 96, 54, frames=2, steps=12, refine=3, iterations=1, missed_rays=True)
     run_traa("traa_half_128x72", 128, 72, frames=3, half=True)
     run_traa("traa_float_96x54", 96, 54, frames=3, half=False)
+    run_final("final_112x63", 112, 63)

@@ -101,6 +101,11 @@ class OracleRenderer:
         O.compose(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[abi.TEX_DENOISE_B0], t[abi.TEX_DENOISE_B1], p, out=t[abi.TEX_COMPOSE], rows=self._rows(),
                   scene=t[abi.TEX_DIRECT_LIGHT])
 
+    def final_compose(self, p):
+        self.calls.append(("final", p.fogMode, p.isDebug))
+        t = self.tex
+        O.final(t[abi.TEX_DEPTH], t[abi.TEX_COMPOSE], t[abi.TEX_DIRECT_LIGHT], p, out=t[abi.TEX_FINAL], rows=self._rows())
+
     def sync(self):
         pass
 

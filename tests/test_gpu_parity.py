@@ -504,3 +504,41 @@ def test_traa_end_to_end_vs_oracle(half):
         assert np.array_equal(c[fi].view(np.uint32), a[fi].view(np.uint32))
     assert all(x.halo_violations() == 0 for x in tiled.ctxs)
     dev.close()
+
+
+def test_final_compose_vs_oracle():
+    """SSGIEffect's own fragment (ssgi_compose.frag): rfx_final_compose against the oracle — the select paths bit-exactly,
+    THREE.Fog / FogExp2 within tolerance — and through SSGIEffect.mainImage with a scene fog."""
+    import types
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.effect import SSGIEffect
+    from rfx_amd.scene import synthetic_frame
+    import rfx_oracle as O
+
+    W, H = 300, 170
+    f = synthetic_frame(W, H, 1)
+    gi = np.random.RandomState(3).rand(H, W, 4).astype(np.float32) * 2.0
+    ctx = Context(W, H)
+    ctx.upload_frame(f)
+    ctx.upload(abi.TEX_COMPOSE, gi)
+    cam = abi.Camera.from_scene(f.camera)
+    for mode, debug in ((0, 0), (0, 1), (1, 0), (2, 0)):
+        p = abi.FinalParams(camera=cam, isDebug=debug, fogMode=mode, fogNear=2.0, fogFar=40.0, fogDensity=0.04)
+        p.fogColor[:] = [0.7, 0.8, 0.9]
+        ctx.final_compose(p)
+        got, want = ctx.download(abi.TEX_FINAL), O.final(f.depth, gi, f.direct, p)
+        if mode == 0:
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        else:
+            assert_close("final fog%d" % mode, got, want, 0.0)
+            assert np.abs(got - O.final(f.depth, gi, f.direct, abi.FinalParams(camera=cam))).max() > 0.01  # the fog did something
+    # through the effect: scene.fog -> USE_FOG / FOG_EXP2 (SSGIEffect.js:47-49,404-417)
+    scene = types.SimpleNamespace(frame=f, fog=types.SimpleNamespace(isFogExp2=True, color=(0.2, 0.3, 0.4), density=0.03))
+    fx = SSGIEffect(None, scene, f.camera, dict(width=W, height=H, steps=8, refineSteps=2), seeds=dict(ssgi=1, denoise=2))
+    fx.update(ctx, None)
+    tex = fx.mainImage(ctx)
+    assert (fx.uniforms.fogMode, tex) == (2, abi.TEX_FINAL)
+    want = O.final(f.depth, ctx.download(abi.TEX_COMPOSE), f.direct, fx.uniforms)
+    assert_close("effect mainImage", ctx.download(tex), want, 0.0)
+    ctx.close()

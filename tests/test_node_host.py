@@ -175,7 +175,8 @@ def test_node_host_drives_the_gpu_bit_identically(tmp_path):
         for k, v in vars(f.camera).items():
             setattr(cam, k, v)
         fx.update(ctx, None)
-    for name, tex in (("compose", abi.TEX_COMPOSE), ("denoise_b0", abi.TEX_DENOISE_B0), ("denoise_b1", abi.TEX_DENOISE_B1), ("temporal0", abi.TEX_TEMPORAL0),
+    fx.mainImage(ctx)
+    for name, tex in (("final", abi.TEX_FINAL), ("compose", abi.TEX_COMPOSE), ("denoise_b0", abi.TEX_DENOISE_B0), ("denoise_b1", abi.TEX_DENOISE_B1), ("temporal0", abi.TEX_TEMPORAL0),
                       ("ssgi", abi.TEX_SSGI)):
         py = ctx.download(tex)
         js = np.fromfile(os.path.join(out, name + ".bin"), py.dtype).reshape(py.shape)

@@ -228,3 +228,23 @@ def test_traa_through_effect(name):
         assert_close(name + " effect out f%d" % fi, r.tex[abi.TEX_TEMPORAL0], g["f%d_out" % fi], FLIP["temporal"] * (fi + 1))
         o = fx.output(r)
         assert (o[..., 3] == 1.0).all() and (o[..., :3] == r.tex[abi.TEX_TEMPORAL0][..., :3]).all()
+
+
+def final_params(g, mode, debug=0):
+    cam = abi.Camera(near_=float(g["near"]), far_=float(g["far"]), isPerspective=1)
+    p = abi.FinalParams(camera=cam, isDebug=debug, fogMode=mode, fogNear=float(g["fogNear"]), fogFar=float(g["fogFar"]), fogDensity=float(g["fogDensity"]))
+    p.fogColor[:] = [float(x) for x in g["fogColor"]]
+    return p
+
+
+def test_final_compose_vs_golden():
+    """SSGIEffect's own fragment (ssgi_compose.frag): background -> scene colour, else composed GI, THREE.Fog / FogExp2, isDebug."""
+    g = G.load(G.GOLDEN_FINAL)
+    depth, gi, scene = (np.ascontiguousarray(g[k]) for k in ("depth", "gi", "scene"))
+    for mode in (0, 1, 2):
+        out = O.final(depth, gi, scene, final_params(g, mode))
+        assert_close("final fog%d" % mode, out, g["final_fog%d" % mode], 0.0)
+        if mode == 0:
+            assert np.array_equal(out.view(np.uint32), g["final_fog0"].view(np.uint32))  # a select: bit-exact
+    assert np.array_equal(O.final(depth, gi, scene, final_params(g, 0, 1)).view(np.uint32), g["final_debug"].view(np.uint32))
+    assert (g["final_fog1"] != g["final_fog0"]).any() and (g["final_fog2"] != g["final_fog1"]).any()
