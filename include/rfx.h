@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 3
+#define RFX_ABI_VERSION 4
 
 enum {
     RFX_OK = 0,
@@ -99,6 +99,11 @@ typedef struct rfx_ssgi_params {
     float thickness;
     float envBlur;            /* env only; accepted, unused without USE_ENVMAP */
     int32_t blueNoiseIndex;   /* uniform blueNoiseIndex (BlueNoiseUtils.js:24-32 recurrence, host side) */
+    int32_t historySource;    /* uniform accumulatedTexture = ssgiEffect.denoiser.texture (SSGIPass.js:89, Denoiser.js:67-78):
+                                 0  denoiseMode "full" / "full_temporal": K4's output, RFX_TEX_COMPOSE;
+                                 1  "temporal": K2's texture[0], RFX_TEX_TEMPORAL0 (whole-frame contexts only);
+                                 2  "denoised": the getter returns an ARRAY of textures, which three binds as its empty
+                                    texture -> every history fetch reads (0,0,0,0)                                          */
 } rfx_ssgi_params;
 
 /* K2 — TemporalReprojectMaterial uniforms/defines (TemporalReprojectPass.js:76-117,162-214). */
@@ -118,7 +123,9 @@ typedef struct rfx_temporal_params {
     int32_t historySource;        /* which textures `accumulatedTexture[i]` are (TemporalReprojectPass.js:148-151):
                                      0  overrideAccumulatedTextures = K3's target B, RFX_TEX_DENOISE_B0/B1 (Denoiser.js:51);
                                      1  the pass's own framebuffer copy RFX_TEX_FBCOPY_F16 (render-target type HalfFloatType);
-                                     2  the same, RFX_TEX_FBCOPY_F32 (FloatType).  1 and 2 need textureCount == 1.          */
+                                     2  the same, RFX_TEX_FBCOPY_F32 (FloatType).  With two textures (denoiseMode
+                                        "full_temporal" / "temporal") BOTH read the one copy, which holds colour attachment 0
+                                        = texture 0: copyFramebufferToTexture reads the framebuffer's read buffer.            */
     int32_t targetHalf;           /* render target type = type of the input texture (:63-68): 0 FloatType — texels stored as
                                      computed; 1 HalfFloatType — every output channel is rounded to half precision on store
                                      (RFX_TEX_TEMPORAL* then hold half-representable floats)                                 */
@@ -143,12 +150,16 @@ typedef struct rfx_denoise_params {
 typedef struct rfx_compose_params {
     rfx_camera camera;
     int32_t inputType; /* 0 TYPE_DIFFUSE_SPECULAR; 2 TYPE_SPECULAR (diffuse component = sceneTexture = RFX_TEX_DIRECT_LIGHT, specular GI = B0) */
+    int32_t giSource;  /* composerInputTextures (Denoiser.js:53): 0 the denoise pass's textures, RFX_TEX_DENOISE_B0/B1 (RGBA16F);
+                          1 denoiseMode "full_temporal": K2's textures, RFX_TEX_TEMPORAL0/1 (RGBA32F, nearest) */
 } rfx_compose_params;
 
 /* SSGIEffect's own fragment — FinalSSGIMaterial uniforms/defines (SSGIEffect.js:34-66,404-417; src/ssgi/shader/ssgi_compose.frag). */
 typedef struct rfx_final_params {
     rfx_camera camera;     /* cameraNear / cameraFar / PERSPECTIVE_CAMERA (only read when fog is on) */
     int32_t isDebug;       /* uniform isDebug: output = inputTexture texel, unmodified */
+    int32_t inputSource;   /* uniform inputTexture = outputTexture[0] ?? outputTexture = denoiser.texture (SSGIEffect.js:139,402):
+                              0 RFX_TEX_COMPOSE ("full", "full_temporal"); 1 RFX_TEX_TEMPORAL0 ("temporal"); 2 RFX_TEX_DENOISE_B0 ("denoised") */
     int32_t fogMode;       /* 0: scene.fog unset; 1: THREE.Fog (USE_FOG); 2: THREE.FogExp2 (USE_FOG + FOG_EXP2) */
     float fogColor[3];
     float fogNear, fogFar; /* fogMode 1 */

@@ -319,7 +319,7 @@ class Program:
 
 DEFAULTS = dict(  # src/ssgi/SSGIOptions.js:26-48
     distance=10.0, thickness=10.0, denoiseIterations=1, radius=3.0, phi=0.5, lumaPhi=5.0, depthPhi=2.0, normalPhi=50.0,
-    roughnessPhi=50.0, specularPhi=50.0, envBlur=0.5, steps=20, refineSteps=5, missedRays=False, mode="ssgi")
+    roughnessPhi=50.0, specularPhi=50.0, envBlur=0.5, steps=20, refineSteps=5, missedRays=False, mode="ssgi", denoiseMode="full")
 
 
 class GLRefChain:
@@ -368,6 +368,11 @@ class GLRefChain:
         self.t_A = [Tex(W, H, FMT_RGBA16F, linear=True), Tex(W, H, FMT_RGBA16F, linear=True)]
         self.t_B = [Tex(W, H, FMT_RGBA16F, linear=True), Tex(W, H, FMT_RGBA16F, linear=True)]
         self.t_compose = Tex(W, H, FMT_RGBA32F)
+        # Denoiser.js:41-61: a denoise pass only in "full"/"denoised" (its target B then overrides K2's history), a compose pass only in "full*"
+        self.dm = self.o["denoiseMode"]
+        assert self.dm in ("full", "full_temporal", "denoised", "temporal")
+        self.has_denoise, self.has_compose = self.dm in ("full", "denoised"), self.dm.startswith("full")
+        self.t_fb = Tex(W, H, FMT_RGBA32F, linear=True) if not self.has_denoise else None  # TemporalReprojectPass.framebufferTexture (:137-142)
         self.keep_data = 0.0  # SSGIEffect's ctor setters call reset() (SSGIEffect.js:264)
         self.prev = None
         self.ms = {}
@@ -382,7 +387,10 @@ class GLRefChain:
     def ssgi(self, cam, blue_noise_index: int):
         p, o = self.p_ssgi, self.o
         near, far = float(cam.near), float(cam.far)
-        p.sampler("accumulatedTexture", self.t_compose)
+        # SSGIPass.js:89 accumulatedTexture = denoiser.texture (Denoiser.js:67-78); "denoised": the getter returns an ARRAY, which
+        # three binds as its empty texture
+        p.sampler("accumulatedTexture", {"full": self.t_compose, "full_temporal": self.t_compose, "temporal": self.t_temporal[0],
+                                         "denoised": self.t_empty}[self.dm])
         p.sampler("gBufferTexture", self.t_gbuffer)
         p.sampler("depthTexture", self.t_depth)
         p.sampler("velocityTexture", self.t_empty)  # SSGIPass.js:89 reads an undefined property
@@ -414,9 +422,13 @@ class GLRefChain:
         prev = self.prev if self.prev is not None else cam  # ctor clones the current matrices (:95-104)
         p.sampler("inputTexture", self.t_ssgi)
         p.sampler("velocityTexture", self.t_velocity)
-        p.sampler("accumulatedTexture0", self.t_B[0])  # Denoiser.js:51 overrideAccumulatedTextures
-        if self.tc == 2:
-            p.sampler("accumulatedTexture1", self.t_B[1])
+        if self.has_denoise:
+            p.sampler("accumulatedTexture0", self.t_B[0])  # Denoiser.js:51 overrideAccumulatedTextures
+            if self.tc == 2:
+                p.sampler("accumulatedTexture1", self.t_B[1])
+        else:  # TemporalReprojectPass.js:148-151: every index reads the pass's one framebuffer copy
+            for i in range(self.tc):
+                p.sampler("accumulatedTexture%d" % i, self.t_fb)
         p.set("projectionMatrix", cam.projectionMatrix)
         p.set("projectionMatrixInverse", cam.projectionMatrixInverse)
         p.set("cameraMatrixWorld", cam.matrixWorld)
@@ -437,6 +449,8 @@ class GLRefChain:
         p.draw(self.t_temporal[:self.tc])
         self.ms["temporal"] = p.last_ms
         self.keep_data = 1.0
+        if not self.has_denoise:  # :197-201 copyFramebufferToTexture reads the framebuffer's read buffer = colour attachment 0
+            self.t_fb.upload(self.t_temporal[0].read())
         self.prev = cam
 
     # -- K3: PoissonDenoisePass.render (src/denoise/pass/PoissonDenoisePass.js:135-149)
@@ -454,7 +468,7 @@ class GLRefChain:
         p.set("resolution", [float(self.W), float(self.H)])
         p.set("blueNoiseSize", [128.0, 128.0])
         self.ms["denoise"] = []
-        for i in range(2 * int(o["denoiseIterations"])):
+        for i in range(2 * int(o["denoiseIterations"]) if self.has_denoise else 0):
             horizontal = i % 2 == 0
             src = self.t_temporal if i == 0 else (self.t_B if horizontal else self.t_A)
             dst = self.t_A if horizontal else self.t_B
@@ -470,12 +484,15 @@ class GLRefChain:
         p = self.p_compose
         p.sampler("depthTexture", self.t_depth)
         p.sampler("gBufferTexture", self.t_gbuffer)
+        if not self.has_compose:
+            return
+        src = self.t_B if self.has_denoise else self.t_temporal  # Denoiser.js:53 composerInputTextures
         if self.tc == 2:
-            p.sampler("diffuseGiTexture", self.t_B[0])
-            p.sampler("specularGiTexture", self.t_B[1])
+            p.sampler("diffuseGiTexture", src[0])
+            p.sampler("specularGiTexture", src[1])
         else:  # DenoiserComposePass.js:26-33 inputType "specular": textures[0] is the specular GI; Denoiser.js:101-103 sceneTexture
             p.sampler("diffuseGiTexture", self.t_empty)
-            p.sampler("specularGiTexture", self.t_B[0])
+            p.sampler("specularGiTexture", src[0])
             p.sampler("sceneTexture", self.t_direct)
         p.set("viewMatrix", cam.matrixWorldInverse)
         p.set("cameraMatrixWorld", cam.matrixWorld)
@@ -577,3 +594,9 @@ def run_final(width, height, depth, gi, scene, cam, fog_mode=0, fog_color=(0.5, 
     for t in (t_depth, t_gi, t_scene, t_out):
         t.free()
     return out
+
+
+def chain_final(c: "GLRefChain", frame, fog_mode=0, **kw):
+    """SSGIEffect's own fragment over a chain's current state: inputTexture = outputTexture[0] ?? outputTexture (SSGIEffect.js:139,402)."""
+    src = {"full": c.t_compose, "full_temporal": c.t_compose, "temporal": c.t_temporal[0], "denoised": c.t_B[0]}[c.dm]
+    return run_final(c.W, c.H, frame.depth, src.read(), frame.direct, frame.camera, fog_mode=fog_mode, **kw)

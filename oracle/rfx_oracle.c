@@ -425,7 +425,9 @@ static v3 k1_do_sample(const k1_ctx *c, const material *mat, v3 viewPos, v3 view
     float ru = cu - 0.0f, rv = cv - 0.0f;
     v3 ssgi;
     if (ru >= 0.0f && ru <= 1.0f && rv >= 0.0f && rv <= 1.0f) {
-        v4 h = fetch_f4(c->history, d, ru, rv);
+        /* accumulatedTexture = denoiser.texture (SSGIPass.js:89): K4's / K2's RGBA32F target, or three's empty texture ("denoised") */
+        v4 h = {0.f, 0.f, 0.f, 0.f};
+        if (c->p->historySource != 2) h = fetch_f4(c->history, d, ru, rv);
         v3 gi = V3(h.x, h.y, h.z);
         /* getSaturation :348-360 */
         float mx = fmaxf(fmaxf(mat->diffuse.x, mat->diffuse.y), mat->diffuse.z);
@@ -781,7 +783,7 @@ static void k2_pixel(const k2_ctx *c, int x, int y, float *out0, float *out1) {
 
 int rfxo_temporal(int W, int H, int y0, int y1, const uint32_t *ssgi, const uint32_t *velocity, const void *hist0, const void *hist1,
                   const rfx_temporal_params *p, float *out0, float *out1) {
-    if (p->historySource < 0 || p->historySource > 2 || (p->historySource != 0 && p->textureCount != 1)) return RFX_EINVAL;
+    if (p->historySource < 0 || p->historySource > 2) return RFX_EINVAL;
     k2_ctx c = {W, H, ssgi, velocity, {hist0, hist1}, p, 0, 0};
     /* TemporalReprojectPass.js:135: invTexSize.set(1 / width, 1 / height) — JS doubles -> float */
     c.invW = (float)(1.0 / (double)W); c.invH = (float)(1.0 / (double)H);
@@ -905,8 +907,9 @@ int rfxo_denoise(int W, int H, int y0, int y1, const float *depth, const uint32_
 /* ==================================================================== K4: DenoiserComposePass */
 /* gi0/gi1: K3 target B ([0] = diffuse, [1] = specular; inputType "specular": gi0 is the specular GI, gi1 unused);
  * scene: the composer's input buffer (sceneTexture), only read when inputType == TYPE_SPECULAR */
-int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_t *gbuffer, const uint16_t *gi0, const uint16_t *gi1,
+int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_t *gbuffer, const void *gi0v, const void *gi1v,
                  const float *scene, const rfx_compose_params *p, float *out) {
+    const uint16_t *gi0 = (const uint16_t *)gi0v, *gi1 = (const uint16_t *)gi1v; /* giSource 0: RGBA16F linear; 1: RGBA32F nearest (K2's targets) */
     if (p->inputType != 0 && p->inputType != 2) return RFX_EUNSUPPORTED;
     if (p->inputType == 2 && !scene) return RFX_EINVAL;
     const float *C = p->camera.matrixWorld, *Vw = p->camera.matrixWorldInverse, *P = p->camera.projectionMatrix, *Pi = p->camera.projectionMatrixInverse;
@@ -932,7 +935,10 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
             /* DenoiserComposePass.js:26-33,78-79: diffuseSpecular -> (textures[0], textures[1]); specular -> specularGi = textures[0],
                diffuseGiTexture unbound (zeros) */
             v4 dgi = {0, 0, 0, 0}, sgi;
-            if (p->inputType == 0) { dgi = fetch_h4_linear(gi0, d, u, v); sgi = fetch_h4_linear(gi1, d, u, v); }
+            if (p->giSource) {
+                if (p->inputType == 0) { dgi = fetch_f4((const float *)gi0v, d, u, v); sgi = fetch_f4((const float *)gi1v, d, u, v); }
+                else sgi = fetch_f4((const float *)gi0v, d, u, v);
+            } else if (p->inputType == 0) { dgi = fetch_h4_linear(gi0, d, u, v); sgi = fetch_h4_linear(gi1, d, u, v); }
             else sgi = fetch_h4_linear(gi0, d, u, v);
             /* constructGlobalIllumination :53-108 */
             float roughness = mat.roughness * mat.roughness;
@@ -974,8 +980,15 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
  * gi = the denoiser's texture (K4 output, `inputTexture`), scene = the composer's input buffer (`sceneTexture`).
  * Fog: three.js fog_fragment (un-vendored, three@0.151: SURVEY.md Appendix H) with its gl_FragColor line removed (SSGIEffect.js:40-44):
  *   FOG_EXP2: fogFactor = 1.0 - exp( - fogDensity * fogDensity * vFogDepth * vFogDepth );  else smoothstep( fogNear, fogFar, vFogDepth ) */
-int rfxo_final(int W, int H, int y0, int y1, const float *depth, const float *gi, const float *scene, const rfx_final_params *p, float *out) {
-    if (p->fogMode < 0 || p->fogMode > 2) return RFX_EINVAL;
+int rfxo_final(int W, int H, int y0, int y1, const float *depth, const void *giv, const float *scene, const rfx_final_params *p, float *out) {
+    if (p->fogMode < 0 || p->fogMode > 2 || p->inputSource < 0 || p->inputSource > 2) return RFX_EINVAL;
+    const float *gi = (const float *)giv;
+    float *tmp = NULL;
+    if (p->inputSource == 2) { /* "denoised": K3's RGBA16F target B sampled at texel centres = the texel */
+        tmp = (float *)malloc((size_t)W * H * 4 * sizeof(float));
+        for (size_t k = 0; k < (size_t)W * H * 4; k++) tmp[k] = half_to_float(((const uint16_t *)giv)[k]);
+        gi = tmp;
+    }
 #pragma omp parallel for schedule(static)
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < W; x++) {
@@ -997,6 +1010,7 @@ int rfxo_final(int W, int H, int y0, int y1, const float *depth, const float *gi
             }
             o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = 1.0f;
         }
+    free(tmp);
     return 0;
 }
 

@@ -95,8 +95,9 @@ def compose(depth, gbuffer, gi0, gi1, params: abi.ComposeParams, out=None, rows=
     H, W = depth.shape
     y0, y1 = rows or (0, H)
     out = np.zeros((H, W, 4), np.float32) if out is None else out
-    rc = lib().rfxo_compose(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gbuffer, np.uint32, (H, W, 4))), _p(_chk(gi0, np.uint16, (H, W, 4))),
-                            _p(_chk(gi1, np.uint16, (H, W, 4))) if gi1 is not None else None,
+    gdt = np.float32 if params.giSource else np.uint16  # giSource 1: K2's RGBA32F targets (denoiseMode "full_temporal")
+    rc = lib().rfxo_compose(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gbuffer, np.uint32, (H, W, 4))), _p(_chk(gi0, gdt, (H, W, 4))),
+                            _p(_chk(gi1, gdt, (H, W, 4))) if gi1 is not None else None,
                             _p(_chk(scene, np.float32, (H, W, 4))) if scene is not None else None, C.byref(params), _p(out))
     assert rc == 0, rc
     return out
@@ -107,7 +108,8 @@ def final(depth, gi, scene, params: abi.FinalParams, out=None, rows=None):
     H, W = depth.shape
     y0, y1 = rows or (0, H)
     out = np.zeros((H, W, 4), np.float32) if out is None else out
-    rc = lib().rfxo_final(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gi, np.float32, (H, W, 4))), _p(_chk(scene, np.float32, (H, W, 4))),
+    rc = lib().rfxo_final(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gi, np.uint16 if params.inputSource == 2 else np.float32, (H, W, 4))),
+                          _p(_chk(scene, np.float32, (H, W, 4))),
                           C.byref(params), _p(out))
     assert rc == 0, rc
     return out

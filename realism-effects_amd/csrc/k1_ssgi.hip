@@ -225,7 +225,8 @@ RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat
     const float2 coords = ray.uv;
     const float ru = coords.x, rv = coords.y;
     if (ru >= 0.0f && ru <= 1.0f && rv >= 0.0f && rv <= 1.0f) {
-        const float4 h = rfx_fetch_f4(A.history, d, ru, rv);
+        // accumulatedTexture: K4's output, K2's texture[0], or (denoiseMode "denoised") three's empty texture — rfx.h historySource
+        const float4 h = A.p.historySource == 2 ? make_float4(0.f, 0.f, 0.f, 0.f) : rfx_fetch_f4(A.history, d, ru, rv);
         float3 gi = make_float3(h.x, h.y, h.z);
         const float mx = fmaxf(fmaxf(mat.diffuse.x, mat.diffuse.y), mat.diffuse.z);
         const float mn = fminf(fminf(mat.diffuse.x, mat.diffuse.y), mat.diffuse.z);

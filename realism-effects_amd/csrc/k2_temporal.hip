@@ -363,11 +363,8 @@ hipError_t rfx_launch_k2(const K2Args &A, hipStream_t stream) {
             else hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, false, false>), grid, block, 0, stream, A);             \
         }                                                                                                                   \
     } while (0)
-    if (A.hist_f32 && A.p.textureCount != 1) return hipErrorInvalidValue;
-    if (A.p.inputType == 0 && A.p.textureCount == 2) {
-        if (lt) hipLaunchKernelGGL((k2_temporal_reproject<0, 2, true, false>), grid, block, 0, stream, A);
-        else hipLaunchKernelGGL((k2_temporal_reproject<0, 2, false, false>), grid, block, 0, stream, A);
-    } else if (A.p.inputType == 1 && A.p.textureCount == 1) K2_LAUNCH(1, 1);
+    if (A.p.inputType == 0 && A.p.textureCount == 2) K2_LAUNCH(0, 2);
+    else if (A.p.inputType == 1 && A.p.textureCount == 1) K2_LAUNCH(1, 1);
     else if (A.p.inputType == 2 && A.p.textureCount == 1) K2_LAUNCH(2, 1);
     else return hipErrorInvalidValue;
 #undef K2_LAUNCH

@@ -32,7 +32,15 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
     // DenoiserComposePass.js:26-33: "diffuseSpecular" -> (textures[0], textures[1]); "specular" -> specularGi = textures[0],
     // diffuseGiTexture unbound (zeros) and the diffuse component comes from sceneTexture
     float4 dgi = make_float4(0.f, 0.f, 0.f, 0.f), sgi;
-    if (A.p.inputType == 0) {
+    if (A.p.giSource) {  // denoiseMode "full_temporal": K2's own targets (RGBA32F, NearestFilter) — the texel itself
+        const size_t gi = rfx_xy_index(d, A.gi0.row0, A.gi0.rows, x, y);
+        if (A.p.inputType == 0) {
+            dgi = ((const float4 *)A.gi0.ptr)[gi];
+            sgi = ((const float4 *)A.gi1.ptr)[gi];
+        } else {
+            sgi = ((const float4 *)A.gi0.ptr)[gi];
+        }
+    } else if (A.p.inputType == 0) {
         dgi = rfx_fetch_h4_linear(A.gi0, d, u, v);
         sgi = rfx_fetch_h4_linear(A.gi1, d, u, v);
     } else {
@@ -88,7 +96,9 @@ __global__ __launch_bounds__(256) void k5_final_compose(K5Args A) {
     if (x < d.W && y < A.y1) {
         const rfx_final_params &p = A.p;
         float4 o;
-        const float4 gi = ((const float4 *)A.gi.ptr)[rfx_xy_index(d, A.gi.row0, A.gi.rows, x, y)];
+        // inputTexture at a texel centre: K4's / K2's RGBA32F texel, or (denoiseMode "denoised") K3's RGBA16F target B texel
+        const size_t gii = rfx_xy_index(d, A.gi.row0, A.gi.rows, x, y);
+        const float4 gi = p.inputSource == 2 ? rfx_load_half4(((const uint2 *)A.gi.ptr)[gii]) : ((const float4 *)A.gi.ptr)[gii];
         if (p.isDebug) {
             o = gi;  // :21-24
         } else {

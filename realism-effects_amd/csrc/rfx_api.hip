@@ -263,7 +263,11 @@ int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
     if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: only PERSPECTIVE_CAMERA is built");
     if (p->steps < 1 || p->refineSteps < 0) return fail(c, RFX_EINVAL, "rfx_ssgi_march: steps/refineSteps");
     hipSetDevice(c->device);
-    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, RFX_TEX_DIRECT_LIGHT, RFX_TEX_COMPOSE, RFX_TEX_BLUE_NOISE, RFX_TEX_SSGI};
+    if (p->historySource < 0 || p->historySource > 2) return fail(c, RFX_EINVAL, "rfx_ssgi_march: historySource");
+    if (p->historySource == 1 && (c->tile_y0 != 0 || c->tile_rows != c->H))
+        return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: historySource TEMPORAL0 (denoiseMode \"temporal\") needs a whole-frame context: K1 gathers it anywhere on screen");
+    const int hist = p->historySource == 1 ? RFX_TEX_TEMPORAL0 : RFX_TEX_COMPOSE;
+    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, RFX_TEX_DIRECT_LIGHT, hist, RFX_TEX_BLUE_NOISE, RFX_TEX_SSGI};
     int rc = need(c, ids, 6);
     if (rc) return rc;
     if (!c->slots[RFX_TEX_DEPTH].uploaded || !c->slots[RFX_TEX_GBUFFER].uploaded || !c->slots[RFX_TEX_BLUE_NOISE].uploaded)
@@ -273,7 +277,7 @@ int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
     // K2's neighbourhood clamp reads +-2 rows of K1's output: produce them redundantly in the halo
     launch_rows(c, RFX_TEX_SSGI, c->halo < 2 ? c->halo : 2, &A.y0, &A.y1);
     A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER); A.direct = view(c, RFX_TEX_DIRECT_LIGHT);
-    A.history = view(c, RFX_TEX_COMPOSE);
+    A.history = view(c, hist);
     A.blue = c->slots[RFX_TEX_BLUE_NOISE].ptr;
     blue_noise_shift(p->blueNoiseIndex, &A.shift_x, &A.shift_y);
     A.out = wview(c, RFX_TEX_SSGI);
@@ -306,8 +310,7 @@ int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
     if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_temporal_reproject: only PERSPECTIVE_CAMERA is built");
     if (!((p->inputType == 0 && p->textureCount == 2) || ((p->inputType == 1 || p->inputType == 2) && p->textureCount == 1)))
         return fail(c, RFX_EINVAL, "rfx_temporal_reproject: inputType/textureCount combination");
-    if (p->historySource < 0 || p->historySource > 2 || (p->historySource != 0 && p->textureCount != 1))
-        return fail(c, RFX_EINVAL, "rfx_temporal_reproject: historySource (the framebuffer copy serves one texture)");
+    if (p->historySource < 0 || p->historySource > 2) return fail(c, RFX_EINVAL, "rfx_temporal_reproject: historySource");
     hipSetDevice(c->device);
     const int h0 = p->historySource == 0 ? RFX_TEX_DENOISE_B0 : (p->historySource == 1 ? RFX_TEX_FBCOPY_F16 : RFX_TEX_FBCOPY_F32);
     // with one texture the reference binds the same history to every index (TemporalReprojectPass.js:148-151)
@@ -390,7 +393,9 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
         return fail(c, RFX_EUNSUPPORTED, "rfx_compose: inputType diffuseSpecular (0) and specular (2) are built");
     if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_compose: only PERSPECTIVE_CAMERA is built");
     hipSetDevice(c->device);
-    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, RFX_TEX_DENOISE_B0, RFX_TEX_DENOISE_B1, RFX_TEX_COMPOSE, RFX_TEX_DIRECT_LIGHT};
+    if (p->giSource != 0 && p->giSource != 1) return fail(c, RFX_EINVAL, "rfx_compose: giSource");
+    const int g0 = p->giSource ? RFX_TEX_TEMPORAL0 : RFX_TEX_DENOISE_B0, g1 = p->giSource ? RFX_TEX_TEMPORAL1 : RFX_TEX_DENOISE_B1;
+    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, g0, g1, RFX_TEX_COMPOSE, RFX_TEX_DIRECT_LIGHT};
     int rc = need(c, ids, 6);
     if (rc) return rc;
     K4Args A;
@@ -399,7 +404,7 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
     if (A.y0 < c->tile_y0) A.y0 = c->tile_y0;  // COMPOSE is held whole: write only the tile
     if (A.y1 > c->tile_y0 + c->tile_rows) A.y1 = c->tile_y0 + c->tile_rows;
     A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER);
-    A.gi0 = view(c, RFX_TEX_DENOISE_B0); A.gi1 = view(c, RFX_TEX_DENOISE_B1);
+    A.gi0 = view(c, g0); A.gi1 = view(c, g1);
     A.scene = view(c, RFX_TEX_DIRECT_LIGHT);  // Denoiser.js:101-103: sceneTexture = the composer's input buffer
     A.out = wview(c, RFX_TEX_COMPOSE);
     A.p = *p;
@@ -412,13 +417,15 @@ int rfx_final_compose(rfx_ctx *c, const rfx_final_params *p) {
     if (p->fogMode < 0 || p->fogMode > 2) return fail(c, RFX_EINVAL, "rfx_final_compose: fogMode");
     if (p->fogMode && !p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_final_compose: only PERSPECTIVE_CAMERA is built");
     hipSetDevice(c->device);
-    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_COMPOSE, RFX_TEX_DIRECT_LIGHT, RFX_TEX_FINAL};
+    if (p->inputSource < 0 || p->inputSource > 2) return fail(c, RFX_EINVAL, "rfx_final_compose: inputSource");
+    const int src = p->inputSource == 0 ? RFX_TEX_COMPOSE : (p->inputSource == 1 ? RFX_TEX_TEMPORAL0 : RFX_TEX_DENOISE_B0);
+    const int ids[] = {RFX_TEX_DEPTH, src, RFX_TEX_DIRECT_LIGHT, RFX_TEX_FINAL};
     int rc = need(c, ids, 4);
     if (rc) return rc;
     K5Args A;
     A.dims = dims(c);
     launch_rows(c, RFX_TEX_FINAL, 0, &A.y0, &A.y1);
-    A.depth = view(c, RFX_TEX_DEPTH); A.gi = view(c, RFX_TEX_COMPOSE); A.scene = view(c, RFX_TEX_DIRECT_LIGHT);
+    A.depth = view(c, RFX_TEX_DEPTH); A.gi = view(c, src); A.scene = view(c, RFX_TEX_DIRECT_LIGHT);
     A.out = wview(c, RFX_TEX_FINAL);
     A.p = *p;
     HIPCHK(c, rfx_launch_k5(A, c->stream));

@@ -49,7 +49,7 @@ struct K3Args {
 struct K4Args {
     FrameDims dims;
     int y0, y1;
-    TexView depth, gbuffer, gi0, gi1;
+    TexView depth, gbuffer, gi0, gi1;  // gi*: K3 target B (RGBA16F, linear) or, giSource 1, K2's targets (RGBA32F, nearest)
     TexView scene;  // the composer's input buffer (sceneTexture): read only by inputType "specular"
     TexViewW out;
     rfx_compose_params p;

@@ -349,7 +349,8 @@ class DenoiserComposePass {
 		options = options || {}
 		this._camera = camera
 		const it = INPUT_TYPES.indexOf(options.inputType)
-		this.uniforms = { camera: null, inputType: it < 0 ? 0 : it }
+		// Denoiser.js:53 composerInputTextures: the denoise pass's targets, or (denoiseMode "full_temporal") K2's own
+		this.uniforms = { camera: null, inputType: it < 0 ? 0 : it, giSource: textures[0] === TEX.TEMPORAL0 ? 1 : 0 }
 	}
 	setSize(width, height) {
 		this.width = width
@@ -392,12 +393,11 @@ class Denoiser {
 			this.denoisePass = new PoissonDenoisePass(camera, [TEX.TEMPORAL0, TEX.TEMPORAL1], popt, blueNoiseStart, halfStoreRTZ)
 			this.temporalReprojectPass.overrideAccumulatedTextures = this.denoisePass.texture
 		}
-		if (options.denoiseMode.startsWith("full")) {
-			if (!this.denoisePass)
-				throw new Error('denoiseMode "full_temporal": K2 history from a framebuffer copy is not built (SURVEY.md Appendix D-11)')
-			this.denoiserComposePass = new DenoiserComposePass(camera, this.denoisePass.texture, TEX.GBUFFER, TEX.DEPTH, options)
-		}
-		if (options.denoiseMode === "temporal") throw new Error('denoiseMode "temporal" is not built (SURVEY.md Appendix D-11)')
+		if (["full", "full_temporal", "denoised", "temporal"].indexOf(options.denoiseMode) < 0) throw new Error("denoiseMode " + options.denoiseMode)
+		const textures = [TEX.TEMPORAL0, TEX.TEMPORAL1].slice(0, textureCount)
+		const composerInputTextures = this.denoisePass ? this.denoisePass.texture : textures // :53
+		if (options.denoiseMode.startsWith("full"))
+			this.denoiserComposePass = new DenoiserComposePass(camera, composerInputTextures, TEX.GBUFFER, TEX.DEPTH, options)
 	}
 	get texture() {
 		switch (this.options.denoiseMode) {
@@ -465,6 +465,10 @@ class SSGIPass {
 		this.gBufferPass.render(renderer)
 		this.uniforms.camera = cloneCamera(this._camera)
 		this.uniforms.blueNoiseIndex = this.blueNoiseIndex.value
+		// :89 accumulatedTexture = ssgiEffect.denoiser.texture: K4's target, K2's texture[0] ("temporal"), or — "denoised", where the
+		// getter returns the ARRAY of K3's targets — what three binds for a non-texture value: its empty texture (zeros)
+		const t = this.ssgiEffect.denoiser.texture
+		this.uniforms.historySource = Array.isArray(t) ? 2 : t === TEX.TEMPORAL0 ? 1 : 0
 		renderer.ssgiMarch(this.uniforms) // :93-94
 	}
 	dispose() {}
@@ -515,7 +519,7 @@ class SSGIEffect {
 		)
 		this.lastSize = { width: options.width, height: options.height, resolutionScale: options.resolutionScale }
 		// FinalSSGIMaterial uniforms (:47-66)
-		this.uniforms = { camera: cloneCamera(camera), isDebug: 0, fogMode: 0, fogColor: [0, 0, 0], fogNear: 0, fogFar: 0, fogDensity: 0 }
+		this.uniforms = { camera: cloneCamera(camera), isDebug: 0, inputSource: 0, fogMode: 0, fogColor: [0, 0, 0], fogNear: 0, fogFar: 0, fogDensity: 0 }
 		this.setSize(options.width, options.height)
 		this.makeOptionsReactive(options)
 		this.outputTexture = this.denoiser.texture
@@ -624,6 +628,9 @@ class SSGIEffect {
 		// :400-417 the effect's own uniforms: inputTexture = the denoiser's texture, sceneTexture = the input buffer, fog from the scene
 		const fog = this._scene.fog
 		const u = this.uniforms
+		let out = this.denoiser.texture // :139,402 inputTexture = outputTexture[0] ?? outputTexture
+		if (Array.isArray(out)) out = out[0]
+		u.inputSource = out === TEX.COMPOSE ? 0 : out === TEX.TEMPORAL0 ? 1 : 2
 		u.fogMode = !fog ? 0 : fog.isFogExp2 ? 2 : 1
 		if (fog) {
 			u.fogColor = Array.from(fog.color)

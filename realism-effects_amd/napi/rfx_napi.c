@@ -226,6 +226,7 @@ static napi_value n_ssgi(napi_env env, napi_callback_info info) {
     p.thickness = (float)prop_num(env, a[1], "thickness", 10);
     p.envBlur = (float)prop_num(env, a[1], "envBlur", 0.5);
     p.blueNoiseIndex = (int32_t)prop_num(env, a[1], "blueNoiseIndex", 0);
+    p.historySource = (int32_t)prop_num(env, a[1], "historySource", 0);
     int rc = rfx_ssgi_march(c, &p);
     if (rc) return throw_rfx(env, c, "rfx_ssgi_march", rc);
     return NULL;
@@ -309,12 +310,13 @@ static napi_value n_compose(napi_env env, napi_callback_info info) {
     memset(&p, 0, sizeof p);
     if (!read_camera(env, a[1], "camera", &p.camera)) return NULL;
     p.inputType = (int32_t)prop_num(env, a[1], "inputType", 0);
+    p.giSource = (int32_t)prop_num(env, a[1], "giSource", 0);
     int rc = rfx_compose(c, &p);
     if (rc) return throw_rfx(env, c, "rfx_compose", rc);
     return NULL;
 }
 
-/* finalCompose(ctx, {camera, isDebug, fogMode, fogColor[3], fogNear, fogFar, fogDensity}) — SSGIEffect's own fragment */
+/* finalCompose(ctx, {camera, isDebug, inputSource, fogMode, fogColor[3], fogNear, fogFar, fogDensity}) — SSGIEffect's own fragment */
 static napi_value n_final(napi_env env, napi_callback_info info) {
     napi_value a[2];
     if (!get_args(env, info, 2, a)) return NULL;
@@ -324,6 +326,7 @@ static napi_value n_final(napi_env env, napi_callback_info info) {
     memset(&p, 0, sizeof p);
     if (!read_camera(env, a[1], "camera", &p.camera)) return NULL;
     p.isDebug = (int32_t)prop_num(env, a[1], "isDebug", 0);
+    p.inputSource = (int32_t)prop_num(env, a[1], "inputSource", 0);
     p.fogMode = (int32_t)prop_num(env, a[1], "fogMode", 0);
     napi_value fc;
     bool has = false;

@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "..", "csrc", "librfx_hip.so")
 
-RFX_ABI_VERSION = 3
+RFX_ABI_VERSION = 4
 RFX_OK, RFX_EINVAL, RFX_ENOMEM, RFX_EDEVICE, RFX_ESTATE, RFX_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 (TEX_DEPTH, TEX_GBUFFER, TEX_VELOCITY, TEX_DIRECT_LIGHT, TEX_BLUE_NOISE, TEX_SSGI, TEX_TEMPORAL0, TEX_TEMPORAL1,
@@ -51,7 +51,8 @@ class Camera(C.Structure):
 class SsgiParams(C.Structure):
     _fields_ = [("camera", Camera), ("steps", C.c_int32), ("refineSteps", C.c_int32), ("mode", C.c_int32),
                 ("useDirectLight", C.c_int32), ("missedRays", C.c_int32), ("importanceSampling", C.c_int32),
-                ("rayDistance", C.c_float), ("thickness", C.c_float), ("envBlur", C.c_float), ("blueNoiseIndex", C.c_int32)]
+                ("rayDistance", C.c_float), ("thickness", C.c_float), ("envBlur", C.c_float), ("blueNoiseIndex", C.c_int32),
+                ("historySource", C.c_int32)]
 
 
 class TemporalParams(C.Structure):
@@ -70,11 +71,11 @@ class DenoiseParams(C.Structure):
 
 
 class ComposeParams(C.Structure):
-    _fields_ = [("camera", Camera), ("inputType", C.c_int32)]
+    _fields_ = [("camera", Camera), ("inputType", C.c_int32), ("giSource", C.c_int32)]
 
 
 class FinalParams(C.Structure):
-    _fields_ = [("camera", Camera), ("isDebug", C.c_int32), ("fogMode", C.c_int32), ("fogColor", C.c_float * 3), ("fogNear", C.c_float),
+    _fields_ = [("camera", Camera), ("isDebug", C.c_int32), ("inputSource", C.c_int32), ("fogMode", C.c_int32), ("fogColor", C.c_float * 3), ("fogNear", C.c_float),
                 ("fogFar", C.c_float), ("fogDensity", C.c_float)]
 
 

@@ -299,7 +299,9 @@ class DenoiserComposePass:
         self._camera = camera
         o = options or {}
         it = _INPUT_TYPES.index(o.get("inputType", "diffuseSpecular")) if o.get("inputType", "diffuseSpecular") in _INPUT_TYPES else 0
-        self.uniforms = abi.ComposeParams(inputType=it)
+        # Denoiser.js:53 composerInputTextures: the denoise pass's targets, or (denoiseMode "full_temporal") K2's own
+        src = 1 if tuple(textures)[0] == abi.TEX_TEMPORAL0 else 0
+        self.uniforms = abi.ComposeParams(inputType=it, giSource=src)
 
     def setSize(self, width, height):
         self.width, self.height = width, height
@@ -336,12 +338,12 @@ class Denoiser:
             popt = {k: v for k, v in o.items() if k in defaultPoissonBlurOptions}
             self.denoisePass = PoissonDenoisePass(camera, (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1), popt, blue_noise_start, half_store_rtz)
             self.temporalReprojectPass.overrideAccumulatedTextures = list(self.denoisePass.texture)
+        if o["denoiseMode"] not in ("full", "full_temporal", "denoised", "temporal"):
+            raise ValueError("denoiseMode %r" % (o["denoiseMode"],))
+        textures = (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1)[:textureCount]
+        composerInputTextures = self.denoisePass.texture if self.denoisePass else textures  # :53
         if o["denoiseMode"].startswith("full"):
-            if self.denoisePass is None:
-                raise NotImplementedError('denoiseMode "full_temporal": K2 history from a framebuffer copy is not built (Appendix D-11)')
-            self.denoiserComposePass = DenoiserComposePass(camera, self.denoisePass.texture, abi.TEX_GBUFFER, abi.TEX_DEPTH, o)
-        if o["denoiseMode"] == "temporal":
-            raise NotImplementedError('denoiseMode "temporal": framebuffer-copy history is not built (Appendix D-11)')
+            self.denoiserComposePass = DenoiserComposePass(camera, composerInputTextures, abi.TEX_GBUFFER, abi.TEX_DEPTH, o)
 
     @property
     def texture(self):
@@ -405,6 +407,10 @@ class SSGIPass:
         self.gBufferPass.render(renderer)
         self.uniforms.camera = abi.Camera.from_scene(self._camera)
         self.uniforms.blueNoiseIndex = self.blueNoiseIndex.value
+        # :89 accumulatedTexture = ssgiEffect.denoiser.texture: K4's target, K2's texture[0] ("temporal"), or — "denoised", where the
+        # getter returns the ARRAY of K3's targets — what three binds for a non-texture value: its empty texture (zeros)
+        t = self.ssgiEffect.denoiser.texture
+        self.uniforms.historySource = 2 if isinstance(t, (tuple, list)) else (1 if t == abi.TEX_TEMPORAL0 else 0)
         renderer.ssgi_march(self.uniforms)  # :93-94
 
     def dispose(self):
@@ -529,6 +535,9 @@ class SSGIEffect:
         self.denoiser.render(renderer, inputBuffer)
         # :400-417 the effect's own uniforms: inputTexture = the denoiser's texture, sceneTexture = the input buffer, fog from the scene
         u = self.uniforms
+        out = self.denoiser.texture  # :139,402 inputTexture = outputTexture[0] ?? outputTexture
+        out = out[0] if isinstance(out, (tuple, list)) else out
+        u.inputSource = {abi.TEX_COMPOSE: 0, abi.TEX_TEMPORAL0: 1, abi.TEX_DENOISE_B0: 2}[out]
         fog = getattr(self._scene, "fog", None)
         u.fogMode = 0 if fog is None else (2 if getattr(fog, "isFogExp2", False) else 1)
         if fog is not None:

@@ -34,12 +34,13 @@ def cam_arrays(cam, prefix):
             ("projectionMatrix", "projectionMatrixInverse", "matrixWorld", "matrixWorldInverse", "position", "quaternion")}
 
 
-def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_start=2000, mode="ssgi", missed_rays=False):
+def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_start=2000, mode="ssgi", missed_rays=False, denoise_mode="full"):
     bn = np.fromfile(os.path.join(ROOT, "realism-effects_amd", "data", "blue_noise_128_rgba8.bin"), np.uint8).reshape(128, 128, 4)
-    c = chain.GLRefChain(W, H, bn, steps=steps, refineSteps=refine, denoiseIterations=iterations, mode=mode, missedRays=missed_rays)
+    c = chain.GLRefChain(W, H, bn, steps=steps, refineSteps=refine, denoiseIterations=iterations, mode=mode, missedRays=missed_rays,
+                         denoiseMode=denoise_mode)
     tc = c.tc
     out = dict(width=W, height=H, frames=frames, steps=steps, refineSteps=refine, denoiseIterations=iterations, ssgi_start=ssgi_start,
-               denoise_start=denoise_start, gl_info=chain.GL.info(), mode=mode, textureCount=tc, missedRays=int(missed_rays))
+               denoise_start=denoise_start, gl_info=chain.GL.info(), mode=mode, textureCount=tc, missedRays=int(missed_rays), denoiseMode=denoise_mode)
     si = di = 0
     for fi in range(frames):
         f = synthetic_frame(W, H, fi)
@@ -56,17 +57,21 @@ def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_
         for j in range(tc):
             out[k + "temporal%d" % j] = c.t_temporal[j].read()
         idx = []
-        for _ in range(2 * iterations):
+        for _ in range(2 * iterations if c.has_denoise else 0):
             di = (denoise_start + di + 1) % M
             idx.append(di)
         c.denoise(f.camera, idx)
         out[k + "denoise_index"] = np.array(idx, np.int64)
-        for j in range(tc):
-            # RGBA16F targets read back as float32 are exactly representable in half
-            out[k + "A%d" % j] = c.t_A[j].read().astype(np.float16).view(np.uint16)
-            out[k + "B%d" % j] = c.t_B[j].read().astype(np.float16).view(np.uint16)
+        if c.has_denoise:
+            for j in range(tc):
+                # RGBA16F targets read back as float32 are exactly representable in half
+                out[k + "A%d" % j] = c.t_A[j].read().astype(np.float16).view(np.uint16)
+                out[k + "B%d" % j] = c.t_B[j].read().astype(np.float16).view(np.uint16)
         c.compose(f.camera)
-        out[k + "compose"] = c.t_compose.read()
+        if c.has_compose:
+            out[k + "compose"] = c.t_compose.read()
+        if denoise_mode != "full":
+            out[k + "final"] = chain.chain_final(c, f)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
@@ -117,6 +122,8 @@ if __name__ == "__main__":
     run("chain_97x55_s8r2_it2", 97, 55, frames=2, steps=8, refine=2, iterations=2)
     run("chain_ssr_128x72_s20r5_it1", 128, 72, frames=2, steps=20, refine=5, iterations=1, mode="ssr")
     run("chain_missed_96x54_s12r3_it1", 96, 54, frames=2, steps=12, refine=3, iterations=1, missed_rays=True)
+    for dm in ("full_temporal", "temporal", "denoised"):  # the other Denoiser modes (Denoiser.js:7,41-78)
+        run("chain_%s_104x58_s10r2" % dm, 104, 58, frames=3, steps=10, refine=2, iterations=1, denoise_mode=dm)
     run_traa("traa_half_128x72", 128, 72, frames=3, half=True)
     run_traa("traa_float_96x54", 96, 54, frames=3, half=False)
     run_final("final_112x63", 112, 63)

@@ -59,7 +59,8 @@ class OracleRenderer:
     def ssgi_march(self, p):
         self.calls.append(("ssgi", p.blueNoiseIndex))
         t = self.tex
-        O.ssgi(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[abi.TEX_DIRECT_LIGHT], t[abi.TEX_COMPOSE], t[abi.TEX_BLUE_NOISE], p,
+        hist = t[abi.TEX_TEMPORAL0] if p.historySource == 1 else t[abi.TEX_COMPOSE]
+        O.ssgi(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[abi.TEX_DIRECT_LIGHT], hist, t[abi.TEX_BLUE_NOISE], p,
                out=t[abi.TEX_SSGI], rows=self._rows(min(2, self.halo)))
 
     def temporal_reproject(self, p):
@@ -98,13 +99,15 @@ class OracleRenderer:
     def compose(self, p):
         self.calls.append(("compose",))
         t = self.tex
-        O.compose(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[abi.TEX_DENOISE_B0], t[abi.TEX_DENOISE_B1], p, out=t[abi.TEX_COMPOSE], rows=self._rows(),
+        g0, g1 = (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1) if p.giSource else (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1)
+        O.compose(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[g0], t[g1], p, out=t[abi.TEX_COMPOSE], rows=self._rows(),
                   scene=t[abi.TEX_DIRECT_LIGHT])
 
     def final_compose(self, p):
         self.calls.append(("final", p.fogMode, p.isDebug))
         t = self.tex
-        O.final(t[abi.TEX_DEPTH], t[abi.TEX_COMPOSE], t[abi.TEX_DIRECT_LIGHT], p, out=t[abi.TEX_FINAL], rows=self._rows())
+        src = (abi.TEX_COMPOSE, abi.TEX_TEMPORAL0, abi.TEX_DENOISE_B0)[p.inputSource]
+        O.final(t[abi.TEX_DEPTH], t[src], t[abi.TEX_DIRECT_LIGHT], p, out=t[abi.TEX_FINAL], rows=self._rows())
 
     def sync(self):
         pass

@@ -154,8 +154,12 @@ def test_presets_and_unsupported_modes():
     scene, cam = _scene()
     fx = effect.SSGIEffect(None, scene, cam, dict(preset="medium", width=32, height=16))
     assert (fx.steps, fx.refineSteps) == (20, 4)
-    with pytest.raises(NotImplementedError):
-        effect.SSGIEffect(None, scene, cam, dict(preset="low"))  # denoiseMode full_temporal: framebuffer-copy history
+    low = effect.SSGIEffect(None, scene, cam, dict(preset="low", width=32, height=16))  # :83-87 -> denoiseMode "full_temporal"
+    assert (low.steps, low.refineSteps) == (10, 2)
+    assert low.denoiser.denoisePass is None and low.denoiser.denoiserComposePass.uniforms.giSource == 1
+    assert not low.denoiser.temporalReprojectPass.overrideAccumulatedTextures
+    with pytest.raises(ValueError):
+        effect.SSGIEffect(None, scene, cam, dict(denoiseMode="bogus", width=32, height=16))
 
 
 def test_traa_option_mapping():

@@ -542,3 +542,87 @@ def test_final_compose_vs_oracle():
     want = O.final(f.depth, ctx.download(abi.TEX_COMPOSE), f.direct, fx.uniforms)
     assert_close("effect mainImage", ctx.download(tex), want, 0.0)
     ctx.close()
+
+
+@pytest.mark.parametrize("dm", ["full_temporal", "temporal", "denoised"])
+def test_denoise_modes_vs_oracle(dm, blue_noise):
+    """The other Denoiser modes (Denoiser.js:7,41-78; preset "low" = "full_temporal") end to end through SSGIEffect on the device and on
+    the oracle renderer in lockstep: every device pass is fed the ORACLE's state of the previous passes, so flips do not compound."""
+    import types
+    from oracle_renderer import OracleRenderer
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.effect import SSGIEffect
+    from rfx_amd.scene import synthetic_frame
+    import rfx_oracle as O
+
+    W, H, NF = 272, 152, 3
+    frames = [synthetic_frame(W, H, i) for i in range(NF)]
+    dev, ora = Context(W, H), OracleRenderer(W, H)
+    slots = (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1, abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1,
+             abi.TEX_COMPOSE, abi.TEX_FBCOPY_F32, abi.TEX_FINAL)
+    lim = dict(ssgi=FLIP["ssgi"], temporal=FLIP["temporal"], denoise=FLIP["denoise"], compose=FLIP["compose"], final=FLIP["denoise"], copy_framebuffer=0.0)
+    out_tex = dict(ssgi=(abi.TEX_SSGI,), temporal=(abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1), compose=(abi.TEX_COMPOSE,), final=(abi.TEX_FINAL,),
+                   copy_framebuffer=(abi.TEX_FBCOPY_F32,))
+
+    class Lockstep:
+        """runs every call on both renderers, compares what the call wrote, then overwrites the device's copy with the oracle's"""
+        def __init__(self):
+            self.W, self.H, self.seen = W, H, []
+
+        def held_rows(self, tex):
+            return dev.held_rows(tex)
+
+        def upload(self, tex, a, r0=None, n=None):
+            dev.upload(tex, a, r0, n)
+            ora.upload(tex, a, r0, n)
+
+        def _both(self, name, p, texs):
+            getattr(dev, name)(p)
+            getattr(ora, name)(p)
+            key = {"ssgi_march": "ssgi", "temporal_reproject": "temporal", "poisson_denoise": "denoise", "final_compose": "final"}.get(name, name)
+            self.seen.append(key)
+            for t in texs:
+                got, want = dev.download(t), ora.tex[t]
+                if got.dtype == np.uint16:
+                    got, want = O.half_bits_to_float(got), O.half_bits_to_float(want)
+                elif t == abi.TEX_SSGI:
+                    ga, gb = O.unpack_ssgi(got)
+                    wa, wb = O.unpack_ssgi(want)
+                    got, want = np.concatenate([ga, gb], -1), np.concatenate([wa, wb], -1)
+                assert_close("%s %s %s" % (dm, key, abi.TEX_NAMES[t]), got, want, lim[key])
+                dev.upload(t, ora.tex[t])
+
+        def ssgi_march(self, p):
+            self._both("ssgi_march", p, out_tex["ssgi"])
+
+        def temporal_reproject(self, p):
+            self._both("temporal_reproject", p, out_tex["temporal"])
+
+        def copy_framebuffer(self, dst):
+            self._both("copy_framebuffer", dst, out_tex["copy_framebuffer"])
+
+        def poisson_denoise(self, p):
+            self._both("poisson_denoise", p, (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1) if p.writeToB else (abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1))
+
+        def compose(self, p):
+            self._both("compose", p, out_tex["compose"])
+
+        def final_compose(self, p):
+            self._both("final_compose", p, out_tex["final"])
+
+    r = Lockstep()
+    scene = types.SimpleNamespace(frame=None)
+    cam = types.SimpleNamespace(**vars(frames[0].camera))
+    fx = SSGIEffect(None, scene, cam, dict(width=W, height=H, steps=10, refineSteps=2, denoiseMode=dm), seeds=dict(ssgi=7, denoise=8))
+    for f in frames:
+        scene.frame = f
+        for k, v in vars(f.camera).items():
+            setattr(cam, k, v)
+        fx.update(r, None)
+        fx.mainImage(r)
+    want = {"full_temporal": ["ssgi", "temporal", "copy_framebuffer", "compose", "final"], "temporal": ["ssgi", "temporal", "copy_framebuffer", "final"],
+            "denoised": ["ssgi", "temporal", "denoise", "denoise", "final"]}[dm]
+    assert r.seen == want * NF
+    assert (fx.ssgiPass.uniforms.historySource, fx.uniforms.inputSource) == {"full_temporal": (0, 0), "temporal": (1, 1), "denoised": (2, 2)}[dm]
+    dev.close()

@@ -50,9 +50,27 @@ for (const type of [fx.HalfFloatType, fx.FloatType]) {
   const e2 = new fx.TRAAEffect(sc, cam, new fx.VelocityDepthNormalPass(sc, cam), { fullAccumulate: true })
   e2.update(RT, { texture: { type }, width: 32, height: 16, data }); e2.update(RT, { texture: { type }, width: 32, height: 16, data })
 }
+// the other Denoiser modes: same pass construction and source wiring on both hosts
+const modeCalls = {}
+for (const dm of ["full_temporal", "temporal", "denoised"]) {
+  const mc = []
+  const RM = {
+    uploadPlane() {},
+    ssgiMarch(u) { mc.push(["ssgi", u.historySource]) },
+    temporalReproject(u) { mc.push(["temporal", u.textureCount, u.historySource, u.targetHalf]) },
+    copyFramebuffer(t) { mc.push(["copy", t]) },
+    poissonDenoise(u) { mc.push(["denoise", u.inputIsTemporal, u.writeToB]) },
+    compose(u) { mc.push(["compose", u.inputType, u.giSource]) },
+    finalCompose(u) { mc.push(["final", u.inputSource, u.fogMode]) }
+  }
+  const em = new fx.SSGIEffect(null, { frame: {}, fog: { isFogExp2: true, color: [0.1, 0.2, 0.3], density: 0.02 } }, cam, { width: 32, height: 16, denoiseMode: dm }, { ssgi: 1, denoise: 2 })
+  em.update(RM, null); em.mainImage(RM)
+  modeCalls[dm] = mc
+}
+const low = new fx.SSGIEffect(null, { frame: {} }, cam, { width: 32, height: 16, preset: "low" }, { ssgi: 1, denoise: 2 })
 const halfProbe = JSON.parse(process.argv[3]).map(fx.roundToHalf).map(x => Number.isFinite(x) ? x : String(x))
 console.log(JSON.stringify({ calls, defaults: fx.SSGIEffect.DefaultOptions, traa: [t.textureCount, t.inputType, t.logTransform, t.maxBlend, t.confidencePower, t.neighborhoodClampIntensity],
-                             traaCalls, halfProbe, r2: fx.r2Sequence.slice(0, 3) }))
+                             traaCalls, halfProbe, r2: fx.r2Sequence.slice(0, 3), modeCalls, low: [low.steps, low.refineSteps, low.denoiser.options.denoiseMode] }))
 """
 
 
@@ -133,6 +151,35 @@ def test_js_and_python_hosts_issue_the_same_calls():
     py = [c for c in rt.calls if c[0] != "upload"]
     assert [c for c in js["traaCalls"] if c[0] != "upload"] == json.loads(json.dumps(py))
     assert [c[:2] for c in js["traaCalls"] if c[0] == "upload"][:2] == [["upload", abi.TEX_VELOCITY], ["upload", abi.TEX_SSGI]]
+    # denoiseMode "full_temporal" / "temporal" / "denoised": same passes, same source wiring
+    class RecModes(Rec):
+        def ssgi_march(self, p):
+            self.calls.append(["ssgi", p.historySource])
+
+        def temporal_reproject(self, p):
+            self.calls.append(["temporal", p.textureCount, p.historySource, p.targetHalf])
+
+        def copy_framebuffer(self, t):
+            self.calls.append(["copy", t])
+
+        def poisson_denoise(self, p):
+            self.calls.append(["denoise", p.inputIsTemporal, p.writeToB])
+
+        def compose(self, p):
+            self.calls.append(["compose", p.inputType, p.giSource])
+
+        def final_compose(self, p):
+            self.calls.append(["final", p.inputSource, p.fogMode])
+
+    for dm in ("full_temporal", "temporal", "denoised"):
+        rm = RecModes()
+        sc = types.SimpleNamespace(frame=f, fog=types.SimpleNamespace(isFogExp2=True, color=(0.1, 0.2, 0.3), density=0.02))
+        em = effect.SSGIEffect(None, sc, f.camera, dict(width=32, height=16, denoiseMode=dm), seeds=dict(ssgi=1, denoise=2))
+        em.update(rm, None)
+        em.mainImage(rm)
+        assert js["modeCalls"][dm] == rm.calls, dm
+    low = effect.SSGIEffect(None, scene, f.camera, dict(width=32, height=16, preset="low"), seeds=dict(ssgi=1, denoise=2))
+    assert js["low"] == [low.steps, low.refineSteps, low.denoiser.options["denoiseMode"]] == [10, 2, "full_temporal"]
     # the JS float->half rounding (no Float16Array in Node 12) against numpy's
     want = np.array(HALF_PROBE, np.float32).astype(np.float16).astype(np.float32)
     got = np.array([float(x) for x in js["halfProbe"]], np.float32)

@@ -248,3 +248,87 @@ def test_final_compose_vs_golden():
             assert np.array_equal(out.view(np.uint32), g["final_fog0"].view(np.uint32))  # a select: bit-exact
     assert np.array_equal(O.final(depth, gi, scene, final_params(g, 0, 1)).view(np.uint32), g["final_debug"].view(np.uint32))
     assert (g["final_fog1"] != g["final_fog0"]).any() and (g["final_fog2"] != g["final_fog1"]).any()
+
+
+@pytest.mark.parametrize("name", G.GOLDEN_MODES)
+def test_denoise_modes_stagewise(name, blue_noise):
+    """denoiseMode "full_temporal" / "temporal" / "denoised" (Denoiser.js:41-78): K2 on its own framebuffer copy (both textures
+    read the copy of colour attachment 0), K4 fed by K2's targets, K1's history = K4's target / K2's texture[0] / three's empty
+    texture, and the effect's own fragment on the mode's output texture — every pass fed with the GOLDEN previous outputs."""
+    g = G.load(name)
+    dm = str(g["denoiseMode"])
+    W, H, nf = int(g["width"]), int(g["height"]), int(g["frames"])
+    zf, z16 = np.zeros((H, W, 4), np.float32), np.zeros((H, W, 4), np.uint16)
+    for fi in range(nf):
+        f = G.frame(g, fi)
+        k, kp = "f%d_" % fi, "f%d_" % (fi - 1)
+        sp, tp, dp, cp = stage_params(g, fi, 0.0 if fi == 0 else 1.0)
+        # K1
+        sp.historySource = {"full_temporal": 0, "temporal": 1, "denoised": 2}[dm]
+        hist = zf if (fi == 0 or dm == "denoised") else np.ascontiguousarray(g[kp + ("compose" if dm == "full_temporal" else "temporal0")])
+        o = O.ssgi(f.depth, f.gbuffer, f.direct, hist, blue_noise, sp)
+        oa, ob = O.unpack_ssgi(o)
+        ga, gb = O.unpack_ssgi(g[k + "ssgi"])
+        assert_close(name + " ssgi.diffuse f%d" % fi, oa, ga, FLIP["ssgi"])
+        assert_close(name + " ssgi.specular f%d" % fi, ob, gb, FLIP["ssgi"])
+        # K2
+        T = [np.ascontiguousarray(g[kp + "temporal%d" % j]) if fi else zf.copy() for j in range(2)]
+        if dm == "denoised":
+            h = [np.ascontiguousarray(g[kp + "B%d" % j]) if fi else z16 for j in range(2)]
+        else:
+            tp.historySource = 2
+            h = [np.ascontiguousarray(g[kp + "temporal0"]) if fi else zf] * 2  # ONE copy, of attachment 0, for both textures
+        O.temporal(np.ascontiguousarray(g[k + "ssgi"]), f.velocity, h[0], h[1], tp, T[0], T[1])
+        for j in range(2):
+            assert_close(name + " temporal%d f%d" % (j, fi), T[j], g[k + "temporal%d" % j], FLIP["temporal"])
+        # K3 ("denoised" only) is the pass test_stagewise pins; here: its last pass from the golden A
+        if dm == "denoised":
+            Bn = [np.ascontiguousarray(g[kp + "B%d" % j]).copy() if fi else z16.copy() for j in range(2)]
+            dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = int(g[k + "denoise_index"][-1]), 0, 1
+            O.denoise(f.depth, f.gbuffer, np.ascontiguousarray(g[k + "A0"]), np.ascontiguousarray(g[k + "A1"]), blue_noise, dp, Bn[0], Bn[1])
+            for j in range(2):
+                assert_close(name + " B%d f%d" % (j, fi), O.half_bits_to_float(Bn[j]), O.half_bits_to_float(g[k + "B%d" % j]), FLIP["denoise"])
+        # K4 ("full_temporal": composerInputTextures = K2's targets)
+        if dm == "full_temporal":
+            cp.giSource = 1
+            comp = (np.ascontiguousarray(g[kp + "compose"]) if fi else zf).copy()
+            O.compose(f.depth, f.gbuffer, np.ascontiguousarray(g[k + "temporal0"]), np.ascontiguousarray(g[k + "temporal1"]), cp, comp)
+            assert_close(name + " compose f%d" % fi, comp, g[k + "compose"], FLIP["compose"])
+        # the effect's own fragment on the mode's output texture
+        fp = abi.FinalParams(camera=abi.Camera.from_scene(f.camera), inputSource={"full_temporal": 0, "temporal": 1, "denoised": 2}[dm])
+        src = {"full_temporal": "compose", "temporal": "temporal0", "denoised": "B0"}[dm]
+        out = O.final(f.depth, np.ascontiguousarray(g[k + src]), f.direct, fp)
+        assert np.array_equal(out.view(np.uint32), g[k + "final"].view(np.uint32)), "final f%d" % fi
+
+
+@pytest.mark.parametrize("name", G.GOLDEN_MODES)
+def test_denoise_modes_through_effect(name):
+    """SSGIEffect(denoiseMode=...) on the oracle renderer: pass construction per mode, history wiring, K1's accumulatedTexture,
+    the effect's inputTexture (rfx_amd.effect Denoiser / SSGIPass / SSGIEffect.update)."""
+    import types
+    from oracle_renderer import OracleRenderer
+    from rfx_amd.effect import SSGIEffect
+
+    g = G.load(name)
+    dm = str(g["denoiseMode"])
+    W, H, nf = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene = types.SimpleNamespace(frame=None)
+    cam = G.camera(g, 0)
+    fx = SSGIEffect(None, scene, cam, dict(steps=int(g["steps"]), refineSteps=int(g["refineSteps"]), denoiseIterations=1, denoiseMode=dm, width=W, height=H),
+                    seeds=dict(ssgi=int(g["ssgi_start"]), denoise=int(g["denoise_start"])))
+    r = OracleRenderer(W, H)
+    want_calls = {"full_temporal": ["ssgi", "temporal", "copy_framebuffer", "compose", "final"], "temporal": ["ssgi", "temporal", "copy_framebuffer", "final"],
+                  "denoised": ["ssgi", "temporal", "denoise", "denoise", "final"]}[dm]
+    for fi in range(nf):
+        scene.frame = G.frame(g, fi)
+        for kk, vv in vars(G.camera(g, fi)).items():
+            setattr(cam, kk, vv)
+        fx.update(r, None)
+        fx.mainImage(r)
+        assert [c[0] for c in r.calls] == want_calls
+        r.calls.clear()
+        k = "f%d_" % fi
+        # flipped K3 taps spread to their neighbours in every later pass (cf. test_full_chain_through_effect)
+        lim = (0.02 if dm == "denoised" else 0.01) * (fi + 1) + 0.005
+        assert_close(name + " chain temporal1 f%d" % fi, r.tex[abi.TEX_TEMPORAL1], g[k + "temporal1"], lim)
+        assert_close(name + " chain final f%d" % fi, r.tex[abi.TEX_FINAL], g[k + "final"], lim)
