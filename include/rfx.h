@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 4
+#define RFX_ABI_VERSION 5
 
 enum {
     RFX_OK = 0,
@@ -94,10 +94,12 @@ typedef struct rfx_ssgi_params {
     int32_t mode;             /* #define mode: 0 = MODE_SSGI (two packed vec4 of halfs), 1 = MODE_SSR (raw vec4: specular GI, packHalf2x16(rayLength, roughness)) */
     int32_t useDirectLight;   /* #define useDirectLight */
     int32_t missedRays;       /* #define missedRays   */
-    int32_t importanceSampling; /* needs an env map: must be 0 (SURVEY.md §8f "next") */
+    int32_t importanceSampling; /* #define importanceSampling (env-map MIS): not built, must be 0 */
+    int32_t useEnvMap;        /* #define USE_ENVMAP: the context holds scene.environment (rfx_set_environment); missed rays and
+                                 the screen-border fade take its colour instead of black (getEnvColor, ssgi.frag:311-346)   */
     float rayDistance;        /* uniform rayDistance = options.distance */
     float thickness;
-    float envBlur;            /* env only; accepted, unused without USE_ENVMAP */
+    float envBlur;            /* uniform envBlur: mip = envBlur * maxEnvMapMipLevel (ssgi.frag:322); unused without USE_ENVMAP */
     int32_t blueNoiseIndex;   /* uniform blueNoiseIndex (BlueNoiseUtils.js:24-32 recurrence, host side) */
     int32_t historySource;    /* uniform accumulatedTexture = ssgiEffect.denoiser.texture (SSGIPass.js:89, Denoiser.js:67-78):
                                  0  denoiseMode "full" / "full_temporal": K4's output, RFX_TEX_COMPOSE;
@@ -191,6 +193,20 @@ int rfx_clear(rfx_ctx *, rfx_tex id); /* zero-fill (render targets start zeroed)
 void *rfx_tex_device_ptr(rfx_ctx *, rfx_tex id);
 /* Use caller-owned device memory (held-rows x width x texel bytes) for a slot. */
 int rfx_bind_external(rfx_ctx *, rfx_tex id, void *device_ptr);
+
+/* ---- scene.environment (SSGIEffect.keepEnvMapUpdated, SSGIEffect.js:309-362): an equirectangular HDR map.  The effect
+ * turns its mipmaps on (`generateMipmaps`, LinearMipMapLinearFilter / LinearFilter, :323-328) and K1 samples it with
+ * textureLod(map, equirectDirectionToUv(dir), envBlur * maxEnvMapMipLevel).  rfx_set_environment takes the base level as
+ * width x height RGBA float32 texels (row 0 = bottom, v = 0), rounds them to half precision when the texture's type is
+ * HalfFloatType (`halfFloatType`, what RGBELoader produces), and builds the mip chain the way glGenerateMipmap does on
+ * the oracle's GL: every level the 2x2 bilinear-centre average of the one above, lerp(.5, lerp(.5,a,b), lerp(.5,c,d)), stored
+ * in the texture's type (half: `halfStoreRTZ` 1 truncates like llvmpipe, 0 rounds to nearest even).  width and height must
+ * be powers of two (wrap: ClampToEdge, three's default for a DataTexture).  maxEnvMapMipLevel = floor(log2(max(w,h))) + 1
+ * (src/ssgi/utils/Utils.js:30-34).  rfx_set_environment(ctx, NULL, 0, 0, 0, 0) removes it. */
+int rfx_set_environment(rfx_ctx *, const float *rgba, int width, int height, int halfFloatType, int halfStoreRTZ);
+/* Read mip level `level` of the environment back (max(w>>level,1) x max(h>>level,1) RGBA float32); *levels (may be NULL) receives the
+ * number of levels.  For inspection and for checking the chain against the driver's. */
+int rfx_download_environment(rfx_ctx *, int level, float *rgba, int *levels);
 
 /* ---- the four draws (+ the framebuffer copy and the effect's own fragment) */
 int rfx_ssgi_march(rfx_ctx *, const rfx_ssgi_params *);

@@ -93,7 +93,7 @@ def _with_blue_noise(src: str) -> str:
     return src.replace("uniform vec2 resolution;", "uniform vec2 resolution;\n" + _rd("utils/shader/blue_noise.glsl"), 1)
 
 
-def assemble_ssgi(steps=20, refine_steps=5, mode=0, use_direct_light=True, missed_rays=False) -> str:
+def assemble_ssgi(steps=20, refine_steps=5, mode=0, use_direct_light=True, missed_rays=False, use_envmap=False) -> str:
     """SSGIMaterial.js:44-56 + SSGIPass.js:38-40 + SSGIEffect.js:143-151,203-221."""
     gb = _rd("gbuffer/shader/gbuffer_packing.glsl")
     s = (_rd("ssgi/shader/ssgi.frag").replace("#include <ssgi_utils>", _rd("ssgi/shader/ssgi_utils.frag"))
@@ -105,6 +105,8 @@ def assemble_ssgi(steps=20, refine_steps=5, mode=0, use_direct_light=True, misse
         d["useDirectLight"] = ""
     if missed_rays:
         d["missedRays"] = ""
+    if use_envmap:  # SSGIEffect.js:344 (importanceSampling stays off: the MIS path is not built)
+        d["USE_ENVMAP"] = ""
     return three_prefix(d, False) + s
 
 
@@ -230,7 +232,7 @@ def write_assembled(outdir: str, **kw):
                       ("temporal", assemble_temporal()), ("denoise", assemble_denoise()), ("compose", assemble_compose()),
                       ("ssgi_ssr_20_5", assemble_ssgi(20, 5, 1)), ("temporal_ssr", assemble_temporal(texture_count=1, input_type=2, reproject_specular=True, neighborhood_clamp=True)),
                       ("denoise_ssr", assemble_denoise(texture_count=1, is_texture_specular=(True, True))), ("compose_ssr", assemble_compose(input_type=2)),
-                      ("temporal_traa", assemble_traa()), ("final_fog0", assemble_final(0)), ("final_fog1", assemble_final(1)),
+                      ("ssgi_env_20_5", assemble_ssgi(20, 5, use_envmap=True)), ("temporal_traa", assemble_traa()), ("final_fog0", assemble_final(0)), ("final_fog1", assemble_final(1)),
                       ("final_fog2", assemble_final(2))):
         with open(os.path.join(outdir, name + ".frag"), "w") as f:
             f.write(src)
@@ -280,6 +282,17 @@ class Tex:
     def read(self) -> np.ndarray:
         out = np.empty((self.h, self.w, 4), np.float32)
         rc = GL.lib().glref_read(self.id, out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, hex(rc)
+        return out
+
+    def generate_mipmaps(self):
+        """three: generateMipmaps + LinearMipMapLinearFilter / LinearFilter (SSGIEffect.js:323-328)"""
+        rc = GL.lib().glref_gen_mipmaps(self.id)
+        assert rc == 0, rc
+
+    def read_level(self, level) -> np.ndarray:
+        out = np.empty((max(self.h >> level, 1), max(self.w >> level, 1), 4), np.float32)
+        rc = GL.lib().glref_read_level(self.id, level, out.ctypes.data_as(ctypes.c_void_p))
         assert rc == 0, hex(rc)
         return out
 
@@ -335,6 +348,8 @@ class GLRefChain:
         self.o.update(options)
         if shader_dir is None and not os.path.isdir(REFERENCE_SRC):
             shader_dir = os.path.join(REF_OUT, "shaders")  # build products of `make -C oracle ref` (GPU box: no /root/reference)
+        self.t_env = None
+        env = self.o.pop("environment", None)  # scene.environment: (H, W, 4) float32 equirect; HalfFloatType like RGBELoader's
         ssr = self.o["mode"] == "ssr"
         self.tc = 1 if ssr else 2  # SSGIEffect.js:70-77: "ssr" -> inputType "specular", one texture
         sfx = "_ssr" if ssr else ""
@@ -344,7 +359,7 @@ class GLRefChain:
                     return f.read()
             if self.o["missedRays"]:
                 raise RuntimeError("prebuilt shaders cover missedRays=false only")
-            self.p_ssgi = Program(rd("ssgi%s_%d_%d" % (sfx, self.o["steps"], self.o["refineSteps"])))
+            self.p_ssgi = Program(rd("ssgi%s%s_%d_%d" % (sfx, "_env" if env is not None else "", self.o["steps"], self.o["refineSteps"])))
             self.p_temporal, self.p_denoise, self.p_compose = Program(rd("temporal" + sfx)), Program(rd("denoise" + sfx)), Program(rd("compose" + sfx))
         elif ssr:
             self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 1, True, self.o["missedRays"]))
@@ -352,7 +367,7 @@ class GLRefChain:
             self.p_denoise = Program(assemble_denoise(texture_count=1, is_texture_specular=(True, True)))
             self.p_compose = Program(assemble_compose(input_type=2))
         else:
-            self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 0, True, self.o["missedRays"]))
+            self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 0, True, self.o["missedRays"], use_envmap=env is not None))
             self.p_temporal = Program(assemble_temporal())
             self.p_denoise = Program(assemble_denoise())
             self.p_compose = Program(assemble_compose())
@@ -368,6 +383,10 @@ class GLRefChain:
         self.t_A = [Tex(W, H, FMT_RGBA16F, linear=True), Tex(W, H, FMT_RGBA16F, linear=True)]
         self.t_B = [Tex(W, H, FMT_RGBA16F, linear=True), Tex(W, H, FMT_RGBA16F, linear=True)]
         self.t_compose = Tex(W, H, FMT_RGBA32F)
+        if env is not None:  # SSGIEffect.keepEnvMapUpdated :309-362
+            self.env_size = (env.shape[1], env.shape[0])
+            self.t_env = Tex(env.shape[1], env.shape[0], FMT_RGBA16F, linear=True, data=np.ascontiguousarray(env, np.float32).astype(np.float16))
+            self.t_env.generate_mipmaps()
         # Denoiser.js:41-61: a denoise pass only in "full"/"denoised" (its target B then overrides K2's history), a compose pass only in "full*"
         self.dm = self.o["denoiseMode"]
         assert self.dm in ("full", "full_temporal", "denoised", "temporal")
@@ -408,7 +427,12 @@ class GLRefChain:
         p.set("rayDistance", float(o["distance"]))
         p.set("thickness", float(o["thickness"]))
         p.set("envBlur", float(o["envBlur"]))
-        p.set("maxEnvMapMipLevel", 0.0)
+        if self.t_env is not None:
+            p.sampler("envMapInfo.map", self.t_env)
+            import math
+            p.set("maxEnvMapMipLevel", float(math.floor(math.log2(max(self.env_size))) + 1))  # getMaxMipLevel, Utils.js:30-34
+        else:
+            p.set("maxEnvMapMipLevel", 0.0)
         p.set("backgroundColor", [0.0, 0.0, 0.0])
         p.set("resolution", [float(self.W), float(self.H)])
         p.set("blueNoiseSize", [128.0, 128.0])

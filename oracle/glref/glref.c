@@ -85,6 +85,7 @@ DECL(PFNGLUNIFORM3FPROC, Uniform3f);
 DECL(PFNGLUNIFORMMATRIX4FVPROC, UniformMatrix4fv);
 DECL(PFNGLACTIVETEXTUREPROC, ActiveTexture);
 DECL(PFNGLGETACTIVEUNIFORMPROC, GetActiveUniform);
+DECL(PFNGLGENERATEMIPMAPPROC, GenerateMipmap);
 static void (*pGenTextures)(GLsizei, GLuint *);
 static void (*pBindTexture)(GLenum, GLuint);
 static void (*pTexImage2D)(GLenum, GLint, GLint, GLsizei, GLsizei, GLint, GLenum, GLenum, const void *);
@@ -160,7 +161,7 @@ int glref_init(void) {
     L(BindAttribLocation); L(GenFramebuffers); L(BindFramebuffer); L(FramebufferTexture2D); L(CheckFramebufferStatus);
     L(GenVertexArrays); L(BindVertexArray); L(GenBuffers); L(BindBuffer); L(BufferData);
     L(VertexAttribPointer); L(EnableVertexAttribArray); L(DrawBuffers); L(GetUniformLocation);
-    L(Uniform1i); L(Uniform1f); L(Uniform2f); L(Uniform3f); L(UniformMatrix4fv); L(ActiveTexture); L(GetActiveUniform);
+    L(Uniform1i); L(Uniform1f); L(Uniform2f); L(Uniform3f); L(UniformMatrix4fv); L(ActiveTexture); L(GetActiveUniform); L(GenerateMipmap);
     L(GenTextures); L(BindTexture); L(TexImage2D); L(TexParameteri); L(Viewport); L(DrawArrays); L(Finish);
     L(GetError); L(GetString); L(ReadPixels); L(ReadBuffer); L(Disable); L(PixelStorei); L(DeleteTextures);
     snprintf(g_info, sizeof g_info, "%s | %s | GLSL %s", (const char *)pGetString(GL_VERSION),
@@ -274,6 +275,34 @@ int glref_tex_upload(int tex, const void *data) {
     pActiveTexture(GL_TEXTURE0 + 31);
     pBindTexture(GL_TEXTURE_2D, T->id);
     pTexImage2D(GL_TEXTURE_2D, 0, internal, T->w, T->h, 0, format, type, data);
+    return (int)pGetError();
+}
+
+/* three.js `generateMipmaps = true; minFilter = LinearMipMapLinearFilter; magFilter = LinearFilter` (SSGIEffect.js:323-328):
+ * the driver builds the chain (glGenerateMipmap), sampling is trilinear. */
+int glref_gen_mipmaps(int tex) {
+    tex_t *T = &g_tex[tex];
+    pActiveTexture(GL_TEXTURE0 + 31);
+    pBindTexture(GL_TEXTURE_2D, T->id);
+    pTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_LINEAR_MIPMAP_LINEAR);
+    pTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
+    pGenerateMipmap(GL_TEXTURE_2D);
+    return (int)pGetError();
+}
+
+/* Read mip level `level` of a texture as RGBA float32 (max(w>>level,1) * max(h>>level,1) * 4 floats). */
+int glref_read_level(int tex, int level, float *out) {
+    tex_t *T = &g_tex[tex];
+    int w = T->w >> level, h = T->h >> level;
+    if (w < 1) w = 1;
+    if (h < 1) h = 1;
+    pBindFramebuffer(GL_FRAMEBUFFER, g_rfbo);
+    pFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, T->id, level);
+    pReadBuffer(GL_COLOR_ATTACHMENT0);
+    GLenum st = pCheckFramebufferStatus(GL_FRAMEBUFFER);
+    if (st != GL_FRAMEBUFFER_COMPLETE) return -(int)st;
+    pReadPixels(0, 0, w, h, GL_RGBA, GL_FLOAT, out);
+    pFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, T->id, 0);
     return (int)pGetError();
 }
 

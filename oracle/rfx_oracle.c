@@ -350,6 +350,7 @@ typedef struct {
     const float *depth; const uint32_t *gbuffer; const float *direct; const float *history; const uint8_t *blue;
     const rfx_ssgi_params *p;
     float nearMulFar, farMinusNear, cameraFar;
+    const float *env; int env_w, env_h, env_levels; /* scene.environment: the whole mip chain, RGBA float32, level l after level l-1 */
 } k1_ctx;
 
 static inline float k1_view_z(const k1_ctx *c, float depth) { /* getViewZ ssgi_utils.frag:7-13 (PERSPECTIVE_CAMERA) */
@@ -398,7 +399,47 @@ static inline float smoothstepf(float e0, float e1, float x) {
     float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
     return t * t * (3.0f - 2.0f * t);
 }
-/* doSample ssgi.frag:362-439 (no env map: getEnvColor == vec3(0)) */
+/* ---- scene.environment (USE_ENVMAP) */
+static inline const float *env_level(const k1_ctx *c, int level, int *w, int *h) {
+    const float *t = c->env;
+    int lw = c->env_w, lh = c->env_h;
+    for (int l = 0; l < level; l++) { t += 4 * (size_t)lw * lh; lw = lw > 1 ? lw >> 1 : 1; lh = lh > 1 ? lh >> 1 : 1; }
+    *w = lw; *h = lh;
+    return t;
+}
+/* GLSL acos as the oracle GL's compiler (Mesa) evaluates it: pi/2 - asin polynomial (measured against llvmpipe: 2.4e-7) */
+static inline float mesa_acos(float x) {
+    float ax = fabsf(x);
+    float r = 1.5707963267948966f - sqrtf(1.0f - ax) * (1.5707963267948966f + ax * (-0.21460183660255172f + ax * (0.08132463f + ax * -0.02363318f)));
+    return 1.5707963267948966f - (x < 0.0f ? -r : r);
+}
+/* getEnvColor ssgi.frag:311-346 (no BOX_PROJECTED_ENV_MAP; isEnvSample is false without MIS): textureLod on a LinearMipMapLinear
+ * texture = two CLAMP_TO_EDGE bilinear taps blended by fract(lod), lod clamped to the chain (measured on llvmpipe) */
+static v3 k1_env_color(const k1_ctx *c, v3 l, float roughness, int isDiffuseSample) {
+    if (!c->p->useEnvMap) return V3(0, 0, 0);
+    v3 dir = normalize3(v4_mul_mat_xyz(c->p->camera.matrixWorldInverse, l, 0.0f)); /* (vec4(l, 0.) * viewMatrix).xyz :315 */
+    float maxMip = 0.0f;
+    { int m = c->env_w > c->env_h ? c->env_w : c->env_h, lg = 0; while ((m >> (lg + 1)) > 0) lg++; maxMip = (float)(lg + 1); } /* Utils.js:30-34 */
+    float mip = c->p->envBlur * maxMip;
+    if (!isDiffuseSample && roughness < 0.15f) mip *= roughness / 0.15f;
+    /* equirectDirectionToUv ssgi_utils.frag:64-74 */
+    float u = atan2f(dir.z, dir.x) / (2.0f * M_PIf), v = mesa_acos(dir.y) / M_PIf;
+    u += 0.5f; v = 1.0f - v;
+    float lod = fminf(fmaxf(mip, 0.0f), (float)(c->env_levels - 1));
+    float fl = floorf(lod);
+    int l0 = (int)fl, l1 = l0 + 1 > c->env_levels - 1 ? c->env_levels - 1 : l0 + 1;
+    int w0, h0, w1, h1;
+    const float *t0 = env_level(c, l0, &w0, &h0), *t1 = env_level(c, l1, &w1, &h1);
+    dims d0 = {w0, h0}, d1 = {w1, h1};
+    v4 c0 = fetch_f4_linear(t0, d0, u, v), c1 = fetch_f4_linear(t1, d1, u, v);
+    float f = lod - fl;
+    v3 col = V3(lerpf(f, c0.x, c1.x), lerpf(f, c0.y, c1.y), lerpf(f, c0.z, c1.z));
+    const float maxEnvLum = 25.0f; /* :330-340 */
+    float envLum = lum(col);
+    if (envLum > maxEnvLum) col = mul3(col, maxEnvLum / envLum);
+    return col;
+}
+/* doSample ssgi.frag:362-439 */
 static v3 k1_do_sample(const k1_ctx *c, const material *mat, v3 viewPos, v3 viewNormal, float metalness, float roughness,
                        int isDiffuseSample, float NoV, float NoL, float NoH, float LoH, float VoH, v4 random,
                        v3 *l, v3 *hitPos, float *brdf, float *pdf) {
@@ -419,7 +460,7 @@ static v3 k1_do_sample(const k1_ctx *c, const material *mat, v3 viewPos, v3 view
     k1_ray_march(c, l, hitPos, random.z, &cu, &cv);
     int allowMissed = c->p->missedRays != 0;
     int isMissed = hitPos->x == 10.0e9f;
-    v3 env = V3(0, 0, 0);
+    v3 env = k1_env_color(c, *l, roughness, isDiffuseSample); /* black without an env map (:342-345) */
     if (isMissed && !allowMissed) return env;
     /* velocityTexture is never wired (SSGIPass.js:89) -> three's empty texture -> velocity = 0 */
     float ru = cu - 0.0f, rv = cv - 0.0f;
@@ -558,10 +599,39 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
     }
 }
 
+/* The mip chain of scene.environment as glGenerateMipmap builds it on the oracle's GL (measured on llvmpipe): level 0 = the texels in the
+ * texture's type, every further level the 2x2 bilinear-centre average lerp(.5, lerp(.5,a,b), lerp(.5,c,d)) stored in that type
+ * (half: RTZ when `rtz`, as llvmpipe).  `out` receives all levels back to back; returns the number of levels. */
+int rfxo_env_build(const float *base, int w, int h, int half, int rtz, float *out) {
+    if (w < 1 || h < 1 || (w & (w - 1)) || (h & (h - 1))) return RFX_EINVAL;
+    for (size_t i = 0; i < (size_t)w * h * 4; i++) out[i] = half ? half_to_float(float_to_half_rne(base[i])) : base[i];
+    int levels = 1;
+    const float *src = out;
+    while (w > 1 || h > 1) {
+        int dw = w > 1 ? w >> 1 : 1, dh = h > 1 ? h >> 1 : 1, fx = w > dw ? 2 : 1, fy = h > dh ? 2 : 1;
+        float *dst = (float *)src + 4 * (size_t)w * h;
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++) {
+                int x0 = x * fx, x1 = x0 + fx - 1, y0 = y * fy, y1 = y0 + fy - 1;
+                for (int k = 0; k < 4; k++) {
+                    float a = src[4 * ((size_t)y0 * w + x0) + k], b = src[4 * ((size_t)y0 * w + x1) + k];
+                    float cc = src[4 * ((size_t)y1 * w + x0) + k], e = src[4 * ((size_t)y1 * w + x1) + k];
+                    float o = lerpf(0.5f, lerpf(0.5f, a, b), lerpf(0.5f, cc, e));
+                    if (half) o = half_to_float(rtz ? float_to_half_rtz(o) : float_to_half_rne(o));
+                    dst[4 * ((size_t)y * dw + x) + k] = o;
+                }
+            }
+        src = dst; w = dw; h = dh; levels++;
+    }
+    return levels;
+}
+
+/* env: the chain rfxo_env_build made (NULL without USE_ENVMAP) */
 int rfxo_ssgi(int W, int H, int y0, int y1, const float *depth, const uint32_t *gbuffer, const float *direct, const float *history,
-              const uint8_t *blue, const rfx_ssgi_params *p, uint32_t *out) {
+              const uint8_t *blue, const rfx_ssgi_params *p, uint32_t *out, const float *env, int env_w, int env_h, int env_levels) {
     if ((p->mode != 0 && p->mode != 1) || p->importanceSampling) return RFX_EUNSUPPORTED;
-    k1_ctx c = {W, H, depth, gbuffer, direct, history, blue, p, 0, 0, 0};
+    if (p->useEnvMap && !env) return RFX_ESTATE;
+    k1_ctx c = {W, H, depth, gbuffer, direct, history, blue, p, 0, 0, 0, env, env_w, env_h, env_levels};
     /* SSGIPass.js:84-87: JS doubles rounded to float uniforms */
     c.nearMulFar = (float)((double)p->camera.near_ * (double)p->camera.far_);
     c.farMinusNear = (float)((double)p->camera.far_ - (double)p->camera.near_);

@@ -51,13 +51,38 @@ def _chk(a, dtype, shape=None):
     return a
 
 
-def ssgi(depth, gbuffer, direct, history, blue, params: abi.SsgiParams, out=None, rows=None):
+class EnvMap:
+    """scene.environment with its mip chain as glGenerateMipmap builds it on the oracle's GL (rfxo_env_build)."""
+
+    def __init__(self, base, half=True, rtz=True):
+        base = np.ascontiguousarray(base, np.float32)
+        self.h, self.w = base.shape[:2]
+        n, w, h = 0, self.w, self.h
+        while True:
+            n += w * h
+            if w == 1 and h == 1:
+                break
+            w, h = max(w >> 1, 1), max(h >> 1, 1)
+        self.chain = np.zeros(n * 4, np.float32)
+        self.levels = lib().rfxo_env_build(_p(base), self.w, self.h, int(half), int(rtz), _p(self.chain))
+        assert self.levels > 0, self.levels
+
+    def level(self, l):
+        off, w, h = 0, self.w, self.h
+        for _ in range(l):
+            off += w * h * 4
+            w, h = max(w >> 1, 1), max(h >> 1, 1)
+        return self.chain[off:off + w * h * 4].reshape(h, w, 4)
+
+
+def ssgi(depth, gbuffer, direct, history, blue, params: abi.SsgiParams, out=None, rows=None, env: "EnvMap | None" = None):
     H, W = depth.shape
     y0, y1 = rows or (0, H)
     if out is None:
         out = np.zeros((H, W, 4), np.uint32)
     rc = lib().rfxo_ssgi(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gbuffer, np.uint32, (H, W, 4))), _p(_chk(direct, np.float32, (H, W, 4))),
-                         _p(_chk(history, np.float32, (H, W, 4))), _p(_chk(blue, np.uint8)), C.byref(params), _p(out))
+                         _p(_chk(history, np.float32, (H, W, 4))), _p(_chk(blue, np.uint8)), C.byref(params), _p(out),
+                         _p(env.chain) if env is not None else None, env.w if env else 0, env.h if env else 0, env.levels if env else 0)
     assert rc == 0, rc
     return out
 

@@ -215,36 +215,83 @@ RFX_DEV float k1_brdf_over_pdf_parts(const Material &mat, float3 viewNormal, flo
     pdf = fmaxf(0.00001f, pdf);
     return brdf;
 }
+// ---- scene.environment (USE_ENVMAP).  One CLAMP_TO_EDGE bilinear tap of a mip level, as the oracle's sampler computes it
+RFX_DEV float3 k1_env_level(const K1Args &A, int level, float u, float v) {
+    const int w = max(A.env_w >> level, 1), h = max(A.env_h >> level, 1);
+    const float4 *t = A.env + A.env_off[level];
+    int x0, x1, y0, y1;
+    float wx, wy;
+    rfx_linear_coord(u, (float)w, w, x0, x1, wx);
+    rfx_linear_coord(v, (float)h, h, y0, y1, wy);
+    const float4 t00 = t[y0 * w + x0], t10 = t[y0 * w + x1], t01 = t[y1 * w + x0], t11 = t[y1 * w + x1];
+    return make_float3(rfx_lerp(wy, rfx_lerp(wx, t00.x, t10.x), rfx_lerp(wx, t01.x, t11.x)), rfx_lerp(wy, rfx_lerp(wx, t00.y, t10.y), rfx_lerp(wx, t01.y, t11.y)),
+                       rfx_lerp(wy, rfx_lerp(wx, t00.z, t10.z), rfx_lerp(wx, t01.z, t11.z)));
+}
+// acos as the oracle's GLSL compiler evaluates it (Mesa: pi/2 - asin polynomial, |err| <= 1.6e-4 rad) — cheaper than libm's and
+// the same function on both sides of the parity test
+RFX_DEV float k1_acos(float x) {
+    const float ax = fabsf(x);
+    const float r = 1.5707963267948966f - rfx_sqrt(1.0f - ax) * (1.5707963267948966f + ax * (-0.21460183660255172f + ax * (0.08132463f + ax * -0.02363318f)));
+    return 1.5707963267948966f - (x < 0.0f ? -r : r);
+}
+// getEnvColor ssgi.frag:311-346 (no BOX_PROJECTED_ENV_MAP, isEnvSample false without MIS): textureLod(map, equirectDirectionToUv(dir), mip)
+// with LinearMipMapLinearFilter = two bilinear taps blended by fract(lod), lod clamped to the chain
+RFX_DEV float3 k1_env_color(const K1Args &A, float3 l, float roughness, bool isDiffuseSample) {
+    const float3 dir = rfx_normalize(rfx_vec_mul_mat(A.p.camera.matrixWorldInverse, l, 0.0f));  // (vec4(l, 0.) * viewMatrix).xyz :315
+    float mip = A.p.envBlur * A.maxEnvMapMipLevel;
+    if (!isDiffuseSample && roughness < 0.15f) mip *= roughness / 0.15f;
+    // equirectDirectionToUv ssgi_utils.frag:64-74
+    float u = atan2f(dir.z, dir.x) / (2.0f * 3.1415926535897932384626433832795f), v = k1_acos(dir.y) / 3.1415926535897932384626433832795f;
+    u += 0.5f;
+    v = 1.0f - v;
+    const float lod = fminf(fmaxf(mip, 0.0f), (float)(A.env_levels - 1));
+    const float fl = floorf(lod);
+    const int l0 = (int)fl, l1 = min(l0 + 1, A.env_levels - 1);
+    const float3 c0 = k1_env_level(A, l0, u, v), c1 = k1_env_level(A, l1, u, v);
+    const float f = lod - fl;
+    float3 c = make_float3(rfx_lerp(f, c0.x, c1.x), rfx_lerp(f, c0.y, c1.y), rfx_lerp(f, c0.z, c1.z));
+    const float maxEnvLum = 25.0f, envLum = rfx_lum(c);  // :330-340
+    if (envLum > maxEnvLum) c = c * (maxEnvLum / envLum);
+    return c;
+}
+
 // ... and the shading of the marched ray: gi * brdf / pdf
-RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat, float roughness, const Ray &ray, float brdf, float pdf) {
+template <bool ENV>
+RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat, float roughness, const Ray &ray, float3 l, bool isDiffuseSample, float brdf,
+                        float pdf) {
     const bool allowMissed = A.p.missedRays != 0;
     const bool isMissed = ray.pos.x == 10.0e9f;
-    float3 ssgi = make_float3(0.f, 0.f, 0.f);
-    if (isMissed && !allowMissed) return ssgi;
-    // velocityTexture is never wired in the reference (SSGIPass.js:89) -> velocity == 0
-    const float2 coords = ray.uv;
-    const float ru = coords.x, rv = coords.y;
-    if (ru >= 0.0f && ru <= 1.0f && rv >= 0.0f && rv <= 1.0f) {
-        // accumulatedTexture: K4's output, K2's texture[0], or (denoiseMode "denoised") three's empty texture — rfx.h historySource
-        const float4 h = A.p.historySource == 2 ? make_float4(0.f, 0.f, 0.f, 0.f) : rfx_fetch_f4(A.history, d, ru, rv);
-        float3 gi = make_float3(h.x, h.y, h.z);
-        const float mx = fmaxf(fmaxf(mat.diffuse.x, mat.diffuse.y), mat.diffuse.z);
-        const float mn = fminf(fminf(mat.diffuse.x, mat.diffuse.y), mat.diffuse.z);
-        const float sat = (mx == mn) ? 0.0f : (mx - mn) / mx;  // getSaturation :348-360
-        const float L = rfx_lum(gi);
-        gi = rfx_mix(gi, make_float3(L, L, L), (1.0f - roughness) * sat * 0.4f);
-        const float border = 0.15f;
-        float bf = k1_smoothstep(0.0f, border, coords.x) * k1_smoothstep(1.0f, 1.0f - border, coords.x) * k1_smoothstep(0.0f, border, coords.y) *
-                   k1_smoothstep(1.0f, 1.0f - border, coords.y);
-        bf = rfx_sqrt(bf);
-        ssgi = rfx_mix(make_float3(0.f, 0.f, 0.f), gi, bf);
-        if (allowMissed && 0.0f > rfx_lum(ssgi)) ssgi = make_float3(0.f, 0.f, 0.f);  // :430-436 with envMapSample == 0
+    // without an env map getEnvColor is black (:342-345)
+    float3 env = make_float3(0.f, 0.f, 0.f);
+    if (ENV) env = k1_env_color(A, l, roughness, isDiffuseSample);
+    float3 ssgi = env;
+    if (!(isMissed && !allowMissed)) {  // :393-395 a missed ray takes the environment
+        // velocityTexture is never wired in the reference (SSGIPass.js:89) -> velocity == 0
+        const float2 coords = ray.uv;
+        const float ru = coords.x, rv = coords.y;
+        if (ru >= 0.0f && ru <= 1.0f && rv >= 0.0f && rv <= 1.0f) {
+            // accumulatedTexture: K4's output, K2's texture[0], or (denoiseMode "denoised") three's empty texture — rfx.h historySource
+            const float4 h = A.p.historySource == 2 ? make_float4(0.f, 0.f, 0.f, 0.f) : rfx_fetch_f4(A.history, d, ru, rv);
+            float3 gi = make_float3(h.x, h.y, h.z);
+            const float mx = fmaxf(fmaxf(mat.diffuse.x, mat.diffuse.y), mat.diffuse.z);
+            const float mn = fminf(fminf(mat.diffuse.x, mat.diffuse.y), mat.diffuse.z);
+            const float sat = (mx == mn) ? 0.0f : (mx - mn) / mx;  // getSaturation :348-360
+            const float L = rfx_lum(gi);
+            gi = rfx_mix(gi, make_float3(L, L, L), (1.0f - roughness) * sat * 0.4f);
+            const float border = 0.15f;
+            float bf = k1_smoothstep(0.0f, border, coords.x) * k1_smoothstep(1.0f, 1.0f - border, coords.x) * k1_smoothstep(0.0f, border, coords.y) *
+                       k1_smoothstep(1.0f, 1.0f - border, coords.y);
+            bf = rfx_sqrt(bf);
+            ssgi = rfx_mix(env, gi, bf);  // :424
+            if (allowMissed && 0.0f > rfx_lum(ssgi)) ssgi = make_float3(0.f, 0.f, 0.f);  // :430-436: `envMapSample` is never assigned -> 0
+        }
+        // else :425-427 the reprojected coordinates left the screen: the environment
     }
     ssgi = ssgi * brdf;
     return make_float3(ssgi.x / pdf, ssgi.y / pdf, ssgi.z / pdf);
 }
 
-template <bool PERSP>
+template <bool PERSP, bool ENV>
 RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     // XCD-aware mapping: hardware block b runs on XCD b % 8 (observed, used for speed only); give XCD k the k-th
     // contiguous eighth of the row-major tile list, i.e. an image band, so its L2 sees a compact part of the depth plane
@@ -325,12 +372,14 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
         dl = make_float3(t.x, t.y, t.z);
     }
     Ray rays[2];
+    float3 diffuseRayDir = make_float3(0.f, 0.f, 0.f);
     float brdfD = 0.f, pdfD = 1.f, brdfS, pdfS;
     rays[0].active = isDiffuseSample;
     rays[0].pos = viewPos;
     rays[0].dir = make_float3(0.f, 0.f, 0.f);
     if (isDiffuseSample) {  // :222-242
         const float3 diffuseRay = rfx_cosine_sample_hemisphere(viewNormal, rnd.x, rnd.y);
+        diffuseRayDir = diffuseRay;
         const Angles ad = k1_angles(diffuseRay, vv, n);
         brdfD = k1_brdf_over_pdf_parts(mat, viewNormal, roughnessSq, true, NoV, ad, diffuseRay, pdfD);
         rays[0].dir = diffuseRay;
@@ -344,8 +393,8 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     k1_march_rays<PERSP>(m, d, rays, rnd.z);
 
     float3 diffuseGI = make_float3(-1.0f, -1.0f, -1.0f);  // "not sampled this frame" marker :277-278
-    if (isDiffuseSample) diffuseGI = k1_shade(d, A, mat, roughnessSq, rays[0], brdfD, pdfD) + dl;
-    const float3 specularGI = k1_shade(d, A, mat, roughnessSq, rays[1], brdfS, pdfS) + dl;
+    if (isDiffuseSample) diffuseGI = k1_shade<ENV>(d, A, mat, roughnessSq, rays[0], diffuseRayDir, true, brdfD, pdfD) + dl;
+    const float3 specularGI = k1_shade<ENV>(d, A, mat, roughnessSq, rays[1], specularRay, isDiffuseSample, brdfS, pdfS) + dl;
     const float3 hitPos = rays[1].pos;
 
     float rayLength = 0.0f;  // :284-296
@@ -361,11 +410,11 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     }
 }
 
-template <bool PERSP>
+template <bool PERSP, bool ENV>
 __global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-    k1_ssgi_march_body<PERSP>(A, d);
+    k1_ssgi_march_body<PERSP, ENV>(A, d);
     rfx_flush_violations(d);
 }
 
@@ -404,7 +453,34 @@ __global__ __launch_bounds__(512) void k1_prepare(const float *depth, float *vie
     }
 }
 
+// scene.environment mip chain: dst texel = bilinear centre of the 2x2 (2x1, 1x2) source block, lerp(.5, lerp(.5,a,b), lerp(.5,c,d)), stored
+// in the texture's type.  dw == sw && dh == sh is the level-0 "upload" (type conversion only).
+__global__ __launch_bounds__(256) void k1_env_mip(const float4 *src, float4 *dst, int sw, int sh, int dw, int dh, int to_half, int rtz) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    float4 o;
+    if (dw == sw && dh == sh) {
+        o = src[(size_t)y * sw + x];
+    } else {
+        const int fx = sw > dw ? 2 : 1, fy = sh > dh ? 2 : 1;
+        const int x0 = x * fx, x1 = min(x0 + fx - 1, sw - 1), y0 = y * fy, y1 = min(y0 + fy - 1, sh - 1);
+        const float4 a = src[(size_t)y0 * sw + x0], b = src[(size_t)y0 * sw + x1], c = src[(size_t)y1 * sw + x0], e = src[(size_t)y1 * sw + x1];
+        o.x = rfx_lerp(0.5f, rfx_lerp(0.5f, a.x, b.x), rfx_lerp(0.5f, c.x, e.x));
+        o.y = rfx_lerp(0.5f, rfx_lerp(0.5f, a.y, b.y), rfx_lerp(0.5f, c.y, e.y));
+        o.z = rfx_lerp(0.5f, rfx_lerp(0.5f, a.z, b.z), rfx_lerp(0.5f, c.z, e.z));
+        o.w = rfx_lerp(0.5f, rfx_lerp(0.5f, a.w, b.w), rfx_lerp(0.5f, c.w, e.w));
+    }
+    if (to_half) o = rfx_round_half4(o, rtz != 0);
+    dst[(size_t)y * dw + x] = o;
+}
+
 }  // namespace
+
+hipError_t rfx_launch_env_mip(const float4 *src, float4 *dst, int sw, int sh, int dw, int dh, bool to_half, bool rtz, hipStream_t stream) {
+    dim3 block(64, 4), grid((dw + 63) / 64, (dh + 3) / 4);
+    hipLaunchKernelGGL(k1_env_mip, grid, block, 0, stream, src, dst, sw, sh, dw, dh, to_half ? 1 : 0, rtz ? 1 : 0);
+    return hipGetLastError();
+}
 
 hipError_t rfx_launch_k1_prepare(const K1Args &A, hipStream_t stream) {
     dim3 block(64, 8), grid((A.dims.W + 63) / 64, (A.dims.H + 7) / 8);
@@ -420,7 +496,10 @@ hipError_t rfx_launch_k1(const K1Args &A, hipStream_t stream) {
     const float *P = A.p.camera.projectionMatrix;
     const bool persp = P[1] == 0.f && P[2] == 0.f && P[3] == 0.f && P[4] == 0.f && P[6] == 0.f && P[7] == 0.f && P[12] == 0.f && P[13] == 0.f &&
                        P[15] == 0.f && P[11] == -1.f;
-    if (persp) hipLaunchKernelGGL(k1_ssgi_march<true>, grid, block, 0, stream, A);
-    else hipLaunchKernelGGL(k1_ssgi_march<false>, grid, block, 0, stream, A);
+    const bool env = A.p.useEnvMap != 0;
+    if (persp && !env) hipLaunchKernelGGL((k1_ssgi_march<true, false>), grid, block, 0, stream, A);
+    else if (persp) hipLaunchKernelGGL((k1_ssgi_march<true, true>), grid, block, 0, stream, A);
+    else if (!env) hipLaunchKernelGGL((k1_ssgi_march<false, false>), grid, block, 0, stream, A);
+    else hipLaunchKernelGGL((k1_ssgi_march<false, true>), grid, block, 0, stream, A);
     return hipGetLastError();
 }

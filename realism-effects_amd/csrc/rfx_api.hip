@@ -25,6 +25,9 @@ struct rfx_ctx {
     unsigned int *halo_violations = nullptr;
     float *viewz = nullptr;    // K1 scratch: view-space Z plane (full frame)
     float2 *coarse = nullptr;  // K1 scratch: (min,max) view Z per 8x8 cell
+    float4 *env = nullptr;     // scene.environment: the whole mip chain, float4 texels
+    int env_w = 0, env_h = 0, env_levels = 0;
+    unsigned int env_off[16] = {0};
     Slot slots[RFX_TEX_COUNT];
     std::string err;
 };
@@ -107,6 +110,7 @@ void rfx_destroy(rfx_ctx *c) {
     if (c->halo_violations) hipFree(c->halo_violations);
     if (c->viewz) hipFree(c->viewz);
     if (c->coarse) hipFree(c->coarse);
+    if (c->env) hipFree(c->env);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -256,10 +260,66 @@ static void launch_rows(rfx_ctx *c, int out_id, int extra, int *y0, int *y1) {
     *y0 = a; *y1 = b;
 }
 
+int rfx_set_environment(rfx_ctx *c, const float *rgba, int width, int height, int halfFloatType, int halfStoreRTZ) {
+    if (!c) return RFX_EINVAL;
+    hipSetDevice(c->device);
+    if (!rgba) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->env) hipFree(c->env);
+        c->env = nullptr; c->env_w = c->env_h = c->env_levels = 0;
+        return RFX_OK;
+    }
+    if (width < 1 || height < 1 || width > 16384 || height > 16384 || (width & (width - 1)) || (height & (height - 1)))
+        return fail(c, RFX_EINVAL, "rfx_set_environment: width and height must be powers of two <= 16384");
+    int levels = 0;
+    size_t total = 0;
+    unsigned int off[16];
+    for (int w = width, h = height;; w = w > 1 ? w >> 1 : 1, h = h > 1 ? h >> 1 : 1) {
+        off[levels++] = (unsigned int)total;
+        total += (size_t)w * h;
+        if (w == 1 && h == 1) break;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->env) hipFree(c->env);
+    c->env = nullptr;
+    hipError_t e = hipMalloc((void **)&c->env, total * sizeof(float4));
+    if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(environment)", e);
+    // staging copy of the base level, then level 0 = the texels in the texture's type, then the chain
+    float4 *stage = nullptr;
+    e = hipMalloc((void **)&stage, (size_t)width * height * sizeof(float4));
+    if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(environment staging)", e);
+    HIPCHK(c, hipMemcpyAsync(stage, rgba, (size_t)width * height * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    // level 0: same size "reduction" = a copy through the type conversion (RNE: the upload of a float image into a half texture)
+    HIPCHK(c, rfx_launch_env_mip(stage, c->env, width, height, width, height, halfFloatType != 0, false, c->stream));
+    for (int l = 1, w = width, h = height; l < levels; l++) {
+        const int dw = w > 1 ? w >> 1 : 1, dh = h > 1 ? h >> 1 : 1;
+        HIPCHK(c, rfx_launch_env_mip(c->env + off[l - 1], c->env + off[l], w, h, dw, dh, halfFloatType != 0, halfStoreRTZ != 0, c->stream));
+        w = dw; h = dh;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller may free `rgba` as soon as we return
+    hipFree(stage);
+    c->env_w = width; c->env_h = height; c->env_levels = levels;
+    memcpy(c->env_off, off, sizeof off);
+    return RFX_OK;
+}
+
+int rfx_download_environment(rfx_ctx *c, int level, float *rgba, int *levels) {
+    if (!c) return RFX_EINVAL;
+    if (levels) *levels = c->env_levels;
+    if (!rgba) return RFX_OK;
+    if (!c->env || level < 0 || level >= c->env_levels) return fail(c, RFX_EINVAL, "rfx_download_environment: no such level");
+    const int w = (c->env_w >> level) > 0 ? c->env_w >> level : 1, h = (c->env_h >> level) > 0 ? c->env_h >> level : 1;
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(rgba, c->env + c->env_off[level], (size_t)w * h * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RFX_OK;
+}
+
 int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
     if (!c || !p) return RFX_EINVAL;
     if (p->mode != 0 && p->mode != 1) return fail(c, RFX_EINVAL, "rfx_ssgi_march: mode must be 0 (MODE_SSGI) or 1 (MODE_SSR)");
-    if (p->importanceSampling) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: importanceSampling needs an env map (not built)");
+    if (p->importanceSampling) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: importanceSampling (env-map MIS) is not built");
+    if (p->useEnvMap && !c->env) return fail(c, RFX_ESTATE, "rfx_ssgi_march: useEnvMap without rfx_set_environment");
     if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: only PERSPECTIVE_CAMERA is built");
     if (p->steps < 1 || p->refineSteps < 0) return fail(c, RFX_EINVAL, "rfx_ssgi_march: steps/refineSteps");
     hipSetDevice(c->device);
@@ -299,6 +359,14 @@ int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
     // band-per-XCD mapping measured SLOWER (1.33 vs 0.99 ms at 4K): sky bands finish early and idle their XCD
     static const int xcd = getenv("RFX_K1_XCD") ? atoi(getenv("RFX_K1_XCD")) : 0;
     A.xcd_map = xcd;
+    A.env = c->env;
+    A.env_w = c->env_w; A.env_h = c->env_h; A.env_levels = c->env_levels;
+    memcpy(A.env_off, c->env_off, sizeof A.env_off);
+    {   // getMaxMipLevel (src/ssgi/utils/Utils.js:30-34): floor(log2(max(w, h))) + 1
+        int m = c->env_w > c->env_h ? c->env_w : c->env_h, lg = 0;
+        while ((m >> (lg + 1)) > 0) lg++;
+        A.maxEnvMapMipLevel = c->env ? (float)(lg + 1) : 0.0f;
+    }
     // the pre-pass runs on EVERY draw: the depth plane is an input that changes every frame
     HIPCHK(c, rfx_launch_k1_prepare(A, c->stream));
     HIPCHK(c, rfx_launch_k1(A, c->stream));

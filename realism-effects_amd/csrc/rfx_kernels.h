@@ -20,7 +20,15 @@ struct K1Args {
     int coarse_w, coarse_h;
     int use_coarse;
     int xcd_map;  // band-per-XCD block mapping (development switch RFX_K1_NO_XCD=1 turns it off)
+    // scene.environment: all mip levels as float4 texels, level l (max(w>>l,1) x max(h>>l,1)) at env + env_off[l]
+    const float4 *env;
+    int env_w, env_h, env_levels;
+    unsigned int env_off[16];
+    float maxEnvMapMipLevel;
 };
+
+// one level of the environment's mip chain from the one above (glGenerateMipmap on the oracle's GL: 2x2 bilinear centre)
+hipError_t rfx_launch_env_mip(const float4 *src, float4 *dst, int sw, int sh, int dw, int dh, bool to_half, bool rtz, hipStream_t);
 
 struct K2Args {
     FrameDims dims;

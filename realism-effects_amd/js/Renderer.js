@@ -104,6 +104,11 @@ class Renderer {
 		addon.clear(this._h, tex)
 	}
 
+	// scene.environment: Float32Array(H*W*4) equirect map (row 0 = bottom) or null — rfx_set_environment
+	setEnvironment(data, width, height, halfFloatType, halfStoreRTZ) {
+		addon.setEnvironment(this._h, data || null, width || 0, height || 0, halfFloatType ? 1 : 0, halfStoreRTZ ? 1 : 0)
+	}
+
 	// the four draws + the framebuffer copy (include/rfx.h)
 	ssgiMarch(uniforms) {
 		addon.ssgiMarch(this._h, uniforms)

@@ -445,6 +445,7 @@ class SSGIPass {
 			useDirectLight: 0,
 			missedRays: 0,
 			importanceSampling: 0,
+			useEnvMap: 0,
 			rayDistance: 0,
 			thickness: 0,
 			envBlur: 0,
@@ -508,6 +509,7 @@ class SSGIEffect {
 		}
 		seeds = seeds || {}
 		this._options = options
+		this._halfStoreRTZ = halfStoreRTZ
 		this.ssgiPass = new SSGIPass(this, options, seeds.ssgi)
 		this.denoiser = new Denoiser(
 			scene,
@@ -620,7 +622,32 @@ class SSGIEffect {
 
 	// :372-436.  inputBuffer: the composer's input buffer (direct lighting) as a Float32Array RGBA plane, or null to
 	// take scene.frame.direct.
+	// :309-362.  scene.environment: null/undefined, or an equirectangular HDR map as dumped state — { data: Float32Array(H*W*4, row 0 =
+	// bottom), width, height, type: HalfFloatType (RGBELoader's, the default) | FloatType }.  The effect turns its mipmaps on (:323-328):
+	// here the device builds the chain (rfx_set_environment).
+	keepEnvMapUpdated(renderer) {
+		const env = this._scene.environment
+		const u = this.ssgiPass.uniforms
+		if (env) {
+			if (this._envUuid !== env) {
+				if (env.isCubeTexture) throw new Error("cube environment maps (CubeToEquirectEnvPass, :316-321) are not built: pass an equirectangular map")
+				if (this._options.importanceSampling)
+					throw new Error("importanceSampling with an environment map (env-map MIS, ssgi.frag:197-216) is not built: construct the effect with importanceSampling: false")
+				const half = env.type === undefined || env.type === null || env.type === HalfFloatType
+				renderer.setEnvironment(env.data, env.width, env.height, half, this._halfStoreRTZ === undefined || this._halfStoreRTZ)
+				this._envUuid = env
+				u.useEnvMap = 1 // defines.USE_ENVMAP :344
+				this.reset() // :356
+			}
+		} else if (u.useEnvMap) {
+			u.useEnvMap = 0 // :361-366
+			renderer.setEnvironment(null)
+			this._envUuid = null
+		}
+	}
+
 	update(renderer, inputBuffer) {
+		this.keepEnvMapUpdated(renderer)
 		const direct = inputBuffer || this._scene.frame.direct
 		renderer.uploadPlane(TEX.DIRECT_LIGHT, direct)
 		this.ssgiPass.render(renderer)

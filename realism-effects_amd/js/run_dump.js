@@ -27,6 +27,14 @@ delete opt.ssgiSeed
 delete opt.denoiseSeed
 const first = rfx.readDump(dumps[0])
 const scene = { frame: first }
+// --env <file.bin> --envWidth W --envHeight H: a raw Float32 RGBA equirect map (row 0 = bottom) as scene.environment (needs --importanceSampling false)
+if (opt.env) {
+	const b = fs.readFileSync(opt.env)
+	scene.environment = { data: new Float32Array(b.buffer, b.byteOffset, b.length / 4), width: opt.envWidth, height: opt.envHeight }
+	delete opt.env
+	delete opt.envWidth
+	delete opt.envHeight
+}
 const camera = Object.assign({}, first.camera)
 const renderer = new rfx.Renderer(first.width, first.height)
 if (opt.traa) {

@@ -206,6 +206,36 @@ static napi_value n_clear(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+/* setEnvironment(ctx, Float32Array | null, width, height, halfFloatType, halfStoreRTZ) — scene.environment (rfx_set_environment) */
+static napi_value n_set_environment(napi_env env, napi_callback_info info) {
+    napi_value a[6];
+    if (!get_args(env, info, 6, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    napi_valuetype vt;
+    napi_typeof(env, a[1], &vt);
+    int32_t w = 0, h = 0, half = 1, rtz = 1;
+    const float *data = NULL;
+    if (vt != napi_null && vt != napi_undefined) {
+        napi_typedarray_type tt;
+        size_t len;
+        void *ptr;
+        if (napi_get_typedarray_info(env, a[1], &tt, &len, &ptr, NULL, NULL) != napi_ok || tt != napi_float32_array) {
+            napi_throw_type_error(env, NULL, "setEnvironment: Float32Array or null expected");
+            return NULL;
+        }
+        if (!get_int(env, a[2], &w) || !get_int(env, a[3], &h) || !get_int(env, a[4], &half) || !get_int(env, a[5], &rtz)) return NULL;
+        if ((size_t)w * (size_t)h * 4 != len) {
+            napi_throw_range_error(env, NULL, "setEnvironment: data length != width * height * 4");
+            return NULL;
+        }
+        data = (const float *)ptr;
+    }
+    int rc = rfx_set_environment(c, data, w, h, half, rtz);
+    if (rc) return throw_rfx(env, c, "rfx_set_environment", rc);
+    return NULL;
+}
+
 /* ssgiMarch(ctx, {camera, steps, refineSteps, mode, useDirectLight, missedRays, importanceSampling,
  *                 rayDistance, thickness, envBlur, blueNoiseIndex}) */
 static napi_value n_ssgi(napi_env env, napi_callback_info info) {
@@ -222,6 +252,7 @@ static napi_value n_ssgi(napi_env env, napi_callback_info info) {
     p.useDirectLight = (int32_t)prop_num(env, a[1], "useDirectLight", 0);
     p.missedRays = (int32_t)prop_num(env, a[1], "missedRays", 0);
     p.importanceSampling = (int32_t)prop_num(env, a[1], "importanceSampling", 0);
+    p.useEnvMap = (int32_t)prop_num(env, a[1], "useEnvMap", 0);
     p.rayDistance = (float)prop_num(env, a[1], "rayDistance", 10);
     p.thickness = (float)prop_num(env, a[1], "thickness", 10);
     p.envBlur = (float)prop_num(env, a[1], "envBlur", 0.5);
@@ -390,7 +421,7 @@ static napi_value n_time_end(napi_env env, napi_callback_info info) {
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
-        {"clear", n_clear}, {"ssgiMarch", n_ssgi}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
+        {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"ssgiMarch", n_ssgi}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
         {"sync", n_sync}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

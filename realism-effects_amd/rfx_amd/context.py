@@ -109,6 +109,29 @@ class Context:
             r0, n = self.held_rows(tex)
             self.upload(tex, plane[r0:r0 + n], r0, n)
 
+    def set_environment(self, rgba, half_float_type=True, half_store_rtz=True):
+        """scene.environment: an (H, W, 4) float32 equirectangular map (row 0 = bottom), or None to remove it."""
+        if rgba is None:
+            self._chk(self.lib.rfx_set_environment(self._h, None, 0, 0, 0, 0), "rfx_set_environment")
+            return
+        a = np.ascontiguousarray(rgba, np.float32)
+        if a.ndim != 3 or a.shape[2] != 4:
+            raise ValueError("environment map must be (H, W, 4)")
+        self._chk(self.lib.rfx_set_environment(self._h, a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0], 1 if half_float_type else 0,
+                                               1 if half_store_rtz else 0), "rfx_set_environment")
+
+    def download_environment(self, level: int, size) -> np.ndarray:
+        """Mip level `level` of the environment; `size` = (width, height) of the base level."""
+        w, h = max(size[0] >> level, 1), max(size[1] >> level, 1)
+        out = np.empty((h, w, 4), np.float32)
+        self._chk(self.lib.rfx_download_environment(self._h, level, out.ctypes.data_as(C.c_void_p), None), "rfx_download_environment")
+        return out
+
+    def environment_levels(self) -> int:
+        n = C.c_int()
+        self._chk(self.lib.rfx_download_environment(self._h, 0, None, C.byref(n)), "rfx_download_environment")
+        return n.value
+
     # -- the four draws (+ the framebuffer copy)
     def ssgi_march(self, p: abi.SsgiParams):
         self._chk(self.lib.rfx_ssgi_march(self._h, C.byref(p)), "rfx_ssgi_march")

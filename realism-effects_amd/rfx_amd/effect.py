@@ -441,6 +441,7 @@ class SSGIEffect:
                 options.update(steps=20, refineSteps=4, denoiseMode="full")
         seeds = seeds or {}
         self._options = options
+        self._half_store_rtz = half_store_rtz
         self.ssgiPass = SSGIPass(self, options, seeds.get("ssgi"))
         dopt = dict(gBufferPass=self.ssgiPass.gBufferPass, velocityDepthNormalPass=options.get("velocityDepthNormalPass"))
         dopt.update(options)
@@ -526,9 +527,34 @@ class SSGIEffect:
         self.ssgiPass.dispose()
         self.denoiser.dispose()
 
+    def keepEnvMapUpdated(self, renderer):
+        """:309-362.  `scene.environment`: None, or an equirectangular HDR map as dumped state — an object/dict with `data`
+        ((H, W, 4) float32, row 0 = bottom) and optionally `type` (HalfFloatType, what RGBELoader yields and the default, or
+        FloatType).  The effect turns its mipmaps on (:323-328): here the device builds the chain (rfx_set_environment)."""
+        env = getattr(self._scene, "environment", None)
+        u = self.ssgiPass.uniforms
+        if env is not None:
+            if self.__dict__.get("_env_uuid") is not env:
+                get = (lambda k, d=None: env.get(k, d)) if isinstance(env, dict) else (lambda k, d=None: getattr(env, k, d))
+                if get("isCubeTexture"):
+                    raise NotImplementedError("cube environment maps (CubeToEquirectEnvPass, :316-321) are not built: pass an equirectangular map")
+                if self._options["importanceSampling"]:
+                    raise NotImplementedError("importanceSampling with an environment map (env-map MIS, ssgi.frag:197-216) is not built: "
+                                              "construct the effect with importanceSampling=False")
+                t = get("type", HalfFloatType)
+                renderer.set_environment(get("data"), half_float_type=(t == HalfFloatType), half_store_rtz=self._half_store_rtz)
+                object.__setattr__(self, "_env_uuid", env)
+                u.useEnvMap = 1  # defines.USE_ENVMAP :344
+                self.reset()     # :356
+        elif u.useEnvMap:  # :361-366
+            u.useEnvMap = 0
+            renderer.set_environment(None)
+            object.__setattr__(self, "_env_uuid", None)
+
     def update(self, renderer, inputBuffer=None):
         """:372-436.  `inputBuffer` = the composer's input buffer (direct lighting) as an (H,W,4)
         float32 array covering the frame, or None to take `scene.frame.direct`."""
+        self.keepEnvMapUpdated(renderer)
         direct = inputBuffer if inputBuffer is not None else self._scene.frame.direct
         _upload_plane(renderer, abi.TEX_DIRECT_LIGHT, direct)
         self.ssgiPass.render(renderer)

@@ -364,3 +364,29 @@ def synthetic_frame(width: int, height: int, frame_index: int = 0, seed: int = 1
     if _default_scene is None or _default_scene[0] != seed:
         _default_scene = (seed, AnalyticScene(seed))
     return _default_scene[1].render(width, height, frame_index, **kw)
+
+
+def synthetic_environment(width: int = 256, height: int = 128, seed: int = 1234) -> np.ndarray:
+    """A synthetic equirectangular HDR environment (`scene.environment`), (H, W, 4) float32, row 0 = bottom (v = 0 = straight
+    down): ground colour below the horizon, a sky gradient above it, a warm sun whose core exceeds the shader's luminance
+    clamp (ssgi.frag:330-340) and a few soft cloud lobes so that neighbouring texels differ at every mip level."""
+    rng = np.random.RandomState(seed)
+    v = (np.arange(height, dtype=np.float64) + 0.5) / height
+    u = (np.arange(width, dtype=np.float64) + 0.5) / width
+    phi = (1.0 - v)[:, None] * np.pi          # equirectUvToDirection, ssgi_utils.frag:77-86
+    theta = (u - 0.5)[None, :] * 2.0 * np.pi
+    d = np.stack([np.sin(phi) * np.cos(theta), np.cos(phi) * np.ones_like(theta), np.sin(phi) * np.sin(theta)], -1)
+    up = d[..., 1]
+    sky = np.array([0.25, 0.45, 0.9]) * (0.35 + 0.65 * np.clip(up, 0, 1)[..., None]) + np.array([0.9, 0.8, 0.7]) * (np.exp(-6.0 * np.abs(up))[..., None] * 0.6)
+    ground = np.array([0.18, 0.16, 0.13]) * (0.6 + 0.4 * np.clip(-up, 0, 1)[..., None])
+    img = np.where((up > 0)[..., None], sky, ground)
+    sun = np.array([0.45, 0.55, -0.7]); sun /= np.linalg.norm(sun)
+    c = np.clip((d * sun).sum(-1), -1, 1)
+    img += np.array([1.0, 0.85, 0.6]) * (60.0 * np.exp(-(1 - c) * 900.0) + 2.5 * np.exp(-(1 - c) * 25.0))[..., None]
+    for _ in range(6):
+        a = rng.normal(size=3); a[1] = abs(a[1]) + 0.2; a /= np.linalg.norm(a)
+        cc = np.clip((d * a).sum(-1), -1, 1)
+        img += np.array([0.8, 0.8, 0.85]) * (rng.uniform(0.3, 0.9) * np.exp(-(1 - cc) * rng.uniform(20, 80)))[..., None]
+    out = np.ones((height, width, 4), np.float32)
+    out[..., :3] = img.astype(np.float32)
+    return out

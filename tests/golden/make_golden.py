@@ -34,13 +34,16 @@ def cam_arrays(cam, prefix):
             ("projectionMatrix", "projectionMatrixInverse", "matrixWorld", "matrixWorldInverse", "position", "quaternion")}
 
 
-def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_start=2000, mode="ssgi", missed_rays=False, denoise_mode="full"):
+def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_start=2000, mode="ssgi", missed_rays=False, denoise_mode="full",
+        environment=None, env_blur=0.5):
     bn = np.fromfile(os.path.join(ROOT, "realism-effects_amd", "data", "blue_noise_128_rgba8.bin"), np.uint8).reshape(128, 128, 4)
     c = chain.GLRefChain(W, H, bn, steps=steps, refineSteps=refine, denoiseIterations=iterations, mode=mode, missedRays=missed_rays,
-                         denoiseMode=denoise_mode)
+                         denoiseMode=denoise_mode, environment=environment, envBlur=env_blur)
     tc = c.tc
     out = dict(width=W, height=H, frames=frames, steps=steps, refineSteps=refine, denoiseIterations=iterations, ssgi_start=ssgi_start,
                denoise_start=denoise_start, gl_info=chain.GL.info(), mode=mode, textureCount=tc, missedRays=int(missed_rays), denoiseMode=denoise_mode)
+    if environment is not None:  # scene.environment (HalfFloatType, mipmapped by the effect) + the envBlur option
+        out["environment"], out["envBlur"] = environment, env_blur
     si = di = 0
     for fi in range(frames):
         f = synthetic_frame(W, H, fi)
@@ -122,6 +125,9 @@ if __name__ == "__main__":
     run("chain_97x55_s8r2_it2", 97, 55, frames=2, steps=8, refine=2, iterations=2)
     run("chain_ssr_128x72_s20r5_it1", 128, 72, frames=2, steps=20, refine=5, iterations=1, mode="ssr")
     run("chain_missed_96x54_s12r3_it1", 96, 54, frames=2, steps=12, refine=3, iterations=1, missed_rays=True)
+    from rfx_amd.scene import synthetic_environment
+    run("chain_env_128x72_s12r3_it1", 128, 72, frames=2, steps=12, refine=3, iterations=1, environment=synthetic_environment(128, 64))
+    run("chain_envsharp_96x54_s12r3_it1", 96, 54, frames=2, steps=12, refine=3, iterations=1, environment=synthetic_environment(128, 64), env_blur=0.1)
     for dm in ("full_temporal", "temporal", "denoised"):  # the other Denoiser modes (Denoiser.js:7,41-78)
         run("chain_%s_104x58_s10r2" % dm, 104, 58, frames=3, steps=10, refine=2, iterations=1, denoise_mode=dm)
     run_traa("traa_half_128x72", 128, 72, frames=3, half=True)

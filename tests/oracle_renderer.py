@@ -56,12 +56,16 @@ class OracleRenderer:
         b0, n = self.held_rows(abi.TEX_SSGI)
         return max(b0, self.tile_y0 - extra), min(b0 + n, self.tile_y0 + self.tile_rows + extra)
 
+    def set_environment(self, rgba, half_float_type=True, half_store_rtz=True):
+        self.calls.append(("set_environment", None if rgba is None else tuple(rgba.shape)))
+        self.env = None if rgba is None else O.EnvMap(rgba, half=half_float_type, rtz=half_store_rtz)
+
     def ssgi_march(self, p):
         self.calls.append(("ssgi", p.blueNoiseIndex))
         t = self.tex
         hist = t[abi.TEX_TEMPORAL0] if p.historySource == 1 else t[abi.TEX_COMPOSE]
         O.ssgi(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[abi.TEX_DIRECT_LIGHT], hist, t[abi.TEX_BLUE_NOISE], p,
-               out=t[abi.TEX_SSGI], rows=self._rows(min(2, self.halo)))
+               out=t[abi.TEX_SSGI], rows=self._rows(min(2, self.halo)), env=getattr(self, "env", None))
 
     def temporal_reproject(self, p):
         self.calls.append(("temporal", p.keepData, p.fullAccumulate))

@@ -626,3 +626,46 @@ def test_denoise_modes_vs_oracle(dm, blue_noise):
     assert r.seen == want * NF
     assert (fx.ssgiPass.uniforms.historySource, fx.uniforms.inputSource) == {"full_temporal": (0, 0), "temporal": (1, 1), "denoised": (2, 2)}[dm]
     dev.close()
+
+
+@pytest.mark.parametrize("env_blur,half", [(0.5, True), (0.08, True), (0.3, False)])
+def test_env_map_vs_oracle(blue_noise, env_blur, half):
+    """scene.environment (USE_ENVMAP): the device-built mip chain is bit-identical to the oracle's (= glGenerateMipmap on llvmpipe), and K1
+    with the environment matches the oracle; HalfFloatType and FloatType maps, blurry and near-mirror lods."""
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_environment, synthetic_frame
+    import rfx_oracle as O
+
+    W, H = 320, 180
+    envimg = synthetic_environment(256, 128)
+    env = O.EnvMap(envimg, half=half, rtz=True)
+    ctx = Context(W, H)
+    ctx.set_environment(envimg, half_float_type=half, half_store_rtz=True)
+    assert ctx.environment_levels() == env.levels == 9
+    for l in range(env.levels):
+        assert np.array_equal(ctx.download_environment(l, (256, 128)).view(np.uint32), env.level(l).view(np.uint32)), "mip level %d" % l
+    comp = np.random.RandomState(4).rand(H, W, 4).astype(np.float32)
+    for fi in range(2):
+        f = synthetic_frame(W, H, fi)
+        sp, _, _, _ = _params(abi, f, f.camera, 1.0, 12, 3)
+        sp.useEnvMap, sp.envBlur, sp.blueNoiseIndex = 1, env_blur, 900 + fi
+        ctx.upload_frame(f)
+        ctx.upload(abi.TEX_COMPOSE, comp)
+        ctx.ssgi_march(sp)
+        g = ctx.download(abi.TEX_SSGI)
+        o = O.ssgi(f.depth, f.gbuffer, f.direct, comp, blue_noise, sp, env=env)
+        ga, gb = O.unpack_ssgi(g)
+        oa, ob = O.unpack_ssgi(o)
+        assert_close("env ssgi.diffuse f%d" % fi, ga, oa, FLIP["ssgi"])
+        assert_close("env ssgi.specular f%d" % fi, gb, ob, FLIP["ssgi"])
+        assert (g == o).all(axis=-1).mean() > 0.99
+        sp.useEnvMap = 0
+        ctx.ssgi_march(sp)
+        assert (ctx.download(abi.TEX_SSGI) != g).any(axis=-1).mean() > 0.2  # the environment contributes
+    # without an environment the define is refused, and removing it works
+    ctx.set_environment(None)
+    sp.useEnvMap = 1
+    with pytest.raises(Exception):
+        ctx.ssgi_march(sp)
+    ctx.close()

@@ -332,3 +332,66 @@ def test_denoise_modes_through_effect(name):
         lim = (0.02 if dm == "denoised" else 0.01) * (fi + 1) + 0.005
         assert_close(name + " chain temporal1 f%d" % fi, r.tex[abi.TEX_TEMPORAL1], g[k + "temporal1"], lim)
         assert_close(name + " chain final f%d" % fi, r.tex[abi.TEX_FINAL], g[k + "final"], lim)
+
+
+@pytest.mark.parametrize("name", G.GOLDEN_ENV)
+def test_env_map_stagewise(name, blue_noise):
+    """scene.environment (USE_ENVMAP, SURVEY.md §8f-1 without MIS): missed rays and the screen-border fade take the equirect map's colour,
+    sampled trilinearly at envBlur * maxEnvMapMipLevel (ssgi.frag:311-346).  The mip chain the effect asks the driver for is part of the
+    statement: rfxo_env_build is pinned bit for bit against glGenerateMipmap on llvmpipe in make_golden's harness (oracle/glref)."""
+    g = G.load(name)
+    W, H, nf = int(g["width"]), int(g["height"]), int(g["frames"])
+    env = O.EnvMap(g["environment"], half=True, rtz=True)
+    assert env.levels == int(np.log2(max(env.w, env.h))) + 1
+    for fi in range(nf):
+        f = G.frame(g, fi)
+        k, kp = "f%d_" % fi, "f%d_" % (fi - 1)
+        sp, _, _, _ = stage_params(g, fi, 0.0 if fi == 0 else 1.0)
+        sp.useEnvMap, sp.envBlur = 1, float(g["envBlur"])
+        hist = np.ascontiguousarray(g[kp + "compose"]) if fi else np.zeros((H, W, 4), np.float32)
+        o = O.ssgi(f.depth, f.gbuffer, f.direct, hist, blue_noise, sp, env=env)
+        ga, gb = O.unpack_ssgi(g[k + "ssgi"])
+        oa, ob = O.unpack_ssgi(o)
+        assert_close(name + " ssgi.diffuse f%d" % fi, oa, ga, FLIP["ssgi"])
+        assert_close(name + " ssgi.specular f%d" % fi, ob, gb, FLIP["ssgi"])
+        assert (o == g[k + "ssgi"]).all(axis=-1).mean() > 0.99
+        # the environment really contributes: the same draw without it differs on a good part of the frame
+        sp.useEnvMap = 0
+        o0 = O.ssgi(f.depth, f.gbuffer, f.direct, hist, blue_noise, sp)
+        assert (o0 != o).any(axis=-1).mean() > 0.2
+
+
+@pytest.mark.parametrize("name", G.GOLDEN_ENV)
+def test_env_map_through_effect(name):
+    """SSGIEffect.keepEnvMapUpdated on the oracle renderer: scene.environment is handed to the device once, USE_ENVMAP switches on, the
+    envBlur option reaches K1; importanceSampling (MIS) with an env map is refused, not approximated."""
+    import types
+    from oracle_renderer import OracleRenderer
+    from rfx_amd.effect import SSGIEffect
+
+    g = G.load(name)
+    W, H, nf = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene = types.SimpleNamespace(frame=None, environment=dict(data=np.ascontiguousarray(g["environment"])))
+    cam = G.camera(g, 0)
+    opts = dict(steps=int(g["steps"]), refineSteps=int(g["refineSteps"]), denoiseIterations=1, envBlur=float(g["envBlur"]), width=W, height=H)
+    with pytest.raises(NotImplementedError):
+        scene.frame = G.frame(g, 0)
+        SSGIEffect(None, scene, cam, opts).update(OracleRenderer(W, H), None)  # importanceSampling defaults to true
+    fx = SSGIEffect(None, scene, cam, dict(opts, importanceSampling=False), seeds=dict(ssgi=int(g["ssgi_start"]), denoise=int(g["denoise_start"])))
+    r = OracleRenderer(W, H)
+    for fi in range(nf):
+        scene.frame = G.frame(g, fi)
+        for kk, vv in vars(G.camera(g, fi)).items():
+            setattr(cam, kk, vv)
+        fx.update(r, None)
+        assert [c[0] for c in r.calls].count("set_environment") == (1 if fi == 0 else 0)
+        r.calls.clear()
+        k = "f%d_" % fi
+        ga, gb = O.unpack_ssgi(g[k + "ssgi"])
+        oa, ob = O.unpack_ssgi(r.tex[abi.TEX_SSGI])
+        lim = 0.03 * (fi + 1)  # frame >= 1 marches against the chain's own (flip-compounded) composed history
+        assert_close(name + " effect ssgi.diffuse f%d" % fi, oa, ga, lim)
+        assert_close(name + " effect compose f%d" % fi, r.tex[abi.TEX_COMPOSE], g[k + "compose"], lim)
+    scene.environment = None  # :361-366 the define goes away with the environment
+    fx.update(r, None)
+    assert fx.ssgiPass.uniforms.useEnvMap == 0 and r.env is None
