@@ -17,6 +17,9 @@ namespace {
 #ifndef RFX_K2_TH
 #define RFX_K2_TH 4
 #endif
+#ifndef RFX_K2_SCHED
+#define RFX_K2_SCHED 0
+#endif
 #ifndef RFX_K2_FENCE
 #define RFX_K2_FENCE 0
 #endif
@@ -234,6 +237,9 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
         if (i) asm volatile("" ::: "memory");  // keep texture 1's 20 history texels out of flight while texture 0 is reduced
 #endif
         const float4 acc = k2_bicubic<HIST_F32>(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
+#if RFX_K2_SCHED
+        __builtin_amdgcn_sched_barrier(0);  // consume the 20 history texels (40 VGPRs) before the neighbourhood's LDS texels are fetched
+#endif
         float3 accrgb = k2_to_log<LOGT>(make_float3(acc.x, acc.y, acc.z));
         float acca = acc.w;
         float3 inrgb = make_float3(inp[i].x, inp[i].y, inp[i].z);

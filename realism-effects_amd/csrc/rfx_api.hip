@@ -281,23 +281,32 @@ int rfx_set_environment(rfx_ctx *c, const float *rgba, int width, int height, in
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->env) hipFree(c->env);
-    c->env = nullptr;
+    c->env = nullptr; c->env_w = c->env_h = c->env_levels = 0;
     hipError_t e = hipMalloc((void **)&c->env, total * sizeof(float4));
     if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(environment)", e);
     // staging copy of the base level, then level 0 = the texels in the texture's type, then the chain
     float4 *stage = nullptr;
     e = hipMalloc((void **)&stage, (size_t)width * height * sizeof(float4));
-    if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(environment staging)", e);
-    HIPCHK(c, hipMemcpyAsync(stage, rgba, (size_t)width * height * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+    if (e != hipSuccess) {
+        hipFree(c->env);
+        c->env = nullptr; c->env_w = c->env_h = c->env_levels = 0;
+        return fail(c, RFX_ENOMEM, "hipMalloc(environment staging)", e);
+    }
+    e = hipMemcpyAsync(stage, rgba, (size_t)width * height * sizeof(float4), hipMemcpyHostToDevice, c->stream);
     // level 0: same size "reduction" = a copy through the type conversion (RNE: the upload of a float image into a half texture)
-    HIPCHK(c, rfx_launch_env_mip(stage, c->env, width, height, width, height, halfFloatType != 0, false, c->stream));
-    for (int l = 1, w = width, h = height; l < levels; l++) {
+    if (e == hipSuccess) e = rfx_launch_env_mip(stage, c->env, width, height, width, height, halfFloatType != 0, false, c->stream);
+    for (int l = 1, w = width, h = height; l < levels && e == hipSuccess; l++) {
         const int dw = w > 1 ? w >> 1 : 1, dh = h > 1 ? h >> 1 : 1;
-        HIPCHK(c, rfx_launch_env_mip(c->env + off[l - 1], c->env + off[l], w, h, dw, dh, halfFloatType != 0, halfStoreRTZ != 0, c->stream));
+        e = rfx_launch_env_mip(c->env + off[l - 1], c->env + off[l], w, h, dw, dh, halfFloatType != 0, halfStoreRTZ != 0, c->stream);
         w = dw; h = dh;
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller may free `rgba` as soon as we return
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // the caller may free `rgba` as soon as we return
     hipFree(stage);
+    if (e != hipSuccess) {
+        hipFree(c->env);
+        c->env = nullptr; c->env_w = c->env_h = c->env_levels = 0;
+        return fail(c, RFX_EDEVICE, "rfx_set_environment: building the mip chain", e);
+    }
     c->env_w = width; c->env_h = height; c->env_levels = levels;
     memcpy(c->env_off, off, sizeof off);
     return RFX_OK;
