@@ -128,7 +128,12 @@ def main():
     log("[rank %d] dump band rows [%d,%d) of %dx%d generated in %.1fs (halo %d)" % (rank, b0, b1, W, H, time.time() - t0, halo))
 
     ctx = Context(W, H, device=local_rank, tile_y0=y0, tile_rows=rows, halo_rows=halo)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # kernels, RCCL ops and torch's sync share one stream
+    # kernels, RCCL ops and torch's copies share ONE created stream: torch's legacy default stream has handle 0, which
+    # rfx_set_stream reads as "use the context's own stream" — the collectives would then not be ordered against the kernels
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ctx.set_stream(stream.cuda_stream)
     ctx.uses_torch_stream = True
     renderer = ctx
     depth_full = band.depth

@@ -177,8 +177,9 @@ void rfx_destroy(rfx_ctx *);
 const char *rfx_last_error(const rfx_ctx *);
 /* Geometry the context was created with (any out pointer may be NULL). */
 int rfx_get_geometry(const rfx_ctx *, int *width, int *height, int *tile_y0, int *tile_rows, int *halo_rows);
-/* Run the context's kernels on a caller-provided hipStream_t (e.g. the framework's current
- * stream); NULL restores the context's own stream. */
+/* Run the context's kernels on a caller-provided hipStream_t (e.g. a stream the framework also uses for its
+ * collectives, so that they are ordered against the kernels); NULL restores the context's own stream.  The legacy
+ * default stream has handle 0 == NULL and therefore cannot be selected: create a stream. */
 int rfx_set_stream(rfx_ctx *, void *hip_stream);
 
 /* ---- textures.  `row0`/`rows` are FRAME rows of the band being transferred; the band must lie

@@ -104,6 +104,7 @@ class TiledRenderer:
         self._sync_before_comm()
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        self._sync_after_comm(self.tensors[texs[0]])
         self.exchange_count += 1
 
     def allgather_compose(self):
@@ -119,11 +120,21 @@ class TiledRenderer:
         else:  # ragged last tile, or a backend without all_gather_into_tensor: one broadcast per owner
             for r, p in enumerate(parts):
                 dist.broadcast(p, src=r, group=self.group)
+        self._sync_after_comm(full)
+
+    def _sync_after_comm(self, tensor):
+        # on device tensors `wait()` only makes torch's current stream wait for the collective; kernels of a context that
+        # runs on ANOTHER stream must not start before the rows have landed
+        if getattr(self.inner, "uses_torch_stream", False) or not tensor.is_cuda:
+            return
+        import torch
+        torch.cuda.current_stream(tensor.device).synchronize()
 
     def _sync_before_comm(self):
-        # kernels run on the context's stream; when that is torch's current stream (bench.py binds it)
-        # the collectives are ordered after them automatically.  A context on its own stream syncs here.
-        if getattr(self.inner, "uses_torch_stream", True):
+        # kernels run on the context's stream; when that is torch's CURRENT stream (bench.py creates one, binds it with
+        # rfx_set_stream and marks the context) the collectives are ordered after them automatically.  Anything else —
+        # a context on its own stream — drains that stream here before its rows are sent.
+        if getattr(self.inner, "uses_torch_stream", False):
             return
         self.inner.sync()
 
