@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--height", type=int, default=H4K, help="rows per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame the CPU baseline processes (0 = auto)")
+    ap.add_argument("--checksum", action="store_true", help="add sha1 of the final whole-frame composed GI to the JSON line (tiled == single check)")
     args = ap.parse_args()
 
     import torch
@@ -84,13 +85,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (args.gpus, world))
+    # functional test hook (tests/test_gpu_parity.py): RFX_BENCH_ONE_GPU=1 puts every rank on device 0 and moves the exchanges over
+    # gloo — RCCL refuses two ranks on one device.  Everything but the transport is the multi-GPU path.
+    one_gpu = os.environ.get("RFX_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # weak scaling: the frame grows with the number of GPUs at constant aspect, so that the per-pixel work (tap
     # footprints, ray lengths in pixels) stays what it is on one GPU; every rank owns W*Ht = const pixels
@@ -134,7 +143,8 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
-    ctx.uses_torch_stream = True
+    # gloo stages device tensors through the host on its own schedule: drain the stream around every exchange there
+    ctx.uses_torch_stream = not one_gpu
     renderer = ctx
     depth_full = band.depth
     if world > 1:
@@ -174,6 +184,10 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = W * H * args.steps / dt / 1e6  # Mpixels/s, whole job
     viol = ctx.halo_violations()
+    compose_sha1 = None
+    if args.checksum:  # before the per-kernel timing below re-runs kernels on this rank's tile only
+        import hashlib
+        compose_sha1 = hashlib.sha1(ctx.download(abi.TEX_COMPOSE).tobytes()).hexdigest()
 
     # ---- per-kernel durations (hipEvents on the kernels' stream), this rank's tile
     sp, tp = fx.ssgiPass.uniforms, fx.denoiser.temporalReprojectPass.uniforms
@@ -220,6 +234,8 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_PX[dom] * px_tile, "avg_launch_ms": round(kms[dom], 4)},
             "halo_violations": viol,
         }
+        if args.checksum:
+            out["compose_sha1"], out["frame_rows"] = compose_sha1, H
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frame, fx, W, H, args.cpu_sample_rows)
         print(json.dumps(out), flush=True)

@@ -669,3 +669,28 @@ def test_env_map_vs_oracle(blue_noise, env_blur, half):
     with pytest.raises(Exception):
         ctx.ssgi_march(sp)
     ctx.close()
+
+
+def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
+    """bench.py's N>1 path end to end — torch.distributed.run, per-rank band dumps, halo Send/Recv after K2 and every K3 pass, the
+    composed-GI all-gather, max-over-ranks timing — with two ranks sharing this GPU over gloo (RCCL refuses two ranks on one device;
+    only the transport differs from the multi-GPU run).  The final whole-frame composed GI must be bit-identical to the single-rank
+    run of the same frame."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RFX_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--checksum"]
+    two = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                   "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--width", "960", "--height", "540"] + common,
+                                  env=env, text=True, stderr=subprocess.DEVNULL, timeout=600)
+    j2 = json.loads([l for l in two.splitlines() if l.startswith("{")][-1])
+    assert j2["n_gpus"] == 2 and j2["halo_violations"] == 0 and j2["value"] > 0 and j2["scaling"] == "weak"
+    W, H = [int(x) for x in j2["config"]["frame"].split("x")]
+    assert H == j2["frame_rows"] == 2 * j2["config"]["tile_rows"]
+    one = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--width", str(W), "--height", str(H)] + common, env=env, text=True,
+                                  stderr=subprocess.DEVNULL, timeout=600)
+    j1 = json.loads([l for l in one.splitlines() if l.startswith("{")][-1])
+    assert j1["compose_sha1"] == j2["compose_sha1"]
