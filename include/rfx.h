@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 5
+#define RFX_ABI_VERSION 6
 
 enum {
     RFX_OK = 0,
@@ -101,6 +101,9 @@ typedef struct rfx_ssgi_params {
     float thickness;
     float envBlur;            /* uniform envBlur: mip = envBlur * maxEnvMapMipLevel (ssgi.frag:322); unused without USE_ENVMAP */
     int32_t blueNoiseIndex;   /* uniform blueNoiseIndex (BlueNoiseUtils.js:24-32 recurrence, host side) */
+    float resolutionScale;    /* SSGIPass.setSize (SSGIPass.js:52-57): the pass renders into a (W*s) x (H*s) target and `resolution` is that size;
+                                 0 is read as 1.  W*s and H*s must be whole numbers; s != 1 needs a whole-frame context.  The target's
+                                 texels are stored row-major at the start of RFX_TEX_SSGI (pitch W*s).                               */
     int32_t historySource;    /* uniform accumulatedTexture = ssgiEffect.denoiser.texture (SSGIPass.js:89, Denoiser.js:67-78):
                                  0  denoiseMode "full" / "full_temporal": K4's output, RFX_TEX_COMPOSE;
                                  1  "temporal": K2's texture[0], RFX_TEX_TEMPORAL0 (whole-frame contexts only);
@@ -132,6 +135,8 @@ typedef struct rfx_temporal_params {
                                      computed; 1 HalfFloatType — every output channel is rounded to half precision on store
                                      (RFX_TEX_TEMPORAL* then hold half-representable floats)                                 */
     int32_t halfStoreRTZ;         /* rounding of that store: 1 truncate (llvmpipe, parity with the oracle), 0 nearest-even    */
+    int32_t inputWidth, inputHeight; /* size of `inputTexture` when it is smaller than the frame (K1 drawn with resolutionScale < 1:
+                                     the pass samples it NEAREST at full-resolution vUv, TemporalReprojectPass.js:118); 0 = frame size */
 } rfx_temporal_params;
 
 /* K3 — PoissonDenoisePass uniforms/defines (PoissonDenoisePass.js:43-71, SSGIEffect.js:175-190). */

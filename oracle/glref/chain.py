@@ -332,7 +332,7 @@ class Program:
 
 DEFAULTS = dict(  # src/ssgi/SSGIOptions.js:26-48
     distance=10.0, thickness=10.0, denoiseIterations=1, radius=3.0, phi=0.5, lumaPhi=5.0, depthPhi=2.0, normalPhi=50.0,
-    roughnessPhi=50.0, specularPhi=50.0, envBlur=0.5, steps=20, refineSteps=5, missedRays=False, mode="ssgi", denoiseMode="full")
+    roughnessPhi=50.0, specularPhi=50.0, envBlur=0.5, steps=20, refineSteps=5, missedRays=False, mode="ssgi", denoiseMode="full", resolutionScale=1.0)
 
 
 class GLRefChain:
@@ -378,7 +378,11 @@ class GLRefChain:
         self.t_direct = Tex(W, H, FMT_RGBA32F)
         self.t_blue = Tex(128, 128, FMT_RGBA8, repeat=True, data=blue_noise_table)
         self.t_empty = Tex(1, 1, FMT_RGBA8, data=np.zeros(4, np.uint8))  # three's empty texture (Appendix D-1)
-        self.t_ssgi = Tex(W, H, FMT_RGBA32F)
+        # SSGIPass.setSize :52-57: the pass's target is (W*s) x (H*s)
+        rs = float(self.o["resolutionScale"])
+        self.ssgi_size = (int(W * rs), int(H * rs))
+        assert self.ssgi_size == (W * rs, H * rs), "W*resolutionScale and H*resolutionScale must be whole"
+        self.t_ssgi = Tex(self.ssgi_size[0], self.ssgi_size[1], FMT_RGBA32F)
         self.t_temporal = [Tex(W, H, FMT_RGBA32F), Tex(W, H, FMT_RGBA32F)]
         self.t_A = [Tex(W, H, FMT_RGBA16F, linear=True), Tex(W, H, FMT_RGBA16F, linear=True)]
         self.t_B = [Tex(W, H, FMT_RGBA16F, linear=True), Tex(W, H, FMT_RGBA16F, linear=True)]
@@ -434,7 +438,7 @@ class GLRefChain:
         else:
             p.set("maxEnvMapMipLevel", 0.0)
         p.set("backgroundColor", [0.0, 0.0, 0.0])
-        p.set("resolution", [float(self.W), float(self.H)])
+        p.set("resolution", [float(self.ssgi_size[0]), float(self.ssgi_size[1])])  # = renderTarget size (SSGIPass.js:56)
         p.set("blueNoiseSize", [128.0, 128.0])
         p.set("blueNoiseIndex", int(blue_noise_index))
         p.draw([self.t_ssgi])

@@ -351,6 +351,7 @@ typedef struct {
     const rfx_ssgi_params *p;
     float nearMulFar, farMinusNear, cameraFar;
     const float *env; int env_w, env_h, env_levels; /* scene.environment: the whole mip chain, RGBA float32, level l after level l-1 */
+    int outW, outH; /* the pass's render target = `resolution` (SSGIPass.js:52-57): W*resolutionScale x H*resolutionScale */
 } k1_ctx;
 
 static inline float k1_view_z(const k1_ctx *c, float depth) { /* getViewZ ssgi_utils.frag:7-13 (PERSPECTIVE_CAMERA) */
@@ -503,7 +504,7 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
     const float *C = p->camera.matrixWorld, *Vw = p->camera.matrixWorldInverse;
     const float *P = p->camera.projectionMatrix, *Pi = p->camera.projectionMatrixInverse;
     dims d = {c->W, c->H};
-    float u = ((float)x + 0.5f) / (float)c->W, v = ((float)y + 0.5f) / (float)c->H;
+    float u = ((float)x + 0.5f) / (float)c->outW, v = ((float)y + 0.5f) / (float)c->outH; /* vUv of the (possibly smaller) target */
     float depth = fetch_r32f(c->depth, d, u, v);
     if (depth == 1.0f) { /* :109-113 */
         v4 dl = fetch_f4(c->direct, d, u, v);
@@ -528,7 +529,7 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
     onb(N, &T, &B);
     V = V3(dot3(V, T), dot3(V, B), dot3(V, N)); /* ToLocal */
     v3 f0 = mix3(V3(0.04f, 0.04f, 0.04f), mat.diffuse, mat.metalness);
-    v4 random = blue_noise(c->blue, x, y, p->blueNoiseIndex, u, v, d);
+    v4 random = blue_noise(c->blue, x, y, p->blueNoiseIndex, u, v, (dims){c->outW, c->outH}); /* `resolution` = the render target's size */
     v3 Hh = sample_ggx_vndf(V, roughnessSq, roughnessSq, random.x, random.y);
     if (Hh.z < 0.0f) Hh = neg3(Hh);
     /* reflect(-V, H) = I - 2*dot(N,I)*N with I=-V */
@@ -631,14 +632,18 @@ int rfxo_ssgi(int W, int H, int y0, int y1, const float *depth, const uint32_t *
               const uint8_t *blue, const rfx_ssgi_params *p, uint32_t *out, const float *env, int env_w, int env_h, int env_levels) {
     if ((p->mode != 0 && p->mode != 1) || p->importanceSampling) return RFX_EUNSUPPORTED;
     if (p->useEnvMap && !env) return RFX_ESTATE;
-    k1_ctx c = {W, H, depth, gbuffer, direct, history, blue, p, 0, 0, 0, env, env_w, env_h, env_levels};
+    /* resolutionScale (SSGIPass.js:52-57): `out` is then the (W*s) x (H*s) target, pitch W*s, and y0/y1 are rows of THAT target */
+    const float rs = p->resolutionScale == 0.0f ? 1.0f : p->resolutionScale;
+    const int oW = (int)((float)W * rs), oH = (int)((float)H * rs);
+    if ((float)oW != (float)W * rs || (float)oH != (float)H * rs || oW < 1 || oH < 1) return RFX_EINVAL;
+    k1_ctx c = {W, H, depth, gbuffer, direct, history, blue, p, 0, 0, 0, env, env_w, env_h, env_levels, oW, oH};
     /* SSGIPass.js:84-87: JS doubles rounded to float uniforms */
     c.nearMulFar = (float)((double)p->camera.near_ * (double)p->camera.far_);
     c.farMinusNear = (float)((double)p->camera.far_ - (double)p->camera.near_);
     c.cameraFar = p->camera.far_;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = y0; y < y1; y++)
-        for (int x = 0; x < W; x++) k1_pixel(&c, x, y, out + 4 * ((size_t)y * W + x));
+        for (int x = 0; x < oW; x++) k1_pixel(&c, x, y, out + 4 * ((size_t)y * oW + x));
     return 0;
 }
 
@@ -724,7 +729,8 @@ static inline v3 expm13(v3 c, int on) { return on ? V3(expf(c.x) - 1.0f, expf(c.
 
 /* input texel i at (u,v) after unpack (DIFFUSE_SPECULAR) or raw */
 static inline v4 k2_input_texel(const k2_ctx *c, float u, float v, int idx) {
-    dims d = {c->W, c->H};
+    /* inputTexture may be smaller than the frame (K1 drawn with resolutionScale < 1): NEAREST at the full-resolution uv */
+    dims d = {c->p->inputWidth > 0 ? c->p->inputWidth : c->W, c->p->inputHeight > 0 ? c->p->inputHeight : c->H};
     const uint32_t *t = fetch_u4(c->ssgi, d, u, v);
     if (c->p->inputType == 0) {
         v4 a, b; unpack_two_vec4(t, &a, &b);

@@ -77,9 +77,13 @@ class EnvMap:
 
 def ssgi(depth, gbuffer, direct, history, blue, params: abi.SsgiParams, out=None, rows=None, env: "EnvMap | None" = None):
     H, W = depth.shape
-    y0, y1 = rows or (0, H)
+    rs = params.resolutionScale or 1.0  # the (W*s) x (H*s) render target: `out` then has that shape, `rows` are its rows
+    oH, oW = int(H * rs), int(W * rs)
+    y0, y1 = rows or (0, oH)
     if out is None:
-        out = np.zeros((H, W, 4), np.uint32)
+        out = np.zeros((oH, oW, 4), np.uint32)
+    if rs != 1.0:
+        assert out.shape == (oH, oW, 4) and out.flags["C_CONTIGUOUS"]
     rc = lib().rfxo_ssgi(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gbuffer, np.uint32, (H, W, 4))), _p(_chk(direct, np.float32, (H, W, 4))),
                          _p(_chk(history, np.float32, (H, W, 4))), _p(_chk(blue, np.uint8)), C.byref(params), _p(out),
                          _p(env.chain) if env is not None else None, env.w if env else 0, env.h if env else 0, env.levels if env else 0)
@@ -89,13 +93,14 @@ def ssgi(depth, gbuffer, direct, history, blue, params: abi.SsgiParams, out=None
 
 def temporal(ssgi_tex, velocity, hist0, hist1, params: abi.TemporalParams, out0=None, out1=None, rows=None):
     """hist*: uint16 half bits (H,W,4) [historySource 0/1] or float32 (H,W,4) [historySource 2, the FloatType framebuffer copy]."""
-    H, W = ssgi_tex.shape[:2]
+    H, W = velocity.shape[:2]
     y0, y1 = rows or (0, H)
     out0 = np.zeros((H, W, 4), np.float32) if out0 is None else out0
     if out1 is None and params.textureCount == 2:
         out1 = np.zeros((H, W, 4), np.float32)
     hdt = np.float32 if params.historySource == 2 else np.uint16
-    rc = lib().rfxo_temporal(W, H, y0, y1, _p(_chk(ssgi_tex, np.uint32, (H, W, 4))), _p(_chk(velocity, np.uint32, (H, W, 4))),
+    iw, ih = params.inputWidth or W, params.inputHeight or H
+    rc = lib().rfxo_temporal(W, H, y0, y1, _p(_chk(ssgi_tex, np.uint32, (ih, iw, 4))), _p(_chk(velocity, np.uint32, (H, W, 4))),
                              _p(_chk(hist0, hdt, (H, W, 4))), _p(_chk(hist1, hdt, (H, W, 4))), C.byref(params), _p(out0), _p(out1))
     assert rc == 0, rc
     return out0, out1

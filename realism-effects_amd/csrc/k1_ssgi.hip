@@ -295,27 +295,30 @@ template <bool PERSP, bool ENV>
 RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     // XCD-aware mapping: hardware block b runs on XCD b % 8 (observed, used for speed only); give XCD k the k-th
     // contiguous eighth of the row-major tile list, i.e. an image band, so its L2 sees a compact part of the depth plane
-    const int nbx = (d.W + 63) / 64, nblocks = gridDim.x;
+    const int nbx = (A.out_w + 63) / 64, nblocks = gridDim.x;
     const int per = (nblocks + 7) / 8;
     const int lb = A.xcd_map ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
     if (lb >= nblocks) return;
     const int x = (lb % nbx) * 64 + threadIdx.x;
     const int y = A.y0 + (lb / nbx) * 4 + threadIdx.y;
-    if (x >= d.W || y >= A.y1) return;
+    if (x >= A.out_w || y >= A.y1) return;
     const rfx_ssgi_params &p = A.p;
     const float *C = p.camera.matrixWorld, *Vw = p.camera.matrixWorldInverse;
     const float *P = p.camera.projectionMatrix, *Pi = p.camera.projectionMatrixInverse;
 
-    const float u = ((float)x + 0.5f) / d.fW, v = ((float)y + 0.5f) / d.fH;
-    const float depth = ((const float *)A.depth.ptr)[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, y)];
-    uint4 *outp = (uint4 *)A.out.ptr + ((size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x);
-    const size_t gi_idx = rfx_xy_index(d, A.direct.row0, A.direct.rows, x, y);
+    // vUv of the (possibly smaller, resolutionScale) render target; the full-resolution inputs are fetched NEAREST at vUv
+    const bool scaled = A.out_w != d.W || A.out_h != d.H;
+    const float u = ((float)x + 0.5f) / (float)A.out_w, v = ((float)y + 0.5f) / (float)A.out_h;
+    const int sx = scaled ? rfx_nearest_idx(u, d.fW, d.W) : x, sy = scaled ? rfx_nearest_idx(v, d.fH, d.H) : y;
+    const float depth = ((const float *)A.depth.ptr)[rfx_xy_index(d, A.depth.row0, A.depth.rows, sx, sy)];
+    uint4 *outp = (uint4 *)A.out.ptr + (scaled ? (size_t)y * A.out_w + x : (size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x);
+    const size_t gi_idx = rfx_xy_index(d, A.direct.row0, A.direct.rows, sx, sy);
     if (depth == 1.0f) {  // background :109-113
         const float4 dl = ((const float4 *)A.direct.ptr)[gi_idx];
         *outp = rfx_pack_two_vec4(dl, dl);
         return;
     }
-    const Material mat = rfx_get_material<false>(((const uint4 *)A.gbuffer.ptr)[rfx_xy_index(d, A.gbuffer.row0, A.gbuffer.rows, x, y)]);
+    const Material mat = rfx_get_material<false>(((const uint4 *)A.gbuffer.ptr)[rfx_xy_index(d, A.gbuffer.row0, A.gbuffer.rows, sx, sy)]);
     const float roughnessSq = rfx_clamp(mat.roughness * mat.roughness, 0.000001f, 1.0f);
 
     MarchCtx m;
@@ -329,7 +332,7 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     m.refineSteps = p.refineSteps;
     m.use_coarse = A.use_coarse != 0;
 
-    const float viewZ = A.viewz[(size_t)y * d.W + x];  // getViewZ(depth) ssgi_utils.frag:7-13, from the pre-pass
+    const float viewZ = A.viewz[(size_t)sy * d.W + sx];  // getViewZ(depth) ssgi_utils.frag:7-13, from the pre-pass
     // getViewPosition ssgi_utils.frag:17-24
     const float clipW = P[2 * 4 + 3] * viewZ + P[3 * 4 + 3];
     const float4 pp = rfx_mat_mul(Pi, ((u - 0.5f) * 2.0f) * clipW, ((v - 0.5f) * 2.0f) * clipW, ((viewZ - 0.5f) * 2.0f) * clipW, 1.0f * clipW);
@@ -490,7 +493,7 @@ hipError_t rfx_launch_k1_prepare(const K1Args &A, hipStream_t stream) {
 }
 
 hipError_t rfx_launch_k1(const K1Args &A, hipStream_t stream) {
-    const int nbx = (A.dims.W + 63) / 64, nby = (A.y1 - A.y0 + 3) / 4;
+    const int nbx = (A.out_w + 63) / 64, nby = (A.y1 - A.y0 + 3) / 4;
     const int nblocks = nbx * nby;
     dim3 block(64, 4), grid(((nblocks + 7) / 8) * 8);
     const float *P = A.p.camera.projectionMatrix;

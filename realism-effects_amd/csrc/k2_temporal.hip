@@ -143,7 +143,15 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
         const int ly = i / LW, lx = i - ly * LW;
         const int gx = tx0 - AP + lx, gy = ty0 - AP + ly;
         if (gx < 0 || gx >= d.W || gy < 0 || gy >= d.H || gy > A.y1 - 1 + AP) continue;
-        const uint4 t = ((const uint4 *)A.ssgi.ptr)[(size_t)rfx_local_row(d, A.ssgi.row0, A.ssgi.rows, gy) * d.W + gx];
+        // the input texel this full-resolution position samples: itself, or — K1 drawn at resolutionScale < 1 — the NEAREST texel of the
+        // smaller target at this pixel's vUv (whole-frame contexts only; the target is stored at the start of the slot, pitch in_w)
+        uint4 t;
+        if (A.in_w != d.W || A.in_h != d.H) {
+            const int ix = rfx_nearest_idx(((float)gx + 0.5f) / d.fW, (float)A.in_w, A.in_w), iy = rfx_nearest_idx(((float)gy + 0.5f) / d.fH, (float)A.in_h, A.in_h);
+            t = ((const uint4 *)A.ssgi.ptr)[(size_t)iy * A.in_w + ix];
+        } else {
+            t = ((const uint4 *)A.ssgi.ptr)[(size_t)rfx_local_row(d, A.ssgi.row0, A.ssgi.rows, gy) * d.W + gx];
+        }
         // a texel that was not sampled (`!(t.r >= 0.)`) takes no part in any neighbourhood AABB (reproject.frag:66) and its
         // colour is never read as a centre texel either: stage its rgb as quiet NaNs, which v_min/v_max skip, so the
         // 25-tap loops below need no per-tap test.  .a (roughness / ray length) is kept.

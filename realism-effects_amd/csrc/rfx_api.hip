@@ -345,6 +345,16 @@ int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
     A.dims = dims(c);
     // K2's neighbourhood clamp reads +-2 rows of K1's output: produce them redundantly in the halo
     launch_rows(c, RFX_TEX_SSGI, c->halo < 2 ? c->halo : 2, &A.y0, &A.y1);
+    A.out_w = c->W; A.out_h = c->H;
+    const float rs = p->resolutionScale == 0.0f ? 1.0f : p->resolutionScale;
+    if (rs != 1.0f) {  // SSGIPass.setSize :52-57
+        const float fw = (float)c->W * rs, fh = (float)c->H * rs;
+        if (!(rs > 0.0f && rs <= 1.0f) || fw != floorf(fw) || fh != floorf(fh) || fw < 1.0f || fh < 1.0f)
+            return fail(c, RFX_EINVAL, "rfx_ssgi_march: resolutionScale must be in (0, 1] with whole W*s and H*s");
+        if (c->tile_y0 != 0 || c->tile_rows != c->H) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: resolutionScale != 1 needs a whole-frame context");
+        A.out_w = (int)fw; A.out_h = (int)fh;
+        A.y0 = 0; A.y1 = A.out_h;
+    }
     A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER); A.direct = view(c, RFX_TEX_DIRECT_LIGHT);
     A.history = view(c, hist);
     A.blue = c->slots[RFX_TEX_BLUE_NOISE].ptr;
@@ -404,6 +414,11 @@ int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
     A.hist0 = view(c, h0);
     A.hist1 = view(c, h1);
     A.hist_f32 = p->historySource == 2;
+    A.in_w = p->inputWidth > 0 ? p->inputWidth : c->W;
+    A.in_h = p->inputHeight > 0 ? p->inputHeight : c->H;
+    if (A.in_w > c->W || A.in_h > c->H) return fail(c, RFX_EINVAL, "rfx_temporal_reproject: inputWidth/inputHeight larger than the frame");
+    if ((A.in_w != c->W || A.in_h != c->H) && (c->tile_y0 != 0 || c->tile_rows != c->H))
+        return fail(c, RFX_EUNSUPPORTED, "rfx_temporal_reproject: a smaller input texture (resolutionScale != 1) needs a whole-frame context");
     A.out0 = wview(c, RFX_TEX_TEMPORAL0); A.out1 = wview(c, o1);
     A.p = *p;
     // TemporalReprojectPass.js:135: invTexSize.set(1 / width, 1 / height) in doubles

@@ -25,6 +25,7 @@ struct K1Args {
     int env_w, env_h, env_levels;
     unsigned int env_off[16];
     float maxEnvMapMipLevel;
+    int out_w, out_h;  // the pass's render target = `resolution` (frame size unless resolutionScale != 1)
 };
 
 // one level of the environment's mip chain from the one above (glGenerateMipmap on the oracle's GL: 2x2 bilinear centre)
@@ -35,6 +36,7 @@ struct K2Args {
     int y0, y1;
     TexView ssgi, velocity, hist0, hist1;  // hist* = K3 target B of the previous frame (RGBA16F, linear), or the pass's framebuffer copy
     int hist_f32;                          // history texels are RGBA32F (FloatType framebuffer copy) instead of RGBA16F
+    int in_w, in_h;                        // size of the input texture (smaller than the frame when K1 ran with resolutionScale < 1)
     TexViewW out0, out1;
     rfx_temporal_params p;
     float invW, invH;

@@ -247,6 +247,8 @@ class TemporalReprojectPass {
 			maxBlend: options.maxBlend,
 			keepData: 1,
 			historySource: 0,
+			inputWidth: 0,
+			inputHeight: 0,
 			targetHalf: this.targetType === HalfFloatType ? 1 : 0,
 			halfStoreRTZ: halfStoreRTZ === undefined || halfStoreRTZ ? 1 : 0
 		}
@@ -458,7 +460,10 @@ class SSGIPass {
 		return TEX.SSGI
 	}
 	setSize(width, height) {
-		if (this.ssgiEffect._options.resolutionScale !== 1) throw new Error("resolutionScale != 1 (SSGIPass.js:53) is not built yet")
+		// :52-57 the pass's render target (and its `resolution` uniform) is width*resolutionScale x height*resolutionScale
+		const s = this.ssgiEffect._options.resolutionScale
+		this.renderTargetSize = [width * s, height * s]
+		this.uniforms.resolutionScale = s
 		this.gBufferPass.setSize(width, height)
 	}
 	render(renderer) {
@@ -606,6 +611,11 @@ class SSGIEffect {
 		if (width === undefined && height === undefined) return
 		this.ssgiPass.setSize(width, height)
 		this.denoiser.setSize(width, height)
+		// K2 samples the pass's (possibly smaller) texture NEAREST at full-resolution vUv: the device needs its size
+		const tu = this.denoiser.temporalReprojectPass.uniforms
+		const scaled = this._options.resolutionScale !== 1
+		tu.inputWidth = scaled ? Math.trunc(this.ssgiPass.renderTargetSize[0]) : 0
+		tu.inputHeight = scaled ? Math.trunc(this.ssgiPass.renderTargetSize[1]) : 0
 		this.lastSize = { width, height, resolutionScale: this._options.resolutionScale }
 	}
 

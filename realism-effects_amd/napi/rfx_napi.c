@@ -258,6 +258,7 @@ static napi_value n_ssgi(napi_env env, napi_callback_info info) {
     p.envBlur = (float)prop_num(env, a[1], "envBlur", 0.5);
     p.blueNoiseIndex = (int32_t)prop_num(env, a[1], "blueNoiseIndex", 0);
     p.historySource = (int32_t)prop_num(env, a[1], "historySource", 0);
+    p.resolutionScale = (float)prop_num(env, a[1], "resolutionScale", 1);
     int rc = rfx_ssgi_march(c, &p);
     if (rc) return throw_rfx(env, c, "rfx_ssgi_march", rc);
     return NULL;
@@ -287,6 +288,8 @@ static napi_value n_temporal(napi_env env, napi_callback_info info) {
     p.historySource = (int32_t)prop_num(env, a[1], "historySource", 0);
     p.targetHalf = (int32_t)prop_num(env, a[1], "targetHalf", 0);
     p.halfStoreRTZ = (int32_t)prop_num(env, a[1], "halfStoreRTZ", 1);
+    p.inputWidth = (int32_t)prop_num(env, a[1], "inputWidth", 0);
+    p.inputHeight = (int32_t)prop_num(env, a[1], "inputHeight", 0);
     int rc = rfx_temporal_reproject(c, &p);
     if (rc) return throw_rfx(env, c, "rfx_temporal_reproject", rc);
     return NULL;

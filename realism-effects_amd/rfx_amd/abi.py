@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "..", "csrc", "librfx_hip.so")
 
-RFX_ABI_VERSION = 5
+RFX_ABI_VERSION = 6
 RFX_OK, RFX_EINVAL, RFX_ENOMEM, RFX_EDEVICE, RFX_ESTATE, RFX_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 (TEX_DEPTH, TEX_GBUFFER, TEX_VELOCITY, TEX_DIRECT_LIGHT, TEX_BLUE_NOISE, TEX_SSGI, TEX_TEMPORAL0, TEX_TEMPORAL1,
@@ -52,7 +52,7 @@ class SsgiParams(C.Structure):
     _fields_ = [("camera", Camera), ("steps", C.c_int32), ("refineSteps", C.c_int32), ("mode", C.c_int32),
                 ("useDirectLight", C.c_int32), ("missedRays", C.c_int32), ("importanceSampling", C.c_int32), ("useEnvMap", C.c_int32),
                 ("rayDistance", C.c_float), ("thickness", C.c_float), ("envBlur", C.c_float), ("blueNoiseIndex", C.c_int32),
-                ("historySource", C.c_int32)]
+                ("resolutionScale", C.c_float), ("historySource", C.c_int32)]
 
 
 class TemporalParams(C.Structure):
@@ -60,7 +60,7 @@ class TemporalParams(C.Structure):
                 ("reprojectSpecular", C.c_int32 * 2), ("neighborhoodClamp", C.c_int32 * 2), ("logTransform", C.c_int32),
                 ("fullAccumulate", C.c_int32), ("confidencePower", C.c_float), ("neighborhoodClampIntensity", C.c_float),
                 ("maxBlend", C.c_float), ("keepData", C.c_float), ("historySource", C.c_int32), ("targetHalf", C.c_int32),
-                ("halfStoreRTZ", C.c_int32)]
+                ("halfStoreRTZ", C.c_int32), ("inputWidth", C.c_int32), ("inputHeight", C.c_int32)]
 
 
 class DenoiseParams(C.Structure):

@@ -398,8 +398,10 @@ class SSGIPass:
         return abi.TEX_SSGI
 
     def setSize(self, width, height):
-        if self.ssgiEffect.resolutionScale != 1:
-            raise NotImplementedError("resolutionScale != 1 (SSGIPass.js:53) is not built yet (SURVEY.md §8f-4)")
+        # :52-57 the pass's render target (and its `resolution` uniform) is width*resolutionScale x height*resolutionScale
+        s = float(self.ssgiEffect._options["resolutionScale"])
+        self.renderTargetSize = (width * s, height * s) if width is not None else (None, None)
+        self.uniforms.resolutionScale = s
         self.gBufferPass.setSize(width, height)
 
     def render(self, renderer):
@@ -514,6 +516,10 @@ class SSGIEffect:
             return
         self.ssgiPass.setSize(width, height)
         self.denoiser.setSize(width, height)
+        # K2 samples the pass's (possibly smaller) texture NEAREST at full-resolution vUv: the device needs its size
+        tw, th = self.ssgiPass.renderTargetSize
+        tu = self.denoiser.temporalReprojectPass.uniforms
+        tu.inputWidth, tu.inputHeight = (0, 0) if (tw is None or self._options["resolutionScale"] == 1) else (int(tw), int(th))
         self.lastSize = dict(width=width, height=height, resolutionScale=self._options["resolutionScale"])
 
     @property

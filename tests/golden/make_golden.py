@@ -35,13 +35,14 @@ def cam_arrays(cam, prefix):
 
 
 def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_start=2000, mode="ssgi", missed_rays=False, denoise_mode="full",
-        environment=None, env_blur=0.5):
+        environment=None, env_blur=0.5, resolution_scale=1.0):
     bn = np.fromfile(os.path.join(ROOT, "realism-effects_amd", "data", "blue_noise_128_rgba8.bin"), np.uint8).reshape(128, 128, 4)
     c = chain.GLRefChain(W, H, bn, steps=steps, refineSteps=refine, denoiseIterations=iterations, mode=mode, missedRays=missed_rays,
-                         denoiseMode=denoise_mode, environment=environment, envBlur=env_blur)
+                         denoiseMode=denoise_mode, environment=environment, envBlur=env_blur, resolutionScale=resolution_scale)
     tc = c.tc
     out = dict(width=W, height=H, frames=frames, steps=steps, refineSteps=refine, denoiseIterations=iterations, ssgi_start=ssgi_start,
                denoise_start=denoise_start, gl_info=chain.GL.info(), mode=mode, textureCount=tc, missedRays=int(missed_rays), denoiseMode=denoise_mode)
+    out["resolutionScale"] = resolution_scale
     if environment is not None:  # scene.environment (HalfFloatType, mipmapped by the effect) + the envBlur option
         out["environment"], out["envBlur"] = environment, env_blur
     si = di = 0
@@ -128,6 +129,11 @@ if __name__ == "__main__":
     from rfx_amd.scene import synthetic_environment
     run("chain_env_128x72_s12r3_it1", 128, 72, frames=2, steps=12, refine=3, iterations=1, environment=synthetic_environment(128, 64))
     run("chain_envsharp_96x54_s12r3_it1", 96, 54, frames=2, steps=12, refine=3, iterations=1, environment=synthetic_environment(128, 64), env_blur=0.1)
+    # resolutionScale option.  Only scales whose sample positions fall on texel CENTRES of the full-resolution inputs are comparable
+    # across rasterisers (0.5 at these sizes): 0.75 puts every third row exactly on a texel boundary, where the nearest texel depends on
+    # the last ulp of the rasteriser's varying interpolation (llvmpipe's vUv differs from (i+0.5)/n by <= 1 ulp, measured) — there the
+    # reference itself is implementation-defined.
+    run("chain_rs050_128x72_s12r3_it1", 128, 72, frames=2, steps=12, refine=3, iterations=1, resolution_scale=0.5)
     for dm in ("full_temporal", "temporal", "denoised"):  # the other Denoiser modes (Denoiser.js:7,41-78)
         run("chain_%s_104x58_s10r2" % dm, 104, 58, frames=3, steps=10, refine=2, iterations=1, denoise_mode=dm)
     run_traa("traa_half_128x72", 128, 72, frames=3, half=True)

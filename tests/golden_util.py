@@ -8,6 +8,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDENS = ["chain_160x90_s20r5_it1", "chain_97x55_s8r2_it2", "chain_missed_96x54_s12r3_it1"]
 GOLDEN_SSR = "chain_ssr_128x72_s20r5_it1"
 GOLDEN_ENV = ["chain_env_128x72_s12r3_it1", "chain_envsharp_96x54_s12r3_it1"]  # scene.environment (USE_ENVMAP), envBlur 0.5 / 0.1
+GOLDEN_RS = ["chain_rs050_128x72_s12r3_it1"]  # resolutionScale 0.5 (SSGIPass.js:52-57); see make_golden.py on other scales
 GOLDEN_MODES = ["chain_full_temporal_104x58_s10r2", "chain_temporal_104x58_s10r2", "chain_denoised_104x58_s10r2"]  # Denoiser.js:7 denoiseMode
 GOLDEN_FINAL = "final_112x63"  # SSGIEffect's own fragment: no fog / Fog / FogExp2 / isDebug
 GOLDEN_TRAA = ["traa_half_128x72", "traa_float_96x54"]  # TRAAEffect: composer buffers HalfFloatType / FloatType

@@ -64,6 +64,12 @@ class OracleRenderer:
         self.calls.append(("ssgi", p.blueNoiseIndex))
         t = self.tex
         hist = t[abi.TEX_TEMPORAL0] if p.historySource == 1 else t[abi.TEX_COMPOSE]
+        rs = p.resolutionScale or 1.0
+        if rs != 1.0:  # the smaller render target lives at the start of the slot, pitch W*s (as on the device)
+            oH, oW = int(self.H * rs), int(self.W * rs)
+            out = t[abi.TEX_SSGI].reshape(-1)[:oH * oW * 4].reshape(oH, oW, 4)
+            O.ssgi(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[abi.TEX_DIRECT_LIGHT], hist, t[abi.TEX_BLUE_NOISE], p, out=out, env=getattr(self, "env", None))
+            return
         O.ssgi(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[abi.TEX_DIRECT_LIGHT], hist, t[abi.TEX_BLUE_NOISE], p,
                out=t[abi.TEX_SSGI], rows=self._rows(min(2, self.halo)), env=getattr(self, "env", None))
 
@@ -75,7 +81,10 @@ class OracleRenderer:
             h1 = t[abi.TEX_DENOISE_B1] if p.textureCount == 2 else h0
         else:
             h0 = h1 = t[abi.TEX_FBCOPY_F16 if p.historySource == 1 else abi.TEX_FBCOPY_F32]
-        O.temporal(t[abi.TEX_SSGI], t[abi.TEX_VELOCITY], h0, h1, p, t[abi.TEX_TEMPORAL0], t[abi.TEX_TEMPORAL1], rows=self._rows())
+        src = t[abi.TEX_SSGI]
+        if p.inputWidth:
+            src = src.reshape(-1)[:p.inputHeight * p.inputWidth * 4].reshape(p.inputHeight, p.inputWidth, 4)
+        O.temporal(src, t[abi.TEX_VELOCITY], h0, h1, p, t[abi.TEX_TEMPORAL0], t[abi.TEX_TEMPORAL1], rows=self._rows())
 
     def copy_framebuffer(self, dst):
         self.calls.append(("copy_framebuffer", dst))

@@ -694,3 +694,63 @@ def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
                                   stderr=subprocess.DEVNULL, timeout=600)
     j1 = json.loads([l for l in one.splitlines() if l.startswith("{")][-1])
     assert j1["compose_sha1"] == j2["compose_sha1"]
+
+
+@pytest.mark.parametrize("rs", [0.5, 0.75, 0.25])
+def test_resolution_scale_vs_oracle(blue_noise, rs):
+    """resolutionScale < 1 (SSGIPass.js:52-57): K1 into a (W*s) x (H*s) target, K2 sampling it NEAREST at full-resolution vUv — kernel by
+    kernel against the oracle (both define vUv = (i + 0.5) / n), then the whole chain through SSGIEffect on both renderers."""
+    import types
+    from oracle_renderer import OracleRenderer
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.effect import SSGIEffect
+    from rfx_amd.scene import synthetic_frame
+    import rfx_oracle as O
+
+    W, H = 256, 144
+    oW, oH = int(W * rs), int(H * rs)
+    ctx = Context(W, H)
+    comp = np.random.RandomState(9).rand(H, W, 4).astype(np.float32)
+    hist = (np.random.RandomState(10).rand(H, W, 4).astype(np.float32) * np.array([1, 1, 1, 6], np.float32)).astype(np.float16).view(np.uint16)
+    f0, f = synthetic_frame(W, H, 0), synthetic_frame(W, H, 1)
+    sp, tp, _, _ = _params(abi, f, f0.camera, 1.0, 12, 3)
+    sp.resolutionScale, sp.blueNoiseIndex = rs, 321
+    ctx.upload_frame(f)
+    ctx.upload(abi.TEX_COMPOSE, comp)
+    ctx.ssgi_march(sp)
+    got = ctx.download(abi.TEX_SSGI).reshape(-1)[:oH * oW * 4].reshape(oH, oW, 4)
+    want = O.ssgi(f.depth, f.gbuffer, f.direct, comp, blue_noise, sp)
+    ga, gb = O.unpack_ssgi(got)
+    wa, wb = O.unpack_ssgi(want)
+    assert_close("rs%g ssgi.diffuse" % rs, ga, wa, FLIP["ssgi"])
+    assert_close("rs%g ssgi.specular" % rs, gb, wb, FLIP["ssgi"])
+    assert (got == want).all(axis=-1).mean() > 0.99
+    # K2 on the oracle's K1 texels
+    full = np.zeros((H, W, 4), np.uint32)
+    full.reshape(-1)[:oH * oW * 4] = want.reshape(-1)
+    ctx.upload(abi.TEX_SSGI, full)
+    ctx.upload(abi.TEX_DENOISE_B0, hist)
+    ctx.upload(abi.TEX_DENOISE_B1, hist)
+    tp.inputWidth, tp.inputHeight = oW, oH
+    ctx.temporal_reproject(tp)
+    T0, T1 = np.zeros((H, W, 4), np.float32), np.zeros((H, W, 4), np.float32)
+    O.temporal(want, f.velocity, hist, hist, tp, T0, T1)
+    assert_close("rs%g temporal0" % rs, ctx.download(abi.TEX_TEMPORAL0), T0, FLIP["temporal"])
+    assert_close("rs%g temporal1" % rs, ctx.download(abi.TEX_TEMPORAL1), T1, FLIP["temporal"])
+    ctx.close()
+
+    def run(renderer):
+        scene = types.SimpleNamespace(frame=None)
+        cam = types.SimpleNamespace(**vars(f0.camera))
+        fx = SSGIEffect(None, scene, cam, dict(width=W, height=H, steps=12, refineSteps=3, resolutionScale=rs), seeds=dict(ssgi=5, denoise=6))
+        for fr in (f0, f):
+            scene.frame = fr
+            for k, v in vars(fr.camera).items():
+                setattr(cam, k, v)
+            fx.update(renderer, None)
+        return renderer.download(abi.TEX_COMPOSE)
+
+    dev = Context(W, H)
+    assert_close("rs%g chain compose" % rs, run(dev), run(OracleRenderer(W, H)), 0.06)
+    dev.close()

@@ -68,9 +68,11 @@ for (const dm of ["full_temporal", "temporal", "denoised"]) {
   modeCalls[dm] = mc
 }
 const low = new fx.SSGIEffect(null, { frame: {} }, cam, { width: 32, height: 16, preset: "low" }, { ssgi: 1, denoise: 2 })
+const half = new fx.SSGIEffect(null, { frame: {} }, cam, { width: 32, height: 16, resolutionScale: 0.5 }, { ssgi: 1, denoise: 2 })
+const halfU = [half.ssgiPass.uniforms.resolutionScale, half.denoiser.temporalReprojectPass.uniforms.inputWidth, half.denoiser.temporalReprojectPass.uniforms.inputHeight]
 const halfProbe = JSON.parse(process.argv[3]).map(fx.roundToHalf).map(x => Number.isFinite(x) ? x : String(x))
 console.log(JSON.stringify({ calls, defaults: fx.SSGIEffect.DefaultOptions, traa: [t.textureCount, t.inputType, t.logTransform, t.maxBlend, t.confidencePower, t.neighborhoodClampIntensity],
-                             traaCalls, halfProbe, r2: fx.r2Sequence.slice(0, 3), modeCalls, low: [low.steps, low.refineSteps, low.denoiser.options.denoiseMode] }))
+                             traaCalls, halfProbe, r2: fx.r2Sequence.slice(0, 3), modeCalls, low: [low.steps, low.refineSteps, low.denoiser.options.denoiseMode], halfU }))
 """
 
 
@@ -180,6 +182,9 @@ def test_js_and_python_hosts_issue_the_same_calls():
         assert js["modeCalls"][dm] == rm.calls, dm
     low = effect.SSGIEffect(None, scene, f.camera, dict(width=32, height=16, preset="low"), seeds=dict(ssgi=1, denoise=2))
     assert js["low"] == [low.steps, low.refineSteps, low.denoiser.options["denoiseMode"]] == [10, 2, "full_temporal"]
+    hs = effect.SSGIEffect(None, scene, f.camera, dict(width=32, height=16, resolutionScale=0.5), seeds=dict(ssgi=1, denoise=2))
+    tu = hs.denoiser.temporalReprojectPass.uniforms
+    assert js["halfU"] == [hs.ssgiPass.uniforms.resolutionScale, tu.inputWidth, tu.inputHeight] == [0.5, 16, 8]
     # the JS float->half rounding (no Float16Array in Node 12) against numpy's
     want = np.array(HALF_PROBE, np.float32).astype(np.float16).astype(np.float32)
     got = np.array([float(x) for x in js["halfProbe"]], np.float32)

@@ -395,3 +395,50 @@ def test_env_map_through_effect(name):
     scene.environment = None  # :361-366 the define goes away with the environment
     fx.update(r, None)
     assert fx.ssgiPass.uniforms.useEnvMap == 0 and r.env is None
+
+
+@pytest.mark.parametrize("name", G.GOLDEN_RS)
+def test_resolution_scale(name, blue_noise):
+    """resolutionScale < 1 (SSGIPass.js:52-57): K1 renders a (W*s) x (H*s) target whose `resolution` drives vUv and the blue-noise pixel;
+    K2 samples that smaller texture NEAREST at full-resolution vUv (its 5x5 neighbourhood then revisits texels).  Stage-wise, then the
+    whole chain through SSGIEffect(resolutionScale=...)."""
+    import types
+    from oracle_renderer import OracleRenderer
+    from rfx_amd.effect import SSGIEffect
+
+    g = G.load(name)
+    W, H, nf, rs = int(g["width"]), int(g["height"]), int(g["frames"]), float(g["resolutionScale"])
+    oW, oH = int(W * rs), int(H * rs)
+    assert g["f0_ssgi"].shape == (oH, oW, 4)
+    z16, zf = np.zeros((H, W, 4), np.uint16), np.zeros((H, W, 4), np.float32)
+    for fi in range(nf):
+        f = G.frame(g, fi)
+        k, kp = "f%d_" % fi, "f%d_" % (fi - 1)
+        sp, tp, _, _ = stage_params(g, fi, 0.0 if fi == 0 else 1.0)
+        sp.resolutionScale = rs
+        hist = np.ascontiguousarray(g[kp + "compose"]) if fi else zf
+        o = O.ssgi(f.depth, f.gbuffer, f.direct, hist, blue_noise, sp)
+        assert o.shape == (oH, oW, 4)
+        ga, gb = O.unpack_ssgi(g[k + "ssgi"])
+        oa, ob = O.unpack_ssgi(o)
+        assert_close(name + " ssgi.diffuse f%d" % fi, oa, ga, FLIP["ssgi"] * 2)
+        assert_close(name + " ssgi.specular f%d" % fi, ob, gb, FLIP["ssgi"] * 2)
+        tp.inputWidth, tp.inputHeight = oW, oH
+        B = [np.ascontiguousarray(g[kp + "B%d" % j]) if fi else z16 for j in range(2)]
+        T = [np.ascontiguousarray(g[kp + "temporal%d" % j]) if fi else zf.copy() for j in range(2)]
+        O.temporal(np.ascontiguousarray(g[k + "ssgi"]), f.velocity, B[0], B[1], tp, T[0], T[1])
+        for j in range(2):
+            assert_close(name + " temporal%d f%d" % (j, fi), T[j], g[k + "temporal%d" % j], FLIP["temporal"])
+    # through the effect
+    scene = types.SimpleNamespace(frame=None)
+    cam = G.camera(g, 0)
+    fx = SSGIEffect(None, scene, cam, dict(steps=int(g["steps"]), refineSteps=int(g["refineSteps"]), denoiseIterations=1, resolutionScale=rs, width=W, height=H),
+                    seeds=dict(ssgi=int(g["ssgi_start"]), denoise=int(g["denoise_start"])))
+    assert (fx.denoiser.temporalReprojectPass.uniforms.inputWidth, fx.denoiser.temporalReprojectPass.uniforms.inputHeight) == (oW, oH)
+    r = OracleRenderer(W, H)
+    for fi in range(nf):
+        scene.frame = G.frame(g, fi)
+        for kk, vv in vars(G.camera(g, fi)).items():
+            setattr(cam, kk, vv)
+        fx.update(r, None)
+        assert_close(name + " chain compose f%d" % fi, r.tex[abi.TEX_COMPOSE], g["f%d_compose" % fi], 0.03 * (fi + 1))
