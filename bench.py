@@ -47,11 +47,11 @@ PMC_KERNEL = {"k1_ssgi_march": "k1_ssgi_march", "k2_temporal_reproject": "k2_tem
 
 def pmc_traffic(kernel_key):
     """HBM-side bytes per launch of a kernel from the committed PMC summary of this same command
-    (profiles/r01_opt/pmc_hbm.csv: separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, values in KiB).
+    (profiles/r01_final/pmc_hbm.csv: separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, values in KiB).
     gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half the bytes of wide coalesced reads -> x2.
     Returns None when the summary is missing or was taken at another frame size."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_opt", "pmc_hbm.csv")
+    path = os.path.join(ROOT, "profiles", "r01_final", "pmc_hbm.csv")
     if not os.path.exists(path):
         return None
     vals = {}
@@ -230,7 +230,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic(dom) if (W, rows) == (W4K, H4K) else None,
-                         "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_opt/pmc_hbm.csv (rocprofv3 --pmc, same command, 4K)",
+                         "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_final/pmc_hbm.csv (rocprofv3 --pmc, same command, 4K)",
                          "algorithmic_bytes_per_launch": BYTES_PER_PX[dom] * px_tile, "avg_launch_ms": round(kms[dom], 4)},
             "halo_violations": viol,
         }

@@ -1,0 +1,49 @@
+#!/bin/bash
+# Run ON THE GPU BOX (through gpurun): collects the artefacts profiles/README.md describes into gpurun_out/<name>/, to be copied into
+# profiles/<name>/ afterwards.   tools/collect_profiles.sh r01_final
+set -u
+NAME=${1:-profile}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$NAME
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+# 1. the bench line itself (un-profiled, with the CPU baselines)
+python $ROOT/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+# 2. kernel trace + stats
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- $BENCH > $OUT/trace.log 2>&1
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
+# 3. counters, one set per pass (never combined with other trace domains)
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
+           "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS_F32" "TCC_HIT_sum TCC_MISS_sum" "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc$i -o p --output-format csv -- $BENCH > $OUT/pmc$i.log 2>&1 || echo "pmc set $i failed: $set" >> $OUT/errors.txt
+done
+python - "$OUT" <<'PY'
+import csv, collections, glob, sys
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "rocclr" in k or "Cijk" in k or "at::" in k or "elementwise" in k:
+            continue
+        acc[r["Counter_Name"]][k].append(float(r["Counter_Value"]))
+with open(out + "/pmc_hbm.csv", "w") as fh:
+    w = csv.writer(fh); w.writerow(["counter", "kernel", "dispatches", "mean_value_KB"])
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for k, v in sorted(acc[c].items()):
+            w.writerow([c, k, len(v), round(sum(v) / len(v), 1)])
+with open(out + "/pmc_sq_l2.csv", "w") as fh:
+    w = csv.writer(fh); w.writerow(["kernel", "counter", "dispatches", "mean_value"])
+    for c in sorted(acc):
+        if c in ("FETCH_SIZE", "WRITE_SIZE"):
+            continue
+        for k, v in sorted(acc[c].items()):
+            w.writerow([k, c, len(v), "%.4g" % (sum(v) / len(v))])
+PY
+rm -rf $OUT/trace $OUT/pmc[0-9]* 
+ls -la $OUT
+tail -1 $OUT/bench.json | cut -c1-300
