@@ -63,6 +63,29 @@ def pmc_traffic(kernel_key):
     return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
 
 
+# measured on MI355X by tools/microbench/valu_rates.hip (profiles/r01_final/valu_rates.txt): a wave64 fp32 VALU instruction issues every
+# 1.026 ns per SIMD at 8 waves/SIMD (2 cycles at the ~1.95 GHz the part sustains), a transcendental (v_exp/v_log/v_rcp/v_sqrt) every 4.1 ns
+VALU_NS, TRANS_NS, N_SIMD = 1.0 / 0.975, 4.1, 256 * 4
+
+
+def valu_floor_ms(kernel_key, pixels):
+    """Issue-bound time of a kernel: its VALU instruction counts per wavefront (committed PMC summary, profiles/r01_final/pmc_sq_l2.csv:
+    SQ_INSTS_VALU, SQ_INSTS_VALU_TRANS_F32, SQ_WAVES — a property of the code, not of the run) priced at the measured issue rates."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_final", "pmc_sq_l2.csv")
+    if not os.path.exists(path):
+        return None
+    c = {}
+    for r in csv.DictReader(open(path)):
+        if PMC_KERNEL[kernel_key] in r["kernel"]:
+            c[r["counter"]] = float(r["mean_value"])
+    if not all(k in c for k in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_WAVES")):
+        return None
+    valu, trans = c["SQ_INSTS_VALU"] / c["SQ_WAVES"], c["SQ_INSTS_VALU_TRANS_F32"] / c["SQ_WAVES"]
+    waves_per_simd = pixels / 64.0 / N_SIMD
+    return ((valu - trans) * VALU_NS + trans * TRANS_NS) * waves_per_simd * 1e-6
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -234,6 +257,12 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_PX[dom] * px_tile, "avg_launch_ms": round(kms[dom], 4)},
             "halo_violations": viol,
         }
+        # the bound that actually binds: VALU issue — reported next to the HBM roofline the metric asks for
+        floors = {k: valu_floor_ms(k, px_tile) for k in kms}
+        if all(v is not None for v in floors.values()):
+            out["valu_issue_roofline"] = {"floor_ms": {k: round(v, 4) for k, v in floors.items()}, "sum_floor_ms": round(sum(floors.values()), 4),
+                                          "frac": round(sum(floors.values()) / chain_ms, 4),
+                                          "note": "VALU + transcendental instructions per wave (profiles/r01_final PMC) at the issue rates measured by tools/microbench/valu_rates.hip"}
         if args.checksum:
             out["compose_sha1"], out["frame_rows"] = compose_sha1, H
         if not args.no_cpu_baseline and world == 1:
