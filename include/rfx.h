@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 6
+#define RFX_ABI_VERSION 7
 
 enum {
     RFX_OK = 0,
@@ -199,6 +199,28 @@ int rfx_clear(rfx_ctx *, rfx_tex id); /* zero-fill (render targets start zeroed)
 void *rfx_tex_device_ptr(rfx_ctx *, rfx_tex id);
 /* Use caller-owned device memory (held-rows x width x texel bytes) for a slot. */
 int rfx_bind_external(rfx_ctx *, rfx_tex id, void *device_ptr);
+
+/* ---- importer: engine-side attribute planes (AOVs) instead of pre-packed dumps.  The two calls stand where the raster passes' fragment
+ * epilogues pack their render targets (GBufferMaterial.js:84-89 `packGBuffer(diffuseColor, worldNormal, roughnessFactor, metalnessFactor,
+ * totalEmissiveRadiance)`; VelocityDepthNormalMaterial.js:76-83,186-188 `vec4(vel.xy, packNormal(worldNormal), fragCoordZ)`) and fill rows
+ * [row0, row0+rows) of RFX_TEX_GBUFFER / RFX_TEX_VELOCITY on the device (encode side of gbuffer_packing.glsl).  Planes are host pointers to
+ * `rows` x width tightly packed float32 texels, row 0 of the band first (bottom up).  Texels with depth == 1 keep the passes' clear colour
+ * (0, 0, 0, 1) (GBufferPass.js:103-105). */
+typedef struct rfx_aov_gbuffer {
+    const float *diffuse;    /* RGBA  diffuseColor (material colour x map, alpha)                     */
+    const float *normal;     /* xyz   WORLD-space normal (normalised by the producer; re-scaled by the oct encoder) */
+    const float *roughness;  /* 1     roughnessFactor                                                 */
+    const float *metalness;  /* 1     metalnessFactor                                                 */
+    const float *emissive;   /* rgb   totalEmissiveRadiance                                           */
+    const float *depth;      /* 1     gl_FragCoord.z, 1.0 = not covered; may be NULL (every texel covered) */
+} rfx_aov_gbuffer;
+typedef struct rfx_aov_velocity {
+    const float *velocity;   /* xy    uv-space motion: pos1 - pos0 with pos = clip.xy / clip.w * .5 + .5 (VelocityDepthNormalMaterial.js:76-80) */
+    const float *normal;     /* xyz   WORLD-space normal                                              */
+    const float *depth;      /* 1     gl_FragCoord.z, 1.0 = not covered                               */
+} rfx_aov_velocity;
+int rfx_pack_gbuffer(rfx_ctx *, const rfx_aov_gbuffer *, int row0, int rows);
+int rfx_pack_velocity(rfx_ctx *, const rfx_aov_velocity *, int row0, int rows);
 
 /* ---- scene.environment (SSGIEffect.keepEnvMapUpdated, SSGIEffect.js:309-362): an equirectangular HDR map.  The effect
  * turns its mipmaps on (`generateMipmaps`, LinearMipMapLinearFilter / LinearFilter, :323-328) and K1 samples it with

@@ -628,3 +628,47 @@ def chain_final(c: "GLRefChain", frame, fog_mode=0, **kw):
     """SSGIEffect's own fragment over a chain's current state: inputTexture = outputTexture[0] ?? outputTexture (SSGIEffect.js:139,402)."""
     src = {"full": c.t_compose, "full_temporal": c.t_compose, "temporal": c.t_temporal[0], "denoised": c.t_B[0]}[c.dm]
     return run_final(c.W, c.H, frame.depth, src.read(), frame.direct, frame.camera, fog_mode=fog_mode, **kw)
+
+
+def assemble_pack() -> str:
+    """The encode side of the codec as the raster passes' fragment epilogues call it (GBufferMaterial.js:84-89, VelocityDepthNormalMaterial.js
+    :76-83,186-188), fed from attribute textures instead of the rasteriser's interpolants: target 0 = packGBuffer(...), target 1 =
+    vec4(vel.xy, packNormal(worldNormal), fragCoordZ)."""
+    gb = _rd("gbuffer/shader/gbuffer_packing.glsl")
+    main = """
+varying vec2 vUv;
+uniform highp sampler2D tDiffuse; uniform highp sampler2D tNormal; uniform highp sampler2D tRoughMetal; uniform highp sampler2D tEmissive;
+uniform highp sampler2D tVelocityDepth;
+layout(location = 0) out highp vec4 oGBuffer;
+layout(location = 1) out highp vec4 oVelocity;
+void main() {
+  vec4 diffuseColor = textureLod(tDiffuse, vUv, 0.);
+  vec3 worldNormal = textureLod(tNormal, vUv, 0.).xyz;
+  vec2 rm = textureLod(tRoughMetal, vUv, 0.).xy;
+  vec3 totalEmissiveRadiance = textureLod(tEmissive, vUv, 0.).xyz;
+  vec4 vd = textureLod(tVelocityDepth, vUv, 0.);
+  oGBuffer = packGBuffer(diffuseColor, worldNormal, rm.x, rm.y, totalEmissiveRadiance);
+  oVelocity = vec4(vd.x, vd.y, packNormal(worldNormal), vd.z);
+}
+"""
+    return three_prefix({}, True) + gb + main
+
+
+def run_pack(aov: dict, depth: np.ndarray):
+    """Both packers on llvmpipe; returns (gbuffer, velocity) as (H, W, 4) uint32 bit patterns (texels with depth == 1 are whatever the
+    packers make of the planes there — the clear colour is the rasteriser's business, not theirs)."""
+    H, W = depth.shape
+    p = Program(assemble_pack())
+    rgba = lambda a: np.ascontiguousarray(np.concatenate([a, np.zeros(a.shape[:2] + (4 - a.shape[2],), np.float32)], -1), np.float32)
+    t = {"tDiffuse": Tex(W, H, FMT_RGBA32F, data=rgba(aov["diffuse"])), "tNormal": Tex(W, H, FMT_RGBA32F, data=rgba(aov["normal"])),
+         "tRoughMetal": Tex(W, H, FMT_RGBA32F, data=rgba(np.stack([aov["roughness"], aov["metalness"]], -1))),
+         "tEmissive": Tex(W, H, FMT_RGBA32F, data=rgba(aov["emissive"])),
+         "tVelocityDepth": Tex(W, H, FMT_RGBA32F, data=rgba(np.concatenate([aov["velocity"], depth[..., None]], -1)))}
+    for k, v in t.items():
+        p.sampler(k, v)
+    og, ov = Tex(W, H, FMT_RGBA32F), Tex(W, H, FMT_RGBA32F)
+    p.draw([og, ov])
+    g, v = og.read().view(np.uint32), ov.read().view(np.uint32)
+    for x in list(t.values()) + [og, ov]:
+        x.free()
+    return g, v

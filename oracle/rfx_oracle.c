@@ -600,6 +600,58 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
     }
 }
 
+/* ==================================================================== encode side of the codec (the raster passes' fragment epilogues)
+ * packGBuffer gbuffer_packing.glsl:166-178 over attribute planes; texels with depth == 1 keep the clear colour (0,0,0,1). */
+static inline uint32_t enc_vec4_to_float(float x, float y, float z, float w) { /* vec4ToFloat :143-149 */
+    const float o = 0.0001f, one = 0.999999f;
+    uint32_t r = (uint32_t)(fminf(x + o, one) * 255.0f), g = (uint32_t)(fminf(y + o, one) * 255.0f);
+    uint32_t b = (uint32_t)(fminf(z + o, one) * 255.0f), a = (uint32_t)(fminf(w + o, one) * 255.0f);
+    return (a << 24) | (b << 16) | (g << 8) | r;
+}
+static inline uint32_t enc_pack_normal(float nx, float ny, float nz) { /* packNormal(encodeOctWrap) :36-61 */
+    float s = fabsf(nx) + fabsf(ny) + fabsf(nz);
+    nx /= s; ny /= s; nz /= s;
+    float wx = 1.0f - fabsf(ny), wy = 1.0f - fabsf(nx);
+    if (nx < 0.0f) wx = -wx;
+    if (ny < 0.0f) wy = -wy;
+    float ox = nz > 0.0f ? nx : wx, oy = nz > 0.0f ? ny : wy;
+    return pack_half2(ox * 0.5f + 0.5f, oy * 0.5f + 0.5f);
+}
+static inline float enc_color2float(float r, float g, float b) { /* color2float :17-22 */
+    const float o = 0.0001f, one = 0.999999f;
+    r = fminf(r + o, one); g = fminf(g + o, one); b = fminf(b + o, one);
+    return floorf(r * 256.0f + 0.5f) + floorf(b * 256.0f + 0.5f) * 257.0f + floorf(g * 256.0f + 0.5f) * 257.0f * 257.0f;
+}
+static inline uint32_t enc_rgbe8(float r, float g, float b) { /* vec4ToFloat(encodeRGBE8) :127-134 */
+    float mx = fmaxf(fmaxf(r, g), b);
+    float fexp = ceilf(log2f(mx)), sc = exp2f(fexp);
+    return enc_vec4_to_float(r / sc, g / sc, b / sc, (fexp + 128.0f) / 255.0f);
+}
+int rfxo_pack_gbuffer(int n, const float *diffuse, const float *normal, const float *roughness, const float *metalness, const float *emissive,
+                      const float *depth, uint32_t *out) {
+    for (int i = 0; i < n; i++) {
+        uint32_t *o = out + 4 * (size_t)i;
+        if (depth && depth[i] == 1.0f) { o[0] = o[1] = o[2] = 0; o[3] = 0x3f800000u; continue; }
+        o[0] = enc_vec4_to_float(diffuse[4 * i], diffuse[4 * i + 1], diffuse[4 * i + 2], diffuse[4 * i + 3]);
+        o[1] = enc_pack_normal(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
+        float f = enc_color2float(roughness[i], metalness[i], 0.0f);
+        memcpy(&o[2], &f, 4);
+        o[3] = enc_rgbe8(emissive[3 * i], emissive[3 * i + 1], emissive[3 * i + 2]);
+    }
+    return 0;
+}
+/* VelocityDepthNormalMaterial.js:76-83,186-188: vec4(vel.xy, packNormal(worldNormal), fragCoordZ) */
+int rfxo_pack_velocity(int n, const float *velocity, const float *normal, const float *depth, uint32_t *out) {
+    for (int i = 0; i < n; i++) {
+        uint32_t *o = out + 4 * (size_t)i;
+        if (depth[i] == 1.0f) { o[0] = o[1] = o[2] = 0; o[3] = 0x3f800000u; continue; }
+        memcpy(&o[0], &velocity[2 * i], 4); memcpy(&o[1], &velocity[2 * i + 1], 4);
+        o[2] = enc_pack_normal(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]);
+        memcpy(&o[3], &depth[i], 4);
+    }
+    return 0;
+}
+
 /* The mip chain of scene.environment as glGenerateMipmap builds it on the oracle's GL (measured on llvmpipe): level 0 = the texels in the
  * texture's type, every further level the 2x2 bilinear-centre average lerp(.5, lerp(.5,a,b), lerp(.5,c,d)) stored in that type
  * (half: RTZ when `rtz`, as llvmpipe).  `out` receives all levels back to back; returns the number of levels. */

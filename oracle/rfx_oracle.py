@@ -145,6 +145,27 @@ def final(depth, gi, scene, params: abi.FinalParams, out=None, rows=None):
     return out
 
 
+def pack_gbuffer(aov: dict, depth=None) -> np.ndarray:
+    """packGBuffer over attribute planes (GBufferMaterial's fragment epilogue) -> (H, W, 4) uint32 texels."""
+    H, W = aov["roughness"].shape
+    out = np.zeros((H, W, 4), np.uint32)
+    f = lambda k: _p(np.ascontiguousarray(aov[k], np.float32))
+    keep = [np.ascontiguousarray(aov[k], np.float32) for k in ("diffuse", "normal", "roughness", "metalness", "emissive")]
+    d = np.ascontiguousarray(depth, np.float32) if depth is not None else None
+    rc = lib().rfxo_pack_gbuffer(H * W, _p(keep[0]), _p(keep[1]), _p(keep[2]), _p(keep[3]), _p(keep[4]), _p(d), _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def pack_velocity(aov: dict, depth) -> np.ndarray:
+    H, W = depth.shape
+    out = np.zeros((H, W, 4), np.uint32)
+    v, n, d = (np.ascontiguousarray(a, np.float32) for a in (aov["velocity"], aov["normal"], depth))
+    rc = lib().rfxo_pack_velocity(H * W, _p(v), _p(n), _p(d), _p(out))
+    assert rc == 0, rc
+    return out
+
+
 def half_bits_to_float(h: np.ndarray) -> np.ndarray:
     return h.view(np.float16).astype(np.float32)
 

@@ -260,6 +260,63 @@ static void launch_rows(rfx_ctx *c, int out_id, int extra, int *y0, int *y1) {
     *y0 = a; *y1 = b;
 }
 
+// stage `n` host planes (floats per texel in `ch`) of a band on the device, back to back; returns the device base in *stage
+static int stage_planes(rfx_ctx *c, const float *const *host, const int *ch, int n, size_t texels, float **stage, const float **dev) {
+    size_t total = 0;
+    for (int i = 0; i < n; i++) total += host[i] ? texels * ch[i] : 0;
+    hipError_t e = hipMalloc((void **)stage, total * sizeof(float));
+    if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(AOV staging)", e);
+    size_t off = 0;
+    for (int i = 0; i < n; i++) {
+        dev[i] = nullptr;
+        if (!host[i]) continue;
+        dev[i] = *stage + off;
+        e = hipMemcpyAsync(*stage + off, host[i], texels * ch[i] * sizeof(float), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { hipFree(*stage); return fail(c, RFX_EDEVICE, "hipMemcpyAsync(AOV plane)", e); }
+        off += texels * ch[i];
+    }
+    return RFX_OK;
+}
+
+int rfx_pack_gbuffer(rfx_ctx *c, const rfx_aov_gbuffer *a, int row0, int rows) {
+    if (!c || !a || !a->diffuse || !a->normal || !a->roughness || !a->metalness || !a->emissive) return RFX_EINVAL;
+    int rc = band_check(c, RFX_TEX_GBUFFER, row0, rows);
+    if (rc) return rc;
+    if ((rc = ensure(c, RFX_TEX_GBUFFER))) return rc;
+    hipSetDevice(c->device);
+    const float *host[6] = {a->diffuse, a->normal, a->roughness, a->metalness, a->emissive, a->depth}, *dev[6];
+    const int ch[6] = {4, 3, 1, 1, 3, 1};
+    float *stage = nullptr;
+    if ((rc = stage_planes(c, host, ch, 6, (size_t)rows * c->W, &stage, dev))) return rc;
+    Slot &s = c->slots[RFX_TEX_GBUFFER];
+    hipError_t e = rfx_launch_pack_gbuffer(c->W, rows, dev[0], dev[1], dev[2], dev[3], dev[4], dev[5],
+                                           (char *)s.ptr + (size_t)(row0 - s.row0) * s.width * s.texel, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // the caller may free the planes as soon as we return
+    hipFree(stage);
+    if (e != hipSuccess) return fail(c, RFX_EDEVICE, "rfx_pack_gbuffer", e);
+    s.uploaded = true;
+    return RFX_OK;
+}
+
+int rfx_pack_velocity(rfx_ctx *c, const rfx_aov_velocity *a, int row0, int rows) {
+    if (!c || !a || !a->velocity || !a->normal || !a->depth) return RFX_EINVAL;
+    int rc = band_check(c, RFX_TEX_VELOCITY, row0, rows);
+    if (rc) return rc;
+    if ((rc = ensure(c, RFX_TEX_VELOCITY))) return rc;
+    hipSetDevice(c->device);
+    const float *host[3] = {a->velocity, a->normal, a->depth}, *dev[3];
+    const int ch[3] = {2, 3, 1};
+    float *stage = nullptr;
+    if ((rc = stage_planes(c, host, ch, 3, (size_t)rows * c->W, &stage, dev))) return rc;
+    Slot &s = c->slots[RFX_TEX_VELOCITY];
+    hipError_t e = rfx_launch_pack_velocity(c->W, rows, dev[0], dev[1], dev[2], (char *)s.ptr + (size_t)(row0 - s.row0) * s.width * s.texel, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(stage);
+    if (e != hipSuccess) return fail(c, RFX_EDEVICE, "rfx_pack_velocity", e);
+    s.uploaded = true;
+    return RFX_OK;
+}
+
 int rfx_set_environment(rfx_ctx *c, const float *rgba, int width, int height, int halfFloatType, int halfStoreRTZ) {
     if (!c) return RFX_EINVAL;
     hipSetDevice(c->device);

@@ -65,6 +65,11 @@ struct K4Args {
     rfx_compose_params p;
 };
 
+// K0 importer (k0_import.hip): device staging planes of `rows` rows -> packed texels
+hipError_t rfx_launch_pack_gbuffer(int W, int rows, const float *diffuse, const float *normal, const float *roughness, const float *metalness,
+                                   const float *emissive, const float *depth, void *out, hipStream_t);
+hipError_t rfx_launch_pack_velocity(int W, int rows, const float *velocity, const float *normal, const float *depth, void *out, hipStream_t);
+
 struct K5Args {
     FrameDims dims;
     int y0, y1;

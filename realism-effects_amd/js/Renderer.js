@@ -104,6 +104,16 @@ class Renderer {
 		addon.clear(this._h, tex)
 	}
 
+	// importer: unpacked attribute planes (Float32Arrays over rows [row0, row0+rows)) -> the packed render targets (rfx_pack_gbuffer / _velocity)
+	packGBuffer(aov, row0, rows) {
+		const held = this.heldRows(TEX.GBUFFER)
+		addon.packGBuffer(this._h, aov, row0 === undefined ? held[0] : row0, rows === undefined ? held[1] : rows)
+	}
+	packVelocity(aov, row0, rows) {
+		const held = this.heldRows(TEX.VELOCITY)
+		addon.packVelocity(this._h, aov, row0 === undefined ? held[0] : row0, rows === undefined ? held[1] : rows)
+	}
+
 	// scene.environment: Float32Array(H*W*4) equirect map (row 0 = bottom) or null — rfx_set_environment
 	setEnvironment(data, width, height, halfFloatType, halfStoreRTZ) {
 		addon.setEnvironment(this._h, data || null, width || 0, height || 0, halfFloatType ? 1 : 0, halfStoreRTZ ? 1 : 0)

@@ -135,8 +135,14 @@ class GBufferPass {
 		this.height = height
 	}
 	render(renderer) {
-		renderer.uploadPlane(TEX.DEPTH, this._scene.frame.depth)
-		renderer.uploadPlane(TEX.GBUFFER, this._scene.frame.gbuffer)
+		const f = this._scene.frame
+		renderer.uploadPlane(TEX.DEPTH, f.depth)
+		if (f.gbuffer) renderer.uploadPlane(TEX.GBUFFER, f.gbuffer)
+		else if (renderer._packedGBuffer !== f.aov) {
+			// an engine dump of UNPACKED whole-frame attribute planes: the device packs them (rfx_pack_gbuffer = the pass's fragment epilogue)
+			renderer.packGBuffer(Object.assign({ depth: f.depth }, f.aov), 0, renderer.height)
+			renderer._packedGBuffer = f.aov
+		}
 	}
 	dispose() {}
 }
@@ -156,7 +162,12 @@ class VelocityDepthNormalPass {
 		this.height = height
 	}
 	render(renderer) {
-		renderer.uploadPlane(TEX.VELOCITY, this._scene.frame.velocity)
+		const f = this._scene.frame
+		if (f.velocity) renderer.uploadPlane(TEX.VELOCITY, f.velocity)
+		else if (renderer._packedVelocity !== f.aov) {
+			renderer.packVelocity({ velocity: f.aov.velocity, normal: f.aov.normal, depth: f.depth }, 0, renderer.height)
+			renderer._packedVelocity = f.aov
+		}
 	}
 	dispose() {}
 }

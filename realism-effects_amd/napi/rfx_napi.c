@@ -206,6 +206,52 @@ static napi_value n_clear(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+static const float *f32_prop(napi_env env, napi_value obj, const char *name, size_t want, int optional, int *ok) {
+    napi_value v;
+    bool has = false;
+    napi_valuetype vt = napi_undefined;
+    if (napi_has_named_property(env, obj, name, &has) == napi_ok && has && napi_get_named_property(env, obj, name, &v) == napi_ok) napi_typeof(env, v, &vt);
+    if (!has || vt == napi_null || vt == napi_undefined) {
+        if (!optional) { napi_throw_type_error(env, NULL, "AOV plane missing"); *ok = 0; }
+        return NULL;
+    }
+    napi_typedarray_type tt;
+    size_t len;
+    void *ptr;
+    if (napi_get_typedarray_info(env, v, &tt, &len, &ptr, NULL, NULL) != napi_ok || tt != napi_float32_array || len != want) {
+        napi_throw_type_error(env, NULL, "AOV plane: Float32Array of rows * width * channels expected");
+        *ok = 0;
+        return NULL;
+    }
+    return (const float *)ptr;
+}
+
+/* packGBuffer(ctx, {diffuse, normal, roughness, metalness, emissive, depth?}, row0, rows) / packVelocity(ctx, {velocity, normal, depth}, row0, rows) */
+static napi_value n_pack(napi_env env, napi_callback_info info, int velocity) {
+    napi_value a[4];
+    int32_t row0, rows, W = 0;
+    if (!get_args(env, info, 4, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[2], &row0) || !get_int(env, a[3], &rows)) return NULL;
+    rfx_get_geometry(c, &W, NULL, NULL, NULL, NULL);
+    const size_t n = (size_t)rows * (size_t)W;
+    int ok = 1, rc;
+    if (velocity) {
+        rfx_aov_velocity v = {f32_prop(env, a[1], "velocity", 2 * n, 0, &ok), f32_prop(env, a[1], "normal", 3 * n, 0, &ok), f32_prop(env, a[1], "depth", n, 0, &ok)};
+        if (!ok) return NULL;
+        rc = rfx_pack_velocity(c, &v, row0, rows);
+    } else {
+        rfx_aov_gbuffer g = {f32_prop(env, a[1], "diffuse", 4 * n, 0, &ok), f32_prop(env, a[1], "normal", 3 * n, 0, &ok), f32_prop(env, a[1], "roughness", n, 0, &ok),
+                             f32_prop(env, a[1], "metalness", n, 0, &ok), f32_prop(env, a[1], "emissive", 3 * n, 0, &ok), f32_prop(env, a[1], "depth", n, 1, &ok)};
+        if (!ok) return NULL;
+        rc = rfx_pack_gbuffer(c, &g, row0, rows);
+    }
+    if (rc) return throw_rfx(env, c, velocity ? "rfx_pack_velocity" : "rfx_pack_gbuffer", rc);
+    return NULL;
+}
+static napi_value n_pack_gbuffer(napi_env env, napi_callback_info info) { return n_pack(env, info, 0); }
+static napi_value n_pack_velocity(napi_env env, napi_callback_info info) { return n_pack(env, info, 1); }
+
 /* setEnvironment(ctx, Float32Array | null, width, height, halfFloatType, halfStoreRTZ) — scene.environment (rfx_set_environment) */
 static napi_value n_set_environment(napi_env env, napi_callback_info info) {
     napi_value a[6];
@@ -424,7 +470,7 @@ static napi_value n_time_end(napi_env env, napi_callback_info info) {
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
-        {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"ssgiMarch", n_ssgi}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
+        {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
         {"sync", n_sync}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

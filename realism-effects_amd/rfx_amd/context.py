@@ -109,6 +109,32 @@ class Context:
             r0, n = self.held_rows(tex)
             self.upload(tex, plane[r0:r0 + n], r0, n)
 
+    # -- importer: engine-side attribute planes -> packed render targets, on the device
+    @staticmethod
+    def _plane(a, ch, rows, width):
+        a = np.ascontiguousarray(a, np.float32)
+        if a.size != rows * width * ch:
+            raise ValueError("AOV plane: expected %d x %d x %d floats, got %s" % (rows, width, ch, a.shape))
+        return a
+
+    def pack_gbuffer(self, aov: dict, depth=None, row0: int | None = None, rows: int | None = None):
+        """rfx_pack_gbuffer: `aov` holds diffuse (RGBA), normal (xyz, world), roughness, metalness, emissive (rgb) planes of the band
+        [row0, row0+rows) (default: everything the context holds); `depth` (1.0 = not covered) may be None."""
+        h0, hn = self.held_rows(abi.TEX_GBUFFER)
+        row0, rows = (h0 if row0 is None else row0), (hn if rows is None else rows)
+        keep = [self._plane(aov[k], ch, rows, self.W) for k, ch in (("diffuse", 4), ("normal", 3), ("roughness", 1), ("metalness", 1), ("emissive", 3))]
+        d = self._plane(depth, 1, rows, self.W) if depth is not None else None
+        ptr = lambda a: a.ctypes.data_as(abi.FP) if a is not None else None
+        s = abi.AovGBuffer(ptr(keep[0]), ptr(keep[1]), ptr(keep[2]), ptr(keep[3]), ptr(keep[4]), ptr(d))
+        self._chk(self.lib.rfx_pack_gbuffer(self._h, C.byref(s), row0, rows), "rfx_pack_gbuffer")
+
+    def pack_velocity(self, aov: dict, depth, row0: int | None = None, rows: int | None = None):
+        h0, hn = self.held_rows(abi.TEX_VELOCITY)
+        row0, rows = (h0 if row0 is None else row0), (hn if rows is None else rows)
+        v, n, d = self._plane(aov["velocity"], 2, rows, self.W), self._plane(aov["normal"], 3, rows, self.W), self._plane(depth, 1, rows, self.W)
+        s = abi.AovVelocity(v.ctypes.data_as(abi.FP), n.ctypes.data_as(abi.FP), d.ctypes.data_as(abi.FP))
+        self._chk(self.lib.rfx_pack_velocity(self._h, C.byref(s), row0, rows), "rfx_pack_velocity")
+
     def set_environment(self, rgba, half_float_type=True, half_store_rtz=True):
         """scene.environment: an (H, W, 4) float32 equirectangular map (row 0 = bottom), or None to remove it."""
         if rgba is None:

@@ -126,6 +126,18 @@ def _upload_plane(renderer, tex, plane):
     cache[tex] = plane
 
 
+def _pack_planes(renderer, tex, aov, depth, pack):
+    """Device-side packing of a dumped frame's attribute planes into `tex` (once per aov object, like _upload_plane)."""
+    cache = renderer.__dict__.setdefault("_resident_planes", {})
+    if cache.get(tex) is aov:
+        return
+    r0, n = renderer.held_rows(tex)
+    full = depth.shape[0] != n  # the caller dumped the whole frame: hand over the band this tile holds
+    band = {k: (v[r0:r0 + n] if full else v) for k, v in aov.items()}
+    pack(band, depth[r0:r0 + n] if full else depth, r0, n)
+    cache[tex] = aov
+
+
 class GBufferPass:
     """Stand-in for src/gbuffer/GBufferPass.js: the rasteriser is out of scope (SURVEY.md §2 row 4);
     `render` uploads the pre-dumped packed G-buffer + depth planes of `scene.frame`."""
@@ -139,8 +151,11 @@ class GBufferPass:
 
     def render(self, renderer):
         f = self._scene.frame
-        for tex, plane in ((abi.TEX_DEPTH, f.depth), (abi.TEX_GBUFFER, f.gbuffer)):
-            _upload_plane(renderer, tex, plane)
+        _upload_plane(renderer, abi.TEX_DEPTH, f.depth)
+        if getattr(f, "gbuffer", None) is not None:
+            _upload_plane(renderer, abi.TEX_GBUFFER, f.gbuffer)
+        else:  # an engine dump of UNPACKED attribute planes: the device packs them (rfx_pack_gbuffer = the pass's fragment epilogue)
+            _pack_planes(renderer, abi.TEX_GBUFFER, f.aov, f.depth, renderer.pack_gbuffer)
 
     def dispose(self):
         pass
@@ -162,7 +177,11 @@ class VelocityDepthNormalPass:
         self.width, self.height = width, height
 
     def render(self, renderer):
-        _upload_plane(renderer, abi.TEX_VELOCITY, self._scene.frame.velocity)
+        f = self._scene.frame
+        if getattr(f, "velocity", None) is not None:
+            _upload_plane(renderer, abi.TEX_VELOCITY, f.velocity)
+        else:  # unpacked planes (uv-space velocity, world normal, depth): rfx_pack_velocity
+            _pack_planes(renderer, abi.TEX_VELOCITY, f.aov, f.depth, renderer.pack_velocity)
 
     def dispose(self):
         pass

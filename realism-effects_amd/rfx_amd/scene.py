@@ -187,6 +187,7 @@ class Frame:
     camera: Camera
     prev_camera: Camera
     frame_index: int = 0
+    aov: dict | None = None  # unpacked attribute planes (render(..., aov=True)): what an engine exports, input of the device importer
 
 
 class AnalyticScene:
@@ -269,12 +270,14 @@ class AnalyticScene:
         return t_best, mat, nrm
 
     def render(self, width: int, height: int, frame_index: int = 0, row0: int = 0, rows: int | None = None,
-               frame_height: int | None = None, vfov_rows: int | None = None) -> Frame:
+               frame_height: int | None = None, vfov_rows: int | None = None, aov: bool = False) -> Frame:
         """Dump frame `frame_index`.  (row0, rows, frame_height) select a horizontal band of a
         taller frame — used by the row-tiled multi-GPU path; default = the whole frame.
         `vfov_rows`: number of rows that span the nominal 40 deg vertical fov; a taller frame
         (weak scaling: N stacked 4K tiles) widens the vertical fov instead of squeezing the
-        horizontal one."""
+        horizontal one.  `aov=True` also keeps the UNPACKED attribute planes an engine would export (frame.aov: diffuse RGBA,
+        world normal, roughness, metalness, emissive, uv-space velocity) — the input of the device-side importer (rfx_pack_gbuffer /
+        rfx_pack_velocity), which must reproduce `gbuffer` / `velocity` from them."""
         fh = frame_height or height
         rows = rows if rows is not None else height
         aspect = width / fh
@@ -296,6 +299,11 @@ class AnalyticScene:
         vel[..., 3] = one_bits
         direct[..., 3] = 1.0
 
+        planes = None
+        if aov:
+            planes = dict(diffuse=np.zeros((rows, width, 4), np.float32), normal=np.zeros((rows, width, 3), np.float32),
+                          roughness=np.zeros((rows, width), np.float32), metalness=np.zeros((rows, width), np.float32),
+                          emissive=np.zeros((rows, width, 3), np.float32), velocity=np.zeros((rows, width, 2), np.float32))
         xs = (np.arange(width) + 0.5) / width * 2 - 1
         chunk = max(1, (1 << 20) // width)
         o = C[:3, 3]
@@ -352,7 +360,17 @@ class AnalyticScene:
             gb[sl] = np.where(hm[..., None], g.reshape(hm.shape + (4,)), gb[sl])
             vel[sl] = np.where(hm[..., None], v4.reshape(hm.shape + (4,)), vel[sl])
             direct[sl] = np.where(hm[..., None], dl.reshape(hm.shape + (4,)), direct[sl])
-        return Frame(width, rows, depth, gb, vel, direct, cam, prev, frame_index)
+            if planes is not None:
+                shp = hm.shape
+                planes["diffuse"][sl] = diff4.reshape(shp + (4,))
+                planes["normal"][sl] = nsafe.astype(np.float32).reshape(shp + (3,))
+                planes["roughness"][sl] = self.mat_rough[m].astype(np.float32).reshape(shp)
+                planes["metalness"][sl] = self.mat_metal[m].astype(np.float32).reshape(shp)
+                planes["emissive"][sl] = self.mat_emissive[m].astype(np.float32).reshape(shp + (3,))
+                planes["velocity"][sl] = velxy.reshape(shp + (2,))
+        fr = Frame(width, rows, depth, gb, vel, direct, cam, prev, frame_index)
+        fr.aov = planes
+        return fr
 
 
 _default_scene = None

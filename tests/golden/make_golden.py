@@ -121,6 +121,22 @@ def run_final(name, W, H):
     print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
 
 
+def run_pack(name, W, H):
+    """The encode side of the codec (packGBuffer, packNormal) on llvmpipe over unpacked attribute planes of the synthetic scene, with HDR
+    emissive values (incl. exact powers of two) sprinkled in."""
+    from rfx_amd.scene import AnalyticScene
+    f = AnalyticScene(1234).render(W, H, 1, aov=True)
+    rng = np.random.RandomState(3)
+    a = {k: v.copy() for k, v in f.aov.items()}
+    m = rng.rand(H, W) < 0.3
+    a["emissive"][m] = (rng.rand(int(m.sum()), 3) * np.array([8, 2, 0.5])).astype(np.float32)
+    a["emissive"][5, 5], a["emissive"][5, 6], a["emissive"][5, 7] = (1.0, 0.5, 0.25), (2.0, 0, 0), (0.5, 0.5, 0.5)
+    g, v = chain.run_pack(a, f.depth)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, width=W, height=H, depth=f.depth, gbuffer=g, velocity=v, gl_info=chain.GL.info(), **{"aov_" + k: x for k, x in a.items()})
+    print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     run("chain_160x90_s20r5_it1", 160, 90, frames=3, steps=20, refine=5, iterations=1)
     run("chain_97x55_s8r2_it2", 97, 55, frames=2, steps=8, refine=2, iterations=2)
@@ -139,3 +155,4 @@ if __name__ == "__main__":
     run_traa("traa_half_128x72", 128, 72, frames=3, half=True)
     run_traa("traa_float_96x54", 96, 54, frames=3, half=False)
     run_final("final_112x63", 112, 63)
+    run_pack("pack_96x54", 96, 54)

@@ -56,6 +56,16 @@ class OracleRenderer:
         b0, n = self.held_rows(abi.TEX_SSGI)
         return max(b0, self.tile_y0 - extra), min(b0 + n, self.tile_y0 + self.tile_rows + extra)
 
+    def pack_gbuffer(self, aov, depth=None, row0=None, rows=None):
+        h0, hn = self.held_rows(abi.TEX_GBUFFER)
+        row0, rows = (h0 if row0 is None else row0), (hn if rows is None else rows)
+        self.tex[abi.TEX_GBUFFER][row0:row0 + rows] = O.pack_gbuffer(aov, depth)
+
+    def pack_velocity(self, aov, depth, row0=None, rows=None):
+        h0, hn = self.held_rows(abi.TEX_VELOCITY)
+        row0, rows = (h0 if row0 is None else row0), (hn if rows is None else rows)
+        self.tex[abi.TEX_VELOCITY][row0:row0 + rows] = O.pack_velocity(aov, depth)
+
     def set_environment(self, rgba, half_float_type=True, half_store_rtz=True):
         self.calls.append(("set_environment", None if rgba is None else tuple(rgba.shape)))
         self.env = None if rgba is None else O.EnvMap(rgba, half=half_float_type, rtz=half_store_rtz)

@@ -754,3 +754,55 @@ def test_resolution_scale_vs_oracle(blue_noise, rs):
     dev = Context(W, H)
     assert_close("rs%g chain compose" % rs, run(dev), run(OracleRenderer(W, H)), 0.06)
     dev.close()
+
+
+def test_import_attribute_planes_vs_oracle():
+    """The device-side importer (rfx_pack_gbuffer / rfx_pack_velocity): engine-style attribute planes -> the reference's packed
+    render targets, bit for bit against the oracle's encoders (themselves pinned to the reference GLSL on llvmpipe); whole frame and row bands;
+    then the chain driven from UNPACKED planes must equal the chain driven from the pre-packed dump."""
+    import types
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.effect import SSGIEffect
+    from rfx_amd.scene import AnalyticScene
+    import rfx_oracle as O
+
+    W, H = 250, 141
+    gen = AnalyticScene(1234)
+    f = gen.render(W, H, 1, aov=True)
+    rng = np.random.RandomState(11)
+    a = {k: v.copy() for k, v in f.aov.items()}
+    m = rng.rand(H, W) < 0.25
+    a["emissive"][m] = (rng.rand(int(m.sum()), 3) * np.array([6, 3, 1])).astype(np.float32)
+    ctx = Context(W, H)
+    ctx.pack_gbuffer(a, f.depth)
+    ctx.pack_velocity(a, f.depth)
+    assert np.array_equal(ctx.download(abi.TEX_GBUFFER), O.pack_gbuffer(a, f.depth))
+    assert np.array_equal(ctx.download(abi.TEX_VELOCITY), O.pack_velocity(a, f.depth))
+    ctx.pack_gbuffer(a, None)  # no coverage plane: every texel is packed
+    assert np.array_equal(ctx.download(abi.TEX_GBUFFER), O.pack_gbuffer(a, None))
+    ctx.clear(abi.TEX_GBUFFER)
+    for r0, n in ((0, 40), (40, 101)):  # two bands
+        ctx.pack_gbuffer({k: v[r0:r0 + n] for k, v in a.items()}, f.depth[r0:r0 + n], r0, n)
+    assert np.array_equal(ctx.download(abi.TEX_GBUFFER), O.pack_gbuffer(a, f.depth))
+    ctx.close()
+
+    def run(frames):
+        c = Context(W, H)
+        scene = types.SimpleNamespace(frame=None)
+        cam = types.SimpleNamespace(**vars(frames[0].camera))
+        fx = SSGIEffect(None, scene, cam, dict(width=W, height=H, steps=10, refineSteps=2), seeds=dict(ssgi=3, denoise=4))
+        for fr in frames:
+            scene.frame = fr
+            for k, v in vars(fr.camera).items():
+                setattr(cam, k, v)
+            fx.update(c, None)
+        out = c.download(abi.TEX_COMPOSE)
+        c.close()
+        return out
+
+    packed = [gen.render(W, H, i, aov=True) for i in range(2)]
+    planes = [types.SimpleNamespace(depth=p.depth, gbuffer=None, velocity=None, direct=p.direct, camera=p.camera, aov=p.aov) for p in packed]
+    a_out, b_out = run(packed), run(planes)
+    # identical but for the emissive word of black-emissive texels (numpy dump writer: 0; reference encoder: 0x00fefefe -> a 2.9e-39 emissive)
+    assert np.abs(a_out - b_out).max() < 1e-30

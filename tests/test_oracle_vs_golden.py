@@ -442,3 +442,29 @@ def test_resolution_scale(name, blue_noise):
             setattr(cam, kk, vv)
         fx.update(r, None)
         assert_close(name + " chain compose f%d" % fi, r.tex[abi.TEX_COMPOSE], g["f%d_compose" % fi], 0.03 * (fi + 1))
+
+
+def test_pack_gbuffer_and_velocity_vs_golden():
+    """Encode side of the codec: packGBuffer / packNormal over attribute planes, bit for bit against the reference GLSL on
+    llvmpipe — except the emissive word of BLACK-emissive texels: encodeRGBE8 takes log2(0) there (Appendix D-9) and what comes out depends
+    on how the platform converts -inf to uint (llvmpipe: exponent byte 255, which DECODES to ~1e38; GPUs and this importer saturate to 0,
+    which decodes to 0)."""
+    g = G.load(G.GOLDEN_PACK)
+    aov = {k[4:]: g[k] for k in g.files if k.startswith("aov_")}
+    depth = np.ascontiguousarray(g["depth"])
+    cov, lit = depth < 1.0, aov["emissive"].max(-1) > 0
+    og = O.pack_gbuffer(aov, None)
+    for ch in range(3):
+        assert np.array_equal(og[..., ch][cov], g["gbuffer"][..., ch][cov]), ch
+    assert np.array_equal(og[..., 3][cov & lit], g["gbuffer"][..., 3][cov & lit])
+    assert set(np.unique(og[..., 3][cov & ~lit])) == {0x00fefefe} and set(np.unique(g["gbuffer"][..., 3][cov & ~lit])) == {0xfffefefe}
+    ov = O.pack_velocity(aov, depth)
+    assert np.array_equal(ov[cov], g["velocity"][cov])
+    # uncovered texels keep the passes' clear colour (0, 0, 0, 1)
+    og2 = O.pack_gbuffer(aov, depth)
+    assert (og2[~cov] == np.array([0, 0, 0, 0x3f800000], np.uint32)).all() and (ov[~cov] == np.array([0, 0, 0, 0x3f800000], np.uint32)).all()
+    # and the synthetic dumps' own (numpy) packer agrees with the importer wherever the emissive is lit or black alike decodes to 0
+    from rfx_amd.scene import AnalyticScene
+    f = AnalyticScene(1234).render(96, 54, 1, aov=True)
+    p = O.pack_gbuffer(f.aov, f.depth)
+    assert np.array_equal(p[..., :3], f.gbuffer[..., :3]) and np.array_equal(O.pack_velocity(f.aov, f.depth), f.velocity)
