@@ -240,6 +240,30 @@ def test_node_host_drives_the_gpu_bit_identically(tmp_path):
         js = np.fromfile(os.path.join(out, name + ".bin"), py.dtype).reshape(py.shape)
         assert np.array_equal(py.view(np.uint8), js.view(np.uint8)), name
     ctx.close()
+    # the Node host from UNPACKED attribute planes (device-side importer) == the Python host from the same planes
+    gen_frames = [__import__("rfx_amd.scene", fromlist=["AnalyticScene"]).AnalyticScene(1234).render(W, H, i, aov=True) for i in range(2)]
+    adirs = []
+    for i, fr in enumerate(gen_frames):
+        d = str(tmp_path / ("aov%d" % i))
+        write_dump(d, fr, packed=False)
+        adirs.append(d)
+    out = str(tmp_path / "js_aov")
+    subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + adirs + ["--out", out, "--steps", "12", "--refineSteps", "3"], text=True)
+    from rfx_amd.dump import read_dump
+    scene = types.SimpleNamespace(frame=None)
+    cam = types.SimpleNamespace(**vars(gen_frames[0].camera))
+    fx2 = effect.SSGIEffect(None, scene, cam, dict(width=W, height=H, steps=12, refineSteps=3), seeds=dict(ssgi=11, denoise=22), half_store_rtz=True)
+    ctx = Context(W, H)
+    for d, fr in zip(adirs, gen_frames):
+        scene.frame = read_dump(d)
+        assert scene.frame.gbuffer is None and scene.frame.aov is not None
+        for k, v in vars(fr.camera).items():
+            setattr(cam, k, v)
+        fx2.update(ctx, None)
+    py = ctx.download(abi.TEX_COMPOSE)
+    js = np.fromfile(os.path.join(out, "compose.bin"), np.float32).reshape(py.shape)
+    assert np.array_equal(py.view(np.uint8), js.view(np.uint8))
+    ctx.close()
     # TRAAEffect through both hosts
     for mode, ttype in (("half", effect.HalfFloatType), ("float", effect.FloatType)):
         out = str(tmp_path / ("js_traa_" + mode))
