@@ -82,7 +82,7 @@ typedef struct rfx_camera {
     float matrixWorldInverse[16]; /* viewMatrix        */
     float position[3];            /* cameraPos (TemporalReprojectPass.js:98) */
     float near_, far_;
-    int32_t isPerspective;        /* only the PERSPECTIVE_CAMERA variant is built (1) */
+    int32_t isPerspective;        /* camera.isPerspectiveCamera -> the PERSPECTIVE_CAMERA define of every pass (1), else the orthographic depth -> view-Z variants (0) */
 } rfx_camera;
 
 /* K1 — SSGIMaterial uniforms/defines (src/ssgi/material/SSGIMaterial.js:15-51,

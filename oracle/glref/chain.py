@@ -93,14 +93,16 @@ def _with_blue_noise(src: str) -> str:
     return src.replace("uniform vec2 resolution;", "uniform vec2 resolution;\n" + _rd("utils/shader/blue_noise.glsl"), 1)
 
 
-def assemble_ssgi(steps=20, refine_steps=5, mode=0, use_direct_light=True, missed_rays=False, use_envmap=False) -> str:
+def assemble_ssgi(steps=20, refine_steps=5, mode=0, use_direct_light=True, missed_rays=False, use_envmap=False, perspective=True) -> str:
     """SSGIMaterial.js:44-56 + SSGIPass.js:38-40 + SSGIEffect.js:143-151,203-221."""
     gb = _rd("gbuffer/shader/gbuffer_packing.glsl")
     s = (_rd("ssgi/shader/ssgi.frag").replace("#include <ssgi_utils>", _rd("ssgi/shader/ssgi_utils.frag"))
          .replace("#include <gbuffer_packing>", gb).replace("#include <packing>", CHUNK_PACKING))
     s = _with_blue_noise(s)
     d = {"steps": int(steps), "refineSteps": int(refine_steps), "CUBEUV_TEXEL_WIDTH": 0, "CUBEUV_TEXEL_HEIGHT": 0,
-         "CUBEUV_MAX_MIP": 0, "vWorldPosition": "worldPos", "PERSPECTIVE_CAMERA": "", "mode": int(mode)}
+         "CUBEUV_MAX_MIP": 0, "vWorldPosition": "worldPos", "mode": int(mode)}
+    if perspective:  # SSGIPass.js:38
+        d["PERSPECTIVE_CAMERA"] = ""
     if use_direct_light:
         d["useDirectLight"] = ""
     if missed_rays:
@@ -111,7 +113,7 @@ def assemble_ssgi(steps=20, refine_steps=5, mode=0, use_direct_light=True, misse
 
 
 def assemble_temporal(texture_count=2, input_type=0, confidence_power=0.75, reproject_specular=(False, True),
-                      neighborhood_clamp=(False, True), log_transform=True, neighborhood_clamp_radius=2) -> str:
+                      neighborhood_clamp=(False, True), log_transform=True, neighborhood_clamp_radius=2, perspective=True) -> str:
     """TemporalReprojectMaterial.js:11-41 + TemporalReprojectPass.js:76-117."""
     gb = _rd("gbuffer/shader/gbuffer_packing.glsl")
     s = (_rd("temporal-reproject/shader/temporal_reproject.frag")
@@ -133,8 +135,10 @@ def assemble_temporal(texture_count=2, input_type=0, confidence_power=0.75, repr
             return "bool[](" + ", ".join(",".join("true" if x else "false" for x in v) for _ in range(texture_count)) + ")"
         return "bool[](" + ", ".join(flat) + ")"
 
-    defines = {"textureCount": texture_count, "PERSPECTIVE_CAMERA": "", "neighborhoodClampRadius": int(neighborhood_clamp_radius),
+    defines = {"textureCount": texture_count, "neighborhoodClampRadius": int(neighborhood_clamp_radius),
                "depthDistance": "2.0000", "worldDistance": "4.0000", "inputType": int(input_type)}
+    if perspective:  # TemporalReprojectPass.js:82
+        defines["PERSPECTIVE_CAMERA"] = ""
     if log_transform:
         defines["logTransform"] = ""
     # (:79 first sets neighborhoodClamp as a flag; :115 overwrites it with the array form below)
@@ -173,7 +177,7 @@ def assemble_denoise(texture_count=2, is_texture_specular=(False, True)) -> str:
     return three_prefix(d, True) + s
 
 
-def assemble_compose(input_type=0) -> str:
+def assemble_compose(input_type=0, perspective=True) -> str:
     """DenoiserComposePass.js:35-110 (inline template literal)."""
     js = _rd("denoise/pass/DenoiserComposePass.js")
     m = re.search(r"fragmentShader:\s*/\* glsl \*/\s*`([\s\S]*?)`,\s*vertexShader", js)
@@ -181,7 +185,10 @@ def assemble_compose(input_type=0) -> str:
     s = s.replace("${gbuffer_packing}", _rd("gbuffer/shader/gbuffer_packing.glsl"))
     s = s.replace("${ssgi_poisson_compose_functions}", _rd("denoise/shader/denoiser_compose_functions.glsl"))
     s = s.replace("#include <common>", CHUNK_COMMON).replace("#include <packing>", CHUNK_PACKING)
-    return three_prefix({"inputType": int(input_type), "PERSPECTIVE_CAMERA": ""}, False) + s
+    d = {"inputType": int(input_type)}
+    if perspective:  # DenoiserComposePass.js:110
+        d["PERSPECTIVE_CAMERA"] = ""
+    return three_prefix(d, False) + s
 
 
 # three@0.151 ShaderChunk.fog_pars_fragment / fog_fragment (un-vendored dependency, restated: SURVEY.md Appendix H)
@@ -209,14 +216,14 @@ CHUNK_FOG = """
 """
 
 
-def assemble_final(fog_mode=0) -> str:
+def assemble_final(fog_mode=0, perspective=True) -> str:
     """SSGIEffect.js:34-66 (FinalSSGIMaterial): ssgi_compose.frag with the fog chunks spliced in as the ctor does
     (`.replace("varying", "")`, the gl_FragColor line deleted by regex), wrapped the way postprocessing's EffectMaterial
     calls an Effect's mainImage (harness boundary): mainImage(inputColor, vUv, outputColor)."""
     s = _rd("ssgi/shader/ssgi_compose.frag")
     s = s.replace("#include <fog_pars_fragment>", CHUNK_FOG_PARS.replace("varying", ""))
     s = s.replace("#include <fog_fragment>", re.sub(r".*gl_FragColor.*", "", CHUNK_FOG))
-    d = {"PERSPECTIVE_CAMERA": 1}
+    d = {"PERSPECTIVE_CAMERA": 1 if perspective else 0}  # SSGIEffect.js:63
     if fog_mode:
         d["USE_FOG"] = ""
     if fog_mode == 2:
@@ -332,7 +339,7 @@ class Program:
 
 DEFAULTS = dict(  # src/ssgi/SSGIOptions.js:26-48
     distance=10.0, thickness=10.0, denoiseIterations=1, radius=3.0, phi=0.5, lumaPhi=5.0, depthPhi=2.0, normalPhi=50.0,
-    roughnessPhi=50.0, specularPhi=50.0, envBlur=0.5, steps=20, refineSteps=5, missedRays=False, mode="ssgi", denoiseMode="full", resolutionScale=1.0)
+    roughnessPhi=50.0, specularPhi=50.0, envBlur=0.5, steps=20, refineSteps=5, missedRays=False, mode="ssgi", denoiseMode="full", resolutionScale=1.0, orthographic=False)
 
 
 class GLRefChain:
@@ -367,10 +374,11 @@ class GLRefChain:
             self.p_denoise = Program(assemble_denoise(texture_count=1, is_texture_specular=(True, True)))
             self.p_compose = Program(assemble_compose(input_type=2))
         else:
-            self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 0, True, self.o["missedRays"], use_envmap=env is not None))
-            self.p_temporal = Program(assemble_temporal())
+            persp = not self.o["orthographic"]  # camera.isPerspectiveCamera -> every pass's PERSPECTIVE_CAMERA define
+            self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 0, True, self.o["missedRays"], use_envmap=env is not None, perspective=persp))
+            self.p_temporal = Program(assemble_temporal(perspective=persp))
             self.p_denoise = Program(assemble_denoise())
-            self.p_compose = Program(assemble_compose())
+            self.p_compose = Program(assemble_compose(perspective=persp))
         W, H = width, height
         self.t_depth = Tex(W, H, FMT_R32F)
         self.t_gbuffer = Tex(W, H, FMT_RGBA32F)
@@ -595,13 +603,14 @@ class GLRefTRAA:
 def run_final(width, height, depth, gi, scene, cam, fog_mode=0, fog_color=(0.5, 0.6, 0.7), fog_near=1.0, fog_far=30.0, fog_density=0.05,
               is_debug=False, shader_dir: str | None = None):
     """One draw of SSGIEffect's own fragment (FinalSSGIMaterial) on llvmpipe; returns the RGBA32F output."""
+    persp = bool(getattr(cam, "isPerspectiveCamera", True))
     if shader_dir is None and not os.path.isdir(REFERENCE_SRC):
         shader_dir = os.path.join(REF_OUT, "shaders")
-    if shader_dir is not None:
+    if shader_dir is not None and persp:
         with open(os.path.join(shader_dir, "final_fog%d.frag" % fog_mode)) as f:
             p = Program(f.read())
     else:
-        p = Program(assemble_final(fog_mode))
+        p = Program(assemble_final(fog_mode, perspective=persp))
     t_depth, t_gi, t_scene = Tex(width, height, FMT_R32F, data=depth), Tex(width, height, FMT_RGBA32F, data=gi), Tex(width, height, FMT_RGBA32F, data=scene)
     t_out = Tex(width, height, FMT_RGBA32F)
     p.sampler("inputTexture", t_gi)

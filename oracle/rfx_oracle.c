@@ -354,7 +354,8 @@ typedef struct {
     int outW, outH; /* the pass's render target = `resolution` (SSGIPass.js:52-57): W*resolutionScale x H*resolutionScale */
 } k1_ctx;
 
-static inline float k1_view_z(const k1_ctx *c, float depth) { /* getViewZ ssgi_utils.frag:7-13 (PERSPECTIVE_CAMERA) */
+static inline float k1_view_z(const k1_ctx *c, float depth) { /* getViewZ ssgi_utils.frag:7-13, both camera variants */
+    if (!c->p->camera.isPerspective) return depth * (float)((double)c->p->camera.near_ - (double)c->p->camera.far_) - c->p->camera.near_;
     return c->nearMulFar / (c->farMinusNear * depth - c->cameraFar);
 }
 static inline void k1_project(const k1_ctx *c, v3 pos, float *u, float *v) { /* viewSpaceToScreenSpace :26-33 */
@@ -708,6 +709,9 @@ typedef struct {
 } k2_ctx;
 
 static inline float perspective_depth_to_view_z(float depth, float n, float f) { return (n * f) / ((f - n) * depth - f); }
+static inline float depth_to_view_z(float depth, float n, float f, int perspective) { /* three <packing>, chosen by PERSPECTIVE_CAMERA */
+    return perspective ? perspective_depth_to_view_z(depth, n, f) : depth * (n - f) - n;
+}
 
 /* getVelocityNormalDepth reproject.frag:97-105 */
 static inline void k2_vnd(const k2_ctx *c, float u, float v, float *vx, float *vy, v3 *normal, float *depth) {
@@ -729,7 +733,7 @@ static float k2_validate(const k2_ctx *c, float ru, float rv, v3 worldPos, v3 wo
     float lvx, lvy, lastDepth; v3 lastN;
     k2_vnd(c, ru, rv, &lvx, &lvy, &lastN, &lastDepth); /* samples the CURRENT velocity texture */
     v3 lastWorldPos = ss_to_ws(ru, rv, lastDepth, c->p->prevCamera.matrixWorld, c->p->prevCamera.projectionMatrixInverse);
-    float viewZ = fabsf(perspective_depth_to_view_z(depth, c->p->camera.near_, c->p->camera.far_));
+    float viewZ = fabsf(depth_to_view_z(depth, c->p->camera.near_, c->p->camera.far_, c->p->camera.isPerspective));
     float distFactor = 1.0f + 1.0f / (viewZ + 1.0f);
     float disoccl = 0.0f;
     v3 dp = sub3(worldPos, lastWorldPos);
@@ -1054,7 +1058,7 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
             if (dep == 1.0f && fw == 0.0f) continue; /* discard DenoiserComposePass.js:61-64 */
             material mat = get_material(fetch_u4(gbuffer, d, u, v));
             v3 viewNormal = v4_mul_mat_xyz(C, mat.normal, 0.0f); /* :71, not normalised */
-            float viewZ = -perspective_depth_to_view_z(dep, p->camera.near_, p->camera.far_); /* :73 */
+            float viewZ = -depth_to_view_z(dep, p->camera.near_, p->camera.far_, p->camera.isPerspective); /* :73 */
             /* getViewPosition denoiser_compose_functions.glsl:13-20 */
             float clipW = P[2 * 4 + 3] * viewZ + P[3 * 4 + 3];
             v4 pp = mat_mul_v4(Pi, ((u - 0.5f) * 2.0f) * clipW, ((v - 0.5f) * 2.0f) * clipW, ((viewZ - 0.5f) * 2.0f) * clipW, 1.0f * clipW);
@@ -1129,7 +1133,7 @@ int rfxo_final(int W, int H, int y0, int y1, const float *depth, const void *giv
             else {
                 c[0] = gi[4 * i]; c[1] = gi[4 * i + 1]; c[2] = gi[4 * i + 2];
                 if (p->fogMode) {
-                    float viewZ = perspective_depth_to_view_z(dep, p->camera.near_, p->camera.far_) * 0.4f;
+                    float viewZ = depth_to_view_z(dep, p->camera.near_, p->camera.far_, p->camera.isPerspective) * 0.4f;
                     float fd = -viewZ, ff;
                     if (p->fogMode == 2) ff = 1.0f - expf(-p->fogDensity * p->fogDensity * fd * fd);
                     else { float t = fminf(fmaxf((fd - p->fogNear) / (p->fogFar - p->fogNear), 0.0f), 1.0f); ff = t * t * (3.0f - 2.0f * t); }

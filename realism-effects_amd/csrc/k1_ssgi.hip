@@ -424,13 +424,14 @@ __global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
 // Pre-pass: view-space Z per texel (getViewZ, ssgi_utils.frag:9: nearMulFar / (farMinusNear * depth - cameraFar), IEEE)
 // and its (min, max) per 8x8 cell.  64x8-pixel workgroups = 8 cells; 8-lane shuffles reduce a row segment, LDS the rows.
 __global__ __launch_bounds__(512) void k1_prepare(const float *depth, float *viewz, float2 *coarse, int W, int H, int coarse_w, float nearMulFar,
-                                                  float farMinusNear, float cameraFar) {
+                                                  float farMinusNear, float cameraFar, float nearMinusFar, float cameraNear, int perspective) {
     __shared__ float s_min[8][8], s_max[8][8];
     const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 8 + threadIdx.y;
     float z = 0.0f;
     const bool in = x < W && y < H;
     if (in) {
-        z = nearMulFar / (farMinusNear * depth[(size_t)y * W + x] - cameraFar);
+        const float dpt = depth[(size_t)y * W + x];  // getViewZ ssgi_utils.frag:7-13, both camera variants
+        z = perspective ? nearMulFar / (farMinusNear * dpt - cameraFar) : dpt * nearMinusFar - cameraNear;
         viewz[(size_t)y * W + x] = z;
     }
     float mn = in ? z : INFINITY, mx = in ? z : -INFINITY;
@@ -488,7 +489,7 @@ hipError_t rfx_launch_env_mip(const float4 *src, float4 *dst, int sw, int sh, in
 hipError_t rfx_launch_k1_prepare(const K1Args &A, hipStream_t stream) {
     dim3 block(64, 8), grid((A.dims.W + 63) / 64, (A.dims.H + 7) / 8);
     hipLaunchKernelGGL(k1_prepare, grid, block, 0, stream, (const float *)A.depth.ptr, A.viewz, A.coarse, A.dims.W, A.dims.H, A.coarse_w, A.nearMulFar,
-                       A.farMinusNear, A.p.camera.far_);
+                       A.farMinusNear, A.p.camera.far_, A.nearMinusFar, A.p.camera.near_, A.p.camera.isPerspective);
     return hipGetLastError();
 }
 

@@ -205,7 +205,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
         roughness = rfx_clamp(ro, 0.0f, 1.0f);
     }
     const float n_ = p.camera.near_, f_ = p.camera.far_;
-    const float viewZ = fabsf((n_ * f_) * rfx_rcp((f_ - n_) * depth - f_));
+    const float viewZ = p.camera.isPerspective ? fabsf((n_ * f_) * rfx_rcp((f_ - n_) * depth - f_)) : fabsf(depth * (n_ - f_) - n_);  // getViewZ reproject.frag:13-19
     const float distFactor = 1.0f + rfx_rcp(viewZ + 1.0f);
 
     // computeReprojectedUv :155-165

@@ -25,7 +25,7 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
     const Material mat = rfx_get_material<true>(((const uint4 *)A.gbuffer.ptr)[rfx_xy_index(d, A.gbuffer.row0, A.gbuffer.rows, x, y)]);
     const float3 viewNormal = rfx_vec_mul_mat(C, mat.normal, 0.0f);  // :71 (not normalised)
     const float n_ = A.p.camera.near_, f_ = A.p.camera.far_;
-    const float viewZ = -((n_ * f_) / ((f_ - n_) * depth - f_));  // -perspectiveDepthToViewZ :73
+    const float viewZ = -rfx_depth_to_view_z(depth, n_, f_, A.p.camera.isPerspective != 0);  // -getViewZ(depth) :73
     const float clipW = P[2 * 4 + 3] * viewZ + P[3 * 4 + 3];
     const float4 pp = rfx_mat_mul(Pi, ((u - 0.5f) * 2.0f) * clipW, ((v - 0.5f) * 2.0f) * clipW, ((viewZ - 0.5f) * 2.0f) * clipW, 1.0f * clipW);
     const float3 viewDir = rfx_normalize(make_float3(pp.x, pp.y, -viewZ));
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k5_final_compose(K5Args A) {
                 c = make_float3(gi.x, gi.y, gi.z);
                 if (p.fogMode) {
                     const float n_ = p.camera.near_, f_ = p.camera.far_;
-                    const float viewZ = ((n_ * f_) / ((f_ - n_) * depth - f_)) * 0.4f;  // getViewZ(depth) * 0.4 :36
+                    const float viewZ = rfx_depth_to_view_z(depth, n_, f_, p.camera.isPerspective != 0) * 0.4f;  // getViewZ(depth) * 0.4 :36
                     const float fd = -viewZ;
                     float ff;
                     if (p.fogMode == 2) {

@@ -386,7 +386,6 @@ int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
     if (p->mode != 0 && p->mode != 1) return fail(c, RFX_EINVAL, "rfx_ssgi_march: mode must be 0 (MODE_SSGI) or 1 (MODE_SSR)");
     if (p->importanceSampling) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: importanceSampling (env-map MIS) is not built");
     if (p->useEnvMap && !c->env) return fail(c, RFX_ESTATE, "rfx_ssgi_march: useEnvMap without rfx_set_environment");
-    if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: only PERSPECTIVE_CAMERA is built");
     if (p->steps < 1 || p->refineSteps < 0) return fail(c, RFX_EINVAL, "rfx_ssgi_march: steps/refineSteps");
     hipSetDevice(c->device);
     if (p->historySource < 0 || p->historySource > 2) return fail(c, RFX_EINVAL, "rfx_ssgi_march: historySource");
@@ -421,6 +420,7 @@ int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
     // SSGIPass.js:84-87: computed in JS doubles, then rounded to float uniforms
     A.nearMulFar = (float)((double)p->camera.near_ * (double)p->camera.far_);
     A.farMinusNear = (float)((double)p->camera.far_ - (double)p->camera.near_);
+    A.nearMinusFar = (float)((double)p->camera.near_ - (double)p->camera.far_);
     A.coarse_w = (c->W + 7) / 8;
     A.coarse_h = (c->H + 7) / 8;
     if (!c->viewz) {
@@ -451,7 +451,6 @@ int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
 
 int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
     if (!c || !p) return RFX_EINVAL;
-    if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_temporal_reproject: only PERSPECTIVE_CAMERA is built");
     if (!((p->inputType == 0 && p->textureCount == 2) || ((p->inputType == 1 || p->inputType == 2) && p->textureCount == 1)))
         return fail(c, RFX_EINVAL, "rfx_temporal_reproject: inputType/textureCount combination");
     if (p->historySource < 0 || p->historySource > 2) return fail(c, RFX_EINVAL, "rfx_temporal_reproject: historySource");
@@ -540,7 +539,6 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
     if (!c || !p) return RFX_EINVAL;
     if (p->inputType != 0 && p->inputType != 2)
         return fail(c, RFX_EUNSUPPORTED, "rfx_compose: inputType diffuseSpecular (0) and specular (2) are built");
-    if (!p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_compose: only PERSPECTIVE_CAMERA is built");
     hipSetDevice(c->device);
     if (p->giSource != 0 && p->giSource != 1) return fail(c, RFX_EINVAL, "rfx_compose: giSource");
     const int g0 = p->giSource ? RFX_TEX_TEMPORAL0 : RFX_TEX_DENOISE_B0, g1 = p->giSource ? RFX_TEX_TEMPORAL1 : RFX_TEX_DENOISE_B1;
@@ -564,7 +562,6 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
 int rfx_final_compose(rfx_ctx *c, const rfx_final_params *p) {
     if (!c || !p) return RFX_EINVAL;
     if (p->fogMode < 0 || p->fogMode > 2) return fail(c, RFX_EINVAL, "rfx_final_compose: fogMode");
-    if (p->fogMode && !p->camera.isPerspective) return fail(c, RFX_EUNSUPPORTED, "rfx_final_compose: only PERSPECTIVE_CAMERA is built");
     hipSetDevice(c->device);
     if (p->inputSource < 0 || p->inputSource > 2) return fail(c, RFX_EINVAL, "rfx_final_compose: inputSource");
     const int src = p->inputSource == 0 ? RFX_TEX_COMPOSE : (p->inputSource == 1 ? RFX_TEX_TEMPORAL0 : RFX_TEX_DENOISE_B0);

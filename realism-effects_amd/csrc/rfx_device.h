@@ -161,6 +161,12 @@ RFX_DEV float4 rfx_fetch_f4_linear(const TexView &t, const FrameDims &d, float u
 // value of an RGBA16F render-target texel after the store (rounded to half, read back as float)
 RFX_DEV float4 rfx_round_half4(float4 v, bool rtz) { return rfx_load_half4(rfx_store_half4(v.x, v.y, v.z, v.w, rtz)); }
 
+// three.js <packing>: perspectiveDepthToViewZ / orthographicDepthToViewZ (reproject.frag:13-19, denoiser_compose_functions.glsl:3-9,
+// ssgi_compose.frag:12-18 choose by the PERSPECTIVE_CAMERA define)
+RFX_DEV float rfx_depth_to_view_z(float depth, float n, float f, bool perspective) {
+    return perspective ? (n * f) / ((f - n) * depth - f) : depth * (n - f) - n;
+}
+
 // ---------------------------------------------------------------- float3 helpers
 RFX_DEV float3 operator+(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
 RFX_DEV float3 operator-(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }

@@ -14,7 +14,7 @@ struct K1Args {
     int shift_x, shift_y;
     TexViewW out;  // RGBA32F holding 8 halfs
     rfx_ssgi_params p;
-    float nearMulFar, farMinusNear;
+    float nearMulFar, farMinusNear, nearMinusFar;
     float *viewz;    // full-frame view-space Z (context scratch, filled by k1_prepare)
     float2 *coarse;  // (min, max) view Z per 8x8 cell
     int coarse_w, coarse_h;

@@ -53,6 +53,18 @@ def make_perspective(fov_deg: float, aspect: float, near: float, far: float) -> 
     return m
 
 
+def make_orthographic(half_height: float, aspect: float, near: float, far: float) -> np.ndarray:
+    """three.js OrthographicCamera.updateProjectionMatrix + Matrix4.makeOrthographic (r151), symmetric frustum."""
+    top, right = half_height, half_height * aspect
+    m = np.zeros((4, 4), np.float64)
+    m[0, 0] = 1.0 / right
+    m[1, 1] = 1.0 / top
+    m[2, 2] = -2.0 / (far - near)
+    m[2, 3] = -(far + near) / (far - near)
+    m[3, 3] = 1.0
+    return m
+
+
 def look_at_world(eye, target, up=(0.0, 1.0, 0.0)) -> np.ndarray:
     """camera.matrixWorld for camera.lookAt(target) (camera looks down -Z)."""
     eye = np.asarray(eye, np.float64)
@@ -87,11 +99,17 @@ class Camera:
 
     @staticmethod
     def orbit(frame: int, aspect: float, fov=40.0, near=0.01, far=250.0, deg_per_frame=0.5,
-              radius=8.5, height=3.2, target=(0.0, 0.9, 0.0), start_deg=30.0) -> "Camera":
+              radius=8.5, height=3.2, target=(0.0, 0.9, 0.0), start_deg=30.0, ortho_half_height: float | None = None) -> "Camera":
+        """`ortho_half_height`: an OrthographicCamera with that half extent (near 0.1, far 16: the far plane cuts the ground, leaving
+        background texels) instead of the PerspectiveCamera."""
         ang = math.radians(start_deg + deg_per_frame * frame)
         eye = np.array([radius * math.cos(ang), height, radius * math.sin(ang)])
         mw = look_at_world(eye, target)
-        p = make_perspective(fov, aspect, near, far)
+        if ortho_half_height is not None:
+            near, far = 0.1, 16.0
+            p = make_orthographic(ortho_half_height, aspect, near, far)
+        else:
+            p = make_perspective(fov, aspect, near, far)
         # quaternion from rotation matrix (for didCameraMove, src/utils/SceneUtils.js:17-27)
         r = mw[:3, :3]
         qw = math.sqrt(max(0.0, 1 + r[0, 0] + r[1, 1] + r[2, 2])) / 2
@@ -101,7 +119,7 @@ class Camera:
         return Camera(near=near, far=far, position=eye.astype(np.float32),
                       projectionMatrix=col_major32(p), projectionMatrixInverse=col_major32(np.linalg.inv(p)),
                       matrixWorld=col_major32(mw), matrixWorldInverse=col_major32(np.linalg.inv(mw)),
-                      quaternion=np.array([qx, qy, qz, qw]))
+                      isPerspectiveCamera=ortho_half_height is None, quaternion=np.array([qx, qy, qz, qw]))
 
     def _m(self, name) -> np.ndarray:
         return getattr(self, name).astype(np.float64).reshape(4, 4).T  # back to [row, col]
@@ -227,7 +245,10 @@ class AnalyticScene:
 
     # ---- ray casting (float64, vectorised over pixels, loop over objects)
     def _trace(self, o: np.ndarray, d: np.ndarray):
+        """`o`: one origin (3,) — perspective — or one per ray (n, 3) — orthographic."""
         n_px = d.shape[0]
+        if o.ndim == 2:
+            return self._trace_many(o, d)
         t_best = np.full(n_px, np.inf)
         mat = np.full(n_px, -1, np.int32)
         nrm = np.zeros((n_px, 3))
@@ -269,8 +290,45 @@ class AnalyticScene:
             nrm[hit] = nn
         return t_best, mat, nrm
 
+    def _trace_many(self, o: np.ndarray, d: np.ndarray):
+        n_px = d.shape[0]
+        t_best = np.full(n_px, np.inf)
+        mat = np.full(n_px, -1, np.int32)
+        nrm = np.zeros((n_px, 3))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = -o[:, 1] / d[:, 1]
+        hit = (d[:, 1] < 0) & (t > 0)
+        t_best = np.where(hit, t, t_best)
+        mat[hit] = 0
+        nrm[hit] = (0, 1, 0)
+        for c, r, m in self.spheres:
+            oc = o - c
+            b = (d * oc).sum(1)
+            cc = (oc * oc).sum(1) - r * r
+            disc = b * b - cc
+            ok = disc > 0
+            t = -b - np.sqrt(np.where(ok, disc, 0))
+            hit = ok & (t > 1e-6) & (t < t_best)
+            t_best = np.where(hit, t, t_best)
+            mat[hit] = m
+            nrm[hit] = (o[hit] + d[hit] * t[hit, None] - c) / r
+        for lo, hi, m in self.boxes:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                inv = 1.0 / d
+                t0, t1 = (lo - o) * inv, (hi - o) * inv
+            tmin, tmax = np.minimum(t0, t1), np.maximum(t0, t1)
+            tn, tf = tmin.max(axis=1), tmax.min(axis=1)
+            hit = (tn < tf) & (tn > 1e-6) & (tn < t_best)
+            t_best = np.where(hit, tn, t_best)
+            mat[hit] = m
+            ax = tmin[hit].argmax(axis=1)
+            nn = np.zeros((int(hit.sum()), 3))
+            nn[np.arange(nn.shape[0]), ax] = -np.sign(d[hit][np.arange(nn.shape[0]), ax])
+            nrm[hit] = nn
+        return t_best, mat, nrm
+
     def render(self, width: int, height: int, frame_index: int = 0, row0: int = 0, rows: int | None = None,
-               frame_height: int | None = None, vfov_rows: int | None = None, aov: bool = False) -> Frame:
+               frame_height: int | None = None, vfov_rows: int | None = None, aov: bool = False, ortho_half_height: float | None = None) -> Frame:
         """Dump frame `frame_index`.  (row0, rows, frame_height) select a horizontal band of a
         taller frame — used by the row-tiled multi-GPU path; default = the whole frame.
         `vfov_rows`: number of rows that span the nominal 40 deg vertical fov; a taller frame
@@ -284,8 +342,8 @@ class AnalyticScene:
         fov = 40.0
         if vfov_rows and vfov_rows != fh:
             fov = min(160.0, 2.0 * math.degrees(math.atan(math.tan(math.radians(20.0)) * fh / vfov_rows)))
-        cam = Camera.orbit(frame_index, aspect, fov=fov)
-        prev = Camera.orbit(frame_index - 1, aspect, fov=fov) if frame_index > 0 else cam
+        cam = Camera.orbit(frame_index, aspect, fov=fov, ortho_half_height=ortho_half_height)
+        prev = Camera.orbit(frame_index - 1, aspect, fov=fov, ortho_half_height=ortho_half_height) if frame_index > 0 else cam
         P, Pi, C, V = cam._m("projectionMatrix"), cam._m("projectionMatrixInverse"), cam._m("matrixWorld"), cam._m("matrixWorldInverse")
         Pp, Vp = prev._m("projectionMatrix"), prev._m("matrixWorldInverse")
 
@@ -316,11 +374,16 @@ class AnalyticScene:
             ndc = np.stack([gx.ravel(), gy.ravel(), -np.ones(n_px), np.ones(n_px)], axis=1)
             pv = ndc @ Pi.T
             pv = pv[:, :3] / pv[:, 3:4]
-            dv = pv / np.linalg.norm(pv, axis=1, keepdims=True)
-            d = dv @ C[:3, :3].T
-            t, mat, nrm = self._trace(o, d)
+            if ortho_half_height is None:
+                dv = pv / np.linalg.norm(pv, axis=1, keepdims=True)
+                d = dv @ C[:3, :3].T
+                ro = o
+            else:  # orthographic: parallel rays down the camera's -Z from the pixel's point on the near plane
+                d = np.tile(-C[:3, 2], (n_px, 1))
+                ro = pv @ C[:3, :3].T + o
+            t, mat, nrm = self._trace(ro, d)
             hit = mat >= 0
-            wp = o + d * np.where(hit, t, 0)[:, None]
+            wp = ro + d * np.where(hit, t, 0)[:, None]
             wp4 = np.concatenate([wp, np.ones((n_px, 1))], axis=1)
             clip = wp4 @ (P @ V).T
             with np.errstate(divide="ignore", invalid="ignore"):

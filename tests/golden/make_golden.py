@@ -35,19 +35,21 @@ def cam_arrays(cam, prefix):
 
 
 def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_start=2000, mode="ssgi", missed_rays=False, denoise_mode="full",
-        environment=None, env_blur=0.5, resolution_scale=1.0):
+        environment=None, env_blur=0.5, resolution_scale=1.0, ortho_half_height=None):
     bn = np.fromfile(os.path.join(ROOT, "realism-effects_amd", "data", "blue_noise_128_rgba8.bin"), np.uint8).reshape(128, 128, 4)
     c = chain.GLRefChain(W, H, bn, steps=steps, refineSteps=refine, denoiseIterations=iterations, mode=mode, missedRays=missed_rays,
-                         denoiseMode=denoise_mode, environment=environment, envBlur=env_blur, resolutionScale=resolution_scale)
+                         denoiseMode=denoise_mode, environment=environment, envBlur=env_blur, resolutionScale=resolution_scale,
+                         orthographic=ortho_half_height is not None)
     tc = c.tc
     out = dict(width=W, height=H, frames=frames, steps=steps, refineSteps=refine, denoiseIterations=iterations, ssgi_start=ssgi_start,
                denoise_start=denoise_start, gl_info=chain.GL.info(), mode=mode, textureCount=tc, missedRays=int(missed_rays), denoiseMode=denoise_mode)
     out["resolutionScale"] = resolution_scale
+    out["orthographic"] = int(ortho_half_height is not None)
     if environment is not None:  # scene.environment (HalfFloatType, mipmapped by the effect) + the envBlur option
         out["environment"], out["envBlur"] = environment, env_blur
     si = di = 0
     for fi in range(frames):
-        f = synthetic_frame(W, H, fi)
+        f = synthetic_frame(W, H, fi, ortho_half_height=ortho_half_height)
         c.upload_frame(f)
         k = "f%d_" % fi
         out[k + "depth"], out[k + "gbuffer"], out[k + "velocity"], out[k + "direct"] = f.depth, f.gbuffer, f.velocity, f.direct
@@ -76,6 +78,8 @@ def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_
             out[k + "compose"] = c.t_compose.read()
         if denoise_mode != "full":
             out[k + "final"] = chain.chain_final(c, f)
+        if ortho_half_height is not None:  # the effect's own fragment with fog: the last orthographic getViewZ site
+            out[k + "final_fog2"] = chain.chain_final(c, f, fog_mode=2)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
@@ -150,6 +154,7 @@ if __name__ == "__main__":
     # the last ulp of the rasteriser's varying interpolation (llvmpipe's vUv differs from (i+0.5)/n by <= 1 ulp, measured) — there the
     # reference itself is implementation-defined.
     run("chain_rs050_128x72_s12r3_it1", 128, 72, frames=2, steps=12, refine=3, iterations=1, resolution_scale=0.5)
+    run("chain_ortho_120x68_s12r3_it1", 120, 68, frames=3, steps=12, refine=3, iterations=1, ortho_half_height=3.2)  # OrthographicCamera
     for dm in ("full_temporal", "temporal", "denoised"):  # the other Denoiser modes (Denoiser.js:7,41-78)
         run("chain_%s_104x58_s10r2" % dm, 104, 58, frames=3, steps=10, refine=2, iterations=1, denoise_mode=dm)
     run_traa("traa_half_128x72", 128, 72, frames=3, half=True)

@@ -806,3 +806,49 @@ def test_import_attribute_planes_vs_oracle():
     a_out, b_out = run(packed), run(planes)
     # identical but for the emissive word of black-emissive texels (numpy dump writer: 0; reference encoder: 0x00fefefe -> a 2.9e-39 emissive)
     assert np.abs(a_out - b_out).max() < 1e-30
+
+
+def test_orthographic_camera_vs_oracle(blue_noise):
+    """OrthographicCamera (no PERSPECTIVE_CAMERA define in any pass): K1 (general projection + orthographic view-Z plane), K2, K4 and the
+    effect's fog against the oracle, each fed the oracle's inputs."""
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_frame
+    import rfx_oracle as O
+
+    W, H = 300, 170
+    ctx = Context(W, H)
+    comp = np.random.RandomState(2).rand(H, W, 4).astype(np.float32)
+    hist = (np.random.RandomState(3).rand(H, W, 4).astype(np.float32) * np.array([1, 1, 1, 5], np.float32)).astype(np.float16).view(np.uint16)
+    f0, f = synthetic_frame(W, H, 0, ortho_half_height=3.2), synthetic_frame(W, H, 1, ortho_half_height=3.2)
+    sp, tp, dp, cp = _params(abi, f, f0.camera, 1.0, 12, 3)
+    assert sp.camera.isPerspective == 0 and (f.depth == 1.0).any() and (f.depth < 1.0).mean() > 0.5
+    sp.blueNoiseIndex = 77
+    ctx.upload_frame(f)
+    ctx.upload(abi.TEX_COMPOSE, comp)
+    ctx.ssgi_march(sp)
+    got, want = ctx.download(abi.TEX_SSGI), O.ssgi(f.depth, f.gbuffer, f.direct, comp, blue_noise, sp)
+    ga, gb = O.unpack_ssgi(got)
+    wa, wb = O.unpack_ssgi(want)
+    assert_close("ortho ssgi.diffuse", ga, wa, FLIP["ssgi"])
+    assert_close("ortho ssgi.specular", gb, wb, FLIP["ssgi"])
+    assert (got == want).all(axis=-1).mean() > 0.99
+    assert (O.unpack_ssgi(want)[1][..., 3] > 0).mean() > 0.05  # rays do hit: the march works in the orthographic frustum
+    ctx.upload(abi.TEX_SSGI, want)
+    ctx.upload(abi.TEX_DENOISE_B0, hist)
+    ctx.upload(abi.TEX_DENOISE_B1, hist)
+    ctx.temporal_reproject(tp)
+    T0, T1 = np.zeros((H, W, 4), np.float32), np.zeros((H, W, 4), np.float32)
+    O.temporal(want, f.velocity, hist, hist, tp, T0, T1)
+    assert_close("ortho temporal0", ctx.download(abi.TEX_TEMPORAL0), T0, FLIP["temporal"])
+    assert_close("ortho temporal1", ctx.download(abi.TEX_TEMPORAL1), T1, FLIP["temporal"])
+    ctx.compose(cp)
+    c2 = comp.copy()
+    O.compose(f.depth, f.gbuffer, hist, hist, cp, c2)
+    assert_close("ortho compose", ctx.download(abi.TEX_COMPOSE), c2, FLIP["compose"])
+    fp = abi.FinalParams(camera=sp.camera, fogMode=1, fogNear=1.0, fogFar=6.0)
+    fp.fogColor[:] = [0.3, 0.5, 0.7]
+    ctx.upload(abi.TEX_COMPOSE, c2)
+    ctx.final_compose(fp)
+    assert_close("ortho final fog", ctx.download(abi.TEX_FINAL), O.final(f.depth, c2, f.direct, fp), 0.0)
+    ctx.close()

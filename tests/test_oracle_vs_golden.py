@@ -468,3 +468,36 @@ def test_pack_gbuffer_and_velocity_vs_golden():
     f = AnalyticScene(1234).render(96, 54, 1, aov=True)
     p = O.pack_gbuffer(f.aov, f.depth)
     assert np.array_equal(p[..., :3], f.gbuffer[..., :3]) and np.array_equal(O.pack_velocity(f.aov, f.depth), f.velocity)
+
+
+def test_orthographic_camera_stagewise(blue_noise):
+    """An OrthographicCamera: every pass is compiled WITHOUT its PERSPECTIVE_CAMERA define (SSGIPass.js:38, TemporalReprojectPass.js:82,
+    DenoiserComposePass.js:110, SSGIEffect.js:63) — depth -> view-Z switches to the orthographic formula in K1 (the march), K2 (the
+    disocclusion distance factor), K4 and the effect's fog; the projection is the general matrix path."""
+    g = G.load(G.GOLDEN_ORTHO)
+    W, H, nf = int(g["width"]), int(g["height"]), int(g["frames"])
+    assert not G.camera(g, 0).isPerspectiveCamera
+    z16, zf = np.zeros((H, W, 4), np.uint16), np.zeros((H, W, 4), np.float32)
+    for fi in range(nf):
+        f = G.frame(g, fi)
+        k, kp = "f%d_" % fi, "f%d_" % (fi - 1)
+        sp, tp, dp, cp = stage_params(g, fi, 0.0 if fi == 0 else 1.0)
+        assert sp.camera.isPerspective == 0
+        hist = np.ascontiguousarray(g[kp + "compose"]) if fi else zf
+        o = O.ssgi(f.depth, f.gbuffer, f.direct, hist, blue_noise, sp)
+        ga, gb = O.unpack_ssgi(g[k + "ssgi"])
+        oa, ob = O.unpack_ssgi(o)
+        assert_close("ortho ssgi.diffuse f%d" % fi, oa, ga, FLIP["ssgi"])
+        assert_close("ortho ssgi.specular f%d" % fi, ob, gb, FLIP["ssgi"])
+        assert (o == g[k + "ssgi"]).all(axis=-1).mean() > 0.99
+        B = [np.ascontiguousarray(g[kp + "B%d" % j]) if fi else z16 for j in range(2)]
+        T = [np.ascontiguousarray(g[kp + "temporal%d" % j]) if fi else zf.copy() for j in range(2)]
+        O.temporal(np.ascontiguousarray(g[k + "ssgi"]), f.velocity, B[0], B[1], tp, T[0], T[1])
+        for j in range(2):
+            assert_close("ortho temporal%d f%d" % (j, fi), T[j], g[k + "temporal%d" % j], FLIP["temporal"])
+        comp = hist.copy()
+        O.compose(f.depth, f.gbuffer, np.ascontiguousarray(g[k + "B0"]), np.ascontiguousarray(g[k + "B1"]), cp, comp)
+        assert_close("ortho compose f%d" % fi, comp, g[k + "compose"], FLIP["compose"])
+        fp = abi.FinalParams(camera=abi.Camera.from_scene(f.camera), fogMode=2, fogDensity=0.05)
+        fp.fogColor[:] = [0.5, 0.6, 0.7]
+        assert_close("ortho final fog f%d" % fi, O.final(f.depth, np.ascontiguousarray(g[k + "compose"]), f.direct, fp), g[k + "final_fog2"], 0.0)
