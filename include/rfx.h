@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 7
+#define RFX_ABI_VERSION 8
 
 enum {
     RFX_OK = 0,
@@ -94,7 +94,8 @@ typedef struct rfx_ssgi_params {
     int32_t mode;             /* #define mode: 0 = MODE_SSGI (two packed vec4 of halfs), 1 = MODE_SSR (raw vec4: specular GI, packHalf2x16(rayLength, roughness)) */
     int32_t useDirectLight;   /* #define useDirectLight */
     int32_t missedRays;       /* #define missedRays   */
-    int32_t importanceSampling; /* #define importanceSampling (env-map MIS): not built, must be 0 */
+    int32_t importanceSampling; /* #define importanceSampling (env-map MIS, ssgi.frag:197-216): needs useEnvMap and the tables of
+                                 rfx_set_environment_importance                                                              */
     int32_t useEnvMap;        /* #define USE_ENVMAP: the context holds scene.environment (rfx_set_environment); missed rays and
                                  the screen-border fade take its colour instead of black (getEnvColor, ssgi.frag:311-346)   */
     float rayDistance;        /* uniform rayDistance = options.distance */
@@ -232,6 +233,11 @@ int rfx_pack_velocity(rfx_ctx *, const rfx_aov_velocity *, int row0, int rows);
  * be powers of two (wrap: ClampToEdge, three's default for a DataTexture).  maxEnvMapMipLevel = floor(log2(max(w,h))) + 1
  * (src/ssgi/utils/Utils.js:30-34).  rfx_set_environment(ctx, NULL, 0, 0, 0, 0) removes it. */
 int rfx_set_environment(rfx_ctx *, const float *rgba, int width, int height, int halfFloatType, int halfStoreRTZ);
+/* The two inverse-CDF tables and the luminance sum that EquirectHdrInfoUniform.updateFrom computes on the CPU (a Web Worker in the
+ * reference, src/ssgi/utils/EquirectHdrInfoUniform.js:148-245,365-400) for `sampleEquirectProbability` (ssgi_utils.frag:210-225):
+ * `marginalWeights` (height floats: an height x 1 NEAREST texture), `conditionalWeights` (width x height floats, row-major), and
+ * totalSumValue split as the reference splits it (`~~total` and the rest).  Sizes are those of the environment set before. */
+int rfx_set_environment_importance(rfx_ctx *, const float *marginalWeights, const float *conditionalWeights, float totalSumWhole, float totalSumDecimal);
 /* Read mip level `level` of the environment back (max(w>>level,1) x max(h>>level,1) RGBA float32); *levels (may be NULL) receives the
  * number of levels.  For inspection and for checking the chain against the driver's. */
 int rfx_download_environment(rfx_ctx *, int level, float *rgba, int *levels);

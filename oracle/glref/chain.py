@@ -93,7 +93,8 @@ def _with_blue_noise(src: str) -> str:
     return src.replace("uniform vec2 resolution;", "uniform vec2 resolution;\n" + _rd("utils/shader/blue_noise.glsl"), 1)
 
 
-def assemble_ssgi(steps=20, refine_steps=5, mode=0, use_direct_light=True, missed_rays=False, use_envmap=False, perspective=True) -> str:
+def assemble_ssgi(steps=20, refine_steps=5, mode=0, use_direct_light=True, missed_rays=False, use_envmap=False, perspective=True,
+                  importance_sampling=False) -> str:
     """SSGIMaterial.js:44-56 + SSGIPass.js:38-40 + SSGIEffect.js:143-151,203-221."""
     gb = _rd("gbuffer/shader/gbuffer_packing.glsl")
     s = (_rd("ssgi/shader/ssgi.frag").replace("#include <ssgi_utils>", _rd("ssgi/shader/ssgi_utils.frag"))
@@ -107,8 +108,10 @@ def assemble_ssgi(steps=20, refine_steps=5, mode=0, use_direct_light=True, misse
         d["useDirectLight"] = ""
     if missed_rays:
         d["missedRays"] = ""
-    if use_envmap:  # SSGIEffect.js:344 (importanceSampling stays off: the MIS path is not built)
+    if use_envmap:  # SSGIEffect.js:344
         d["USE_ENVMAP"] = ""
+    if importance_sampling:  # :348-351, once EquirectHdrInfoUniform.updateFrom has resolved
+        d["importanceSampling"] = ""
     return three_prefix(d, False) + s
 
 
@@ -239,7 +242,7 @@ def write_assembled(outdir: str, **kw):
                       ("temporal", assemble_temporal()), ("denoise", assemble_denoise()), ("compose", assemble_compose()),
                       ("ssgi_ssr_20_5", assemble_ssgi(20, 5, 1)), ("temporal_ssr", assemble_temporal(texture_count=1, input_type=2, reproject_specular=True, neighborhood_clamp=True)),
                       ("denoise_ssr", assemble_denoise(texture_count=1, is_texture_specular=(True, True))), ("compose_ssr", assemble_compose(input_type=2)),
-                      ("ssgi_env_20_5", assemble_ssgi(20, 5, use_envmap=True)), ("temporal_traa", assemble_traa()), ("final_fog0", assemble_final(0)), ("final_fog1", assemble_final(1)),
+                      ("ssgi_env_20_5", assemble_ssgi(20, 5, use_envmap=True)), ("ssgi_envmis_20_5", assemble_ssgi(20, 5, use_envmap=True, importance_sampling=True)), ("temporal_traa", assemble_traa()), ("final_fog0", assemble_final(0)), ("final_fog1", assemble_final(1)),
                       ("final_fog2", assemble_final(2))):
         with open(os.path.join(outdir, name + ".frag"), "w") as f:
             f.write(src)
@@ -357,6 +360,8 @@ class GLRefChain:
             shader_dir = os.path.join(REF_OUT, "shaders")  # build products of `make -C oracle ref` (GPU box: no /root/reference)
         self.t_env = None
         env = self.o.pop("environment", None)  # scene.environment: (H, W, 4) float32 equirect; HalfFloatType like RGBELoader's
+        # importanceSampling: (marginalWeights[H], conditionalWeights[H, W], totalSumValue) as EquirectHdrInfoUniform's worker computes them
+        self.importance = self.o.pop("importance", None)
         ssr = self.o["mode"] == "ssr"
         self.tc = 1 if ssr else 2  # SSGIEffect.js:70-77: "ssr" -> inputType "specular", one texture
         sfx = "_ssr" if ssr else ""
@@ -366,7 +371,8 @@ class GLRefChain:
                     return f.read()
             if self.o["missedRays"]:
                 raise RuntimeError("prebuilt shaders cover missedRays=false only")
-            self.p_ssgi = Program(rd("ssgi%s%s_%d_%d" % (sfx, "_env" if env is not None else "", self.o["steps"], self.o["refineSteps"])))
+            self.p_ssgi = Program(rd("ssgi%s%s_%d_%d" % (sfx, ("_envmis" if self.importance is not None else "_env") if env is not None else "",
+                                                            self.o["steps"], self.o["refineSteps"])))
             self.p_temporal, self.p_denoise, self.p_compose = Program(rd("temporal" + sfx)), Program(rd("denoise" + sfx)), Program(rd("compose" + sfx))
         elif ssr:
             self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 1, True, self.o["missedRays"]))
@@ -375,7 +381,8 @@ class GLRefChain:
             self.p_compose = Program(assemble_compose(input_type=2))
         else:
             persp = not self.o["orthographic"]  # camera.isPerspectiveCamera -> every pass's PERSPECTIVE_CAMERA define
-            self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 0, True, self.o["missedRays"], use_envmap=env is not None, perspective=persp))
+            self.p_ssgi = Program(assemble_ssgi(self.o["steps"], self.o["refineSteps"], 0, True, self.o["missedRays"], use_envmap=env is not None, perspective=persp,
+                                                importance_sampling=self.importance is not None))
             self.p_temporal = Program(assemble_temporal(perspective=persp))
             self.p_denoise = Program(assemble_denoise())
             self.p_compose = Program(assemble_compose(perspective=persp))
@@ -399,6 +406,10 @@ class GLRefChain:
             self.env_size = (env.shape[1], env.shape[0])
             self.t_env = Tex(env.shape[1], env.shape[0], FMT_RGBA16F, linear=True, data=np.ascontiguousarray(env, np.float32).astype(np.float16))
             self.t_env.generate_mipmaps()
+            if self.importance is not None:  # EquirectHdrInfoUniform.updateFrom :383-389: height x 1 and width x height R32F, NearestFilter
+                mw, cw, _ = self.importance
+                self.t_marginal = Tex(env.shape[0], 1, FMT_R32F, data=np.ascontiguousarray(mw, np.float32))
+                self.t_conditional = Tex(env.shape[1], env.shape[0], FMT_R32F, data=np.ascontiguousarray(cw, np.float32))
         # Denoiser.js:41-61: a denoise pass only in "full"/"denoised" (its target B then overrides K2's history), a compose pass only in "full*"
         self.dm = self.o["denoiseMode"]
         assert self.dm in ("full", "full_temporal", "denoised", "temporal")
@@ -441,6 +452,13 @@ class GLRefChain:
         p.set("envBlur", float(o["envBlur"]))
         if self.t_env is not None:
             p.sampler("envMapInfo.map", self.t_env)
+            if self.importance is not None:
+                tot = float(self.importance[2])
+                p.sampler("envMapInfo.marginalWeights", self.t_marginal)
+                p.sampler("envMapInfo.conditionalWeights", self.t_conditional)
+                p.set("envMapInfo.size", [float(self.env_size[0]), float(self.env_size[1])])
+                p.set("envMapInfo.totalSumWhole", float(int(tot)))          # ~~totalSumValue (:391-394)
+                p.set("envMapInfo.totalSumDecimal", float(tot - int(tot)))
             import math
             p.set("maxEnvMapMipLevel", float(math.floor(math.log2(max(self.env_size))) + 1))  # getMaxMipLevel, Utils.js:30-34
         else:

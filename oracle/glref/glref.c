@@ -290,6 +290,20 @@ int glref_gen_mipmaps(int tex) {
     return (int)pGetError();
 }
 
+/* Overwrite one mip level (probes: a chain whose level l holds the constant l makes textureLod / texture return the lod they used). */
+int glref_tex_upload_level(int tex, int level, const void *data) {
+    tex_t *T = &g_tex[tex];
+    GLint internal; GLenum format, type;
+    fmt_to_gl(T->fmt, &internal, &format, &type);
+    int w = T->w >> level, h = T->h >> level;
+    if (w < 1) w = 1;
+    if (h < 1) h = 1;
+    pActiveTexture(GL_TEXTURE0 + 31);
+    pBindTexture(GL_TEXTURE_2D, T->id);
+    pTexImage2D(GL_TEXTURE_2D, level, internal, w, h, 0, format, type, data);
+    return (int)pGetError();
+}
+
 /* Read mip level `level` of a texture as RGBA float32 (max(w>>level,1) * max(h>>level,1) * 4 floats). */
 int glref_read_level(int tex, int level, float *out) {
     tex_t *T = &g_tex[tex];

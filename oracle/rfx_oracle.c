@@ -352,6 +352,7 @@ typedef struct {
     float nearMulFar, farMinusNear, cameraFar;
     const float *env; int env_w, env_h, env_levels; /* scene.environment: the whole mip chain, RGBA float32, level l after level l-1 */
     int outW, outH; /* the pass's render target = `resolution` (SSGIPass.js:52-57): W*resolutionScale x H*resolutionScale */
+    const float *marginal, *conditional; float totalSumWhole, totalSumDecimal; /* EquirectHdrInfo tables (importanceSampling) */
 } k1_ctx;
 
 static inline float k1_view_z(const k1_ctx *c, float depth) { /* getViewZ ssgi_utils.frag:7-13, both camera variants */
@@ -417,7 +418,18 @@ static inline float mesa_acos(float x) {
 }
 /* getEnvColor ssgi.frag:311-346 (no BOX_PROJECTED_ENV_MAP; isEnvSample is false without MIS): textureLod on a LinearMipMapLinear
  * texture = two CLAMP_TO_EDGE bilinear taps blended by fract(lod), lod clamped to the chain (measured on llvmpipe) */
-static v3 k1_env_color(const k1_ctx *c, v3 l, float roughness, int isDiffuseSample) {
+static v3 k1_env_trilinear(const k1_ctx *c, float u, float v, float lod_unclamped) {
+    float lod = fminf(fmaxf(lod_unclamped, 0.0f), (float)(c->env_levels - 1));
+    float fl = floorf(lod);
+    int l0 = (int)fl, l1 = l0 + 1 > c->env_levels - 1 ? c->env_levels - 1 : l0 + 1;
+    int w0, h0, w1, h1;
+    const float *t0 = env_level(c, l0, &w0, &h0), *t1 = env_level(c, l1, &w1, &h1);
+    dims d0 = {w0, h0}, d1 = {w1, h1};
+    v4 c0 = fetch_f4_linear(t0, d0, u, v), c1 = fetch_f4_linear(t1, d1, u, v);
+    float f = lod - fl;
+    return V3(lerpf(f, c0.x, c1.x), lerpf(f, c0.y, c1.y), lerpf(f, c0.z, c1.z));
+}
+static v3 k1_env_color(const k1_ctx *c, v3 l, float roughness, int isDiffuseSample, int isEnvSample) {
     if (!c->p->useEnvMap) return V3(0, 0, 0);
     v3 dir = normalize3(v4_mul_mat_xyz(c->p->camera.matrixWorldInverse, l, 0.0f)); /* (vec4(l, 0.) * viewMatrix).xyz :315 */
     float maxMip = 0.0f;
@@ -427,23 +439,15 @@ static v3 k1_env_color(const k1_ctx *c, v3 l, float roughness, int isDiffuseSamp
     /* equirectDirectionToUv ssgi_utils.frag:64-74 */
     float u = atan2f(dir.z, dir.x) / (2.0f * M_PIf), v = mesa_acos(dir.y) / M_PIf;
     u += 0.5f; v = 1.0f - v;
-    float lod = fminf(fmaxf(mip, 0.0f), (float)(c->env_levels - 1));
-    float fl = floorf(lod);
-    int l0 = (int)fl, l1 = l0 + 1 > c->env_levels - 1 ? c->env_levels - 1 : l0 + 1;
-    int w0, h0, w1, h1;
-    const float *t0 = env_level(c, l0, &w0, &h0), *t1 = env_level(c, l1, &w1, &h1);
-    dims d0 = {w0, h0}, d1 = {w1, h1};
-    v4 c0 = fetch_f4_linear(t0, d0, u, v), c1 = fetch_f4_linear(t1, d1, u, v);
-    float f = lod - fl;
-    v3 col = V3(lerpf(f, c0.x, c1.x), lerpf(f, c0.y, c1.y), lerpf(f, c0.z, c1.z));
-    const float maxEnvLum = 25.0f; /* :330-340 */
+    v3 col = k1_env_trilinear(c, u, v, mip);
+    const float maxEnvLum = isEnvSample ? 100.0f : 25.0f; /* :328-340 */
     float envLum = lum(col);
     if (envLum > maxEnvLum) col = mul3(col, maxEnvLum / envLum);
     return col;
 }
 /* doSample ssgi.frag:362-439 */
 static v3 k1_do_sample(const k1_ctx *c, const material *mat, v3 viewPos, v3 viewNormal, float metalness, float roughness,
-                       int isDiffuseSample, float NoV, float NoL, float NoH, float LoH, float VoH, v4 random,
+                       int isDiffuseSample, int isEnvSample, float NoV, float NoL, float NoH, float LoH, float VoH, v4 random,
                        v3 *l, v3 *hitPos, float *brdf, float *pdf) {
     (void)VoH;
     dims d = {c->W, c->H};
@@ -462,7 +466,7 @@ static v3 k1_do_sample(const k1_ctx *c, const material *mat, v3 viewPos, v3 view
     k1_ray_march(c, l, hitPos, random.z, &cu, &cv);
     int allowMissed = c->p->missedRays != 0;
     int isMissed = hitPos->x == 10.0e9f;
-    v3 env = k1_env_color(c, *l, roughness, isDiffuseSample); /* black without an env map (:342-345) */
+    v3 env = k1_env_color(c, *l, roughness, isDiffuseSample, isEnvSample); /* black without an env map (:342-345) */
     if (isMissed && !allowMissed) return env;
     /* velocityTexture is never wired (SSGIPass.js:89) -> three's empty texture -> velocity = 0 */
     float ru = cu - 0.0f, rv = cv - 0.0f;
@@ -498,6 +502,26 @@ static inline void calc_angles(v3 l, v3 v, v3 n, float *NoL, float *NoH, float *
     *NoH = clampf(dot3(n, h), E, OME);
     *LoH = clampf(dot3(l, h), E, OME);
     *VoH = clampf(dot3(v, h), E, OME);
+}
+
+/* sampleEquirectProbability's table walk (ssgi_utils.frag:212-214): marginalWeights is an env_h x 1 NEAREST texture read at (blueNoise.x, 0),
+ * conditionalWeights env_w x env_h read at (blueNoise.y, v); the pixel is whatever ivec2(vUv * resolution) makes of it = (px, py) */
+static inline void k1_cdf_uv(const k1_ctx *c, int px, int py, float *u, float *v) {
+    dims dres = {c->outW, c->outH};
+    {   /* A quad partner that is a background texel (main() returned at :109-113) or lies outside the target never ran the blue-noise fetch:
+         * on the oracle's GL its `random` still holds the zero initialisation, so it contributes the table entry of (0, 0) to the quad's
+         * derivatives (GLSL leaves derivatives after a non-uniform return undefined; measured on llvmpipe, reproduced) */
+        dims d = {c->W, c->H};
+        float pu = ((float)px + 0.5f) / (float)c->outW, pv = ((float)py + 0.5f) / (float)c->outH;
+        if (px >= c->outW || py >= c->outH || fetch_r32f(c->depth, d, pu, pv) == 1.0f) {
+            *v = c->marginal[0];
+            *u = c->conditional[(size_t)nearest_idx(*v, c->env_h) * c->env_w + 0];
+            return;
+        }
+    }
+    v4 r = blue_noise(c->blue, px, py, c->p->blueNoiseIndex, ((float)px + 0.5f) / (float)c->outW, ((float)py + 0.5f) / (float)c->outH, dres);
+    *v = c->marginal[nearest_idx(r.x, c->env_h)];
+    *u = c->conditional[(size_t)nearest_idx(*v, c->env_h) * c->env_w + nearest_idx(r.y, c->env_w)];
 }
 
 static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
@@ -552,29 +576,69 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
         diffW *= invW;
         isDiffuseSample = random.z < diffW;
     }
-    v3 diffuseRay = cosine_sample_hemisphere(viewNormal, random.x, random.y);
-    v3 specularRay = l;
+    /* importanceSampling :197-216 */
+    float emsPdf = 1.0f;
+    int isEnvSample = 0;
+    v3 envMisDir = V3(0, 0, 0);
+    if (p->importanceSampling) {
+        float cu, cv;
+        k1_cdf_uv(c, x, y, &cu, &cv);
+        /* equirectUvToDirection ssgi_utils.frag:77-86 */
+        float theta = ((cu - 0.5f) * 2.0f) * M_PIf, phi = (1.0f - cv) * M_PIf;
+        float sinPhi = sinf(phi);
+        v3 derived = V3(sinPhi * cosf(theta), cosf(phi), sinPhi * sinf(theta));
+        /* texture(info.map, uv): implicit lod, one per 2x2 quad from its top-left pixel's differences (measured on llvmpipe) */
+        int qx = x & ~1, qy = y & ~1;
+        float tlu, tlv, tru, trv, blu, blv;
+        k1_cdf_uv(c, qx, qy, &tlu, &tlv); k1_cdf_uv(c, qx + 1, qy, &tru, &trv); k1_cdf_uv(c, qx, qy + 1, &blu, &blv);
+        float fw = (float)c->env_w, fh = (float)c->env_h;
+        float ax = (tru - tlu) * fw, ay = (trv - tlv) * fh, bx = (blu - tlu) * fw, by = (blv - tlv) * fh;
+        float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
+        uint32_t bits; memcpy(&bits, &rho2, 4);
+        uint32_t mb = (bits & 0x7fffffu) | 0x3f800000u; float mant; memcpy(&mant, &mb, 4);
+        float lod = 0.5f * ((float)((int)((bits >> 23) & 0xffu) - 127) + (mant - 1.0f));
+        v3 col = k1_env_trilinear(c, cu, cv, lod);
+        float totalSum = c->totalSumWhole + c->totalSumDecimal;
+        emsPdf = ((float)c->env_w * (float)c->env_h) * (lum(col) / totalSum);
+        envMisDir = normalize3(v4_mul_mat_xyz(C, derived, 0.0f)); /* (vec4(dir, 0.) * cameraMatrixWorld).xyz */
+        float prob = dot3(envMisDir, viewNormal);
+        prob *= mat.roughness;
+        prob = fminf(1.0f - 0.00001f, prob);
+        isEnvSample = random.w < prob;
+        if (isEnvSample) {
+            emsPdf /= 1.0f - prob;
+            l = envMisDir;
+            calc_angles(l, vv, n, &NoL, &NoH, &LoH, &VoH);
+        } else {
+            emsPdf = 1.0f - prob;
+        }
+    }
+    v3 diffuseRay = isEnvSample ? envMisDir : cosine_sample_hemisphere(viewNormal, random.x, random.y);
+    v3 specularRay = isEnvSample ? envMisDir : l;
     v3 diffuseGI = V3(0, 0, 0), specularGI = V3(0, 0, 0), hitPos = V3(0, 0, 0);
     float diffuseSamples = 0.0f;
     float brdf, pdf;
     if (p->mode == 0 && isDiffuseSample) { /* :222-242 */
         l = diffuseRay;
         calc_angles(l, vv, n, &NoL, &NoH, &LoH, &VoH);
-        v3 gi = k1_do_sample(c, &mat, viewPos, viewNormal, mat.metalness, roughnessSq, isDiffuseSample, NoV, NoL, NoH, LoH, VoH, random,
+        v3 gi = k1_do_sample(c, &mat, viewPos, viewNormal, mat.metalness, roughnessSq, isDiffuseSample, isEnvSample, NoV, NoL, NoH, LoH, VoH, random,
                              &l, &hitPos, &brdf, &pdf);
         gi = mul3(gi, brdf);
-        gi = V3(gi.x / pdf, gi.y / pdf, gi.z / pdf);
-        gi = V3(gi.x / 1.0f, gi.y / 1.0f, gi.z / 1.0f); /* ems.pdf = 1 */
+        if (isEnvSample) gi = mul3(gi, (emsPdf * emsPdf) / (emsPdf * emsPdf + pdf * pdf)); /* misHeuristic */
+        else gi = V3(gi.x / pdf, gi.y / pdf, gi.z / pdf);
+        gi = V3(gi.x / emsPdf, gi.y / emsPdf, gi.z / emsPdf);
         diffuseSamples += 1.0f;
         diffuseGI = gi; /* mix(0, gi, 1/1) */
     }
     l = specularRay; /* :246-265 */
     calc_angles(l, vv, n, &NoL, &NoH, &LoH, &VoH);
     {
-        v3 gi = k1_do_sample(c, &mat, viewPos, viewNormal, mat.metalness, roughnessSq, isDiffuseSample, NoV, NoL, NoH, LoH, VoH, random,
+        v3 gi = k1_do_sample(c, &mat, viewPos, viewNormal, mat.metalness, roughnessSq, isDiffuseSample, isEnvSample, NoV, NoL, NoH, LoH, VoH, random,
                              &l, &hitPos, &brdf, &pdf);
         gi = mul3(gi, brdf);
-        gi = V3(gi.x / pdf, gi.y / pdf, gi.z / pdf);
+        if (isEnvSample) gi = mul3(gi, (emsPdf * emsPdf) / (emsPdf * emsPdf + pdf * pdf));
+        else gi = V3(gi.x / pdf, gi.y / pdf, gi.z / pdf);
+        gi = V3(gi.x / emsPdf, gi.y / emsPdf, gi.z / emsPdf);
         specularGI = gi;
     }
     v3 specularHitPos = hitPos;
@@ -682,14 +746,16 @@ int rfxo_env_build(const float *base, int w, int h, int half, int rtz, float *ou
 
 /* env: the chain rfxo_env_build made (NULL without USE_ENVMAP) */
 int rfxo_ssgi(int W, int H, int y0, int y1, const float *depth, const uint32_t *gbuffer, const float *direct, const float *history,
-              const uint8_t *blue, const rfx_ssgi_params *p, uint32_t *out, const float *env, int env_w, int env_h, int env_levels) {
-    if ((p->mode != 0 && p->mode != 1) || p->importanceSampling) return RFX_EUNSUPPORTED;
+              const uint8_t *blue, const rfx_ssgi_params *p, uint32_t *out, const float *env, int env_w, int env_h, int env_levels,
+              const float *marginal, const float *conditional, float totalSumWhole, float totalSumDecimal) {
+    if (p->mode != 0 && p->mode != 1) return RFX_EUNSUPPORTED;
     if (p->useEnvMap && !env) return RFX_ESTATE;
+    if (p->importanceSampling && (!p->useEnvMap || !marginal || !conditional)) return RFX_ESTATE;
     /* resolutionScale (SSGIPass.js:52-57): `out` is then the (W*s) x (H*s) target, pitch W*s, and y0/y1 are rows of THAT target */
     const float rs = p->resolutionScale == 0.0f ? 1.0f : p->resolutionScale;
     const int oW = (int)((float)W * rs), oH = (int)((float)H * rs);
     if ((float)oW != (float)W * rs || (float)oH != (float)H * rs || oW < 1 || oH < 1) return RFX_EINVAL;
-    k1_ctx c = {W, H, depth, gbuffer, direct, history, blue, p, 0, 0, 0, env, env_w, env_h, env_levels, oW, oH};
+    k1_ctx c = {W, H, depth, gbuffer, direct, history, blue, p, 0, 0, 0, env, env_w, env_h, env_levels, oW, oH, marginal, conditional, totalSumWhole, totalSumDecimal};
     /* SSGIPass.js:84-87: JS doubles rounded to float uniforms */
     c.nearMulFar = (float)((double)p->camera.near_ * (double)p->camera.far_);
     c.farMinusNear = (float)((double)p->camera.far_ - (double)p->camera.near_);

@@ -66,6 +66,16 @@ class EnvMap:
         self.chain = np.zeros(n * 4, np.float32)
         self.levels = lib().rfxo_env_build(_p(base), self.w, self.h, int(half), int(rtz), _p(self.chain))
         assert self.levels > 0, self.levels
+        self.marginal = self.conditional = None  # EquirectHdrInfo tables (set_importance), needed for importanceSampling
+        self.total_whole = self.total_decimal = 0.0
+
+    def set_importance(self, marginal, conditional, total_sum):
+        """The tables the reference's CPU pass computes (rfx_amd.envmap.build_importance, pinned to the reference's own JS)."""
+        self.marginal = np.ascontiguousarray(marginal, np.float32)
+        self.conditional = np.ascontiguousarray(conditional, np.float32)
+        assert self.marginal.shape == (self.h,) and self.conditional.shape == (self.h, self.w)
+        self.total_whole = float(int(total_sum))  # ~~totalSumValue
+        self.total_decimal = float(total_sum - int(total_sum))
 
     def level(self, l):
         off, w, h = 0, self.w, self.h
@@ -86,7 +96,10 @@ def ssgi(depth, gbuffer, direct, history, blue, params: abi.SsgiParams, out=None
         assert out.shape == (oH, oW, 4) and out.flags["C_CONTIGUOUS"]
     rc = lib().rfxo_ssgi(W, H, y0, y1, _p(_chk(depth, np.float32)), _p(_chk(gbuffer, np.uint32, (H, W, 4))), _p(_chk(direct, np.float32, (H, W, 4))),
                          _p(_chk(history, np.float32, (H, W, 4))), _p(_chk(blue, np.uint8)), C.byref(params), _p(out),
-                         _p(env.chain) if env is not None else None, env.w if env else 0, env.h if env else 0, env.levels if env else 0)
+                         _p(env.chain) if env is not None else None, env.w if env else 0, env.h if env else 0, env.levels if env else 0,
+                         _p(env.marginal) if env is not None and env.marginal is not None else None,
+                         _p(env.conditional) if env is not None and env.conditional is not None else None,
+                         C.c_float(env.total_whole if env else 0.0), C.c_float(env.total_decimal if env else 0.0))
     assert rc == 0, rc
     return out
 

@@ -236,7 +236,15 @@ RFX_DEV float k1_acos(float x) {
 }
 // getEnvColor ssgi.frag:311-346 (no BOX_PROJECTED_ENV_MAP, isEnvSample false without MIS): textureLod(map, equirectDirectionToUv(dir), mip)
 // with LinearMipMapLinearFilter = two bilinear taps blended by fract(lod), lod clamped to the chain
-RFX_DEV float3 k1_env_color(const K1Args &A, float3 l, float roughness, bool isDiffuseSample) {
+RFX_DEV float3 k1_env_trilinear(const K1Args &A, float u, float v, float lod_unclamped) {
+    const float lod = fminf(fmaxf(lod_unclamped, 0.0f), (float)(A.env_levels - 1));
+    const float fl = floorf(lod);
+    const int l0 = (int)fl, l1 = min(l0 + 1, A.env_levels - 1);
+    const float3 c0 = k1_env_level(A, l0, u, v), c1 = k1_env_level(A, l1, u, v);
+    const float f = lod - fl;
+    return make_float3(rfx_lerp(f, c0.x, c1.x), rfx_lerp(f, c0.y, c1.y), rfx_lerp(f, c0.z, c1.z));
+}
+RFX_DEV float3 k1_env_color(const K1Args &A, float3 l, float roughness, bool isDiffuseSample, bool isEnvSample) {
     const float3 dir = rfx_normalize(rfx_vec_mul_mat(A.p.camera.matrixWorldInverse, l, 0.0f));  // (vec4(l, 0.) * viewMatrix).xyz :315
     float mip = A.p.envBlur * A.maxEnvMapMipLevel;
     if (!isDiffuseSample && roughness < 0.15f) mip *= roughness / 0.15f;
@@ -244,26 +252,56 @@ RFX_DEV float3 k1_env_color(const K1Args &A, float3 l, float roughness, bool isD
     float u = atan2f(dir.z, dir.x) / (2.0f * 3.1415926535897932384626433832795f), v = k1_acos(dir.y) / 3.1415926535897932384626433832795f;
     u += 0.5f;
     v = 1.0f - v;
-    const float lod = fminf(fmaxf(mip, 0.0f), (float)(A.env_levels - 1));
-    const float fl = floorf(lod);
-    const int l0 = (int)fl, l1 = min(l0 + 1, A.env_levels - 1);
-    const float3 c0 = k1_env_level(A, l0, u, v), c1 = k1_env_level(A, l1, u, v);
-    const float f = lod - fl;
-    float3 c = make_float3(rfx_lerp(f, c0.x, c1.x), rfx_lerp(f, c0.y, c1.y), rfx_lerp(f, c0.z, c1.z));
-    const float maxEnvLum = 25.0f, envLum = rfx_lum(c);  // :330-340
+    float3 c = k1_env_trilinear(A, u, v, mip);
+    const float maxEnvLum = isEnvSample ? 100.0f : 25.0f, envLum = rfx_lum(c);  // :328-340
     if (envLum > maxEnvLum) c = c * (maxEnvLum / envLum);
     return c;
 }
 
+// ---- importanceSampling (ssgi.frag:197-216, sampleEquirectProbability ssgi_utils.frag:210-225)
+// uv of the environment texel the pixel's blue-noise pair selects through the two inverse-CDF tables: marginalWeights is an env_h x 1 NEAREST
+// texture read at (blueNoise.x, 0), conditionalWeights an env_w x env_h one read at (blueNoise.y, v)
+// A pixel that is background (main() returned before the blue-noise fetch, ssgi.frag:109-113) or outside the target takes part in its quad's
+// derivatives with `random` = 0, its zero initialisation: GLSL leaves derivatives after a non-uniform return undefined, this is what the
+// oracle's GL does (measured).
+RFX_DEV float2 k1_cdf_uv(const K1Args &A, const FrameDims &d, int px, int py) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (px < A.out_w && py < A.out_h) {
+        const int sx = rfx_nearest_idx(((float)px + 0.5f) / (float)A.out_w, d.fW, d.W), sy = rfx_nearest_idx(((float)py + 0.5f) / (float)A.out_h, d.fH, d.H);
+        if (((const float *)A.depth.ptr)[rfx_xy_index(d, A.depth.row0, A.depth.rows, sx, sy)] != 1.0f)
+            r = rfx_blue_noise((const uchar4 *)A.blue, px, py, A.shift_x, A.shift_y);
+    }
+    const float v = A.env_marginal[rfx_nearest_idx(r.x, (float)A.env_h, A.env_h)];
+    const float u = A.env_conditional[rfx_nearest_idx(v, (float)A.env_h, A.env_h) * A.env_w + rfx_nearest_idx(r.y, (float)A.env_w, A.env_w)];
+    return make_float2(u, v);
+}
+// `texture(info.map, uv)` — implicit level of detail.  uv is an unrelated value in every pixel, so the level is whatever the rasteriser derives
+// from the 2x2 quad; the oracle's (llvmpipe, measured to 4 decimals on a chain whose level l holds the constant l): ONE lod per quad, from
+// the differences tr - tl and bl - tl of the quad's top-left pixel, rho^2 = max(|dP/dx|^2, |dP/dy|^2) with P in texels, and
+// lod = 0.5 * (exponent(rho^2) + mantissa(rho^2) - 1)  (a linear-mantissa log2), clamped to the chain, blended by fract(lod).
+RFX_DEV float k1_implicit_lod(const K1Args &A, float2 tl, float2 tr, float2 bl) {
+    const float fw = (float)A.env_w, fh = (float)A.env_h;
+    const float ax = (tr.x - tl.x) * fw, ay = (tr.y - tl.y) * fh, bx = (bl.x - tl.x) * fw, by = (bl.y - tl.y) * fh;
+    const float rho2 = fmaxf(ax * ax + ay * ay, bx * bx + by * by);
+    const uint32_t bits = __float_as_uint(rho2);
+    const float e = (float)((int)((bits >> 23) & 0xffu) - 127), m = __uint_as_float((bits & 0x7fffffu) | 0x3f800000u);
+    return 0.5f * (e + (m - 1.0f));
+}
+struct EnvMis {  // EnvMisSample ssgi.frag:79-83
+    float pdf;
+    bool isEnvSample;
+};
+RFX_DEV float k1_mis_heuristic(float a, float b) { return (a * a) / (a * a + b * b); }  // misHeuristic ssgi_utils.frag:227-231
+
 // ... and the shading of the marched ray: gi * brdf / pdf
-template <bool ENV>
+template <bool ENV, bool MIS>
 RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat, float roughness, const Ray &ray, float3 l, bool isDiffuseSample, float brdf,
-                        float pdf) {
+                        float pdf, EnvMis ems) {
     const bool allowMissed = A.p.missedRays != 0;
     const bool isMissed = ray.pos.x == 10.0e9f;
     // without an env map getEnvColor is black (:342-345)
     float3 env = make_float3(0.f, 0.f, 0.f);
-    if (ENV) env = k1_env_color(A, l, roughness, isDiffuseSample);
+    if (ENV) env = k1_env_color(A, l, roughness, isDiffuseSample, MIS && ems.isEnvSample);
     float3 ssgi = env;
     if (!(isMissed && !allowMissed)) {  // :393-395 a missed ray takes the environment
         // velocityTexture is never wired in the reference (SSGIPass.js:89) -> velocity == 0
@@ -287,11 +325,14 @@ RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat
         }
         // else :425-427 the reprojected coordinates left the screen: the environment
     }
-    ssgi = ssgi * brdf;
-    return make_float3(ssgi.x / pdf, ssgi.y / pdf, ssgi.z / pdf);
+    ssgi = ssgi * brdf;  // :236-244 / :256-264
+    if (MIS && ems.isEnvSample) ssgi = ssgi * k1_mis_heuristic(ems.pdf, pdf);
+    else ssgi = make_float3(ssgi.x / pdf, ssgi.y / pdf, ssgi.z / pdf);
+    if (MIS) ssgi = make_float3(ssgi.x / ems.pdf, ssgi.y / ems.pdf, ssgi.z / ems.pdf);  // without MIS ems.pdf == 1
+    return ssgi;
 }
 
-template <bool PERSP, bool ENV>
+template <bool PERSP, bool ENV, bool MIS>
 RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     // XCD-aware mapping: hardware block b runs on XCD b % 8 (observed, used for speed only); give XCD k the k-th
     // contiguous eighth of the row-major tile list, i.e. an image band, so its L2 sees a compact part of the depth plane
@@ -368,7 +409,37 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
         diffW *= invW;
         isDiffuseSample = rnd.z < diffW;
     }
-    const float3 specularRay = l;
+    EnvMis ems;
+    ems.pdf = 1.0f;
+    ems.isEnvSample = false;
+    float3 envMisDir = make_float3(0.f, 0.f, 0.f);
+    if (MIS) {  // :197-216
+        const float2 uv = k1_cdf_uv(A, d, x, y);
+        // equirectUvToDirection ssgi_utils.frag:77-86
+        float sph, cph, sth, cth;
+        {
+            const float theta = ((uv.x - 0.5f) * 2.0f) * 3.141592653589793f, phi = (1.0f - uv.y) * 3.141592653589793f;
+            sph = sinf(phi); cph = cosf(phi); sth = sinf(theta); cth = cosf(theta);
+        }
+        const float3 derived = make_float3(sph * cth, cph, sph * sth);
+        const int qx = x & ~1, qy = y & ~1;
+        const float lod = k1_implicit_lod(A, k1_cdf_uv(A, d, qx, qy), k1_cdf_uv(A, d, qx + 1, qy), k1_cdf_uv(A, d, qx, qy + 1));
+        const float3 col = k1_env_trilinear(A, uv.x, uv.y, lod);
+        const float totalSum = A.totalSumWhole + A.totalSumDecimal;
+        ems.pdf = ((float)A.env_w * (float)A.env_h) * (rfx_lum(col) / totalSum);
+        envMisDir = rfx_normalize(rfx_vec_mul_mat(C, derived, 0.0f));  // (vec4(dir, 0.) * cameraMatrixWorld).xyz :199
+        float prob = rfx_dot(envMisDir, viewNormal);
+        prob *= mat.roughness;
+        prob = fminf(1.0f - 0.00001f, prob);
+        ems.isEnvSample = rnd.w < prob;
+        if (ems.isEnvSample) {
+            ems.pdf /= 1.0f - prob;
+            l = envMisDir;
+        } else {
+            ems.pdf = 1.0f - prob;
+        }
+    }
+    const float3 specularRay = l;  // :218-219 (l already is envMisDir for an env sample)
     float3 dl = make_float3(0.f, 0.f, 0.f);
     if (p.useDirectLight) {
         const float4 t = ((const float4 *)A.direct.ptr)[gi_idx];
@@ -381,7 +452,7 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     rays[0].pos = viewPos;
     rays[0].dir = make_float3(0.f, 0.f, 0.f);
     if (isDiffuseSample) {  // :222-242
-        const float3 diffuseRay = rfx_cosine_sample_hemisphere(viewNormal, rnd.x, rnd.y);
+        const float3 diffuseRay = (MIS && ems.isEnvSample) ? envMisDir : rfx_cosine_sample_hemisphere(viewNormal, rnd.x, rnd.y);
         diffuseRayDir = diffuseRay;
         const Angles ad = k1_angles(diffuseRay, vv, n);
         brdfD = k1_brdf_over_pdf_parts(mat, viewNormal, roughnessSq, true, NoV, ad, diffuseRay, pdfD);
@@ -396,8 +467,8 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     k1_march_rays<PERSP>(m, d, rays, rnd.z);
 
     float3 diffuseGI = make_float3(-1.0f, -1.0f, -1.0f);  // "not sampled this frame" marker :277-278
-    if (isDiffuseSample) diffuseGI = k1_shade<ENV>(d, A, mat, roughnessSq, rays[0], diffuseRayDir, true, brdfD, pdfD) + dl;
-    const float3 specularGI = k1_shade<ENV>(d, A, mat, roughnessSq, rays[1], specularRay, isDiffuseSample, brdfS, pdfS) + dl;
+    if (isDiffuseSample) diffuseGI = k1_shade<ENV, MIS>(d, A, mat, roughnessSq, rays[0], diffuseRayDir, true, brdfD, pdfD, ems) + dl;
+    const float3 specularGI = k1_shade<ENV, MIS>(d, A, mat, roughnessSq, rays[1], specularRay, isDiffuseSample, brdfS, pdfS, ems) + dl;
     const float3 hitPos = rays[1].pos;
 
     float rayLength = 0.0f;  // :284-296
@@ -413,11 +484,11 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     }
 }
 
-template <bool PERSP, bool ENV>
+template <bool PERSP, bool ENV, bool MIS>
 __global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-    k1_ssgi_march_body<PERSP, ENV>(A, d);
+    k1_ssgi_march_body<PERSP, ENV, MIS>(A, d);
     rfx_flush_violations(d);
 }
 
@@ -500,10 +571,10 @@ hipError_t rfx_launch_k1(const K1Args &A, hipStream_t stream) {
     const float *P = A.p.camera.projectionMatrix;
     const bool persp = P[1] == 0.f && P[2] == 0.f && P[3] == 0.f && P[4] == 0.f && P[6] == 0.f && P[7] == 0.f && P[12] == 0.f && P[13] == 0.f &&
                        P[15] == 0.f && P[11] == -1.f;
-    const bool env = A.p.useEnvMap != 0;
-    if (persp && !env) hipLaunchKernelGGL((k1_ssgi_march<true, false>), grid, block, 0, stream, A);
-    else if (persp) hipLaunchKernelGGL((k1_ssgi_march<true, true>), grid, block, 0, stream, A);
-    else if (!env) hipLaunchKernelGGL((k1_ssgi_march<false, false>), grid, block, 0, stream, A);
-    else hipLaunchKernelGGL((k1_ssgi_march<false, true>), grid, block, 0, stream, A);
+    const bool env = A.p.useEnvMap != 0, mis = env && A.p.importanceSampling != 0;
+#define K1_GO(P, E, M) hipLaunchKernelGGL((k1_ssgi_march<P, E, M>), grid, block, 0, stream, A)
+    if (persp) { if (mis) K1_GO(true, true, true); else if (env) K1_GO(true, true, false); else K1_GO(true, false, false); }
+    else { if (mis) K1_GO(false, true, true); else if (env) K1_GO(false, true, false); else K1_GO(false, false, false); }
+#undef K1_GO
     return hipGetLastError();
 }

@@ -182,25 +182,17 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
     const float3 fwn = make_float3(fabsf(xb.x - xa.x) + fabsf(yb.x - ya.x), fabsf(xb.y - xa.y) + fabsf(yb.y - ya.y), fabsf(xb.z - xa.z) + fabsf(yb.z - ya.z));
     const float curvature = rfx_length(fwn);  // getCurvature reproject.frag:265-269
 
-    // getTexels + preprocessInput :124-145
-    float4 inp[TC];
-    bool sampled[TC];
-#pragma unroll
-    for (int i = 0; i < TC; i++) {
-        inp[i] = s.tex[i][ci];
-        sampled[i] = inp[i].x >= 0.0f;
-        const float3 c = k2_to_log<LOGT>(make_float3(fmaxf(inp[i].x, 0.0f), fmaxf(inp[i].y, 0.0f), fmaxf(inp[i].z, 0.0f)));
-        inp[i].x = c.x; inp[i].y = c.y; inp[i].z = c.z;
-    }
+    // getTexels + preprocessInput :124-145 happen per texture below (the centre texel is re-read from LDS there instead of being held in
+    // registers across the disocclusion tests); only the two scalars getRoughnessRayLength needs are taken here
     const float3 worldNormal = make_float3(cvn.x, cvn.y, cvn.z);
     const float3 worldPos = k2_ss_to_ws(u, v, depth, p.camera.matrixWorld, p.camera.projectionMatrixInverse);
     float rayLength = 0.0f, roughness = 1.0f;  // getRoughnessRayLength :167-176
     if (INPUT_TYPE == 0) {
-        rayLength = inp[TC - 1].w;
-        roughness = rfx_clamp(inp[0].w, 0.0f, 1.0f);
+        rayLength = s.tex[TC - 1][ci].w;
+        roughness = rfx_clamp(s.tex[0][ci].w, 0.0f, 1.0f);
     } else if (INPUT_TYPE == 2) {
         float rl, ro;
-        rfx_unpack_half2(__float_as_uint(inp[0].w), rl, ro);
+        rfx_unpack_half2(__float_as_uint(s.tex[0][ci].w), rl, ro);
         rayLength = rl;
         roughness = rfx_clamp(ro, 0.0f, 1.0f);
     }
@@ -250,8 +242,10 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
 #endif
         float3 accrgb = k2_to_log<LOGT>(make_float3(acc.x, acc.y, acc.z));
         float acca = acc.w;
-        float3 inrgb = make_float3(inp[i].x, inp[i].y, inp[i].z);
-        if (!sampled[i]) {
+        const float4 inp = s.tex[i][ci];  // preprocessInput :124-128 (an unsampled texel was staged with NaN rgb: !(NaN >= 0))
+        const bool sampled_i = inp.x >= 0.0f;
+        float3 inrgb = k2_to_log<LOGT>(make_float3(fmaxf(inp.x, 0.0f), fmaxf(inp.y, 0.0f), fmaxf(inp.z, 0.0f)));
+        if (!sampled_i) {
             inrgb = accrgb;
         } else {
             acca += 1.0f;

@@ -26,6 +26,8 @@ struct rfx_ctx {
     float *viewz = nullptr;    // K1 scratch: view-space Z plane (full frame)
     float2 *coarse = nullptr;  // K1 scratch: (min,max) view Z per 8x8 cell
     float4 *env = nullptr;     // scene.environment: the whole mip chain, float4 texels
+    float *env_marginal = nullptr, *env_conditional = nullptr;  // EquirectHdrInfo inverse-CDF tables (importanceSampling)
+    float env_sum_whole = 1.0f, env_sum_decimal = 0.0f;
     int env_w = 0, env_h = 0, env_levels = 0;
     unsigned int env_off[16] = {0};
     Slot slots[RFX_TEX_COUNT];
@@ -111,6 +113,8 @@ void rfx_destroy(rfx_ctx *c) {
     if (c->viewz) hipFree(c->viewz);
     if (c->coarse) hipFree(c->coarse);
     if (c->env) hipFree(c->env);
+    if (c->env_marginal) hipFree(c->env_marginal);
+    if (c->env_conditional) hipFree(c->env_conditional);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -324,6 +328,9 @@ int rfx_set_environment(rfx_ctx *c, const float *rgba, int width, int height, in
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->env) hipFree(c->env);
         c->env = nullptr; c->env_w = c->env_h = c->env_levels = 0;
+        if (c->env_marginal) hipFree(c->env_marginal);
+        if (c->env_conditional) hipFree(c->env_conditional);
+        c->env_marginal = c->env_conditional = nullptr;
         return RFX_OK;
     }
     if (width < 1 || height < 1 || width > 16384 || height > 16384 || (width & (width - 1)) || (height & (height - 1)))
@@ -339,6 +346,9 @@ int rfx_set_environment(rfx_ctx *c, const float *rgba, int width, int height, in
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->env) hipFree(c->env);
     c->env = nullptr; c->env_w = c->env_h = c->env_levels = 0;
+    if (c->env_marginal) hipFree(c->env_marginal);  // tables of the previous map: a new one needs its own
+    if (c->env_conditional) hipFree(c->env_conditional);
+    c->env_marginal = c->env_conditional = nullptr;
     hipError_t e = hipMalloc((void **)&c->env, total * sizeof(float4));
     if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(environment)", e);
     // staging copy of the base level, then level 0 = the texels in the texture's type, then the chain
@@ -369,6 +379,24 @@ int rfx_set_environment(rfx_ctx *c, const float *rgba, int width, int height, in
     return RFX_OK;
 }
 
+int rfx_set_environment_importance(rfx_ctx *c, const float *marginal, const float *conditional, float totalSumWhole, float totalSumDecimal) {
+    if (!c || !marginal || !conditional) return RFX_EINVAL;
+    if (!c->env) return fail(c, RFX_ESTATE, "rfx_set_environment_importance: no environment set");
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->env_marginal) hipFree(c->env_marginal);
+    if (c->env_conditional) hipFree(c->env_conditional);
+    c->env_marginal = c->env_conditional = nullptr;
+    hipError_t e = hipMalloc((void **)&c->env_marginal, (size_t)c->env_h * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->env_conditional, (size_t)c->env_w * c->env_h * sizeof(float));
+    if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(environment importance tables)", e);
+    HIPCHK(c, hipMemcpyAsync(c->env_marginal, marginal, (size_t)c->env_h * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->env_conditional, conditional, (size_t)c->env_w * c->env_h * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->env_sum_whole = totalSumWhole; c->env_sum_decimal = totalSumDecimal;
+    return RFX_OK;
+}
+
 int rfx_download_environment(rfx_ctx *c, int level, float *rgba, int *levels) {
     if (!c) return RFX_EINVAL;
     if (levels) *levels = c->env_levels;
@@ -384,7 +412,8 @@ int rfx_download_environment(rfx_ctx *c, int level, float *rgba, int *levels) {
 int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
     if (!c || !p) return RFX_EINVAL;
     if (p->mode != 0 && p->mode != 1) return fail(c, RFX_EINVAL, "rfx_ssgi_march: mode must be 0 (MODE_SSGI) or 1 (MODE_SSR)");
-    if (p->importanceSampling) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: importanceSampling (env-map MIS) is not built");
+    if (p->importanceSampling && (!p->useEnvMap || !c->env_marginal))
+        return fail(c, RFX_ESTATE, "rfx_ssgi_march: importanceSampling needs useEnvMap and rfx_set_environment_importance");
     if (p->useEnvMap && !c->env) return fail(c, RFX_ESTATE, "rfx_ssgi_march: useEnvMap without rfx_set_environment");
     if (p->steps < 1 || p->refineSteps < 0) return fail(c, RFX_EINVAL, "rfx_ssgi_march: steps/refineSteps");
     hipSetDevice(c->device);
@@ -437,6 +466,8 @@ int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
     A.xcd_map = xcd;
     A.env = c->env;
     A.env_w = c->env_w; A.env_h = c->env_h; A.env_levels = c->env_levels;
+    A.env_marginal = c->env_marginal; A.env_conditional = c->env_conditional;
+    A.totalSumWhole = c->env_sum_whole; A.totalSumDecimal = c->env_sum_decimal;
     memcpy(A.env_off, c->env_off, sizeof A.env_off);
     {   // getMaxMipLevel (src/ssgi/utils/Utils.js:30-34): floor(log2(max(w, h))) + 1
         int m = c->env_w > c->env_h ? c->env_w : c->env_h, lg = 0;

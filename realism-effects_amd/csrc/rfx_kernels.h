@@ -25,6 +25,8 @@ struct K1Args {
     int env_w, env_h, env_levels;
     unsigned int env_off[16];
     float maxEnvMapMipLevel;
+    const float *env_marginal, *env_conditional;  // EquirectHdrInfo.marginalWeights (env_h) / conditionalWeights (env_w x env_h), importanceSampling
+    float totalSumWhole, totalSumDecimal;
     int out_w, out_h;  // the pass's render target = `resolution` (frame size unless resolutionScale != 1)
 };
 

@@ -119,6 +119,12 @@ class Renderer {
 		addon.setEnvironment(this._h, data || null, width || 0, height || 0, halfFloatType ? 1 : 0, halfStoreRTZ ? 1 : 0)
 	}
 
+	// EquirectHdrInfoUniform's tables for importanceSampling (js/envmap.js buildImportance) — rfx_set_environment_importance
+	setEnvironmentImportance(marginalWeights, conditionalWeights, totalSumValue) {
+		const whole = Math.trunc(totalSumValue) // ~~totalSumValue (EquirectHdrInfoUniform.js:391-394)
+		addon.setEnvironmentImportance(this._h, marginalWeights, conditionalWeights, whole, totalSumValue - whole)
+	}
+
 	// the four draws + the framebuffer copy (include/rfx.h)
 	ssgiMarch(uniforms) {
 		addon.ssgiMarch(this._h, uniforms)

@@ -14,6 +14,7 @@
 // src/temporal-reproject/TemporalReprojectPass.js, src/temporal-reproject/pass/VelocityDepthNormalPass.js,
 // src/traa/TRAAEffect.js, src/utils/BlueNoiseUtils.js, src/utils/SceneUtils.js
 const { TEX } = require("./Renderer")
+const { buildImportance } = require("./envmap")
 
 // src/ssgi/SSGIOptions.js:26-48
 const defaultSSGIOptions = {
@@ -593,7 +594,8 @@ class SSGIEffect {
 							this.reset()
 							break
 						case "importanceSampling":
-							// only effective with an env map (SSGIEffect.js:344-354); the dumps carry none
+							// only effective with an env map (SSGIEffect.js:344-354): keepEnvMapUpdated re-reads the option when the environment is (re)set
+							this._envUuid = null
 							this.reset()
 							break
 						case "missedRays":
@@ -652,16 +654,30 @@ class SSGIEffect {
 		if (env) {
 			if (this._envUuid !== env) {
 				if (env.isCubeTexture) throw new Error("cube environment maps (CubeToEquirectEnvPass, :316-321) are not built: pass an equirectangular map")
-				if (this._options.importanceSampling)
-					throw new Error("importanceSampling with an environment map (env-map MIS, ssgi.frag:197-216) is not built: construct the effect with importanceSampling: false")
 				const half = env.type === undefined || env.type === null || env.type === HalfFloatType
 				renderer.setEnvironment(env.data, env.width, env.height, half, this._halfStoreRTZ === undefined || this._halfStoreRTZ)
+				u.importanceSampling = 0
+				if (this._options.importanceSampling) {
+					// :348-351 EquirectHdrInfoUniform.updateFrom, then the define.  The worker sees the half-float texels (fromHalfFloat); `data` is
+					// in GL row order (row 0 = bottom): with texture.flipY the reference's array is the other way up and the worker "un-flips" it
+					let texels = half ? toHalfPrecision(env.data) : env.data
+					if (env.flipY) {
+						const r = new Float32Array(texels.length)
+						const rowLen = env.width * 4
+						for (let y = 0; y < env.height; y++) r.set(texels.subarray(y * rowLen, (y + 1) * rowLen), (env.height - 1 - y) * rowLen)
+						texels = r
+					}
+					const imp = buildImportance(texels, env.width, env.height, !!env.flipY)
+					renderer.setEnvironmentImportance(imp.marginalWeights, imp.conditionalWeights, imp.totalSumValue)
+					u.importanceSampling = 1
+				}
 				this._envUuid = env
 				u.useEnvMap = 1 // defines.USE_ENVMAP :344
 				this.reset() // :356
 			}
 		} else if (u.useEnvMap) {
 			u.useEnvMap = 0 // :361-366
+			u.importanceSampling = 0
 			renderer.setEnvironment(null)
 			this._envUuid = null
 		}

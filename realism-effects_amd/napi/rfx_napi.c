@@ -282,6 +282,31 @@ static napi_value n_set_environment(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+/* setEnvironmentImportance(ctx, Float32Array marginal, Float32Array conditional, totalSumWhole, totalSumDecimal) */
+static napi_value n_set_environment_importance(napi_env env, napi_callback_info info) {
+    napi_value a[5];
+    if (!get_args(env, info, 5, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    const float *tab[2];
+    for (int k = 0; k < 2; k++) {
+        napi_typedarray_type tt;
+        size_t len;
+        void *ptr;
+        if (napi_get_typedarray_info(env, a[1 + k], &tt, &len, &ptr, NULL, NULL) != napi_ok || tt != napi_float32_array) {
+            napi_throw_type_error(env, NULL, "setEnvironmentImportance: Float32Array expected");
+            return NULL;
+        }
+        tab[k] = (const float *)ptr;
+    }
+    double whole = 0, dec = 0;
+    napi_get_value_double(env, a[3], &whole);
+    napi_get_value_double(env, a[4], &dec);
+    int rc = rfx_set_environment_importance(c, tab[0], tab[1], (float)whole, (float)dec);
+    if (rc) return throw_rfx(env, c, "rfx_set_environment_importance", rc);
+    return NULL;
+}
+
 /* ssgiMarch(ctx, {camera, steps, refineSteps, mode, useDirectLight, missedRays, importanceSampling,
  *                 rayDistance, thickness, envBlur, blueNoiseIndex}) */
 static napi_value n_ssgi(napi_env env, napi_callback_info info) {
@@ -470,7 +495,7 @@ static napi_value n_time_end(napi_env env, napi_callback_info info) {
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
-        {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
+        {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"setEnvironmentImportance", n_set_environment_importance}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
         {"sync", n_sync}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

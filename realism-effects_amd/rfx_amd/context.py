@@ -146,6 +146,15 @@ class Context:
         self._chk(self.lib.rfx_set_environment(self._h, a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0], 1 if half_float_type else 0,
                                                1 if half_store_rtz else 0), "rfx_set_environment")
 
+    def set_environment_importance(self, marginal, conditional, total_sum: float):
+        """The tables of EquirectHdrInfoUniform.updateFrom (rfx_amd.envmap.build_importance) for importanceSampling; totalSumValue is split the
+        way the reference splits it for its uniform struct (`~~total` and the rest, :391-394)."""
+        m = np.ascontiguousarray(marginal, np.float32)
+        c = np.ascontiguousarray(conditional, np.float32)
+        whole = float(int(total_sum))
+        self._chk(self.lib.rfx_set_environment_importance(self._h, m.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), whole, float(total_sum - whole)),
+                  "rfx_set_environment_importance")
+
     def download_environment(self, level: int, size) -> np.ndarray:
         """Mip level `level` of the environment; `size` = (width, height) of the base level."""
         w, h = max(size[0] >> level, 1), max(size[1] >> level, 1)

@@ -511,7 +511,8 @@ class SSGIEffect:
             setattr(self.ssgiPass.uniforms, key, int(value))
             self.reset()
         elif key == "importanceSampling":
-            # only effective with an env map (SSGIEffect.js:344-354); no env map in the dumps -> define stays unset
+            # only effective with an env map (SSGIEffect.js:344-354): keepEnvMapUpdated re-reads the option when the environment is (re)set
+            object.__setattr__(self, "_env_uuid", None)
             self.reset()
         elif key == "missedRays":
             self.ssgiPass.uniforms.missedRays = 1 if value else 0
@@ -563,16 +564,23 @@ class SSGIEffect:
                 get = (lambda k, d=None: env.get(k, d)) if isinstance(env, dict) else (lambda k, d=None: getattr(env, k, d))
                 if get("isCubeTexture"):
                     raise NotImplementedError("cube environment maps (CubeToEquirectEnvPass, :316-321) are not built: pass an equirectangular map")
-                if self._options["importanceSampling"]:
-                    raise NotImplementedError("importanceSampling with an environment map (env-map MIS, ssgi.frag:197-216) is not built: "
-                                              "construct the effect with importanceSampling=False")
                 t = get("type", HalfFloatType)
-                renderer.set_environment(get("data"), half_float_type=(t == HalfFloatType), half_store_rtz=self._half_store_rtz)
+                data = np.ascontiguousarray(get("data"), np.float32)
+                renderer.set_environment(data, half_float_type=(t == HalfFloatType), half_store_rtz=self._half_store_rtz)
+                u.importanceSampling = 0
+                if self._options["importanceSampling"]:  # :348-351 EquirectHdrInfoUniform.updateFrom, then the define
+                    from .envmap import build_importance
+                    texels = data.astype(np.float16).astype(np.float32) if t == HalfFloatType else data  # the worker's fromHalfFloat view
+                    # `data` is in GL row order (row 0 = bottom, as sampled).  With texture.flipY the reference's DataTexture array is the
+                    # other way up and the worker "un-flips" it (its own, lossy way): hand it what it would have seen
+                    flip = bool(get("flipY", False))
+                    renderer.set_environment_importance(*build_importance(texels[::-1] if flip else texels, flip))
+                    u.importanceSampling = 1
                 object.__setattr__(self, "_env_uuid", env)
                 u.useEnvMap = 1  # defines.USE_ENVMAP :344
                 self.reset()     # :356
         elif u.useEnvMap:  # :361-366
-            u.useEnvMap = 0
+            u.useEnvMap = u.importanceSampling = 0
             renderer.set_environment(None)
             object.__setattr__(self, "_env_uuid", None)
 

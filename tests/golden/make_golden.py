@@ -29,15 +29,39 @@ import chain  # noqa: E402
 M = 0x7FFFFFFF
 
 
+def reference_importance(env, flip_y=False):
+    """EquirectHdrInfoUniform's CPU pass run by the REFERENCE'S OWN code: the worker function (plain ES2015) is cut out of
+    src/ssgi/utils/EquirectHdrInfoUniform.js at run time and executed by node with a stub postMessage."""
+    import json
+    import re
+    import subprocess
+    import tempfile
+    src = open("/root/reference/src/ssgi/utils/EquirectHdrInfoUniform.js", encoding="utf-8-sig").read()
+    fn = re.search(r"const workerOnMessage = (\(\{ data: \{ width, height, isFloatType, flipY, data \} \}\) => \{[\s\S]*?\n\})\n\nconst blob", src).group(1)
+    d = tempfile.mkdtemp()
+    h, w = env.shape[:2]
+    np.ascontiguousarray(env, np.float32).tofile(os.path.join(d, "env.bin"))
+    js = ("const fs=require('fs');let r=null;global.postMessage=x=>{r=x};const f=%s;const b=fs.readFileSync('%s/env.bin');"
+          "f({data:{width:%d,height:%d,isFloatType:true,flipY:%s,data:new Float32Array(b.buffer,b.byteOffset,b.length/4)}});"
+          "fs.writeFileSync('%s/m.bin',Buffer.from(r.marginalDataArray.buffer));fs.writeFileSync('%s/c.bin',Buffer.from(r.conditionalDataArray.buffer));"
+          "console.log(JSON.stringify(r.totalSumValue))") % (fn, d, w, h, "true" if flip_y else "false", d, d)
+    open(os.path.join(d, "run.js"), "w").write(js)
+    tot = json.loads(subprocess.check_output(["node", os.path.join(d, "run.js")], text=True))
+    return np.fromfile(os.path.join(d, "m.bin"), np.float32), np.fromfile(os.path.join(d, "c.bin"), np.float32).reshape(h, w), float(tot)
+
+
 def cam_arrays(cam, prefix):
     return {prefix + k: np.asarray(getattr(cam, k)) for k in
             ("projectionMatrix", "projectionMatrixInverse", "matrixWorld", "matrixWorldInverse", "position", "quaternion")}
 
 
 def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_start=2000, mode="ssgi", missed_rays=False, denoise_mode="full",
-        environment=None, env_blur=0.5, resolution_scale=1.0, ortho_half_height=None):
+        environment=None, env_blur=0.5, resolution_scale=1.0, ortho_half_height=None, importance_sampling=False):
     bn = np.fromfile(os.path.join(ROOT, "realism-effects_amd", "data", "blue_noise_128_rgba8.bin"), np.uint8).reshape(128, 128, 4)
-    c = chain.GLRefChain(W, H, bn, steps=steps, refineSteps=refine, denoiseIterations=iterations, mode=mode, missedRays=missed_rays,
+    importance = None
+    if importance_sampling:  # the half-float map's texels, as the worker converts them (fromHalfFloat) before the CDF pass
+        importance = reference_importance(np.ascontiguousarray(environment, np.float32).astype(np.float16).astype(np.float32))
+    c = chain.GLRefChain(W, H, bn, steps=steps, refineSteps=refine, denoiseIterations=iterations, mode=mode, missedRays=missed_rays, importance=importance,
                          denoiseMode=denoise_mode, environment=environment, envBlur=env_blur, resolutionScale=resolution_scale,
                          orthographic=ortho_half_height is not None)
     tc = c.tc
@@ -47,6 +71,9 @@ def run(name, W, H, frames, steps, refine, iterations, ssgi_start=1000, denoise_
     out["orthographic"] = int(ortho_half_height is not None)
     if environment is not None:  # scene.environment (HalfFloatType, mipmapped by the effect) + the envBlur option
         out["environment"], out["envBlur"] = environment, env_blur
+    out["importanceSampling"] = int(importance_sampling)
+    if importance is not None:  # what the reference's own JS produced: pins rfx_amd.envmap / js/envmap.js
+        out["marginalWeights"], out["conditionalWeights"], out["totalSumValue"] = importance
     si = di = 0
     for fi in range(frames):
         f = synthetic_frame(W, H, fi, ortho_half_height=ortho_half_height)
@@ -149,6 +176,8 @@ if __name__ == "__main__":
     from rfx_amd.scene import synthetic_environment
     run("chain_env_128x72_s12r3_it1", 128, 72, frames=2, steps=12, refine=3, iterations=1, environment=synthetic_environment(128, 64))
     run("chain_envsharp_96x54_s12r3_it1", 96, 54, frames=2, steps=12, refine=3, iterations=1, environment=synthetic_environment(128, 64), env_blur=0.1)
+    run("chain_envmis_128x72_s12r3_it1", 128, 72, frames=2, steps=12, refine=3, iterations=1, environment=synthetic_environment(128, 64),
+        importance_sampling=True)  # the reference's DEFAULT with an environment: importanceSampling (MIS)
     # resolutionScale option.  Only scales whose sample positions fall on texel CENTRES of the full-resolution inputs are comparable
     # across rasterisers (0.5 at these sizes): 0.75 puts every third row exactly on a texel boundary, where the nearest texel depends on
     # the last ulp of the rasteriser's varying interpolation (llvmpipe's vUv differs from (i+0.5)/n by <= 1 ulp, measured) — there the

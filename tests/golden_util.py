@@ -10,6 +10,7 @@ GOLDEN_SSR = "chain_ssr_128x72_s20r5_it1"
 GOLDEN_ENV = ["chain_env_128x72_s12r3_it1", "chain_envsharp_96x54_s12r3_it1"]  # scene.environment (USE_ENVMAP), envBlur 0.5 / 0.1
 GOLDEN_ORTHO = "chain_ortho_120x68_s12r3_it1"  # OrthographicCamera: every pass without its PERSPECTIVE_CAMERA define
 GOLDEN_RS = ["chain_rs050_128x72_s12r3_it1"]  # resolutionScale 0.5 (SSGIPass.js:52-57); see make_golden.py on other scales
+GOLDEN_ENVMIS = "chain_envmis_128x72_s12r3_it1"  # USE_ENVMAP + importanceSampling (the default with an environment)
 GOLDEN_MODES = ["chain_full_temporal_104x58_s10r2", "chain_temporal_104x58_s10r2", "chain_denoised_104x58_s10r2"]  # Denoiser.js:7 denoiseMode
 GOLDEN_PACK = "pack_96x54"  # packGBuffer / packNormal (the raster passes' fragment epilogues) over attribute planes
 GOLDEN_FINAL = "final_112x63"  # SSGIEffect's own fragment: no fog / Fog / FogExp2 / isDebug

@@ -70,6 +70,10 @@ class OracleRenderer:
         self.calls.append(("set_environment", None if rgba is None else tuple(rgba.shape)))
         self.env = None if rgba is None else O.EnvMap(rgba, half=half_float_type, rtz=half_store_rtz)
 
+    def set_environment_importance(self, marginal, conditional, total_sum):
+        self.calls.append(("set_environment_importance", float(total_sum)))
+        self.env.set_importance(marginal, conditional, total_sum)
+
     def ssgi_march(self, p):
         self.calls.append(("ssgi", p.blueNoiseIndex))
         t = self.tex

@@ -220,13 +220,12 @@ def test_node_host_drives_the_gpu_bit_identically(tmp_path):
     envf = str(tmp_path / "env.bin")
     envimg.tofile(envf)
     res = subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", out, "--steps", "12", "--refineSteps", "3", "--env", json.dumps(envf),
-                                   "--envWidth", "64", "--envHeight", "32", "--importanceSampling", "false"], text=True)
+                                   "--envWidth", "64", "--envHeight", "32"], text=True)  # default options: importanceSampling
     assert json.loads(res.strip().splitlines()[-1])["frames"] == 2
 
     scene = types.SimpleNamespace(frame=None, environment=dict(data=envimg))
     cam = types.SimpleNamespace(**vars(frames[0].camera))
-    fx = effect.SSGIEffect(None, scene, cam, dict(width=W, height=H, steps=12, refineSteps=3, importanceSampling=False), seeds=dict(ssgi=11, denoise=22),
-                           half_store_rtz=True)
+    fx = effect.SSGIEffect(None, scene, cam, dict(width=W, height=H, steps=12, refineSteps=3), seeds=dict(ssgi=11, denoise=22), half_store_rtz=True)
     ctx = Context(W, H)
     for f in frames:
         scene.frame = f

@@ -364,7 +364,7 @@ def test_env_map_stagewise(name, blue_noise):
 @pytest.mark.parametrize("name", G.GOLDEN_ENV)
 def test_env_map_through_effect(name):
     """SSGIEffect.keepEnvMapUpdated on the oracle renderer: scene.environment is handed to the device once, USE_ENVMAP switches on, the
-    envBlur option reaches K1; importanceSampling (MIS) with an env map is refused, not approximated."""
+    envBlur option reaches K1 (importanceSampling: false)."""
     import types
     from oracle_renderer import OracleRenderer
     from rfx_amd.effect import SSGIEffect
@@ -374,9 +374,6 @@ def test_env_map_through_effect(name):
     scene = types.SimpleNamespace(frame=None, environment=dict(data=np.ascontiguousarray(g["environment"])))
     cam = G.camera(g, 0)
     opts = dict(steps=int(g["steps"]), refineSteps=int(g["refineSteps"]), denoiseIterations=1, envBlur=float(g["envBlur"]), width=W, height=H)
-    with pytest.raises(NotImplementedError):
-        scene.frame = G.frame(g, 0)
-        SSGIEffect(None, scene, cam, opts).update(OracleRenderer(W, H), None)  # importanceSampling defaults to true
     fx = SSGIEffect(None, scene, cam, dict(opts, importanceSampling=False), seeds=dict(ssgi=int(g["ssgi_start"]), denoise=int(g["denoise_start"])))
     r = OracleRenderer(W, H)
     for fi in range(nf):
@@ -501,3 +498,66 @@ def test_orthographic_camera_stagewise(blue_noise):
         fp = abi.FinalParams(camera=abi.Camera.from_scene(f.camera), fogMode=2, fogDensity=0.05)
         fp.fogColor[:] = [0.5, 0.6, 0.7]
         assert_close("ortho final fog f%d" % fi, O.final(f.depth, np.ascontiguousarray(g[k + "compose"]), f.direct, fp), g[k + "final_fog2"], 0.0)
+
+
+def test_env_map_importance_sampling(blue_noise):
+    """USE_ENVMAP + importanceSampling — the reference's DEFAULT once the scene has an environment (ssgi.frag:197-216, sampleEquirectProbability
+    ssgi_utils.frag:210-225, misHeuristic).  Three things are pinned: (1) the host's CPU pass (rfx_amd.envmap.build_importance) equals the
+    tables the reference's OWN worker code produced (run by node in make_golden); (2) the implicit-LOD `texture(info.map, uv)` at an unrelated
+    uv per pixel, as llvmpipe resolves it (one lod per quad, from its top-left pixel, linear-mantissa log2 of rho^2); (3) K1's MIS arithmetic."""
+    from rfx_amd.envmap import build_importance
+    g = G.load(G.GOLDEN_ENVMIS)
+    W, H, nf = int(g["width"]), int(g["height"]), int(g["frames"])
+    envimg = np.ascontiguousarray(g["environment"])
+    env = O.EnvMap(envimg, half=True, rtz=True)
+    mw, cw, tot = build_importance(env.level(0))  # the half-float texels, as the worker sees them after fromHalfFloat
+    assert np.array_equal(mw, g["marginalWeights"]) and np.array_equal(cw, g["conditionalWeights"]) and tot == float(g["totalSumValue"])
+    env.set_importance(mw, cw, tot)
+    for fi in range(nf):
+        f = G.frame(g, fi)
+        k, kp = "f%d_" % fi, "f%d_" % (fi - 1)
+        sp, _, _, _ = stage_params(g, fi, 0.0 if fi == 0 else 1.0)
+        sp.useEnvMap, sp.importanceSampling, sp.envBlur = 1, 1, float(g["envBlur"])
+        hist = np.ascontiguousarray(g[kp + "compose"]) if fi else np.zeros((H, W, 4), np.float32)
+        o = O.ssgi(f.depth, f.gbuffer, f.direct, hist, blue_noise, sp, env=env)
+        ga, gb = O.unpack_ssgi(g[k + "ssgi"])
+        oa, ob = O.unpack_ssgi(o)
+        assert_close("envmis ssgi.diffuse f%d" % fi, oa, ga, FLIP["ssgi"] * 2)
+        assert_close("envmis ssgi.specular f%d" % fi, ob, gb, FLIP["ssgi"] * 2)
+        assert (o == g[k + "ssgi"]).all(axis=-1).mean() > 0.98
+        # MIS changes a good part of the frame with respect to plain environment lighting
+        sp.importanceSampling = 0
+        assert (O.ssgi(f.depth, f.gbuffer, f.direct, hist, blue_noise, sp, env=env) != o).any(axis=-1).mean() > 0.2
+
+
+def test_env_map_importance_sampling_through_effect():
+    """The DEFAULT options with an environment (importanceSampling: true): keepEnvMapUpdated builds the importance tables on the host
+    (EquirectHdrInfoUniform.updateFrom) and switches the define on; the chain reproduces the reference's."""
+    import types
+    from oracle_renderer import OracleRenderer
+    from rfx_amd.effect import SSGIEffect
+
+    g = G.load(G.GOLDEN_ENVMIS)
+    W, H, nf = int(g["width"]), int(g["height"]), int(g["frames"])
+    scene = types.SimpleNamespace(frame=None, environment=dict(data=np.ascontiguousarray(g["environment"])))
+    cam = G.camera(g, 0)
+    fx = SSGIEffect(None, scene, cam, dict(steps=int(g["steps"]), refineSteps=int(g["refineSteps"]), denoiseIterations=1, width=W, height=H),
+                    seeds=dict(ssgi=int(g["ssgi_start"]), denoise=int(g["denoise_start"])))
+    r = OracleRenderer(W, H)
+    for fi in range(nf):
+        scene.frame = G.frame(g, fi)
+        for kk, vv in vars(G.camera(g, fi)).items():
+            setattr(cam, kk, vv)
+        fx.update(r, None)
+        names = [c[0] for c in r.calls]
+        assert (names.count("set_environment"), names.count("set_environment_importance")) == ((1, 1) if fi == 0 else (0, 0))
+        r.calls.clear()
+        assert fx.ssgiPass.uniforms.importanceSampling == 1
+        ga, gb = O.unpack_ssgi(g["f%d_ssgi" % fi])
+        oa, ob = O.unpack_ssgi(r.tex[abi.TEX_SSGI])
+        lim = 0.03 * (fi + 1)
+        assert_close("envmis effect ssgi.specular f%d" % fi, ob, gb, lim)
+        assert_close("envmis effect compose f%d" % fi, r.tex[abi.TEX_COMPOSE], g["f%d_compose" % fi], lim)
+    fx.importanceSampling = False  # the reactive option: the environment is re-examined, the define goes away
+    fx.update(r, None)
+    assert fx.ssgiPass.uniforms.importanceSampling == 0 and fx.ssgiPass.uniforms.useEnvMap == 1
