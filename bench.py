@@ -11,7 +11,8 @@ K2 temporal reprojection -> 2 x K3 Poisson denoise (denoiseIterations 1) -> K4 c
 region starts.  N > 1: weak scaling — the frame keeps its 16:9 aspect and grows to N x 8.29 Mpixel
 (e.g. 7680x4320 for N = 4), is cut into N row tiles (one per GPU, 8.29 Mpixel each) which exchange
 halo rows with their neighbours over RCCL after K2 and after every K3 pass, plus an all-gather of
-the composed GI (rfx_amd/tiling.py).
+the composed GI that runs asynchronously under the next frame's depth pre-pass + ray march (K1 is
+split into rfx_ssgi_trace / rfx_ssgi_shade for that; rfx_amd/tiling.py).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (largest share of the
 step), measured live with hipEvents on the stream the kernels run on; `cpu_baseline` is the
@@ -186,6 +187,9 @@ def main():
         fx.update(renderer, None)
 
     def barrier():
+        fin = getattr(renderer, "finish_pending", None)
+        if fin:  # the composed-GI all-gather of the last frame is asynchronous (tiling.py): it belongs to that frame
+            fin()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -245,7 +249,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: %dx%d (%.2f Mpixel) per GPU, steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step" % (W, Ht, W * Ht / 1e6),
                        "frame": "%dx%d" % (W, H), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz",
-                       "parallelism": "row-tiles x%d, RCCL halo send/recv + compose all-gather" % world if world > 1 else "single GPU"},
+                       "parallelism": "row-tiles x%d, RCCL halo send/recv + compose all-gather (async, overlapped with the next frame's K1 trace)" % world if world > 1 else "single GPU"},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
             "chain": {"algorithmic_bytes_per_px": chain_bytes, "sum_kernel_ms": round(chain_ms, 4),
                       "achieved_GBs": round(chain_bytes * px_tile / (chain_ms * 1e-3) / 1e9, 1),

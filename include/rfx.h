@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 8
+#define RFX_ABI_VERSION 9
 
 enum {
     RFX_OK = 0,
@@ -244,6 +244,14 @@ int rfx_download_environment(rfx_ctx *, int level, float *rgba, int *levels);
 
 /* ---- the four draws (+ the framebuffer copy and the effect's own fragment) */
 int rfx_ssgi_march(rfx_ctx *, const rfx_ssgi_params *);
+/* The same draw in two launches, for a row-tiled run: rfx_ssgi_trace runs the fragment up to the end of RayMarch/BinarySearch
+ * (ssgi.frag:441-503) and keeps the rays' end state in context scratch (32 B per pixel); rfx_ssgi_shade finishes the fragment
+ * (doSample's shading :385-439 and the output packing) from it.  Only the shading reads `accumulatedTexture` (RFX_TEX_COMPOSE or
+ * RFX_TEX_TEMPORAL0, historySource) — gathered anywhere on screen — so the all-gather that refreshes it between frames may still be in
+ * flight during the trace and has to have landed only before the shade (rfx_amd/tiling.py).  Same params for both calls; the
+ * result in RFX_TEX_SSGI is bit-identical to rfx_ssgi_march's.  rfx_ssgi_shade without a pending trace: RFX_ESTATE. */
+int rfx_ssgi_trace(rfx_ctx *, const rfx_ssgi_params *);
+int rfx_ssgi_shade(rfx_ctx *, const rfx_ssgi_params *);
 int rfx_temporal_reproject(rfx_ctx *, const rfx_temporal_params *);
 /* renderer.copyFramebufferToTexture(tmpVec2, this.framebufferTexture), TemporalReprojectPass.js:198-201: the tile rows of
  * the pass's render target RFX_TEX_TEMPORAL0 become the history the NEXT rfx_temporal_reproject samples (linear filter).

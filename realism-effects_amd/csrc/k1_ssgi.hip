@@ -332,7 +332,12 @@ RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat
     return ssgi;
 }
 
-template <bool PERSP, bool ENV, bool MIS>
+// STAGE 0: the whole fragment in one launch.  STAGE 1 ("trace") stops after the march and leaves the two rays' end state in
+// A.hits (2 x float4 per pixel: uv0 uv1 | pos0.x pos1.xyz); STAGE 2 ("shade") redoes the cheap per-pixel setup, takes the rays
+// from A.hits instead of marching and finishes the fragment.  Only the shading reads last frame's composed GI anywhere on
+// screen, so a row-tiled run can let that texture's all-gather overlap the march (rfx.h rfx_ssgi_trace / rfx_ssgi_shade).
+// Same arithmetic in the same order either way (no contraction in this file): split == fused bit for bit (tests).
+template <bool PERSP, bool ENV, bool MIS, int STAGE>
 RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     // XCD-aware mapping: hardware block b runs on XCD b % 8 (observed, used for speed only); give XCD k the k-th
     // contiguous eighth of the row-major tile list, i.e. an image band, so its L2 sees a compact part of the depth plane
@@ -352,11 +357,14 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     const float u = ((float)x + 0.5f) / (float)A.out_w, v = ((float)y + 0.5f) / (float)A.out_h;
     const int sx = scaled ? rfx_nearest_idx(u, d.fW, d.W) : x, sy = scaled ? rfx_nearest_idx(v, d.fH, d.H) : y;
     const float depth = ((const float *)A.depth.ptr)[rfx_xy_index(d, A.depth.row0, A.depth.rows, sx, sy)];
-    uint4 *outp = (uint4 *)A.out.ptr + (scaled ? (size_t)y * A.out_w + x : (size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x);
+    const size_t out_idx = scaled ? (size_t)y * A.out_w + x : (size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x;
+    uint4 *outp = (uint4 *)A.out.ptr + out_idx;
     const size_t gi_idx = rfx_xy_index(d, A.direct.row0, A.direct.rows, sx, sy);
     if (depth == 1.0f) {  // background :109-113
-        const float4 dl = ((const float4 *)A.direct.ptr)[gi_idx];
-        *outp = rfx_pack_two_vec4(dl, dl);
+        if (STAGE != 1) {
+            const float4 dl = ((const float4 *)A.direct.ptr)[gi_idx];
+            *outp = rfx_pack_two_vec4(dl, dl);
+        }
         return;
     }
     const Material mat = rfx_get_material<false>(((const uint4 *)A.gbuffer.ptr)[rfx_xy_index(d, A.gbuffer.row0, A.gbuffer.rows, sx, sy)]);
@@ -464,7 +472,20 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     rays[1].active = true;
     rays[1].pos = viewPos;
     rays[1].dir = specularRay;
-    k1_march_rays<PERSP>(m, d, rays, rnd.z);
+    if (STAGE == 2) {
+        const float4 h0 = A.hits[2 * out_idx], h1 = A.hits[2 * out_idx + 1];
+        rays[0].uv = make_float2(h0.x, h0.y);
+        rays[1].uv = make_float2(h0.z, h0.w);
+        rays[0].pos = make_float3(h1.x, h1.x, h1.x);  // only "missed" (pos.x == 10.0e9) is read of the diffuse ray
+        rays[1].pos = make_float3(h1.y, h1.z, h1.w);
+    } else {
+        k1_march_rays<PERSP>(m, d, rays, rnd.z);
+    }
+    if (STAGE == 1) {
+        A.hits[2 * out_idx] = make_float4(rays[0].uv.x, rays[0].uv.y, rays[1].uv.x, rays[1].uv.y);
+        A.hits[2 * out_idx + 1] = make_float4(rays[0].pos.x, rays[1].pos.x, rays[1].pos.y, rays[1].pos.z);
+        return;
+    }
 
     float3 diffuseGI = make_float3(-1.0f, -1.0f, -1.0f);  // "not sampled this frame" marker :277-278
     if (isDiffuseSample) diffuseGI = k1_shade<ENV, MIS>(d, A, mat, roughnessSq, rays[0], diffuseRayDir, true, brdfD, pdfD, ems) + dl;
@@ -484,11 +505,11 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     }
 }
 
-template <bool PERSP, bool ENV, bool MIS>
+template <bool PERSP, bool ENV, bool MIS, int STAGE>
 __global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-    k1_ssgi_march_body<PERSP, ENV, MIS>(A, d);
+    k1_ssgi_march_body<PERSP, ENV, MIS, STAGE>(A, d);
     rfx_flush_violations(d);
 }
 
@@ -564,7 +585,7 @@ hipError_t rfx_launch_k1_prepare(const K1Args &A, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t rfx_launch_k1(const K1Args &A, hipStream_t stream) {
+hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
     const int nbx = (A.out_w + 63) / 64, nby = (A.y1 - A.y0 + 3) / 4;
     const int nblocks = nbx * nby;
     dim3 block(64, 4), grid(((nblocks + 7) / 8) * 8);
@@ -572,7 +593,12 @@ hipError_t rfx_launch_k1(const K1Args &A, hipStream_t stream) {
     const bool persp = P[1] == 0.f && P[2] == 0.f && P[3] == 0.f && P[4] == 0.f && P[6] == 0.f && P[7] == 0.f && P[12] == 0.f && P[13] == 0.f &&
                        P[15] == 0.f && P[11] == -1.f;
     const bool env = A.p.useEnvMap != 0, mis = env && A.p.importanceSampling != 0;
-#define K1_GO(P, E, M) hipLaunchKernelGGL((k1_ssgi_march<P, E, M>), grid, block, 0, stream, A)
+#define K1_GO(P, E, M)                                                                                   \
+    do {                                                                                                 \
+        if (stage == 0) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 0>), grid, block, 0, stream, A);      \
+        else if (stage == 1) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 1>), grid, block, 0, stream, A); \
+        else hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 2>), grid, block, 0, stream, A);                 \
+    } while (0)
     if (persp) { if (mis) K1_GO(true, true, true); else if (env) K1_GO(true, true, false); else K1_GO(true, false, false); }
     else { if (mis) K1_GO(false, true, true); else if (env) K1_GO(false, true, false); else K1_GO(false, false, false); }
 #undef K1_GO

@@ -24,6 +24,8 @@ struct rfx_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned int *halo_violations = nullptr;
     float *viewz = nullptr;    // K1 scratch: view-space Z plane (full frame)
+    float4 *hits = nullptr;    // K1 trace -> shade hand-over (rfx_ssgi_trace), 2 texels per SSGI texel
+    bool hits_traced = false;  // a trace is waiting for its shade
     float2 *coarse = nullptr;  // K1 scratch: (min,max) view Z per 8x8 cell
     float4 *env = nullptr;     // scene.environment: the whole mip chain, float4 texels
     float *env_marginal = nullptr, *env_conditional = nullptr;  // EquirectHdrInfo inverse-CDF tables (importanceSampling)
@@ -111,6 +113,7 @@ void rfx_destroy(rfx_ctx *c) {
         if (c->slots[i].owned && c->slots[i].ptr) hipFree(c->slots[i].ptr);
     if (c->halo_violations) hipFree(c->halo_violations);
     if (c->viewz) hipFree(c->viewz);
+    if (c->hits) hipFree(c->hits);
     if (c->coarse) hipFree(c->coarse);
     if (c->env) hipFree(c->env);
     if (c->env_marginal) hipFree(c->env_marginal);
@@ -409,23 +412,24 @@ int rfx_download_environment(rfx_ctx *c, int level, float *rgba, int *levels) {
     return RFX_OK;
 }
 
-int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
+// stage 0: rfx_ssgi_march (one launch); 1: rfx_ssgi_trace; 2: rfx_ssgi_shade
+static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
     if (!c || !p) return RFX_EINVAL;
-    if (p->mode != 0 && p->mode != 1) return fail(c, RFX_EINVAL, "rfx_ssgi_march: mode must be 0 (MODE_SSGI) or 1 (MODE_SSR)");
+    if (p->mode != 0 && p->mode != 1) return fail(c, RFX_EINVAL, "rfx_ssgi_march/trace/shade: mode must be 0 (MODE_SSGI) or 1 (MODE_SSR)");
     if (p->importanceSampling && (!p->useEnvMap || !c->env_marginal))
-        return fail(c, RFX_ESTATE, "rfx_ssgi_march: importanceSampling needs useEnvMap and rfx_set_environment_importance");
-    if (p->useEnvMap && !c->env) return fail(c, RFX_ESTATE, "rfx_ssgi_march: useEnvMap without rfx_set_environment");
-    if (p->steps < 1 || p->refineSteps < 0) return fail(c, RFX_EINVAL, "rfx_ssgi_march: steps/refineSteps");
+        return fail(c, RFX_ESTATE, "rfx_ssgi_march/trace/shade: importanceSampling needs useEnvMap and rfx_set_environment_importance");
+    if (p->useEnvMap && !c->env) return fail(c, RFX_ESTATE, "rfx_ssgi_march/trace/shade: useEnvMap without rfx_set_environment");
+    if (p->steps < 1 || p->refineSteps < 0) return fail(c, RFX_EINVAL, "rfx_ssgi_march/trace/shade: steps/refineSteps");
     hipSetDevice(c->device);
-    if (p->historySource < 0 || p->historySource > 2) return fail(c, RFX_EINVAL, "rfx_ssgi_march: historySource");
+    if (p->historySource < 0 || p->historySource > 2) return fail(c, RFX_EINVAL, "rfx_ssgi_march/trace/shade: historySource");
     if (p->historySource == 1 && (c->tile_y0 != 0 || c->tile_rows != c->H))
-        return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: historySource TEMPORAL0 (denoiseMode \"temporal\") needs a whole-frame context: K1 gathers it anywhere on screen");
+        return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march/trace/shade: historySource TEMPORAL0 (denoiseMode \"temporal\") needs a whole-frame context: K1 gathers it anywhere on screen");
     const int hist = p->historySource == 1 ? RFX_TEX_TEMPORAL0 : RFX_TEX_COMPOSE;
     const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, RFX_TEX_DIRECT_LIGHT, hist, RFX_TEX_BLUE_NOISE, RFX_TEX_SSGI};
     int rc = need(c, ids, 6);
     if (rc) return rc;
     if (!c->slots[RFX_TEX_DEPTH].uploaded || !c->slots[RFX_TEX_GBUFFER].uploaded || !c->slots[RFX_TEX_BLUE_NOISE].uploaded)
-        return fail(c, RFX_ESTATE, "rfx_ssgi_march: depth / gbuffer / blue-noise not uploaded");
+        return fail(c, RFX_ESTATE, "rfx_ssgi_march/trace/shade: depth / gbuffer / blue-noise not uploaded");
     K1Args A;
     A.dims = dims(c);
     // K2's neighbourhood clamp reads +-2 rows of K1's output: produce them redundantly in the halo
@@ -435,8 +439,8 @@ int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
     if (rs != 1.0f) {  // SSGIPass.setSize :52-57
         const float fw = (float)c->W * rs, fh = (float)c->H * rs;
         if (!(rs > 0.0f && rs <= 1.0f) || fw != floorf(fw) || fh != floorf(fh) || fw < 1.0f || fh < 1.0f)
-            return fail(c, RFX_EINVAL, "rfx_ssgi_march: resolutionScale must be in (0, 1] with whole W*s and H*s");
-        if (c->tile_y0 != 0 || c->tile_rows != c->H) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march: resolutionScale != 1 needs a whole-frame context");
+            return fail(c, RFX_EINVAL, "rfx_ssgi_march/trace/shade: resolutionScale must be in (0, 1] with whole W*s and H*s");
+        if (c->tile_y0 != 0 || c->tile_rows != c->H) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march/trace/shade: resolutionScale != 1 needs a whole-frame context");
         A.out_w = (int)fw; A.out_h = (int)fh;
         A.y0 = 0; A.y1 = A.out_h;
     }
@@ -474,11 +478,29 @@ int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) {
         while ((m >> (lg + 1)) > 0) lg++;
         A.maxEnvMapMipLevel = c->env ? (float)(lg + 1) : 0.0f;
     }
-    // the pre-pass runs on EVERY draw: the depth plane is an input that changes every frame
-    HIPCHK(c, rfx_launch_k1_prepare(A, c->stream));
-    HIPCHK(c, rfx_launch_k1(A, c->stream));
+    A.hits = nullptr;
+    if (stage != 0) {
+        // hand-over plane, indexed like the output texture (resolutionScale needs a whole-frame context, so W * held rows covers it)
+        const size_t n = (size_t)c->W * c->slots[RFX_TEX_SSGI].rows * 2;
+        if (stage == 2 && (!c->hits || !c->hits_traced))
+            return fail(c, RFX_ESTATE, "rfx_ssgi_shade: no rfx_ssgi_trace of this frame to finish");
+        if (!c->hits) {
+            hipError_t e = hipMalloc((void **)&c->hits, n * sizeof(float4));
+            if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(K1 trace hand-over)", e);
+        }
+        A.hits = c->hits;
+    }
+    // the pre-pass runs on EVERY draw: the depth plane is an input that changes every frame (the shade stage reuses the trace's)
+    if (stage != 2) HIPCHK(c, rfx_launch_k1_prepare(A, c->stream));
+    HIPCHK(c, rfx_launch_k1(A, stage, c->stream));
+    c->hits_traced = stage == 1;
     return RFX_OK;
 }
+
+int rfx_ssgi_march(rfx_ctx *c, const rfx_ssgi_params *p) { return ssgi_draw(c, p, 0); }
+int rfx_ssgi_trace(rfx_ctx *c, const rfx_ssgi_params *p) { return ssgi_draw(c, p, 1); }
+int rfx_ssgi_shade(rfx_ctx *c, const rfx_ssgi_params *p) { return ssgi_draw(c, p, 2); }
+
 
 int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
     if (!c || !p) return RFX_EINVAL;

@@ -28,6 +28,7 @@ struct K1Args {
     const float *env_marginal, *env_conditional;  // EquirectHdrInfo.marginalWeights (env_h) / conditionalWeights (env_w x env_h), importanceSampling
     float totalSumWhole, totalSumDecimal;
     int out_w, out_h;  // the pass's render target = `resolution` (frame size unless resolutionScale != 1)
+    float4 *hits;      // trace -> shade hand-over (2 texels per output pixel, indexed like `out`); null for the fused launch
 };
 
 // one level of the environment's mip chain from the one above (glGenerateMipmap on the oracle's GL: 2x2 bilinear centre)
@@ -82,7 +83,7 @@ struct K5Args {
 
 hipError_t rfx_launch_k5(const K5Args &, hipStream_t);
 hipError_t rfx_launch_k1_prepare(const K1Args &, hipStream_t);
-hipError_t rfx_launch_k1(const K1Args &, hipStream_t);
+hipError_t rfx_launch_k1(const K1Args &, int stage /* 0 fused, 1 trace, 2 shade */, hipStream_t);
 hipError_t rfx_launch_k2(const K2Args &, hipStream_t);
 hipError_t rfx_launch_k3(const K3Args &, hipStream_t);
 hipError_t rfx_launch_k4(const K4Args &, hipStream_t);

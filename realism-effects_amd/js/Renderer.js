@@ -129,6 +129,13 @@ class Renderer {
 	ssgiMarch(uniforms) {
 		addon.ssgiMarch(this._h, uniforms)
 	}
+	// the same draw in two launches (rfx_ssgi_trace / rfx_ssgi_shade): only the second reads last frame's composed GI
+	ssgiTrace(uniforms) {
+		addon.ssgiTrace(this._h, uniforms)
+	}
+	ssgiShade(uniforms) {
+		addon.ssgiShade(this._h, uniforms)
+	}
 	temporalReproject(uniforms) {
 		addon.temporalReproject(this._h, uniforms)
 	}

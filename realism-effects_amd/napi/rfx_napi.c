@@ -307,9 +307,9 @@ static napi_value n_set_environment_importance(napi_env env, napi_callback_info 
     return NULL;
 }
 
-/* ssgiMarch(ctx, {camera, steps, refineSteps, mode, useDirectLight, missedRays, importanceSampling,
- *                 rayDistance, thickness, envBlur, blueNoiseIndex}) */
-static napi_value n_ssgi(napi_env env, napi_callback_info info) {
+/* ssgiMarch / ssgiTrace / ssgiShade(ctx, {camera, steps, refineSteps, mode, useDirectLight, missedRays, importanceSampling,
+ *                 rayDistance, thickness, envBlur, blueNoiseIndex, historySource, resolutionScale, useEnvMap}) */
+static napi_value ssgi_stage(napi_env env, napi_callback_info info, int stage) {
     napi_value a[2];
     if (!get_args(env, info, 2, a)) return NULL;
     rfx_ctx *c = get_ctx(env, a[0]);
@@ -330,10 +330,13 @@ static napi_value n_ssgi(napi_env env, napi_callback_info info) {
     p.blueNoiseIndex = (int32_t)prop_num(env, a[1], "blueNoiseIndex", 0);
     p.historySource = (int32_t)prop_num(env, a[1], "historySource", 0);
     p.resolutionScale = (float)prop_num(env, a[1], "resolutionScale", 1);
-    int rc = rfx_ssgi_march(c, &p);
-    if (rc) return throw_rfx(env, c, "rfx_ssgi_march", rc);
+    int rc = stage == 0 ? rfx_ssgi_march(c, &p) : (stage == 1 ? rfx_ssgi_trace(c, &p) : rfx_ssgi_shade(c, &p));
+    if (rc) return throw_rfx(env, c, stage == 0 ? "rfx_ssgi_march" : (stage == 1 ? "rfx_ssgi_trace" : "rfx_ssgi_shade"), rc);
     return NULL;
 }
+static napi_value n_ssgi(napi_env env, napi_callback_info info) { return ssgi_stage(env, info, 0); }
+static napi_value n_ssgi_trace(napi_env env, napi_callback_info info) { return ssgi_stage(env, info, 1); }
+static napi_value n_ssgi_shade(napi_env env, napi_callback_info info) { return ssgi_stage(env, info, 2); }
 
 /* temporalReproject(ctx, {camera, prevCamera, textureCount, inputType, reprojectSpecular[2], neighborhoodClamp[2],
  *                         logTransform, fullAccumulate, confidencePower, neighborhoodClampIntensity, maxBlend, keepData,
@@ -495,7 +498,7 @@ static napi_value n_time_end(napi_env env, napi_callback_info info) {
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
-        {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"setEnvironmentImportance", n_set_environment_importance}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
+        {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"setEnvironmentImportance", n_set_environment_importance}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"ssgiTrace", n_ssgi_trace}, {"ssgiShade", n_ssgi_shade}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
         {"sync", n_sync}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

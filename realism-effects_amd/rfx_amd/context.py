@@ -171,6 +171,14 @@ class Context:
     def ssgi_march(self, p: abi.SsgiParams):
         self._chk(self.lib.rfx_ssgi_march(self._h, C.byref(p)), "rfx_ssgi_march")
 
+    def ssgi_trace(self, p: abi.SsgiParams):
+        """First half of ssgi_march (up to the end of the ray march); see rfx.h."""
+        self._chk(self.lib.rfx_ssgi_trace(self._h, C.byref(p)), "rfx_ssgi_trace")
+
+    def ssgi_shade(self, p: abi.SsgiParams):
+        """Second half: shades the traced rays; the only part that reads last frame's composed GI."""
+        self._chk(self.lib.rfx_ssgi_shade(self._h, C.byref(p)), "rfx_ssgi_shade")
+
     def temporal_reproject(self, p: abi.TemporalParams):
         self._chk(self.lib.rfx_temporal_reproject(self._h, C.byref(p)), "rfx_temporal_reproject")
 

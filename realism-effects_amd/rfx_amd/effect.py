@@ -432,7 +432,13 @@ class SSGIPass:
         # getter returns the ARRAY of K3's targets — what three binds for a non-texture value: its empty texture (zeros)
         t = self.ssgiEffect.denoiser.texture
         self.uniforms.historySource = 2 if isinstance(t, (tuple, list)) else (1 if t == abi.TEX_TEMPORAL0 else 0)
-        renderer.ssgi_march(self.uniforms)  # :93-94
+        if getattr(renderer, "overlap_history_gather", False):
+            # row-tiled run: last frame's composed GI is still being all-gathered; only the shading half of the draw reads it
+            renderer.ssgi_trace(self.uniforms)
+            renderer.before_ssgi_shade()
+            renderer.ssgi_shade(self.uniforms)
+        else:
+            renderer.ssgi_march(self.uniforms)  # :93-94
 
     def dispose(self):
         pass

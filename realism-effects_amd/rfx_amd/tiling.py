@@ -8,7 +8,11 @@ rows above and below and three exchange steps keep them current:
                                      written (RCCL over xGMI; message = halo*W*texel bytes per
                                      texture and direction — latency-bound)
   after K4                         : all-gather of the composed GI tile rows (next frame's K1
-                                     gathers it anywhere on screen)
+                                     gathers it anywhere on screen).  It is the one big message
+                                     (tile bytes x (N-1) per rank) and only the SHADING half of K1
+                                     reads it, so it is started asynchronously and waited for
+                                     between rfx_ssgi_trace and rfx_ssgi_shade: it overlaps the next
+                                     frame's depth pre-pass and ray march
   after a framebuffer copy (TRAA)  : the same neighbour Send/Recv for the pass's own history
 
 K1 needs no exchange: it recomputes the +-2 rows K2's neighbourhood clamp reads, from the
@@ -65,9 +69,35 @@ class TiledRenderer:
         self.W, self.H = inner.W, inner.H
         self.tile_y0, self.tile_rows, self.halo = inner.tile_y0, inner.tile_rows, inner.halo
         self.exchange_count = 0
+        self._pending = []  # (works, tensor) of the composed-GI all-gather in flight
+        # effect.SSGIPass splits K1 into trace + shade around before_ssgi_shade() when this is set
+        self.overlap_history_gather = world > 1 and hasattr(inner, "ssgi_trace")
 
     def __getattr__(self, name):  # everything else (upload, the four draws, ...) goes to the tile's renderer
         return getattr(self.inner, name)
+
+    # anything that reads the whole composed GI, or hands control back to the caller, first lets the all-gather land
+    def before_ssgi_shade(self):
+        self.finish_pending()
+
+    def ssgi_march(self, p):
+        self.finish_pending()
+        return self.inner.ssgi_march(p)
+
+    def download(self, *a, **k):
+        self.finish_pending()
+        return self.inner.download(*a, **k)
+
+    def sync(self):
+        self.finish_pending()
+        return self.inner.sync()
+
+    def finish_pending(self):
+        pending, self._pending = self._pending, []
+        for works, tensor in pending:
+            for w in works:
+                w.wait()
+            self._sync_after_comm(tensor)
 
     # ---- hooks called by rfx_amd.effect
     def after_temporal_pass(self):
@@ -113,14 +143,16 @@ class TiledRenderer:
         dist = self._dist
         full = self.tensors[abi.TEX_COMPOSE]  # whole frame
         mine = full[self.tile_y0:self.tile_y0 + self.tile_rows]
+        self.finish_pending()
         self._sync_before_comm()
         parts = [full[y0:y0 + n] for (y0, n) in split_rows(self.H, self.world)]
         if all(p.shape == mine.shape for p in parts) and full.is_cuda:
-            dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group)
+            works = [dist.all_gather_into_tensor(full, mine.contiguous(), group=self.group, async_op=True)]
         else:  # ragged last tile, or a backend without all_gather_into_tensor: one broadcast per owner
-            for r, p in enumerate(parts):
-                dist.broadcast(p, src=r, group=self.group)
-        self._sync_after_comm(full)
+            works = [dist.broadcast(p, src=r, group=self.group, async_op=True) for r, p in enumerate(parts)]
+        self._pending.append((works, full))
+        if not self.overlap_history_gather:
+            self.finish_pending()
 
     def _sync_after_comm(self, tensor):
         # on device tensors `wait()` only makes torch's current stream wait for the collective; kernels of a context that

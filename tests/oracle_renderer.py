@@ -87,6 +87,17 @@ class OracleRenderer:
         O.ssgi(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[abi.TEX_DIRECT_LIGHT], hist, t[abi.TEX_BLUE_NOISE], p,
                out=t[abi.TEX_SSGI], rows=self._rows(min(2, self.halo)), env=getattr(self, "env", None))
 
+    # the split draw: the double has nothing to overlap, so the trace is a no-op and the shade runs the whole fragment —
+    # which makes a shade that starts before the composed-GI all-gather has landed visible as a wrong frame
+    def ssgi_trace(self, p):
+        self.calls.append(("ssgi_trace", p.blueNoiseIndex))
+        self._traced = True
+
+    def ssgi_shade(self, p):
+        assert getattr(self, "_traced", False), "ssgi_shade without ssgi_trace"
+        self._traced = False
+        self.ssgi_march(p)
+
     def temporal_reproject(self, p):
         self.calls.append(("temporal", p.keepData, p.fullAccumulate))
         t = self.tex

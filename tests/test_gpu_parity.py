@@ -894,3 +894,54 @@ def test_env_map_importance_sampling_vs_oracle(blue_noise, half, size):
     ctx.ssgi_march(sp)
     assert (ctx.download(abi.TEX_SSGI) != g).any(axis=-1).mean() > 0.2
     ctx.close()
+
+
+@pytest.mark.parametrize("variant", ["plain", "ssr_missed", "env", "envmis", "ortho", "rs050", "tile"])
+def test_ssgi_trace_plus_shade_is_bit_identical_to_march(blue_noise, variant):
+    """rfx_ssgi_trace + rfx_ssgi_shade (the split a row-tiled run uses to hide the composed-GI all-gather under the march) must leave
+    exactly the texels rfx_ssgi_march leaves — every kernel variant — also when the history texture CHANGES between trace and shade
+    (that is the point: only the shade may read it); a shade without a trace is refused."""
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.envmap import build_importance
+    from rfx_amd.scene import synthetic_environment, synthetic_frame
+
+    W, H = 256, 144
+    kw = dict(ortho_half_height=3.2) if variant == "ortho" else {}
+    f = synthetic_frame(W, H, 1, **kw)
+    sp, _, _, _ = _params(abi, f, f.camera, 1.0, 12, 3)
+    sp.blueNoiseIndex = 77
+    tile = dict(tile_y0=48, tile_rows=48, halo_rows=8) if variant == "tile" else {}
+    ctx = Context(W, H, **tile)
+    if variant == "ssr_missed":
+        sp.mode, sp.missedRays = 1, 1
+    if variant in ("env", "envmis"):
+        envimg = synthetic_environment(128, 64)
+        ctx.set_environment(envimg, half_float_type=True, half_store_rtz=True)
+        sp.useEnvMap = 1
+        if variant == "envmis":
+            mw, cw, tot = build_importance(ctx.download_environment(0, (128, 64)))
+            ctx.set_environment_importance(mw, cw, tot)
+            sp.importanceSampling = 1
+    if variant == "rs050":
+        sp.resolutionScale = 0.5
+    comp = np.random.RandomState(4).rand(H, W, 4).astype(np.float32)
+    junk = np.full((H, W, 4), 1e6, np.float32)
+    ctx.upload_frame(f)  # a tile context takes the band it holds
+    with pytest.raises(Exception):
+        ctx.ssgi_shade(sp)  # nothing traced
+    ctx.upload(abi.TEX_COMPOSE, comp)
+    ctx.ssgi_march(sp)
+    want = ctx.download(abi.TEX_SSGI)
+    ctx.clear(abi.TEX_SSGI)
+    ctx.upload(abi.TEX_COMPOSE, junk)  # the "all-gather still in flight" state: the trace must not look at it
+    ctx.ssgi_trace(sp)
+    ctx.upload(abi.TEX_COMPOSE, comp)
+    ctx.ssgi_shade(sp)
+    got = ctx.download(abi.TEX_SSGI)
+    assert np.array_equal(got, want), "%s: %.4f%% texels differ" % (variant, 100 * (got != want).any(axis=-1).mean())
+    assert (want != 0).any(), "the draw wrote nothing"
+    with pytest.raises(Exception):
+        ctx.ssgi_shade(sp)  # the trace was consumed
+    assert ctx.halo_violations() == 0 or variant == "tile"
+    ctx.close()

@@ -57,6 +57,10 @@ def _worker(rank, world, port, outdir):
     scene = types.SimpleNamespace(frame=None)
     _chain(r, scene, frames[0].camera, frames)
     assert r.exchange_count == FRAMES * 3  # after K2, after K3 pass 0, after K3 pass 1
+    # K1 ran as trace + shade with the (asynchronous) composed-GI all-gather waited for in between; the last one is still pending
+    assert r.overlap_history_gather and sum(1 for c in inner.calls if c[0] == "ssgi_trace") == FRAMES
+    assert len(r._pending) == 1
+    r.finish_pending()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), y0=y0, rows=rows, halo=halo,
              **{abi.TEX_NAMES[t]: inner.tex[t][y0:y0 + rows] for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0,
                                                                      abi.TEX_DENOISE_B1)},
