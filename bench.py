@@ -214,7 +214,9 @@ def main():
     compose_sha1 = None
     if args.checksum:  # before the per-kernel timing below re-runs kernels on this rank's tile only
         import hashlib
-        compose_sha1 = hashlib.sha1(ctx.download(abi.TEX_COMPOSE).tobytes()).hexdigest()
+        # .rgb of the whole composed frame: what a tiled run gathers (RFX_TEX_COMPOSE_RGB) and what the next frame's K1 reads
+        rgb = ctx.download(abi.TEX_COMPOSE_RGB) if getattr(renderer, "gather_history_rgb", False) else ctx.download(abi.TEX_COMPOSE)[..., :3]
+        compose_sha1 = hashlib.sha1(np.ascontiguousarray(rgb).tobytes()).hexdigest()
 
     # ---- per-kernel durations (hipEvents on the kernels' stream), this rank's tile
     sp, tp = fx.ssgiPass.uniforms, fx.denoiser.temporalReprojectPass.uniforms

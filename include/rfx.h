@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 9
+#define RFX_ABI_VERSION 10
 
 enum {
     RFX_OK = 0,
@@ -71,6 +71,8 @@ typedef enum rfx_tex {
     RFX_TEX_FBCOPY_F16,     /* RGBA16F linear   TemporalReprojectPass.framebufferTexture (:137-142) when the pass's    */
     RFX_TEX_FBCOPY_F32,     /* RGBA32F linear   input / render target is HalfFloatType resp. FloatType (:66,139-140)   */
     RFX_TEX_FINAL,          /* RGBA32F   SSGIEffect's own fragment (ssgi_compose.frag mainImage): the effect's output colour */
+    RFX_TEX_COMPOSE_RGB,    /* RGB32F    .rgb of RFX_TEX_COMPOSE as 12-byte texels, held whole: the part of `accumulatedTexture` K1 reads,
+                               kept beside it (rfx_compose_params.writeHistoryRGB) so that a row-tiled run all-gathers 12 B/px, not 16 */
     RFX_TEX_COUNT
 } rfx_tex;
 
@@ -109,7 +111,8 @@ typedef struct rfx_ssgi_params {
                                  0  denoiseMode "full" / "full_temporal": K4's output, RFX_TEX_COMPOSE;
                                  1  "temporal": K2's texture[0], RFX_TEX_TEMPORAL0 (whole-frame contexts only);
                                  2  "denoised": the getter returns an ARRAY of textures, which three binds as its empty
-                                    texture -> every history fetch reads (0,0,0,0)                                          */
+                                    texture -> every history fetch reads (0,0,0,0);
+                                 3  as 0, read from RFX_TEX_COMPOSE_RGB (same values: rfx_compose_params.writeHistoryRGB)    */
 } rfx_ssgi_params;
 
 /* K2 — TemporalReprojectMaterial uniforms/defines (TemporalReprojectPass.js:76-117,162-214). */
@@ -160,6 +163,8 @@ typedef struct rfx_compose_params {
     int32_t inputType; /* 0 TYPE_DIFFUSE_SPECULAR; 2 TYPE_SPECULAR (diffuse component = sceneTexture = RFX_TEX_DIRECT_LIGHT, specular GI = B0) */
     int32_t giSource;  /* composerInputTextures (Denoiser.js:53): 0 the denoise pass's textures, RFX_TEX_DENOISE_B0/B1 (RGBA16F);
                           1 denoiseMode "full_temporal": K2's textures, RFX_TEX_TEMPORAL0/1 (RGBA32F, nearest) */
+    int32_t writeHistoryRGB; /* 1: also keep RFX_TEX_COMPOSE_RGB = .rgb of every tile texel of RFX_TEX_COMPOSE (discarded background
+                                fragments copy what the target holds), for rfx_ssgi_params.historySource 3 */
 } rfx_compose_params;
 
 /* SSGIEffect's own fragment — FinalSSGIMaterial uniforms/defines (SSGIEffect.js:34-66,404-417; src/ssgi/shader/ssgi_compose.frag). */

@@ -309,8 +309,14 @@ RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat
         const float ru = coords.x, rv = coords.y;
         if (ru >= 0.0f && ru <= 1.0f && rv >= 0.0f && rv <= 1.0f) {
             // accumulatedTexture: K4's output, K2's texture[0], or (denoiseMode "denoised") three's empty texture — rfx.h historySource
-            const float4 h = A.p.historySource == 2 ? make_float4(0.f, 0.f, 0.f, 0.f) : rfx_fetch_f4(A.history, d, ru, rv);
-            float3 gi = make_float3(h.x, h.y, h.z);
+            float3 gi = make_float3(0.f, 0.f, 0.f);
+            if (A.p.historySource == 3) {  // RFX_TEX_COMPOSE_RGB: the same .rgb as 12-byte texels
+                const float *h = (const float *)A.history.ptr + rfx_texel_index(d, A.history.row0, A.history.rows, ru, rv) * 3;
+                gi = make_float3(h[0], h[1], h[2]);
+            } else if (A.p.historySource != 2) {
+                const float4 h = rfx_fetch_f4(A.history, d, ru, rv);
+                gi = make_float3(h.x, h.y, h.z);
+            }
             const float mx = fmaxf(fmaxf(mat.diffuse.x, mat.diffuse.y), mat.diffuse.z);
             const float mn = fminf(fminf(mat.diffuse.x, mat.diffuse.y), mat.diffuse.z);
             const float sat = (mx == mn) ? 0.0f : (mx - mn) / mx;  // getSaturation :348-360

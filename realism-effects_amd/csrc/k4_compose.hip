@@ -20,7 +20,14 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
         const int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
         float dxa = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, qx0, y)], dxb = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, qx1, y)];
         float dya = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, qy0)], dyb = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, qy1)];
-        if (depth == 1.0f && (fabsf(dxb - dxa) + fabsf(dyb - dya)) == 0.0f) return;  // discard :61-64
+        if (depth == 1.0f && (fabsf(dxb - dxa) + fabsf(dyb - dya)) == 0.0f) {  // discard :61-64
+            if (A.rgb_out) {  // the target keeps its texel: mirror it, so COMPOSE_RGB stays == COMPOSE.rgb on every tile texel
+                const float4 keep = ((const float4 *)A.out.ptr)[(size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x];
+                float *r = A.rgb_out + ((size_t)y * d.W + x) * 3;
+                r[0] = keep.x; r[1] = keep.y; r[2] = keep.z;
+            }
+            return;
+        }
     }
     const Material mat = rfx_get_material<true>(((const uint4 *)A.gbuffer.ptr)[rfx_xy_index(d, A.gbuffer.row0, A.gbuffer.rows, x, y)]);
     const float3 viewNormal = rfx_vec_mul_mat(C, mat.normal, 0.0f);  // :71 (not normalised)
@@ -77,6 +84,10 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
     o.z = (dc.z + sgi.z * F.z) + mat.emissive.z;
     o.w = 1.0f;
     ((float4 *)A.out.ptr)[(size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x] = o;
+    if (A.rgb_out) {
+        float *r = A.rgb_out + ((size_t)y * d.W + x) * 3;
+        r[0] = o.x; r[1] = o.y; r[2] = o.z;
+    }
 }
 
 __global__ __launch_bounds__(256) void k4_compose(K4Args A) {

@@ -42,6 +42,7 @@ static size_t texel_bytes(int id) {
     switch (id) {
     case RFX_TEX_DEPTH: return 4;
     case RFX_TEX_BLUE_NOISE: return 4;
+    case RFX_TEX_COMPOSE_RGB: return 12;
     case RFX_TEX_DENOISE_A0: case RFX_TEX_DENOISE_A1: case RFX_TEX_DENOISE_B0: case RFX_TEX_DENOISE_B1: case RFX_TEX_FBCOPY_F16: return 8;
     default: return 16;
     }
@@ -97,7 +98,7 @@ rfx_ctx *rfx_create(int device, int width, int height, int tile_y0, int tile_row
         s.texel = texel_bytes(i);
         s.width = width;
         // K1 gathers depth and last frame's composed GI anywhere on screen -> held whole
-        const bool whole = (i == RFX_TEX_DEPTH || i == RFX_TEX_COMPOSE);
+        const bool whole = (i == RFX_TEX_DEPTH || i == RFX_TEX_COMPOSE || i == RFX_TEX_COMPOSE_RGB);
         s.row0 = whole ? 0 : b0;
         s.rows = whole ? height : b1 - b0;
         if (i == RFX_TEX_BLUE_NOISE) { s.row0 = 0; s.rows = 128; s.width = 128; }
@@ -421,10 +422,10 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
     if (p->useEnvMap && !c->env) return fail(c, RFX_ESTATE, "rfx_ssgi_march/trace/shade: useEnvMap without rfx_set_environment");
     if (p->steps < 1 || p->refineSteps < 0) return fail(c, RFX_EINVAL, "rfx_ssgi_march/trace/shade: steps/refineSteps");
     hipSetDevice(c->device);
-    if (p->historySource < 0 || p->historySource > 2) return fail(c, RFX_EINVAL, "rfx_ssgi_march/trace/shade: historySource");
+    if (p->historySource < 0 || p->historySource > 3) return fail(c, RFX_EINVAL, "rfx_ssgi_march/trace/shade: historySource");
     if (p->historySource == 1 && (c->tile_y0 != 0 || c->tile_rows != c->H))
         return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march/trace/shade: historySource TEMPORAL0 (denoiseMode \"temporal\") needs a whole-frame context: K1 gathers it anywhere on screen");
-    const int hist = p->historySource == 1 ? RFX_TEX_TEMPORAL0 : RFX_TEX_COMPOSE;
+    const int hist = p->historySource == 1 ? RFX_TEX_TEMPORAL0 : (p->historySource == 3 ? RFX_TEX_COMPOSE_RGB : RFX_TEX_COMPOSE);
     const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, RFX_TEX_DIRECT_LIGHT, hist, RFX_TEX_BLUE_NOISE, RFX_TEX_SSGI};
     int rc = need(c, ids, 6);
     if (rc) return rc;
@@ -607,6 +608,12 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
     A.gi0 = view(c, g0); A.gi1 = view(c, g1);
     A.scene = view(c, RFX_TEX_DIRECT_LIGHT);  // Denoiser.js:101-103: sceneTexture = the composer's input buffer
     A.out = wview(c, RFX_TEX_COMPOSE);
+    A.rgb_out = nullptr;
+    if (p->writeHistoryRGB) {
+        const int rgb[] = {RFX_TEX_COMPOSE_RGB};
+        if ((rc = need(c, rgb, 1))) return rc;
+        A.rgb_out = (float *)c->slots[RFX_TEX_COMPOSE_RGB].ptr;  // held whole, like COMPOSE: frame row y at y * W
+    }
     A.p = *p;
     HIPCHK(c, rfx_launch_k4(A, c->stream));
     return RFX_OK;

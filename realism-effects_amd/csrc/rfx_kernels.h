@@ -65,6 +65,7 @@ struct K4Args {
     TexView depth, gbuffer, gi0, gi1;  // gi*: K3 target B (RGBA16F, linear) or, giSource 1, K2's targets (RGBA32F, nearest)
     TexView scene;  // the composer's input buffer (sceneTexture): read only by inputType "specular"
     TexViewW out;
+    float *rgb_out;  // RFX_TEX_COMPOSE_RGB (whole frame, 3 floats per texel) or null
     rfx_compose_params p;
 };
 

@@ -25,7 +25,8 @@ const TEX = {
 	COMPOSE: 12,
 	FBCOPY_F16: 13,
 	FBCOPY_F32: 14,
-	FINAL: 15
+	FINAL: 15,
+	COMPOSE_RGB: 16
 }
 // [TypedArray constructor, elements per texel]
 const FORMAT = {
@@ -44,7 +45,8 @@ const FORMAT = {
 	12: [Float32Array, 4],
 	13: [Uint16Array, 4],
 	14: [Float32Array, 4],
-	15: [Float32Array, 4]
+	15: [Float32Array, 4],
+	16: [Float32Array, 3]
 }
 
 // 128x128 RGBA8 blue-noise table: decoded once from the reference's PNG asset, already flipY'd

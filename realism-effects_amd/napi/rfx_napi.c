@@ -419,6 +419,7 @@ static napi_value n_compose(napi_env env, napi_callback_info info) {
     if (!read_camera(env, a[1], "camera", &p.camera)) return NULL;
     p.inputType = (int32_t)prop_num(env, a[1], "inputType", 0);
     p.giSource = (int32_t)prop_num(env, a[1], "giSource", 0);
+    p.writeHistoryRGB = (int32_t)prop_num(env, a[1], "writeHistoryRGB", 0);
     int rc = rfx_compose(c, &p);
     if (rc) return throw_rfx(env, c, "rfx_compose", rc);
     return NULL;

@@ -13,20 +13,21 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "..", "csrc", "librfx_hip.so")
 
-RFX_ABI_VERSION = 9
+RFX_ABI_VERSION = 10
 RFX_OK, RFX_EINVAL, RFX_ENOMEM, RFX_EDEVICE, RFX_ESTATE, RFX_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 (TEX_DEPTH, TEX_GBUFFER, TEX_VELOCITY, TEX_DIRECT_LIGHT, TEX_BLUE_NOISE, TEX_SSGI, TEX_TEMPORAL0, TEX_TEMPORAL1,
- TEX_DENOISE_A0, TEX_DENOISE_A1, TEX_DENOISE_B0, TEX_DENOISE_B1, TEX_COMPOSE, TEX_FBCOPY_F16, TEX_FBCOPY_F32, TEX_FINAL, TEX_COUNT) = range(17)
+ TEX_DENOISE_A0, TEX_DENOISE_A1, TEX_DENOISE_B0, TEX_DENOISE_B1, TEX_COMPOSE, TEX_FBCOPY_F16, TEX_FBCOPY_F32, TEX_FINAL, TEX_COMPOSE_RGB, TEX_COUNT) = range(18)
 
 TEX_NAMES = ["depth", "gbuffer", "velocity", "direct_light", "blue_noise", "ssgi", "temporal0", "temporal1",
-             "denoise_a0", "denoise_a1", "denoise_b0", "denoise_b1", "compose", "fbcopy_f16", "fbcopy_f32", "final"]
+             "denoise_a0", "denoise_a1", "denoise_b0", "denoise_b1", "compose", "fbcopy_f16", "fbcopy_f32", "final", "compose_rgb"]
 # (numpy dtype, channels) per slot, matching rfx_tex_texel_bytes()
 TEX_FORMAT = {
     TEX_DEPTH: (np.float32, 1), TEX_GBUFFER: (np.uint32, 4), TEX_VELOCITY: (np.uint32, 4), TEX_DIRECT_LIGHT: (np.float32, 4),
     TEX_BLUE_NOISE: (np.uint8, 4), TEX_SSGI: (np.uint32, 4), TEX_TEMPORAL0: (np.float32, 4), TEX_TEMPORAL1: (np.float32, 4),
     TEX_DENOISE_A0: (np.uint16, 4), TEX_DENOISE_A1: (np.uint16, 4), TEX_DENOISE_B0: (np.uint16, 4), TEX_DENOISE_B1: (np.uint16, 4),
     TEX_COMPOSE: (np.float32, 4), TEX_FBCOPY_F16: (np.uint16, 4), TEX_FBCOPY_F32: (np.float32, 4), TEX_FINAL: (np.float32, 4),
+    TEX_COMPOSE_RGB: (np.float32, 3),
 }
 
 M16 = C.c_float * 16
@@ -71,7 +72,7 @@ class DenoiseParams(C.Structure):
 
 
 class ComposeParams(C.Structure):
-    _fields_ = [("camera", Camera), ("inputType", C.c_int32), ("giSource", C.c_int32)]
+    _fields_ = [("camera", Camera), ("inputType", C.c_int32), ("giSource", C.c_int32), ("writeHistoryRGB", C.c_int32)]
 
 
 FP = C.POINTER(C.c_float)

@@ -331,6 +331,8 @@ class DenoiserComposePass:
 
     def render(self, renderer):
         self.uniforms.camera = abi.Camera.from_scene(self._camera)
+        # a row-tiled renderer all-gathers the part of this target K1 reads next frame (.rgb) as 12-byte texels
+        self.uniforms.writeHistoryRGB = 1 if getattr(renderer, "gather_history_rgb", False) else 0
         renderer.compose(self.uniforms)
 
     def dispose(self):
@@ -432,6 +434,8 @@ class SSGIPass:
         # getter returns the ARRAY of K3's targets — what three binds for a non-texture value: its empty texture (zeros)
         t = self.ssgiEffect.denoiser.texture
         self.uniforms.historySource = 2 if isinstance(t, (tuple, list)) else (1 if t == abi.TEX_TEMPORAL0 else 0)
+        if self.uniforms.historySource == 0 and getattr(renderer, "gather_history_rgb", False):
+            self.uniforms.historySource = 3  # the same values from RFX_TEX_COMPOSE_RGB (tiling.py)
         if getattr(renderer, "overlap_history_gather", False):
             # row-tiled run: last frame's composed GI is still being all-gathered; only the shading half of the draw reads it
             renderer.ssgi_trace(self.uniforms)

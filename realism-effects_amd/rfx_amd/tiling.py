@@ -8,7 +8,8 @@ rows above and below and three exchange steps keep them current:
                                      written (RCCL over xGMI; message = halo*W*texel bytes per
                                      texture and direction — latency-bound)
   after K4                         : all-gather of the composed GI tile rows (next frame's K1
-                                     gathers it anywhere on screen).  It is the one big message
+                                     gathers it anywhere on screen) — of its .rgb, which is all K1
+                                     reads, kept by K4 as 12-byte texels in RFX_TEX_COMPOSE_RGB.  It is the one big message
                                      (tile bytes x (N-1) per rank) and only the SHADING half of K1
                                      reads it, so it is started asynchronously and waited for
                                      between rfx_ssgi_trace and rfx_ssgi_shade: it overlaps the next
@@ -72,6 +73,8 @@ class TiledRenderer:
         self._pending = []  # (works, tensor) of the composed-GI all-gather in flight
         # effect.SSGIPass splits K1 into trace + shade around before_ssgi_shade() when this is set
         self.overlap_history_gather = world > 1 and hasattr(inner, "ssgi_trace")
+        # K1 reads only .rgb of the composed GI: when the RGB twin is bound, K4 keeps it and IT is gathered (12 B/px instead of 16)
+        self.gather_history_rgb = world > 1 and abi.TEX_COMPOSE_RGB in tensors
 
     def __getattr__(self, name):  # everything else (upload, the four draws, ...) goes to the tile's renderer
         return getattr(self.inner, name)
@@ -141,7 +144,7 @@ class TiledRenderer:
         if self.world == 1:
             return
         dist = self._dist
-        full = self.tensors[abi.TEX_COMPOSE]  # whole frame
+        full = self.tensors[abi.TEX_COMPOSE_RGB if self.gather_history_rgb else abi.TEX_COMPOSE]  # whole frame
         mine = full[self.tile_y0:self.tile_y0 + self.tile_rows]
         self.finish_pending()
         self._sync_before_comm()
@@ -177,7 +180,7 @@ def bind_torch_buffers(ctx, device, texs=None):
     `texs` defaults to what the SSGI chain exchanges; a TRAA run binds (TEX_FBCOPY_F16,) or (TEX_FBCOPY_F32,)."""
     import torch
     tensors = {}
-    for tex in (EXCHANGED + (abi.TEX_COMPOSE,) if texs is None else tuple(texs)):
+    for tex in (EXCHANGED + (abi.TEX_COMPOSE_RGB,) if texs is None else tuple(texs)):
         r0, n = ctx.held_rows(tex)
         dtype, ch = abi.TEX_FORMAT[tex]
         nbytes = np.dtype(dtype).itemsize * ch * ctx.W

@@ -27,7 +27,7 @@ class OracleRenderer:
         self.calls = []
 
     def held_rows(self, tex):
-        if tex in (abi.TEX_DEPTH, abi.TEX_COMPOSE):
+        if tex in (abi.TEX_DEPTH, abi.TEX_COMPOSE, abi.TEX_COMPOSE_RGB):
             return 0, self.H
         if tex == abi.TEX_BLUE_NOISE:
             return 0, 128
@@ -78,6 +78,10 @@ class OracleRenderer:
         self.calls.append(("ssgi", p.blueNoiseIndex))
         t = self.tex
         hist = t[abi.TEX_TEMPORAL0] if p.historySource == 1 else t[abi.TEX_COMPOSE]
+        if p.historySource == 3:  # the RGB twin of the composed GI: same texels, so the oracle reads them as source 0
+            hist = np.concatenate([t[abi.TEX_COMPOSE_RGB], np.zeros((self.H, self.W, 1), np.float32)], axis=-1)
+            p = abi.SsgiParams.from_buffer_copy(p)
+            p.historySource = 0
         rs = p.resolutionScale or 1.0
         if rs != 1.0:  # the smaller render target lives at the start of the slot, pitch W*s (as on the device)
             oH, oW = int(self.H * rs), int(self.W * rs)
@@ -140,6 +144,9 @@ class OracleRenderer:
         g0, g1 = (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1) if p.giSource else (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1)
         O.compose(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[g0], t[g1], p, out=t[abi.TEX_COMPOSE], rows=self._rows(),
                   scene=t[abi.TEX_DIRECT_LIGHT])
+        if p.writeHistoryRGB:
+            y0, y1 = self._rows()
+            t[abi.TEX_COMPOSE_RGB][y0:y1] = t[abi.TEX_COMPOSE][y0:y1, :, :3]
 
     def final_compose(self, p):
         self.calls.append(("final", p.fogMode, p.isDebug))

@@ -945,3 +945,40 @@ def test_ssgi_trace_plus_shade_is_bit_identical_to_march(blue_noise, variant):
         ctx.ssgi_shade(sp)  # the trace was consumed
     assert ctx.halo_violations() == 0 or variant == "tile"
     ctx.close()
+
+
+def test_rgb_history_twin_matches_composed_gi(blue_noise):
+    """RFX_TEX_COMPOSE_RGB (what a row-tiled run all-gathers instead of the RGBA32F target: K1 reads only .rgb): K4 with writeHistoryRGB keeps
+    it equal to COMPOSE.rgb on every tile texel — discarded background fragments included — and K1 reading it (historySource 3) writes
+    exactly the texels it writes from COMPOSE."""
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_frame
+
+    W, H = 256, 144
+    f = synthetic_frame(W, H, 1)
+    assert (f.depth == 1.0).mean() > 0.02  # there IS background: K4 discards there
+    sp, tp, dp, cp = _params(abi, f, f.camera, 1.0, 12, 3)
+    ctx = Context(W, H)
+    ctx.upload_frame(f)
+    rs = np.random.RandomState(8)
+    ctx.upload(abi.TEX_COMPOSE, rs.rand(H, W, 4).astype(np.float32))  # what the target "held" before: survives under discarded fragments
+    for t in (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1):
+        ctx.upload(t, rs.rand(H, W, 4).astype(np.float16).view(np.uint16))
+    cp.writeHistoryRGB = 1
+    ctx.compose(cp)
+    comp, rgb = ctx.download(abi.TEX_COMPOSE), ctx.download(abi.TEX_COMPOSE_RGB)
+    assert rgb.shape == (H, W, 3) and np.array_equal(rgb, comp[..., :3])
+    sp.blueNoiseIndex = 31
+    ctx.ssgi_march(sp)
+    want = ctx.download(abi.TEX_SSGI)
+    ctx.clear(abi.TEX_SSGI)
+    ctx.upload(abi.TEX_COMPOSE, np.full((H, W, 4), 7e5, np.float32))  # must not be looked at any more
+    sp.historySource = 3
+    ctx.ssgi_march(sp)
+    assert np.array_equal(ctx.download(abi.TEX_SSGI), want)
+    ctx.clear(abi.TEX_SSGI)
+    ctx.ssgi_trace(sp)
+    ctx.ssgi_shade(sp)
+    assert np.array_equal(ctx.download(abi.TEX_SSGI), want)
+    ctx.close()

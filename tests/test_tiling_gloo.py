@@ -50,7 +50,7 @@ def _worker(rank, world, port, outdir):
     y0, rows = tiling.split_rows(H, world)[rank]
     inner = OracleRenderer(W, H, y0, rows, halo)
     tensors = {}
-    for tex in tiling.EXCHANGED + (abi.TEX_COMPOSE,):
+    for tex in tiling.EXCHANGED + (abi.TEX_COMPOSE_RGB,):
         b0, n = inner.held_rows(tex)
         tensors[tex] = torch.from_numpy(inner.tex[tex][b0:b0 + n])  # shares memory with the renderer's planes
     r = tiling.TiledRenderer(inner, tensors, rank, world)
@@ -58,13 +58,13 @@ def _worker(rank, world, port, outdir):
     _chain(r, scene, frames[0].camera, frames)
     assert r.exchange_count == FRAMES * 3  # after K2, after K3 pass 0, after K3 pass 1
     # K1 ran as trace + shade with the (asynchronous) composed-GI all-gather waited for in between; the last one is still pending
-    assert r.overlap_history_gather and sum(1 for c in inner.calls if c[0] == "ssgi_trace") == FRAMES
+    assert r.gather_history_rgb and r.overlap_history_gather and sum(1 for c in inner.calls if c[0] == "ssgi_trace") == FRAMES
     assert len(r._pending) == 1
     r.finish_pending()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), y0=y0, rows=rows, halo=halo,
              **{abi.TEX_NAMES[t]: inner.tex[t][y0:y0 + rows] for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0,
                                                                      abi.TEX_DENOISE_B1)},
-             compose_full=inner.tex[abi.TEX_COMPOSE])
+             compose_tile=inner.tex[abi.TEX_COMPOSE][y0:y0 + rows], compose_rgb_full=inner.tex[abi.TEX_COMPOSE_RGB])
     # TRAAEffect on the same tiles: one exchange per frame, of the pass's own history
     inner2 = OracleRenderer(W, H, y0, rows, tiling.required_halo(0.0, vmax, H, W))
     b0, n = inner2.held_rows(abi.TEX_FBCOPY_F16)
@@ -98,8 +98,9 @@ def test_two_rank_tiled_chain_is_bit_identical(tmp_path):
         y0, rows = int(z["y0"]), int(z["rows"])
         for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1):
             assert np.array_equal(z[abi.TEX_NAMES[t]], ref.tex[t][y0:y0 + rows]), "rank %d %s differs" % (rank, abi.TEX_NAMES[t])
-        # every rank ends with the WHOLE composed frame (next frame's K1 gathers it anywhere)
-        assert np.array_equal(z["compose_full"], ref.tex[abi.TEX_COMPOSE]), "rank %d compose differs" % rank
+        # every rank ends with .rgb of the WHOLE composed frame (next frame's K1 gathers it anywhere), and its own tile of the target
+        assert np.array_equal(z["compose_rgb_full"], ref.tex[abi.TEX_COMPOSE][..., :3]), "rank %d gathered composed GI differs" % rank
+        assert np.array_equal(z["compose_tile"], ref.tex[abi.TEX_COMPOSE][y0:y0 + rows]), "rank %d compose tile differs" % rank
     ref2 = OracleRenderer(W, H)
     _traa(ref2, types.SimpleNamespace(frame=None), types.SimpleNamespace(**vars(frames[0].camera)), frames)
     for rank in range(world):
