@@ -190,7 +190,8 @@ const char *rfx_last_error(const rfx_ctx *);
 int rfx_get_geometry(const rfx_ctx *, int *width, int *height, int *tile_y0, int *tile_rows, int *halo_rows);
 /* Run the context's kernels on a caller-provided hipStream_t (e.g. a stream the framework also uses for its
  * collectives, so that they are ordered against the kernels); NULL restores the context's own stream.  The legacy
- * default stream has handle 0 == NULL and therefore cannot be selected: create a stream. */
+ * default stream has handle 0 == NULL and therefore cannot be selected: create a stream.  Switching drains the
+ * stream used so far (its uploads and zero-fills must not race kernels on the new one): set it once, not per frame. */
 int rfx_set_stream(rfx_ctx *, void *hip_stream);
 
 /* ---- textures.  `row0`/`rows` are FRAME rows of the band being transferred; the band must lie

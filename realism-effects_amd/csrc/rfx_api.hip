@@ -86,7 +86,8 @@ rfx_ctx *rfx_create(int device, int width, int height, int tile_y0, int tile_row
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipMalloc((void **)&c->halo_violations, sizeof(unsigned int)) != hipSuccess) {
         fail(nullptr, RFX_EDEVICE, "rfx_create: stream/event creation failed");
-        delete c;
+        c->stream = c->own_stream;
+        rfx_destroy(c);  // releases whatever was created
         return nullptr;
     }
     hipMemset(c->halo_violations, 0, sizeof(unsigned int));
@@ -139,6 +140,9 @@ int rfx_get_geometry(const rfx_ctx *c, int *width, int *height, int *tile_y0, in
 
 int rfx_set_stream(rfx_ctx *c, void *hip_stream) {
     if (!c) return RFX_EINVAL;
+    hipSetDevice(c->device);
+    // work already enqueued (uploads, the zero-fill of fresh render targets) must not race kernels on the new stream
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return RFX_OK;
 }
@@ -176,6 +180,7 @@ int rfx_upload(rfx_ctx *c, rfx_tex id, const void *host, int row0, int rows) {
     int rc = band_check(c, id, row0, rows);
     if (rc) return rc;
     if ((rc = ensure(c, id))) return rc;
+    hipSetDevice(c->device);
     Slot &s = c->slots[id];
     const size_t pitch = (size_t)s.width * s.texel;
     HIPCHK(c, hipMemcpyAsync((char *)s.ptr + (size_t)(row0 - s.row0) * pitch, host, (size_t)rows * pitch, hipMemcpyHostToDevice, c->stream));
@@ -189,6 +194,7 @@ int rfx_download(rfx_ctx *c, rfx_tex id, void *host, int row0, int rows) {
     int rc = band_check(c, id, row0, rows);
     if (rc) return rc;
     if ((rc = ensure(c, id))) return rc;
+    hipSetDevice(c->device);
     Slot &s = c->slots[id];
     const size_t pitch = (size_t)s.width * s.texel;
     HIPCHK(c, hipMemcpyAsync(host, (char *)s.ptr + (size_t)(row0 - s.row0) * pitch, (size_t)rows * pitch, hipMemcpyDeviceToHost, c->stream));
@@ -200,6 +206,7 @@ int rfx_clear(rfx_ctx *c, rfx_tex id) {
     if (!c || id < 0 || id >= RFX_TEX_COUNT) return RFX_EINVAL;
     int rc = ensure(c, id);
     if (rc) return rc;
+    hipSetDevice(c->device);
     Slot &s = c->slots[id];
     HIPCHK(c, hipMemsetAsync(s.ptr, 0, (size_t)s.rows * s.width * s.texel, c->stream));
     return RFX_OK;
@@ -214,7 +221,11 @@ void *rfx_tex_device_ptr(rfx_ctx *c, rfx_tex id) {
 int rfx_bind_external(rfx_ctx *c, rfx_tex id, void *device_ptr) {
     if (!c || id < 0 || id >= RFX_TEX_COUNT || !device_ptr) return RFX_EINVAL;
     Slot &s = c->slots[id];
-    if (s.owned && s.ptr) { hipSetDevice(c->device); hipFree(s.ptr); }
+    if (s.owned && s.ptr) {  // launches that still use the old buffer finish first
+        hipSetDevice(c->device);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        hipFree(s.ptr);
+    }
     s.ptr = device_ptr;
     s.owned = false;
     s.uploaded = true;
@@ -393,7 +404,11 @@ int rfx_set_environment_importance(rfx_ctx *c, const float *marginal, const floa
     c->env_marginal = c->env_conditional = nullptr;
     hipError_t e = hipMalloc((void **)&c->env_marginal, (size_t)c->env_h * sizeof(float));
     if (e == hipSuccess) e = hipMalloc((void **)&c->env_conditional, (size_t)c->env_w * c->env_h * sizeof(float));
-    if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(environment importance tables)", e);
+    if (e != hipSuccess) {
+        if (c->env_marginal) hipFree(c->env_marginal);
+        c->env_marginal = c->env_conditional = nullptr;
+        return fail(c, RFX_ENOMEM, "hipMalloc(environment importance tables)", e);
+    }
     HIPCHK(c, hipMemcpyAsync(c->env_marginal, marginal, (size_t)c->env_h * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->env_conditional, conditional, (size_t)c->env_w * c->env_h * sizeof(float), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
