@@ -19,13 +19,38 @@
 
 namespace {
 
-constexpr int CELL = 8;  // coarse cell edge in texels
+// The (min, max) view-Z table the march consults before touching a texel: one 4-byte cell = two halfs, min rounded
+// DOWN and max rounded UP, so a widened range can only reject fewer taps — the rejection tests stay exact.  The cell edge is
+// 2^cell_shift texels, chosen per frame size so that the whole table stays <= 32 KiB (rfx_api; 4K: 32-texel cells): it then lives
+// in the CUs' L1 and a lookup costs what an LDS read costs.  Measured at 4K (same box, bit-identical output): 8-texel float2
+// cells (1 MiB) 0.789 ms, half cells 0.749, 16-texel 0.727, 32/64-texel 0.694-0.712; an LDS copy per workgroup (RFX_K1_LDS=1,
+// table <= 16 KiB) 0.700 — no better than the cached global lookup, so it is off.
+#ifndef RFX_K1_LDS
+#define RFX_K1_LDS 0
+#endif
+constexpr int BASE = 16;  // edge of the pre-pass's exact (float) cells, reduced to the final cells by k1_pack_cells
+typedef uint32_t k1_cell_t;
+RFX_DEV uint32_t k1_half_toward(float v, bool up) {  // nearest half not below (up) / not above (!up) v
+    uint32_t h = rfx_f2h_rne(v) & 0xffffu;
+    const float f = rfx_h2f((unsigned short)h);
+    if (up ? (f < v) : (f > v)) {
+        const bool neg = (h & 0x8000u) != 0;
+        if (up) h = neg ? (h == 0x8000u ? 0x0001u : h - 1u) : h + 1u;
+        else h = neg ? h + 1u : (h == 0x0000u ? 0x8001u : h - 1u);
+    }
+    return h;
+}
+RFX_DEV k1_cell_t k1_cell_pack(float mn, float mx) { return k1_half_toward(mn, false) | (k1_half_toward(mx, true) << 16); }
+RFX_DEV float2 k1_cell_load(const k1_cell_t *t, int i) {
+    const uint32_t v = t[i];
+    return make_float2(rfx_h2f((unsigned short)(v & 0xffffu)), rfx_h2f((unsigned short)(v >> 16)));
+}
 
 struct MarchCtx {
     const float *P;            // projectionMatrix (column-major)
     const float *viewz;        // full-frame view-space Z plane (k1_prepare)
-    const float2 *coarse;      // (min, max) view Z per CELL x CELL block
-    int coarse_w;
+    const k1_cell_t *coarse;   // (min, max) view Z per 2^cell_shift-texel cell (LDS copy, or global)
+    int coarse_w, cell_shift;
     float rayDistance, thickness;
     int steps, refineSteps;
     bool use_coarse;
@@ -65,7 +90,7 @@ RFX_DEV Tap k1_tap(const MarchCtx &m, const FrameDims &d, float2 uv) {
     const int xi = rfx_nearest_idx(uv.x, d.fW, d.W), yi = rfx_nearest_idx(uv.y, d.fH, d.H);
     Tap t;
     t.idx = yi * d.W + xi;
-    t.cell = (int)(((unsigned)yi / CELL) * (unsigned)m.coarse_w + ((unsigned)xi / CELL));
+    t.cell = (yi >> m.cell_shift) * m.coarse_w + (xi >> m.cell_shift);
     return t;
 }
 // RayMarch (:441-475) + BinarySearch (:477-503) for the pixel's TWO rays at once (slot 0 = optional diffuse ray,
@@ -106,7 +131,7 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         for (int r = 0; r < 2; r++) tap[r] = k1_tap(m, d, rays[r].uv);
         if (m.use_coarse) {
 #pragma unroll
-            for (int r = 0; r < 2; r++) mm[r] = m.coarse[tap[r].cell];
+            for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const float h = rays[r].pos.z;
@@ -152,7 +177,7 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
             }
             if (m.use_coarse) {
 #pragma unroll
-                for (int r = 0; r < 2; r++) mm[r] = m.coarse[tap[r].cell];
+                for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     const float h = rays[r].pos.z;
@@ -338,6 +363,10 @@ RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat
     return ssgi;
 }
 
+#if RFX_K1_LDS
+extern __shared__ uint4 k1_lds[];  // the (min, max) table
+#endif
+
 // STAGE 0: the whole fragment in one launch.  STAGE 1 ("trace") stops after the march and leaves the two rays' end state in
 // A.hits (2 x float4 per pixel: uv0 uv1 | pos0.x pos1.xyz); STAGE 2 ("shade") redoes the cheap per-pixel setup, takes the rays
 // from A.hits instead of marching and finishes the fragment.  Only the shading reads last frame's composed GI anywhere on
@@ -379,8 +408,13 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     MarchCtx m;
     m.P = P;
     m.viewz = A.viewz;
-    m.coarse = A.coarse;
-    m.coarse_w = A.coarse_w;
+#if RFX_K1_LDS
+    m.coarse = reinterpret_cast<const k1_cell_t *>(k1_lds);
+#else
+    m.coarse = (const k1_cell_t *)A.cells;
+#endif
+    m.coarse_w = A.cells_w;
+    m.cell_shift = A.cell_shift;
     m.rayDistance = p.rayDistance;
     m.thickness = p.thickness;
     m.steps = p.steps;
@@ -515,16 +549,24 @@ template <bool PERSP, bool ENV, bool MIS, int STAGE>
 __global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
+#if RFX_K1_LDS
+    if (STAGE != 2) {  // every lane takes part, before any early exit
+        const uint4 *src = (const uint4 *)A.cells;
+        for (int i = threadIdx.y * 64 + threadIdx.x; i < A.cells_vec4; i += 256) k1_lds[i] = src[i];
+        __syncthreads();
+    }
+#endif
     k1_ssgi_march_body<PERSP, ENV, MIS, STAGE>(A, d);
     rfx_flush_violations(d);
 }
 
 // Pre-pass: view-space Z per texel (getViewZ, ssgi_utils.frag:9: nearMulFar / (farMinusNear * depth - cameraFar), IEEE)
 // and its (min, max) per 8x8 cell.  64x8-pixel workgroups = 8 cells; 8-lane shuffles reduce a row segment, LDS the rows.
-__global__ __launch_bounds__(512) void k1_prepare(const float *depth, float *viewz, float2 *coarse, int W, int H, int coarse_w, float nearMulFar,
-                                                  float farMinusNear, float cameraFar, float nearMinusFar, float cameraNear, int perspective) {
-    __shared__ float s_min[8][8], s_max[8][8];
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 8 + threadIdx.y;
+__global__ __launch_bounds__(64 * BASE) void k1_prepare(const float *depth, float *viewz, float2 *base, int W, int H, int base_w, float nearMulFar,
+                                                        float farMinusNear, float cameraFar, float nearMinusFar, float cameraNear, int perspective) {
+    constexpr int CPR = 64 / BASE;  // cells per block row
+    __shared__ float s_min[BASE][CPR], s_max[BASE][CPR];
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BASE + threadIdx.y;
     float z = 0.0f;
     const bool in = x < W && y < H;
     if (in) {
@@ -534,25 +576,45 @@ __global__ __launch_bounds__(512) void k1_prepare(const float *depth, float *vie
     }
     float mn = in ? z : INFINITY, mx = in ? z : -INFINITY;
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
+    for (int o = 1; o < BASE; o <<= 1) {
         mn = fminf(mn, __shfl_xor(mn, o));
         mx = fmaxf(mx, __shfl_xor(mx, o));
     }
-    if ((threadIdx.x & 7) == 0) {
-        s_min[threadIdx.y][threadIdx.x >> 3] = mn;
-        s_max[threadIdx.y][threadIdx.x >> 3] = mx;
+    if ((threadIdx.x & (BASE - 1)) == 0) {
+        s_min[threadIdx.y][threadIdx.x / BASE] = mn;
+        s_max[threadIdx.y][threadIdx.x / BASE] = mx;
     }
     __syncthreads();
-    if (threadIdx.y == 0 && threadIdx.x < 8) {
+    if (threadIdx.y == 0 && threadIdx.x < CPR) {
         float a = s_min[0][threadIdx.x], b = s_max[0][threadIdx.x];
 #pragma unroll
-        for (int r = 1; r < 8; r++) {
+        for (int r = 1; r < BASE; r++) {
             a = fminf(a, s_min[r][threadIdx.x]);
             b = fmaxf(b, s_max[r][threadIdx.x]);
         }
-        const int cx = blockIdx.x * 8 + threadIdx.x;
-        if (cx < coarse_w) coarse[(size_t)blockIdx.y * coarse_w + cx] = make_float2(a, b);
+        const int cx = blockIdx.x * CPR + threadIdx.x;
+        if (cx < base_w) base[(size_t)blockIdx.y * base_w + cx] = make_float2(a, b);
     }
+}
+
+// ... and the march's table: cell (cx, cy) of edge BASE << up = the (min, max) of its (1 << up)^2 base cells, packed to two halfs
+__global__ __launch_bounds__(256) void k1_pack_cells(const float2 *base, int base_w, int base_h, k1_cell_t *cells, int cells_w, int cells_h, int up,
+                                                     int cells_padded) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cells_padded) return;
+    if (i >= cells_w * cells_h) {  // padding up to a whole 16-byte vector (the LDS copy moves uint4s)
+        cells[i] = 0u;
+        return;
+    }
+    const int cy = i / cells_w, cx = i - cy * cells_w;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int by = cy << up; by < min((cy + 1) << up, base_h); by++)
+        for (int bx = cx << up; bx < min((cx + 1) << up, base_w); bx++) {
+            const float2 b = base[(size_t)by * base_w + bx];
+            mn = fminf(mn, b.x);
+            mx = fmaxf(mx, b.y);
+        }
+    cells[i] = k1_cell_pack(mn, mx);
 }
 
 // scene.environment mip chain: dst texel = bilinear centre of the 2x2 (2x1, 1x2) source block, lerp(.5, lerp(.5,a,b), lerp(.5,c,d)), stored
@@ -584,16 +646,24 @@ hipError_t rfx_launch_env_mip(const float4 *src, float4 *dst, int sw, int sh, in
     return hipGetLastError();
 }
 
+int rfx_k1_base_cell() { return BASE; }
+
 hipError_t rfx_launch_k1_prepare(const K1Args &A, hipStream_t stream) {
-    dim3 block(64, 8), grid((A.dims.W + 63) / 64, (A.dims.H + 7) / 8);
+    dim3 block(64, BASE), grid((A.dims.W + 63) / 64, (A.dims.H + BASE - 1) / BASE);
     hipLaunchKernelGGL(k1_prepare, grid, block, 0, stream, (const float *)A.depth.ptr, A.viewz, A.coarse, A.dims.W, A.dims.H, A.coarse_w, A.nearMulFar,
                        A.farMinusNear, A.p.camera.far_, A.nearMinusFar, A.p.camera.near_, A.p.camera.isPerspective);
+    int up = 0;
+    while ((BASE << up) < (1 << A.cell_shift)) up++;
+    const int padded = A.cells_vec4 * 4;
+    hipLaunchKernelGGL(k1_pack_cells, dim3((padded + 255) / 256), dim3(256), 0, stream, (const float2 *)A.coarse, A.coarse_w, A.coarse_h,
+                       (k1_cell_t *)A.cells, A.cells_w, A.cells_h, up, padded);
     return hipGetLastError();
 }
 
 hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
     const int nbx = (A.out_w + 63) / 64, nby = (A.y1 - A.y0 + 3) / 4;
     const int nblocks = nbx * nby;
+    const size_t lds = (RFX_K1_LDS && stage != 2) ? (size_t)A.cells_vec4 * 16 : 0;
     dim3 block(64, 4), grid(((nblocks + 7) / 8) * 8);
     const float *P = A.p.camera.projectionMatrix;
     const bool persp = P[1] == 0.f && P[2] == 0.f && P[3] == 0.f && P[4] == 0.f && P[6] == 0.f && P[7] == 0.f && P[12] == 0.f && P[13] == 0.f &&
@@ -601,8 +671,8 @@ hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
     const bool env = A.p.useEnvMap != 0, mis = env && A.p.importanceSampling != 0;
 #define K1_GO(P, E, M)                                                                                   \
     do {                                                                                                 \
-        if (stage == 0) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 0>), grid, block, 0, stream, A);      \
-        else if (stage == 1) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 1>), grid, block, 0, stream, A); \
+        if (stage == 0) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 0>), grid, block, lds, stream, A);      \
+        else if (stage == 1) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 1>), grid, block, lds, stream, A); \
         else hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 2>), grid, block, 0, stream, A);                 \
     } while (0)
     if (persp) { if (mis) K1_GO(true, true, true); else if (env) K1_GO(true, true, false); else K1_GO(true, false, false); }

@@ -26,7 +26,8 @@ struct rfx_ctx {
     float *viewz = nullptr;    // K1 scratch: view-space Z plane (full frame)
     float4 *hits = nullptr;    // K1 trace -> shade hand-over (rfx_ssgi_trace), 2 texels per SSGI texel
     bool hits_traced = false;  // a trace is waiting for its shade
-    float2 *coarse = nullptr;  // K1 scratch: (min,max) view Z per 8x8 cell
+    float2 *coarse = nullptr;  // K1 scratch: exact (min,max) view Z per 16x16 base cell
+    unsigned int *cells = nullptr;  // K1 scratch: the march's half-packed (min,max) table
     float4 *env = nullptr;     // scene.environment: the whole mip chain, float4 texels
     float *env_marginal = nullptr, *env_conditional = nullptr;  // EquirectHdrInfo inverse-CDF tables (importanceSampling)
     float env_sum_whole = 1.0f, env_sum_decimal = 0.0f;
@@ -117,6 +118,7 @@ void rfx_destroy(rfx_ctx *c) {
     if (c->viewz) hipFree(c->viewz);
     if (c->hits) hipFree(c->hits);
     if (c->coarse) hipFree(c->coarse);
+    if (c->cells) hipFree(c->cells);
     if (c->env) hipFree(c->env);
     if (c->env_marginal) hipFree(c->env_marginal);
     if (c->env_conditional) hipFree(c->env_conditional);
@@ -470,15 +472,26 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
     A.nearMulFar = (float)((double)p->camera.near_ * (double)p->camera.far_);
     A.farMinusNear = (float)((double)p->camera.far_ - (double)p->camera.near_);
     A.nearMinusFar = (float)((double)p->camera.near_ - (double)p->camera.far_);
-    A.coarse_w = (c->W + 7) / 8;
-    A.coarse_h = (c->H + 7) / 8;
+    const int base = rfx_k1_base_cell();
+    A.coarse_w = (c->W + base - 1) / base;
+    A.coarse_h = (c->H + base - 1) / base;
+    // the march's table is kept L1-sized: double the cell edge until it is <= 32 KiB (4K: 32-texel cells, 31.9 KiB)
+    static const int lds_budget = getenv("RFX_K1_TABLE_BYTES") ? atoi(getenv("RFX_K1_TABLE_BYTES")) : 32768;
+    for (A.cell_shift = 4;; A.cell_shift++) {
+        A.cells_w = (c->W + (1 << A.cell_shift) - 1) >> A.cell_shift;
+        A.cells_h = (c->H + (1 << A.cell_shift) - 1) >> A.cell_shift;
+        A.cells_vec4 = (A.cells_w * A.cells_h + 3) / 4;
+        if ((size_t)A.cells_vec4 * 16 <= (size_t)lds_budget || A.cell_shift >= 12) break;
+    }
     if (!c->viewz) {
         hipError_t e = hipMalloc((void **)&c->viewz, (size_t)c->W * c->H * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&c->coarse, (size_t)A.coarse_w * A.coarse_h * sizeof(float2));
+        if (e == hipSuccess) e = hipMalloc((void **)&c->cells, (size_t)A.cells_vec4 * 16);
         if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(K1 scratch)", e);
     }
     A.viewz = c->viewz;
     A.coarse = c->coarse;
+    A.cells = c->cells;
     static const int no_coarse = getenv("RFX_K1_NO_COARSE") ? atoi(getenv("RFX_K1_NO_COARSE")) : 0;
     A.use_coarse = !no_coarse;
     // band-per-XCD mapping measured SLOWER (1.33 vs 0.99 ms at 4K): sky bands finish early and idle their XCD

@@ -16,8 +16,10 @@ struct K1Args {
     rfx_ssgi_params p;
     float nearMulFar, farMinusNear, nearMinusFar;
     float *viewz;    // full-frame view-space Z (context scratch, filled by k1_prepare)
-    float2 *coarse;  // (min, max) view Z per 8x8 cell
+    float2 *coarse;  // exact (min, max) view Z per 16x16-texel base cell (k1_prepare)
     int coarse_w, coarse_h;
+    unsigned int *cells;  // the march's table: two halfs per 2^cell_shift-texel cell, padded to whole uint4s (k1_pack_cells)
+    int cells_w, cells_h, cell_shift, cells_vec4;
     int use_coarse;
     int xcd_map;  // band-per-XCD block mapping (development switch RFX_K1_NO_XCD=1 turns it off)
     // scene.environment: all mip levels as float4 texels, level l (max(w>>l,1) x max(h>>l,1)) at env + env_off[l]
@@ -83,6 +85,7 @@ struct K5Args {
 };
 
 hipError_t rfx_launch_k5(const K5Args &, hipStream_t);
+int rfx_k1_base_cell();  // edge of k1_prepare's base cells in texels
 hipError_t rfx_launch_k1_prepare(const K1Args &, hipStream_t);
 hipError_t rfx_launch_k1(const K1Args &, int stage /* 0 fused, 1 trace, 2 shade */, hipStream_t);
 hipError_t rfx_launch_k2(const K2Args &, hipStream_t);

@@ -58,3 +58,7 @@ for name, fn, bpp in stages:
     if not name.startswith("K4") and not name.startswith("K1t") and not name.startswith("K1s"): tot += ms
 print("K1+K2+2xK3: %.3f ms  -> %.1f Mpix/s; 268 B/px -> %.1f GB/s (%.1f%% of 8 TB/s)" % (tot, W * H / tot / 1e3, 268 * W * H / tot / 1e6, 268 * W * H / tot / 1e6 / 80))
 print("halo violations", ctx.halo_violations())
+if only.startswith("K1") or not only:  # variants of the exact kernel must not change a single texel
+    import hashlib
+    ctx.ssgi_march(sp)
+    print("ssgi sha1", hashlib.sha1(ctx.download(abi.TEX_SSGI).tobytes()).hexdigest()[:16])
