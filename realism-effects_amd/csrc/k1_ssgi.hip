@@ -41,8 +41,8 @@ RFX_DEV uint32_t k1_half_toward(float v, bool up) {  // nearest half not below (
     return h;
 }
 RFX_DEV k1_cell_t k1_cell_pack(float mn, float mx) { return k1_half_toward(mn, false) | (k1_half_toward(mx, true) << 16); }
-RFX_DEV float2 k1_cell_load(const k1_cell_t *t, int i) {
-    const uint32_t v = t[i];
+RFX_DEV float2 k1_cell_load(const k1_cell_t *t, unsigned int i) {
+    const uint32_t v = rfx_gather<uint32_t>(t, i);
     return make_float2(rfx_h2f((unsigned short)(v & 0xffffu)), rfx_h2f((unsigned short)(v >> 16)));
 }
 
@@ -83,14 +83,14 @@ RFX_DEV float2 k1_project(const MarchCtx &m, float3 p) {
 }
 
 struct Tap {
-    int idx;     // texel index into the view-Z plane
-    int cell;    // index into the coarse table
+    unsigned int idx;   // texel index into the view-Z plane (32-bit byte offsets from the wave-uniform base: the plane is < 4 GiB)
+    unsigned int cell;  // index into the (min, max) table
 };
 RFX_DEV Tap k1_tap(const MarchCtx &m, const FrameDims &d, float2 uv) {
     const int xi = rfx_nearest_idx(uv.x, d.fW, d.W), yi = rfx_nearest_idx(uv.y, d.fH, d.H);
     Tap t;
-    t.idx = yi * d.W + xi;
-    t.cell = (yi >> m.cell_shift) * m.coarse_w + (xi >> m.cell_shift);
+    t.idx = (unsigned int)(__mul24(yi, d.W) + xi);  // rows and widths are < 2^23: the full-rate 24-bit multiply-add
+    t.cell = (unsigned int)(__mul24(yi >> m.cell_shift, m.coarse_w) + (xi >> m.cell_shift));
     return t;
 }
 // RayMarch (:441-475) + BinarySearch (:477-503) for the pixel's TWO rays at once (slot 0 = optional diffuse ray,
@@ -143,7 +143,7 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         }
         float z[2];
 #pragma unroll
-        for (int r = 0; r < 2; r++) z[r] = need[r] ? m.viewz[tap[r].idx] : 0.0f;
+        for (int r = 0; r < 2; r++) z[r] = need[r] ? rfx_gather<float>(m.viewz, tap[r].idx) : 0.0f;
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const float diff = z[r] - rays[r].pos.z;
@@ -187,7 +187,7 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
             }
             float z[2];
 #pragma unroll
-            for (int r = 0; r < 2; r++) z[r] = need[r] ? m.viewz[tap[r].idx] : 0.0f;
+            for (int r = 0; r < 2; r++) z[r] = need[r] ? rfx_gather<float>(m.viewz, tap[r].idx) : 0.0f;
 #pragma unroll
             for (int r = 0; r < 2; r++)
                 if (rays[r].hit) {

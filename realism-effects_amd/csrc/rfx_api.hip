@@ -74,6 +74,11 @@ rfx_ctx *rfx_create(int device, int width, int height, int tile_y0, int tile_row
         fail(nullptr, RFX_EINVAL, "rfx_create: bad geometry");
         return nullptr;
     }
+    // kernels address texels with 24-bit multiplies and 32-bit byte offsets: a plane stays < 4 GiB (16K x 16K RGBA32F)
+    if (width > 32768 || height > 32768 || (size_t)width * height > ((size_t)1 << 28)) {
+        fail(nullptr, RFX_EINVAL, "rfx_create: frames above 32768 in an edge or 2^28 texels are not supported");
+        return nullptr;
+    }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || device < 0 || device >= ndev) {

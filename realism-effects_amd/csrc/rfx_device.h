@@ -46,8 +46,9 @@ RFX_DEV void rfx_flush_violations(const FrameDims &d) {
 // NaN and |c| >= 2^31 give INT_MIN -> texel 0 (AMD's v_cvt_i32_f32 would saturate to size-1).
 RFX_DEV int rfx_nearest_idx(float u, float fsize, int size) {
     float c = u * fsize;
-    int i = (c < 2147483648.0f) ? max((int)c, 0) : 0; // NaN compares false -> 0
-    return min(i, size - 1);
+    c = (c < 2147483648.0f) ? c : 0.0f;  // NaN compares false -> 0
+    // clamp in float, then truncate: the same index as max((int)c, 0) then min(.., size - 1) for every finite c (size <= 2^24)
+    return (int)__builtin_amdgcn_fmed3f(c, 0.0f, (float)(size - 1));
 }
 
 RFX_DEV size_t rfx_texel_index(const FrameDims &d, int row0, int rows, float u, float v) {
