@@ -53,7 +53,6 @@ struct MarchCtx {
     int coarse_w, cell_shift;
     float rayDistance, thickness;
     int steps, refineSteps;
-    bool use_coarse;
 };
 
 // viewSpaceToScreenSpace ssgi_utils.frag:26-33.  PERSP: the projection matrix has the sparsity of a (possibly
@@ -129,17 +128,12 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         bool need[2];
 #pragma unroll
         for (int r = 0; r < 2; r++) tap[r] = k1_tap(m, d, rays[r].uv);
-        if (m.use_coarse) {
 #pragma unroll
-            for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
+        for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const float h = rays[r].pos.z;
-                need[r] = rays[r].active && !((mm[r].y - h < 0.0f) || (mm[r].x - h >= m.thickness));
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 2; r++) need[r] = rays[r].active;
+        for (int r = 0; r < 2; r++) {  // (bitwise on purpose: no short-circuit branches in the loop)
+            const float h = rays[r].pos.z;
+            need[r] = rays[r].active & !((mm[r].y - h < 0.0f) | (mm[r].x - h >= m.thickness));
         }
         float z[2];
 #pragma unroll
@@ -175,15 +169,15 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
                 need[r] = rays[r].hit;
                 behind[r] = false;
             }
-            if (m.use_coarse) {
 #pragma unroll
-                for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
+            for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
 #pragma unroll
-                for (int r = 0; r < 2; r++) {
-                    const float h = rays[r].pos.z;
-                    if (mm[r].y - h < 0.0f) need[r] = false;                               // diff < 0 everywhere in the cell
-                    else if (mm[r].x - h >= 0.0f) { need[r] = false; behind[r] = true; }   // diff >= 0 everywhere
-                }
+            for (int r = 0; r < 2; r++) {
+                const float h = rays[r].pos.z;
+                const bool below = mm[r].y - h < 0.0f;          // diff < 0 everywhere in the cell
+                const bool above = !below & (mm[r].x - h >= 0.0f);  // diff >= 0 everywhere
+                need[r] = need[r] & !(below | above);
+                behind[r] = above;
             }
             float z[2];
 #pragma unroll
@@ -419,7 +413,6 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     m.thickness = p.thickness;
     m.steps = p.steps;
     m.refineSteps = p.refineSteps;
-    m.use_coarse = A.use_coarse != 0;
 
     const float viewZ = A.viewz[(size_t)sy * d.W + sx];  // getViewZ(depth) ssgi_utils.frag:7-13, from the pre-pass
     // getViewPosition ssgi_utils.frag:17-24

@@ -497,8 +497,6 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
     A.viewz = c->viewz;
     A.coarse = c->coarse;
     A.cells = c->cells;
-    static const int no_coarse = getenv("RFX_K1_NO_COARSE") ? atoi(getenv("RFX_K1_NO_COARSE")) : 0;
-    A.use_coarse = !no_coarse;
     // band-per-XCD mapping measured SLOWER (1.33 vs 0.99 ms at 4K): sky bands finish early and idle their XCD
     static const int xcd = getenv("RFX_K1_XCD") ? atoi(getenv("RFX_K1_XCD")) : 0;
     A.xcd_map = xcd;

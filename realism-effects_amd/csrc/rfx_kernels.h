@@ -20,7 +20,6 @@ struct K1Args {
     int coarse_w, coarse_h;
     unsigned int *cells;  // the march's table: two halfs per 2^cell_shift-texel cell, padded to whole uint4s (k1_pack_cells)
     int cells_w, cells_h, cell_shift, cells_vec4;
-    int use_coarse;
     int xcd_map;  // band-per-XCD block mapping (development switch RFX_K1_NO_XCD=1 turns it off)
     // scene.environment: all mip levels as float4 texels, level l (max(w>>l,1) x max(h>>l,1)) at env + env_off[l]
     const float4 *env;
