@@ -150,14 +150,14 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
             const int ix = rfx_nearest_idx(((float)gx + 0.5f) / d.fW, (float)A.in_w, A.in_w), iy = rfx_nearest_idx(((float)gy + 0.5f) / d.fH, (float)A.in_h, A.in_h);
             t = ((const uint4 *)A.ssgi.ptr)[(size_t)iy * A.in_w + ix];
         } else {
-            t = ((const uint4 *)A.ssgi.ptr)[(size_t)rfx_local_row(d, A.ssgi.row0, A.ssgi.rows, gy) * d.W + gx];
+            t = rfx_gather<uint4>(A.ssgi.ptr, (unsigned int)(__mul24(rfx_local_row(d, A.ssgi.row0, A.ssgi.rows, gy), d.W) + gx));
         }
         // a texel that was not sampled (`!(t.r >= 0.)`) takes no part in any neighbourhood AABB (reproject.frag:66) and its
         // colour is never read as a centre texel either: stage its rgb as quiet NaNs, which v_min/v_max skip, so the
         // 25-tap loops below need no per-tap test.  .a (roughness / ray length) is kept.
         s.tex[0][i] = k2_mask_unsampled(k2_unpack<INPUT_TYPE>(t, 0));
         if (INPUT_TYPE == 0) s.tex[1][i] = k2_mask_unsampled(k2_unpack<INPUT_TYPE>(t, 1));
-        const VND vd = k2_vnd(((const uint4 *)A.velocity.ptr)[(size_t)rfx_local_row(d, A.velocity.row0, A.velocity.rows, gy) * d.W + gx]);
+        const VND vd = k2_vnd(rfx_gather<uint4>(A.velocity.ptr, (unsigned int)(__mul24(rfx_local_row(d, A.velocity.row0, A.velocity.rows, gy), d.W) + gx)));
         s.vn[i] = make_float4(vd.normal.x, vd.normal.y, vd.normal.z, vd.depth);
         s.vel[i] = make_float2(vd.vx, vd.vy);
     }
@@ -219,7 +219,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
         }
     }
     const float moveFactor = fminf((cvel.x * cvel.x + cvel.y * cvel.y) * 10000.0f, 1.0f);
-    const size_t oi = (size_t)rfx_local_row(d, A.out0.row0, A.out0.rows, y) * d.W + x;
+    const size_t oi = (size_t)(unsigned int)(__mul24(rfx_local_row(d, A.out0.row0, A.out0.rows, y), d.W) + x);
 
     // neighbourhood columns with CLAMP_TO_EDGE, as LDS offsets
     int nxo[5];
@@ -257,13 +257,13 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
             const float qnan = __builtin_nanf("");
             float3 mni = ic, mxi = ic;
             float3 mno = make_float3(qnan, qnan, qnan), mxo = mno;
-            const float4 *nt = s.tex[(INPUT_TYPE == 0 && spec) ? 1 : 0];
+            const float4 *nt = (INPUT_TYPE == 0 && spec) ? s.tex[1] : s.tex[0];
 #ifndef RFX_K2_UNROLL_Y
 #define RFX_K2_UNROLL_Y 5
 #endif
 #pragma unroll RFX_K2_UNROLL_Y
             for (int oy = 0; oy < 5; oy++) {  // one row of five 12-byte LDS reads in flight at a time keeps the kernel under 128 VGPRs
-                const int nrow = (min(max(y + oy - 2, 0), d.H - 1) - ty0 + AP) * LW;  // CLAMP_TO_EDGE row, as an LDS offset
+                const int nrow = __mul24(min(max(y + oy - 2, 0), d.H - 1) - ty0 + AP, LW);  // CLAMP_TO_EDGE row, as an LDS offset
                 const float4 t0 = nt[nrow + nxo[0]], t1 = nt[nrow + nxo[1]], t2 = nt[nrow + nxo[2]], t3 = nt[nrow + nxo[3]], t4 = nt[nrow + nxo[4]];
 #define K2_RED3(acc_mn, acc_mx, a, b)                                                                                         \
     acc_mn = make_float3(rfx_min3_raw(acc_mn.x, a.x, b.x), rfx_min3_raw(acc_mn.y, a.y, b.y), rfx_min3_raw(acc_mn.z, a.z, b.z)); \

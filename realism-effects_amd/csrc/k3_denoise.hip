@@ -71,26 +71,29 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     const uint4 *gbp = (const uint4 *)A.gbuffer.ptr;
 
     // ---- stage the tile + apron (texels outside the frame are never addressed: taps clamp to the edge first)
+    const float invLW = 1.0f / (float)LW;
     for (int i = tid; i < LW * LH; i += NT) {
-        const int ly = i / LW, lx = i - ly * LW;
+        // i / LW without the integer-division sequence: (i + 0.5) / LW is at least 0.5 / LW away from an integer, far above the
+        // rounding error of the product for these sizes (i < 2^16, LW < 2^8)
+        const int ly = (int)(((float)i + 0.5f) * invLW), lx = i - __mul24(ly, LW);
         const int gx = tx0 - Rx + lx, gy = ty0 - Ry + ly;
         // skip texels no tap of a PRODUCED pixel can address: outside the frame (taps clamp to the edge first) or
         // beyond the apron of the last produced row (the workgroup may overhang the launch's row range)
         if (gx < 0 || gx >= d.W || gy < 0 || gy >= d.H || gy > A.y1 - 1 + Ry) continue;
-        const uint4 g = gbp[(size_t)rfx_local_row(d, A.gbuffer.row0, A.gbuffer.rows, gy) * d.W + gx];
+        const uint4 g = rfx_gather<uint4>(gbp, (unsigned int)(__mul24(rfx_local_row(d, A.gbuffer.row0, A.gbuffer.rows, gy), d.W) + gx));
         const float3 n = rfx_unpack_normal(g.y);
         s_geom[i] = make_float4(n.x, n.y, n.z, rfx_decode_roughness(g.z));
-        s_depth[i] = depthp[(size_t)rfx_local_row(d, A.depth.row0, A.depth.rows, gy) * d.W + gx];
+        s_depth[i] = rfx_gather<float>(depthp, (unsigned int)(__mul24(rfx_local_row(d, A.depth.row0, A.depth.rows, gy), d.W) + gx));
 #pragma unroll
         for (int t = 0; t < TC; t++) {
             const TexView &src = t ? A.in1 : A.in0;
-            const size_t idx = (size_t)rfx_local_row(d, src.row0, src.rows, gy) * d.W + gx;
+            const unsigned int idx = (unsigned int)(__mul24(rfx_local_row(d, src.row0, src.rows, gy), d.W) + gx);
             if constexpr (IN_TEMPORAL) {
-                const float4 v = ((const float4 *)src.ptr)[idx];
+                const float4 v = rfx_gather<float4>(src.ptr, idx);
                 const float3 l = k3_log3(v.x, v.y, v.z);
                 s_in0[t * ntex + i] = make_float4(l.x, l.y, l.z, k3_luma(l));
             } else {
-                s_inN[t * ntex + i] = ((const uint2 *)src.ptr)[idx];
+                s_inN[t * ntex + i] = rfx_gather<uint2>(src.ptr, idx);
             }
         }
     }
@@ -99,13 +102,13 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     const int x = tx0 + threadIdx.x, y = ty0 + threadIdx.y;
     if (x >= d.W || y >= A.y1) return;
     const int cx = threadIdx.x + Rx, cy = threadIdx.y + Ry;  // this pixel inside the staged tile
-    const int ci = cy * LW + cx;
+    const int ci = __mul24(cy, LW) + cx;
     const float u = ((float)x + 0.5f) / d.fW, v = ((float)y + 0.5f) / d.fH;
     const float depth = s_depth[ci];
 
     // fine 2x2 quad derivatives; a partner beyond the frame edge fetches the edge texel
-    const int qx0 = cy * LW + min(x & ~1, d.W - 1) - tx0 + Rx, qx1 = cy * LW + min(x | 1, d.W - 1) - tx0 + Rx;
-    const int qy0 = (min(y & ~1, d.H - 1) - ty0 + Ry) * LW + cx, qy1 = (min(y | 1, d.H - 1) - ty0 + Ry) * LW + cx;
+    const int qx0 = __mul24(cy, LW) + min(x & ~1, d.W - 1) - tx0 + Rx, qx1 = __mul24(cy, LW) + min(x | 1, d.W - 1) - tx0 + Rx;
+    const int qy0 = __mul24(min(y & ~1, d.H - 1) - ty0 + Ry, LW) + cx, qy1 = __mul24(min(y | 1, d.H - 1) - ty0 + Ry, LW) + cx;
     {
         const float fw = fabsf(s_depth[qx1] - s_depth[qx0]) + fabsf(s_depth[qy1] - s_depth[qy0]);
         if (depth == 1.0f && fw == 0.0f) return;  // discard (:129-132): target keeps its contents
@@ -113,7 +116,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     const float4 gc = s_geom[ci];
     const float3 normal = make_float3(gc.x, gc.y, gc.z);
     const float roughness = gc.w;
-    const float glossiness = fmaxf(0.0f, 4.0f * (1.0f - roughness / 0.25f));
+    const float glossiness = fmaxf(0.0f, 4.0f * (1.0f - roughness * 4.0f));  // roughness / 0.25, exactly
     const float l2spec = -glossiness * p.specularPhi * K3_LOG2E;  // log2(specularFactor) :169
     const float lumaPhiL2 = p.lumaPhi * K3_LOG2E;
     float flatness;
@@ -132,7 +135,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         rfx_linear_coord(fu, d.fW, d.W, x0, x1, wx);
         rfx_linear_coord(fv, d.fH, d.H, y0, y1, wy);
         x0 = min(max(x0 - tx0 + Rx, 0), LW - 1); x1 = min(max(x1 - tx0 + Rx, 0), LW - 1);
-        y0 = min(max(y0 - ty0 + Ry, 0), LH - 1) * LW; y1 = min(max(y1 - ty0 + Ry, 0), LH - 1) * LW;
+        y0 = __mul24(min(max(y0 - ty0 + Ry, 0), LH - 1), LW); y1 = __mul24(min(max(y1 - ty0 + Ry, 0), LH - 1), LW);
         const uint2 *sn = s_inN + t * ntex;
         const float4 t00 = rfx_load_half4(sn[y0 + x0]), t10 = rfx_load_half4(sn[y0 + x1]);
         const float4 t01 = rfx_load_half4(sn[y1 + x0]), t11 = rfx_load_half4(sn[y1 + x1]);
@@ -153,11 +156,11 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         float4 t;
         if constexpr (IN_TEMPORAL) {
             const TexView &src = ti ? A.in1 : A.in0;
-            t = ((const float4 *)src.ptr)[(size_t)rfx_local_row(d, src.row0, src.rows, y) * d.W + x];
+            t = rfx_gather<float4>(src.ptr, (unsigned int)(__mul24(rfx_local_row(d, src.row0, src.rows, y), d.W) + x));
         } else {
             t = lds_linear(ti, u, v);
         }
-        c[i].w = 1.0f / rfx_pow(t.w + 1.0f, 1.2f * p.phi);
+        c[i].w = rfx_rcp(rfx_pow(t.w + 1.0f, 1.2f * p.phi));
         const float3 col = k3_log3(t.x * 1.0003f, t.y * 1.0003f, t.z * 1.0003f);
         c[i].rgb = col;
         c[i].a = t.w;
@@ -185,7 +188,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         const float nu = u + (m00 * ox + m10 * oy), nv = v + (m01 * ox + m11 * oy);
         const int nx = min(max(rfx_nearest_idx(nu, d.fW, d.W) - tx0 + Rx, 0), LW - 1);
         const int ny = min(max(rfx_nearest_idx(nv, d.fH, d.H) - ty0 + Ry, 0), LH - 1);
-        const int ni = ny * LW + nx;
+        const int ni = __mul24(ny, LW) + nx;
         // getBasicNeighborWeight :52-78
         const float nd = s_depth[ni];
         const float4 ng = s_geom[ni];
@@ -209,10 +212,11 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         }
     }
 
-    const size_t oi = (size_t)rfx_local_row(d, A.out0.row0, A.out0.rows, y) * d.W + x;
+    const size_t oi = (size_t)(unsigned int)(__mul24(rfx_local_row(d, A.out0.row0, A.out0.rows, y), d.W) + x);
 #pragma unroll
     for (int i = 0; i < TC; i++) {  // outputTexel :94-100
-        float3 o = make_float3(c[i].rgb.x / c[i].total, c[i].rgb.y / c[i].total, c[i].rgb.z / c[i].total);
+        const float inv = rfx_rcp(c[i].total);
+        float3 o = make_float3(c[i].rgb.x * inv, c[i].rgb.y * inv, c[i].rgb.z * inv);
         o = make_float3(rfx_exp(o.x) - 1.0f, rfx_exp(o.y) - 1.0f, rfx_exp(o.z) - 1.0f);
         ((uint2 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = rfx_store_half4(o.x, o.y, o.z, c[i].a, p.halfStoreRTZ != 0);
     }

@@ -54,7 +54,8 @@ RFX_DEV int rfx_nearest_idx(float u, float fsize, int size) {
 RFX_DEV size_t rfx_texel_index(const FrameDims &d, int row0, int rows, float u, float v) {
     int x = rfx_nearest_idx(u, d.fW, d.W);
     int y = rfx_nearest_idx(v, d.fH, d.H);
-    return (size_t)rfx_local_row(d, row0, rows, y) * d.W + x;
+    // rows and widths are < 2^23 and a plane < 2^28 texels (rfx_create): the full-rate 24-bit multiply, not a 64-bit mad
+    return (size_t)(unsigned int)(__mul24(rfx_local_row(d, row0, rows, y), d.W) + x);
 }
 
 RFX_DEV float rfx_fetch_r32f(const TexView &t, const FrameDims &d, float u, float v) {
@@ -70,7 +71,7 @@ RFX_DEV float4 rfx_fetch_f4(const TexView &t, const FrameDims &d, float u, float
 RFX_DEV size_t rfx_xy_index(const FrameDims &d, int row0, int rows, int x, int y) {
     x = min(max(x, 0), d.W - 1);
     y = min(max(y, 0), d.H - 1);
-    return (size_t)rfx_local_row(d, row0, rows, y) * d.W + x;
+    return (size_t)(unsigned int)(__mul24(rfx_local_row(d, row0, rows, y), d.W) + x);
 }
 
 // ---------------------------------------------------------------- half floats
@@ -132,7 +133,7 @@ RFX_DEV float4 rfx_fetch_h4_linear(const TexView &t, const FrameDims &d, float u
     float wx, wy;
     rfx_linear_coord(u, d.fW, d.W, x0, x1, wx);
     rfx_linear_coord(v, d.fH, d.H, y0, y1, wy);
-    const unsigned int r0 = (unsigned int)(rfx_local_row(d, t.row0, t.rows, y0) * d.W), r1 = (unsigned int)(rfx_local_row(d, t.row0, t.rows, y1) * d.W);
+    const unsigned int r0 = (unsigned int)__mul24(rfx_local_row(d, t.row0, t.rows, y0), d.W), r1 = (unsigned int)__mul24(rfx_local_row(d, t.row0, t.rows, y1), d.W);
     float4 t00 = rfx_load_half4(rfx_gather<uint2>(t.ptr, r0 + x0)), t10 = rfx_load_half4(rfx_gather<uint2>(t.ptr, r0 + x1));
     float4 t01 = rfx_load_half4(rfx_gather<uint2>(t.ptr, r1 + x0)), t11 = rfx_load_half4(rfx_gather<uint2>(t.ptr, r1 + x1));
     float4 r;
@@ -149,7 +150,7 @@ RFX_DEV float4 rfx_fetch_f4_linear(const TexView &t, const FrameDims &d, float u
     float wx, wy;
     rfx_linear_coord(u, d.fW, d.W, x0, x1, wx);
     rfx_linear_coord(v, d.fH, d.H, y0, y1, wy);
-    const unsigned int r0 = (unsigned int)(rfx_local_row(d, t.row0, t.rows, y0) * d.W), r1 = (unsigned int)(rfx_local_row(d, t.row0, t.rows, y1) * d.W);
+    const unsigned int r0 = (unsigned int)__mul24(rfx_local_row(d, t.row0, t.rows, y0), d.W), r1 = (unsigned int)__mul24(rfx_local_row(d, t.row0, t.rows, y1), d.W);
     const float4 t00 = rfx_gather<float4>(t.ptr, r0 + x0), t10 = rfx_gather<float4>(t.ptr, r0 + x1);
     const float4 t01 = rfx_gather<float4>(t.ptr, r1 + x0), t11 = rfx_gather<float4>(t.ptr, r1 + x1);
     float4 r;
