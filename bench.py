@@ -187,9 +187,10 @@ def main():
         fx.update(renderer, None)
 
     def barrier():
-        fin = getattr(renderer, "finish_pending", None)
-        if fin:  # the composed-GI all-gather of the last frame is asynchronous (tiling.py): it belongs to that frame
-            fin()
+        for name in ("finish_pending", "finish_halo"):  # the exchanges of the last frame are asynchronous (tiling.py): they belong to it
+            fin = getattr(renderer, name, None)
+            if fin:
+                fin()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

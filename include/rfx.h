@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 10
+#define RFX_ABI_VERSION 11
 
 enum {
     RFX_OK = 0,
@@ -193,6 +193,11 @@ int rfx_get_geometry(const rfx_ctx *, int *width, int *height, int *tile_y0, int
  * default stream has handle 0 == NULL and therefore cannot be selected: create a stream.  Switching drains the
  * stream used so far (its uploads and zero-fills must not race kernels on the new one): set it once, not per frame. */
 int rfx_set_stream(rfx_ctx *, void *hip_stream);
+/* Restrict the rows the following draws PRODUCE to frame rows [y0, y1) (intersected with what each draw would produce anyway);
+ * y1 <= y0 resets.  Every pixel's result is independent of how the rows are split over launches, so a row-tiled run can draw the
+ * interior of its tile while the halo rows of the input are still being exchanged, then the two boundary strips (rfx_amd/tiling.py).
+ * Draws whose window is empty return RFX_OK without launching.  Ignored by rfx_ssgi_* with resolutionScale != 1 (whole-frame only). */
+int rfx_set_row_window(rfx_ctx *, int y0, int y1);
 
 /* ---- textures.  `row0`/`rows` are FRAME rows of the band being transferred; the band must lie
  * inside the rows the context holds: [max(0,tile_y0-halo), min(H,tile_y0+tile_rows+halo)).

@@ -26,6 +26,7 @@ struct rfx_ctx {
     float *viewz = nullptr;    // K1 scratch: view-space Z plane (full frame)
     float4 *hits = nullptr;    // K1 trace -> shade hand-over (rfx_ssgi_trace), 2 texels per SSGI texel
     bool hits_traced = false;  // a trace is waiting for its shade
+    int win_y0 = 0, win_y1 = 0x7fffffff;  // rfx_set_row_window: rows the draws may produce
     float2 *coarse = nullptr;  // K1 scratch: exact (min,max) view Z per 16x16 base cell
     unsigned int *cells = nullptr;  // K1 scratch: the march's half-packed (min,max) table
     float4 *env = nullptr;     // scene.environment: the whole mip chain, float4 texels
@@ -154,6 +155,13 @@ int rfx_set_stream(rfx_ctx *c, void *hip_stream) {
     return RFX_OK;
 }
 
+int rfx_set_row_window(rfx_ctx *c, int y0, int y1) {
+    if (!c) return RFX_EINVAL;
+    if (y1 <= y0) { c->win_y0 = 0; c->win_y1 = 0x7fffffff; }  // reset
+    else { c->win_y0 = y0; c->win_y1 = y1; }
+    return RFX_OK;
+}
+
 int rfx_tex_held_rows(const rfx_ctx *c, rfx_tex id, int *row0, int *rows) {
     if (!c || id < 0 || id >= RFX_TEX_COUNT) return RFX_EINVAL;
     if (row0) *row0 = c->slots[id].row0;
@@ -278,12 +286,15 @@ static void blue_noise_shift(int index, int *sx, int *sy) {
 
 // Rows a launch produces: the tile, widened by `extra` rows on each side (clipped to what the
 // output slot holds).
-static void launch_rows(rfx_ctx *c, int out_id, int extra, int *y0, int *y1) {
+static bool launch_rows(rfx_ctx *c, int out_id, int extra, int *y0, int *y1) {
     const Slot &s = c->slots[out_id];
     int a = c->tile_y0 - extra, b = c->tile_y0 + c->tile_rows + extra;
     if (a < s.row0) a = s.row0;
     if (b > s.row0 + s.rows) b = s.row0 + s.rows;
+    if (a < c->win_y0) a = c->win_y0;  // rfx_set_row_window
+    if (b > c->win_y1) b = c->win_y1;
     *y0 = a; *y1 = b;
+    return b > a;  // false: nothing to draw
 }
 
 // stage `n` host planes (floats per texel in `ch`) of a band on the device, back to back; returns the device base in *stage
@@ -456,7 +467,7 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
     K1Args A;
     A.dims = dims(c);
     // K2's neighbourhood clamp reads +-2 rows of K1's output: produce them redundantly in the halo
-    launch_rows(c, RFX_TEX_SSGI, c->halo < 2 ? c->halo : 2, &A.y0, &A.y1);
+    bool any = launch_rows(c, RFX_TEX_SSGI, c->halo < 2 ? c->halo : 2, &A.y0, &A.y1);
     A.out_w = c->W; A.out_h = c->H;
     const float rs = p->resolutionScale == 0.0f ? 1.0f : p->resolutionScale;
     if (rs != 1.0f) {  // SSGIPass.setSize :52-57
@@ -466,6 +477,7 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
         if (c->tile_y0 != 0 || c->tile_rows != c->H) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march/trace/shade: resolutionScale != 1 needs a whole-frame context");
         A.out_w = (int)fw; A.out_h = (int)fh;
         A.y0 = 0; A.y1 = A.out_h;
+        any = true;  // whole-frame contexts only: the row window does not apply to the scaled target
     }
     A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER); A.direct = view(c, RFX_TEX_DIRECT_LIGHT);
     A.history = view(c, hist);
@@ -524,7 +536,7 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
     }
     // the pre-pass runs on EVERY draw: the depth plane is an input that changes every frame (the shade stage reuses the trace's)
     if (stage != 2) HIPCHK(c, rfx_launch_k1_prepare(A, c->stream));
-    HIPCHK(c, rfx_launch_k1(A, stage, c->stream));
+    if (any) HIPCHK(c, rfx_launch_k1(A, stage, c->stream));
     c->hits_traced = stage == 1;
     return RFX_OK;
 }
@@ -550,7 +562,7 @@ int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
     if (!c->slots[RFX_TEX_VELOCITY].uploaded) return fail(c, RFX_ESTATE, "rfx_temporal_reproject: velocity not uploaded");
     K2Args A;
     A.dims = dims(c);
-    launch_rows(c, RFX_TEX_TEMPORAL0, 0, &A.y0, &A.y1);
+    if (!launch_rows(c, RFX_TEX_TEMPORAL0, 0, &A.y0, &A.y1)) return RFX_OK;
     A.ssgi = view(c, RFX_TEX_SSGI); A.velocity = view(c, RFX_TEX_VELOCITY);
     A.hist0 = view(c, h0);
     A.hist1 = view(c, h1);
@@ -586,7 +598,7 @@ int rfx_copy_framebuffer(rfx_ctx *c, rfx_tex dst) {
     int rc = need(c, ids, 2);
     if (rc) return rc;
     int y0, y1;
-    launch_rows(c, dst, 0, &y0, &y1);
+    if (!launch_rows(c, dst, 0, &y0, &y1)) return RFX_OK;
     HIPCHK(c, rfx_launch_copy_fb(dims(c), y0, y1, view(c, RFX_TEX_TEMPORAL0), wview(c, dst), dst == RFX_TEX_FBCOPY_F16, c->stream));
     return RFX_OK;
 }
@@ -606,7 +618,7 @@ int rfx_poisson_denoise(rfx_ctx *c, const rfx_denoise_params *p) {
         return fail(c, RFX_ESTATE, "rfx_poisson_denoise: depth / gbuffer / blue-noise not uploaded");
     K3Args A;
     A.dims = dims(c);
-    launch_rows(c, out0, 0, &A.y0, &A.y1);
+    if (!launch_rows(c, out0, 0, &A.y0, &A.y1)) return RFX_OK;
     A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER);
     A.in0 = view(c, in0);
     A.in1 = view(c, p->textureCount == 2 ? in1 : in0);  // `#define inputTexture2 inputTexture` (poisson_denoise.frag:30-32)
@@ -635,6 +647,7 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
     launch_rows(c, RFX_TEX_COMPOSE, 0, &A.y0, &A.y1);
     if (A.y0 < c->tile_y0) A.y0 = c->tile_y0;  // COMPOSE is held whole: write only the tile
     if (A.y1 > c->tile_y0 + c->tile_rows) A.y1 = c->tile_y0 + c->tile_rows;
+    const bool any = A.y1 > A.y0;
     A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER);
     A.gi0 = view(c, g0); A.gi1 = view(c, g1);
     A.scene = view(c, RFX_TEX_DIRECT_LIGHT);  // Denoiser.js:101-103: sceneTexture = the composer's input buffer
@@ -646,7 +659,7 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
         A.rgb_out = (float *)c->slots[RFX_TEX_COMPOSE_RGB].ptr;  // held whole, like COMPOSE: frame row y at y * W
     }
     A.p = *p;
-    HIPCHK(c, rfx_launch_k4(A, c->stream));
+    if (any) HIPCHK(c, rfx_launch_k4(A, c->stream));
     return RFX_OK;
 }
 
@@ -661,7 +674,7 @@ int rfx_final_compose(rfx_ctx *c, const rfx_final_params *p) {
     if (rc) return rc;
     K5Args A;
     A.dims = dims(c);
-    launch_rows(c, RFX_TEX_FINAL, 0, &A.y0, &A.y1);
+    if (!launch_rows(c, RFX_TEX_FINAL, 0, &A.y0, &A.y1)) return RFX_OK;
     A.depth = view(c, RFX_TEX_DEPTH); A.gi = view(c, src); A.scene = view(c, RFX_TEX_DIRECT_LIGHT);
     A.out = wview(c, RFX_TEX_FINAL);
     A.p = *p;

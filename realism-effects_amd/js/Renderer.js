@@ -131,6 +131,10 @@ class Renderer {
 	ssgiMarch(uniforms) {
 		addon.ssgiMarch(this._h, uniforms)
 	}
+	// restrict the rows the following draws produce to [y0, y1); no arguments resets (rfx_set_row_window)
+	setRowWindow(y0, y1) {
+		addon.setRowWindow(this._h, y0 | 0, y1 | 0)
+	}
 	// the same draw in two launches (rfx_ssgi_trace / rfx_ssgi_shade): only the second reads last frame's composed GI
 	ssgiTrace(uniforms) {
 		addon.ssgiTrace(this._h, uniforms)

@@ -370,6 +370,18 @@ static napi_value n_temporal(napi_env env, napi_callback_info info) {
 }
 
 /* copyFramebuffer(ctx, dstTex) — renderer.copyFramebufferToTexture of TemporalReprojectPass.js:198-201 */
+/* setRowWindow(ctx, y0, y1): rfx_set_row_window (y1 <= y0 resets) */
+static napi_value n_set_row_window(napi_env env, napi_callback_info info) {
+    napi_value a[3];
+    int32_t y0, y1;
+    if (!get_args(env, info, 3, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[1], &y0) || !get_int(env, a[2], &y1)) return NULL;
+    int rc = rfx_set_row_window(c, y0, y1);
+    if (rc) return throw_rfx(env, c, "rfx_set_row_window", rc);
+    return NULL;
+}
+
 static napi_value n_copy_framebuffer(napi_env env, napi_callback_info info) {
     napi_value a[2];
     int32_t tex;
@@ -500,7 +512,7 @@ static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
         {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"setEnvironmentImportance", n_set_environment_importance}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"ssgiTrace", n_ssgi_trace}, {"ssgiShade", n_ssgi_shade}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
-        {"sync", n_sync}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
+        {"sync", n_sync}, {"setRowWindow", n_set_row_window}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -167,6 +167,10 @@ class Context:
         self._chk(self.lib.rfx_download_environment(self._h, 0, None, C.byref(n)), "rfx_download_environment")
         return n.value
 
+    def set_row_window(self, y0: int = 0, y1: int = 0):
+        """Restrict the rows the following draws produce to [y0, y1); no arguments (or y1 <= y0) resets (rfx_set_row_window)."""
+        self._chk(self.lib.rfx_set_row_window(self._h, int(y0), int(y1)), "rfx_set_row_window")
+
     # -- the four draws (+ the framebuffer copy)
     def ssgi_march(self, p: abi.SsgiParams):
         self._chk(self.lib.rfx_ssgi_march(self._h, C.byref(p)), "rfx_ssgi_march")

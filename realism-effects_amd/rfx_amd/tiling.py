@@ -6,7 +6,11 @@ rows above and below and three exchange steps keep them current:
 
   after K2 and after every K3 pass : neighbour Send/Recv of `halo` rows of the textures just
                                      written (RCCL over xGMI; message = halo*W*texel bytes per
-                                     texture and direction — latency-bound)
+                                     texture and direction — latency-bound).
+                                     Issued asynchronously: the next draw (K3 pass, K4) first
+                                     produces the INTERIOR of the tile — rows whose taps stay
+                                     inside the tile's own rows — through rfx_set_row_window,
+                                     waits for the halo rows, then draws the two boundary strips
   after K4                         : all-gather of the composed GI tile rows (next frame's K1
                                      gathers it anywhere on screen) — of its .rgb, which is all K1
                                      reads, kept by K4 as 12-byte texels in RFX_TEX_COMPOSE_RGB.  It is the one big message
@@ -71,6 +75,9 @@ class TiledRenderer:
         self.tile_y0, self.tile_rows, self.halo = inner.tile_y0, inner.tile_rows, inner.halo
         self.exchange_count = 0
         self._pending = []  # (works, tensor) of the composed-GI all-gather in flight
+        self._halo_pending = []  # (works, tensor) of halo Send/Recvs in flight
+        # draws overlap the halo exchange of their input (interior first) when the tile renderer can window its launches
+        self.overlap_halo_exchange = world > 1 and hasattr(inner, "set_row_window")
         # effect.SSGIPass splits K1 into trace + shade around before_ssgi_shade() when this is set
         self.overlap_history_gather = world > 1 and hasattr(inner, "ssgi_trace")
         # K1 reads only .rgb of the composed GI: when the RGB twin is bound, K4 keeps it and IT is gathered (12 B/px instead of 16)
@@ -87,13 +94,64 @@ class TiledRenderer:
         self.finish_pending()
         return self.inner.ssgi_march(p)
 
+    # K2 gathers its history (exchanged at the end of the previous frame) at vUv - velocity: anywhere within the halo
+    def temporal_reproject(self, p):
+        self.finish_halo()
+        return self.inner.temporal_reproject(p)
+
+    def copy_framebuffer(self, dst):
+        self.finish_halo()
+        return self.inner.copy_framebuffer(dst)
+
+    # K3 passes and K4 read the textures whose halo rows may still be in flight: interior first
+    def poisson_denoise(self, p):
+        return self._interior_first(lambda: self.inner.poisson_denoise(p))
+
+    def compose(self, p):
+        return self._interior_first(lambda: self.inner.compose(p))
+
+    def final_compose(self, p):
+        self.finish_halo()
+        return self.inner.final_compose(p)
+
+    def _interior_first(self, draw):
+        if not self._halo_pending:
+            return draw()
+        y0, y1, h = self.tile_y0, self.tile_y0 + self.tile_rows, self.halo
+        lo = y0 + (h if self.rank > 0 else 0)               # rows below `lo` / from `hi` on may read the halo rows
+        hi = y1 - (h if self.rank < self.world - 1 else 0)
+        if not self.overlap_halo_exchange or hi <= lo:
+            self.finish_halo()
+            return draw()
+        try:
+            self.inner.set_row_window(lo, hi)
+            draw()
+            self.finish_halo()
+            if lo > y0:
+                self.inner.set_row_window(y0, lo)
+                draw()
+            if hi < y1:
+                self.inner.set_row_window(hi, y1)
+                draw()
+        finally:
+            self.inner.set_row_window(0, 0)
+
     def download(self, *a, **k):
         self.finish_pending()
+        self.finish_halo()
         return self.inner.download(*a, **k)
 
     def sync(self):
         self.finish_pending()
+        self.finish_halo()
         return self.inner.sync()
+
+    def finish_halo(self):
+        pending, self._halo_pending = self._halo_pending, []
+        for works, tensor in pending:
+            for w in works:
+                w.wait()
+            self._sync_after_comm(tensor)
 
     def finish_pending(self):
         pending, self._pending = self._pending, []
@@ -134,11 +192,12 @@ class TiledRenderer:
             if down >= 0:
                 ops.append(dist.P2POp(dist.isend, t[lo:lo + h], down, self.group))
                 ops.append(dist.P2POp(dist.irecv, t[lo - h:lo], down, self.group))
+        self.finish_halo()  # one exchange in flight at a time (and the same order on every rank)
         self._sync_before_comm()
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-        self._sync_after_comm(self.tensors[texs[0]])
+        self._halo_pending.append((dist.batch_isend_irecv(ops), self.tensors[texs[0]]))
         self.exchange_count += 1
+        if not self.overlap_halo_exchange:
+            self.finish_halo()
 
     def allgather_compose(self):
         if self.world == 1:

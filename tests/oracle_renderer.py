@@ -54,7 +54,12 @@ class OracleRenderer:
 
     def _rows(self, extra=0):
         b0, n = self.held_rows(abi.TEX_SSGI)
-        return max(b0, self.tile_y0 - extra), min(b0 + n, self.tile_y0 + self.tile_rows + extra)
+        w0, w1 = getattr(self, "_window", (0, 1 << 30))
+        return max(b0, self.tile_y0 - extra, w0), min(b0 + n, self.tile_y0 + self.tile_rows + extra, w1)
+
+    def set_row_window(self, y0=0, y1=0):
+        self.calls.append(("set_row_window", y0, y1))
+        self._window = (y0, y1) if y1 > y0 else (0, 1 << 30)
 
     def pack_gbuffer(self, aov, depth=None, row0=None, rows=None):
         h0, hn = self.held_rows(abi.TEX_GBUFFER)
@@ -113,6 +118,8 @@ class OracleRenderer:
         src = t[abi.TEX_SSGI]
         if p.inputWidth:
             src = src.reshape(-1)[:p.inputHeight * p.inputWidth * 4].reshape(p.inputHeight, p.inputWidth, 4)
+        if self._rows()[1] <= self._rows()[0]:
+            return
         O.temporal(src, t[abi.TEX_VELOCITY], h0, h1, p, t[abi.TEX_TEMPORAL0], t[abi.TEX_TEMPORAL1], rows=self._rows())
 
     def copy_framebuffer(self, dst):
@@ -136,12 +143,16 @@ class OracleRenderer:
         o0, o1 = (t[abi.TEX_DENOISE_B0], t[abi.TEX_DENOISE_B1]) if p.writeToB else (t[abi.TEX_DENOISE_A0], t[abi.TEX_DENOISE_A1])
         if p.textureCount == 1:
             i1 = i0
+        if self._rows()[1] <= self._rows()[0]:
+            return
         O.denoise(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], i0, i1, t[abi.TEX_BLUE_NOISE], p, o0, o1, rows=self._rows())
 
     def compose(self, p):
         self.calls.append(("compose",))
         t = self.tex
         g0, g1 = (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1) if p.giSource else (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1)
+        if self._rows()[1] <= self._rows()[0]:
+            return
         O.compose(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], t[g0], t[g1], p, out=t[abi.TEX_COMPOSE], rows=self._rows(),
                   scene=t[abi.TEX_DIRECT_LIGHT])
         if p.writeHistoryRGB:

@@ -982,3 +982,50 @@ def test_rgb_history_twin_matches_composed_gi(blue_noise):
     ctx.ssgi_shade(sp)
     assert np.array_equal(ctx.download(abi.TEX_SSGI), want)
     ctx.close()
+
+
+def test_row_windowed_draws_are_bit_identical(blue_noise):
+    """rfx_set_row_window: a draw split into interior + two boundary strips (what a row tile does while its halo rows are still in
+    flight) leaves exactly the texels the single launch leaves, for every kernel; an empty window draws nothing."""
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_frame
+
+    W, H = 256, 144
+    f0, f = synthetic_frame(W, H, 0), synthetic_frame(W, H, 1)
+    sp, tp, dp, cp = _params(abi, f, f0.camera, 1.0, 12, 3)
+    sp.blueNoiseIndex, dp.blueNoiseIndex = 5, 9
+    ctx = Context(W, H, tile_y0=40, tile_rows=64, halo_rows=8)
+    ctx.upload_frame(f)
+    rs = np.random.RandomState(3)
+    ctx.upload(abi.TEX_COMPOSE, rs.rand(H, W, 4).astype(np.float32))
+    for t in (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1):
+        b0, n = ctx.held_rows(t)
+        ctx.upload(t, (rs.rand(n, W, 4).astype(np.float32) * 3).astype(np.float16).view(np.uint16))
+
+    def k3(i):
+        dp.inputIsTemporal, dp.writeToB = (1, 0) if i == 0 else (0, 1)
+        ctx.poisson_denoise(dp)
+
+    draws = [("K1", lambda: ctx.ssgi_march(sp), (abi.TEX_SSGI,)), ("K2", lambda: ctx.temporal_reproject(tp), (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1)),
+             ("K3p0", lambda: k3(0), (abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1)), ("K3p1", lambda: k3(1), (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1)),
+             ("K4", lambda: ctx.compose(cp), (abi.TEX_COMPOSE,))]
+    for name, draw, outs in draws:
+        before = {t: ctx.download(t) for t in outs}
+        draw()
+        want = {t: ctx.download(t) for t in outs}
+        assert any((want[t] != before[t]).any() for t in outs), name
+        for t in outs:  # put the previous contents back (K3 p1 / K4 overwrite textures that are ALSO inputs of earlier draws' history)
+            ctx.upload(t, before[t])
+        ctx.set_row_window(10, 20)  # outside the tile: nothing is drawn
+        draw()
+        for t in outs:
+            assert np.array_equal(ctx.download(t), before[t]), name + " drew outside its window"
+        for y0, y1 in ((48, 96), (38, 48), (96, 106)):  # K1 also produces the +-2 rows K2's clamp reads; the others clip to the tile
+            ctx.set_row_window(y0, y1)
+            draw()
+        ctx.set_row_window()
+        for t in outs:
+            assert np.array_equal(ctx.download(t), want[t]), "%s: windowed != whole" % name
+    assert ctx.halo_violations() == 0
+    ctx.close()

@@ -61,6 +61,9 @@ def _worker(rank, world, port, outdir):
     assert r.gather_history_rgb and r.overlap_history_gather and sum(1 for c in inner.calls if c[0] == "ssgi_trace") == FRAMES
     assert len(r._pending) == 1
     r.finish_pending()
+    # the halo exchanges are asynchronous too: K3 passes and K4 drew their interior first (windowed launches), then the boundary strips
+    assert r.overlap_halo_exchange and sum(1 for c in inner.calls if c[0] == "set_row_window") >= FRAMES * 3 * 3
+    r.finish_halo()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), y0=y0, rows=rows, halo=halo,
              **{abi.TEX_NAMES[t]: inner.tex[t][y0:y0 + rows] for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0,
                                                                      abi.TEX_DENOISE_B1)},
@@ -71,6 +74,7 @@ def _worker(rank, world, port, outdir):
     r2 = tiling.TiledRenderer(inner2, {abi.TEX_FBCOPY_F16: torch.from_numpy(inner2.tex[abi.TEX_FBCOPY_F16][b0:b0 + n])}, rank, world)
     _traa(r2, types.SimpleNamespace(frame=None), types.SimpleNamespace(**vars(frames[0].camera)), frames)
     assert r2.exchange_count == FRAMES
+    r2.finish_halo()
     np.save(os.path.join(outdir, "traa%d.npy" % rank), inner2.tex[abi.TEX_TEMPORAL0][y0:y0 + rows])
     dist.barrier()
     dist.destroy_process_group()
