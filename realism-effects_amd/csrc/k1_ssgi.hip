@@ -115,12 +115,23 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
     for (int i = 1; i < m.steps && (rays[0].active || rays[1].active); i++) {
         const float t = (float)i + random_b - 0.5f;
         const float cs = 1.0f - rfx_exp(-0.25f * (t * t));
+#ifndef RFX_K1_UNCOND
+#define RFX_K1_UNCOND 1  // measured 0.654 vs 0.666 ms at 4K, same texels
+#endif
 #pragma unroll
-        for (int r = 0; r < 2; r++)
+        for (int r = 0; r < 2; r++) {
+#if RFX_K1_UNCOND
+            // straight-line: a stopped ray keeps its position (select) and re-derives the same uv — no exec-mask region per ray
+            const float3 np = rays[r].pos + rays[r].dir * cs;
+            rays[r].pos = make_float3(rays[r].active ? np.x : rays[r].pos.x, rays[r].active ? np.y : rays[r].pos.y, rays[r].active ? np.z : rays[r].pos.z);
+            rays[r].uv = k1_project<PERSP>(m, rays[r].pos);
+#else
             if (rays[r].active) {
                 rays[r].pos = rays[r].pos + rays[r].dir * cs;
                 rays[r].uv = k1_project<PERSP>(m, rays[r].pos);
             }
+#endif
+        }
         // taps of both rays in flight together: the two coarse cells first, then the exact texels of the cells that cannot
         // rule a hit out (a hit needs 0 <= z - h < thickness; the cell range rules it out when max - h < 0 or min - h >= thickness)
         Tap tap[2];

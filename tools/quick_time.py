@@ -62,3 +62,6 @@ if only.startswith("K1") or not only:  # variants of the exact kernel must not c
     import hashlib
     ctx.ssgi_march(sp)
     print("ssgi sha1", hashlib.sha1(ctx.download(abi.TEX_SSGI).tobytes()).hexdigest()[:16])
+if not only:
+    for _, fn, _b in stages: fn()
+    print("b0 sha1", hashlib.sha1(ctx.download(abi.TEX_DENOISE_B0).tobytes()).hexdigest()[:16], "compose sha1", hashlib.sha1(ctx.download(abi.TEX_COMPOSE).tobytes()).hexdigest()[:16])
