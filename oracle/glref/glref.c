@@ -108,6 +108,7 @@ static void (*pDeleteTextures)(GLsizei, const GLuint *);
 typedef struct {
     GLuint id;
     int w, h, fmt;
+    int cube; /* 1: GL_TEXTURE_CUBE_MAP (sampler binding only; never a render target) */
 } tex_t;
 typedef struct {
     GLuint id;
@@ -268,6 +269,58 @@ int glref_texture(int w, int h, int fmt, int linear, int repeat, const void *dat
     return g_ntex++;
 }
 
+/* A cube map for `uniform samplerCube` (CubeToEquirectEnvPass.js:28): six size x size faces in GL order +X -X +Y -Y +Z -Z, back to
+ * back in `data`, each row 0 first as handed to glTexImage2D.  filter: 0 NEAREST, 1 LINEAR (no mip chain),
+ * 2 LINEAR_MIPMAP_LINEAR + LINEAR with glGenerateMipmap (three's CubeTexture default), 3 the same filters with NO generation: the
+ * caller uploads every level (glref_cube_upload_level; probes).  ES 3 contexts filter cube maps seamlessly. */
+int glref_cube_texture(int size, int fmt, int filter, const void *data) {
+    if (g_ntex >= MAX_TEX) return -1;
+    GLint internal; GLenum format, type;
+    fmt_to_gl(fmt, &internal, &format, &type);
+    const size_t texel = fmt == FMT_RGBA32F ? 16 : (fmt == FMT_RGBA16F ? 8 : (fmt == FMT_R32F ? 4 : 4));
+    GLuint t;
+    pGenTextures(1, &t);
+    pActiveTexture(GL_TEXTURE0 + 31);
+    pBindTexture(GL_TEXTURE_CUBE_MAP, t);
+    for (int f = 0; f < 6; f++)
+        pTexImage2D(GL_TEXTURE_CUBE_MAP_POSITIVE_X + f, 0, internal, size, size, 0, format, type, (const char *)data + (size_t)f * size * size * texel);
+    pTexParameteri(GL_TEXTURE_CUBE_MAP, GL_TEXTURE_MIN_FILTER, filter == 0 ? GL_NEAREST : (filter == 1 ? GL_LINEAR : GL_LINEAR_MIPMAP_LINEAR));
+    pTexParameteri(GL_TEXTURE_CUBE_MAP, GL_TEXTURE_MAG_FILTER, filter == 0 ? GL_NEAREST : GL_LINEAR);
+    pTexParameteri(GL_TEXTURE_CUBE_MAP, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
+    pTexParameteri(GL_TEXTURE_CUBE_MAP, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
+    if (filter == 2) pGenerateMipmap(GL_TEXTURE_CUBE_MAP);
+    g_tex[g_ntex].id = t; g_tex[g_ntex].w = size; g_tex[g_ntex].h = size; g_tex[g_ntex].fmt = fmt; g_tex[g_ntex].cube = 1;
+    return pGetError() ? -(int)pGetError() - 100 : g_ntex++;
+}
+
+/* One mip level of one face (level size = max(size >> level, 1)). */
+int glref_cube_upload_level(int tex, int face, int level, const void *data) {
+    tex_t *T = &g_tex[tex];
+    GLint internal; GLenum format, type;
+    fmt_to_gl(T->fmt, &internal, &format, &type);
+    int w = T->w >> level;
+    if (w < 1) w = 1;
+    pActiveTexture(GL_TEXTURE0 + 31);
+    pBindTexture(GL_TEXTURE_CUBE_MAP, T->id);
+    pTexImage2D(GL_TEXTURE_CUBE_MAP_POSITIVE_X + face, level, internal, w, w, 0, format, type, data);
+    return (int)pGetError();
+}
+
+/* Read one face / level back as RGBA float32. */
+int glref_cube_read(int tex, int face, int level, float *out) {
+    tex_t *T = &g_tex[tex];
+    int w = T->w >> level;
+    if (w < 1) w = 1;
+    pBindFramebuffer(GL_FRAMEBUFFER, g_rfbo);
+    pFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_CUBE_MAP_POSITIVE_X + face, T->id, level);
+    pReadBuffer(GL_COLOR_ATTACHMENT0);
+    GLenum st = pCheckFramebufferStatus(GL_FRAMEBUFFER);
+    if (st != GL_FRAMEBUFFER_COMPLETE) return -(int)st;
+    pReadPixels(0, 0, w, w, GL_RGBA, GL_FLOAT, out);
+    pFramebufferTexture2D(GL_FRAMEBUFFER, GL_COLOR_ATTACHMENT0, GL_TEXTURE_2D, 0, 0);
+    return (int)pGetError();
+}
+
 int glref_tex_upload(int tex, const void *data) {
     tex_t *T = &g_tex[tex];
     GLint internal; GLenum format, type;
@@ -374,7 +427,7 @@ int glref_draw(int prog, const int *targets, int ntargets) {
     pUseProgram(P->id);
     for (int i = 0; i < P->nsamp; i++) {
         pActiveTexture(GL_TEXTURE0 + i);
-        pBindTexture(GL_TEXTURE_2D, g_tex[P->samp_tex[i]].id);
+        pBindTexture(g_tex[P->samp_tex[i]].cube ? GL_TEXTURE_CUBE_MAP : GL_TEXTURE_2D, g_tex[P->samp_tex[i]].id);
         pUniform1i(P->samp_loc[i], i);
     }
     pBindFramebuffer(GL_FRAMEBUFFER, g_fbo);
