@@ -343,15 +343,26 @@ class PoissonDenoisePass {
 	get texture() {
 		return [TEX.DENOISE_B0, TEX.DENOISE_B1]
 	}
-	render(renderer) {
-		for (let i = 0; i < 2 * this.iterations; i++) {
+	// composeWith: the DenoiserComposePass that runs right after this pass (Denoiser.render): its draw rides on the last denoise
+	// draw (rfx_poisson_denoise_compose) when the renderer offers that. Returns true when it did.
+	render(renderer, composeWith) {
+		const n = 2 * this.iterations
+		let composed = false
+		for (let i = 0; i < n; i++) {
 			const horizontal = i % 2 === 0
 			this.uniforms.inputIsTemporal = i === 0 ? 1 : 0
 			this.uniforms.writeToB = horizontal ? 0 : 1
 			this.uniforms.blueNoiseIndex = this.blueNoiseIndex.value
-			renderer.poissonDenoise(this.uniforms)
+			if (i === n - 1 && composeWith && renderer.poissonDenoiseCompose && composeWith.uniforms.giSource === 0) {
+				composeWith.prepare(renderer)
+				renderer.poissonDenoiseCompose(this.uniforms, composeWith.uniforms)
+				composed = true
+			} else {
+				renderer.poissonDenoise(this.uniforms)
+			}
 			if (renderer.afterDenoisePass) renderer.afterDenoisePass(i, this.uniforms)
 		}
+		return composed
 	}
 	dispose() {}
 }
@@ -373,8 +384,11 @@ class DenoiserComposePass {
 	get texture() {
 		return TEX.COMPOSE
 	}
-	render(renderer) {
+	prepare(renderer) {
 		this.uniforms.camera = cloneCamera(this._camera)
+	}
+	render(renderer) {
+		this.prepare(renderer)
 		renderer.compose(this.uniforms)
 	}
 	dispose() {}
@@ -436,9 +450,10 @@ class Denoiser {
 		if (this.isOwnVelocityDepthNormalPass) this.velocityDepthNormalPass.render(renderer)
 		this.temporalReprojectPass.render(renderer)
 		if (renderer.afterTemporalPass) renderer.afterTemporalPass()
-		if (this.denoisePass) this.denoisePass.render(renderer)
+		let composed = false
+		if (this.denoisePass) composed = this.denoisePass.render(renderer, this.denoiserComposePass)
 		if (this.denoiserComposePass) {
-			this.denoiserComposePass.render(renderer)
+			if (!composed) this.denoiserComposePass.render(renderer)
 			if (renderer.afterComposePass) renderer.afterComposePass()
 		}
 	}
