@@ -6,7 +6,7 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one frame through SSGIEffect.update(): K1 SSGI march (steps 20 / refineSteps 5) ->
-K2 temporal reprojection -> 2 x K3 Poisson denoise (denoiseIterations 1) -> K4 compose (riding on the last K3 launch), over a
+K2 temporal reprojection -> 2 x K3 Poisson denoise (denoiseIterations 1) -> K4 compose, over a
 3840x2160 synthetic G-buffer dump (seed 1234) that is ALREADY RESIDENT in HBM when the timed
 region starts.  N > 1: weak scaling — the frame keeps its 16:9 aspect and grows to N x 8.29 Mpixel
 (e.g. 7680x4320 for N = 4), is cut into N row tiles (one per GPU, 8.29 Mpixel each) which exchange
@@ -38,13 +38,12 @@ from rfx_amd.scene import AnalyticScene  # noqa: E402
 W4K, H4K = 3840, 2160
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 # algorithmic bytes per pixel per launch, reference texel formats (SURVEY.md §8d / DESIGN.md)
-# the last denoise pass and the compose pass are ONE launch (rfx_poisson_denoise_compose): 4 depth + 16 gbuffer + 2x8 in + 2x8 out + 16 composed
-BYTES_PER_PX = {"k1_ssgi_march": 68, "k2_temporal_reproject": 80, "k3_poisson_denoise_pass0": 68, "k3_pass1_plus_k4_compose": 68}
+BYTES_PER_PX = {"k1_ssgi_march": 68, "k2_temporal_reproject": 80, "k3_poisson_denoise_pass0": 68, "k3_poisson_denoise_pass1": 52, "k4_compose": 52}
 
 
 # rocprofv3 kernel-name fragments of bench.py's kernel keys (profiles/*/pmc_hbm.csv)
 PMC_KERNEL = {"k1_ssgi_march": "k1_ssgi_march", "k2_temporal_reproject": "k2_temporal_reproject", "k3_poisson_denoise_pass0": "k3_tiled<true",
-              "k3_pass1_plus_k4_compose": "k3_tiled<false"}
+              "k3_poisson_denoise_pass1": "k3_tiled<false", "k4_compose": "k4_compose"}
 
 
 def pmc_traffic(kernel_key):
@@ -226,13 +225,10 @@ def main():
 
     def k3(pass_i):
         dp.inputIsTemporal, dp.writeToB = (1, 0) if pass_i == 0 else (0, 1)
-        if pass_i == 0:
-            ctx.poisson_denoise(dp)
-        else:  # what SSGIEffect.update() issues for the last pass: denoise + compose in one launch
-            ctx.poisson_denoise_compose(dp, cp)
+        ctx.poisson_denoise(dp)
 
     kernels = [("k1_ssgi_march", lambda: ctx.ssgi_march(sp)), ("k2_temporal_reproject", lambda: ctx.temporal_reproject(tp)),
-               ("k3_poisson_denoise_pass0", lambda: k3(0)), ("k3_pass1_plus_k4_compose", lambda: k3(1))]
+               ("k3_poisson_denoise_pass0", lambda: k3(0)), ("k3_poisson_denoise_pass1", lambda: k3(1)), ("k4_compose", lambda: ctx.compose(cp))]
     iters = max(5, min(args.steps, 20))
     kms = {}
     for name, fn in kernels:
@@ -254,7 +250,7 @@ def main():
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: %dx%d (%.2f Mpixel) per GPU, steps=20 refineSteps=5 denoiseIterations=1, K1 + K2 + K3 + (K3+K4 fused) per step" % (W, Ht, W * Ht / 1e6),
+            "config": {"workload": "configs[2]: %dx%d (%.2f Mpixel) per GPU, steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step" % (W, Ht, W * Ht / 1e6),
                        "frame": "%dx%d" % (W, H), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz",
                        "parallelism": "row-tiles x%d, RCCL halo send/recv + compose all-gather (async, overlapped with the next frame's K1 trace)" % world if world > 1 else "single GPU"},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},

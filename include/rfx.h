@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 12
+#define RFX_ABI_VERSION 11
 
 enum {
     RFX_OK = 0,
@@ -270,13 +270,6 @@ int rfx_temporal_reproject(rfx_ctx *, const rfx_temporal_params *);
  * exact, as in the reference where both sides have the same type) or RFX_TEX_FBCOPY_F32. */
 int rfx_copy_framebuffer(rfx_ctx *, rfx_tex dst);
 int rfx_poisson_denoise(rfx_ctx *, const rfx_denoise_params *);
-/* The LAST PoissonDenoisePass draw (PoissonDenoisePass.js:146-147, writeToB = 1) together with DenoiserComposePass's draw
- * (DenoiserComposePass.js:133-134, giSource 0): RFX_TEX_DENOISE_B0/B1 exactly as rfx_poisson_denoise leaves them and RFX_TEX_COMPOSE
- * [+ RFX_TEX_COMPOSE_RGB] as rfx_compose would then compose them — in ONE launch when the LDS-tiled denoise kernel runs on the
- * diffuse + specular pair (the composed texel then takes the pass's own stored texel, where the separate draw re-samples target B
- * bilinearly at the pixel centre, weights (1 - e, e) with e <= 1e-7), otherwise as the two launches.  Saves the second read of
- * target B and a launch. */
-int rfx_poisson_denoise_compose(rfx_ctx *, const rfx_denoise_params *, const rfx_compose_params *);
 int rfx_compose(rfx_ctx *, const rfx_compose_params *);
 /* The effect's mainImage (src/ssgi/shader/ssgi_compose.frag:20-45), which postprocessing's EffectPass runs after
  * SSGIEffect.update(): background texels take the scene colour (RFX_TEX_DIRECT_LIGHT = the composer's input buffer),

@@ -12,7 +12,6 @@
 //   * k3_generic: one pixel per lane with direct global gathers, for radius > 3.
 // 64 consecutive pixels of a row per wavefront -> coalesced 16 B / 8 B per lane row reads and writes.
 #include <type_traits>
-#include "rfx_compose_inl.h"
 #include "rfx_device.h"
 #include "rfx_kernels.h"
 
@@ -56,7 +55,7 @@ RFX_DEV void k3_apply(CenterTexel &c, float l2w, float3 tl, float tapLuma, float
 //   pass 0 : float4 in[2][n] log(rgb+1), luma^(1/8)     pass >= 1 : uint2 in[2][n] raw RGBA16F
 //   float  depth[n]
 
-template <bool IN_TEMPORAL, int TC, bool FUSE>
+template <bool IN_TEMPORAL, int TC>
 RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     extern __shared__ float4 lds[];
     const int Rx = A.tile.Rx, Ry = A.tile.Ry, LW = A.tile.LW, LH = A.tile.LH;
@@ -112,14 +111,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     const int qy0 = __mul24(min(y & ~1, d.H - 1) - ty0 + Ry, LW) + cx, qy1 = __mul24(min(y | 1, d.H - 1) - ty0 + Ry, LW) + cx;
     {
         const float fw = fabsf(s_depth[qx1] - s_depth[qx0]) + fabsf(s_depth[qy1] - s_depth[qy0]);
-        if (depth == 1.0f && fw == 0.0f) {  // discard (:129-132): target keeps its contents
-            if (FUSE && A.rgb_out) {  // ... and so does DenoiserComposePass's (same test, :61-64): mirror its texel into the RGB twin
-                const float4 keep = ((const float4 *)A.compose_out.ptr)[(size_t)rfx_local_row(d, A.compose_out.row0, A.compose_out.rows, y) * d.W + x];
-                float *r = A.rgb_out + ((size_t)y * d.W + x) * 3;
-                r[0] = keep.x; r[1] = keep.y; r[2] = keep.z;
-            }
-            return;
-        }
+        if (depth == 1.0f && fw == 0.0f) return;  // discard (:129-132): target keeps its contents
     }
     const float4 gc = s_geom[ci];
     const float3 normal = make_float3(gc.x, gc.y, gc.z);
@@ -221,26 +213,12 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     }
 
     const size_t oi = (size_t)(unsigned int)(__mul24(rfx_local_row(d, A.out0.row0, A.out0.rows, y), d.W) + x);
-    float4 gi[2];
 #pragma unroll
     for (int i = 0; i < TC; i++) {  // outputTexel :94-100
         const float inv = rfx_rcp(c[i].total);
         float3 o = make_float3(c[i].rgb.x * inv, c[i].rgb.y * inv, c[i].rgb.z * inv);
         o = make_float3(rfx_exp(o.x) - 1.0f, rfx_exp(o.y) - 1.0f, rfx_exp(o.z) - 1.0f);
-        const uint2 st = rfx_store_half4(o.x, o.y, o.z, c[i].a, p.halfStoreRTZ != 0);
-        ((uint2 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = st;
-        if (FUSE) gi[i] = rfx_load_half4(st);  // what the compose pass reads back from the RGBA16F target
-    }
-    if constexpr (FUSE && TC == 2) {
-        // DenoiserComposePass on the texels just produced (textures[0] = diffuse GI, textures[1] = specular GI).  The separate draw
-        // re-samples them bilinearly at the pixel centre, i.e. with weights (1 - e, e), e <= 1e-7: the texel itself here.
-        const Material mat = rfx_get_material<true>(rfx_gather<uint4>(gbp, (unsigned int)(__mul24(rfx_local_row(d, A.gbuffer.row0, A.gbuffer.rows, y), d.W) + x)));
-        const float4 o = k4_shade(A.cp, d, x, y, u, v, depth, mat, gi[0], gi[1], A.scene);
-        ((float4 *)A.compose_out.ptr)[(size_t)rfx_local_row(d, A.compose_out.row0, A.compose_out.rows, y) * d.W + x] = o;
-        if (A.rgb_out) {
-            float *r = A.rgb_out + ((size_t)y * d.W + x) * 3;
-            r[0] = o.x; r[1] = o.y; r[2] = o.z;
-        }
+        ((uint2 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = rfx_store_half4(o.x, o.y, o.z, c[i].a, p.halfStoreRTZ != 0);
     }
 }
 
@@ -335,11 +313,11 @@ RFX_DEV void k3_generic_body(const K3Args &A, const FrameDims &d) {
     }
 }
 
-template <bool IN_TEMPORAL, int TC, bool FUSE>
+template <bool IN_TEMPORAL, int TC>
 __global__ __launch_bounds__(NT) void k3_tiled(K3Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-    k3_tiled_body<IN_TEMPORAL, TC, FUSE>(A, d);
+    k3_tiled_body<IN_TEMPORAL, TC>(A, d);
     rfx_flush_violations(d);
 }
 template <bool IN_TEMPORAL, int TC>
@@ -352,9 +330,8 @@ __global__ __launch_bounds__(256) void k3_generic(K3Args A) {
 
 }  // namespace
 
-hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *composed) {
+hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream) {
     K3Args A = A_in;
-    if (composed) *composed = false;
     const bool temporal = A.p.inputIsTemporal != 0;
     // apron of the tap footprint: anisotropic because the reference rotates in UV space
     const float aspect = A.dims.fW / A.dims.fH;
@@ -379,27 +356,21 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *composed)
     const bool tiled = A.p.radius >= 0.0f && lds <= 80 * 1024 && A.force_generic != 1;
     if (tiled) {
         dim3 block(TW, TH), grid((A.dims.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH);
-#define K3_TILED(T, C, F)                                                                                                    \
+#define K3_TILED(T, C)                                                                                                       \
     do {                                                                                                                     \
         static bool attr_set = false;                                                                                        \
         if (!attr_set) {                                                                                                     \
-            hipFuncSetAttribute((const void *)k3_tiled<T, C, F>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);     \
+            hipFuncSetAttribute((const void *)k3_tiled<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);        \
             attr_set = true;                                                                                                 \
         }                                                                                                                    \
-        hipLaunchKernelGGL((k3_tiled<T, C, F>), grid, block, lds, stream, A);                                                \
+        hipLaunchKernelGGL((k3_tiled<T, C>), grid, block, lds, stream, A);                                                   \
     } while (0)
         if (A.p.textureCount == 2) {
-            if (A.fuse_compose) {  // the last pass also writes DenoiserComposePass's target (rfx_poisson_denoise_compose)
-                if (temporal) K3_TILED(true, 2, true);
-                else K3_TILED(false, 2, true);
-                if (composed) *composed = true;
-            } else {
-                if (temporal) K3_TILED(true, 2, false);
-                else K3_TILED(false, 2, false);
-            }
+            if (temporal) K3_TILED(true, 2);
+            else K3_TILED(false, 2);
         } else {
-            if (temporal) K3_TILED(true, 1, false);
-            else K3_TILED(false, 1, false);
+            if (temporal) K3_TILED(true, 1);
+            else K3_TILED(false, 1);
         }
 #undef K3_TILED
     } else {

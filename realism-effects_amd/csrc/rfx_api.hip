@@ -603,37 +603,8 @@ int rfx_copy_framebuffer(rfx_ctx *c, rfx_tex dst) {
     return RFX_OK;
 }
 
-// fills K4Args for rfx_compose; *any = false when the row window leaves nothing to draw
-static int compose_args(rfx_ctx *c, const rfx_compose_params *p, K4Args *out, bool *any) {
-    if (p->inputType != 0 && p->inputType != 2)
-        return fail(c, RFX_EUNSUPPORTED, "rfx_compose: inputType diffuseSpecular (0) and specular (2) are built");
-    if (p->giSource != 0 && p->giSource != 1) return fail(c, RFX_EINVAL, "rfx_compose: giSource");
-    const int g0 = p->giSource ? RFX_TEX_TEMPORAL0 : RFX_TEX_DENOISE_B0, g1 = p->giSource ? RFX_TEX_TEMPORAL1 : RFX_TEX_DENOISE_B1;
-    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, g0, g1, RFX_TEX_COMPOSE, RFX_TEX_DIRECT_LIGHT};
-    int rc = need(c, ids, 6);
-    if (rc) return rc;
-    K4Args &A = *out;
-    A.dims = dims(c);
-    launch_rows(c, RFX_TEX_COMPOSE, 0, &A.y0, &A.y1);
-    if (A.y0 < c->tile_y0) A.y0 = c->tile_y0;  // COMPOSE is held whole: write only the tile
-    if (A.y1 > c->tile_y0 + c->tile_rows) A.y1 = c->tile_y0 + c->tile_rows;
-    *any = A.y1 > A.y0;
-    A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER);
-    A.gi0 = view(c, g0); A.gi1 = view(c, g1);
-    A.scene = view(c, RFX_TEX_DIRECT_LIGHT);  // Denoiser.js:101-103: sceneTexture = the composer's input buffer
-    A.out = wview(c, RFX_TEX_COMPOSE);
-    A.rgb_out = nullptr;
-    if (p->writeHistoryRGB) {
-        const int rgb[] = {RFX_TEX_COMPOSE_RGB};
-        if ((rc = need(c, rgb, 1))) return rc;
-        A.rgb_out = (float *)c->slots[RFX_TEX_COMPOSE_RGB].ptr;  // held whole, like COMPOSE: frame row y at y * W
-    }
-    A.p = *p;
-    return RFX_OK;
-}
-
-// one PoissonDenoisePass draw; with `cp` also DenoiserComposePass's draw — in the same launch when the LDS-tiled kernel runs
-static int denoise_draw(rfx_ctx *c, const rfx_denoise_params *p, const rfx_compose_params *cp) {
+int rfx_poisson_denoise(rfx_ctx *c, const rfx_denoise_params *p) {
+    if (!c || !p) return RFX_EINVAL;
     if (p->textureCount != 1 && p->textureCount != 2) return fail(c, RFX_EINVAL, "rfx_poisson_denoise: textureCount");
     hipSetDevice(c->device);
     const int in0 = p->inputIsTemporal ? RFX_TEX_TEMPORAL0 : (p->writeToB ? RFX_TEX_DENOISE_A0 : RFX_TEX_DENOISE_B0);
@@ -645,13 +616,6 @@ static int denoise_draw(rfx_ctx *c, const rfx_denoise_params *p, const rfx_compo
     if (rc) return rc;
     if (!c->slots[RFX_TEX_DEPTH].uploaded || !c->slots[RFX_TEX_GBUFFER].uploaded || !c->slots[RFX_TEX_BLUE_NOISE].uploaded)
         return fail(c, RFX_ESTATE, "rfx_poisson_denoise: depth / gbuffer / blue-noise not uploaded");
-    K4Args C4;
-    bool compose_any = false;
-    if (cp) {
-        if (!p->writeToB || cp->giSource != 0)
-            return fail(c, RFX_EINVAL, "rfx_poisson_denoise_compose: the compose pass reads target B (writeToB = 1, giSource = 0)");
-        if ((rc = compose_args(c, cp, &C4, &compose_any))) return rc;
-    }
     K3Args A;
     A.dims = dims(c);
     if (!launch_rows(c, out0, 0, &A.y0, &A.y1)) return RFX_OK;
@@ -664,38 +628,37 @@ static int denoise_draw(rfx_ctx *c, const rfx_denoise_params *p, const rfx_compo
     A.p = *p;
     static const int force_generic = getenv("RFX_K3_GENERIC") ? atoi(getenv("RFX_K3_GENERIC")) : 0;
     A.force_generic = force_generic;
-    // fused only for the diffuse+specular layout the compose fragment takes as (textures[0], textures[1]) — anything else: two launches
-    A.fuse_compose = (cp && compose_any && p->textureCount == 2 && cp->inputType == 0 && !p->isTextureSpecular[0] && p->isTextureSpecular[1]) ? 1 : 0;
-    A.rgb_out = nullptr;
-    if (A.fuse_compose) {
-        A.cp = *cp;
-        A.compose_out = C4.out;
-        A.rgb_out = C4.rgb_out;
-        A.scene = C4.scene;
-    }
-    bool composed = false;
-    HIPCHK(c, rfx_launch_k3(A, c->stream, &composed));
-    if (cp && compose_any && !composed) HIPCHK(c, rfx_launch_k4(C4, c->stream));
+    HIPCHK(c, rfx_launch_k3(A, c->stream));
     return RFX_OK;
-}
-
-int rfx_poisson_denoise(rfx_ctx *c, const rfx_denoise_params *p) {
-    if (!c || !p) return RFX_EINVAL;
-    return denoise_draw(c, p, nullptr);
-}
-
-int rfx_poisson_denoise_compose(rfx_ctx *c, const rfx_denoise_params *p, const rfx_compose_params *cp) {
-    if (!c || !p || !cp) return RFX_EINVAL;
-    return denoise_draw(c, p, cp);
 }
 
 int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
     if (!c || !p) return RFX_EINVAL;
+    if (p->inputType != 0 && p->inputType != 2)
+        return fail(c, RFX_EUNSUPPORTED, "rfx_compose: inputType diffuseSpecular (0) and specular (2) are built");
     hipSetDevice(c->device);
-    K4Args A;
-    bool any = false;
-    int rc = compose_args(c, p, &A, &any);
+    if (p->giSource != 0 && p->giSource != 1) return fail(c, RFX_EINVAL, "rfx_compose: giSource");
+    const int g0 = p->giSource ? RFX_TEX_TEMPORAL0 : RFX_TEX_DENOISE_B0, g1 = p->giSource ? RFX_TEX_TEMPORAL1 : RFX_TEX_DENOISE_B1;
+    const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, g0, g1, RFX_TEX_COMPOSE, RFX_TEX_DIRECT_LIGHT};
+    int rc = need(c, ids, 6);
     if (rc) return rc;
+    K4Args A;
+    A.dims = dims(c);
+    launch_rows(c, RFX_TEX_COMPOSE, 0, &A.y0, &A.y1);
+    if (A.y0 < c->tile_y0) A.y0 = c->tile_y0;  // COMPOSE is held whole: write only the tile
+    if (A.y1 > c->tile_y0 + c->tile_rows) A.y1 = c->tile_y0 + c->tile_rows;
+    const bool any = A.y1 > A.y0;
+    A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER);
+    A.gi0 = view(c, g0); A.gi1 = view(c, g1);
+    A.scene = view(c, RFX_TEX_DIRECT_LIGHT);  // Denoiser.js:101-103: sceneTexture = the composer's input buffer
+    A.out = wview(c, RFX_TEX_COMPOSE);
+    A.rgb_out = nullptr;
+    if (p->writeHistoryRGB) {
+        const int rgb[] = {RFX_TEX_COMPOSE_RGB};
+        if ((rc = need(c, rgb, 1))) return rc;
+        A.rgb_out = (float *)c->slots[RFX_TEX_COMPOSE_RGB].ptr;  // held whole, like COMPOSE: frame row y at y * W
+    }
+    A.p = *p;
     if (any) HIPCHK(c, rfx_launch_k4(A, c->stream));
     return RFX_OK;
 }

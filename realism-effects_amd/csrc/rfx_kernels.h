@@ -58,12 +58,6 @@ struct K3Args {
     int force_generic;  // development switch (env RFX_K3_GENERIC=1): use the untiled kernel for any radius
     struct { int Rx, Ry, LW, LH; } tile;  // filled by the launcher
     float tap_ox[8], tap_oy[8];           // POISSON[k] / resolution, filled by the launcher
-    // rfx_poisson_denoise_compose: the pass also writes DenoiserComposePass's target from the texels it has just produced
-    int fuse_compose;
-    rfx_compose_params cp;
-    TexViewW compose_out;  // RFX_TEX_COMPOSE
-    float *rgb_out;        // RFX_TEX_COMPOSE_RGB or null
-    TexView scene;
 };
 
 struct K4Args {
@@ -94,8 +88,7 @@ int rfx_k1_base_cell();  // edge of k1_prepare's base cells in texels
 hipError_t rfx_launch_k1_prepare(const K1Args &, hipStream_t);
 hipError_t rfx_launch_k1(const K1Args &, int stage /* 0 fused, 1 trace, 2 shade */, hipStream_t);
 hipError_t rfx_launch_k2(const K2Args &, hipStream_t);
-// *composed (may be null): the launch also wrote the compose target (A.fuse_compose was set and the LDS-tiled kernel ran)
-hipError_t rfx_launch_k3(const K3Args &, hipStream_t, bool *composed);
+hipError_t rfx_launch_k3(const K3Args &, hipStream_t);
 hipError_t rfx_launch_k4(const K4Args &, hipStream_t);
 // rows [y0, y1) of an RGBA32F plane -> the same rows of an RGBA16F (to_half) or RGBA32F plane
 hipError_t rfx_launch_copy_fb(const FrameDims &, int y0, int y1, TexView src, TexViewW dst, bool to_half, hipStream_t);

@@ -152,10 +152,6 @@ class Renderer {
 	poissonDenoise(uniforms) {
 		addon.poissonDenoise(this._h, uniforms)
 	}
-	// the last denoise draw + the compose draw, one launch when the tiled kernel runs (rfx_poisson_denoise_compose)
-	poissonDenoiseCompose(uniforms, composeUniforms) {
-		addon.poissonDenoiseCompose(this._h, uniforms, composeUniforms)
-	}
 	compose(uniforms) {
 		addon.compose(this._h, uniforms)
 	}

@@ -343,26 +343,15 @@ class PoissonDenoisePass {
 	get texture() {
 		return [TEX.DENOISE_B0, TEX.DENOISE_B1]
 	}
-	// composeWith: the DenoiserComposePass that runs right after this pass (Denoiser.render): its draw rides on the last denoise
-	// draw (rfx_poisson_denoise_compose) when the renderer offers that. Returns true when it did.
-	render(renderer, composeWith) {
-		const n = 2 * this.iterations
-		let composed = false
-		for (let i = 0; i < n; i++) {
+	render(renderer) {
+		for (let i = 0; i < 2 * this.iterations; i++) {
 			const horizontal = i % 2 === 0
 			this.uniforms.inputIsTemporal = i === 0 ? 1 : 0
 			this.uniforms.writeToB = horizontal ? 0 : 1
 			this.uniforms.blueNoiseIndex = this.blueNoiseIndex.value
-			if (i === n - 1 && composeWith && renderer.poissonDenoiseCompose && composeWith.uniforms.giSource === 0) {
-				composeWith.prepare(renderer)
-				renderer.poissonDenoiseCompose(this.uniforms, composeWith.uniforms)
-				composed = true
-			} else {
-				renderer.poissonDenoise(this.uniforms)
-			}
+			renderer.poissonDenoise(this.uniforms)
 			if (renderer.afterDenoisePass) renderer.afterDenoisePass(i, this.uniforms)
 		}
-		return composed
 	}
 	dispose() {}
 }
@@ -384,11 +373,8 @@ class DenoiserComposePass {
 	get texture() {
 		return TEX.COMPOSE
 	}
-	prepare(renderer) {
-		this.uniforms.camera = cloneCamera(this._camera)
-	}
 	render(renderer) {
-		this.prepare(renderer)
+		this.uniforms.camera = cloneCamera(this._camera)
 		renderer.compose(this.uniforms)
 	}
 	dispose() {}
@@ -450,10 +436,9 @@ class Denoiser {
 		if (this.isOwnVelocityDepthNormalPass) this.velocityDepthNormalPass.render(renderer)
 		this.temporalReprojectPass.render(renderer)
 		if (renderer.afterTemporalPass) renderer.afterTemporalPass()
-		let composed = false
-		if (this.denoisePass) composed = this.denoisePass.render(renderer, this.denoiserComposePass)
+		if (this.denoisePass) this.denoisePass.render(renderer)
 		if (this.denoiserComposePass) {
-			if (!composed) this.denoiserComposePass.render(renderer)
+			this.denoiserComposePass.render(renderer)
 			if (renderer.afterComposePass) renderer.afterComposePass()
 		}
 	}

@@ -395,38 +395,26 @@ static napi_value n_copy_framebuffer(napi_env env, napi_callback_info info) {
 
 /* poissonDenoise(ctx, {radius, phi, lumaPhi, depthPhi, normalPhi, roughnessPhi, specularPhi, textureCount,
  *                      isTextureSpecular[2], blueNoiseIndex, inputIsTemporal, writeToB, halfStoreRTZ}) */
-static void read_denoise(napi_env env, napi_value o, rfx_denoise_params *p) {
-    memset(p, 0, sizeof *p);
-    p->radius = (float)prop_num(env, o, "radius", 3);
-    p->phi = (float)prop_num(env, o, "phi", 0.5);
-    p->lumaPhi = (float)prop_num(env, o, "lumaPhi", 5);
-    p->depthPhi = (float)prop_num(env, o, "depthPhi", 2);
-    p->normalPhi = (float)prop_num(env, o, "normalPhi", 3.25);
-    p->roughnessPhi = (float)prop_num(env, o, "roughnessPhi", 0.0 / 0.0);
-    p->specularPhi = (float)prop_num(env, o, "specularPhi", 0.0 / 0.0);
-    p->textureCount = (int32_t)prop_num(env, o, "textureCount", 2);
-    prop_bool2(env, o, "isTextureSpecular", p->isTextureSpecular);
-    p->blueNoiseIndex = (int32_t)prop_num(env, o, "blueNoiseIndex", 0);
-    p->inputIsTemporal = (int32_t)prop_num(env, o, "inputIsTemporal", 1);
-    p->writeToB = (int32_t)prop_num(env, o, "writeToB", 0);
-    p->halfStoreRTZ = (int32_t)prop_num(env, o, "halfStoreRTZ", 0);
-}
-static int read_compose(napi_env env, napi_value o, rfx_compose_params *p) {
-    memset(p, 0, sizeof *p);
-    if (!read_camera(env, o, "camera", &p->camera)) return 0;
-    p->inputType = (int32_t)prop_num(env, o, "inputType", 0);
-    p->giSource = (int32_t)prop_num(env, o, "giSource", 0);
-    p->writeHistoryRGB = (int32_t)prop_num(env, o, "writeHistoryRGB", 0);
-    return 1;
-}
-
 static napi_value n_denoise(napi_env env, napi_callback_info info) {
     napi_value a[2];
     if (!get_args(env, info, 2, a)) return NULL;
     rfx_ctx *c = get_ctx(env, a[0]);
     if (!c) return NULL;
     rfx_denoise_params p;
-    read_denoise(env, a[1], &p);
+    memset(&p, 0, sizeof p);
+    p.radius = (float)prop_num(env, a[1], "radius", 3);
+    p.phi = (float)prop_num(env, a[1], "phi", 0.5);
+    p.lumaPhi = (float)prop_num(env, a[1], "lumaPhi", 5);
+    p.depthPhi = (float)prop_num(env, a[1], "depthPhi", 2);
+    p.normalPhi = (float)prop_num(env, a[1], "normalPhi", 3.25);
+    p.roughnessPhi = (float)prop_num(env, a[1], "roughnessPhi", 0.0 / 0.0);
+    p.specularPhi = (float)prop_num(env, a[1], "specularPhi", 0.0 / 0.0);
+    p.textureCount = (int32_t)prop_num(env, a[1], "textureCount", 2);
+    prop_bool2(env, a[1], "isTextureSpecular", p.isTextureSpecular);
+    p.blueNoiseIndex = (int32_t)prop_num(env, a[1], "blueNoiseIndex", 0);
+    p.inputIsTemporal = (int32_t)prop_num(env, a[1], "inputIsTemporal", 1);
+    p.writeToB = (int32_t)prop_num(env, a[1], "writeToB", 0);
+    p.halfStoreRTZ = (int32_t)prop_num(env, a[1], "halfStoreRTZ", 0);
     int rc = rfx_poisson_denoise(c, &p);
     if (rc) return throw_rfx(env, c, "rfx_poisson_denoise", rc);
     return NULL;
@@ -439,24 +427,13 @@ static napi_value n_compose(napi_env env, napi_callback_info info) {
     rfx_ctx *c = get_ctx(env, a[0]);
     if (!c) return NULL;
     rfx_compose_params p;
-    if (!read_compose(env, a[1], &p)) return NULL;
+    memset(&p, 0, sizeof p);
+    if (!read_camera(env, a[1], "camera", &p.camera)) return NULL;
+    p.inputType = (int32_t)prop_num(env, a[1], "inputType", 0);
+    p.giSource = (int32_t)prop_num(env, a[1], "giSource", 0);
+    p.writeHistoryRGB = (int32_t)prop_num(env, a[1], "writeHistoryRGB", 0);
     int rc = rfx_compose(c, &p);
     if (rc) return throw_rfx(env, c, "rfx_compose", rc);
-    return NULL;
-}
-
-/* poissonDenoiseCompose(ctx, denoiseUniforms, composeUniforms): rfx_poisson_denoise_compose */
-static napi_value n_denoise_compose(napi_env env, napi_callback_info info) {
-    napi_value a[3];
-    if (!get_args(env, info, 3, a)) return NULL;
-    rfx_ctx *c = get_ctx(env, a[0]);
-    if (!c) return NULL;
-    rfx_denoise_params p;
-    rfx_compose_params cp;
-    read_denoise(env, a[1], &p);
-    if (!read_compose(env, a[2], &cp)) return NULL;
-    int rc = rfx_poisson_denoise_compose(c, &p, &cp);
-    if (rc) return throw_rfx(env, c, "rfx_poisson_denoise_compose", rc);
     return NULL;
 }
 
@@ -534,7 +511,7 @@ static napi_value n_time_end(napi_env env, napi_callback_info info) {
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
-        {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"setEnvironmentImportance", n_set_environment_importance}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"ssgiTrace", n_ssgi_trace}, {"ssgiShade", n_ssgi_shade}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"poissonDenoiseCompose", n_denoise_compose}, {"finalCompose", n_final},
+        {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"setEnvironmentImportance", n_set_environment_importance}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"ssgiTrace", n_ssgi_trace}, {"ssgiShade", n_ssgi_shade}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
         {"sync", n_sync}, {"setRowWindow", n_set_row_window}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {

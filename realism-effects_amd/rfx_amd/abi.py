@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "..", "csrc", "librfx_hip.so")
 
-RFX_ABI_VERSION = 12
+RFX_ABI_VERSION = 11
 RFX_OK, RFX_EINVAL, RFX_ENOMEM, RFX_EDEVICE, RFX_ESTATE, RFX_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 (TEX_DEPTH, TEX_GBUFFER, TEX_VELOCITY, TEX_DIRECT_LIGHT, TEX_BLUE_NOISE, TEX_SSGI, TEX_TEMPORAL0, TEX_TEMPORAL1,
@@ -93,7 +93,7 @@ class FinalParams(C.Structure):
 
 EXPORTS = [
     "rfx_abi_version", "rfx_create", "rfx_destroy", "rfx_last_error", "rfx_get_geometry", "rfx_set_stream", "rfx_tex_texel_bytes", "rfx_tex_held_rows",
-    "rfx_upload", "rfx_download", "rfx_clear", "rfx_tex_device_ptr", "rfx_bind_external", "rfx_pack_gbuffer", "rfx_pack_velocity", "rfx_set_environment", "rfx_set_environment_importance", "rfx_download_environment", "rfx_set_row_window", "rfx_poisson_denoise_compose", "rfx_ssgi_march", "rfx_ssgi_trace", "rfx_ssgi_shade", "rfx_temporal_reproject",
+    "rfx_upload", "rfx_download", "rfx_clear", "rfx_tex_device_ptr", "rfx_bind_external", "rfx_pack_gbuffer", "rfx_pack_velocity", "rfx_set_environment", "rfx_set_environment_importance", "rfx_download_environment", "rfx_set_row_window", "rfx_ssgi_march", "rfx_ssgi_trace", "rfx_ssgi_shade", "rfx_temporal_reproject",
     "rfx_copy_framebuffer", "rfx_poisson_denoise", "rfx_compose", "rfx_final_compose", "rfx_sync", "rfx_halo_violations", "rfx_time_begin", "rfx_time_end",
 ]
 
@@ -136,7 +136,6 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rfx_set_environment_importance.argtypes = [vp, vp, vp, f, f]
     lib.rfx_download_environment.argtypes = [vp, i, vp, C.POINTER(i)]
     lib.rfx_set_row_window.argtypes = [vp, C.c_int, C.c_int]
-    lib.rfx_poisson_denoise_compose.argtypes = [vp, C.POINTER(DenoiseParams), C.POINTER(ComposeParams)]
     lib.rfx_ssgi_march.argtypes = [vp, C.POINTER(SsgiParams)]
     lib.rfx_ssgi_trace.argtypes = [vp, C.POINTER(SsgiParams)]
     lib.rfx_ssgi_shade.argtypes = [vp, C.POINTER(SsgiParams)]

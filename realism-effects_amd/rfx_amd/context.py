@@ -189,10 +189,6 @@ class Context:
     def copy_framebuffer(self, dst: int):
         self._chk(self.lib.rfx_copy_framebuffer(self._h, dst), "rfx_copy_framebuffer")
 
-    def poisson_denoise_compose(self, p: abi.DenoiseParams, cp: abi.ComposeParams):
-        """The last denoise draw + the compose draw (one launch when the tiled kernel runs); see rfx.h."""
-        self._chk(self.lib.rfx_poisson_denoise_compose(self._h, C.byref(p), C.byref(cp)), "rfx_poisson_denoise_compose")
-
     def poisson_denoise(self, p: abi.DenoiseParams):
         self._chk(self.lib.rfx_poisson_denoise(self._h, C.byref(p)), "rfx_poisson_denoise")
 

@@ -296,25 +296,16 @@ class PoissonDenoisePass:
     def texture(self):
         return (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1)
 
-    def render(self, renderer, compose_with=None):
-        """`compose_with`: the DenoiserComposePass that runs right after this pass (Denoiser.render): its draw rides on the last
-        denoise draw (rfx_poisson_denoise_compose) when the renderer offers that.  Returns True when it did."""
-        n, composed = 2 * int(self.iterations), False
-        for i in range(n):  # :135-149
+    def render(self, renderer):
+        for i in range(2 * int(self.iterations)):  # :135-149
             horizontal = i % 2 == 0
             self.uniforms.inputIsTemporal = 1 if i == 0 else 0
             self.uniforms.writeToB = 0 if horizontal else 1
             self.uniforms.blueNoiseIndex = self.blueNoiseIndex.value
-            if i == n - 1 and compose_with is not None and hasattr(renderer, "poisson_denoise_compose") and compose_with.uniforms.giSource == 0:
-                compose_with.prepare(renderer)
-                renderer.poisson_denoise_compose(self.uniforms, compose_with.uniforms)
-                composed = True
-            else:
-                renderer.poisson_denoise(self.uniforms)
+            renderer.poisson_denoise(self.uniforms)
             hook = getattr(renderer, "after_denoise_pass", None)
             if hook:
                 hook(i, self.uniforms)  # multi-GPU: halo exchange of the target just written
-        return composed
 
     def dispose(self):
         pass
@@ -338,13 +329,10 @@ class DenoiserComposePass:
     def texture(self):
         return abi.TEX_COMPOSE
 
-    def prepare(self, renderer):
+    def render(self, renderer):
         self.uniforms.camera = abi.Camera.from_scene(self._camera)
         # a row-tiled renderer all-gathers the part of this target K1 reads next frame (.rgb) as 12-byte texels
         self.uniforms.writeHistoryRGB = 1 if getattr(renderer, "gather_history_rgb", False) else 0
-
-    def render(self, renderer):
-        self.prepare(renderer)
         renderer.compose(self.uniforms)
 
     def dispose(self):
@@ -405,12 +393,10 @@ class Denoiser:
         hook = getattr(renderer, "after_temporal_pass", None)
         if hook:
             hook()
-        composed = False
         if self.denoisePass:
-            composed = self.denoisePass.render(renderer, compose_with=self.denoiserComposePass)
+            self.denoisePass.render(renderer)
         if self.denoiserComposePass:
-            if not composed:
-                self.denoiserComposePass.render(renderer)
+            self.denoiserComposePass.render(renderer)
             hook = getattr(renderer, "after_compose_pass", None)
             if hook:
                 hook()

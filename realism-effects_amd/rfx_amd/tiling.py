@@ -110,9 +110,6 @@ class TiledRenderer:
     def compose(self, p):
         return self._interior_first(lambda: self.inner.compose(p))
 
-    def poisson_denoise_compose(self, p, cp):
-        return self._interior_first(lambda: self.inner.poisson_denoise_compose(p, cp))
-
     def final_compose(self, p):
         self.finish_halo()
         return self.inner.final_compose(p)

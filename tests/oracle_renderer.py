@@ -147,10 +147,6 @@ class OracleRenderer:
             return
         O.denoise(t[abi.TEX_DEPTH], t[abi.TEX_GBUFFER], i0, i1, t[abi.TEX_BLUE_NOISE], p, o0, o1, rows=self._rows())
 
-    def poisson_denoise_compose(self, p, cp):
-        self.poisson_denoise(p)
-        self.compose(cp)
-
     def compose(self, p):
         self.calls.append(("compose",))
         t = self.tex

@@ -1029,53 +1029,3 @@ def test_row_windowed_draws_are_bit_identical(blue_noise):
             assert np.array_equal(ctx.download(t), want[t]), "%s: windowed != whole" % name
     assert ctx.halo_violations() == 0
     ctx.close()
-
-
-def test_fused_last_denoise_pass_plus_compose(blue_noise):
-    """rfx_poisson_denoise_compose: target B exactly as rfx_poisson_denoise leaves it; RFX_TEX_COMPOSE as rfx_compose composes it, up to the
-    (1 - e, e) bilinear re-sampling of target B at pixel centres that the one-launch form skips (e <= 1e-7 relative); the RGB twin follows,
-    discarded background included; layouts the fused kernel does not take (one texture, the untiled kernel) fall back to the two launches
-    and are bit-identical."""
-    from rfx_amd import abi
-    from rfx_amd.context import Context
-    from rfx_amd.scene import synthetic_frame
-
-    W, H = 256, 144
-    f0, f = synthetic_frame(W, H, 0), synthetic_frame(W, H, 1)
-    sp, tp, dp, cp = _params(abi, f, f0.camera, 1.0, 12, 3)
-    dp.blueNoiseIndex = 17
-    ctx = Context(W, H)
-    ctx.upload_frame(f)
-    rs = np.random.RandomState(11)
-    for t in (abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1):
-        ctx.upload(t, (rs.rand(H, W, 4).astype(np.float32) * np.array([2, 2, 2, 6], np.float32)).astype(np.float16).view(np.uint16))
-    held = rs.rand(H, W, 4).astype(np.float32)
-    dp.inputIsTemporal, dp.writeToB = 0, 1
-    for radius, tc, exact in ((3.0, 2, False), (3.0, 1, True), (9.0, 2, True)):
-        dp.radius, dp.textureCount = radius, tc
-        dp.isTextureSpecular[:] = [0, 1] if tc == 2 else [1, 1]
-        cp.inputType = 0 if tc == 2 else 2
-        cp.writeHistoryRGB = 1
-        ctx.upload(abi.TEX_COMPOSE, held)
-        ctx.poisson_denoise(dp)
-        ctx.compose(cp)
-        want = {t: ctx.download(t) for t in (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1, abi.TEX_COMPOSE, abi.TEX_COMPOSE_RGB)}
-        for t in (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1, abi.TEX_COMPOSE_RGB):
-            ctx.clear(t)
-        ctx.upload(abi.TEX_COMPOSE, held)
-        ctx.poisson_denoise_compose(dp, cp)
-        got = {t: ctx.download(t) for t in want}
-        tag = "radius %g, %d texture(s)" % (radius, tc)
-        assert np.array_equal(got[abi.TEX_DENOISE_B0], want[abi.TEX_DENOISE_B0]), tag
-        if tc == 2:
-            assert np.array_equal(got[abi.TEX_DENOISE_B1], want[abi.TEX_DENOISE_B1]), tag
-        assert np.array_equal(got[abi.TEX_COMPOSE_RGB], got[abi.TEX_COMPOSE][..., :3]), tag
-        bg = f.depth == 1.0
-        assert bg.any() and np.array_equal(got[abi.TEX_COMPOSE][bg], want[abi.TEX_COMPOSE][bg])  # discarded: the held texels
-        if exact:
-            assert np.array_equal(got[abi.TEX_COMPOSE], want[abi.TEX_COMPOSE]), tag
-        else:
-            err = np.abs(got[abi.TEX_COMPOSE] - want[abi.TEX_COMPOSE])
-            assert err.max() <= 2e-6 * max(1.0, float(np.abs(want[abi.TEX_COMPOSE]).max())), (tag, float(err.max()))
-            assert (got[abi.TEX_COMPOSE] != want[abi.TEX_COMPOSE]).any(axis=-1).mean() < 0.5
-    ctx.close()

@@ -62,7 +62,7 @@ def _worker(rank, world, port, outdir):
     assert len(r._pending) == 1
     r.finish_pending()
     # the halo exchanges are asynchronous too: K3 passes and K4 drew their interior first (windowed launches), then the boundary strips
-    assert r.overlap_halo_exchange and sum(1 for c in inner.calls if c[0] == "set_row_window") >= FRAMES * 2 * 3  # K3 pass 0, K3 pass 1 + K4 (one draw)
+    assert r.overlap_halo_exchange and sum(1 for c in inner.calls if c[0] == "set_row_window") >= FRAMES * 3 * 3
     r.finish_halo()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), y0=y0, rows=rows, halo=halo,
              **{abi.TEX_NAMES[t]: inner.tex[t][y0:y0 + rows] for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0,

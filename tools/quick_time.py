@@ -37,8 +37,7 @@ cp = abi.ComposeParams(camera=cam, inputType=0)
 def d0(): dp.inputIsTemporal, dp.writeToB = 1, 0; ctx.poisson_denoise(dp)
 def d1(): dp.inputIsTemporal, dp.writeToB = 0, 1; ctx.poisson_denoise(dp)
 stages = [("K1 ssgi", lambda: ctx.ssgi_march(sp), 68), ("K1t trace", lambda: ctx.ssgi_trace(sp), 40), ("K1s shade", lambda: ctx.ssgi_shade(sp), 92), ("K2 temporal", lambda: ctx.temporal_reproject(tp), 80), ("K3 pass0", d0, 68), ("K3 pass1", d1, 52),
-          ("K4 compose", lambda: ctx.compose(cp), 52), ("K3p1+K4 fused", lambda: (d1_params(), ctx.poisson_denoise_compose(dp, cp)), 68)]
-def d1_params(): dp.inputIsTemporal, dp.writeToB = 0, 1
+          ("K4 compose", lambda: ctx.compose(cp), 52)]
 # two warm frames so the history textures are populated
 for _ in range(2):
     for _, fn, _b in stages: fn()
@@ -56,7 +55,7 @@ for name, fn, bpp in stages:
     if name.startswith("K1s"): ms -= trace_ms
     gbs = bpp * W * H / (ms * 1e-3) / 1e9
     print("%-12s %8.3f ms  %8.1f Mpix/s  algorithmic %6.1f GB/s (%.1f%% of 8 TB/s)" % (name, ms, W * H / ms / 1e3, gbs, gbs / 80), flush=True)
-    if not name.startswith("K4") and not name.startswith("K1t") and not name.startswith("K1s") and not name.startswith("K3p1+"): tot += ms
+    if not name.startswith("K4") and not name.startswith("K1t") and not name.startswith("K1s"): tot += ms
 print("K1+K2+2xK3: %.3f ms  -> %.1f Mpix/s; 268 B/px -> %.1f GB/s (%.1f%% of 8 TB/s)" % (tot, W * H / tot / 1e3, 268 * W * H / tot / 1e6, 268 * W * H / tot / 1e6 / 80))
 print("halo violations", ctx.halo_violations())
 if only.startswith("K1") or not only:  # variants of the exact kernel must not change a single texel
