@@ -90,11 +90,24 @@ RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &te
         S2[k] = (tc + 2.0f) * its[k];
     }
     const float sw0 = Wb[0] * Wa[1], sw1 = Wa[0] * Wb[1], sw2 = Wb[0] * Wb[1], sw3 = Wc[0] * Wb[1], sw4 = Wb[0] * Wc[1];
+    // A compiler barrier between the bilinear taps: left alone, the scheduler puts all 20 texels of the five taps in flight at once
+    // (40 VGPRs, 147 in total -> 3 waves/SIMD); fenced, the kernel fits 125 VGPRs -> 4 waves/SIMD: 0.48 -> 0.445 ms, same texels.
+    // (Ablation, same build: one tap instead of five 0.316 ms / 74 VGPRs, no history fetch 0.272, no neighbourhood AABB 0.467,
+    // staging + reprojection alone 0.176 — the five-tap fetch is 38 % of K2, by arithmetic and registers, not by its addresses.)
+#ifndef RFX_K2_TAPSEQ
+#define RFX_K2_TAPSEQ 2  // a barrier after every n-th tap (1, 2 and 3 compile to the same 125 VGPRs); 0: none
+#endif
+#define K2_TAP_FENCE(k) do { if (RFX_K2_TAPSEQ && ((k) % RFX_K2_TAPSEQ) == 0) asm volatile("" ::: "memory"); } while (0)
     const float4 Ct = k2_history_tap<HIST_F32>(tex, d, S1[0], S0[1]);
+    K2_TAP_FENCE(1);
     const float4 Cl = k2_history_tap<HIST_F32>(tex, d, S0[0], S1[1]);
+    K2_TAP_FENCE(2);
     const float4 Cc = k2_history_tap<HIST_F32>(tex, d, S1[0], S1[1]);
+    K2_TAP_FENCE(3);
     const float4 Cr = k2_history_tap<HIST_F32>(tex, d, S2[0], S1[1]);
+    K2_TAP_FENCE(4);
     const float4 Cb = k2_history_tap<HIST_F32>(tex, d, S1[0], S2[1]);
+#undef K2_TAP_FENCE
     const float wm = rfx_rcp((((sw0 + sw1) + sw2) + sw3) + sw4);
     float4 r;
     r.x = fmaxf(((((Ct.x * sw0 + Cl.x * sw1) + Cc.x * sw2) + Cr.x * sw3) + Cb.x * sw4) * wm, 0.0f);
@@ -262,7 +275,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
 #define RFX_K2_UNROLL_Y 5
 #endif
 #pragma unroll RFX_K2_UNROLL_Y
-            for (int oy = 0; oy < 5; oy++) {  // one row of five 12-byte LDS reads in flight at a time keeps the kernel under 128 VGPRs
+            for (int oy = 0; oy < 5; oy++) {  // one row of five 12-byte LDS reads in flight at a time
                 const int nrow = __mul24(min(max(y + oy - 2, 0), d.H - 1) - ty0 + AP, LW);  // CLAMP_TO_EDGE row, as an LDS offset
                 const float4 t0 = nt[nrow + nxo[0]], t1 = nt[nrow + nxo[1]], t2 = nt[nrow + nxo[2]], t3 = nt[nrow + nxo[3]], t4 = nt[nrow + nxo[4]];
 #define K2_RED3(acc_mn, acc_mx, a, b)                                                                                         \
