@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the row-tiled chain (halo Send/Recv after K2 and every K3 pass,
+"""CPU, world_size 2 and 3 over gloo (3: a middle rank with two neighbours, ragged tiles -> the per-owner broadcast form of the gather): the row-tiled chain (halo Send/Recv after K2 and every K3 pass,
 all-gather of the composed GI; for TRAAEffect the Send/Recv of its framebuffer copy) must be BIT-IDENTICAL to the single-tile chain.  The per-tile
 compute is the oracle double (tests only); the exchange code is the product's (rfx_amd.tiling)."""
 import os
@@ -81,7 +81,8 @@ def _worker(rank, world, port, outdir):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_tiled_chain_is_bit_identical(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])  # 3: a middle rank with two neighbours, a ragged last tile
+def test_tiled_chain_is_bit_identical(tmp_path, world):
     import socket
     from oracle_renderer import OracleRenderer
     from rfx_amd import abi
@@ -91,7 +92,6 @@ def test_two_rank_tiled_chain_is_bit_identical(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    world = 2
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
 
     frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
