@@ -178,7 +178,8 @@ def main():
         full = torch.empty((H, W), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(full, mine)
         depth_full = full.cpu().numpy()
-    frame = types.SimpleNamespace(depth=depth_full, gbuffer=band.gbuffer, velocity=band.velocity, direct=band.direct, camera=band.camera)
+    # static: the same dump every step, uploaded once before the timed region (the metric is quoted with inputs resident in HBM)
+    frame = types.SimpleNamespace(depth=depth_full, gbuffer=band.gbuffer, velocity=band.velocity, direct=band.direct, camera=band.camera, static=True)
     scene = types.SimpleNamespace(frame=frame)
     cam = band.camera
     fx = SSGIEffect(None, scene, cam, opts, seeds=dict(ssgi=1, denoise=2), half_store_rtz=True)

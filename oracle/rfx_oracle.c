@@ -29,6 +29,43 @@
 #include <limits.h>
 #include "../include/rfx.h"
 
+/* ------------------------------------------------------------------ perturbed primitives (parity tests only)
+ * Second, independent proof of a flip (the first: the discontinuity margins below).  The only freedom two correct
+ * implementations have is the last bits of exp/log/pow/sqrt/sin/cos/atan: the reference GL's are accurate to <= 6e-6
+ * relative (measured, oracle/glref/probes/probe_transcendentals.py), the GPU's hardware forms to ~1 ulp.  With a
+ * perturbation armed (rfxo_set_perturbation) every such result is multiplied by (1 +- rel) — and sin/cos moved by
+ * +- abs — with a sign drawn per call from a per-fragment seeded generator.  A fragment whose output moves by more
+ * than the tolerance under such perturbations is UNSTABLE: it sits on a branch / nearest-texel boundary or on an
+ * ill-conditioned expression (e.g. SampleGGXVNDF's sqrt(1 - t1^2 - t2^2) at blueNoise.x = 1), and two correct
+ * implementations may disagree on it.  A fragment that is stable may not.  (tests/parity.py, tests/stagewise.py) */
+static float g_pert_rel = 0.0f, g_pert_abs = 0.0f; /* rel: exp/log/pow class; sqrt and the angle functions take 2 ulps relative (+ abs) */
+static uint32_t g_pert_seed = 0; /* 0 = off */
+static _Thread_local uint32_t g_pert_state = 0;
+void rfxo_set_perturbation(uint32_t seed, float rel, float abs_) { g_pert_seed = seed; g_pert_rel = rel; g_pert_abs = abs_; }
+static inline void pert_begin(int x, int y) {
+    if (!g_pert_seed) { g_pert_state = 0; return; }
+    uint32_t h = g_pert_seed * 0x9E3779B1u ^ ((uint32_t)x * 0x85EBCA77u) ^ ((uint32_t)y * 0xC2B2AE3Du);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    g_pert_state = h | 1u;
+}
+static inline float pert_sign(void) {
+    g_pert_state = g_pert_state * 1664525u + 1013904223u;
+    return (g_pert_state & 0x00800000u) ? 1.0f : -1.0f;
+}
+static inline float pert_rel(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * g_pert_rel) : v; }
+static inline float pert_ang(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * 2.4e-7f) + pert_sign() * g_pert_abs : v; }
+static inline float pert_sqrt(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * 2.4e-7f) : v; }
+/* function-like macros are not re-expanded inside their own expansion: (expf)(x) is libm's */
+#define expf(x) pert_rel((expf)(x))
+#define logf(x) pert_rel((logf)(x))
+#define powf(x, y) pert_rel((powf)(x, y))
+#define sqrtf(x) pert_sqrt((sqrtf)(x))
+#define exp2f(x) pert_rel((exp2f)(x))
+#define log2f(x) pert_rel((log2f)(x))
+#define sinf(x) pert_ang((sinf)(x))
+#define cosf(x) pert_ang((cosf)(x))
+#define atan2f(y, x) pert_ang((atan2f)(y, x))
+
 /* ------------------------------------------------------------------ small vector helpers */
 typedef struct { float x, y, z; } v3;
 typedef struct { float x, y, z, w; } v4;
@@ -47,6 +84,29 @@ static inline float mixf(float x, float y, float a) { return x * (1.0f - a) + y 
 static inline v3 mix3(v3 x, v3 y, float a) { return V3(mixf(x.x, y.x, a), mixf(x.y, y.y, a), mixf(x.z, y.z, a)); }
 static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 static inline float lum(v3 c) { return 0.2125f * c.x + 0.7154f * c.y + 0.0721f * c.z; } /* dot(vec3(0.2125,0.7154,0.0721), c) */
+
+/* ------------------------------------------------------------------ discontinuity margins (parity tests only)
+ * The path branches on comparisons and addresses NEAREST texels: two correct implementations whose exp/log/sin differ in the
+ * last ulp take different sides of such a decision in a few pixels and differ there by O(1).  To PROVE that an out-of-tolerance
+ * pixel is such a flip — instead of assuming it — every decision a fragment takes records how close it was, normalised by the
+ * distance an ulp-level perturbation of its operands can move it (`scale`): margin = gap / scale.  The minimum over the
+ * fragment's decisions goes to an optional per-pixel plane (rfxo_set_margin_plane).  margin < 1: the fragment sits on a
+ * discontinuity and may legitimately flip; margin >= 1: it may not, a mismatch there is a bug.  (tests/parity.py) */
+static _Thread_local float g_margin = 3.0e38f;
+static float *g_margin_plane = NULL; /* W*H floats of the stage being run, or NULL */
+void rfxo_set_margin_plane(float *plane) { g_margin_plane = plane; }
+static inline void margin_note(float m) { if (m < g_margin) g_margin = m; }
+/* decision `a ? b` between two computed quantities; rel = relative perturbation either side can carry */
+static inline void margin_cmp(float a, float b, float rel) {
+    float s = rel * fmaxf(fmaxf(fabsf(a), fabsf(b)), 1e-30f);
+    margin_note(fabsf(a - b) / s);
+}
+/* scales (relative error an operand of the decision can carry between two implementations with ulp-accurate primitives) */
+#define MARGIN_REL_MARCH 5e-7f   /* ray position after <= 40 accumulated steps of dir * (1 - exp(..)), projected */
+#define MARGIN_REL_SHORT 4e-6f   /* a handful of fp32 operations incl. one transcendental */
+#define MARGIN_REL_WEIGHT 1e-4f  /* products of exp(-phi * diff): the exponents reach ~10 and carry their own rounding */
+
+static _Thread_local float g_unc_dir = 4e-7f; /* absolute uncertainty of the direction the next calc_angles() receives (set by the sampler) */
 
 /* column-major mat4: M[c*4+r].  M * vec4(p, w): ((M0*x + M1*y) + M2*z) + M3*w */
 static inline v4 mat_mul_v4(const float *M, float x, float y, float z, float w) {
@@ -119,8 +179,20 @@ static inline uint16_t float_to_half_rtz(float f) {
 /* ------------------------------------------------------------------ texture fetch */
 /* nearest CLAMP_TO_EDGE index: clamp(cvttss2si(u*size), 0, size-1); cvttss2si returns INT_MIN
  * for NaN and anything outside int range (Appendix C-4) */
+/* texel-boundary margin of a nearest fetch at coordinate c (texels): the coordinate carries a few ulps of its own magnitude
+ * plus whatever its inputs carry (rel_in, relative to the OFFSET that was added to a pixel centre, passed in texels) */
+static _Thread_local float g_fetch_rel = 0.0f, g_fetch_abs = 0.0f; /* what the coordinate's INPUTS carry (set by the caller that knows) */
+static inline void margin_texel(float c, int size) {
+    if (!(c > 0.0f && c < (float)size)) return; /* clamped region: flat */
+    float fl = floorf(c), fr = c - fl;
+    float dlo = fl >= 1.0f ? fr : 3.0e38f;                      /* the boundary at fl exists unless it is the clamp at 0 */
+    float dhi = fl <= (float)(size - 2) ? 1.0f - fr : 3.0e38f;  /* the boundary at fl + 1 exists unless it is the clamp at size */
+    float scale = (4.0f * 1.1920929e-7f + g_fetch_rel) * fabsf(c) + g_fetch_abs;
+    margin_note(fminf(dlo, dhi) / fmaxf(scale, 1e-30f));
+}
 static inline int nearest_idx(float u, int size) {
     float c = u * (float)size;
+    margin_texel(c, size);
     int i;
     if (!(c > -2147483904.0f && c < 2147483648.0f)) i = INT_MIN;
     else i = (int)c;
@@ -328,7 +400,16 @@ static inline v3 sample_ggx_vndf(v3 V, float ax, float ay, float r1, float r2) {
     float t1 = r * cosf(phi), t2 = r * sinf(phi);
     float s = 0.5f * (1.0f + Vh.z);
     t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
-    float k = sqrtf(fmaxf(0.0f, 1.0f - t1 * t1 - t2 * t2));
+    float q = 1.0f - t1 * t1 - t2 * t2;
+    float k = sqrtf(fmaxf(0.0f, q));
+    /* ill-conditioning, not a branch: at blueNoise.r -> 1 the sample sits on the rim of the projected disk, q cancels to a few ulps and
+     * sqrt amplifies them: dk = dq / 2k (or sqrt(dq) at q ~ 0).  H carries that uncertainty into l = reflect(-V, H) (twice) and into
+     * every angle derived from it (calc_angles, where h = normalize(v + l) and v + l -> 0 for a rim sample: dot(V, H) -> 0). */
+    {
+        const float dq = 6e-7f; /* ~5 ulps of the O(1) terms */
+        float dk = q > dq ? dq / (2.0f * (sqrtf)(q)) : (sqrtf)(dq);
+        g_unc_dir = 2.0f * dk + 4e-7f;
+    }
     v3 Nh = add3(add3(mul3(T1, t1), mul3(T2, t2)), mul3(Vh, k));
     return normalize3(V3(ax * Nh.x, ay * Nh.y, fmaxf(0.0f, Nh.z)));
 }
@@ -373,6 +454,7 @@ static void k1_binary_search(const k1_ctx *c, v3 *dir, v3 *hitPos, float *u, flo
         k1_project(c, *hitPos, u, v);
         float z = k1_view_z(c, fetch_r32f(c->depth, d, *u, *v));
         float diff = z - hitPos->z;
+        margin_cmp(z, hitPos->z, MARGIN_REL_MARCH); /* :493 sign of diff */
         *dir = mul3(*dir, 0.5f);
         if (diff >= 0.0f) *hitPos = sub3(*hitPos, *dir); else *hitPos = add3(*hitPos, *dir);
     }
@@ -381,6 +463,7 @@ static void k1_binary_search(const k1_ctx *c, v3 *dir, v3 *hitPos, float *u, flo
 /* RayMarch ssgi.frag:441-475 */
 static void k1_ray_march(const k1_ctx *c, v3 *dir, v3 *hitPos, float random_b, float *u, float *v) {
     dims d = {c->W, c->H};
+    g_fetch_rel = MARGIN_REL_MARCH; /* the depth taps (and the history fetch at the hit) sit at the projected ray position */
     *dir = mul3(*dir, c->p->rayDistance / (float)c->p->steps);
     *u = 0.0f; *v = 0.0f;
     for (int i = 1; i < c->p->steps; i++) {
@@ -390,6 +473,8 @@ static void k1_ray_march(const k1_ctx *c, v3 *dir, v3 *hitPos, float random_b, f
         k1_project(c, *hitPos, u, v);
         float z = k1_view_z(c, fetch_r32f(c->depth, d, *u, *v));
         float diff = z - hitPos->z;
+        margin_cmp(z, hitPos->z, MARGIN_REL_MARCH);                                   /* :463 diff >= 0 */
+        margin_cmp(z - c->p->thickness, hitPos->z, MARGIN_REL_MARCH);                 /* :463 diff < thickness */
         if (diff >= 0.0f && diff < c->p->thickness) {
             if (c->p->refineSteps == 0) return;
             k1_binary_search(c, dir, hitPos, u, v);
@@ -464,6 +549,7 @@ static v3 k1_do_sample(const k1_ctx *c, const material *mat, v3 viewPos, v3 view
     *hitPos = viewPos;
     float cu, cv;
     k1_ray_march(c, l, hitPos, random.z, &cu, &cv);
+    /* (g_fetch_rel stays set for the history fetch below; k1_pixel resets it) */
     int allowMissed = c->p->missedRays != 0;
     int isMissed = hitPos->x == 10.0e9f;
     v3 env = k1_env_color(c, *l, roughness, isDiffuseSample, isEnvSample); /* black without an env map (:342-345) */
@@ -471,6 +557,8 @@ static v3 k1_do_sample(const k1_ctx *c, const material *mat, v3 viewPos, v3 view
     /* velocityTexture is never wired (SSGIPass.js:89) -> three's empty texture -> velocity = 0 */
     float ru = cu - 0.0f, rv = cv - 0.0f;
     v3 ssgi;
+    margin_cmp(ru, 0.0f, MARGIN_REL_MARCH); margin_cmp(ru, 1.0f, MARGIN_REL_MARCH);
+    margin_cmp(rv, 0.0f, MARGIN_REL_MARCH); margin_cmp(rv, 1.0f, MARGIN_REL_MARCH);
     if (ru >= 0.0f && ru <= 1.0f && rv >= 0.0f && rv <= 1.0f) {
         /* accumulatedTexture = denoiser.texture (SSGIPass.js:89): K4's / K2's RGBA32F target, or three's empty texture ("denoised") */
         v4 h = {0.f, 0.f, 0.f, 0.f};
@@ -497,6 +585,9 @@ static v3 k1_do_sample(const k1_ctx *c, const material *mat, v3 viewPos, v3 view
 }
 static inline void calc_angles(v3 l, v3 v, v3 n, float *NoL, float *NoH, float *LoH, float *VoH) { /* :93-100 */
     const float E = 0.00001f, OME = 1.0f - 0.00001f;
+    /* h = normalize(v + l): a direction error u in l turns h by u / |v + l|; the BRDF, pdf and Fresnel terms move by about as much.
+     * margin < 1: they may move by more than the 1e-3 tolerance */
+    margin_note(length3(add3(v, l)) * 1e-3f / g_unc_dir);
     v3 h = normalize3(add3(v, l));
     *NoL = clampf(dot3(n, l), E, OME);
     *NoH = clampf(dot3(n, h), E, OME);
@@ -556,6 +647,7 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
     v3 f0 = mix3(V3(0.04f, 0.04f, 0.04f), mat.diffuse, mat.metalness);
     v4 random = blue_noise(c->blue, x, y, p->blueNoiseIndex, u, v, (dims){c->outW, c->outH}); /* `resolution` = the render target's size */
     v3 Hh = sample_ggx_vndf(V, roughnessSq, roughnessSq, random.x, random.y);
+    margin_note(fabsf(Hh.z) / MARGIN_REL_SHORT); /* |H| = 1 */
     if (Hh.z < 0.0f) Hh = neg3(Hh);
     /* reflect(-V, H) = I - 2*dot(N,I)*N with I=-V */
     v3 I = neg3(V);
@@ -575,6 +667,7 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
         float invW = 1.0f / (diffW + specW);
         diffW *= invW;
         isDiffuseSample = random.z < diffW;
+        margin_cmp(random.z, diffW, MARGIN_REL_SHORT); /* :186 */
     }
     /* importanceSampling :197-216 */
     float emsPdf = 1.0f;
@@ -605,6 +698,7 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
         prob *= mat.roughness;
         prob = fminf(1.0f - 0.00001f, prob);
         isEnvSample = random.w < prob;
+        margin_cmp(random.w, prob, MARGIN_REL_SHORT);
         if (isEnvSample) {
             emsPdf /= 1.0f - prob;
             l = envMisDir;
@@ -613,6 +707,8 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
             emsPdf = 1.0f - prob;
         }
     }
+    float unc_spec = g_unc_dir;
+    g_unc_dir = 4e-7f; /* the cosine-hemisphere and environment directions are well conditioned */
     v3 diffuseRay = isEnvSample ? envMisDir : cosine_sample_hemisphere(viewNormal, random.x, random.y);
     v3 specularRay = isEnvSample ? envMisDir : l;
     v3 diffuseGI = V3(0, 0, 0), specularGI = V3(0, 0, 0), hitPos = V3(0, 0, 0);
@@ -631,6 +727,7 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
         diffuseGI = gi; /* mix(0, gi, 1/1) */
     }
     l = specularRay; /* :246-265 */
+    g_unc_dir = isEnvSample ? 4e-7f : unc_spec;
     calc_angles(l, vv, n, &NoL, &NoH, &LoH, &VoH);
     {
         v3 gi = k1_do_sample(c, &mat, viewPos, viewNormal, mat.metalness, roughnessSq, isDiffuseSample, isEnvSample, NoV, NoL, NoH, LoH, VoH, random,
@@ -762,7 +859,11 @@ int rfxo_ssgi(int W, int H, int y0, int y1, const float *depth, const uint32_t *
     c.cameraFar = p->camera.far_;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = y0; y < y1; y++)
-        for (int x = 0; x < oW; x++) k1_pixel(&c, x, y, out + 4 * ((size_t)y * oW + x));
+        for (int x = 0; x < oW; x++) {
+            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
+            k1_pixel(&c, x, y, out + 4 * ((size_t)y * oW + x));
+            if (g_margin_plane) g_margin_plane[(size_t)y * oW + x] = g_margin;
+        }
     return 0;
 }
 
@@ -795,6 +896,8 @@ static inline v3 ss_to_ws(float u, float v, float depth, const float *matWorld, 
 }
 /* validateReprojectedUV reproject.frag:130-167 (angleMix/lastViewAngle are dead) */
 static float k2_validate(const k2_ctx *c, float ru, float rv, v3 worldPos, v3 worldNormal, float depth) {
+    margin_cmp(ru, 0.0f, MARGIN_REL_SHORT); margin_cmp(ru, 1.0f, MARGIN_REL_SHORT);
+    margin_cmp(rv, 0.0f, MARGIN_REL_SHORT); margin_cmp(rv, 1.0f, MARGIN_REL_SHORT);
     if (ru > 1.0f || ru < 0.0f || rv > 1.0f || rv < 0.0f) return 0.0f;
     float lvx, lvy, lastDepth; v3 lastN;
     k2_vnd(c, ru, rv, &lvx, &lvy, &lastN, &lastDepth); /* samples the CURRENT velocity texture */
@@ -900,6 +1003,7 @@ static void k2_pixel(const k2_ctx *c, int x, int y, float *out0, float *out1) {
     if (p->inputType == 0 || p->inputType == 2) {
         /* reprojectHitPoint reproject.frag:169-193 */
         float hu, hv;
+        margin_cmp(curvature, 0.05f, MARGIN_REL_SHORT);
         if (curvature > 0.05f || rayLength < 0.01f) { hu = -1.0f; hv = -1.0f; }
         else {
             v3 camPos = V3(p->camera.position[0], p->camera.position[1], p->camera.position[2]);
@@ -914,9 +1018,11 @@ static void k2_pixel(const k2_ctx *c, int x, int y, float *out0, float *out1) {
                                         A[3 * 4 + row] * Bm[col * 4 + 3];
             v4 r = mat_mul_v4(PV, hp.x, hp.y, hp.z, 1.0f);
             hu = (r.x / r.w) * 0.5f + 0.5f; hv = (r.y / r.w) * 0.5f + 0.5f;
+            g_fetch_rel = MARGIN_REL_SHORT; /* the validation fetch sits at a projected point (normalize, two matrix products, a division) */
         }
         rs[0] = hu; rs[1] = hv;
         rs[2] = k2_validate(c, hu, hv, worldPos, worldNormal, depth);
+        g_fetch_rel = 0.0f;
         if (rs[0] == -1.0f) { rs[0] = rd[0]; rs[1] = rd[1]; rs[2] = rd[2]; }
     }
     float moveFactor = fminf((velx * velx + vely * vely) * 10000.0f, 1.0f);
@@ -989,7 +1095,9 @@ int rfxo_temporal(int W, int H, int y0, int y1, const uint32_t *ssgi, const uint
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < W; x++) {
             size_t o = 4 * ((size_t)y * W + x);
+            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
             k2_pixel(&c, x, y, out0 + o, out1 ? out1 + o : NULL);
+            if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
         }
     return 0;
 }
@@ -1054,6 +1162,8 @@ static void k3_pixel(const k3_ctx *c, int x, int y, uint16_t *out0, uint16_t *ou
     for (int k = 0; k < 8; k++) {
         float ox = POI[k][0] / (float)c->W, oy = POI[k][1] / (float)c->H;
         float nu = u + (m00 * ox + m10 * oy), nv = v + (m01 * ox + m11 * oy);
+        /* the tap offset is r * flatness * (cos, sin)(angle) * POISSON[k]: sin/cos/sqrt carry ~1e-6 of an offset of up to `reach` texels */
+        g_fetch_abs = 4e-6f * (r * fmaxf((float)c->W / (float)c->H, (float)c->H / (float)c->W) + 1.0f);
         /* getBasicNeighborWeight :52-78 */
         float wBasic;
         {
@@ -1076,6 +1186,7 @@ static void k3_pixel(const k3_ctx *c, int x, int y, uint16_t *out0, uint16_t *ou
             float lumaDiff = fminf(fabsf(L[i] - k3_lum(tl)), 0.5f);
             float lumaFactor = expf(-lumaDiff * p->lumaPhi);
             w = mixf(w * lumaFactor, disocclW, w_age[i]) * w_age[i];
+            margin_cmp(w, 0.0001f, MARGIN_REL_WEIGHT);
             w *= (w < 0.0001f) ? 0.0f : 1.0f; /* step(0.0001, w) */
             rgb[i] = add3(rgb[i], mul3(tl, w));
             tw[i] += w;
@@ -1097,7 +1208,9 @@ int rfxo_denoise(int W, int H, int y0, int y1, const float *depth, const uint32_
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < W; x++) {
             size_t o = 4 * ((size_t)y * W + x);
+            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
             k3_pixel(&c, x, y, out0 + o, out1 ? out1 + o : NULL);
+            if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
         }
     return 0;
 }
@@ -1115,6 +1228,8 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < W; x++) {
+            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
+            if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
             float u = ((float)x + 0.5f) / (float)W, v = ((float)y + 0.5f) / (float)H;
             float dep = fetch_r32f(depth, d, u, v);
             int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
@@ -1147,11 +1262,13 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
             onb(N, &T, &B);
             V = V3(dot3(V, T), dot3(V, B), dot3(V, N));
             v3 Hh = sample_ggx_vndf(V, roughness, roughness, 0.25f, 0.25f);
+            margin_note(fabsf(Hh.z) / MARGIN_REL_SHORT);
             if (Hh.z < 0.0f) Hh = neg3(Hh);
             v3 I = neg3(V);
             v3 l = normalize3(sub3(I, mul3(Hh, 2.0f * dot3(Hh, I))));
             l = add3(add3(mul3(T, l.x), mul3(B, l.y)), mul3(N, l.z));
             l = normalize3(v4_mul_mat_xyz(C, l, 1.0f)); /* vec4(l, 1.) quirk :81 */
+            margin_note(fabsf(dot3(viewNormal, l)) / (MARGIN_REL_SHORT * fmaxf(length3(viewNormal), 1e-30f)));
             if (dot3(viewNormal, l) < 0.0f) l = neg3(l);
             v3 h = normalize3(add3(vv, l));
             float VoH = fmaxf(1e-6f, dot3(vv, h)); /* EPSILON from <common> */
@@ -1169,6 +1286,7 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
             o[1] = diffuseC.y + specC.y + mat.emissive.y;
             o[2] = diffuseC.z + specC.z + mat.emissive.z;
             o[3] = 1.0f;
+            if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
         }
     return 0;
 }

@@ -40,6 +40,39 @@ def lib():
     return _lib
 
 
+class margins:
+    """with margins(H, W) as m: O.ssgi(...)  ->  m.plane[y, x] = the smallest normalised distance of the fragment's decisions to a
+    discontinuity (rfx_oracle.c "discontinuity margins"); < 1: the fragment may legitimately flip between two correct implementations."""
+
+    def __init__(self, H, W):
+        self.plane = np.full((H, W), 3.0e38, np.float32)
+
+    def __enter__(self):
+        lib().rfxo_set_margin_plane(_p(self.plane))
+        return self
+
+    def __exit__(self, *exc):
+        lib().rfxo_set_margin_plane(None)
+        return False
+
+
+class perturbation:
+    """with perturbation(seed): every exp/log/pow/sqrt/sin/cos/atan result of the oracle is moved by (1 +- rel) (sin/cos/atan also by
+    +- abs), signs drawn per call from a per-fragment generator seeded with `seed` (rfx_oracle.c "perturbed primitives")."""
+    REL, ABS = 6e-6, 2e-7  # the reference GL's measured worst case (probe_transcendentals.py); hardware forms are ~1 ulp
+
+    def __init__(self, seed, rel=None, abs_=None):
+        self.args = (int(seed), float(self.REL if rel is None else rel), float(self.ABS if abs_ is None else abs_))
+
+    def __enter__(self):
+        lib().rfxo_set_perturbation(C.c_uint32(self.args[0]), C.c_float(self.args[1]), C.c_float(self.args[2]))
+        return self
+
+    def __exit__(self, *exc):
+        lib().rfxo_set_perturbation(C.c_uint32(0), C.c_float(0.0), C.c_float(0.0))
+        return False
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 

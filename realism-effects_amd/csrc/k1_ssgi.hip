@@ -5,15 +5,16 @@
 //
 // One pixel per lane, 64x4-pixel workgroups: the G-buffer / direct-light / output planes are read and
 // written as coalesced 16 B/lane rows.  The march's depth taps are data-dependent gathers anywhere on
-// screen; three things keep them off the HBM/fabric path:
+// screen; two things keep them off the HBM/fabric path:
 //   * k1_prepare (one streaming pre-pass per draw) converts the depth plane to VIEW-SPACE Z once per texel
-//     (the same IEEE expression every tap would evaluate, ssgi_utils.frag:9) and reduces it to an 8x8-cell
-//     (min, max) table that stays resident in every XCD's L2 (1 MiB at 4K);
+//     (the same IEEE expression every tap would evaluate, ssgi_utils.frag:9) and reduces it to exact
+//     16x16-texel (min, max) cells, which k1_pack_cells folds into a table of half-packed cells small
+//     enough (<= 32 KiB; 4K: 32-texel cells) to stay resident in every CU's L1;
 //   * every tap first consults its cell: when the cell's range proves the texel cannot satisfy
 //     `0 <= z - hitPos.z < thickness` (RayMarch :463) — or fixes the sign BinarySearch tests (:493) — the
 //     exact texel is never fetched.  The decision is exact, not approximate: fp subtraction is monotonic,
-//     so the cell bounds bound the per-texel difference;
-//   * workgroups are mapped to XCDs by image band, so an XCD's L2 holds the neighbourhood its rays visit.
+//     so the cell bounds bound the per-texel difference.
+// Workgroups take tiles in launch order (a band-per-XCD mapping measured slower: sky bands idle their XCD).
 #include "rfx_brdf.h"
 #include "rfx_kernels.h"
 
@@ -23,11 +24,8 @@ namespace {
 // DOWN and max rounded UP, so a widened range can only reject fewer taps — the rejection tests stay exact.  The cell edge is
 // 2^cell_shift texels, chosen per frame size so that the whole table stays <= 32 KiB (rfx_api; 4K: 32-texel cells): it then lives
 // in the CUs' L1 and a lookup costs what an LDS read costs.  Measured at 4K (same box, bit-identical output): 8-texel float2
-// cells (1 MiB) 0.789 ms, half cells 0.749, 16-texel 0.727, 32/64-texel 0.694-0.712; an LDS copy per workgroup (RFX_K1_LDS=1,
-// table <= 16 KiB) 0.700 — no better than the cached global lookup, so it is off.
-#ifndef RFX_K1_LDS
-#define RFX_K1_LDS 0
-#endif
+// cells (1 MiB) 0.789 ms, half cells 0.749, 16-texel 0.727, 32/64-texel 0.694-0.712; a per-workgroup LDS copy of the table
+// measured 0.700 — no better than the cached global lookup, so there is none.
 constexpr int BASE = 16;  // edge of the pre-pass's exact (float) cells, reduced to the final cells by k1_pack_cells
 typedef uint32_t k1_cell_t;
 RFX_DEV uint32_t k1_half_toward(float v, bool up) {  // nearest half not below (up) / not above (!up) v
@@ -49,7 +47,7 @@ RFX_DEV float2 k1_cell_load(const k1_cell_t *t, unsigned int i) {
 struct MarchCtx {
     const float *P;            // projectionMatrix (column-major)
     const float *viewz;        // full-frame view-space Z plane (k1_prepare)
-    const k1_cell_t *coarse;   // (min, max) view Z per 2^cell_shift-texel cell (LDS copy, or global)
+    const k1_cell_t *coarse;   // (min, max) view Z per 2^cell_shift-texel cell
     int coarse_w, cell_shift;
     float rayDistance, thickness;
     int steps, refineSteps;
@@ -115,22 +113,13 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
     for (int i = 1; i < m.steps && (rays[0].active || rays[1].active); i++) {
         const float t = (float)i + random_b - 0.5f;
         const float cs = 1.0f - rfx_exp(-0.25f * (t * t));
-#ifndef RFX_K1_UNCOND
-#define RFX_K1_UNCOND 1  // measured 0.654 vs 0.666 ms at 4K, same texels
-#endif
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-#if RFX_K1_UNCOND
             // straight-line: a stopped ray keeps its position (select) and re-derives the same uv — no exec-mask region per ray
+            // (measured 0.654 vs 0.666 ms at 4K, same texels)
             const float3 np = rays[r].pos + rays[r].dir * cs;
             rays[r].pos = make_float3(rays[r].active ? np.x : rays[r].pos.x, rays[r].active ? np.y : rays[r].pos.y, rays[r].active ? np.z : rays[r].pos.z);
             rays[r].uv = k1_project<PERSP>(m, rays[r].pos);
-#else
-            if (rays[r].active) {
-                rays[r].pos = rays[r].pos + rays[r].dir * cs;
-                rays[r].uv = k1_project<PERSP>(m, rays[r].pos);
-            }
-#endif
         }
         // taps of both rays in flight together: the two coarse cells first, then the exact texels of the cells that cannot
         // rule a hit out (a hit needs 0 <= z - h < thickness; the cell range rules it out when max - h < 0 or min - h >= thickness)
@@ -368,10 +357,6 @@ RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat
     return ssgi;
 }
 
-#if RFX_K1_LDS
-extern __shared__ uint4 k1_lds[];  // the (min, max) table
-#endif
-
 // STAGE 0: the whole fragment in one launch.  STAGE 1 ("trace") stops after the march and leaves the two rays' end state in
 // A.hits (2 x float4 per pixel: uv0 uv1 | pos0.x pos1.xyz); STAGE 2 ("shade") redoes the cheap per-pixel setup, takes the rays
 // from A.hits instead of marching and finishes the fragment.  Only the shading reads last frame's composed GI anywhere on
@@ -379,12 +364,8 @@ extern __shared__ uint4 k1_lds[];  // the (min, max) table
 // Same arithmetic in the same order either way (no contraction in this file): split == fused bit for bit (tests).
 template <bool PERSP, bool ENV, bool MIS, int STAGE>
 RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
-    // XCD-aware mapping: hardware block b runs on XCD b % 8 (observed, used for speed only); give XCD k the k-th
-    // contiguous eighth of the row-major tile list, i.e. an image band, so its L2 sees a compact part of the depth plane
-    const int nbx = (A.out_w + 63) / 64, nblocks = gridDim.x;
-    const int per = (nblocks + 7) / 8;
-    const int lb = A.xcd_map ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
-    if (lb >= nblocks) return;
+    const int nbx = (A.out_w + 63) / 64;
+    const int lb = blockIdx.x;
     const int x = (lb % nbx) * 64 + threadIdx.x;
     const int y = A.y0 + (lb / nbx) * 4 + threadIdx.y;
     if (x >= A.out_w || y >= A.y1) return;
@@ -413,11 +394,7 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     MarchCtx m;
     m.P = P;
     m.viewz = A.viewz;
-#if RFX_K1_LDS
-    m.coarse = reinterpret_cast<const k1_cell_t *>(k1_lds);
-#else
     m.coarse = (const k1_cell_t *)A.cells;
-#endif
     m.coarse_w = A.cells_w;
     m.cell_shift = A.cell_shift;
     m.rayDistance = p.rayDistance;
@@ -553,13 +530,6 @@ template <bool PERSP, bool ENV, bool MIS, int STAGE>
 __global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-#if RFX_K1_LDS
-    if (STAGE != 2) {  // every lane takes part, before any early exit
-        const uint4 *src = (const uint4 *)A.cells;
-        for (int i = threadIdx.y * 64 + threadIdx.x; i < A.cells_vec4; i += 256) k1_lds[i] = src[i];
-        __syncthreads();
-    }
-#endif
     k1_ssgi_march_body<PERSP, ENV, MIS, STAGE>(A, d);
     rfx_flush_violations(d);
 }
@@ -667,16 +637,15 @@ hipError_t rfx_launch_k1_prepare(const K1Args &A, hipStream_t stream) {
 hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
     const int nbx = (A.out_w + 63) / 64, nby = (A.y1 - A.y0 + 3) / 4;
     const int nblocks = nbx * nby;
-    const size_t lds = (RFX_K1_LDS && stage != 2) ? (size_t)A.cells_vec4 * 16 : 0;
-    dim3 block(64, 4), grid(((nblocks + 7) / 8) * 8);
+    dim3 block(64, 4), grid(nblocks);
     const float *P = A.p.camera.projectionMatrix;
     const bool persp = P[1] == 0.f && P[2] == 0.f && P[3] == 0.f && P[4] == 0.f && P[6] == 0.f && P[7] == 0.f && P[12] == 0.f && P[13] == 0.f &&
                        P[15] == 0.f && P[11] == -1.f;
     const bool env = A.p.useEnvMap != 0, mis = env && A.p.importanceSampling != 0;
 #define K1_GO(P, E, M)                                                                                   \
     do {                                                                                                 \
-        if (stage == 0) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 0>), grid, block, lds, stream, A);      \
-        else if (stage == 1) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 1>), grid, block, lds, stream, A); \
+        if (stage == 0) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 0>), grid, block, 0, stream, A);      \
+        else if (stage == 1) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 1>), grid, block, 0, stream, A); \
         else hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 2>), grid, block, 0, stream, A);                 \
     } while (0)
     if (persp) { if (mis) K1_GO(true, true, true); else if (env) K1_GO(true, true, false); else K1_GO(true, false, false); }

@@ -14,19 +14,10 @@
 
 namespace {
 
-#ifndef RFX_K2_TH
-#define RFX_K2_TH 4
+#ifndef RFX_K2_XCD_G
+#define RFX_K2_XCD_G 8  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major
 #endif
-#ifndef RFX_K2_SCHED
-#define RFX_K2_SCHED 0
-#endif
-#ifndef RFX_K2_FENCE
-#define RFX_K2_FENCE 0
-#endif
-#ifndef RFX_K2_WAVES
-#define RFX_K2_WAVES 0
-#endif
-constexpr int TW = 64, TH = RFX_K2_TH, AP = 2;    // tile, apron (neighbourhood radius <= 2)
+constexpr int TW = 64, TH = 4, AP = 2;    // tile, apron (neighbourhood radius <= 2)
 constexpr int LW = TW + 2 * AP, LH = TH + 2 * AP;  // 68 x 8 staged texels
 constexpr int NT = TW * TH;
 
@@ -94,10 +85,7 @@ RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &te
     // (40 VGPRs, 147 in total -> 3 waves/SIMD); fenced, the kernel fits 125 VGPRs -> 4 waves/SIMD: 0.48 -> 0.445 ms, same texels.
     // (Ablation, same build: one tap instead of five 0.316 ms / 74 VGPRs, no history fetch 0.272, no neighbourhood AABB 0.467,
     // staging + reprojection alone 0.176 — the five-tap fetch is 38 % of K2, by arithmetic and registers, not by its addresses.)
-#ifndef RFX_K2_TAPSEQ
-#define RFX_K2_TAPSEQ 2  // a barrier after every n-th tap (1, 2 and 3 compile to the same 125 VGPRs); 0: none
-#endif
-#define K2_TAP_FENCE(k) do { if (RFX_K2_TAPSEQ && ((k) % RFX_K2_TAPSEQ) == 0) asm volatile("" ::: "memory"); } while (0)
+#define K2_TAP_FENCE(k) do { if (((k) % 2) == 0) asm volatile("" ::: "memory"); } while (0)  // after every 2nd tap (1, 2, 3 compile alike)
     const float4 Ct = k2_history_tap<HIST_F32>(tex, d, S1[0], S0[1]);
     K2_TAP_FENCE(1);
     const float4 Cl = k2_history_tap<HIST_F32>(tex, d, S0[0], S1[1]);
@@ -148,7 +136,9 @@ template <int INPUT_TYPE, int TC, bool LOGT, bool HIST_F32>
 RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
     __shared__ Tile s;
     const rfx_temporal_params &p = A.p;
-    const int tx0 = blockIdx.x * TW, ty0 = A.y0 + blockIdx.y * TH;
+    const TileXY tile = rfx_xcd_tile<RFX_K2_XCD_G>((d.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH);
+    if (!tile.valid) return;  // grid padding (uniform per workgroup, before the barrier)
+    const int tx0 = tile.bx * TW, ty0 = A.y0 + tile.by * TH;
     const int tid = threadIdx.y * TW + threadIdx.x;
 
     // ---- stage tile + apron (out-of-frame texels are never addressed: CLAMP_TO_EDGE is applied first)
@@ -246,13 +236,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
         // reproject() :83-122.  The 5 bilinear history fetches of THIS texture (sampleReprojectedTexture, reproject.frag:257-263)
         // are issued here, ahead of the LDS neighbourhood reduction that hides their latency; fetching both textures' taps
         // up front held 80 VGPRs of texels and capped the kernel at one workgroup per CU.
-#if RFX_K2_FENCE
-        if (i) asm volatile("" ::: "memory");  // keep texture 1's 20 history texels out of flight while texture 0 is reduced
-#endif
         const float4 acc = k2_bicubic<HIST_F32>(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
-#if RFX_K2_SCHED
-        __builtin_amdgcn_sched_barrier(0);  // consume the 20 history texels (40 VGPRs) before the neighbourhood's LDS texels are fetched
-#endif
         float3 accrgb = k2_to_log<LOGT>(make_float3(acc.x, acc.y, acc.z));
         float acca = acc.w;
         const float4 inp = s.tex[i][ci];  // preprocessInput :124-128 (an unsampled texel was staged with NaN rgb: !(NaN >= 0))
@@ -271,10 +255,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
             float3 mni = ic, mxi = ic;
             float3 mno = make_float3(qnan, qnan, qnan), mxo = mno;
             const float4 *nt = (INPUT_TYPE == 0 && spec) ? s.tex[1] : s.tex[0];
-#ifndef RFX_K2_UNROLL_Y
-#define RFX_K2_UNROLL_Y 5
-#endif
-#pragma unroll RFX_K2_UNROLL_Y
+#pragma unroll
             for (int oy = 0; oy < 5; oy++) {  // one row of five 12-byte LDS reads in flight at a time
                 const int nrow = __mul24(min(max(y + oy - 2, 0), d.H - 1) - ty0 + AP, LW);  // CLAMP_TO_EDGE row, as an LDS offset
                 const float4 t0 = nt[nrow + nxo[0]], t1 = nt[nrow + nxo[1]], t2 = nt[nrow + nxo[2]], t3 = nt[nrow + nxo[3]], t4 = nt[nrow + nxo[4]];
@@ -335,11 +316,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
 }
 
 template <int INPUT_TYPE, int TC, bool LOGT, bool HIST_F32>
-#if RFX_K2_WAVES
-__global__ __launch_bounds__(NT, RFX_K2_WAVES) void k2_temporal_reproject(K2Args A) {
-#else
 __global__ __launch_bounds__(NT) void k2_temporal_reproject(K2Args A) {
-#endif
     FrameDims d = A.dims;
     d.viol = 0;
     k2_body<INPUT_TYPE, TC, LOGT, HIST_F32>(A, d);
@@ -372,7 +349,7 @@ hipError_t rfx_launch_copy_fb(const FrameDims &d, int y0, int y1, TexView src, T
 }
 
 hipError_t rfx_launch_k2(const K2Args &A, hipStream_t stream) {
-    dim3 block(TW, TH), grid((A.dims.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH);
+    dim3 block(TW, TH), grid(rfx_xcd_grid(RFX_K2_XCD_G, (A.dims.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH));
     const bool lt = A.p.logTransform != 0;
 #define K2_LAUNCH(IT, TC)                                                                                                   \
     do {                                                                                                                    \

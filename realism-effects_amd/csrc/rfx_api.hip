@@ -427,9 +427,14 @@ int rfx_set_environment_importance(rfx_ctx *c, const float *marginal, const floa
         c->env_marginal = c->env_conditional = nullptr;
         return fail(c, RFX_ENOMEM, "hipMalloc(environment importance tables)", e);
     }
-    HIPCHK(c, hipMemcpyAsync(c->env_marginal, marginal, (size_t)c->env_h * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->env_conditional, conditional, (size_t)c->env_w * c->env_h * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    e = hipMemcpyAsync(c->env_marginal, marginal, (size_t)c->env_h * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->env_conditional, conditional, (size_t)c->env_w * c->env_h * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {  // tables with undefined contents must not pass the importanceSampling validation
+        hipFree(c->env_marginal); hipFree(c->env_conditional);
+        c->env_marginal = c->env_conditional = nullptr;
+        return fail(c, RFX_EDEVICE, "rfx_set_environment_importance: copying the tables", e);
+    }
     c->env_sum_whole = totalSumWhole; c->env_sum_decimal = totalSumDecimal;
     return RFX_OK;
 }
@@ -493,25 +498,28 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
     A.coarse_w = (c->W + base - 1) / base;
     A.coarse_h = (c->H + base - 1) / base;
     // the march's table is kept L1-sized: double the cell edge until it is <= 32 KiB (4K: 32-texel cells, 31.9 KiB)
-    static const int lds_budget = getenv("RFX_K1_TABLE_BYTES") ? atoi(getenv("RFX_K1_TABLE_BYTES")) : 32768;
+    const int table_budget = 32768;
     for (A.cell_shift = 4;; A.cell_shift++) {
         A.cells_w = (c->W + (1 << A.cell_shift) - 1) >> A.cell_shift;
         A.cells_h = (c->H + (1 << A.cell_shift) - 1) >> A.cell_shift;
         A.cells_vec4 = (A.cells_w * A.cells_h + 3) / 4;
-        if ((size_t)A.cells_vec4 * 16 <= (size_t)lds_budget || A.cell_shift >= 12) break;
+        if ((size_t)A.cells_vec4 * 16 <= (size_t)table_budget || A.cell_shift >= 12) break;
     }
     if (!c->viewz) {
         hipError_t e = hipMalloc((void **)&c->viewz, (size_t)c->W * c->H * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&c->coarse, (size_t)A.coarse_w * A.coarse_h * sizeof(float2));
         if (e == hipSuccess) e = hipMalloc((void **)&c->cells, (size_t)A.cells_vec4 * 16);
-        if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(K1 scratch)", e);
+        if (e != hipSuccess) {  // all three or none: a later draw must not find viewz set and the tables missing
+            if (c->viewz) hipFree(c->viewz);
+            if (c->coarse) hipFree(c->coarse);
+            if (c->cells) hipFree(c->cells);
+            c->viewz = nullptr; c->coarse = nullptr; c->cells = nullptr;
+            return fail(c, RFX_ENOMEM, "hipMalloc(K1 scratch)", e);
+        }
     }
     A.viewz = c->viewz;
     A.coarse = c->coarse;
     A.cells = c->cells;
-    // band-per-XCD mapping measured SLOWER (1.33 vs 0.99 ms at 4K): sky bands finish early and idle their XCD
-    static const int xcd = getenv("RFX_K1_XCD") ? atoi(getenv("RFX_K1_XCD")) : 0;
-    A.xcd_map = xcd;
     A.env = c->env;
     A.env_w = c->env_w; A.env_h = c->env_h; A.env_levels = c->env_levels;
     A.env_marginal = c->env_marginal; A.env_conditional = c->env_conditional;
@@ -626,8 +634,6 @@ int rfx_poisson_denoise(rfx_ctx *c, const rfx_denoise_params *p) {
     blue_noise_shift(p->blueNoiseIndex, &A.shift_x, &A.shift_y);
     A.out0 = wview(c, out0); A.out1 = wview(c, out1);
     A.p = *p;
-    static const int force_generic = getenv("RFX_K3_GENERIC") ? atoi(getenv("RFX_K3_GENERIC")) : 0;
-    A.force_generic = force_generic;
     HIPCHK(c, rfx_launch_k3(A, c->stream));
     return RFX_OK;
 }

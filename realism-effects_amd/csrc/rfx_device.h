@@ -42,6 +42,38 @@ RFX_DEV void rfx_flush_violations(const FrameDims &d) {
     if (d.viol && d.halo_violations) atomicAdd(d.halo_violations, 1u);
 }
 
+// ---------------------------------------------------------------- XCD-aware tile order (speed only, never correctness)
+// The LDS-tiled kernels (K2, K3) re-read an apron around every tile: 1.8-2.4 staged texels per produced pixel.  Hardware block
+// b runs on XCD b % 8 (observed; MI355X_MICROARCH.md "Workgroup dispatch"), each XCD has its own 4 MiB L2, so with a plain 2-D
+// grid the eight neighbours of a tile sit on other XCDs and every apron texel crosses the fabric once per tile that stages it.
+// Here a 1-D grid is folded so that XCD k owns every 8th GROUP of G tile rows, and walks a group column by column (down the G
+// rows first): the 64-96 workgroups resident on an XCD at any time then cover a compact G x ~20-tile patch whose shared apron
+// texels are L2 hits, while groups of all image regions stay interleaved over the XCDs (a band-per-XCD split idles the XCDs that
+// own sky).  The launch pads the grid to 8 * ceil(groups / 8) * G * nbx blocks; a block whose tile row is past the end returns.
+struct TileXY { int bx, by; bool valid; };
+template <int G>
+RFX_DEV TileXY rfx_xcd_tile(int nbx, int nby) {
+    TileXY t;
+    if (G <= 0) {  // plain row-major order over a 1-D grid
+        t.by = blockIdx.x / nbx; t.bx = blockIdx.x - t.by * nbx;
+        t.valid = t.by < nby;
+        return t;
+    }
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_group = G * nbx;
+    const int gi = slot / per_group, within = slot - gi * per_group;
+    const int group = gi * 8 + xcd;
+    t.bx = within / G;
+    t.by = group * G + (within - t.bx * G);
+    t.valid = t.by < nby;
+    return t;
+}
+inline int rfx_xcd_grid(int G, int nbx, int nby) {
+    if (G <= 0) return nbx * nby;
+    const int groups = (nby + G - 1) / G;
+    return 8 * ((groups + 7) / 8) * G * nbx;
+}
+
 // nearest CLAMP_TO_EDGE index as x86 cvttss2si + clamp computes it:
 // NaN and |c| >= 2^31 give INT_MIN -> texel 0 (AMD's v_cvt_i32_f32 would saturate to size-1).
 RFX_DEV int rfx_nearest_idx(float u, float fsize, int size) {

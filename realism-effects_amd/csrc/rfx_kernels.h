@@ -20,7 +20,6 @@ struct K1Args {
     int coarse_w, coarse_h;
     unsigned int *cells;  // the march's table: two halfs per 2^cell_shift-texel cell, padded to whole uint4s (k1_pack_cells)
     int cells_w, cells_h, cell_shift, cells_vec4;
-    int xcd_map;  // band-per-XCD block mapping (development switch RFX_K1_NO_XCD=1 turns it off)
     // scene.environment: all mip levels as float4 texels, level l (max(w>>l,1) x max(h>>l,1)) at env + env_off[l]
     const float4 *env;
     int env_w, env_h, env_levels;
@@ -55,7 +54,6 @@ struct K3Args {
     int shift_x, shift_y;
     TexViewW out0, out1;
     rfx_denoise_params p;
-    int force_generic;  // development switch (env RFX_K3_GENERIC=1): use the untiled kernel for any radius
     struct { int Rx, Ry, LW, LH; } tile;  // filled by the launcher
     float tap_ox[8], tap_oy[8];           // POISSON[k] / resolution, filled by the launcher
 };

@@ -82,9 +82,11 @@ class Renderer {
 		addon.upload(this._h, tex, array, row0, rows)
 	}
 
-	// a dumped FULL-FRAME plane: the slot takes the band it holds; an already resident plane is not re-sent
-	uploadPlane(tex, plane) {
-		if (this._resident[tex] === plane) return
+	// a dumped FULL-FRAME plane: the slot takes the band it holds.  Every call uploads (the reference re-renders its raster passes every
+	// frame) unless the dump declares itself unchanged (frame.static): then an already resident plane object is not re-sent — opt-in,
+	// because a buffer refilled in place is the same object with new texels
+	uploadPlane(tex, plane, isStatic) {
+		if (isStatic && this._resident[tex] === plane) return
 		const held = this.heldRows(tex)
 		const per = FORMAT[tex][1] * this.width
 		const band = plane.length === held[1] * per ? plane : plane.subarray(held[0] * per, (held[0] + held[1]) * per)

@@ -111,12 +111,14 @@ def didCameraMove(camera, last_position, last_quaternion) -> bool:
     return 2 * math.acos(d) > 0.001  # Quaternion.angleTo
 
 
-def _upload_plane(renderer, tex, plane):
-    """Hand one dumped full-frame plane to the device (the slot takes the band it holds).  A plane
-    object that is already resident (same ndarray as last time) is not sent again — the dump is
-    the "render" of the raster passes, re-rendering an unchanged scene changes nothing."""
+def _upload_plane(renderer, tex, plane, static=False):
+    """Hand one dumped full-frame plane to the device (the slot takes the band it holds).  The reference re-renders its raster passes
+    every frame; so does this — every call uploads — unless the dump DECLARES itself unchanged (`scene.frame.static = True`): then a
+    plane object that is already resident (same ndarray as last time) is not sent again.  Opt-in because identity says nothing about
+    contents: a caller that refills a preallocated buffer in place (the normal per-frame dump loop) hands over the same object every
+    frame with new texels in it."""
     cache = renderer.__dict__.setdefault("_resident_planes", {})
-    if cache.get(tex) is plane:
+    if static and cache.get(tex) is plane:
         return
     r0, n = renderer.held_rows(tex)
     if plane.shape[0] == n:  # the caller dumped exactly the band this tile holds
@@ -126,10 +128,10 @@ def _upload_plane(renderer, tex, plane):
     cache[tex] = plane
 
 
-def _pack_planes(renderer, tex, aov, depth, pack):
-    """Device-side packing of a dumped frame's attribute planes into `tex` (once per aov object, like _upload_plane)."""
+def _pack_planes(renderer, tex, aov, depth, pack, static=False):
+    """Device-side packing of a dumped frame's attribute planes into `tex` (skipped only for a `static` frame's resident aov, like _upload_plane)."""
     cache = renderer.__dict__.setdefault("_resident_planes", {})
-    if cache.get(tex) is aov:
+    if static and cache.get(tex) is aov:
         return
     r0, n = renderer.held_rows(tex)
     full = depth.shape[0] != n  # the caller dumped the whole frame: hand over the band this tile holds
@@ -151,11 +153,11 @@ class GBufferPass:
 
     def render(self, renderer):
         f = self._scene.frame
-        _upload_plane(renderer, abi.TEX_DEPTH, f.depth)
+        _upload_plane(renderer, abi.TEX_DEPTH, f.depth, getattr(f, "static", False))
         if getattr(f, "gbuffer", None) is not None:
-            _upload_plane(renderer, abi.TEX_GBUFFER, f.gbuffer)
+            _upload_plane(renderer, abi.TEX_GBUFFER, f.gbuffer, getattr(f, "static", False))
         else:  # an engine dump of UNPACKED attribute planes: the device packs them (rfx_pack_gbuffer = the pass's fragment epilogue)
-            _pack_planes(renderer, abi.TEX_GBUFFER, f.aov, f.depth, renderer.pack_gbuffer)
+            _pack_planes(renderer, abi.TEX_GBUFFER, f.aov, f.depth, renderer.pack_gbuffer, getattr(f, "static", False))
 
     def dispose(self):
         pass
@@ -179,9 +181,9 @@ class VelocityDepthNormalPass:
     def render(self, renderer):
         f = self._scene.frame
         if getattr(f, "velocity", None) is not None:
-            _upload_plane(renderer, abi.TEX_VELOCITY, f.velocity)
+            _upload_plane(renderer, abi.TEX_VELOCITY, f.velocity, getattr(f, "static", False))
         else:  # unpacked planes (uv-space velocity, world normal, depth): rfx_pack_velocity
-            _pack_planes(renderer, abi.TEX_VELOCITY, f.aov, f.depth, renderer.pack_velocity)
+            _pack_planes(renderer, abi.TEX_VELOCITY, f.aov, f.depth, renderer.pack_velocity, getattr(f, "static", False))
 
     def dispose(self):
         pass
@@ -599,7 +601,7 @@ class SSGIEffect:
         float32 array covering the frame, or None to take `scene.frame.direct`."""
         self.keepEnvMapUpdated(renderer)
         direct = inputBuffer if inputBuffer is not None else self._scene.frame.direct
-        _upload_plane(renderer, abi.TEX_DIRECT_LIGHT, direct)
+        _upload_plane(renderer, abi.TEX_DIRECT_LIGHT, direct, getattr(self._scene.frame, "static", False))
         self.ssgiPass.render(renderer)
         self.denoiser.render(renderer, inputBuffer)
         # :400-417 the effect's own uniforms: inputTexture = the denoiser's texture, sceneTexture = the input buffer, fog from the scene
@@ -688,7 +690,7 @@ class TRAAEffect:
             if cache[0] is not data:
                 cache[0], cache[1] = data, np.asarray(data, np.float32).astype(np.float16).astype(np.float32)
             data = cache[1]
-        _upload_plane(renderer, abi.TEX_SSGI, data)  # K2's `inputTexture` (:118)
+        _upload_plane(renderer, abi.TEX_SSGI, data, bool(inputBuffer.get("static", False) if isinstance(inputBuffer, dict) else getattr(inputBuffer, "static", False)))  # K2's `inputTexture` (:118)
         self.temporalReprojectPass.unjitter()  # :68-73
         self.unjitteredProjectionMatrix = np.array(self._camera.projectionMatrix, np.float32).copy()
         self.temporalReprojectPass.jitter()

@@ -447,6 +447,28 @@ def synthetic_frame(width: int, height: int, frame_index: int = 0, seed: int = 1
     return _default_scene[1].render(width, height, frame_index, **kw)
 
 
+def _render_band(args):
+    seed, width, height, frame_index, row0, rows = args
+    f = AnalyticScene(seed).render(width, rows, frame_index, row0=row0, rows=rows, frame_height=height)
+    return f.depth, f.gbuffer, f.velocity, f.direct, f.camera, f.prev_camera
+
+
+def synthetic_frame_parallel(width: int, height: int, frame_index: int = 0, seed: int = 1234, workers: int | None = None) -> Frame:
+    """synthetic_frame() ray-cast by a pool of processes, one horizontal band each — the same texels (every band is rendered against the
+    whole frame's camera), in a fraction of the wall time on a many-core host (a 4K dump takes ~13 s single-threaded)."""
+    import multiprocessing as mp
+    import os
+    workers = workers or max(1, min(len(os.sched_getaffinity(0)), 32))
+    if workers == 1 or height < 4 * workers:
+        return synthetic_frame(width, height, frame_index, seed)
+    edges = [height * i // workers for i in range(workers + 1)]
+    jobs = [(seed, width, height, frame_index, edges[i], edges[i + 1] - edges[i]) for i in range(workers) if edges[i + 1] > edges[i]]
+    with mp.get_context("fork").Pool(len(jobs)) as pool:
+        parts = pool.map(_render_band, jobs)
+    cat = lambda k: np.ascontiguousarray(np.concatenate([p[k] for p in parts], axis=0))  # noqa: E731
+    return Frame(width, height, cat(0), cat(1), cat(2), cat(3), parts[0][4], parts[0][5], frame_index)
+
+
 def synthetic_environment(width: int = 256, height: int = 128, seed: int = 1234) -> np.ndarray:
     """A synthetic equirectangular HDR environment (`scene.environment`), (H, W, 4) float32, row 0 = bottom (v = 0 = straight
     down): ground colour below the horizon, a sky gradient above it, a warm sun whose core exceeds the shader's luminance

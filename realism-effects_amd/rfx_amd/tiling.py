@@ -43,6 +43,8 @@ EXCHANGED = (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_A0, abi.TEX_D
 def split_rows(height: int, world: int):
     """Even split; tile boundaries on EVEN rows so the 2x2 derivative quads never straddle tiles."""
     base = (height // world) & ~1
+    if world < 1 or base <= 0:
+        raise ValueError("split_rows: %d rows cannot be cut into %d tiles of at least 2 rows" % (height, world))
     starts = [r * base for r in range(world)]
     rows = [base] * world
     rows[-1] = height - starts[-1]
@@ -73,6 +75,17 @@ class TiledRenderer:
         self.inner, self.tensors, self.rank, self.world, self.group = inner, tensors, rank, world, group
         self.W, self.H = inner.W, inner.H
         self.tile_y0, self.tile_rows, self.halo = inner.tile_y0, inner.tile_rows, inner.halo
+        if world > 1:
+            # the exchange forwards a tile's OWN boundary rows to its neighbour: the tile must be the rank's share of the even split and
+            # every tile must be at least `halo` rows high, or a neighbour would be sent rows this rank only holds as (stale) halo —
+            # silently wrong pixels, not an error (multi-hop exchanges are not built: use fewer ranks or a smaller halo)
+            tiles = split_rows(self.H, world)
+            if (self.tile_y0, self.tile_rows) != tiles[rank]:
+                raise ValueError("TiledRenderer: rank %d of %d holds rows [%d, %d), split_rows() assigns [%d, %d)" % (
+                    rank, world, self.tile_y0, self.tile_y0 + self.tile_rows, tiles[rank][0], tiles[rank][0] + tiles[rank][1]))
+            if self.halo > min(n for _, n in tiles):
+                raise ValueError("TiledRenderer: halo %d rows exceeds the smallest tile (%d rows) of a %d-way split of %d rows" % (
+                    self.halo, min(n for _, n in tiles), world, self.H))
         self.exchange_count = 0
         self._pending = []  # (works, tensor) of the composed-GI all-gather in flight
         self._halo_pending = []  # (works, tensor) of halo Send/Recvs in flight
@@ -181,11 +194,17 @@ class TiledRenderer:
         ops = []
         up, down = self.rank + 1, self.rank - 1  # up = higher frame rows
         for tex in texs:
+            if tex not in self.tensors:
+                raise KeyError("TiledRenderer.exchange: texture %s is not bound for exchange — pass it to bind_torch_buffers(texs=...) "
+                               "(exchanged_textures(denoise_mode) lists what a configuration needs)" % abi.TEX_NAMES[tex])
             t = self.tensors[tex]
-            b0, _ = self.inner.held_rows(tex)
+            b0, bn = self.inner.held_rows(tex)
             lo = self.tile_y0 - b0  # first tile row inside the held band
             hi = lo + self.tile_rows
             h = self.halo
+            if (down >= 0 and lo < h) or (up < self.world and hi + h > bn):
+                raise ValueError("TiledRenderer.exchange: the held band of %s [%d, %d) does not contain %d halo rows around the tile" % (
+                    abi.TEX_NAMES[tex], b0, b0 + bn, h))
             if up < self.world:
                 ops.append(dist.P2POp(dist.isend, t[hi - h:hi], up, self.group))
                 ops.append(dist.P2POp(dist.irecv, t[hi:hi + h], up, self.group))
@@ -233,13 +252,26 @@ class TiledRenderer:
         self.inner.sync()
 
 
-def bind_torch_buffers(ctx, device, texs=None):
+def exchanged_textures(denoise_mode: str = "full"):
+    """The textures a row-tiled SSGIEffect run exchanges, by Denoiser mode (Denoiser.js:41-61): modes without a denoise pass
+    ("full_temporal", preset "low"; "temporal") keep K2's history in the pass's own RGBA32F framebuffer copy, which is then the
+    texture whose halo rows travel after every frame."""
+    if denoise_mode in ("full", "denoised"):
+        return EXCHANGED + (abi.TEX_COMPOSE_RGB,)
+    if denoise_mode == "full_temporal":
+        return (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_FBCOPY_F32, abi.TEX_COMPOSE_RGB)
+    if denoise_mode == "temporal":  # K1's history is K2's texture[0], gathered anywhere: whole-frame contexts only (rfx.h historySource 1)
+        raise ValueError("denoiseMode \"temporal\" cannot be row-tiled: K1 gathers K2's target anywhere on screen")
+    raise ValueError("unknown denoiseMode %r" % (denoise_mode,))
+
+
+def bind_torch_buffers(ctx, device, texs=None, denoise_mode: str = "full"):
     """Allocate the exchanged textures as torch tensors on `device` and bind them into the rfx
     context (rfx_bind_external), so torch.distributed can send/receive their rows in place.
-    `texs` defaults to what the SSGI chain exchanges; a TRAA run binds (TEX_FBCOPY_F16,) or (TEX_FBCOPY_F32,)."""
+    `texs` defaults to what the SSGI chain exchanges in `denoise_mode`; a TRAA run binds (TEX_FBCOPY_F16,) or (TEX_FBCOPY_F32,)."""
     import torch
     tensors = {}
-    for tex in (EXCHANGED + (abi.TEX_COMPOSE_RGB,) if texs is None else tuple(texs)):
+    for tex in (exchanged_textures(denoise_mode) if texs is None else tuple(texs)):
         r0, n = ctx.held_rows(tex)
         dtype, ch = abi.TEX_FORMAT[tex]
         nbytes = np.dtype(dtype).itemsize * ch * ctx.W

@@ -1,20 +1,125 @@
 """Shared parity metric.
 
-Tolerance (BASELINE.json north_star): 1e-3 per-channel L-inf.  Values above 1 are compared
-relatively (|a-b| <= 1e-3*max(1,|b|)): K1's output is stored as binary16, whose ulp already
-exceeds 1e-3 above 2.0, so an absolute 1e-3 is unattainable there for ANY two implementations
-that are not bit-identical in their transcendental functions (SURVEY.md §7 "hard parts").
+Bar (BASELINE.json north_star): 1e-3 per-channel L-inf against the reference GLSL on identical inputs.
 
-The path contains hard discontinuities (lobe selection `random.b < diffW`, ray hit tests,
-nearest-texel boundaries of the rotated Poisson taps, `step(1e-4, w)`): a 1-ulp difference in
-exp/log/sin between two correct implementations flips a branch for a few pixels and changes
-them by O(1).  Those pixels are counted separately and bounded as a FRACTION of the frame.
+Two facts shape how that bar can be stated honestly:
+
+1. Storage formats.  K1's output and K3's targets are binary16.  Above 2.0 two ADJACENT half values are more than 1e-3
+   apart, so any two implementations that differ by one rounding there differ by > 1e-3.  For half-stored outputs a channel
+   is in tolerance when |a-b| <= 1e-3 OR a and b are the same or adjacent binary16 values.  For fp32 outputs (K2, K4) a
+   channel is in tolerance when |a-b| <= 1e-3 OR |a-b| <= 1e-5*|b| (fp32 rounding noise on large radiances).  Both the
+   strict absolute L-inf and the metric's verdict are REPORTED (`Report.linf_abs`).
+
+2. Discontinuities.  The path branches on comparisons (lobe selection ssgi.frag:186, hit tests :463/:493, step(1e-4,w)
+   poisson_denoise.frag:120, ...) and addresses NEAREST texels at computed coordinates.  Two correct implementations whose
+   exp/log/sin differ in the last ulp take different sides in a few pixels and differ there by O(1).  Those pixels are not
+   assumed, they are PROVEN, two independent ways (oracle/rfx_oracle.c): (a) the oracle records for every fragment how close
+   its closest decision was ("discontinuity margins": margin < 1 = within reach of ulp-level operand differences); (b) the
+   oracle re-evaluates the stage with its exp/log/pow/sqrt/sin/cos results perturbed within the reference GL's MEASURED error
+   ("perturbed primitives") — a fragment whose output then moves by more than the tolerance is unstable, which also catches
+   ill-conditioned expressions that are not branches.  An out-of-tolerance pixel is *explained* when (a) or (b) holds and
+   *unexplained* otherwise.  Tests assert `unexplained == 0`, bound the explained flips, and print the at-risk population
+   (explainable pixels among ALL pixels) so the reader can see the criteria discriminate.
 """
+from dataclasses import dataclass
+
 import numpy as np
 
 ATOL = 1e-3
+RTOL_F32 = 1e-5
 
 
+def _half_ulp_distance(a, b):
+    """ordered-integer distance between the binary16 values of two float arrays that hold half-representable numbers"""
+    ha = np.asarray(a, np.float32).astype(np.float16).view(np.int16).astype(np.int32)
+    hb = np.asarray(b, np.float32).astype(np.float16).view(np.int16).astype(np.int32)
+    ha = np.where(ha < 0, -32768 - ha, ha)
+    hb = np.where(hb < 0, -32768 - hb, hb)
+    return np.abs(ha - hb)
+
+
+@dataclass
+class Report:
+    name: str
+    pixels: int
+    linf_abs: float          # true per-channel L-inf over ALL pixels, absolute
+    linf_abs_ok: float       # the same over pixels that are in tolerance
+    bad: int                 # pixels with a channel out of tolerance
+    explained: int           # ... of which the oracle proves unstable (margin < 1, or output moves under perturbed primitives)
+    unexplained: int
+    at_risk: int             # explainable pixels among all pixels (None without an oracle run)
+    worst_unexplained: tuple
+
+    def line(self):
+        ar = "" if self.at_risk is None else ", at-risk %d (%.4f%%)" % (self.at_risk, 100.0 * self.at_risk / max(self.pixels, 1))
+        return "%-22s px %9d  Linf(all) %.3e  Linf(in-tol) %.3e  out-of-tol %6d (%.4f%%) = explained %d + UNEXPLAINED %d%s" % (
+            self.name, self.pixels, self.linf_abs, self.linf_abs_ok, self.bad, 100.0 * self.bad / max(self.pixels, 1), self.explained,
+            self.unexplained, ar)
+
+
+def out_of_tolerance(a, b, half):
+    """(H, W) bool: some channel of the pixel is outside the metric"""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if a.ndim == 2:
+        a, b = a[..., None], b[..., None]
+    with np.errstate(invalid="ignore"):
+        err = np.abs(a - b)
+    err = np.where(np.isnan(a) & np.isnan(b), 0.0, err)
+    err = np.where(np.isnan(a) != np.isnan(b), np.inf, err)
+    err = np.where(np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b)), 0.0, err)
+    ok = err <= ATOL
+    ok |= (_half_ulp_distance(a, b) <= 1) if half else (err <= RTOL_F32 * np.abs(b))
+    return ~ok.all(axis=-1)
+
+
+def strict(name, a, b, explainable=None, half=False, ignore=None):
+    """a: implementation under test, b: reference; (H, W, C) float arrays.  explainable: (H, W) bool from the oracle (margin < 1 or
+    unstable under perturbed primitives) or None.  ignore: optional (H, W) bool mask of pixels excluded from the comparison."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if a.ndim == 2:
+        a, b = a[..., None], b[..., None]
+    with np.errstate(invalid="ignore"):
+        err = np.abs(a - b)
+    nan_mismatch = np.isnan(a) != np.isnan(b)
+    both_nan = np.isnan(a) & np.isnan(b)
+    err = np.where(both_nan, 0.0, err)
+    err = np.where(nan_mismatch, np.inf, err)
+    same_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
+    err = np.where(same_inf, 0.0, err)
+    ok = err <= ATOL
+    if half:
+        ok |= _half_ulp_distance(a, b) <= 1
+    else:
+        ok |= err <= RTOL_F32 * np.abs(b)
+    badpx = ~ok.all(axis=-1)
+    if ignore is not None:
+        badpx &= ~ignore
+        err = np.where(ignore[..., None], 0.0, err)
+    perpx = err.max(axis=-1)
+    n = int(badpx.size if ignore is None else (~ignore).sum())
+    nbad = int(badpx.sum())
+    if explainable is not None:
+        expl = badpx & explainable
+        unex = badpx & ~explainable
+        at_risk = int((explainable & (True if ignore is None else ~ignore)).sum())
+    else:
+        expl = np.zeros_like(badpx)
+        unex = badpx
+        at_risk = None
+    worst = ()
+    if unex.any():
+        idx = np.argwhere(unex)
+        k = np.argmax(perpx[unex])
+        y, x = idx[k]
+        worst = (int(y), int(x), float(perpx[y, x]))
+    finite = np.isfinite(perpx)
+    return Report(name, n, float(perpx[finite].max()) if finite.any() else 0.0, float(perpx[~badpx].max()) if (~badpx).any() else 0.0, nbad,
+                  int(expl.sum()), int(unex.sum()), at_risk, worst)
+
+
+# ---- the round-1 metric (relative above 1.0, flips bounded as a fraction); kept for the many stage tests that use it
 def compare(a, b):
     """returns (fraction of pixels with any channel out of tolerance, max error among in-tolerance channels)"""
     a = np.asarray(a, np.float64)

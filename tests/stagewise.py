@@ -1,0 +1,264 @@
+"""Stage-wise parity of an implementation against the REFERENCE GLSL running live on llvmpipe (oracle/glref), with the
+strict metric of tests/parity.py.
+
+The reference chain (GLRefChain: the reference's own fragment shaders under the uniform values of its JS drivers) renders
+frame after frame; before every pass its input textures are read back and handed to the implementation under test — the
+HIP path through the C ABI (`HipStages`) or the C restatement (`OracleStages`) — so every stage is compared on IDENTICAL
+inputs and a flipped pixel of one stage never compounds into the next.  The oracle additionally yields, per stage and
+pixel, the discontinuity margin that proves (or refuses) every out-of-tolerance pixel (rfx_oracle.c).
+
+Test infrastructure: imports oracle/; never imported by the product.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (os.path.join(ROOT, "realism-effects_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "glref"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import rfx_oracle as O  # noqa: E402
+from parity import out_of_tolerance, strict  # noqa: E402
+from rfx_amd import abi  # noqa: E402
+
+M31 = 0x7FFFFFFF
+
+
+def stage_params(cam, prev_cam, keep, steps, refine):
+    """The uniform blocks the reference's drivers set for defaultSSGIOptions (SSGIOptions.js:26-48), camera_moved = True."""
+    c, pc = abi.Camera.from_scene(cam), abi.Camera.from_scene(prev_cam)
+    sp = abi.SsgiParams(camera=c, steps=steps, refineSteps=refine, mode=0, useDirectLight=1, rayDistance=10, thickness=10, envBlur=0.5, blueNoiseIndex=0)
+    tp = abi.TemporalParams(camera=c, prevCamera=pc, textureCount=2, inputType=0, logTransform=1, fullAccumulate=0, confidencePower=0.75,
+                            neighborhoodClampIntensity=0.5, maxBlend=1.0, keepData=keep)
+    tp.reprojectSpecular[:] = [0, 1]
+    tp.neighborhoodClamp[:] = [0, 1]
+    dp = abi.DenoiseParams(radius=3, phi=0.5, lumaPhi=5, depthPhi=2, normalPhi=50, roughnessPhi=50, specularPhi=50, textureCount=2, halfStoreRTZ=1)
+    dp.isTextureSpecular[:] = [0, 1]
+    cp = abi.ComposeParams(camera=c, inputType=0)
+    return sp, tp, dp, cp
+
+
+class OracleStages:
+    """the C restatement as the implementation under test (CPU: pins the oracle itself against the reference)"""
+    name = "oracle"
+
+    def __init__(self, W, H, blue):
+        self.W, self.H, self.blue = W, H, blue
+
+    def frame(self, f):
+        self.f = f
+
+    def ssgi(self, history, sp):
+        return O.ssgi(self.f.depth, self.f.gbuffer, self.f.direct, history, self.blue, sp)
+
+    def temporal(self, ssgi, B, T_init, tp):
+        T = [t.copy() for t in T_init]
+        O.temporal(ssgi, self.f.velocity, B[0], B[1], tp, T[0], T[1])
+        return T
+
+    def denoise(self, ins, outs_init, dp):
+        outs = [t.copy() for t in outs_init]
+        O.denoise(self.f.depth, self.f.gbuffer, ins[0], ins[1], self.blue, dp, outs[0], outs[1])
+        return outs
+
+    def compose(self, B, comp_init, cp):
+        comp = comp_init.copy()
+        O.compose(self.f.depth, self.f.gbuffer, B[0], B[1], cp, comp)
+        return comp
+
+    def close(self):
+        pass
+
+
+class HipStages:
+    """the product: librfx_hip.so through the C ABI (rfx_amd.context.Context)"""
+    name = "hip"
+
+    def __init__(self, W, H, blue=None):
+        from rfx_amd.context import Context
+        self.ctx = Context(W, H)
+
+    def frame(self, f):
+        self.ctx.upload_frame(f)
+
+    def ssgi(self, history, sp):
+        self.ctx.upload(abi.TEX_COMPOSE, history)
+        self.ctx.ssgi_march(sp)
+        return self.ctx.download(abi.TEX_SSGI)
+
+    def temporal(self, ssgi, B, T_init, tp):
+        c = self.ctx
+        c.upload(abi.TEX_SSGI, ssgi)
+        c.upload(abi.TEX_DENOISE_B0, B[0]); c.upload(abi.TEX_DENOISE_B1, B[1])
+        c.upload(abi.TEX_TEMPORAL0, T_init[0]); c.upload(abi.TEX_TEMPORAL1, T_init[1])
+        c.temporal_reproject(tp)
+        return [c.download(abi.TEX_TEMPORAL0), c.download(abi.TEX_TEMPORAL1)]
+
+    def denoise(self, ins, outs_init, dp):
+        c = self.ctx
+        if dp.inputIsTemporal:
+            c.upload(abi.TEX_TEMPORAL0, ins[0]); c.upload(abi.TEX_TEMPORAL1, ins[1])
+        else:
+            i0, i1 = (abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1) if dp.writeToB else (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1)
+            c.upload(i0, ins[0]); c.upload(i1, ins[1])
+        o0, o1 = (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1) if dp.writeToB else (abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1)
+        c.upload(o0, outs_init[0]); c.upload(o1, outs_init[1])
+        c.poisson_denoise(dp)
+        return [c.download(o0), c.download(o1)]
+
+    def compose(self, B, comp_init, cp):
+        c = self.ctx
+        c.upload(abi.TEX_DENOISE_B0, B[0]); c.upload(abi.TEX_DENOISE_B1, B[1])
+        c.upload(abi.TEX_COMPOSE, comp_init)
+        c.compose(cp)
+        return c.download(abi.TEX_COMPOSE)
+
+    def close(self):
+        assert self.ctx.halo_violations() == 0
+        self.ctx.close()
+
+
+def _h(t):  # RGBA16F target read back as float32 -> the half bit patterns (exactly representable)
+    return np.ascontiguousarray(t.read().astype(np.float16).view(np.uint16))
+
+
+def run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start=1000, denoise_start=2000, shader_dir=None, log=print,
+        with_margins=True, n_perturb=6):
+    """Returns the list of parity.Report (one per stage output and frame).  frame_fn(i) -> dump frame i (rfx_amd.scene Frame)."""
+    import chain
+    ref = chain.GLRefChain(W, H, blue, shader_dir=shader_dir, steps=steps, refineSteps=refine, denoiseIterations=iterations)
+    impl = impl_cls(W, H, blue)
+    ora = OracleStages(W, H, blue) if with_margins else None
+    reports = []
+    si = di = 0
+    prev_cam, keep = None, 0.0
+
+    def as_float(outs):  # a stage's outputs as one (H, W, C) float array (halfs decoded, K1's packed texel as its 8 halfs)
+        outs = outs if isinstance(outs, (list, tuple)) else [outs]
+        parts = []
+        for o in outs:
+            if o.dtype == np.uint16:
+                parts.append(O.half_bits_to_float(o))
+            elif o.dtype == np.uint32:
+                parts.append(O.half_bits_to_float(np.ascontiguousarray(o).view(np.uint16)))
+            else:
+                parts.append(o)
+        return np.concatenate(parts, axis=-1)
+
+    def margins_of(fn, half):
+        """(H, W) bool: the oracle proves the pixel unstable — discontinuity margin < 1, or its output moves out of tolerance when the
+        oracle's transcendental results are perturbed within the reference GL's measured error (n_perturb seeded runs)"""
+        if ora is None:
+            return None
+        with O.margins(H, W) as mm:
+            base = as_float(fn())
+        unstable = mm.plane < 1.0
+        for seed in range(1, n_perturb + 1):
+            with O.perturbation(seed):
+                unstable |= out_of_tolerance(as_float(fn()), base, half)
+        return unstable
+
+    def check(name, got, want, m, half):
+        if isinstance(got, np.ndarray) and got.dtype == np.uint16:
+            got, want = O.half_bits_to_float(got), O.half_bits_to_float(want)
+        r = strict(name, got, want, explainable=m, half=half)
+        reports.append(r)
+        log(r.line())
+        return r
+
+    for fi in range(frames):
+        f = frame_fn(fi)
+        ref.upload_frame(f)
+        impl.frame(f)
+        if ora is not None:
+            ora.frame(f)
+        sp, tp, dp, cp = stage_params(f.camera, prev_cam or f.camera, keep, steps, refine)
+        tag = "f%d " % fi
+        # ---- K1 (history = the reference's composed GI of the previous frame)
+        hist = ref.t_compose.read()
+        si = (ssgi_start + si + 1) % M31
+        sp.blueNoiseIndex = si
+        ref.ssgi(f.camera, si)
+        R = np.ascontiguousarray(ref.t_ssgi.read().view(np.uint32))
+        I = impl.ssgi(hist, sp)
+        # the packed texel's 8 halfs as stored (unpackTwoVec4 subtracts the same 1e-4 from both sides)
+        got, want = as_float(np.ascontiguousarray(I)), as_float(R)
+        r = check(tag + "K1 ssgi", got, want, margins_of(lambda: ora.ssgi(hist, sp), True), half=True)
+        r.bit_identical = float((I == R).all(axis=-1).mean())
+        # ---- K2 (input: the reference's K1 output; history: its K3 target B of the previous frame; targets keep discarded texels)
+        B_prev = [_h(t) for t in ref.t_B]
+        T_prev = [np.ascontiguousarray(t.read()) for t in ref.t_temporal]
+        ref.temporal(f.camera, camera_moved=True)
+        RT = [np.ascontiguousarray(t.read()) for t in ref.t_temporal]
+        IT = impl.temporal(R, B_prev, T_prev, tp)
+        m = margins_of(lambda: ora.temporal(R, B_prev, T_prev, tp), False)
+        for j in range(2):
+            check(tag + "K2 temporal%d" % j, IT[j], RT[j], m, half=False)
+        keep, prev_cam = 1.0, f.camera
+        # ---- K3 passes (PoissonDenoisePass.js:135-149: 2 * iterations draws, ping-pong A/B; pass 0 reads K2's targets)
+        idx = []
+        for _ in range(2 * iterations):
+            di = (denoise_start + di + 1) % M31
+            idx.append(di)
+        for pi in range(2 * iterations):
+            horizontal = pi % 2 == 0
+            ins = RT if pi == 0 else ([_h(t) for t in (ref.t_B if horizontal else ref.t_A)])
+            outs_init = [_h(t) for t in (ref.t_A if horizontal else ref.t_B)]
+            ref.o["denoiseIterations"] = iterations
+            _one_denoise_pass(ref, f.camera, pi, idx[pi])
+            RO = [_h(t) for t in (ref.t_A if horizontal else ref.t_B)]
+            dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = idx[pi], int(pi == 0), int(not horizontal)
+            IO = impl.denoise(ins, outs_init, dp)
+            m = margins_of(lambda: ora.denoise(ins, outs_init, dp), True)
+            for j in range(2):
+                check(tag + "K3 pass%d tex%d" % (pi, j), IO[j], RO[j], m, half=True)
+        # ---- K4 (reads target B — never written when denoiseIterations == 0)
+        Bc = [_h(t) for t in ref.t_B]
+        comp_prev = np.ascontiguousarray(ref.t_compose.read())
+        ref.compose(f.camera)
+        RC = np.ascontiguousarray(ref.t_compose.read())
+        IC = impl.compose(Bc, comp_prev, cp)
+        check(tag + "K4 compose", IC, RC, margins_of(lambda: ora.compose(Bc, comp_prev, cp), False), half=False)
+    impl.close()
+    return reports
+
+
+def _one_denoise_pass(ref, cam, i, blue_noise_index):
+    """draw i of PoissonDenoisePass.render on the reference chain (GLRefChain.denoise runs all of them at once)"""
+    p, o = ref.p_denoise, ref.o
+    p.sampler("depthTexture", ref.t_depth)
+    p.sampler("gBufferTexture", ref.t_gbuffer)
+    p.sampler("blueNoiseTexture", ref.t_blue)
+    for k in ("radius", "phi", "lumaPhi", "depthPhi", "normalPhi", "roughnessPhi", "specularPhi"):
+        p.set(k, float(o[k]))
+    p.set("projectionMatrix", cam.projectionMatrix)
+    p.set("projectionMatrixInverse", cam.projectionMatrixInverse)
+    p.set("cameraMatrixWorld", cam.matrixWorld)
+    p.set("viewMatrix", cam.matrixWorldInverse)
+    p.set("resolution", [float(ref.W), float(ref.H)])
+    p.set("blueNoiseSize", [128.0, 128.0])
+    horizontal = i % 2 == 0
+    src = ref.t_temporal if i == 0 else (ref.t_B if horizontal else ref.t_A)
+    dst = ref.t_A if horizontal else ref.t_B
+    p.sampler("inputTexture", src[0])
+    p.sampler("inputTexture2", src[1])
+    p.set("blueNoiseIndex", int(blue_noise_index))
+    p.draw(dst[:2])
+
+
+def summarize(reports):
+    """aggregate per stage kind over frames -> dict kind -> (pixels, linf_all, linf_in_tol, bad, explained, unexplained, at_risk)"""
+    agg = {}
+    for r in reports:
+        kind = r.name.split(" ", 1)[1]
+        a = agg.setdefault(kind, [0, 0.0, 0.0, 0, 0, 0, 0])
+        a[0] += r.pixels
+        a[1] = max(a[1], r.linf_abs)
+        a[2] = max(a[2], r.linf_abs_ok)
+        a[3] += r.bad
+        a[4] += r.explained
+        a[5] += r.unexplained
+        a[6] += r.at_risk or 0
+    return agg

