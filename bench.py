@@ -46,13 +46,24 @@ PMC_KERNEL = {"k1_ssgi_march": "k1_ssgi_march", "k2_temporal_reproject": "k2_tem
               "k3_poisson_denoise_pass1": "k3_tiled<false", "k4_compose": "k4_compose"}
 
 
+PROFILE_DIR = "profiles/r02_final"  # the committed rocprofv3 collection the static counter figures are read from
+
+
+def profile_meta():
+    """which collection (directory, git commit, date) the PMC-derived figures of the line come from"""
+    try:
+        return json.load(open(os.path.join(ROOT, PROFILE_DIR, "meta.json")))
+    except Exception:  # noqa: BLE001
+        return {}
+
+
 def pmc_traffic(kernel_key):
     """HBM-side bytes per launch of a kernel from the committed PMC summary of this same command
-    (profiles/r01_final/pmc_hbm.csv: separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, values in KiB).
+    (PROFILE_DIR/pmc_hbm.csv: separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, values in KiB).
     gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half the bytes of wide coalesced reads -> x2.
     Returns None when the summary is missing or was taken at another frame size."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_final", "pmc_hbm.csv")
+    path = os.path.join(ROOT, PROFILE_DIR, "pmc_hbm.csv")
     if not os.path.exists(path):
         return None
     vals = {}
@@ -70,10 +81,10 @@ VALU_NS, TRANS_NS, N_SIMD = 1.0 / 0.975, 4.1, 256 * 4
 
 
 def valu_floor_ms(kernel_key, pixels):
-    """Issue-bound time of a kernel: its VALU instruction counts per wavefront (committed PMC summary, profiles/r01_final/pmc_sq_l2.csv:
+    """Issue-bound time of a kernel: its VALU instruction counts per wavefront (committed PMC summary, PROFILE_DIR/pmc_sq_l2.csv:
     SQ_INSTS_VALU, SQ_INSTS_VALU_TRANS_F32, SQ_WAVES — a property of the code, not of the run) priced at the measured issue rates."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_final", "pmc_sq_l2.csv")
+    path = os.path.join(ROOT, PROFILE_DIR, "pmc_sq_l2.csv")
     if not os.path.exists(path):
         return None
     c = {}
@@ -91,16 +102,138 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def ctl_device(dist, dev):
+    """control-plane tensors (barrier payloads, the max-over-ranks reduction, set-up gathers) live where the process group's backend wants them"""
+    return dev if (dist is not None and dist.get_backend() == "nccl") else "cpu"
+
+
+def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, refine, iterations, vfov_rows=None, use_c=False):
+    """Dump + context + effect of one benchmark case on this rank: frame W x H cut into `tiles` (one per rank).  Returns a dict with
+    the step function, the context and what the JSON line reports about the case."""
+    import torch
+    y0, rows = tiles[rank]
+    t0 = time.time()
+    scene_gen = AnalyticScene(1234)
+    opts = dict(width=W, height=H, steps=steps, refineSteps=refine, denoiseIterations=iterations)
+    # frame 1 of the orbit: non-zero velocity (camera moved 0.5 deg since frame 0).  The tile is dumped first, the
+    # velocity bound over ALL tiles fixes the halo width, then the halo rows are dumped and attached.
+    kw = dict(frame_height=H, vfov_rows=vfov_rows) if vfov_rows else dict(frame_height=H)
+    tile = scene_gen.render(W, rows, 1, row0=y0, rows=rows, **kw)
+    vmax = float(np.abs(tile.velocity[..., 1].view(np.float32)).max())
+    if dist is not None:  # every rank must use the SAME halo: the neighbours' send/recv sizes have to match
+        t = torch.tensor([vmax], dtype=torch.float64, device=ctl_device(dist, dev))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        vmax = float(t.item())
+    halo = 0 if world == 1 else tiling.required_halo(3.0, vmax, H, W)
+    b0, b1 = max(0, y0 - halo), min(H, y0 + rows + halo)
+    parts = [tile]
+    if b0 < y0:
+        parts.insert(0, scene_gen.render(W, y0 - b0, 1, row0=b0, rows=y0 - b0, **kw))
+    if b1 > y0 + rows:
+        parts.append(scene_gen.render(W, b1 - y0 - rows, 1, row0=y0 + rows, rows=b1 - y0 - rows, **kw))
+    band = types.SimpleNamespace(camera=tile.camera, **{k: np.concatenate([getattr(q, k) for q in parts], axis=0)
+                                                         for k in ("depth", "gbuffer", "velocity", "direct")})
+    log("[rank %d] dump band rows [%d,%d) of %dx%d generated in %.1fs (halo %d)" % (rank, b0, b1, W, H, time.time() - t0, halo))
+
+    ctx = Context(W, H, device=local_rank, tile_y0=y0, tile_rows=rows, halo_rows=halo)
+    renderer, exchange = ctx, "none"
+    depth_full = band.depth
+    if world > 1:
+        cd = ctl_device(dist, dev)
+        mine = torch.from_numpy(np.ascontiguousarray(band.depth[y0 - b0:y0 - b0 + rows])).to(cd)
+        parts_d = [torch.empty((n, W), dtype=torch.float32, device=cd) for (_, n) in tiles]
+        dist.all_gather(parts_d, mine)  # set-up only (the dump's depth plane is held whole by every rank, SURVEY.md §8e)
+        depth_full = torch.cat(parts_d, 0).cpu().numpy()
+        if use_c:
+            box = [Context.comm_unique_id() if rank == 0 else None]  # one ncclUniqueId per communicator
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+            # the exchanges behind the C ABI: RCCL Send/Recv + all-gather on the context's own exchange stream (rfx.h "row-tiled runs")
+            renderer = tiling.CommTiledRenderer(ctx, rank, world, uid)
+            exchange = "C ABI: rfx_halo_exchange / rfx_allgather_history (RCCL, own stream, overlapped)"
+        else:
+            # torch.distributed transport (gloo in the one-GPU functional mode, or the NCCL backend): kernels, collectives and torch's
+            # copies share ONE created stream — handle 0 would mean "the context's own stream" to rfx_set_stream
+            stream = torch.cuda.Stream(device=dev)
+            torch.cuda.set_stream(stream)
+            ctx.set_stream(stream.cuda_stream)
+            ctx.uses_torch_stream = not one_gpu  # gloo stages device tensors through the host: drain the stream around every exchange there
+            renderer = tiling.TiledRenderer(ctx, tiling.bind_torch_buffers(ctx, dev), rank, world)
+            exchange = "torch.distributed (%s)" % ("gloo, one-GPU functional mode" if one_gpu else "nccl = RCCL")
+    # static: the same dump every step, uploaded once before the timed region (the metric is quoted with inputs resident in HBM)
+    frame = types.SimpleNamespace(depth=depth_full, gbuffer=band.gbuffer, velocity=band.velocity, direct=band.direct, camera=band.camera, static=True)
+    scene = types.SimpleNamespace(frame=frame)
+    fx = SSGIEffect(None, scene, band.camera, opts, seeds=dict(ssgi=1, denoise=2), half_store_rtz=True)
+    return dict(ctx=ctx, renderer=renderer, fx=fx, frame=frame, halo=halo, rows=rows, W=W, H=H, exchange=exchange, steps=steps, refine=refine, it=iterations)
+
+
+def time_case(case, dist, n_steps, n_warmup, dev="cpu"):
+    """W untimed steps, then exactly K timed steps between barriers + device synchronisation; max over ranks."""
+    import torch
+    ctx, renderer, fx = case["ctx"], case["renderer"], case["fx"]
+
+    def barrier():
+        for name in ("finish_pending", "finish_halo"):  # the exchanges of the last frame are asynchronous: they belong to it
+            fin = getattr(renderer, name, None)
+            if fin:
+                fin()
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fx.update(renderer, None)  # first frame: uploads the dump (not timed), keepData = 0
+    for _ in range(n_warmup):
+        fx.update(renderer, None)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        fx.update(renderer, None)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=ctl_device(dist, dev))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def kernel_times(case, iters):
+    """per-kernel durations (hipEvents on the kernels' stream), this rank's tile"""
+    ctx, fx = case["ctx"], case["fx"]
+    sp, tp = fx.ssgiPass.uniforms, fx.denoiser.temporalReprojectPass.uniforms
+    dp, cp = fx.denoiser.denoisePass.uniforms, fx.denoiser.denoiserComposePass.uniforms
+
+    def k3(pass_i):
+        dp.inputIsTemporal, dp.writeToB = (1, 0) if pass_i == 0 else (0, 1)
+        ctx.poisson_denoise(dp)
+
+    kernels = [("k1_ssgi_march", lambda: ctx.ssgi_march(sp)), ("k2_temporal_reproject", lambda: ctx.temporal_reproject(tp)),
+               ("k3_poisson_denoise_pass0", lambda: k3(0)), ("k3_poisson_denoise_pass1", lambda: k3(1)), ("k4_compose", lambda: ctx.compose(cp))]
+    kms = {}
+    for name, fn in kernels:
+        fn()
+        ctx.time_begin()
+        for _ in range(iters):
+            fn()
+        kms[name] = ctx.time_end() / iters
+    ctx.sync()
+    return kms
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=W4K)
-    ap.add_argument("--height", type=int, default=H4K, help="rows per GPU")
+    ap.add_argument("--height", type=int, default=H4K, help="frame rows (N = 1) / rows of the 4K frame that is cut into N tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame the CPU baseline processes (0 = auto)")
     ap.add_argument("--checksum", action="store_true", help="add sha1 of the final whole-frame composed GI to the JSON line (tiled == single check)")
+    ap.add_argument("--exchange", choices=("c", "torch"), default="c", help="N > 1: exchanges through the C ABI's RCCL entry points (default) or torch.distributed")
+    ap.add_argument("--no-extras", action="store_true", help="N > 1: only the headline case (skip the weak-scaling and configs[4] extras)")
     args = ap.parse_args()
 
     import torch
@@ -116,152 +249,107 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    dist, use_c = None, False
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_gpu:
+        use_c = args.exchange == "c" and not one_gpu
+        if use_c:
+            # control plane (barriers, the max-over-ranks reduction, set-up gathers) over gloo; the DATA path is RCCL through the C ABI.
+            # If the communicator cannot be created on this node the run falls back to the torch.distributed NCCL (= RCCL) transport.
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            box = [None]
+            if rank == 0:
+                try:
+                    box[0] = Context.comm_unique_id()  # probe: is RCCL loadable here?
+                except Exception as e:  # noqa: BLE001
+                    log("[rank 0] rfx_comm_unique_id failed (%s): falling back to torch.distributed NCCL" % e)
+            dist.broadcast_object_list(box, src=0)
+            if box[0] is None:
+                use_c = False
+                dist.destroy_process_group()
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        elif one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # weak scaling: the frame grows with the number of GPUs at constant aspect, so that the per-pixel work (tap
-    # footprints, ray lengths in pixels) stays what it is on one GPU; every rank owns W*Ht = const pixels
     W1, H1 = args.width, args.height
-    if world == 1:
-        W, H, Ht = W1, H1, H1
-    else:
-        W = int(round(W1 * world ** 0.5 / 64.0)) * 64
-        Ht = int(W1 * H1 / W) & ~1
-        H = Ht * world
-    tiles = [(r * Ht, Ht) for r in range(world)]
-    y0, rows = tiles[rank]
-
-    # ---- synthetic dump: every rank ray-casts the band it holds (+ halo); depth is gathered whole
-    t0 = time.time()
-    scene_gen = AnalyticScene(1234)
-    opts = dict(width=W, height=H, steps=20, refineSteps=5, denoiseIterations=1)
-    # frame 1 of the orbit: non-zero velocity (camera moved 0.5 deg since frame 0).  The tile is dumped first, the
-    # velocity bound over ALL tiles fixes the halo width, then the halo rows are dumped and attached.
-    tile = scene_gen.render(W, rows, 1, row0=y0, rows=rows, frame_height=H)
-    vmax = float(np.abs(tile.velocity[..., 1].view(np.float32)).max())
-    if dist is not None:  # every rank must use the SAME halo: the neighbours' send/recv sizes have to match
-        t = torch.tensor([vmax], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        vmax = float(t.item())
-    halo = 0 if world == 1 else tiling.required_halo(3.0, vmax, H, W)
-    b0, b1 = max(0, y0 - halo), min(H, y0 + rows + halo)
-    parts = [tile]
-    if b0 < y0:
-        parts.insert(0, scene_gen.render(W, y0 - b0, 1, row0=b0, rows=y0 - b0, frame_height=H))
-    if b1 > y0 + rows:
-        parts.append(scene_gen.render(W, b1 - y0 - rows, 1, row0=y0 + rows, rows=b1 - y0 - rows, frame_height=H))
-    band = types.SimpleNamespace(camera=tile.camera, **{k: np.concatenate([getattr(q, k) for q in parts], axis=0)
-                                                         for k in ("depth", "gbuffer", "velocity", "direct")})
-    log("[rank %d] dump band rows [%d,%d) of %dx%d generated in %.1fs (halo %d)" % (rank, b0, b1, W, H, time.time() - t0, halo))
-
-    ctx = Context(W, H, device=local_rank, tile_y0=y0, tile_rows=rows, halo_rows=halo)
-    # kernels, RCCL ops and torch's copies share ONE created stream: torch's legacy default stream has handle 0, which
-    # rfx_set_stream reads as "use the context's own stream" — the collectives would then not be ordered against the kernels
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    ctx.set_stream(stream.cuda_stream)
-    # gloo stages device tensors through the host on its own schedule: drain the stream around every exchange there
-    ctx.uses_torch_stream = not one_gpu
-    renderer = ctx
-    depth_full = band.depth
-    if world > 1:
-        tensors = tiling.bind_torch_buffers(ctx, dev)
-        renderer = tiling.TiledRenderer(ctx, tensors, rank, world)
-        mine = torch.from_numpy(np.ascontiguousarray(band.depth[y0 - b0:y0 - b0 + rows])).to(dev)
-        full = torch.empty((H, W), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(full, mine)
-        depth_full = full.cpu().numpy()
-    # static: the same dump every step, uploaded once before the timed region (the metric is quoted with inputs resident in HBM)
-    frame = types.SimpleNamespace(depth=depth_full, gbuffer=band.gbuffer, velocity=band.velocity, direct=band.direct, camera=band.camera, static=True)
-    scene = types.SimpleNamespace(frame=frame)
-    cam = band.camera
-    fx = SSGIEffect(None, scene, cam, opts, seeds=dict(ssgi=1, denoise=2), half_store_rtz=True)
-
-    def step():
-        fx.update(renderer, None)
-
-    def barrier():
-        for name in ("finish_pending", "finish_halo"):  # the exchanges of the last frame are asynchronous (tiling.py): they belong to it
-            fin = getattr(renderer, name, None)
-            if fin:
-                fin()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    step()  # first frame: uploads the dump (not timed), keepData = 0
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # ---- headline: N = 1 -> BASELINE configs[2] (the 4K frame on one GPU); N > 1 -> configs[3]: THE SAME 4K frame cut into N row
+    # tiles (strong scaling: 1080 / 540 / 270 rows per GPU at N = 2 / 4 / 8), RCCL halo exchange + composed-GI all-gather
+    tiles = [(0, H1)] if world == 1 else tiling.split_rows(H1, world)
+    case = build_case(world, rank, local_rank, dev, dist, one_gpu, W1, H1, tiles, 20, 5, 1, use_c=use_c)
+    dt = time_case(case, dist, args.steps, args.warmup, dev)
+    ctx = case["ctx"]
     ms_per_step = dt / args.steps * 1e3
-    value = W * H * args.steps / dt / 1e6  # Mpixels/s, whole job
+    value = W1 * H1 * args.steps / dt / 1e6  # Mpixels/s, whole job
     viol = ctx.halo_violations()
     compose_sha1 = None
     if args.checksum:  # before the per-kernel timing below re-runs kernels on this rank's tile only
         import hashlib
+        renderer = case["renderer"]
         # .rgb of the whole composed frame: what a tiled run gathers (RFX_TEX_COMPOSE_RGB) and what the next frame's K1 reads
         rgb = ctx.download(abi.TEX_COMPOSE_RGB) if getattr(renderer, "gather_history_rgb", False) else ctx.download(abi.TEX_COMPOSE)[..., :3]
         compose_sha1 = hashlib.sha1(np.ascontiguousarray(rgb).tobytes()).hexdigest()
+    kms = kernel_times(case, max(5, min(args.steps, 20)))
+    rows, halo = case["rows"], case["halo"]
 
-    # ---- per-kernel durations (hipEvents on the kernels' stream), this rank's tile
-    sp, tp = fx.ssgiPass.uniforms, fx.denoiser.temporalReprojectPass.uniforms
-    dp, cp = fx.denoiser.denoisePass.uniforms, fx.denoiser.denoiserComposePass.uniforms
-
-    def k3(pass_i):
-        dp.inputIsTemporal, dp.writeToB = (1, 0) if pass_i == 0 else (0, 1)
-        ctx.poisson_denoise(dp)
-
-    kernels = [("k1_ssgi_march", lambda: ctx.ssgi_march(sp)), ("k2_temporal_reproject", lambda: ctx.temporal_reproject(tp)),
-               ("k3_poisson_denoise_pass0", lambda: k3(0)), ("k3_poisson_denoise_pass1", lambda: k3(1)), ("k4_compose", lambda: ctx.compose(cp))]
-    iters = max(5, min(args.steps, 20))
-    kms = {}
-    for name, fn in kernels:
-        fn()
-        ctx.time_begin()
-        for _ in range(iters):
-            fn()
-        kms[name] = ctx.time_end() / iters
-    barrier()
+    extras = {}
+    if world > 1 and not args.no_extras:
+        # (a) weak scaling, the round-1 headline: the frame grows with N at constant aspect, every rank owns 8.29 Mpixel
+        Ww = int(round(W1 * world ** 0.5 / 64.0)) * 64
+        Ht = int(W1 * H1 / Ww) & ~1
+        ctx.close()
+        case = None
+        wtiles = [(r * Ht, Ht) for r in range(world)]
+        if all(t == s for t, s in zip(wtiles, tiling.split_rows(Ht * world, world))):
+            wcase = build_case(world, rank, local_rank, dev, dist, one_gpu, Ww, Ht * world, wtiles, 20, 5, 1, use_c=use_c)
+            wdt = time_case(wcase, dist, args.steps, args.warmup, dev)
+            extras["weak_scaling"] = {"frame": "%dx%d" % (Ww, Ht * world), "tile_rows": Ht, "halo_rows": wcase["halo"], "ms_per_step": round(wdt / args.steps * 1e3, 4),
+                                      "value": round(Ww * Ht * world * args.steps / wdt / 1e6, 2), "unit": "Mpixels/s",
+                                      "halo_violations": wcase["ctx"].halo_violations()}
+            wcase["ctx"].close()
+        # (b) BASELINE configs[4]: 8K, steps 40, denoiseIterations 3, row-tiled (the 16-frame sequence re-renders one dumped frame)
+        c4 = build_case(world, rank, local_rank, dev, dist, one_gpu, 7680, 4320, tiling.split_rows(4320, world), 40, 5, 3, use_c=use_c)
+        n4 = max(4, min(args.steps, 16))
+        d4 = time_case(c4, dist, n4, 2, dev)
+        extras["configs4_8k"] = {"frame": "7680x4320", "steps": 40, "refineSteps": 5, "denoiseIterations": 3, "frames_timed": n4, "halo_rows": c4["halo"],
+                                 "ms_per_frame": round(d4 / n4 * 1e3, 4), "value": round(7680 * 4320 * n4 / d4 / 1e6, 2), "unit": "Mpixels/s",
+                                 "halo_violations": c4["ctx"].halo_violations()}
+        c4["ctx"].close()
 
     if rank == 0:
-        px_tile = W * rows
+        px_tile = W1 * rows
         dom = max(kms, key=kms.get)
         achieved = BYTES_PER_PX[dom] * px_tile / (kms[dom] * 1e-3) / 1e9
         chain_bytes = sum(BYTES_PER_PX[k] for k in kms)
         chain_ms = sum(kms.values())
+        ns_ms = chain_ms - kms["k4_compose"]  # the north-star quantity: K1 + K2 + 2 x K3 (268 B/px)
+        ns_bytes = chain_bytes - BYTES_PER_PX["k4_compose"]
+        prof = profile_meta()
+        workload = ("configs[2]: %dx%d (%.2f Mpixel) on one GPU" % (W1, H1, W1 * H1 / 1e6) if world == 1 else
+                    "configs[3]: the %dx%d frame cut into %d row tiles of %d rows" % (W1, H1, world, rows))
         out = {
             "metric": "Mpixels/s SSGI+denoise @4K steps=20; achieved HBM GB/s vs peak",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: %dx%d (%.2f Mpixel) per GPU, steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step" % (W, Ht, W * Ht / 1e6),
-                       "frame": "%dx%d" % (W, H), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz",
-                       "parallelism": "row-tiles x%d, RCCL halo send/recv + compose all-gather (async, overlapped with the next frame's K1 trace)" % world if world > 1 else "single GPU"},
+            "config": {"workload": workload + ", steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step",
+                       "frame": "%dx%d" % (W1, H1), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz",
+                       "parallelism": "row-tiles x%d, RCCL halo send/recv after K2 and every K3 pass + composed-GI all-gather (async, under the next frame's K1 trace); exchange: %s" % (
+                           world, case_exchange(use_c, one_gpu, args)) if world > 1 else "single GPU"},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
             "chain": {"algorithmic_bytes_per_px": chain_bytes, "sum_kernel_ms": round(chain_ms, 4),
                       "achieved_GBs": round(chain_bytes * px_tile / (chain_ms * 1e-3) / 1e9, 1),
                       "frac_of_peak": round(chain_bytes * px_tile / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "north_star_chain": {"kernels": "K1+K2+2xK3", "algorithmic_bytes_per_px": ns_bytes, "sum_kernel_ms": round(ns_ms, 4),
+                                 "achieved_GBs": round(ns_bytes * px_tile / (ns_ms * 1e-3) / 1e9, 1),
+                                 "frac_of_peak": round(ns_bytes * px_tile / (ns_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "target_frac": 0.70},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(dom) if (W, rows) == (W4K, H4K) else None,
-                         "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/r01_final/pmc_hbm.csv (rocprofv3 --pmc, same command, 4K)",
+                         "traffic": pmc_traffic(dom) if (W1, rows) == (W4K, H4K) else None,
+                         "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 from %s/pmc_hbm.csv (rocprofv3 --pmc, this command at 4K; collected at git %s)" % (
+                             PROFILE_DIR, prof.get("git_commit", "?")),
                          "algorithmic_bytes_per_launch": BYTES_PER_PX[dom] * px_tile, "avg_launch_ms": round(kms[dom], 4)},
             "halo_violations": viol,
         }
@@ -270,16 +358,25 @@ def main():
         if all(v is not None for v in floors.values()):
             out["valu_issue_roofline"] = {"floor_ms": {k: round(v, 4) for k, v in floors.items()}, "sum_floor_ms": round(sum(floors.values()), 4),
                                           "frac": round(sum(floors.values()) / chain_ms, 4),
-                                          "note": "VALU + transcendental instructions per wave (profiles/r01_final PMC) at the issue rates measured by tools/microbench/valu_rates.hip"}
+                                          "note": "VALU + transcendental instructions per wave (%s/pmc_sq_l2.csv, git %s) at the issue rates measured by tools/microbench/valu_rates.hip" % (
+                                              PROFILE_DIR, prof.get("git_commit", "?"))}
+        out.update(extras)
         if args.checksum:
-            out["compose_sha1"], out["frame_rows"] = compose_sha1, H
+            out["compose_sha1"], out["frame_rows"] = compose_sha1, H1
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frame, fx, W, H, args.cpu_sample_rows)
+            out["cpu_baseline"] = cpu_baseline(case["frame"], case["fx"], W1, H1, args.cpu_sample_rows)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    if case is not None:
+        ctx.close()
+
+
+def case_exchange(use_c, one_gpu, args):
+    if uid is not None:
+        return "C ABI rfx_halo_exchange / rfx_allgather_history (RCCL on the context's exchange stream)"
+    return "torch.distributed (%s)" % ("gloo, one-GPU functional mode" if one_gpu else "nccl = RCCL")
 
 
 def cpu_baseline_llvmpipe(frame, W, H):

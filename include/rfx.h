@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 11
+#define RFX_ABI_VERSION 12
 
 enum {
     RFX_OK = 0,
@@ -248,7 +248,8 @@ int rfx_set_environment(rfx_ctx *, const float *rgba, int width, int height, int
  * reference, src/ssgi/utils/EquirectHdrInfoUniform.js:148-245,365-400) for `sampleEquirectProbability` (ssgi_utils.frag:210-225):
  * `marginalWeights` (height floats: an height x 1 NEAREST texture), `conditionalWeights` (width x height floats, row-major), and
  * totalSumValue split as the reference splits it (`~~total` and the rest).  Sizes are those of the environment set before. */
-int rfx_set_environment_importance(rfx_ctx *, const float *marginalWeights, const float *conditionalWeights, float totalSumWhole, float totalSumDecimal);
+int rfx_set_environment_importance(rfx_ctx *, const float *marginalWeights, size_t marginalCount, const float *conditionalWeights,
+                                   size_t conditionalCount, float totalSumWhole, float totalSumDecimal);  /* counts in floats: RFX_EINVAL unless height / width*height */
 /* Read mip level `level` of the environment back (max(w>>level,1) x max(h>>level,1) RGBA float32); *levels (may be NULL) receives the
  * number of levels.  For inspection and for checking the chain against the driver's. */
 int rfx_download_environment(rfx_ctx *, int level, float *rgba, int *levels);
@@ -277,6 +278,26 @@ int rfx_compose(rfx_ctx *, const rfx_compose_params *);
 int rfx_final_compose(rfx_ctx *, const rfx_final_params *);
 
 int rfx_sync(rfx_ctx *);
+
+/* ---- row-tiled runs: the exchanges, one process per GPU, RCCL over xGMI.  RCCL is bound at run time (a
+ * single-GPU host needs none; a process that already maps an RCCL — e.g. torch's — shares it).
+ * Tiles: rank r of n owns rfx_split_rows(height, n, r) — boundaries on even rows, the last tile takes the remainder; every tile
+ * must be at least halo_rows high.  The exchanges run on a second stream of the context: each call orders itself AFTER all draws
+ * enqueued so far and returns; rfx_comm_wait orders all LATER draws after the exchanges issued so far.  In between the host may
+ * enqueue draws that do not touch the rows in flight (the tile interior through rfx_set_row_window; rfx_ssgi_trace while the
+ * composed GI is gathered), which is how their time is hidden.
+ * Replaces nothing in the reference (it has no multi-GPU path); it is the halo step north_star / SURVEY.md §8e prescribe. */
+int rfx_split_rows(int height, int nranks, int rank, int *tile_y0, int *tile_rows);
+int rfx_comm_unique_id(void *id128);                                            /* ncclGetUniqueId: 128 bytes, rank 0 hands them to the others */
+int rfx_comm_init(rfx_ctx *, const void *id128, int rank, int nranks);          /* ncclCommInitRank on the context's device (collective) */
+int rfx_comm_destroy(rfx_ctx *);
+/* ncclGroupStart; ncclSend/ncclRecv of halo_rows rows of texture `id` with the tile above (`up_rank`, higher frame rows) and
+ * below (`down_rank`); ncclGroupEnd — -1 = no such neighbour.  `ncclComm` (an ncclComm_t) may be NULL: the context's own. */
+int rfx_halo_exchange(rfx_ctx *, rfx_tex id, void *ncclComm, int up_rank, int down_rank);
+/* every rank's tile rows of RFX_TEX_COMPOSE or RFX_TEX_COMPOSE_RGB (held whole) to every rank, in place: next frame's K1 gathers
+ * last frame's composed GI anywhere on screen.  ncclAllGather (equal tiles) or one ncclBroadcast per owner in a group (ragged). */
+int rfx_allgather_history(rfx_ctx *, rfx_tex id, void *ncclComm);
+int rfx_comm_wait(rfx_ctx *);
 
 /* Number of texel fetches that fell outside the rows a tile context holds since creation
  * (they are clamped into the band, i.e. the halo was too small for the frame's motion/radius).

@@ -102,7 +102,7 @@ static inline void margin_cmp(float a, float b, float rel) {
     margin_note(fabsf(a - b) / s);
 }
 /* scales (relative error an operand of the decision can carry between two implementations with ulp-accurate primitives) */
-#define MARGIN_REL_MARCH 5e-7f   /* ray position after <= 40 accumulated steps of dir * (1 - exp(..)), projected */
+#define MARGIN_REL_MARCH 2e-6f   /* ray position after <= 40 accumulated steps of dir * (1 - exp(..)), projected */
 #define MARGIN_REL_SHORT 4e-6f   /* a handful of fp32 operations incl. one transcendental */
 #define MARGIN_REL_WEIGHT 1e-4f  /* products of exp(-phi * diff): the exponents reach ~10 and carry their own rounding */
 

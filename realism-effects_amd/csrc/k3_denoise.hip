@@ -20,7 +20,7 @@ namespace {
 constexpr int TW = 64, TH = 8;  // pixels per workgroup tile
 constexpr int NT = TW * TH;     // 512 threads
 #ifndef RFX_K3_XCD_G
-#define RFX_K3_XCD_G 4  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major
+#define RFX_K3_XCD_G 1  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major.  Measured at 4K (pass 0 / pass 1 ms): 0: 0.248/0.380, 1: 0.244/0.376, 2: 0.245/0.390, 4: 0.255/0.414, 8: 0.266/0.423, 16: 0.288/0.434
 #endif
 // The tile is staged with an apron of (Rx, Ry) texels.  The reference rotates the Poisson offsets in UV space
 // (`rm * (offset / resolution)`, poisson_denoise.frag:183-189), so on a W x H frame the tap footprint is

@@ -8,61 +8,9 @@
 #include "../../include/rfx.h"
 #include "rfx_kernels.h"
 
-struct Slot {
-    void *ptr = nullptr;
-    bool owned = false;
-    int row0 = 0, rows = 0;  // held band (frame rows)
-    size_t texel = 0;
-    int width = 0;
-    bool uploaded = false;
-};
+#include "rfx_ctx.h"
 
-struct rfx_ctx {
-    int device = 0;
-    int W = 0, H = 0, tile_y0 = 0, tile_rows = 0, halo = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    unsigned int *halo_violations = nullptr;
-    float *viewz = nullptr;    // K1 scratch: view-space Z plane (full frame)
-    float4 *hits = nullptr;    // K1 trace -> shade hand-over (rfx_ssgi_trace), 2 texels per SSGI texel
-    bool hits_traced = false;  // a trace is waiting for its shade
-    int win_y0 = 0, win_y1 = 0x7fffffff;  // rfx_set_row_window: rows the draws may produce
-    float2 *coarse = nullptr;  // K1 scratch: exact (min,max) view Z per 16x16 base cell
-    unsigned int *cells = nullptr;  // K1 scratch: the march's half-packed (min,max) table
-    float4 *env = nullptr;     // scene.environment: the whole mip chain, float4 texels
-    float *env_marginal = nullptr, *env_conditional = nullptr;  // EquirectHdrInfo inverse-CDF tables (importanceSampling)
-    float env_sum_whole = 1.0f, env_sum_decimal = 0.0f;
-    int env_w = 0, env_h = 0, env_levels = 0;
-    unsigned int env_off[16] = {0};
-    Slot slots[RFX_TEX_COUNT];
-    std::string err;
-};
-
-static thread_local std::string g_create_err;
-
-static size_t texel_bytes(int id) {
-    switch (id) {
-    case RFX_TEX_DEPTH: return 4;
-    case RFX_TEX_BLUE_NOISE: return 4;
-    case RFX_TEX_COMPOSE_RGB: return 12;
-    case RFX_TEX_DENOISE_A0: case RFX_TEX_DENOISE_A1: case RFX_TEX_DENOISE_B0: case RFX_TEX_DENOISE_B1: case RFX_TEX_FBCOPY_F16: return 8;
-    default: return 16;
-    }
-}
-
-static int fail(rfx_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
-    char buf[512];
-    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-    else snprintf(buf, sizeof buf, "%s", what);
-    if (c) c->err = buf;
-    else g_create_err = buf;
-    return code;
-}
-#define HIPCHK(c, call)                                              \
-    do {                                                             \
-        hipError_t e__ = (call);                                     \
-        if (e__ != hipSuccess) return fail(c, RFX_EDEVICE, #call, e__); \
-    } while (0)
+thread_local std::string g_create_err;
 
 extern "C" {
 
@@ -118,6 +66,7 @@ void rfx_destroy(rfx_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    rfx_comm_release(c);
     for (int i = 0; i < RFX_TEX_COUNT; i++)
         if (c->slots[i].owned && c->slots[i].ptr) hipFree(c->slots[i].ptr);
     if (c->halo_violations) hipFree(c->halo_violations);
@@ -412,9 +361,12 @@ int rfx_set_environment(rfx_ctx *c, const float *rgba, int width, int height, in
     return RFX_OK;
 }
 
-int rfx_set_environment_importance(rfx_ctx *c, const float *marginal, const float *conditional, float totalSumWhole, float totalSumDecimal) {
+int rfx_set_environment_importance(rfx_ctx *c, const float *marginal, size_t marginalCount, const float *conditional, size_t conditionalCount,
+                                   float totalSumWhole, float totalSumDecimal) {
     if (!c || !marginal || !conditional) return RFX_EINVAL;
     if (!c->env) return fail(c, RFX_ESTATE, "rfx_set_environment_importance: no environment set");
+    if (marginalCount != (size_t)c->env_h || conditionalCount != (size_t)c->env_w * c->env_h)
+        return fail(c, RFX_EINVAL, "rfx_set_environment_importance: marginalWeights must hold height floats and conditionalWeights width*height");
     hipSetDevice(c->device);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->env_marginal) hipFree(c->env_marginal);

@@ -1,0 +1,266 @@
+// rfx_comm.hip — the exchanges of a row-tiled run behind the C ABI (include/rfx.h "row-tiled runs"):
+// RCCL Send/Recv of halo rows between row neighbours and the all-gather of the composed GI, one process per GPU.
+//
+// RCCL is bound at run time (dlopen), not at link time: a single-GPU host needs no RCCL at all, and a process that already
+// carries one (a torch process maps its own librccl.so.1) must not get a second copy — the already-mapped library is reused.
+// The exchanges run on a second stream of the context.  rfx_halo_exchange / rfx_allgather_history order themselves AFTER every
+// draw enqueued so far (event on the draw stream) and return; rfx_comm_wait orders every later draw after the exchanges issued
+// so far.  Between the two the host may enqueue draws that do not touch the rows in flight — the interior of the tile
+// (rfx_set_row_window), the next frame's ray march — which is how the exchange time is hidden.
+#include <dlfcn.h>
+#include <string.h>
+#include <mutex>
+#include "rfx_ctx.h"
+
+namespace {
+
+// the slice of rccl.h this file uses (ABI of RCCL 2.x: NCCL_UNIQUE_ID_BYTES 128, ncclUint8 == 1, ncclSuccess == 0)
+struct NcclUniqueId { char internal[128]; };
+typedef void *NcclComm;
+typedef int NcclResult;
+constexpr int kNcclUint8 = 1;
+
+struct Rccl {
+    void *handle = nullptr;
+    NcclResult (*GetUniqueId)(NcclUniqueId *) = nullptr;
+    NcclResult (*CommInitRank)(NcclComm *, int, NcclUniqueId, int) = nullptr;
+    NcclResult (*CommDestroy)(NcclComm) = nullptr;
+    NcclResult (*GroupStart)() = nullptr;
+    NcclResult (*GroupEnd)() = nullptr;
+    NcclResult (*Send)(const void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    NcclResult (*Recv)(void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    NcclResult (*AllGather)(const void *, void *, size_t, int, NcclComm, hipStream_t) = nullptr;
+    NcclResult (*Broadcast)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(NcclResult) = nullptr;
+    std::string why;  // why loading failed
+};
+
+Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // an RCCL this process already maps (torch's) first, then the ROCm installation's
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *n : names)
+            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char *n : names)
+            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!r.handle) r.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!r.handle) {
+            r.why = std::string("librccl.so.1 not loadable: ") + (dlerror() ? dlerror() : "?");
+            return;
+        }
+#define RFX_SYM(field, name)                                          \
+    r.field = (decltype(r.field))dlsym(r.handle, name);              \
+    if (!r.field && r.why.empty()) r.why = std::string("RCCL symbol missing: ") + name
+        RFX_SYM(GetUniqueId, "ncclGetUniqueId");
+        RFX_SYM(CommInitRank, "ncclCommInitRank");
+        RFX_SYM(CommDestroy, "ncclCommDestroy");
+        RFX_SYM(GroupStart, "ncclGroupStart");
+        RFX_SYM(GroupEnd, "ncclGroupEnd");
+        RFX_SYM(Send, "ncclSend");
+        RFX_SYM(Recv, "ncclRecv");
+        RFX_SYM(AllGather, "ncclAllGather");
+        RFX_SYM(Broadcast, "ncclBroadcast");
+        RFX_SYM(GetErrorString, "ncclGetErrorString");
+#undef RFX_SYM
+        if (!r.why.empty()) r.handle = nullptr;
+    });
+    return r.handle ? &r : nullptr;
+}
+
+int nccl_fail(rfx_ctx *c, const char *what, NcclResult rc) {
+    char buf[384];
+    Rccl *r = rccl();
+    snprintf(buf, sizeof buf, "%s: %s", what, (r && r->GetErrorString) ? r->GetErrorString(rc) : "RCCL error");
+    return fail(c, RFX_EDEVICE, buf);
+}
+#define NCCLCHK(c, call)                                   \
+    do {                                                   \
+        NcclResult rc__ = (call);                          \
+        if (rc__ != 0) return nccl_fail(c, #call, rc__);   \
+    } while (0)
+
+// the exchange stream starts after everything enqueued on the draw stream so far
+int comm_begin(rfx_ctx *c) {
+    hipSetDevice(c->device);
+    hipError_t e = hipEventRecord(c->ev_draws, c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->comm_stream, c->ev_draws, 0);
+    return e == hipSuccess ? RFX_OK : fail(c, RFX_EDEVICE, "rfx_comm: ordering the exchange stream after the draws", e);
+}
+int comm_end(rfx_ctx *c) {
+    hipError_t e = hipEventRecord(c->ev_comm, c->comm_stream);
+    if (e != hipSuccess) return fail(c, RFX_EDEVICE, "rfx_comm: hipEventRecord", e);
+    c->comm_pending = true;
+    return RFX_OK;
+}
+int ensure_streams(rfx_ctx *c) {
+    if (c->comm_stream) return RFX_OK;
+    hipSetDevice(c->device);
+    hipError_t e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_draws, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming);
+    return e == hipSuccess ? RFX_OK : fail(c, RFX_EDEVICE, "rfx_comm: stream/event creation", e);
+}
+
+}  // namespace
+
+void rfx_comm_release(rfx_ctx *c) {
+    if (!c) return;
+    if (c->comm_stream) hipStreamSynchronize(c->comm_stream);
+    if (c->comm && c->comm_owned) {
+        Rccl *r = rccl();
+        if (r) r->CommDestroy(c->comm);
+    }
+    c->comm = nullptr;
+    c->comm_owned = false;
+    if (c->ev_draws) hipEventDestroy(c->ev_draws);
+    if (c->ev_comm) hipEventDestroy(c->ev_comm);
+    if (c->comm_stream) hipStreamDestroy(c->comm_stream);
+    c->ev_draws = c->ev_comm = nullptr;
+    c->comm_stream = nullptr;
+    c->comm_pending = false;
+}
+
+extern "C" {
+
+int rfx_split_rows(int height, int nranks, int rank, int *tile_y0, int *tile_rows) {
+    if (height <= 0 || nranks <= 0 || rank < 0 || rank >= nranks) return RFX_EINVAL;
+    const int base = (height / nranks) & ~1;  // tile boundaries on even rows
+    if (base <= 0) return RFX_EINVAL;
+    if (tile_y0) *tile_y0 = rank * base;
+    if (tile_rows) *tile_rows = rank == nranks - 1 ? height - rank * base : base;
+    return RFX_OK;
+}
+
+int rfx_comm_unique_id(void *id128) {
+    if (!id128) return RFX_EINVAL;
+    Rccl *r = rccl();
+    if (!r) return RFX_EUNSUPPORTED;
+    NcclUniqueId id;
+    if (r->GetUniqueId(&id) != 0) return RFX_EDEVICE;
+    memcpy(id128, &id, sizeof id);
+    return RFX_OK;
+}
+
+int rfx_comm_init(rfx_ctx *c, const void *id128, int rank, int nranks) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return RFX_EINVAL;
+    Rccl *r = rccl();
+    if (!r) {
+        static Rccl probe;  // rccl() keeps the reason
+        return fail(c, RFX_EUNSUPPORTED, "rfx_comm_init: RCCL (librccl.so.1) cannot be loaded on this host");
+    }
+    if (c->comm) return fail(c, RFX_ESTATE, "rfx_comm_init: this context already has a communicator");
+    int y0 = 0, rows = 0;
+    if (rfx_split_rows(c->H, nranks, rank, &y0, &rows) != RFX_OK || y0 != c->tile_y0 || rows != c->tile_rows)
+        return fail(c, RFX_EINVAL, "rfx_comm_init: the context's tile is not rfx_split_rows(height, nranks, rank)");
+    if (nranks > 1) {
+        int smallest = 0;
+        rfx_split_rows(c->H, nranks, 0, nullptr, &smallest);
+        // a tile forwards its OWN boundary rows to its neighbour: it must be at least `halo` rows high (multi-hop exchanges are not built)
+        if (c->halo > smallest) return fail(c, RFX_EINVAL, "rfx_comm_init: halo_rows exceeds the smallest tile of this split");
+    }
+    int rc = ensure_streams(c);
+    if (rc) return rc;
+    hipSetDevice(c->device);
+    NcclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    NcclComm comm = nullptr;
+    NCCLCHK(c, r->CommInitRank(&comm, nranks, id, rank));
+    c->comm = comm;
+    c->comm_owned = true;
+    c->comm_rank = rank;
+    c->comm_nranks = nranks;
+    return RFX_OK;
+}
+
+int rfx_comm_destroy(rfx_ctx *c) {
+    if (!c) return RFX_EINVAL;
+    hipSetDevice(c->device);
+    rfx_comm_release(c);
+    return RFX_OK;
+}
+
+int rfx_halo_exchange(rfx_ctx *c, rfx_tex id, void *nccl_comm, int up_rank, int down_rank) {
+    if (!c || id < 0 || id >= RFX_TEX_COUNT) return RFX_EINVAL;
+    Rccl *r = rccl();
+    if (!r) return fail(c, RFX_EUNSUPPORTED, "rfx_halo_exchange: RCCL cannot be loaded on this host");
+    NcclComm comm = nccl_comm ? nccl_comm : c->comm;
+    if (!comm) return fail(c, RFX_ESTATE, "rfx_halo_exchange: no communicator (rfx_comm_init, or pass one)");
+    if (c->halo == 0 || (up_rank < 0 && down_rank < 0)) return RFX_OK;
+    int rc = ensure_streams(c);
+    if (rc) return rc;
+    char *base = (char *)rfx_tex_device_ptr(c, id);
+    if (!base) return RFX_ENOMEM;
+    const Slot &s = c->slots[id];
+    const size_t pitch = (size_t)s.width * s.texel;
+    const int h = c->halo, lo = c->tile_y0 - s.row0, hi = lo + c->tile_rows;  // tile rows inside the held band
+    if (h > c->tile_rows || (down_rank >= 0 && lo < h) || (up_rank >= 0 && hi + h > s.rows))
+        return fail(c, RFX_EINVAL, "rfx_halo_exchange: the held band does not contain halo_rows rows around the tile (whole-frame slot, or halo > tile)");
+    if ((rc = comm_begin(c))) return rc;
+    const size_t bytes = (size_t)h * pitch;
+    NCCLCHK(c, r->GroupStart());
+    NcclResult e = 0;
+    if (up_rank >= 0) {  // `up` owns the rows above this tile: it needs our top rows, we need its bottom rows
+        if (!e) e = r->Send(base + (size_t)(hi - h) * pitch, bytes, kNcclUint8, up_rank, comm, c->comm_stream);
+        if (!e) e = r->Recv(base + (size_t)hi * pitch, bytes, kNcclUint8, up_rank, comm, c->comm_stream);
+    }
+    if (down_rank >= 0) {
+        if (!e) e = r->Send(base + (size_t)lo * pitch, bytes, kNcclUint8, down_rank, comm, c->comm_stream);
+        if (!e) e = r->Recv(base + (size_t)(lo - h) * pitch, bytes, kNcclUint8, down_rank, comm, c->comm_stream);
+    }
+    NcclResult e2 = r->GroupEnd();
+    if (e) return nccl_fail(c, "rfx_halo_exchange: ncclSend/ncclRecv", e);
+    if (e2) return nccl_fail(c, "rfx_halo_exchange: ncclGroupEnd", e2);
+    return comm_end(c);
+}
+
+int rfx_allgather_history(rfx_ctx *c, rfx_tex id, void *nccl_comm) {
+    if (!c) return RFX_EINVAL;
+    if (id != RFX_TEX_COMPOSE && id != RFX_TEX_COMPOSE_RGB) return fail(c, RFX_EINVAL, "rfx_allgather_history: RFX_TEX_COMPOSE or RFX_TEX_COMPOSE_RGB");
+    Rccl *r = rccl();
+    if (!r) return fail(c, RFX_EUNSUPPORTED, "rfx_allgather_history: RCCL cannot be loaded on this host");
+    NcclComm comm = nccl_comm ? nccl_comm : c->comm;
+    if (!comm) return fail(c, RFX_ESTATE, "rfx_allgather_history: no communicator (rfx_comm_init, or pass one)");
+    const int n = c->comm_nranks, rank = c->comm_rank;
+    if (nccl_comm && !c->comm) return fail(c, RFX_ESTATE, "rfx_allgather_history: rank and size come from rfx_comm_init");
+    int rc = ensure_streams(c);
+    if (rc) return rc;
+    char *base = (char *)rfx_tex_device_ptr(c, id);  // held whole: frame row y at y * pitch
+    if (!base) return RFX_ENOMEM;
+    const Slot &s = c->slots[id];
+    const size_t pitch = (size_t)s.width * s.texel;
+    if ((rc = comm_begin(c))) return rc;
+    int y0 = 0, rows = 0, last_rows = 0;
+    rfx_split_rows(c->H, n, 0, &y0, &rows);
+    rfx_split_rows(c->H, n, n - 1, nullptr, &last_rows);
+    if (last_rows == rows) {  // equal tiles: one in-place all-gather (every rank's tile already sits at its frame position)
+        NCCLCHK(c, r->AllGather(base + (size_t)c->tile_y0 * pitch, base, (size_t)rows * pitch, kNcclUint8, comm, c->comm_stream));
+    } else {  // ragged last tile: one broadcast per owner, aggregated in a group
+        NCCLCHK(c, r->GroupStart());
+        NcclResult e = 0;
+        for (int k = 0; k < n && !e; k++) {
+            int ky0 = 0, krows = 0;
+            rfx_split_rows(c->H, n, k, &ky0, &krows);
+            char *p = base + (size_t)ky0 * pitch;
+            e = r->Broadcast(p, p, (size_t)krows * pitch, kNcclUint8, k, comm, c->comm_stream);
+        }
+        NcclResult e2 = r->GroupEnd();
+        if (e) return nccl_fail(c, "rfx_allgather_history: ncclBroadcast", e);
+        if (e2) return nccl_fail(c, "rfx_allgather_history: ncclGroupEnd", e2);
+    }
+    (void)rank;
+    return comm_end(c);
+}
+
+int rfx_comm_wait(rfx_ctx *c) {
+    if (!c) return RFX_EINVAL;
+    if (!c->comm_pending) return RFX_OK;
+    hipSetDevice(c->device);
+    hipError_t e = hipStreamWaitEvent(c->stream, c->ev_comm, 0);
+    if (e != hipSuccess) return fail(c, RFX_EDEVICE, "rfx_comm_wait: hipStreamWaitEvent", e);
+    c->comm_pending = false;
+    return RFX_OK;
+}
+
+}  // extern "C"

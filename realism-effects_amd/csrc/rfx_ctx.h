@@ -1,0 +1,73 @@
+// rfx_ctx.h — the context object behind the opaque rfx_ctx handle, shared by rfx_api.hip (slots, draws) and rfx_comm.hip
+// (RCCL exchanges of a row-tiled run).  Private to librfx_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string>
+#include "../../include/rfx.h"
+
+struct Slot {
+    void *ptr = nullptr;
+    bool owned = false;
+    int row0 = 0, rows = 0;  // held band (frame rows)
+    size_t texel = 0;
+    int width = 0;
+    bool uploaded = false;
+};
+
+struct rfx_ctx {
+    int device = 0;
+    int W = 0, H = 0, tile_y0 = 0, tile_rows = 0, halo = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned int *halo_violations = nullptr;
+    float *viewz = nullptr;    // K1 scratch: view-space Z plane (full frame)
+    float4 *hits = nullptr;    // K1 trace -> shade hand-over (rfx_ssgi_trace), 2 texels per SSGI texel
+    bool hits_traced = false;  // a trace is waiting for its shade
+    int win_y0 = 0, win_y1 = 0x7fffffff;  // rfx_set_row_window: rows the draws may produce
+    float2 *coarse = nullptr;  // K1 scratch: exact (min,max) view Z per 16x16 base cell
+    unsigned int *cells = nullptr;  // K1 scratch: the march's half-packed (min,max) table
+    float4 *env = nullptr;     // scene.environment: the whole mip chain, float4 texels
+    float *env_marginal = nullptr, *env_conditional = nullptr;  // EquirectHdrInfo inverse-CDF tables (importanceSampling)
+    float env_sum_whole = 1.0f, env_sum_decimal = 0.0f;
+    int env_w = 0, env_h = 0, env_levels = 0;
+    unsigned int env_off[16] = {0};
+    Slot slots[RFX_TEX_COUNT];
+    // row-tiled runs (rfx_comm.hip): the RCCL communicator of the tile ring, a second stream the exchanges run on, and the two
+    // events that order it against the draw stream
+    void *comm = nullptr;            // ncclComm_t
+    bool comm_owned = false;
+    int comm_rank = 0, comm_nranks = 1;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_draws = nullptr, ev_comm = nullptr;
+    bool comm_pending = false;       // exchanges issued since the last rfx_comm_wait
+    std::string err;
+};
+void rfx_comm_release(rfx_ctx *c);  // rfx_comm.hip: called by rfx_destroy
+
+extern thread_local std::string g_create_err;
+
+static inline size_t texel_bytes(int id) {
+    switch (id) {
+    case RFX_TEX_DEPTH: return 4;
+    case RFX_TEX_BLUE_NOISE: return 4;
+    case RFX_TEX_COMPOSE_RGB: return 12;
+    case RFX_TEX_DENOISE_A0: case RFX_TEX_DENOISE_A1: case RFX_TEX_DENOISE_B0: case RFX_TEX_DENOISE_B1: case RFX_TEX_FBCOPY_F16: return 8;
+    default: return 16;
+    }
+}
+
+static inline int fail(rfx_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    if (c) c->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+#define HIPCHK(c, call)                                              \
+    do {                                                             \
+        hipError_t e__ = (call);                                     \
+        if (e__ != hipSuccess) return fail(c, RFX_EDEVICE, #call, e__); \
+    } while (0)
+

@@ -375,6 +375,8 @@ class DenoiserComposePass {
 	}
 	render(renderer) {
 		this.uniforms.camera = cloneCamera(this._camera)
+		// a row-tiled renderer all-gathers the part of this target K1 reads next frame (.rgb) as 12-byte texels
+		this.uniforms.writeHistoryRGB = renderer.gatherHistoryRGB ? 1 : 0
 		renderer.compose(this.uniforms)
 	}
 	dispose() {}
@@ -487,7 +489,13 @@ class SSGIPass {
 		// getter returns the ARRAY of K3's targets — what three binds for a non-texture value: its empty texture (zeros)
 		const t = this.ssgiEffect.denoiser.texture
 		this.uniforms.historySource = Array.isArray(t) ? 2 : t === TEX.TEMPORAL0 ? 1 : 0
-		renderer.ssgiMarch(this.uniforms) // :93-94
+		if (this.uniforms.historySource === 0 && renderer.gatherHistoryRGB) this.uniforms.historySource = 3 // the same values from RFX_TEX_COMPOSE_RGB (tiling.js)
+		if (renderer.overlapHistoryGather) {
+			// row-tiled run: last frame's composed GI is still being all-gathered; only the shading half of the draw reads it
+			renderer.ssgiTrace(this.uniforms)
+			renderer.beforeSsgiShade()
+			renderer.ssgiShade(this.uniforms)
+		} else renderer.ssgiMarch(this.uniforms) // :93-94
 	}
 	dispose() {}
 }

@@ -5,6 +5,9 @@
 // denoise_b1.bin / temporal0.bin / ssgi.bin / final.bin (the effect's mainImage output) of the LAST frame into --out.
 // With --traa '"half"' | '"float"': runs TRAAEffect.update() instead, the dump's direct.bin standing for the composer's
 // input buffer (HalfFloatType / FloatType), and writes traa.bin (traa_compose output, RGBA32F) of the last frame.
+// With --ranks N (N > 1): the frame is cut into N row tiles, ONE NODE PROCESS PER GPU (this process spawns them: rank r drives
+// device r), which exchange halo rows and the composed GI over RCCL through the C ABI (js/tiling.js); rank 0 creates the
+// ncclUniqueId and hands it over through a file.  The parent stitches the tiles: the outputs are bit-identical to a --ranks 1 run.
 const fs = require("fs")
 const path = require("path")
 const rfx = require("./index")
@@ -22,6 +25,43 @@ if (!dumps.length) {
 	console.error("usage: run_dump.js <dumpdir>... --out <dir> [--steps N ...]")
 	process.exit(2)
 }
+// ---- row-tiled run: parent process
+if (opt.ranks > 1 && opt.rank === undefined) {
+	const cp = require("child_process")
+	const os = require("os")
+	fs.mkdirSync(out, { recursive: true })
+	const idFile = path.join(fs.mkdtempSync(path.join(os.tmpdir(), "rfx-")), "nccl_id")
+	const kids = []
+	for (let r = 0; r < opt.ranks; r++)
+		kids.push(cp.spawn(process.execPath, [__filename].concat(args, ["--rank", String(r), "--idFile", JSON.stringify(idFile)]), { stdio: ["ignore", "pipe", "inherit"] }))
+	let left = kids.length, failed = false
+	const lines = new Array(kids.length).fill("")
+	kids.forEach((k, r) => {
+		k.stdout.on("data", d => (lines[r] += d))
+		k.on("exit", code => {
+			if (code !== 0) failed = true
+			if (--left) return
+			if (failed) {
+				console.error("a rank failed")
+				process.exit(1)
+			}
+			// stitch the row tiles (rank order = ascending rows)
+			for (const name of ["final", "compose", "denoise_b0", "denoise_b1", "temporal0", "ssgi"]) {
+				const parts = kids.map((_, q) => fs.readFileSync(path.join(out, name + ".rank" + q + ".bin")))
+				fs.writeFileSync(path.join(out, name + ".bin"), Buffer.concat(parts))
+				kids.forEach((_, q) => fs.unlinkSync(path.join(out, name + ".rank" + q + ".bin")))
+			}
+			const info = lines.map(l => JSON.parse(l.trim().split("\n").pop()))
+			console.log(JSON.stringify({ frames: dumps.length, width: info[0].width, height: info[0].height, ranks: opt.ranks, haloRows: info[0].haloRows,
+				haloViolations: info.reduce((a, b) => a + b.haloViolations, 0), exchanges: info[0].exchanges }))
+		})
+	})
+	return
+}
+const tiled = opt.ranks > 1 ? { rank: opt.rank, ranks: opt.ranks, idFile: opt.idFile } : null
+delete opt.ranks
+delete opt.rank
+delete opt.idFile
 const seeds = { ssgi: opt.ssgiSeed === undefined ? 11 : opt.ssgiSeed, denoise: opt.denoiseSeed === undefined ? 22 : opt.denoiseSeed }
 delete opt.ssgiSeed
 delete opt.denoiseSeed
@@ -36,7 +76,32 @@ if (opt.env) {
 	delete opt.envHeight
 }
 const camera = Object.assign({}, first.camera)
-const renderer = new rfx.Renderer(first.width, first.height)
+let renderer
+if (tiled) {
+	// halo: the K3 tap footprint and the largest vertical motion of the sequence (rfx_amd/tiling.py required_halo)
+	let vmax = 0
+	for (const d of dumps) {
+		const f = d === dumps[0] ? first : rfx.readDump(d)
+		if (!f.velocity) throw new Error("--ranks needs packed velocity.bin dumps")
+		const v = new Float32Array(f.velocity.buffer, f.velocity.byteOffset, f.velocity.length)
+		for (let i = 1; i < v.length; i += 4) if (Math.abs(v[i]) > vmax) vmax = Math.abs(v[i])
+	}
+	const halo = rfx.requiredHalo(opt.radius === undefined ? 3 : opt.radius, vmax, first.height, first.width)
+	let id
+	if (tiled.rank === 0) {
+		id = rfx.commUniqueId()
+		fs.writeFileSync(tiled.idFile + ".tmp", id)
+		fs.renameSync(tiled.idFile + ".tmp", tiled.idFile)
+	} else {
+		const t0 = Date.now()
+		while (!fs.existsSync(tiled.idFile)) {
+			if (Date.now() - t0 > 120000) throw new Error("rank " + tiled.rank + ": no ncclUniqueId from rank 0")
+			Atomics.wait(new Int32Array(new SharedArrayBuffer(4)), 0, 0, 20)
+		}
+		id = fs.readFileSync(tiled.idFile)
+	}
+	renderer = new rfx.TiledRenderer(first.width, first.height, tiled.rank, tiled.ranks, halo, id, { device: process.env.RFX_ONE_GPU === "1" ? 0 : tiled.rank })
+} else renderer = new rfx.Renderer(first.width, first.height)
 if (opt.traa) {
 	const half = opt.traa === "half"
 	const traa = new rfx.TRAAEffect(scene, camera, new rfx.VelocityDepthNormalPass(scene, camera), { fullAccumulate: true }, true)
@@ -65,7 +130,9 @@ fs.mkdirSync(out, { recursive: true })
 const T = rfx.TEX
 effect.mainImage(renderer) // the effect's own fragment -> final.bin
 for (const [name, tex] of [["final", T.FINAL], ["compose", T.COMPOSE], ["denoise_b0", T.DENOISE_B0], ["denoise_b1", T.DENOISE_B1], ["temporal0", T.TEMPORAL0], ["ssgi", T.SSGI]]) {
-	const a = renderer.download(tex)
-	fs.writeFileSync(path.join(out, name + ".bin"), Buffer.from(a.buffer, a.byteOffset, a.byteLength))
+	// a tile writes its own rows; the parent stitches them
+	const a = tiled ? renderer.download(tex, renderer.tileY0, renderer.tileRows) : renderer.download(tex)
+	fs.writeFileSync(path.join(out, name + (tiled ? ".rank" + tiled.rank : "") + ".bin"), Buffer.from(a.buffer, a.byteOffset, a.byteLength))
 }
-console.log(JSON.stringify({ frames: dumps.length, width: first.width, height: first.height, haloViolations: renderer.haloViolations() }))
+console.log(JSON.stringify({ frames: dumps.length, width: first.width, height: first.height, haloViolations: renderer.haloViolations(),
+	haloRows: tiled ? renderer.haloRows : 0, exchanges: tiled ? renderer.exchangeCount : 0 }))

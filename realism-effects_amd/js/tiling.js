@@ -1,0 +1,140 @@
+"use strict"
+// Row tiling over the GPUs of one node, one Node process per GPU (SURVEY.md §8e; Python twin: rfx_amd/tiling.py).
+// TiledRenderer wraps the tile's Renderer and performs the exchange steps through the C ABI's RCCL entry points
+// (include/rfx.h "row-tiled runs": rfx_halo_exchange / rfx_allgather_history / rfx_comm_wait):
+//   after K2 and after every K3 pass : halo Send/Recv of the textures just written with the row neighbours, issued on the
+//                                      context's exchange stream; the next draw (K3 pass, K4) first produces the tile INTERIOR
+//                                      (setRowWindow), then waits, then draws the two boundary strips
+//   after K4                         : all-gather of .rgb of the composed GI (RFX_TEX_COMPOSE_RGB) — next frame's K1 gathers it
+//                                      anywhere; only its shading half reads it, so K1 runs as ssgiTrace / ssgiShade with the
+//                                      wait in between
+const addon = require("../napi/rfx_napi.node")
+const { Renderer, TEX } = require("./Renderer")
+
+function splitRows(height, nranks, rank) {
+	return addon.splitRows(height, nranks, rank)
+}
+
+// rows of halo that make the tiled result exact (rfx_amd/tiling.py required_halo)
+function requiredHalo(radius, maxAbsVelocityY, frameHeight, frameWidth) {
+	const aspectRows = frameWidth ? Math.max(1, frameHeight / frameWidth) : 1
+	const k3 = Math.ceil(radius * aspectRows) + 2
+	const k2 = Math.ceil(Math.abs(maxAbsVelocityY) * frameHeight) + 4
+	return Math.max(k3, k2, 2)
+}
+
+class TiledRenderer {
+	// `uniqueId`: the 128-byte Buffer of commUniqueId() made by rank 0 and handed to every process
+	constructor(width, height, rank, nranks, haloRows, uniqueId, options) {
+		const t = splitRows(height, nranks, rank)
+		this.rank = rank
+		this.nranks = nranks
+		this.inner = new Renderer(width, height, Object.assign({}, options || {}, { tileY0: t[0], tileRows: t[1], haloRows: nranks > 1 ? haloRows : 0 }))
+		this.width = width
+		this.height = height
+		this.tileY0 = t[0]
+		this.tileRows = t[1]
+		this.haloRows = this.inner.haloRows
+		addon.commInit(this.inner._h, uniqueId, rank, nranks)
+		this.gatherHistoryRGB = nranks > 1
+		this.overlapHistoryGather = nranks > 1
+		this._haloPending = false
+		this.exchangeCount = 0
+		// everything that is not intercepted below goes to the tile's renderer
+		return new Proxy(this, {
+			get: (target, prop) => {
+				if (prop in target) return target[prop]
+				const v = target.inner[prop]
+				return typeof v === "function" ? v.bind(target.inner) : v
+			}
+		})
+	}
+	_up() {
+		return this.rank + 1 < this.nranks ? this.rank + 1 : -1 // owns the rows above this tile
+	}
+	_down() {
+		return this.rank > 0 ? this.rank - 1 : -1
+	}
+	exchange(texs) {
+		if (this.nranks === 1 || this.haloRows === 0) return
+		for (const tex of texs) addon.haloExchange(this.inner._h, tex, this._up(), this._down())
+		this._haloPending = true
+		this.exchangeCount++
+	}
+	commWait() {
+		addon.commWait(this.inner._h)
+		this._haloPending = false
+	}
+	// hooks called by effects.js
+	afterTemporalPass() {
+		this.exchange([TEX.TEMPORAL0, TEX.TEMPORAL1])
+	}
+	afterDenoisePass(i, uniforms) {
+		this.exchange(uniforms.writeToB ? [TEX.DENOISE_B0, TEX.DENOISE_B1] : [TEX.DENOISE_A0, TEX.DENOISE_A1])
+	}
+	afterComposePass() {
+		if (this.nranks > 1) addon.allgatherHistory(this.inner._h, TEX.COMPOSE_RGB)
+	}
+	afterCopyFramebuffer(tex) {
+		this.exchange([tex])
+	}
+	beforeSsgiShade() {
+		this.commWait()
+	}
+	ssgiMarch(u) {
+		this.commWait()
+		this.inner.ssgiMarch(u)
+	}
+	temporalReproject(u) {
+		this.commWait() // K2 gathers its history (exchanged at the end of the previous frame) anywhere within the halo
+		this.inner.temporalReproject(u)
+	}
+	copyFramebuffer(dst) {
+		this.commWait()
+		this.inner.copyFramebuffer(dst)
+	}
+	poissonDenoise(u) {
+		this._interiorFirst(() => this.inner.poissonDenoise(u))
+	}
+	compose(u) {
+		this._interiorFirst(() => this.inner.compose(u))
+	}
+	finalCompose(u) {
+		this.commWait()
+		this.inner.finalCompose(u)
+	}
+	_interiorFirst(draw) {
+		if (!this._haloPending) return draw()
+		const y0 = this.tileY0, y1 = this.tileY0 + this.tileRows, h = this.haloRows
+		const lo = y0 + (this.rank > 0 ? h : 0), hi = y1 - (this.rank < this.nranks - 1 ? h : 0)
+		if (hi <= lo) {
+			this.commWait()
+			return draw()
+		}
+		try {
+			this.inner.setRowWindow(lo, hi)
+			draw()
+			this.commWait()
+			if (lo > y0) {
+				this.inner.setRowWindow(y0, lo)
+				draw()
+			}
+			if (hi < y1) {
+				this.inner.setRowWindow(hi, y1)
+				draw()
+			}
+		} finally {
+			this.inner.setRowWindow(0, 0)
+		}
+	}
+	download(tex, row0, rows) {
+		this.commWait()
+		return this.inner.download(tex, row0, rows)
+	}
+	sync() {
+		this.commWait()
+		this.inner.sync()
+	}
+}
+
+module.exports = { TiledRenderer, splitRows, requiredHalo, commUniqueId: addon.commUniqueId }

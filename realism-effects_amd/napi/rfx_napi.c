@@ -289,6 +289,7 @@ static napi_value n_set_environment_importance(napi_env env, napi_callback_info 
     rfx_ctx *c = get_ctx(env, a[0]);
     if (!c) return NULL;
     const float *tab[2];
+    size_t count[2];
     for (int k = 0; k < 2; k++) {
         napi_typedarray_type tt;
         size_t len;
@@ -298,11 +299,14 @@ static napi_value n_set_environment_importance(napi_env env, napi_callback_info 
             return NULL;
         }
         tab[k] = (const float *)ptr;
+        count[k] = len;  /* the library checks them against the environment's size before it copies */
     }
     double whole = 0, dec = 0;
-    napi_get_value_double(env, a[3], &whole);
-    napi_get_value_double(env, a[4], &dec);
-    int rc = rfx_set_environment_importance(c, tab[0], tab[1], (float)whole, (float)dec);
+    if (napi_get_value_double(env, a[3], &whole) != napi_ok || napi_get_value_double(env, a[4], &dec) != napi_ok) {
+        napi_throw_type_error(env, NULL, "setEnvironmentImportance: totalSumWhole / totalSumDecimal must be numbers");
+        return NULL;
+    }
+    int rc = rfx_set_environment_importance(c, tab[0], count[0], tab[1], count[1], (float)whole, (float)dec);
     if (rc) return throw_rfx(env, c, "rfx_set_environment_importance", rc);
     return NULL;
 }
@@ -379,6 +383,95 @@ static napi_value n_set_row_window(napi_env env, napi_callback_info info) {
     if (!c || !get_int(env, a[1], &y0) || !get_int(env, a[2], &y1)) return NULL;
     int rc = rfx_set_row_window(c, y0, y1);
     if (rc) return throw_rfx(env, c, "rfx_set_row_window", rc);
+    return NULL;
+}
+
+/* ---- row-tiled runs (rfx.h "row-tiled runs"): one Node process per GPU */
+/* splitRows(height, nranks, rank) -> [tile_y0, tile_rows] */
+static napi_value n_split_rows(napi_env env, napi_callback_info info) {
+    napi_value a[3], arr, v;
+    int32_t h, n, r;
+    int y0 = 0, rows = 0;
+    if (!get_args(env, info, 3, a) || !get_int(env, a[0], &h) || !get_int(env, a[1], &n) || !get_int(env, a[2], &r)) return NULL;
+    if (rfx_split_rows(h, n, r, &y0, &rows) != RFX_OK) {
+        napi_throw_range_error(env, NULL, "splitRows: height cannot be cut into that many tiles of at least 2 rows");
+        return NULL;
+    }
+    NAPI_CALL(env, napi_create_array_with_length(env, 2, &arr));
+    NAPI_CALL(env, napi_create_int32(env, y0, &v));
+    napi_set_element(env, arr, 0, v);
+    NAPI_CALL(env, napi_create_int32(env, rows, &v));
+    napi_set_element(env, arr, 1, v);
+    return arr;
+}
+/* commUniqueId() -> Buffer(128) (ncclGetUniqueId; rank 0 hands it to the other processes, e.g. through a file) */
+static napi_value n_comm_unique_id(napi_env env, napi_callback_info info) {
+    char id[128];
+    napi_value buf;
+    void *data = NULL;
+    int rc = rfx_comm_unique_id(id);
+    if (rc) {
+        napi_throw_error(env, NULL, "rfx_comm_unique_id failed: RCCL not loadable on this host or no device");
+        return NULL;
+    }
+    NAPI_CALL(env, napi_create_buffer_copy(env, sizeof id, id, &data, &buf));
+    return buf;
+}
+/* commInit(ctx, Buffer id128, rank, nranks) */
+static napi_value n_comm_init(napi_env env, napi_callback_info info) {
+    napi_value a[4];
+    int32_t rank, n;
+    void *data = NULL;
+    size_t len = 0;
+    if (!get_args(env, info, 4, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[2], &rank) || !get_int(env, a[3], &n)) return NULL;
+    if (napi_get_buffer_info(env, a[1], &data, &len) != napi_ok || len != 128) {
+        napi_throw_type_error(env, NULL, "commInit: the unique id is a 128-byte Buffer");
+        return NULL;
+    }
+    int rc = rfx_comm_init(c, data, rank, n);
+    if (rc) return throw_rfx(env, c, "rfx_comm_init", rc);
+    return NULL;
+}
+/* haloExchange(ctx, tex, upRank, downRank) — -1 = no such neighbour */
+static napi_value n_halo_exchange(napi_env env, napi_callback_info info) {
+    napi_value a[4];
+    int32_t tex, up, down;
+    if (!get_args(env, info, 4, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[1], &tex) || !get_int(env, a[2], &up) || !get_int(env, a[3], &down)) return NULL;
+    int rc = rfx_halo_exchange(c, (rfx_tex)tex, NULL, up, down);
+    if (rc) return throw_rfx(env, c, "rfx_halo_exchange", rc);
+    return NULL;
+}
+/* allgatherHistory(ctx, tex) */
+static napi_value n_allgather_history(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    int32_t tex;
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[1], &tex)) return NULL;
+    int rc = rfx_allgather_history(c, (rfx_tex)tex, NULL);
+    if (rc) return throw_rfx(env, c, "rfx_allgather_history", rc);
+    return NULL;
+}
+/* commWait(ctx) / commDestroy(ctx) */
+static napi_value n_comm_wait(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    int rc = rfx_comm_wait(c);
+    if (rc) return throw_rfx(env, c, "rfx_comm_wait", rc);
+    return NULL;
+}
+static napi_value n_comm_destroy(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    rfx_comm_destroy(c);
     return NULL;
 }
 
@@ -513,6 +606,8 @@ static napi_value init(napi_env env, napi_value exports) {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
         {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"setEnvironmentImportance", n_set_environment_importance}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"ssgiTrace", n_ssgi_trace}, {"ssgiShade", n_ssgi_shade}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
         {"sync", n_sync}, {"setRowWindow", n_set_row_window}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
+        {"splitRows", n_split_rows}, {"commUniqueId", n_comm_unique_id}, {"commInit", n_comm_init}, {"haloExchange", n_halo_exchange},
+        {"allgatherHistory", n_allgather_history}, {"commWait", n_comm_wait}, {"commDestroy", n_comm_destroy},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -152,8 +152,9 @@ class Context:
         m = np.ascontiguousarray(marginal, np.float32)
         c = np.ascontiguousarray(conditional, np.float32)
         whole = float(int(total_sum))
-        self._chk(self.lib.rfx_set_environment_importance(self._h, m.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), whole, float(total_sum - whole)),
-                  "rfx_set_environment_importance")
+        # the library checks the counts against the environment's size (height / width*height floats)
+        self._chk(self.lib.rfx_set_environment_importance(self._h, m.ctypes.data_as(C.c_void_p), m.size, c.ctypes.data_as(C.c_void_p), c.size, whole,
+                                                          float(total_sum - whole)), "rfx_set_environment_importance")
 
     def download_environment(self, level: int, size) -> np.ndarray:
         """Mip level `level` of the environment; `size` = (width, height) of the base level."""
@@ -200,6 +201,39 @@ class Context:
 
     def sync(self):
         self._chk(self.lib.rfx_sync(self._h), "rfx_sync")
+
+    # -- row-tiled runs: RCCL exchanges behind the C ABI (rfx.h "row-tiled runs")
+    @staticmethod
+    def split_rows(height: int, nranks: int, rank: int):
+        y0, n = C.c_int(), C.c_int()
+        if abi.load_library().rfx_split_rows(int(height), int(nranks), int(rank), C.byref(y0), C.byref(n)) != 0:
+            raise ValueError("rfx_split_rows(%d, %d, %d)" % (height, nranks, rank))
+        return y0.value, n.value
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = abi.load_library().rfx_comm_unique_id(buf)
+        if rc != 0:
+            raise RfxError("rfx_comm_unique_id failed (%d): RCCL not loadable on this host?" % rc)
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, nranks: int):
+        assert len(unique_id) == 128
+        self._chk(self.lib.rfx_comm_init(self._h, C.c_char_p(unique_id), int(rank), int(nranks)), "rfx_comm_init")
+        self.comm_rank, self.comm_nranks = int(rank), int(nranks)
+
+    def comm_destroy(self):
+        self._chk(self.lib.rfx_comm_destroy(self._h), "rfx_comm_destroy")
+
+    def halo_exchange(self, tex: int, up_rank: int, down_rank: int):
+        self._chk(self.lib.rfx_halo_exchange(self._h, tex, None, int(up_rank), int(down_rank)), "rfx_halo_exchange")
+
+    def allgather_history(self, tex: int):
+        self._chk(self.lib.rfx_allgather_history(self._h, tex, None), "rfx_allgather_history")
+
+    def comm_wait(self):
+        self._chk(self.lib.rfx_comm_wait(self._h), "rfx_comm_wait")
 
     def time_begin(self):
         self._chk(self.lib.rfx_time_begin(self._h), "rfx_time_begin")

@@ -72,6 +72,9 @@ class TiledRenderer:
     def __init__(self, inner, tensors: dict, rank: int, world: int, group=None):
         import torch.distributed as dist
         self._dist = dist
+        self._setup(inner, tensors, rank, world, group)
+
+    def _setup(self, inner, tensors, rank, world, group=None):
         self.inner, self.tensors, self.rank, self.world, self.group = inner, tensors, rank, world, group
         self.W, self.H = inner.W, inner.H
         self.tile_y0, self.tile_rows, self.halo = inner.tile_y0, inner.tile_rows, inner.halo
@@ -250,6 +253,44 @@ class TiledRenderer:
         if getattr(self.inner, "uses_torch_stream", False):
             return
         self.inner.sync()
+
+
+class CommTiledRenderer(TiledRenderer):
+    """The same protocol with the exchanges BEHIND THE C ABI (include/rfx.h "row-tiled runs"): rfx_halo_exchange /
+    rfx_allgather_history enqueue RCCL Send/Recv / all-gather on the context's exchange stream, ordered after the draws issued so
+    far; rfx_comm_wait orders the following draws after them.  No torch, no bound external buffers: the textures stay the
+    context's own.  `unique_id`: the 128 bytes of Context.comm_unique_id() made by rank 0 and handed to every rank."""
+
+    def __init__(self, ctx, rank: int, world: int, unique_id: bytes, denoise_mode: str = "full"):
+        self._dist = None
+        self._setup(ctx, {t: None for t in (exchanged_textures(denoise_mode) if world > 1 else ())}, rank, world)
+        ctx.comm_init(unique_id, rank, world)
+        self._comm_pending = False
+
+    def exchange(self, texs):
+        if self.world == 1 or self.halo == 0:
+            return
+        up = self.rank + 1 if self.rank + 1 < self.world else -1
+        down = self.rank - 1
+        for tex in texs:
+            if tex not in self.tensors:
+                raise KeyError("CommTiledRenderer.exchange: texture %s is not part of this run's exchange set" % abi.TEX_NAMES[tex])
+            self.inner.halo_exchange(tex, up, down)
+        self._halo_pending = [True]
+        self.exchange_count += 1
+
+    def allgather_compose(self):
+        if self.world == 1:
+            return
+        self.inner.allgather_history(abi.TEX_COMPOSE_RGB if self.gather_history_rgb else abi.TEX_COMPOSE)
+        self._pending = [True]
+
+    def finish_halo(self):
+        if self._halo_pending or self._pending:
+            self.inner.comm_wait()  # one event covers everything issued so far on the exchange stream
+        self._halo_pending, self._pending = [], []
+
+    finish_pending = finish_halo
 
 
 def exchanged_textures(denoise_mode: str = "full"):

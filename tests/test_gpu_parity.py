@@ -671,6 +671,51 @@ def test_env_map_vs_oracle(blue_noise, env_blur, half):
     ctx.close()
 
 
+def test_comm_entry_points_on_a_single_rank_ring(blue_noise):
+    """The RCCL exchanges behind the C ABI (rfx.h "row-tiled runs") on the one GPU a test box has: a ring of ONE rank.  RCCL is bound at
+    run time, the communicator is created on the context's device, the all-gather of the composed GI runs in place on the exchange
+    stream and rfx_comm_wait orders the next draw after it; a frame driven through CommTiledRenderer is bit-identical to the plain
+    context's.  (Two ranks need two GPUs — RCCL refuses duplicate devices; the driver's N = 2/4/8 bench runs are that test, the
+    exchange LOGIC is covered over gloo in test_tiling_gloo.py.)"""
+    import types
+    from rfx_amd import abi, tiling
+    from rfx_amd.context import Context, RfxError
+    from rfx_amd.effect import SSGIEffect
+    from rfx_amd.scene import synthetic_frame
+
+    W, H = 192, 108
+    assert Context.split_rows(2160, 8, 7) == (1890, 270) and Context.split_rows(90, 4, 3) == (66, 24)
+    outs = []
+    for tiled in (False, True):
+        ctx = Context(W, H)
+        r = tiling.CommTiledRenderer(ctx, 0, 1, Context.comm_unique_id()) if tiled else ctx
+        scene = types.SimpleNamespace(frame=None)
+        cam = types.SimpleNamespace(**vars(synthetic_frame(W, H, 0).camera))
+        fx = SSGIEffect(None, scene, cam, dict(width=W, height=H), seeds=dict(ssgi=3, denoise=4), half_store_rtz=True)
+        for fi in range(2):
+            f = synthetic_frame(W, H, fi)
+            scene.frame = f
+            for k, v in vars(f.camera).items():
+                setattr(cam, k, v)
+            fx.update(r, None)
+            if tiled:  # the entry points themselves (a one-rank ring has no neighbours: -1 / -1; the gather is the identity)
+                ctx.halo_exchange(abi.TEX_DENOISE_B0, -1, -1)
+                ctx.allgather_history(abi.TEX_COMPOSE)
+                ctx.comm_wait()
+        outs.append((ctx.download(abi.TEX_COMPOSE), ctx.download(abi.TEX_DENOISE_B1)))
+        if tiled:
+            with pytest.raises(RfxError):
+                ctx.comm_init(Context.comm_unique_id(), 0, 1)  # already has a communicator
+            ctx.comm_destroy()
+        ctx.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # a tile that is not the rank's share of the split is refused before any RCCL call
+    ctx = Context(W, H, tile_y0=10, tile_rows=44, halo_rows=2)
+    with pytest.raises(RfxError, match="rfx_split_rows"):
+        ctx.comm_init(Context.comm_unique_id(), 0, 2)
+    ctx.close()
+
+
 def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
     """bench.py's N>1 path end to end — torch.distributed.run, per-rank band dumps, halo Send/Recv after K2 and every K3 pass, the
     composed-GI all-gather, max-over-ranks timing — with two ranks sharing this GPU over gloo (RCCL refuses two ranks on one device;
@@ -682,14 +727,15 @@ def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RFX_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
-    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--checksum"]
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--checksum", "--no-extras"]
     two = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                                    "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--width", "960", "--height", "540"] + common,
                                   env=env, text=True, stderr=subprocess.DEVNULL, timeout=600)
     j2 = json.loads([l for l in two.splitlines() if l.startswith("{")][-1])
-    assert j2["n_gpus"] == 2 and j2["halo_violations"] == 0 and j2["value"] > 0 and j2["scaling"] == "weak"
+    # N > 1 is BASELINE configs[3]'s shape: THE SAME frame cut into N row tiles (strong scaling)
+    assert j2["n_gpus"] == 2 and j2["halo_violations"] == 0 and j2["value"] > 0 and j2["scaling"] == "strong"
     W, H = [int(x) for x in j2["config"]["frame"].split("x")]
-    assert H == j2["frame_rows"] == 2 * j2["config"]["tile_rows"]
+    assert (W, H) == (960, 540) and H == j2["frame_rows"] == 2 * j2["config"]["tile_rows"]
     one = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--width", str(W), "--height", str(H)] + common, env=env, text=True,
                                   stderr=subprocess.DEVNULL, timeout=600)
     j1 = json.loads([l for l in one.splitlines() if l.startswith("{")][-1])
