@@ -279,6 +279,20 @@ int rfx_final_compose(rfx_ctx *, const rfx_final_params *);
 
 int rfx_sync(rfx_ctx *);
 
+/* ---- streaming dumps: host buffers that cross PCIe every frame (an offline run over a dumped sequence).  rfx_upload is synchronous
+ * (the caller may free the plane on return).  The streaming form double-buffers the four input planes of the dump (depth, gbuffer,
+ * velocity, direct light): rfx_stage_upload enqueues the copy of the NEXT frame's plane into the slot's back buffer on the context's
+ * upload stream and returns; rfx_stage_flip makes everything staged since the last flip current — draws enqueued after it wait for
+ * those copies, and copies staged after it wait for the draws enqueued before it (they overwrite the buffer those draws read).
+ *     stage(frame 0); flip();   loop: stage(frame n+1); draws of frame n; flip()
+ * `host` must stay valid and unchanged until the flip that publishes it has been followed by rfx_sync, or come from rfx_host_alloc
+ * and not be rewritten before the next-but-one flip.  Pinned memory (rfx_host_alloc = hipHostMalloc) is what makes the copy
+ * asynchronous; a pageable plane is accepted and simply does not overlap. */
+void *rfx_host_alloc(size_t bytes);
+void rfx_host_free(void *);
+int rfx_stage_upload(rfx_ctx *, rfx_tex id, const void *host, int row0, int rows);
+int rfx_stage_flip(rfx_ctx *);
+
 /* ---- row-tiled runs: the exchanges, one process per GPU, RCCL over xGMI.  RCCL is bound at run time (a
  * single-GPU host needs none; a process that already maps an RCCL — e.g. torch's — shares it).
  * Tiles: rank r of n owns rfx_split_rows(height, n, r) — boundaries on even rows, the last tile takes the remainder; every tile

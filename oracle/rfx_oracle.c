@@ -95,6 +95,11 @@ static inline float lum(v3 c) { return 0.2125f * c.x + 0.7154f * c.y + 0.0721f *
 static _Thread_local float g_margin = 3.0e38f;
 static float *g_margin_plane = NULL; /* W*H floats of the stage being run, or NULL */
 void rfxo_set_margin_plane(float *plane) { g_margin_plane = plane; }
+/* optional W*H byte mask: fragments whose byte is 0 are SKIPPED by every stage driver (their output texels keep what the caller put
+ * there).  Lets the parity tests re-evaluate — with margins, perturbed — only the out-of-tolerance pixels and a random sample instead of
+ * whole 4K / 8K frames. */
+static const uint8_t *g_pixel_mask = NULL;
+void rfxo_set_pixel_mask(const uint8_t *mask) { g_pixel_mask = mask; }
 static inline void margin_note(float m) { if (m < g_margin) g_margin = m; }
 /* decision `a ? b` between two computed quantities; rel = relative perturbation either side can carry */
 static inline void margin_cmp(float a, float b, float rel) {
@@ -860,6 +865,7 @@ int rfxo_ssgi(int W, int H, int y0, int y1, const float *depth, const uint32_t *
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < oW; x++) {
+            if (g_pixel_mask && !g_pixel_mask[(size_t)y * oW + x]) continue;
             g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
             k1_pixel(&c, x, y, out + 4 * ((size_t)y * oW + x));
             if (g_margin_plane) g_margin_plane[(size_t)y * oW + x] = g_margin;
@@ -1095,6 +1101,7 @@ int rfxo_temporal(int W, int H, int y0, int y1, const uint32_t *ssgi, const uint
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < W; x++) {
             size_t o = 4 * ((size_t)y * W + x);
+            if (g_pixel_mask && !g_pixel_mask[(size_t)y * W + x]) continue;
             g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
             k2_pixel(&c, x, y, out0 + o, out1 ? out1 + o : NULL);
             if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
@@ -1208,6 +1215,7 @@ int rfxo_denoise(int W, int H, int y0, int y1, const float *depth, const uint32_
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < W; x++) {
             size_t o = 4 * ((size_t)y * W + x);
+            if (g_pixel_mask && !g_pixel_mask[(size_t)y * W + x]) continue;
             g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
             k3_pixel(&c, x, y, out0 + o, out1 ? out1 + o : NULL);
             if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
@@ -1228,6 +1236,7 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < W; x++) {
+            if (g_pixel_mask && !g_pixel_mask[(size_t)y * W + x]) continue;
             g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
             if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
             float u = ((float)x + 0.5f) / (float)W, v = ((float)y + 0.5f) / (float)H;

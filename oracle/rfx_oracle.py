@@ -56,6 +56,22 @@ class margins:
         return False
 
 
+class pixel_mask:
+    """with pixel_mask(mask): every oracle stage evaluates only the fragments where the (H, W) bool/uint8 mask is non-zero; the other
+    output texels keep what the caller passed in (rfx_oracle.c rfxo_set_pixel_mask)."""
+
+    def __init__(self, mask):
+        self.mask = np.ascontiguousarray(mask, np.uint8)
+
+    def __enter__(self):
+        lib().rfxo_set_pixel_mask(_p(self.mask))
+        return self
+
+    def __exit__(self, *exc):
+        lib().rfxo_set_pixel_mask(None)
+        return False
+
+
 class perturbation:
     """with perturbation(seed): every exp/log/pow/sqrt/sin/cos/atan result of the oracle is moved by (1 +- rel) (sin/cos/atan also by
     +- abs), signs drawn per call from a per-fragment generator seeded with `seed` (rfx_oracle.c "perturbed primitives")."""

@@ -67,8 +67,13 @@ void rfx_destroy(rfx_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     rfx_comm_release(c);
-    for (int i = 0; i < RFX_TEX_COUNT; i++)
+    for (int i = 0; i < RFX_TEX_COUNT; i++) {
         if (c->slots[i].owned && c->slots[i].ptr) hipFree(c->slots[i].ptr);
+        if (c->slots[i].back) hipFree(c->slots[i].back);
+    }
+    if (c->upload_stream) { hipStreamSynchronize(c->upload_stream); hipStreamDestroy(c->upload_stream); }
+    if (c->ev_staged) hipEventDestroy(c->ev_staged);
+    if (c->ev_frame_done) hipEventDestroy(c->ev_frame_done);
     if (c->halo_violations) hipFree(c->halo_violations);
     if (c->viewz) hipFree(c->viewz);
     if (c->hits) hipFree(c->hits);
@@ -163,6 +168,64 @@ int rfx_download(rfx_ctx *c, rfx_tex id, void *host, int row0, int rows) {
     const size_t pitch = (size_t)s.width * s.texel;
     HIPCHK(c, hipMemcpyAsync(host, (char *)s.ptr + (size_t)(row0 - s.row0) * pitch, (size_t)rows * pitch, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return RFX_OK;
+}
+
+// ---- streaming dumps: the next frame's planes cross PCIe on their own stream while the current frame is drawn
+void *rfx_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+void rfx_host_free(void *p) {
+    if (p) hipHostFree(p);
+}
+
+static bool is_dump_input(int id) { return id == RFX_TEX_DEPTH || id == RFX_TEX_GBUFFER || id == RFX_TEX_VELOCITY || id == RFX_TEX_DIRECT_LIGHT; }
+
+int rfx_stage_upload(rfx_ctx *c, rfx_tex id, const void *host, int row0, int rows) {
+    if (!c || !host) return RFX_EINVAL;
+    if (!is_dump_input(id)) return fail(c, RFX_EINVAL, "rfx_stage_upload: only the dump's input planes (depth, gbuffer, velocity, direct light) are double-buffered");
+    int rc = band_check(c, id, row0, rows);
+    if (rc) return rc;
+    if ((rc = ensure(c, id))) return rc;
+    hipSetDevice(c->device);
+    Slot &s = c->slots[id];
+    if (!s.owned) return fail(c, RFX_ESTATE, "rfx_stage_upload: the slot is bound to an external buffer");
+    const size_t pitch = (size_t)s.width * s.texel, bytes = (size_t)s.rows * pitch;
+    if (!c->upload_stream) {
+        hipError_t e = hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_frame_done, hipEventDisableTiming);
+        if (e != hipSuccess) return fail(c, RFX_EDEVICE, "rfx_stage_upload: stream/event creation", e);
+        // nothing of an earlier frame can still be reading a back buffer: there is none yet
+        HIPCHK(c, hipEventRecord(c->ev_frame_done, c->stream));
+    }
+    if (!s.back) {
+        hipError_t e = hipMalloc(&s.back, bytes);
+        if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(back buffer)", e);
+    }
+    // the buffer being filled was the FRONT buffer until the last flip: the draws that read it were enqueued before that flip
+    HIPCHK(c, hipStreamWaitEvent(c->upload_stream, c->ev_frame_done, 0));
+    HIPCHK(c, hipMemcpyAsync((char *)s.back + (size_t)(row0 - s.row0) * pitch, host, (size_t)rows * pitch, hipMemcpyHostToDevice, c->upload_stream));
+    s.back_filled = true;
+    return RFX_OK;
+}
+
+int rfx_stage_flip(rfx_ctx *c) {
+    if (!c) return RFX_EINVAL;
+    if (!c->upload_stream) return fail(c, RFX_ESTATE, "rfx_stage_flip: nothing staged");
+    hipSetDevice(c->device);
+    // draws enqueued from now on wait for the staged copies; copies staged from now on wait for the draws enqueued so far
+    HIPCHK(c, hipEventRecord(c->ev_staged, c->upload_stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_staged, 0));
+    HIPCHK(c, hipEventRecord(c->ev_frame_done, c->stream));
+    for (int id = 0; id < RFX_TEX_COUNT; id++) {
+        Slot &s = c->slots[id];
+        if (!s.back_filled) continue;
+        void *t = s.ptr; s.ptr = s.back; s.back = t;
+        s.back_filled = false;
+        s.uploaded = true;
+    }
     return RFX_OK;
 }
 

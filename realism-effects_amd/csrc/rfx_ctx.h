@@ -13,6 +13,9 @@ struct Slot {
     size_t texel = 0;
     int width = 0;
     bool uploaded = false;
+    // streaming dumps (rfx_stage_upload / rfx_stage_flip): the BACK buffer the next frame's plane is copied into while the draws read `ptr`
+    void *back = nullptr;
+    bool back_filled = false;
 };
 
 struct rfx_ctx {
@@ -41,6 +44,9 @@ struct rfx_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_draws = nullptr, ev_comm = nullptr;
     bool comm_pending = false;       // exchanges issued since the last rfx_comm_wait
+    // streaming dumps: a third stream for the host-to-device copies of the NEXT frame and the two events that order it against the draws
+    hipStream_t upload_stream = nullptr;
+    hipEvent_t ev_staged = nullptr, ev_frame_done = nullptr;
     std::string err;
 };
 void rfx_comm_release(rfx_ctx *c);  // rfx_comm.hip: called by rfx_destroy

@@ -86,12 +86,31 @@ class Renderer {
 	// frame) unless the dump declares itself unchanged (frame.static): then an already resident plane object is not re-sent — opt-in,
 	// because a buffer refilled in place is the same object with new texels
 	uploadPlane(tex, plane, isStatic) {
-		if (isStatic && this._resident[tex] === plane) return
+		if (isStatic === "resident" || (isStatic && this._resident[tex] === plane)) return
 		const held = this.heldRows(tex)
 		const per = FORMAT[tex][1] * this.width
 		const band = plane.length === held[1] * per ? plane : plane.subarray(held[0] * per, (held[0] + held[1]) * per)
 		this.upload(tex, band, held[0], held[1])
 		this._resident[tex] = plane
+	}
+
+	// streaming dumps (rfx.h): stage the NEXT frame's planes asynchronously (pinned memory from Renderer.hostAlloc), then stageFlip()
+	// after the current frame's draws; a frame streamed this way carries `static: "resident"` so the loader shims do not upload it again
+	static hostAlloc(Ctor, length) {
+		return new Ctor(addon.hostAlloc(length * Ctor.BYTES_PER_ELEMENT))
+	}
+	stageFrame(frame) {
+		for (const pt of [[TEX.DEPTH, frame.depth], [TEX.GBUFFER, frame.gbuffer], [TEX.VELOCITY, frame.velocity], [TEX.DIRECT_LIGHT, frame.direct]]) {
+			const held = this.heldRows(pt[0])
+			const per = FORMAT[pt[0]][1] * this.width
+			const plane = pt[1]
+			const band = plane.length === held[1] * per ? plane : plane.subarray(held[0] * per, (held[0] + held[1]) * per)
+			addon.stageUpload(this._h, pt[0], band, held[0], held[1])
+		}
+		this._staged = frame // keep the planes alive while they are in flight
+	}
+	stageFlip() {
+		addon.stageFlip(this._h)
 	}
 
 	download(tex, row0, rows) {

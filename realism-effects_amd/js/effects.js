@@ -137,8 +137,8 @@ class GBufferPass {
 	}
 	render(renderer) {
 		const f = this._scene.frame
-		renderer.uploadPlane(TEX.DEPTH, f.depth, !!f.static)
-		if (f.gbuffer) renderer.uploadPlane(TEX.GBUFFER, f.gbuffer, !!f.static)
+		renderer.uploadPlane(TEX.DEPTH, f.depth, f.static)
+		if (f.gbuffer) renderer.uploadPlane(TEX.GBUFFER, f.gbuffer, f.static)
 		else if (renderer._packedGBuffer !== f.aov) {
 			// an engine dump of UNPACKED whole-frame attribute planes: the device packs them (rfx_pack_gbuffer = the pass's fragment epilogue)
 			renderer.packGBuffer(Object.assign({ depth: f.depth }, f.aov), 0, renderer.height)
@@ -164,7 +164,7 @@ class VelocityDepthNormalPass {
 	}
 	render(renderer) {
 		const f = this._scene.frame
-		if (f.velocity) renderer.uploadPlane(TEX.VELOCITY, f.velocity, !!f.static)
+		if (f.velocity) renderer.uploadPlane(TEX.VELOCITY, f.velocity, f.static)
 		else if (renderer._packedVelocity !== f.aov) {
 			renderer.packVelocity({ velocity: f.aov.velocity, normal: f.aov.normal, depth: f.depth }, 0, renderer.height)
 			renderer._packedVelocity = f.aov
@@ -694,7 +694,7 @@ class SSGIEffect {
 	update(renderer, inputBuffer) {
 		this.keepEnvMapUpdated(renderer)
 		const direct = inputBuffer || this._scene.frame.direct
-		renderer.uploadPlane(TEX.DIRECT_LIGHT, direct, !!(this._scene.frame && this._scene.frame.static))
+		renderer.uploadPlane(TEX.DIRECT_LIGHT, direct, this._scene.frame && this._scene.frame.static)
 		this.ssgiPass.render(renderer)
 		this.denoiser.render(renderer, inputBuffer)
 		// :400-417 the effect's own uniforms: inputTexture = the denoiser's texture, sceneTexture = the input buffer, fog from the scene

@@ -5,6 +5,8 @@
 // denoise_b1.bin / temporal0.bin / ssgi.bin / final.bin (the effect's mainImage output) of the LAST frame into --out.
 // With --traa '"half"' | '"float"': runs TRAAEffect.update() instead, the dump's direct.bin standing for the composer's
 // input buffer (HalfFloatType / FloatType), and writes traa.bin (traa_compose output, RGBA32F) of the last frame.
+// --png <file> [--tonemap '"aces"'|'"linear"' --exposure X] / --exr <file> / --pfm <file>: also write final.bin as an image (tone-mapped
+// 8-bit sRGB PNG; scene-linear float OpenEXR / PFM) — js/imageio.js.
 // With --ranks N (N > 1): the frame is cut into N row tiles, ONE NODE PROCESS PER GPU (this process spawns them: rank r drives
 // device r), which exchange halo rows and the composed GI over RCCL through the C ABI (js/tiling.js); rank 0 creates the
 // ncclUniqueId and hands it over through a file.  The parent stitches the tiles: the outputs are bit-identical to a --ranks 1 run.
@@ -62,6 +64,8 @@ const tiled = opt.ranks > 1 ? { rank: opt.rank, ranks: opt.ranks, idFile: opt.id
 delete opt.ranks
 delete opt.rank
 delete opt.idFile
+const images = { png: opt.png, exr: opt.exr, pfm: opt.pfm, tonemap: opt.tonemap, exposure: opt.exposure }
+for (const k of Object.keys(images)) delete opt[k]
 const seeds = { ssgi: opt.ssgiSeed === undefined ? 11 : opt.ssgiSeed, denoise: opt.denoiseSeed === undefined ? 22 : opt.denoiseSeed }
 delete opt.ssgiSeed
 delete opt.denoiseSeed
@@ -133,6 +137,12 @@ for (const [name, tex] of [["final", T.FINAL], ["compose", T.COMPOSE], ["denoise
 	// a tile writes its own rows; the parent stitches them
 	const a = tiled ? renderer.download(tex, renderer.tileY0, renderer.tileRows) : renderer.download(tex)
 	fs.writeFileSync(path.join(out, name + (tiled ? ".rank" + tiled.rank : "") + ".bin"), Buffer.from(a.buffer, a.byteOffset, a.byteLength))
+}
+if (!tiled && (images.png || images.exr || images.pfm)) {
+	const fin = renderer.download(T.FINAL)
+	if (images.exr) rfx.writeEXR(images.exr, fin, first.width, first.height)
+	if (images.pfm) rfx.writePFM(images.pfm, fin, first.width, first.height)
+	if (images.png) rfx.writePNG(images.png, rfx.tonemap(fin, first.width, first.height, images.tonemap, images.exposure), first.width, first.height, 3)
 }
 console.log(JSON.stringify({ frames: dumps.length, width: first.width, height: first.height, haloViolations: renderer.haloViolations(),
 	haloRows: tiled ? renderer.haloRows : 0, exchanges: tiled ? renderer.exchangeCount : 0 }))

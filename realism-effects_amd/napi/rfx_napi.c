@@ -188,9 +188,40 @@ static napi_value xfer(napi_env env, napi_callback_info info, int up) {
         napi_throw_range_error(env, NULL, "upload/download: TypedArray byte length != rows * width * texel bytes");
         return NULL;
     }
-    int rc = up ? rfx_upload(c, (rfx_tex)tex, data, row0, rows) : rfx_download(c, (rfx_tex)tex, data, row0, rows);
-    if (rc) return throw_rfx(env, c, up ? "rfx_upload" : "rfx_download", rc);
+    int rc = up == 2 ? rfx_stage_upload(c, (rfx_tex)tex, data, row0, rows)
+             : up ? rfx_upload(c, (rfx_tex)tex, data, row0, rows) : rfx_download(c, (rfx_tex)tex, data, row0, rows);
+    if (rc) return throw_rfx(env, c, up == 2 ? "rfx_stage_upload" : up ? "rfx_upload" : "rfx_download", rc);
     return NULL;
+}
+/* stageUpload(ctx, tex, typedArray, row0, rows): asynchronous copy into the slot's back buffer (rfx.h "streaming dumps"); the array —
+ * ideally a view of hostAlloc() memory — must stay alive and unchanged until the flip that publishes it has been synced */
+static napi_value n_stage_upload(napi_env env, napi_callback_info info) { return xfer(env, info, 2); }
+static napi_value n_stage_flip(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    int rc = rfx_stage_flip(c);
+    if (rc) return throw_rfx(env, c, "rfx_stage_flip", rc);
+    return NULL;
+}
+static void host_free_cb(napi_env env, void *data, void *hint) { (void)env; (void)hint; rfx_host_free(data); }
+/* hostAlloc(bytes) -> ArrayBuffer over pinned host memory (hipHostMalloc), freed when the buffer is collected */
+static napi_value n_host_alloc(napi_env env, napi_callback_info info) {
+    napi_value a[1], ab;
+    double bytes = 0;
+    if (!get_args(env, info, 1, a) || napi_get_value_double(env, a[0], &bytes) != napi_ok || bytes <= 0) {
+        napi_throw_range_error(env, NULL, "hostAlloc: a positive byte count");
+        return NULL;
+    }
+    void *p = rfx_host_alloc((size_t)bytes);
+    if (!p) { napi_throw_error(env, NULL, "rfx_host_alloc failed"); return NULL; }
+    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, host_free_cb, NULL, &ab) != napi_ok) {
+        rfx_host_free(p);
+        napi_throw_error(env, NULL, "hostAlloc: napi_create_external_arraybuffer failed");
+        return NULL;
+    }
+    return ab;
 }
 static napi_value n_upload(napi_env env, napi_callback_info info) { return xfer(env, info, 1); }
 static napi_value n_download(napi_env env, napi_callback_info info) { return xfer(env, info, 0); }
@@ -606,6 +637,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
         {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"setEnvironmentImportance", n_set_environment_importance}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"ssgiTrace", n_ssgi_trace}, {"ssgiShade", n_ssgi_shade}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
         {"sync", n_sync}, {"setRowWindow", n_set_row_window}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
+        {"stageUpload", n_stage_upload}, {"stageFlip", n_stage_flip}, {"hostAlloc", n_host_alloc},
         {"splitRows", n_split_rows}, {"commUniqueId", n_comm_unique_id}, {"commInit", n_comm_init}, {"haloExchange", n_halo_exchange},
         {"allgatherHistory", n_allgather_history}, {"commWait", n_comm_wait}, {"commDestroy", n_comm_destroy},
     };

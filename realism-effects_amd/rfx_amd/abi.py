@@ -95,7 +95,7 @@ EXPORTS = [
     "rfx_abi_version", "rfx_create", "rfx_destroy", "rfx_last_error", "rfx_get_geometry", "rfx_set_stream", "rfx_tex_texel_bytes", "rfx_tex_held_rows",
     "rfx_upload", "rfx_download", "rfx_clear", "rfx_tex_device_ptr", "rfx_bind_external", "rfx_pack_gbuffer", "rfx_pack_velocity", "rfx_set_environment", "rfx_set_environment_importance", "rfx_download_environment", "rfx_set_row_window", "rfx_ssgi_march", "rfx_ssgi_trace", "rfx_ssgi_shade", "rfx_temporal_reproject",
     "rfx_copy_framebuffer", "rfx_poisson_denoise", "rfx_compose", "rfx_final_compose", "rfx_sync", "rfx_halo_violations", "rfx_time_begin", "rfx_time_end",
-    "rfx_split_rows", "rfx_comm_unique_id", "rfx_comm_init", "rfx_comm_destroy", "rfx_halo_exchange", "rfx_allgather_history", "rfx_comm_wait",
+    "rfx_host_alloc", "rfx_host_free", "rfx_stage_upload", "rfx_stage_flip", "rfx_split_rows", "rfx_comm_unique_id", "rfx_comm_init", "rfx_comm_destroy", "rfx_halo_exchange", "rfx_allgather_history", "rfx_comm_wait",
 ]
 
 _lib = None
@@ -150,6 +150,12 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rfx_halo_violations.restype = C.c_uint
     lib.rfx_time_begin.argtypes = [vp]
     lib.rfx_time_end.argtypes = [vp, C.POINTER(f)]
+    lib.rfx_host_alloc.argtypes = [C.c_size_t]
+    lib.rfx_host_alloc.restype = vp
+    lib.rfx_host_free.argtypes = [vp]
+    lib.rfx_host_free.restype = None
+    lib.rfx_stage_upload.argtypes = [vp, i, vp, i, i]
+    lib.rfx_stage_flip.argtypes = [vp]
     lib.rfx_split_rows.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     lib.rfx_comm_unique_id.argtypes = [vp]
     lib.rfx_comm_init.argtypes = [vp, vp, i, i]

@@ -41,6 +41,8 @@ class Context:
         if getattr(self, "_h", None):
             self.lib.rfx_destroy(self._h)
             self._h = None
+            for p in self.__dict__.pop("_pinned", []):
+                self.lib.rfx_host_free(p)
 
     def __del__(self):
         try:
@@ -85,6 +87,39 @@ class Context:
         out = np.empty((rows, width, ch) if ch > 1 else (rows, width), dtype)
         self._chk(self.lib.rfx_download(self._h, tex, out.ctypes.data_as(C.c_void_p), row0, rows), "rfx_download")
         return out
+
+    # -- streaming dumps (rfx.h "streaming dumps"): the next frame's planes cross PCIe while the current frame is drawn
+    def host_alloc(self, shape, dtype) -> np.ndarray:
+        """A pinned (hipHostMalloc) numpy array: what makes rfx_stage_upload asynchronous.  Freed with the context."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.rfx_host_alloc(n)
+        if not p:
+            raise RfxError("rfx_host_alloc(%d bytes) failed" % n)
+        self.__dict__.setdefault("_pinned", []).append(p)
+        return np.frombuffer((C.c_char * n).from_address(p), dtype=dtype).reshape(shape)
+
+    def stage_upload(self, tex: int, array: np.ndarray, row0: int | None = None, rows: int | None = None):
+        """Asynchronous upload of rows [row0, row0+rows) into the slot's BACK buffer; published by stage_flip()."""
+        h0, hn = self.held_rows(tex)
+        row0 = h0 if row0 is None else row0
+        rows = hn if rows is None else rows
+        dtype, ch = abi.TEX_FORMAT[tex]
+        a = array if array.flags["C_CONTIGUOUS"] else np.ascontiguousarray(array)
+        if a.nbytes != rows * self.W * ch * np.dtype(dtype).itemsize:
+            raise ValueError("texture %s: %d bytes do not cover %d rows" % (abi.TEX_NAMES[tex], a.nbytes, rows))
+        self.__dict__.setdefault("_staged_keepalive", []).append(a)
+        self._chk(self.lib.rfx_stage_upload(self._h, tex, a.ctypes.data_as(C.c_void_p), row0, rows), "rfx_stage_upload")
+
+    def stage_frame(self, frame):
+        for tex, plane in ((abi.TEX_DEPTH, frame.depth), (abi.TEX_GBUFFER, frame.gbuffer), (abi.TEX_VELOCITY, frame.velocity),
+                           (abi.TEX_DIRECT_LIGHT, frame.direct)):
+            r0, n = self.held_rows(tex)
+            self.stage_upload(tex, plane[r0:r0 + n] if plane.shape[0] != n else plane, r0, n)
+
+    def stage_flip(self):
+        self._chk(self.lib.rfx_stage_flip(self._h), "rfx_stage_flip")
+        keep = self.__dict__.get("_staged_keepalive", [])
+        self.__dict__["_staged_keepalive"] = keep[-8:]  # the planes of the two frames that can still be in flight
 
     def clear(self, tex: int):
         self._chk(self.lib.rfx_clear(self._h, tex), "rfx_clear")

@@ -9,6 +9,9 @@ An engine that exports UNPACKED attribute planes writes, instead of gbuffer.bin 
   aov_diffuse.bin float32 W*H*4   aov_normal.bin float32 W*H*3 (world space)   aov_roughness.bin / aov_metalness.bin float32 W*H
   aov_emissive.bin float32 W*H*3  aov_velocity.bin float32 W*H*2 (uv units)
 and the device packs them (rfx_pack_gbuffer / rfx_pack_velocity).
+
+A renderer's usual AOV container is one multi-layer OpenEXR per frame: read_exr_dump() / write_exr_dump() map it onto the same frame
+object (layer names: rfx_amd.imageio.AOV_LAYOUT; the cameras travel in the EXR's side-car `<name>.json`, same fields as frame.json).
 """
 from __future__ import annotations
 
@@ -66,3 +69,33 @@ def read_dump(dirname: str):
     else:
         fr.aov = {k: rd("aov_%s.bin" % k, np.float32, (H, W, ch) if ch > 1 else (H, W)) for k, ch in _AOV}
     return fr
+
+
+def write_exr_dump(path: str, frame, compression: str = "zip") -> None:
+    """One multi-layer EXR (`path`) + side-car `path`.json (cameras) from a frame that carries unpacked attribute planes (frame.aov)."""
+    from . import imageio
+    ch = {}
+    for key, names in imageio.AOV_LAYOUT.items():
+        a = frame.depth if key == "depth" else (frame.direct if key == "direct" else frame.aov[key])
+        a = np.asarray(a, np.float32)
+        a = a[..., None] if a.ndim == 2 else a
+        for i, n in enumerate(names):
+            ch[n] = a[..., i]
+    imageio.write_exr(path, ch, compression)
+    meta = dict(width=int(frame.width), height=int(frame.height), camera=_cam_to_json(frame.camera),
+                prevCamera=_cam_to_json(getattr(frame, "prev_camera", frame.camera)))
+    with open(path + ".json", "w") as f:
+        json.dump(meta, f)
+
+
+def read_exr_dump(path: str, names: dict | None = None):
+    """The inverse: a frame whose G-buffer / velocity come as unpacked attribute planes (frame.aov) for the device-side importer."""
+    from . import imageio
+    planes = imageio.exr_to_dump_planes(path, names)
+    with open(path + ".json") as f:
+        meta = json.load(f)
+    H, W = planes["depth"].shape
+    if (W, H) != (meta["width"], meta["height"]):
+        raise ValueError("%s: image is %dx%d, side-car says %dx%d" % (path, W, H, meta["width"], meta["height"]))
+    return types.SimpleNamespace(width=W, height=H, camera=_cam_from_json(meta["camera"]), prev_camera=_cam_from_json(meta["prevCamera"]),
+                                 depth=planes["depth"], direct=planes["direct"], gbuffer=None, velocity=None, aov=planes["aov"])

@@ -118,8 +118,8 @@ def _upload_plane(renderer, tex, plane, static=False):
     contents: a caller that refills a preallocated buffer in place (the normal per-frame dump loop) hands over the same object every
     frame with new texels in it."""
     cache = renderer.__dict__.setdefault("_resident_planes", {})
-    if static and cache.get(tex) is plane:
-        return
+    if static == "resident" or (static and cache.get(tex) is plane):
+        return  # "resident": the caller streamed the planes itself (Context.stage_frame / stage_flip)
     r0, n = renderer.held_rows(tex)
     if plane.shape[0] == n:  # the caller dumped exactly the band this tile holds
         renderer.upload(tex, plane, r0, n)

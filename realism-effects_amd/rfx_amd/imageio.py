@@ -1,0 +1,332 @@
+"""File formats either side of the hot path: what an engine exports (AOV planes, environment maps) and what an
+offline run leaves on disk (HDR and tone-mapped images).  Pure Python + numpy + zlib — no imaging library is installed here.
+
+  read_hdr          Radiance RGBE (.hdr): the format of the reference example's environments (example/public/hdr/*.hdr, loaded there
+                    by three's RGBELoader) -> scene.environment for rfx_set_environment
+  read_exr/write_exr  OpenEXR, scanline, compression NONE / ZIPS / ZIP, HALF / FLOAT / UINT channels, arbitrary layer.channel names —
+                    the usual container of renderer AOVs; `exr_to_dump_planes` maps its layers onto the dump's attribute planes
+  read_pfm/write_pfm  Portable Float Map (the simplest HDR interchange format)
+  write_png         8-bit RGB(A) PNG
+  tonemap           linear radiance -> display: ACES filmic (the reference example's renderer.toneMapping, example/main.js) or plain
+                    clamp, then the sRGB transfer function
+
+All images are (H, W, C) float32 with ROW 0 = BOTTOM, the orientation of every plane in this package (GL texture rows); file formats
+that store the top row first are flipped on the way in and out.
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------------ Radiance .hdr (RGBE)
+def read_hdr(path: str) -> np.ndarray:
+    """-> (H, W, 3) float32 linear radiance, row 0 = bottom.  New-style RLE and flat scanlines, -Y +X orientation (the only one
+    written in practice)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = 0
+    if not data.startswith(b"#?"):
+        raise ValueError("%s: not a Radiance file" % path)
+    fmt_ok = False
+    while True:
+        end = data.index(b"\n", pos)
+        line = data[pos:end]
+        pos = end + 1
+        if line.startswith(b"FORMAT="):
+            fmt_ok = line.strip() == b"FORMAT=32-bit_rle_rgbe"
+        if line == b"":
+            break
+    if not fmt_ok:
+        raise ValueError("%s: only FORMAT=32-bit_rle_rgbe is supported" % path)
+    end = data.index(b"\n", pos)
+    res = data[pos:end].split()
+    pos = end + 1
+    if len(res) != 4 or res[0] != b"-Y" or res[2] != b"+X":
+        raise ValueError("%s: unsupported orientation %r" % (path, res))
+    H, W = int(res[1]), int(res[3])
+    rgbe = np.empty((H, W, 4), np.uint8)
+    buf = np.frombuffer(data, np.uint8)
+    for y in range(H):
+        if W < 8 or W > 0x7FFF or buf[pos] != 2 or buf[pos + 1] != 2 or (buf[pos + 2] & 0x80):
+            rgbe[y] = buf[pos:pos + 4 * W].reshape(W, 4)  # flat scanline
+            pos += 4 * W
+            continue
+        if (int(buf[pos + 2]) << 8 | int(buf[pos + 3])) != W:
+            raise ValueError("%s: scanline width mismatch" % path)
+        pos += 4
+        for c in range(4):
+            x = 0
+            row = rgbe[y, :, c]
+            while x < W:
+                n = int(buf[pos]); pos += 1
+                if n > 128:  # run
+                    n -= 128
+                    row[x:x + n] = buf[pos]; pos += 1
+                else:  # literal
+                    row[x:x + n] = buf[pos:pos + n]; pos += n
+                x += n
+    e = rgbe[..., 3].astype(np.int32)
+    scale = np.where(e > 0, np.ldexp(1.0, e - 136), 0.0).astype(np.float32)  # 2^(e-128) / 256
+    out = rgbe[..., :3].astype(np.float32) * scale[..., None]
+    return np.ascontiguousarray(out[::-1])  # file rows run top -> bottom
+
+
+def environment_from_hdr(path: str) -> np.ndarray:
+    """(H, W, 4) float32 equirectangular scene.environment for Context.set_environment (alpha 1), as RGBELoader hands it to three."""
+    rgb = read_hdr(path)
+    out = np.ones(rgb.shape[:2] + (4,), np.float32)
+    out[..., :3] = rgb
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ PFM
+def write_pfm(path: str, img: np.ndarray):
+    img = np.asarray(img, np.float32)
+    if img.ndim == 2:
+        img = img[..., None]
+    if img.shape[2] not in (1, 3):
+        raise ValueError("PFM holds 1 or 3 channels")
+    with open(path, "wb") as f:
+        f.write(b"%s\n%d %d\n-1.0\n" % (b"PF" if img.shape[2] == 3 else b"Pf", img.shape[1], img.shape[0]))
+        f.write(np.ascontiguousarray(img, "<f4").tobytes())  # PFM rows run bottom -> top: this package's orientation
+
+
+def read_pfm(path: str) -> np.ndarray:
+    with open(path, "rb") as f:
+        kind = f.readline().strip()
+        w, h = [int(v) for v in f.readline().split()]
+        scale = float(f.readline())
+        ch = {b"PF": 3, b"Pf": 1}[kind]
+        a = np.frombuffer(f.read(w * h * ch * 4), "<f4" if scale < 0 else ">f4").reshape(h, w, ch)
+    return np.ascontiguousarray(a.astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------ PNG
+def write_png(path: str, rgb8: np.ndarray):
+    """rgb8: (H, W, 3|4) uint8, row 0 = bottom."""
+    a = np.ascontiguousarray(np.asarray(rgb8, np.uint8)[::-1])
+    h, w, c = a.shape
+    if c not in (3, 4):
+        raise ValueError("PNG: 3 or 4 channels")
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), a.reshape(h, w * c)], axis=1).tobytes()  # filter type 0 per scanline
+
+    def chunk(tag, payload):
+        return struct.pack(">I", len(payload)) + tag + payload + struct.pack(">I", zlib.crc32(tag + payload) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+        f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0)))
+        f.write(chunk(b"IDAT", zlib.compress(raw, 6)))
+        f.write(chunk(b"IEND", b""))
+
+
+def read_png(path: str) -> np.ndarray:
+    """8-bit RGB / RGBA, non-interlaced (what write_png writes and what the reference's blue-noise asset is) -> (H, W, C) uint8, row 0 = bottom."""
+    with open(path, "rb") as f:
+        d = f.read()
+    if d[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG")
+    pos, idat, hdr = 8, b"", None
+    while pos < len(d):
+        n, tag = struct.unpack(">I4s", d[pos:pos + 8])
+        if tag == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", d[pos + 8:pos + 8 + n])
+        elif tag == b"IDAT":
+            idat += d[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    w, h, depth, ctype, _, _, interlace = hdr
+    if depth != 8 or ctype not in (2, 6) or interlace:
+        raise ValueError("PNG: only 8-bit non-interlaced RGB / RGBA")
+    c = 3 if ctype == 2 else 4
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * c)
+    out = np.zeros((h, w * c), np.uint8)
+    for y in range(h):  # undo the per-scanline filters
+        ft, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        prev = out[y - 1].astype(np.int32) if y else np.zeros(w * c, np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:
+            cur = np.zeros(w * c, np.int32)
+            for i in range(w * c):
+                a = cur[i - c] if i >= c else 0
+                b = prev[i]
+                cc = prev[i - c] if i >= c else 0
+                if ft == 1:
+                    p = a
+                elif ft == 3:
+                    p = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - cc), abs(a - cc), abs(a + b - 2 * cc)
+                    p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else cc)
+                cur[i] = (line[i] + p) & 255
+        out[y] = cur
+    return np.ascontiguousarray(out.reshape(h, w, c)[::-1])
+
+
+def tonemap(linear: np.ndarray, operator: str = "aces", exposure: float = 1.0) -> np.ndarray:
+    """(H, W, >=3) linear radiance -> (H, W, 3) uint8 sRGB.  "aces": three.js ACESFilmicToneMapping (the reference example's renderer
+    setting, example/main.js: RRT+ODT fit by Stephen Hill, exposure / 0.6); "linear": clamp only."""
+    c = np.nan_to_num(np.asarray(linear, np.float64)[..., :3], nan=0.0, posinf=65504.0, neginf=0.0)
+    c = np.clip(c, 0.0, 65504.0) * exposure
+    if operator == "aces":
+        m_in = np.array([[0.59719, 0.35458, 0.04823], [0.07600, 0.90834, 0.01566], [0.02840, 0.13383, 0.83777]])
+        m_out = np.array([[1.60475, -0.53108, -0.07367], [-0.10208, 1.10813, -0.00605], [-0.00327, -0.07276, 1.07602]])
+        c = (c / 0.6) @ m_in.T
+        c = (c * (c + 0.0245786) - 0.000090537) / (c * (0.983729 * c + 0.4329510) + 0.238081)
+        c = c @ m_out.T
+    elif operator != "linear":
+        raise ValueError("tonemap operator %r" % (operator,))
+    c = np.clip(np.nan_to_num(c, nan=0.0, posinf=1.0, neginf=0.0), 0.0, 1.0)
+    s = np.where(c <= 0.0031308, c * 12.92, 1.055 * np.power(c, 1.0 / 2.4) - 0.055)  # sRGB OETF
+    return (s * 255.0 + 0.5).astype(np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------ OpenEXR (scanline)
+_PT_UINT, _PT_HALF, _PT_FLOAT = 0, 1, 2
+_PT_DTYPE = {_PT_UINT: "<u4", _PT_HALF: "<f2", _PT_FLOAT: "<f4"}
+_COMP_NONE, _COMP_ZIPS, _COMP_ZIP = 0, 2, 3
+
+
+def _exr_attr(name: bytes, typ: bytes, payload: bytes) -> bytes:
+    return name + b"\0" + typ + b"\0" + struct.pack("<i", len(payload)) + payload
+
+
+def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = False):
+    """channels: name -> (H, W) array (row 0 = bottom); e.g. {"R": .., "G": .., "B": ..} or layered AOVs {"normal.X": .., "depth.Z": ..}.
+    float32 (or half=True: binary16) samples, scanline file, compression "none" | "zips" | "zip"."""
+    names = sorted(channels)  # the format requires alphabetical channel order
+    planes = [np.asarray(channels[n]) for n in names]
+    H, W = planes[0].shape
+    pt = _PT_HALF if half else _PT_FLOAT
+    comp = {"none": _COMP_NONE, "zips": _COMP_ZIPS, "zip": _COMP_ZIP}[compression]
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", pt, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<iiii", 0, 0, W - 1, H - 1)
+    header = (b"\x76\x2f\x31\x01" + struct.pack("<i", 2) +
+              _exr_attr(b"channels", b"chlist", chlist) + _exr_attr(b"compression", b"compression", bytes([comp])) +
+              _exr_attr(b"dataWindow", b"box2i", box) + _exr_attr(b"displayWindow", b"box2i", box) +
+              _exr_attr(b"lineOrder", b"lineOrder", b"\0") + _exr_attr(b"pixelAspectRatio", b"float", struct.pack("<f", 1.0)) +
+              _exr_attr(b"screenWindowCenter", b"v2f", struct.pack("<ff", 0.0, 0.0)) + _exr_attr(b"screenWindowWidth", b"float", struct.pack("<f", 1.0)) + b"\0")
+    per_block = {_COMP_NONE: 1, _COMP_ZIPS: 1, _COMP_ZIP: 16}[comp]
+    dt = _PT_DTYPE[pt]
+    top_down = [np.ascontiguousarray(p[::-1].astype(dt)) for p in planes]  # EXR y = 0 is the TOP row
+    blocks = []
+    for y0 in range(0, H, per_block):
+        y1 = min(H, y0 + per_block)
+        raw = b"".join(tp[y].tobytes() for y in range(y0, y1) for tp in top_down)
+        if comp != _COMP_NONE:
+            a = np.frombuffer(raw, np.uint8)
+            re = np.concatenate([a[0::2], a[1::2]])  # reorder: even bytes, then odd bytes
+            d = re.astype(np.int16)
+            d[1:] = d[1:] - re[:-1].astype(np.int16) + 128  # predictor
+            packed = zlib.compress((d & 255).astype(np.uint8).tobytes(), 4)
+            if len(packed) < len(raw):
+                raw = packed
+        blocks.append(struct.pack("<ii", y0, len(raw)) + raw)
+    table_pos = len(header)
+    offs, pos = [], table_pos + 8 * len(blocks)
+    for b in blocks:
+        offs.append(pos)
+        pos += len(b)
+    with open(path, "wb") as f:
+        f.write(header)
+        f.write(struct.pack("<%dQ" % len(offs), *offs))
+        for b in blocks:
+            f.write(b)
+
+
+def read_exr(path: str) -> dict:
+    """-> {channel name: (H, W) float32 (UINT channels: uint32)}, row 0 = bottom.  Single-part scanline files, compression NONE / ZIPS / ZIP,
+    no subsampling — what renderers write for AOV passes by default."""
+    with open(path, "rb") as f:
+        d = f.read()
+    if d[:4] != b"\x76\x2f\x31\x01":
+        raise ValueError("%s: not an OpenEXR file" % path)
+    version = struct.unpack("<i", d[4:8])[0]
+    if version & 0x1A00:  # tiled / deep / multipart bits
+        raise ValueError("%s: only single-part scanline EXR is supported" % path)
+    pos, attrs = 8, {}
+    while d[pos] != 0:
+        e = d.index(b"\0", pos); name = d[pos:e]; pos = e + 1
+        e = d.index(b"\0", pos); typ = d[pos:e]; pos = e + 1
+        n = struct.unpack("<i", d[pos:pos + 4])[0]; pos += 4
+        attrs[name] = (typ, d[pos:pos + n]); pos += n
+    pos += 1
+    chans, p, cl = [], 0, attrs[b"channels"][1]
+    while cl[p] != 0:
+        e = cl.index(b"\0", p); nm = cl[p:e].decode(); p = e + 1
+        pt, _, xs, ys = struct.unpack("<iB3xii", cl[p:p + 16]); p += 16
+        if xs != 1 or ys != 1:
+            raise ValueError("%s: subsampled channels are not supported" % path)
+        chans.append((nm, pt))
+    comp = attrs[b"compression"][1][0]
+    if comp not in (_COMP_NONE, _COMP_ZIPS, _COMP_ZIP):
+        raise ValueError("%s: compression %d not supported (NONE / ZIPS / ZIP are)" % (path, comp))
+    x0, y0, x1, y1 = struct.unpack("<iiii", attrs[b"dataWindow"][1])
+    W, H = x1 - x0 + 1, y1 - y0 + 1
+    per_block = 16 if comp == _COMP_ZIP else 1
+    nblocks = (H + per_block - 1) // per_block
+    offs = struct.unpack("<%dQ" % nblocks, d[pos:pos + 8 * nblocks])
+    out = {nm: np.empty((H, W), np.uint32 if pt == _PT_UINT else np.float32) for nm, pt in chans}
+    line_bytes = sum(W * np.dtype(_PT_DTYPE[pt]).itemsize for _, pt in chans)
+    for o in offs:
+        by, n = struct.unpack("<ii", d[o:o + 8])
+        rows = min(per_block, y1 - by + 1)
+        raw = d[o + 8:o + 8 + n]
+        if comp != _COMP_NONE and n < rows * line_bytes:
+            a = np.frombuffer(zlib.decompress(raw), np.uint8).astype(np.int32)
+            a = ((np.cumsum(a - 128) + 128) & 255).astype(np.uint8)  # undo the predictor: t[i] = t[i-1] + d[i] - 128, t[0] = d[0]
+            half_n = (a.size + 1) // 2
+            re = np.empty(a.size, np.uint8)
+            re[0::2], re[1::2] = a[:half_n], a[half_n:]
+            raw = re.tobytes()
+        p = 0
+        for r in range(rows):
+            y = by - y0 + r
+            for nm, pt in chans:
+                dt = np.dtype(_PT_DTYPE[pt])
+                out[nm][H - 1 - y] = np.frombuffer(raw, dt, W, p)
+                p += W * dt.itemsize
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ AOV EXR -> dump planes
+# layer.channel names a renderer's AOV EXR is expected to carry (rename on export, or pass `names=`): the attributes the G-buffer and
+# velocity raster passes of the reference write (GBufferMaterial.js:56-91, VelocityDepthNormalMaterial.js:75-83,180-189)
+AOV_LAYOUT = {
+    "diffuse": ("diffuse.R", "diffuse.G", "diffuse.B", "diffuse.A"),   # base colour, alpha
+    "normal": ("normal.X", "normal.Y", "normal.Z"),                    # WORLD-space normal
+    "roughness": ("roughness.Y",),
+    "metalness": ("metalness.Y",),
+    "emissive": ("emissive.R", "emissive.G", "emissive.B"),
+    "velocity": ("velocity.X", "velocity.Y"),                          # uv-space motion, current - previous
+    "depth": ("depth.Z",),                                             # gl_FragCoord.z in [0, 1], 1 = not covered
+    "direct": ("direct.R", "direct.G", "direct.B", "direct.A"),        # the composer's input buffer (direct lighting)
+}
+
+
+def exr_to_dump_planes(path: str, names: dict | None = None) -> dict:
+    """One multi-layer AOV EXR -> the dump's unpacked attribute planes: {"aov": {diffuse, normal, roughness, metalness, emissive,
+    velocity}, "depth": (H, W), "direct": (H, W, 4)} ready for Context.pack_gbuffer / pack_velocity (the device packs them into the
+    reference's texel formats) or rfx_amd.dump.write_dump."""
+    ch = read_exr(path)
+    layout = dict(AOV_LAYOUT)
+    layout.update(names or {})
+    planes = {}
+    for key, cn in layout.items():
+        missing = [c for c in cn if c not in ch]
+        if missing:
+            if key == "diffuse" and missing == [cn[3]]:  # no alpha layer: opaque
+                ch[cn[3]] = np.ones_like(ch[cn[0]])
+            elif key == "direct" and missing == [cn[3]]:
+                ch[cn[3]] = np.ones_like(ch[cn[0]])
+            else:
+                raise KeyError("%s: channel(s) %s of AOV %r missing (have: %s)" % (path, missing, key, sorted(ch)))
+        a = np.stack([ch[c].astype(np.float32) for c in cn], axis=-1)
+        planes[key] = a[..., 0] if len(cn) == 1 else a
+    depth, direct = planes.pop("depth"), planes.pop("direct")
+    return {"aov": planes, "depth": np.ascontiguousarray(depth), "direct": np.ascontiguousarray(direct)}

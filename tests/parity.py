@@ -47,7 +47,7 @@ class Report:
     bad: int                 # pixels with a channel out of tolerance
     explained: int           # ... of which the oracle proves unstable (margin < 1, or output moves under perturbed primitives)
     unexplained: int
-    at_risk: int             # explainable pixels among all pixels (None without an oracle run)
+    at_risk: int             # explainable pixels among ALL pixels (estimated from a random sample; None without an oracle run)
     worst_unexplained: tuple
 
     def line(self):

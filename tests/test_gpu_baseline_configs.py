@@ -54,8 +54,8 @@ def _have_reference_gl():
 @pytest.mark.parametrize("name,W,H,steps,refine,it,frames,n_perturb", [
     ("configs[0]", 1920, 1080, 8, 2, 0, 2, 10),
     ("configs[1]", 1920, 1080, 20, 5, 1, 2, 10),
-    ("configs[2]", 3840, 2160, 20, 5, 1, 2, 8),
-    ("configs[4]", 7680, 4320, 40, 5, 3, 2, 4),
+    ("configs[2]", 3840, 2160, 20, 5, 1, 2, 10),
+    ("configs[4]", 7680, 4320, 40, 5, 3, 2, 10),
 ])
 def test_baseline_config_stagewise_vs_reference_glsl(blue_noise, name, W, H, steps, refine, it, frames, n_perturb):
     if not _have_reference_gl():

@@ -1,0 +1,105 @@
+"""CPU: the file formats either side of the path: EXR / PFM / PNG round trips, the AOV-EXR importer feeding the
+device-side packer's oracle, tone mapping, and — where /root/reference exists — the reference example's own Radiance .hdr environment and
+its blue-noise PNG."""
+import os
+
+import numpy as np
+import pytest
+
+import rfx_oracle as O
+from rfx_amd import dump, imageio
+from rfx_amd.scene import AnalyticScene
+
+
+def test_exr_round_trip_all_compressions(tmp_path):
+    rng = np.random.RandomState(1)
+    H, W = 37, 53
+    ch = {"diffuse.R": rng.rand(H, W).astype(np.float32), "normal.X": rng.rand(H, W).astype(np.float32) * 2 - 1,
+          "depth.Z": rng.rand(H, W).astype(np.float32) * 1e3}
+    for comp in ("none", "zips", "zip"):
+        for half in (False, True):
+            p = str(tmp_path / "t.exr")
+            imageio.write_exr(p, ch, comp, half)
+            r = imageio.read_exr(p)
+            assert sorted(r) == sorted(ch)
+            for k in ch:
+                want = ch[k].astype(np.float16).astype(np.float32) if half else ch[k]
+                assert np.array_equal(r[k], want), (comp, half, k)
+
+
+def test_pfm_png_round_trip_and_tonemap(tmp_path):
+    rng = np.random.RandomState(2)
+    img = rng.rand(20, 30, 3).astype(np.float32)
+    imageio.write_pfm(str(tmp_path / "a.pfm"), img)
+    assert np.array_equal(imageio.read_pfm(str(tmp_path / "a.pfm")), img)
+    png = (rng.rand(20, 30, 4) * 255).astype(np.uint8)
+    imageio.write_png(str(tmp_path / "a.png"), png)
+    assert np.array_equal(imageio.read_png(str(tmp_path / "a.png")), png)
+    t = imageio.tonemap(np.array([[[0.0, 0.0, 0.0], [0.18, 0.18, 0.18], [1e9, np.nan, np.inf]]], np.float32))
+    assert t.dtype == np.uint8 and (t[0, 0] == 0).all() and 100 < t[0, 1, 0] < 150 and t[0, 2, 0] == 255
+    lin = imageio.tonemap(np.array([[[0.5, 0.5, 0.5]]], np.float32), "linear")
+    assert abs(int(lin[0, 0, 0]) - 188) <= 1  # sRGB OETF of 0.5
+
+
+def test_aov_exr_import_feeds_the_packer(tmp_path):
+    """A frame exported as ONE multi-layer AOV EXR (what a renderer writes) comes back as the attribute planes the importer packs; packing
+    them reproduces the packed dump's texels (oracle of the device-side packer; the GPU test does the same through rfx_pack_gbuffer)."""
+    f = AnalyticScene(1234).render(96, 54, 1, aov=True)
+    p = str(tmp_path / "frame.exr")
+    dump.write_exr_dump(p, f)
+    g = dump.read_exr_dump(p)
+    assert (g.width, g.height) == (96, 54) and np.array_equal(g.depth, f.depth) and np.array_equal(g.direct, f.direct)
+    for k in ("diffuse", "normal", "roughness", "metalness", "emissive", "velocity"):
+        assert np.array_equal(g.aov[k], np.asarray(f.aov[k], np.float32)), k
+    gb = O.pack_gbuffer(g.aov, g.depth)
+    cov = f.depth != 1.0
+    assert np.array_equal(gb[cov][:, :3], f.gbuffer[cov][:, :3])  # diffuse, normal, roughness/metalness words (emissive: see D-9, log2(0))
+    assert np.array_equal(O.pack_velocity(g.aov, g.depth)[cov], f.velocity[cov])
+    # and through the dump directory both hosts read
+    d = str(tmp_path / "dumpdir")
+    dump.write_dump(d, g, packed=False)
+    h = dump.read_dump(d)
+    assert h.gbuffer is None and np.array_equal(h.aov["normal"], g.aov["normal"])
+    np.testing.assert_allclose(h.camera.projectionMatrix, f.camera.projectionMatrix)
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not os.path.isdir("/root/reference/example/public/hdr"), reason="/root/reference absent")
+def test_reference_example_assets_import(blue_noise):
+    """Non-synthetic inputs: the reference example's environment map (example/public/hdr/*.hdr, what its RGBELoader loads into
+    scene.environment) through read_hdr -> the environment chain + the importance tables; and the reference's blue-noise PNG decodes
+    to exactly the table this package ships (src/utils/blue_noise_rgba.png, flipY as BlueNoiseUtils.js:9-15)."""
+    from rfx_amd import envmap
+    env = imageio.environment_from_hdr("/root/reference/example/public/hdr/spree_bank_1k.hdr")
+    assert env.shape == (512, 1024, 4) and np.isfinite(env).all() and env[..., :3].max() > 4.0 and (env[..., :3] >= 0).all()
+    e = O.EnvMap(env, half=True)
+    assert e.levels == 11 and np.isfinite(e.level(10)).all()
+    # the sky half of an outdoor panorama is brighter than the ground half
+    assert env[256:, :, :3].mean() > env[:256, :, :3].mean()
+    m, c, tot = envmap.build_importance(env[::4, ::4].astype(np.float16).astype(np.float32))
+    assert m.shape == (128,) and c.shape == (128, 256) and tot > 0 and (np.diff(m) >= 0).all()
+    assert np.array_equal(imageio.read_png("/root/reference/src/utils/blue_noise_rgba.png"), blue_noise)
+
+
+def test_node_image_writers_match_python(tmp_path):
+    """js/imageio.js (what run_dump.js --png / --exr / --pfm write) against the Python twin: the EXR and PFM carry the exact float32
+    texels, the tone-mapped PNG equals imageio.tonemap to 1 LSB."""
+    import subprocess
+    W, H = 23, 11
+    rng = np.random.RandomState(5)
+    img = (rng.rand(H, W, 4).astype(np.float32) * np.array([3, 2, 1, 1], np.float32))
+    img[0, 0, :3] = [np.nan, np.inf, 1e-9]
+    src = tmp_path / "img.bin"
+    img.tofile(str(src))
+    js = ("const io=require('%s');const fs=require('fs');const b=fs.readFileSync('%s');"
+          "const a=new Float32Array(b.buffer.slice(b.byteOffset,b.byteOffset+b.length));"
+          "io.writeEXR('%s/o.exr',a,%d,%d);io.writePFM('%s/o.pfm',a,%d,%d);io.writePNG('%s/o.png',io.tonemap(a,%d,%d),%d,%d,3)") % (
+        os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "realism-effects_amd", "js", "imageio.js"), src,
+        tmp_path, W, H, tmp_path, W, H, tmp_path, W, H, W, H)
+    subprocess.check_call(["node", "-e", js])
+    e = imageio.read_exr(str(tmp_path / "o.exr"))
+    for i, c in enumerate("RGBA"):
+        assert np.array_equal(e[c], img[..., i], equal_nan=True), c
+    assert np.array_equal(imageio.read_pfm(str(tmp_path / "o.pfm")), img[..., :3], equal_nan=True)
+    png = imageio.read_png(str(tmp_path / "o.png")).astype(np.int32)
+    assert np.abs(png - imageio.tonemap(img).astype(np.int32)).max() <= 1

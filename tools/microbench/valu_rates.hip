@@ -3,6 +3,71 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #define ITERS 4096
+typedef float f2_t __attribute__((ext_vector_type(2)));
+// packed fp32: one instruction = two fma per lane.  Is it issued at the rate of a plain v_fma_f32 (2x the flops) or at half of it?
+template <int PK>
+__global__ __launch_bounds__(256) void kpk(float *out, float seed) {
+    f2_t a[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = (f2_t){seed + threadIdx.x * 1e-6f + i, seed + i * 0.5f};
+    const f2_t m = (f2_t){1.0000001f, 0.9999999f}, c = (f2_t){1e-7f, 2e-7f};
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (PK == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(m), "v"(c));
+            if (PK == 2) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(m));
+            if (PK == 3) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(c));
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += a[i].x + a[i].y;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// other single-issue ops the kernels lean on
+template <int OP>
+__global__ __launch_bounds__(256) void kop(float *out, float seed) {
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = seed + threadIdx.x * 1e-6f + i;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (OP == 1) asm volatile("v_med3_f32 %0, %1, %2, 0" : "=v"(a[i]) : "v"(a[i]), "v"(seed));
+            if (OP == 2) asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(a[i]) : "v"(a[i]));
+            if (OP == 3) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(a[i]), "v"(seed));
+            if (OP == 4) asm volatile("v_min3_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(seed), "v"(seed));
+            if (OP == 5) asm volatile("v_mul_i32_i24 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(seed));
+            if (OP == 6) asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(a[i]) : "v"(a[i]));
+            if (OP == 7) asm volatile("v_sin_f32 %0, %1" : "=v"(a[i]) : "v"(a[i]));
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <typename K>
+void run_kernel(const char *name, K kern, int waves_per_simd) {
+    int blocks = 256 * waves_per_simd;
+    float *out;
+    hipMalloc(&out, (size_t)blocks * 256 * 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    kern<<<blocks, 256>>>(out, 1.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    kern<<<blocks, 256>>>(out, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    double per_simd = (double)ITERS * 8 * waves_per_simd;
+    printf("%-28s %d waves/SIMD: %.3f ms  -> %.3f instr/ns/SIMD  (%.2f cycles per instr at 2.4 GHz)\n", name, waves_per_simd, ms, per_simd / (ms * 1e6),
+           (ms * 1e6) * 2.4 / per_simd);
+    hipFree(out);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float *out, float seed) {
     float a[8];
@@ -58,6 +123,18 @@ int main() {
         run<3>("v_add + v_rcp_f32", 1, 1, w);
         run<4>("v_add + v_sqrt_f32", 1, 1, w);
         run<5>("v_mul + v_exp + 12 fma", 13, 1, w);
+    }
+    for (int w : {2, 8}) {
+        run_kernel("v_pk_fma_f32", kpk<1>, w);
+        run_kernel("v_pk_mul_f32", kpk<2>, w);
+        run_kernel("v_pk_add_f32", kpk<3>, w);
+        run_kernel("v_med3_f32", kop<1>, w);
+        run_kernel("v_cvt_f32_f16", kop<2>, w);
+        run_kernel("v_cndmask_b32", kop<3>, w);
+        run_kernel("v_min3_f32", kop<4>, w);
+        run_kernel("v_mul_i32_i24", kop<5>, w);
+        run_kernel("v_cvt_i32_f32", kop<6>, w);
+        run_kernel("v_sin_f32", kop<7>, w);
     }
     return 0;
 }
