@@ -139,11 +139,12 @@ def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, 
     renderer, exchange = ctx, "none"
     depth_full = band.depth
     if world > 1:
-        cd = ctl_device(dist, dev)
-        mine = torch.from_numpy(np.ascontiguousarray(band.depth[y0 - b0:y0 - b0 + rows])).to(cd)
-        parts_d = [torch.empty((n, W), dtype=torch.float32, device=cd) for (_, n) in tiles]
-        dist.all_gather(parts_d, mine)  # set-up only (the dump's depth plane is held whole by every rank)
-        depth_full = torch.cat(parts_d, 0).cpu().numpy()
+        # set-up only: the dump's depth plane is held whole by every rank.  Every rank contributes its rows of a zero
+        # frame and the sum is the frame (works for ragged tiles on every backend)
+        full = torch.zeros((H, W), dtype=torch.float32, device=ctl_device(dist, dev))
+        full[y0:y0 + rows] = torch.from_numpy(np.ascontiguousarray(band.depth[y0 - b0:y0 - b0 + rows]))
+        dist.all_reduce(full, op=dist.ReduceOp.SUM)
+        depth_full = full.cpu().numpy()
         if use_c:
             box = [Context.comm_unique_id() if rank == 0 else None]  # one ncclUniqueId per communicator
             dist.broadcast_object_list(box, src=0)

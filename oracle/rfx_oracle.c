@@ -54,6 +54,10 @@ static inline float pert_sign(void) {
 }
 static inline float pert_rel(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * g_pert_rel) : v; }
 static inline float pert_ang(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * 2.4e-7f) + pert_sign() * g_pert_abs : v; }
+/* the fragment's vUv: a rasteriser interpolates the varying from plane equations and lands within an ulp of (x + 0.5) / W — measured on
+ * the reference GL: off by one ulp on 40-75 % of the rows (resolutionScale).  One ulp of u is one ulp of u * W: up to
+ * 5e-4 texel at 8K, which is what a LINEAR fetch at a pixel centre (K4, K3's later passes) turns into a weight error */
+static inline float pert_uv(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * 1.1920929e-7f) : v; }
 static inline float pert_sqrt(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * 2.4e-7f) : v; }
 /* function-like macros are not re-expanded inside their own expansion: (expf)(x) is libm's */
 #define expf(x) pert_rel((expf)(x))
@@ -107,7 +111,7 @@ static inline void margin_cmp(float a, float b, float rel) {
     margin_note(fabsf(a - b) / s);
 }
 /* scales (relative error an operand of the decision can carry between two implementations with ulp-accurate primitives) */
-#define MARGIN_REL_MARCH 2e-6f   /* ray position after <= 40 accumulated steps of dir * (1 - exp(..)), projected */
+#define MARGIN_REL_MARCH 5e-7f   /* ray position after <= 40 accumulated steps of dir * (1 - exp(..)), projected */
 #define MARGIN_REL_SHORT 4e-6f   /* a handful of fp32 operations incl. one transcendental */
 #define MARGIN_REL_WEIGHT 1e-4f  /* products of exp(-phi * diff): the exponents reach ~10 and carry their own rounding */
 
@@ -468,7 +472,8 @@ static void k1_binary_search(const k1_ctx *c, v3 *dir, v3 *hitPos, float *u, flo
 /* RayMarch ssgi.frag:441-475 */
 static void k1_ray_march(const k1_ctx *c, v3 *dir, v3 *hitPos, float random_b, float *u, float *v) {
     dims d = {c->W, c->H};
-    g_fetch_rel = MARGIN_REL_MARCH; /* the depth taps (and the history fetch at the hit) sit at the projected ray position */
+    /* the taps' texel boundaries get no blanket slack: a tap that changes texel rarely changes the hit decision.  The perturbed runs move
+     * the ray by its actual error and re-take every decision; the margins below cover the z compares themselves */
     *dir = mul3(*dir, c->p->rayDistance / (float)c->p->steps);
     *u = 0.0f; *v = 0.0f;
     for (int i = 1; i < c->p->steps; i++) {
@@ -625,7 +630,7 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
     const float *C = p->camera.matrixWorld, *Vw = p->camera.matrixWorldInverse;
     const float *P = p->camera.projectionMatrix, *Pi = p->camera.projectionMatrixInverse;
     dims d = {c->W, c->H};
-    float u = ((float)x + 0.5f) / (float)c->outW, v = ((float)y + 0.5f) / (float)c->outH; /* vUv of the (possibly smaller) target */
+    float u = pert_uv(((float)x + 0.5f) / (float)c->outW), v = pert_uv(((float)y + 0.5f) / (float)c->outH); /* vUv of the (possibly smaller) target */
     float depth = fetch_r32f(c->depth, d, u, v);
     if (depth == 1.0f) { /* :109-113 */
         v4 dl = fetch_f4(c->direct, d, u, v);
@@ -973,7 +978,7 @@ static inline v4 k2_input_texel(const k2_ctx *c, float u, float v, int idx) {
 static void k2_pixel(const k2_ctx *c, int x, int y, float *out0, float *out1) {
     const rfx_temporal_params *p = c->p;
     const int tc = p->textureCount, lt = p->logTransform;
-    float u = ((float)x + 0.5f) / (float)c->W, v = ((float)y + 0.5f) / (float)c->H;
+    float u = pert_uv(((float)x + 0.5f) / (float)c->W), v = pert_uv(((float)y + 0.5f) / (float)c->H);
     float velx, vely, depth; v3 worldNormal;
     k2_vnd(c, u, v, &velx, &vely, &worldNormal, &depth);
     /* getTexels + preprocessInput temporal_reproject.frag:124-145 */
@@ -1128,7 +1133,7 @@ static void k3_pixel(const k3_ctx *c, int x, int y, uint16_t *out0, uint16_t *ou
     const rfx_denoise_params *p = c->p;
     dims d = {c->W, c->H};
     const int tc = p->textureCount;
-    float u = ((float)x + 0.5f) / (float)c->W, v = ((float)y + 0.5f) / (float)c->H;
+    float u = pert_uv(((float)x + 0.5f) / (float)c->W), v = pert_uv(((float)y + 0.5f) / (float)c->H);
     float depth = fetch_r32f(c->depth, d, u, v);
     int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
     float fx0 = ((float)qx0 + 0.5f) / (float)c->W, fx1 = ((float)qx1 + 0.5f) / (float)c->W;
@@ -1239,7 +1244,7 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
             if (g_pixel_mask && !g_pixel_mask[(size_t)y * W + x]) continue;
             g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
             if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
-            float u = ((float)x + 0.5f) / (float)W, v = ((float)y + 0.5f) / (float)H;
+            float u = pert_uv(((float)x + 0.5f) / (float)W), v = pert_uv(((float)y + 0.5f) / (float)H);
             float dep = fetch_r32f(depth, d, u, v);
             int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
             float fx0 = ((float)qx0 + 0.5f) / (float)W, fx1 = ((float)qx1 + 0.5f) / (float)W;

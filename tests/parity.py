@@ -57,43 +57,38 @@ class Report:
             self.unexplained, ar)
 
 
-def out_of_tolerance(a, b, half):
-    """(H, W) bool: some channel of the pixel is outside the metric"""
-    a = np.asarray(a, np.float64)
-    b = np.asarray(b, np.float64)
+def _errors(a, b, half):
+    """(per-channel abs error with NaN/inf conventions applied, (H, W) bool out-of-tolerance) — float32 throughout (8K frames)"""
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
     if a.ndim == 2:
         a, b = a[..., None], b[..., None]
-    with np.errstate(invalid="ignore"):
+    with np.errstate(invalid="ignore", over="ignore"):
         err = np.abs(a - b)
-    err = np.where(np.isnan(a) & np.isnan(b), 0.0, err)
-    err = np.where(np.isnan(a) != np.isnan(b), np.inf, err)
-    err = np.where(np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b)), 0.0, err)
-    ok = err <= ATOL
-    ok |= (_half_ulp_distance(a, b) <= 1) if half else (err <= RTOL_F32 * np.abs(b))
-    return ~ok.all(axis=-1)
+        special = ~np.isfinite(err)
+        if special.any():  # NaN == NaN and inf == inf of the same sign agree; NaN vs number / inf vs number do not
+            na, nb = np.isnan(a), np.isnan(b)
+            same = (na & nb) | (np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b)))
+            err = np.where(same, np.float32(0.0), np.where(special, np.float32(np.inf), err))
+        ok = err <= np.float32(ATOL)
+        if half:
+            rest = ~ok
+            if rest.any():  # adjacent binary16 values: only looked at where the absolute rule failed
+                ok[rest] = _half_ulp_distance(a[rest], b[rest]) <= 1
+        else:
+            ok |= err <= np.float32(RTOL_F32) * np.abs(b)
+    return err, ~ok.all(axis=-1)
+
+
+def out_of_tolerance(a, b, half):
+    """(H, W) bool: some channel of the pixel is outside the metric"""
+    return _errors(a, b, half)[1]
 
 
 def strict(name, a, b, explainable=None, half=False, ignore=None):
     """a: implementation under test, b: reference; (H, W, C) float arrays.  explainable: (H, W) bool from the oracle (margin < 1 or
     unstable under perturbed primitives) or None.  ignore: optional (H, W) bool mask of pixels excluded from the comparison."""
-    a = np.asarray(a, np.float64)
-    b = np.asarray(b, np.float64)
-    if a.ndim == 2:
-        a, b = a[..., None], b[..., None]
-    with np.errstate(invalid="ignore"):
-        err = np.abs(a - b)
-    nan_mismatch = np.isnan(a) != np.isnan(b)
-    both_nan = np.isnan(a) & np.isnan(b)
-    err = np.where(both_nan, 0.0, err)
-    err = np.where(nan_mismatch, np.inf, err)
-    same_inf = np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b))
-    err = np.where(same_inf, 0.0, err)
-    ok = err <= ATOL
-    if half:
-        ok |= _half_ulp_distance(a, b) <= 1
-    else:
-        ok |= err <= RTOL_F32 * np.abs(b)
-    badpx = ~ok.all(axis=-1)
+    err, badpx = _errors(a, b, half)
     if ignore is not None:
         badpx &= ~ignore
         err = np.where(ignore[..., None], 0.0, err)

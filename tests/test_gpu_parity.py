@@ -728,9 +728,11 @@ def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RFX_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--checksum", "--no-extras"]
-    two = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                                   "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--width", "960", "--height", "540"] + common,
-                                  env=env, text=True, stderr=subprocess.DEVNULL, timeout=600)
+    p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--width", "960", "--height", "540"] + common,
+                        env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    two = p2.stdout
     j2 = json.loads([l for l in two.splitlines() if l.startswith("{")][-1])
     # N > 1 is BASELINE configs[3]'s shape: THE SAME frame cut into N row tiles (strong scaling)
     assert j2["n_gpus"] == 2 and j2["halo_violations"] == 0 and j2["value"] > 0 and j2["scaling"] == "strong"

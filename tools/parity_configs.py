@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import stagewise as S  # noqa: E402
 from rfx_amd.context import load_blue_noise_table  # noqa: E402
-from rfx_amd.scene import synthetic_frame  # noqa: E402
+from rfx_amd.scene import synthetic_frame_parallel  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--impl", default="hip")
@@ -26,6 +26,7 @@ ap.add_argument("--refine", type=int, default=5)
 ap.add_argument("--it", type=int, default=1)
 ap.add_argument("--frames", type=int, default=2)
 ap.add_argument("--out", default=None)
+ap.add_argument("--perturb", type=int, default=16, help="perturbed oracle re-evaluations per stage (of the out-of-tolerance + sampled pixels)")
 a = ap.parse_args()
 W, H = [int(v) for v in a.size.split("x")]
 lines = []
@@ -44,11 +45,12 @@ frames = {}
 
 def frame_fn(i):
     if i not in frames:
-        frames[i] = synthetic_frame(W, H, i)
+        frames.clear()  # one dump resident at a time (8K: 1.9 GB)
+        frames[i] = synthetic_frame_parallel(W, H, i)
     return frames[i]
 
 
-reports = S.run(S.HipStages if a.impl == "hip" else S.OracleStages, W, H, a.steps, a.refine, a.it, a.frames, load_blue_noise_table(), frame_fn, log=log)
+reports = S.run(S.HipStages if a.impl == "hip" else S.OracleStages, W, H, a.steps, a.refine, a.it, a.frames, load_blue_noise_table(), frame_fn, log=log, n_perturb=a.perturb)
 log("# summary (all frames)   kind: pixels, Linf(all), Linf(in-tol), out-of-tol, explained, UNEXPLAINED, at-risk")
 for kind, v in S.summarize(reports).items():
     log("#   %-18s %10d  %.3e  %.3e  %7d  %7d  %7d  %8d" % ((kind,) + tuple(v)))
