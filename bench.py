@@ -75,9 +75,12 @@ def pmc_traffic(kernel_key):
     return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
 
 
-# measured on MI355X by tools/microbench/valu_rates.hip (profiles/r01_final/valu_rates.txt): a wave64 fp32 VALU instruction issues every
-# 1.026 ns per SIMD at 8 waves/SIMD (2 cycles at the ~1.95 GHz the part sustains), a transcendental (v_exp/v_log/v_rcp/v_sqrt) every 4.1 ns
-VALU_NS, TRANS_NS, N_SIMD = 1.0 / 0.975, 4.1, 256 * 4
+# measured on MI355X by tools/microbench/valu_rates.hip (profiles/r02_final/valu_rates.txt), 8 waves/SIMD: a wave64 VALU instruction
+# (v_cvt / v_med3 / v_min3 / v_mul_i24 / unpacked v_fma ...) issues every ~4.2 shader cycles = 1.77 ns per SIMD; a packed fp32 one
+# (v_pk_fma/mul/add_f32, two results per lane) every 1.95 ns; a transcendental (v_exp / v_log / v_rcp / v_sqrt / v_sin) every 3.4 ns.
+# (Round 1 priced a plain VALU at 1.03 ns: its microbenchmark's eight fma chains had been auto-packed into four v_pk_fma_f32 per
+# iteration, i.e. it measured 2 fma per 2.05 ns.)  The PMC counters do not separate packed from plain: all are priced as plain.
+VALU_NS, TRANS_NS, N_SIMD = 1.77, 3.4, 256 * 4
 
 
 def valu_floor_ms(kernel_key, pixels):
@@ -359,7 +362,7 @@ def main():
         if all(v is not None for v in floors.values()):
             out["valu_issue_roofline"] = {"floor_ms": {k: round(v, 4) for k, v in floors.items()}, "sum_floor_ms": round(sum(floors.values()), 4),
                                           "frac": round(sum(floors.values()) / chain_ms, 4),
-                                          "note": "VALU + transcendental instructions per wave (%s/pmc_sq_l2.csv, git %s) at the issue rates measured by tools/microbench/valu_rates.hip" % (
+                                          "note": "VALU + transcendental instructions per wave (%s/pmc_sq_l2.csv, git %s) at the issue rates measured by tools/microbench/valu_rates.hip (1.77 ns plain, 3.4 ns transcendental per wave64 instruction per SIMD; packed fp32 counted as plain); > 1 = faster than that model (clock / packing)" % (
                                               PROFILE_DIR, prof.get("git_commit", "?"))}
         out.update(extras)
         if args.checksum:

@@ -19,9 +19,6 @@ namespace {
 
 constexpr int TW = 64, TH = 8;  // pixels per workgroup tile
 constexpr int NT = TW * TH;     // 512 threads
-#ifndef RFX_K3_AOS
-#define RFX_K3_AOS 1  // later passes, two textures: stage the RGBA16F texels of both textures interleaved (uint4 per texel)
-#endif
 #ifndef RFX_K3_XCD_G
 #define RFX_K3_XCD_G 1  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major.  Measured at 4K (pass 0 / pass 1 ms): 0: 0.248/0.380, 1: 0.244/0.376, 2: 0.245/0.390, 4: 0.255/0.414, 8: 0.266/0.423, 16: 0.288/0.434
 #endif
@@ -100,8 +97,6 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
                 const float4 v = rfx_gather<float4>(src.ptr, idx);
                 const float3 l = k3_log3(v.x, v.y, v.z);
                 s_in0[t * ntex + i] = make_float4(l.x, l.y, l.z, k3_luma(l));
-            } else if (TC == 2 && RFX_K3_AOS) {
-                s_inN[2 * i + t] = rfx_gather<uint2>(src.ptr, idx);  // both textures' texel side by side: one 16-byte LDS read per tap texel
             } else {
                 s_inN[t * ntex + i] = rfx_gather<uint2>(src.ptr, idx);
             }
@@ -157,35 +152,8 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         return r;
     };
 
-    // both textures at once from the interleaved stage: one ds_read_b128 per footprint texel instead of two ds_read_b64
-    auto lds_linear2 = [&](float fu, float fv, float4 &r0, float4 &r1) {
-        int x0, x1, y0, y1;
-        float wx, wy;
-        rfx_linear_coord(fu, d.fW, d.W, x0, x1, wx);
-        rfx_linear_coord(fv, d.fH, d.H, y0, y1, wy);
-        x0 = min(max(x0 - tx0 + Rx, 0), LW - 1); x1 = min(max(x1 - tx0 + Rx, 0), LW - 1);
-        y0 = __mul24(min(max(y0 - ty0 + Ry, 0), LH - 1), LW); y1 = __mul24(min(max(y1 - ty0 + Ry, 0), LH - 1), LW);
-        const uint4 *sn = reinterpret_cast<const uint4 *>(s_inN);
-        const uint4 q00 = sn[y0 + x0], q10 = sn[y0 + x1], q01 = sn[y1 + x0], q11 = sn[y1 + x1];
-#define K3_BLEND(dst, A, B)                                                                                                  \
-    {                                                                                                                        \
-        const float4 t00 = rfx_load_half4(make_uint2(q00.A, q00.B)), t10 = rfx_load_half4(make_uint2(q10.A, q10.B));         \
-        const float4 t01 = rfx_load_half4(make_uint2(q01.A, q01.B)), t11 = rfx_load_half4(make_uint2(q11.A, q11.B));         \
-        dst.x = rfx_lerp(wy, rfx_lerp(wx, t00.x, t10.x), rfx_lerp(wx, t01.x, t11.x));                                        \
-        dst.y = rfx_lerp(wy, rfx_lerp(wx, t00.y, t10.y), rfx_lerp(wx, t01.y, t11.y));                                        \
-        dst.z = rfx_lerp(wy, rfx_lerp(wx, t00.z, t10.z), rfx_lerp(wx, t01.z, t11.z));                                        \
-        dst.w = rfx_lerp(wy, rfx_lerp(wx, t00.w, t10.w), rfx_lerp(wx, t01.w, t11.w));                                        \
-    }
-        K3_BLEND(r0, x, y)
-        K3_BLEND(r1, z, w)
-#undef K3_BLEND
-    };
-    constexpr bool AOS = !IN_TEMPORAL && TC == 2 && RFX_K3_AOS;
-
     CenterTexel c[TC];
     bool isSpec[TC];
-    float4 both[2];
-    if constexpr (AOS) lds_linear2(u, v, both[0], both[1]);
 #pragma unroll
     for (int i = 0; i < TC; i++) {  // :137-165
         isSpec[i] = p.isTextureSpecular[i] != 0;
@@ -194,8 +162,6 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         if constexpr (IN_TEMPORAL) {
             const TexView &src = ti ? A.in1 : A.in0;
             t = rfx_gather<float4>(src.ptr, (unsigned int)(__mul24(rfx_local_row(d, src.row0, src.rows, y), d.W) + x));
-        } else if constexpr (AOS) {
-            t = ti ? both[1] : both[0];
         } else {
             t = lds_linear(ti, u, v);
         }
@@ -230,8 +196,6 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         const float roughDiff = fabsf(roughness - ng.w);
         float l2basic = (-normalDiff * p.normalPhi - depthDiff * p.depthPhi - roughDiff * p.roughnessPhi) * K3_LOG2E;
         l2basic = (nd != 1.0f) ? l2basic : -__builtin_inff();
-        float4 tap2[2];
-        if constexpr (AOS) lds_linear2(nu, nv, tap2[0], tap2[1]);
 #pragma unroll
         for (int i = 0; i < TC; i++) {
             const int ti = (TC == 2 && isSpec[i]) ? 1 : 0;
@@ -240,7 +204,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
                 const float4 tl = s_in0[ti * ntex + ni];
                 k3_apply(c[i], l2w, make_float3(tl.x, tl.y, tl.z), tl.w, lumaPhiL2);
             } else {
-                const float4 t = AOS ? (ti ? tap2[1] : tap2[0]) : lds_linear(ti, nu, nv);
+                const float4 t = lds_linear(ti, nu, nv);
                 const float3 tl = k3_log3(t.x, t.y, t.z);
                 k3_apply(c[i], l2w, tl, k3_luma(tl), lumaPhiL2);
             }

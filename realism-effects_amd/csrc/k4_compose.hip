@@ -14,15 +14,28 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
     const float *C = A.p.camera.matrixWorld, *Vw = A.p.camera.matrixWorldInverse;
     const float *P = A.p.camera.projectionMatrix, *Pi = A.p.camera.projectionMatrixInverse;
     const float u = ((float)x + 0.5f) / d.fW, v = ((float)y + 0.5f) / d.fH;
-    // A streaming kernel: every fetch of the fragment is issued up front, before the discard test, so that the six dependent
-    // memory round trips the straight-line form makes (depth -> quad partners -> G-buffer -> GI taps) become one (the addresses are
-    // always valid; a discarded background fragment wastes its fetches, ~15 % of a frame).  Same arithmetic afterwards.
     const float *depthp = (const float *)A.depth.ptr;
-    const int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
     const float depth = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, y)];
-    const float dxa = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, qx0, y)], dxb = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, qx1, y)];
-    const float dya = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, qy0)], dyb = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, qy1)];
-    const uint4 gtexel = ((const uint4 *)A.gbuffer.ptr)[rfx_xy_index(d, A.gbuffer.row0, A.gbuffer.rows, x, y)];
+    {
+        const int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
+        float dxa = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, qx0, y)], dxb = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, qx1, y)];
+        float dya = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, qy0)], dyb = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, qy1)];
+        if (depth == 1.0f && (fabsf(dxb - dxa) + fabsf(dyb - dya)) == 0.0f) {  // discard :61-64
+            if (A.rgb_out) {  // the target keeps its texel: mirror it, so COMPOSE_RGB stays == COMPOSE.rgb on every tile texel
+                const float4 keep = ((const float4 *)A.out.ptr)[(size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x];
+                float *r = A.rgb_out + ((size_t)y * d.W + x) * 3;
+                r[0] = keep.x; r[1] = keep.y; r[2] = keep.z;
+            }
+            return;
+        }
+    }
+    const Material mat = rfx_get_material<true>(((const uint4 *)A.gbuffer.ptr)[rfx_xy_index(d, A.gbuffer.row0, A.gbuffer.rows, x, y)]);
+    const float3 viewNormal = rfx_vec_mul_mat(C, mat.normal, 0.0f);  // :71 (not normalised)
+    const float n_ = A.p.camera.near_, f_ = A.p.camera.far_;
+    const float viewZ = -rfx_depth_to_view_z(depth, n_, f_, A.p.camera.isPerspective != 0);  // -getViewZ(depth) :73
+    const float clipW = P[2 * 4 + 3] * viewZ + P[3 * 4 + 3];
+    const float4 pp = rfx_mat_mul(Pi, ((u - 0.5f) * 2.0f) * clipW, ((v - 0.5f) * 2.0f) * clipW, ((viewZ - 0.5f) * 2.0f) * clipW, 1.0f * clipW);
+    const float3 viewDir = rfx_normalize(make_float3(pp.x, pp.y, -viewZ));
     // DenoiserComposePass.js:26-33: "diffuseSpecular" -> (textures[0], textures[1]); "specular" -> specularGi = textures[0],
     // diffuseGiTexture unbound (zeros) and the diffuse component comes from sceneTexture
     float4 dgi = make_float4(0.f, 0.f, 0.f, 0.f), sgi;
@@ -35,45 +48,11 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
             sgi = ((const float4 *)A.gi0.ptr)[gi];
         }
     } else if (A.p.inputType == 0) {
-        // both textures' bilinear footprints in flight together (the same four texel positions in each)
-        int x0, x1, y0, y1;
-        float wx, wy;
-        rfx_linear_coord(u, d.fW, d.W, x0, x1, wx);
-        rfx_linear_coord(v, d.fH, d.H, y0, y1, wy);
-        const unsigned int r0 = (unsigned int)__mul24(rfx_local_row(d, A.gi0.row0, A.gi0.rows, y0), d.W), r1 = (unsigned int)__mul24(rfx_local_row(d, A.gi0.row0, A.gi0.rows, y1), d.W);
-        const uint2 a00 = rfx_gather<uint2>(A.gi0.ptr, r0 + x0), a10 = rfx_gather<uint2>(A.gi0.ptr, r0 + x1);
-        const uint2 a01 = rfx_gather<uint2>(A.gi0.ptr, r1 + x0), a11 = rfx_gather<uint2>(A.gi0.ptr, r1 + x1);
-        const uint2 b00 = rfx_gather<uint2>(A.gi1.ptr, r0 + x0), b10 = rfx_gather<uint2>(A.gi1.ptr, r0 + x1);
-        const uint2 b01 = rfx_gather<uint2>(A.gi1.ptr, r1 + x0), b11 = rfx_gather<uint2>(A.gi1.ptr, r1 + x1);
-#define K4_BLEND(dst, q00, q10, q01, q11)                                                                  \
-    {                                                                                                      \
-        const float4 t00 = rfx_load_half4(q00), t10 = rfx_load_half4(q10), t01 = rfx_load_half4(q01), t11 = rfx_load_half4(q11); \
-        dst.x = rfx_lerp(wy, rfx_lerp(wx, t00.x, t10.x), rfx_lerp(wx, t01.x, t11.x));                      \
-        dst.y = rfx_lerp(wy, rfx_lerp(wx, t00.y, t10.y), rfx_lerp(wx, t01.y, t11.y));                      \
-        dst.z = rfx_lerp(wy, rfx_lerp(wx, t00.z, t10.z), rfx_lerp(wx, t01.z, t11.z));                      \
-        dst.w = rfx_lerp(wy, rfx_lerp(wx, t00.w, t10.w), rfx_lerp(wx, t01.w, t11.w));                      \
-    }
-        K4_BLEND(dgi, a00, a10, a01, a11)
-        K4_BLEND(sgi, b00, b10, b01, b11)
-#undef K4_BLEND
+        dgi = rfx_fetch_h4_linear(A.gi0, d, u, v);
+        sgi = rfx_fetch_h4_linear(A.gi1, d, u, v);
     } else {
         sgi = rfx_fetch_h4_linear(A.gi0, d, u, v);
     }
-    if (depth == 1.0f && (fabsf(dxb - dxa) + fabsf(dyb - dya)) == 0.0f) {  // discard :61-64
-        if (A.rgb_out) {  // the target keeps its texel: mirror it, so COMPOSE_RGB stays == COMPOSE.rgb on every tile texel
-            const float4 keep = ((const float4 *)A.out.ptr)[(size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x];
-            float *r = A.rgb_out + ((size_t)y * d.W + x) * 3;
-            r[0] = keep.x; r[1] = keep.y; r[2] = keep.z;
-        }
-        return;
-    }
-    const Material mat = rfx_get_material<true>(gtexel);
-    const float3 viewNormal = rfx_vec_mul_mat(C, mat.normal, 0.0f);  // :71 (not normalised)
-    const float n_ = A.p.camera.near_, f_ = A.p.camera.far_;
-    const float viewZ = -rfx_depth_to_view_z(depth, n_, f_, A.p.camera.isPerspective != 0);  // -getViewZ(depth) :73
-    const float clipW = P[2 * 4 + 3] * viewZ + P[3 * 4 + 3];
-    const float4 pp = rfx_mat_mul(Pi, ((u - 0.5f) * 2.0f) * clipW, ((v - 0.5f) * 2.0f) * clipW, ((viewZ - 0.5f) * 2.0f) * clipW, 1.0f * clipW);
-    const float3 viewDir = rfx_normalize(make_float3(pp.x, pp.y, -viewZ));
 
     // constructGlobalIllumination
     const float roughness = mat.roughness * mat.roughness;

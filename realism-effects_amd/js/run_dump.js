@@ -7,6 +7,8 @@
 // input buffer (HalfFloatType / FloatType), and writes traa.bin (traa_compose output, RGBA32F) of the last frame.
 // --png <file> [--tonemap '"aces"'|'"linear"' --exposure X] / --exr <file> / --pfm <file>: also write final.bin as an image (tone-mapped
 // 8-bit sRGB PNG; scene-linear float OpenEXR / PFM) — js/imageio.js.
+// --stream true: the dumps cross PCIe on the context's upload stream from pinned planes, frame n+1 while frame n is drawn
+// (rfx_stage_upload / rfx_stage_flip); same outputs.
 // With --ranks N (N > 1): the frame is cut into N row tiles, ONE NODE PROCESS PER GPU (this process spawns them: rank r drives
 // device r), which exchange halo rows and the composed GI over RCCL through the C ABI (js/tiling.js); rank 0 creates the
 // ncclUniqueId and hands it over through a file.  The parent stitches the tiles: the outputs are bit-identical to a --ranks 1 run.
@@ -64,6 +66,8 @@ const tiled = opt.ranks > 1 ? { rank: opt.rank, ranks: opt.ranks, idFile: opt.id
 delete opt.ranks
 delete opt.rank
 delete opt.idFile
+const stream = !!opt.stream
+delete opt.stream
 const images = { png: opt.png, exr: opt.exr, pfm: opt.pfm, tonemap: opt.tonemap, exposure: opt.exposure }
 for (const k of Object.keys(images)) delete opt[k]
 const seeds = { ssgi: opt.ssgiSeed === undefined ? 11 : opt.ssgiSeed, denoise: opt.denoiseSeed === undefined ? 22 : opt.denoiseSeed }
@@ -123,12 +127,35 @@ if (opt.traa) {
 	process.exit(0)
 }
 const effect = new rfx.SSGIEffect(null, scene, camera, Object.assign({ width: first.width, height: first.height }, opt), seeds, true)
-for (const d of dumps) {
-	const f = d === dumps[0] ? first : rfx.readDump(d)
-	scene.frame = f
-	Object.assign(camera, f.camera)
-	effect.update(renderer, null)
-}
+if (stream && !tiled) {
+	if (!first.gbuffer) throw new Error("--stream needs packed gbuffer.bin / velocity.bin dumps")
+	const n = first.width * first.height
+	const sets = [0, 1].map(() => ({ depth: rfx.Renderer.hostAlloc(Float32Array, n), gbuffer: rfx.Renderer.hostAlloc(Uint32Array, 4 * n),
+		velocity: rfx.Renderer.hostAlloc(Uint32Array, 4 * n), direct: rfx.Renderer.hostAlloc(Float32Array, 4 * n) }))
+	const load = (d, set) => { // disk -> pinned planes (a reader thread's job in a long run)
+		const f = d === dumps[0] ? first : rfx.readDump(d)
+		for (const k of ["depth", "gbuffer", "velocity", "direct"]) set[k].set(f[k])
+		return Object.assign({}, f, set, { static: "resident" })
+	}
+	let cur = load(dumps[0], sets[0])
+	renderer.stageFrame(cur)
+	renderer.stageFlip()
+	for (let i = 0; i < dumps.length; i++) {
+		const next = i + 1 < dumps.length ? load(dumps[i + 1], sets[(i + 1) & 1]) : null
+		if (next) renderer.stageFrame(next) // frame i+1 starts crossing PCIe ...
+		scene.frame = cur
+		Object.assign(camera, cur.camera)
+		effect.update(renderer, null) // ... while frame i is drawn
+		renderer.stageFlip()
+		cur = next
+	}
+} else
+	for (const d of dumps) {
+		const f = d === dumps[0] ? first : rfx.readDump(d)
+		scene.frame = f
+		Object.assign(camera, f.camera)
+		effect.update(renderer, null)
+	}
 renderer.sync()
 fs.mkdirSync(out, { recursive: true })
 const T = rfx.TEX

@@ -11,7 +11,9 @@ llvmpipe on this box (oracle/_ref/shaders: the reference's own fragment sources 
 configs[0] 1080p steps 8/2 denoiseIterations 0 (K4 then reads a never-written target: SURVEY Appendix D-7)
 configs[1] 1080p steps 20/5 denoiseIterations 1
 configs[2] 4K    steps 20/5 denoiseIterations 1  (whole frame)
-configs[4] 8K    steps 40/5 denoiseIterations 3, a short distinct-frame sequence (the full 16 frames: tools/parity_configs.py)
+configs[4] 8K    steps 40/5 denoiseIterations 3: its OPTIONS (the steps-40 program, six K3 passes, K4 feedback over three distinct frames)
+           run here at 1080p; the 8K frames themselves take ~5 minutes each through the llvmpipe harness and numpy, so that case runs
+           with RFX_TEST_8K=1 (or `tools/parity_configs.py --size 7680x4320 --steps 40 --it 3`; report: profiles/r02_parity/)
 (configs[3] is configs[2] row-tiled: bit-identity to the single-context run, test_gpu_parity.py / test_tiling_gloo.py.)
 """
 import os
@@ -23,7 +25,8 @@ import stagewise as S
 pytestmark = pytest.mark.gpu
 
 # allowed fraction of (explained) out-of-tolerance pixels per stage kind: ~3x the largest fraction measured on MI355X
-FLIP = {"K1 ssgi": 3e-4, "K2 temporal0": 1e-4, "K2 temporal1": 2e-4, "K3 pass0": 2.5e-3, "K3 passN": 1e-3, "K4 compose": 5e-5}
+# measured maxima over configs[0..4] (profiles/r02_parity/): K1 0.0153 %, K2 0.0008 %, K3 pass 0 0.18 %, K3 later passes 0.0024 %, K4 0.0016 %
+FLIP = {"K1 ssgi": 5e-4, "K2 temporal0": 3e-5, "K2 temporal1": 3e-5, "K3 pass0": 5.4e-3, "K3 passN": 8e-5, "K4 compose": 5e-5}
 
 
 def _bound(kind):
@@ -52,10 +55,11 @@ def _have_reference_gl():
 
 
 @pytest.mark.parametrize("name,W,H,steps,refine,it,frames,n_perturb", [
-    ("configs[0]", 1920, 1080, 8, 2, 0, 2, 10),
-    ("configs[1]", 1920, 1080, 20, 5, 1, 2, 10),
-    ("configs[2]", 3840, 2160, 20, 5, 1, 2, 10),
-    ("configs[4]", 7680, 4320, 40, 5, 3, 2, 10),
+    ("configs[0]", 1920, 1080, 8, 2, 0, 2, 16),
+    ("configs[1]", 1920, 1080, 20, 5, 1, 2, 16),
+    ("configs[2]", 3840, 2160, 20, 5, 1, 2, 16),
+    ("configs[4] options @1080p", 1920, 1080, 40, 5, 3, 3, 16),
+    pytest.param("configs[4]", 7680, 4320, 40, 5, 3, 2, 16, marks=pytest.mark.skipif(os.environ.get("RFX_TEST_8K") != "1", reason="~10 min: set RFX_TEST_8K=1")),
 ])
 def test_baseline_config_stagewise_vs_reference_glsl(blue_noise, name, W, H, steps, refine, it, frames, n_perturb):
     if not _have_reference_gl():

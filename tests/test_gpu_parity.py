@@ -671,6 +671,68 @@ def test_env_map_vs_oracle(blue_noise, env_blur, half):
     ctx.close()
 
 
+def test_streamed_dumps_equal_uploaded_dumps():
+    """rfx.h "streaming dumps": frame n+1's planes are staged (pinned host memory, upload stream) while frame n is drawn and published
+    by rfx_stage_flip — three frames through SSGIEffect give the same textures, bit for bit, as the synchronous rfx_upload path; a
+    pageable plane is accepted too."""
+    import types
+    from rfx_amd import abi
+    from rfx_amd.context import Context, RfxError
+    from rfx_amd.effect import SSGIEffect
+    from rfx_amd.scene import synthetic_frame
+
+    W, H = 224, 126
+    frames = [synthetic_frame(W, H, i) for i in range(3)]
+
+    def run(streamed):
+        ctx = Context(W, H)
+        scene = types.SimpleNamespace(frame=None)
+        cam = types.SimpleNamespace(**vars(frames[0].camera))
+        fx = SSGIEffect(None, scene, cam, dict(width=W, height=H), seeds=dict(ssgi=3, denoise=4), half_store_rtz=True)
+        if streamed:
+            sets = []
+            for k in range(2):
+                st = {n: ctx.host_alloc(getattr(frames[0], n).shape, getattr(frames[0], n).dtype) for n in ("depth", "gbuffer", "velocity", "direct")}
+                sets.append(st)
+
+            def load(i):
+                st = sets[i & 1]
+                for n in st:
+                    st[n][...] = getattr(frames[i], n)
+                return types.SimpleNamespace(camera=frames[i].camera, static="resident", **st)
+            cur = load(0)
+            ctx.stage_frame(cur)
+            ctx.stage_flip()
+        for i, f in enumerate(frames):
+            if streamed:
+                nxt = load(i + 1) if i + 1 < len(frames) else None
+                if nxt is not None:
+                    ctx.stage_frame(nxt)
+                scene.frame = cur
+            else:
+                scene.frame = f
+            for k, v in vars(f.camera).items():
+                setattr(cam, k, v)
+            fx.update(ctx, None)
+            if streamed:
+                ctx.stage_flip()
+                cur = nxt
+        out = [ctx.download(t) for t in (abi.TEX_COMPOSE, abi.TEX_DENOISE_B0, abi.TEX_TEMPORAL1, abi.TEX_SSGI)]
+        assert ctx.halo_violations() == 0
+        if streamed:
+            ctx.stage_upload(abi.TEX_DEPTH, frames[0].depth)  # pageable: simply not asynchronous
+            ctx.stage_flip()
+            assert np.array_equal(ctx.download(abi.TEX_DEPTH), frames[0].depth)
+            with pytest.raises(RfxError):
+                ctx.stage_upload(abi.TEX_COMPOSE, np.zeros((H, W, 4), np.float32))  # only the dump's input planes are double-buffered
+        ctx.close()
+        return out
+
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
+
+
 def test_comm_entry_points_on_a_single_rank_ring(blue_noise):
     """The RCCL exchanges behind the C ABI (rfx.h "row-tiled runs") on the one GPU a test box has: a ring of ONE rank.  RCCL is bound at
     run time, the communicator is created on the context's device, the all-gather of the composed GI runs in place on the exchange

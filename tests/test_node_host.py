@@ -238,7 +238,21 @@ def test_node_host_drives_the_gpu_bit_identically(tmp_path):
         py = ctx.download(tex)
         js = np.fromfile(os.path.join(out, name + ".bin"), py.dtype).reshape(py.shape)
         assert np.array_equal(py.view(np.uint8), js.view(np.uint8)), name
+    final_py = ctx.download(abi.TEX_FINAL)
     ctx.close()
+    # --stream (pinned planes on the upload stream, frame n+1 staged while frame n is drawn) writes the same bytes; --png / --exr carry
+    # the final image: the EXR holds its exact float32 texels, the PNG is the ACES tone map of them (to 1 LSB of the Python twin)
+    from rfx_amd import imageio
+    out_s = str(tmp_path / "js_stream")
+    res = subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", out_s, "--steps", "12", "--refineSteps", "3", "--env", json.dumps(envf),
+                                   "--envWidth", "64", "--envHeight", "32", "--stream", "true", "--png", json.dumps(str(tmp_path / "f.png")),
+                                   "--exr", json.dumps(str(tmp_path / "f.exr"))], text=True)
+    assert json.loads(res.strip().splitlines()[-1])["haloViolations"] == 0
+    for name in ("final", "compose", "denoise_b1"):
+        assert open(os.path.join(out, name + ".bin"), "rb").read() == open(os.path.join(out_s, name + ".bin"), "rb").read(), name
+    e = imageio.read_exr(str(tmp_path / "f.exr"))
+    assert np.array_equal(np.stack([e[c] for c in "RGBA"], -1), final_py)
+    assert np.abs(imageio.read_png(str(tmp_path / "f.png")).astype(np.int32) - imageio.tonemap(final_py).astype(np.int32)).max() <= 1
     # the Node host from UNPACKED attribute planes (device-side importer) == the Python host from the same planes
     gen_frames = [__import__("rfx_amd.scene", fromlist=["AnalyticScene"]).AnalyticScene(1234).render(W, H, i, aov=True) for i in range(2)]
     adirs = []

@@ -6,6 +6,18 @@ NAME=${1:-profile}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$NAME
 mkdir -p $OUT
+python - "$OUT" <<'PY'
+import json, subprocess, sys, time, os
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+try:
+    commit = open(os.path.join(root, "gpurun_commit.txt")).read().strip()
+except Exception:
+    commit = "unknown"
+json.dump({"profile": os.path.basename(sys.argv[1]), "git_commit": commit, "collected": time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime()),
+           "command": "tools/collect_profiles.sh (bench.py at 3840x2160, steps 20/5, denoiseIterations 1; rocprofv3 --kernel-trace --stats; one --pmc set per pass)"},
+          open(os.path.join(sys.argv[1], "meta.json"), "w"))
+PY
+$ROOT/tools/microbench/bin/valu_rates > $OUT/valu_rates.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 # 1. the bench line itself (un-profiled, with the CPU baselines)

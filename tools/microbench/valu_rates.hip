@@ -40,6 +40,18 @@ __global__ __launch_bounds__(256) void kop(float *out, float seed) {
             if (OP == 5) asm volatile("v_mul_i32_i24 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(seed));
             if (OP == 6) asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(a[i]) : "v"(a[i]));
             if (OP == 7) asm volatile("v_sin_f32 %0, %1" : "=v"(a[i]) : "v"(a[i]));
+            // the UNPACKED forms, as inline asm: left to the compiler, eight independent fma chains become four v_pk_fma_f32 (that is what
+            // run<0> "v_fma_f32" above measures: 2 fma per ~4.8 cycles, not one per 2.4)
+            if (OP == 8) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(a[i]), "v"(seed), "v"(seed));
+            if (OP == 9) asm volatile("v_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(seed));
+            if (OP == 10) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(seed));
+            if (OP == 11) asm volatile("v_exp_f32 %0, %1" : "=v"(a[i]) : "v"(a[i]));
+            if (OP == 12) asm volatile("v_log_f32 %0, %1" : "=v"(a[i]) : "v"(a[i]));
+            if (OP == 13) asm volatile("v_rcp_f32 %0, %1" : "=v"(a[i]) : "v"(a[i]));
+            if (OP == 14) asm volatile("v_sqrt_f32 %0, %1" : "=v"(a[i]) : "v"(a[i]));
+            if (OP == 15) asm volatile("v_cmp_gt_f32 vcc, %1, %2\n\tv_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(a[i]), "v"(seed) : "vcc");
+            if (OP == 16) asm volatile("v_max_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[i]), "v"(seed));
+            if (OP == 17) asm volatile("v_lshlrev_b32 %0, 1, %1" : "=v"(a[i]) : "v"(a[i]));
         }
     }
     float s = 0;
@@ -130,11 +142,20 @@ int main() {
         run_kernel("v_pk_add_f32", kpk<3>, w);
         run_kernel("v_med3_f32", kop<1>, w);
         run_kernel("v_cvt_f32_f16", kop<2>, w);
-        run_kernel("v_cndmask_b32", kop<3>, w);
-        run_kernel("v_min3_f32", kop<4>, w);
+                run_kernel("v_min3_f32", kop<4>, w);
         run_kernel("v_mul_i32_i24", kop<5>, w);
         run_kernel("v_cvt_i32_f32", kop<6>, w);
         run_kernel("v_sin_f32", kop<7>, w);
+        run_kernel("v_fma_f32 (unpacked, asm)", kop<8>, w);
+        run_kernel("v_add_f32 (asm)", kop<9>, w);
+        run_kernel("v_mul_f32 (asm)", kop<10>, w);
+        run_kernel("v_exp_f32 (asm)", kop<11>, w);
+        run_kernel("v_log_f32 (asm)", kop<12>, w);
+        run_kernel("v_rcp_f32 (asm)", kop<13>, w);
+        run_kernel("v_sqrt_f32 (asm)", kop<14>, w);
+        run_kernel("v_cmp + v_cndmask (2 instr)", kop<15>, w);
+        run_kernel("v_max_f32 (asm)", kop<16>, w);
+        run_kernel("v_lshlrev_b32 (asm)", kop<17>, w);
     }
     return 0;
 }
