@@ -234,7 +234,8 @@ def main():
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K, help="frame rows (N = 1) / rows of the 4K frame that is cut into N tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame the CPU baseline processes (0 = auto)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame the CPU port baseline processes (0 = auto)")
+    ap.add_argument("--cpu-port", action="store_true", help="also time the C restatement (OpenMP) as a second, non-GL CPU line (+10 s)")
     ap.add_argument("--checksum", action="store_true", help="add sha1 of the final whole-frame composed GI to the JSON line (tiled == single check)")
     ap.add_argument("--exchange", choices=("c", "torch"), default="c", help="N > 1: exchanges through the C ABI's RCCL entry points (default) or torch.distributed")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: only the headline case (skip the weak-scaling and configs[4] extras)")
@@ -368,7 +369,7 @@ def main():
         if args.checksum:
             out["compose_sha1"], out["frame_rows"] = compose_sha1, H1
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(case["frame"], case["fx"], W1, H1, args.cpu_sample_rows)
+            out["cpu_baseline"] = cpu_baseline(case["frame"], case["fx"], W1, H1, args.cpu_sample_rows, args.cpu_port)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -378,7 +379,7 @@ def main():
 
 
 def case_exchange(use_c, one_gpu, args):
-    if uid is not None:
+    if use_c:
         return "C ABI rfx_halo_exchange / rfx_allgather_history (RCCL on the context's exchange stream)"
     return "torch.distributed (%s)" % ("gloo, one-GPU functional mode" if one_gpu else "nccl = RCCL")
 
@@ -415,16 +416,18 @@ def cpu_baseline_llvmpipe(frame, W, H):
                       "%.0f ms per frame; %s; box has %d cores, LP_NUM_THREADS=%s" % (n, W, H, med, chain.GL.info(), cores, os.environ["LP_NUM_THREADS"])}
 
 
-def cpu_baseline(frame, fx, W, H, sample_rows):
-    """Preferred: the reference GLSL on llvmpipe (kind "reference").  Fallback / second line: the oracle
-    (oracle/rfx_oracle.c, kind "port": scalar C restatement, OpenMP over rows) on the host cores of
-    this box: the same chain on a bounded band of the same 4K frame."""
-    port = cpu_baseline_port(frame, fx, W, H, sample_rows)
+def cpu_baseline(frame, fx, W, H, sample_rows, with_port=False):
+    """The reference GLSL on llvmpipe (kind "reference"): the reference's own code on this box's host cores.  The C restatement
+    (oracle/rfx_oracle.c, kind "port": scalar, OpenMP over rows) is slower than llvmpipe's vectorised JIT even on 8x the threads
+    (2.0-2.9 vs 10-12 Mpix/s), so it is only the fallback when the GL harness is unavailable, or an extra line on request."""
     try:
         ref = cpu_baseline_llvmpipe(frame, W, H)
-        ref["port"] = {k: port[k] for k in ("value", "unit", "cores", "sample")}
+        if with_port:
+            port = cpu_baseline_port(frame, fx, W, H, sample_rows)
+            ref["port"] = {k: port[k] for k in ("value", "unit", "cores", "sample")}
         return ref
     except Exception as e:  # no swrast_dri.so / no prebuilt shaders on this box
+        port = cpu_baseline_port(frame, fx, W, H, sample_rows)
         port["llvmpipe_unavailable"] = repr(e)[:200]
         return port
 

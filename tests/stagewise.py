@@ -176,6 +176,8 @@ def run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_
                     with O.perturbation(seed):
                         unstable |= out_of_tolerance(as_float(fn()), base, half) & rest
             rest = bad & ~unstable
+        if rest.any():  # diagnostics for the test log: what the oracle itself computes at the pixels nobody could explain
+            diag["oracle_at_unexplained"] = (np.argwhere(rest)[:6], base[rest][:6], mm.plane[rest][:6])
         return unstable, int(round(float(unstable[sample].mean()) * H * W)) if sample.any() else 0
 
     def bad_of(gots, wants, half):
@@ -186,12 +188,23 @@ def run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_
             b |= out_of_tolerance(as_float(g), as_float(w), half)
         return b
 
+    diag = {}
+
     def check(name, got, want, mr, half):
         m, at_risk = mr
         if isinstance(got, np.ndarray) and got.dtype == np.uint16:
             got, want = O.half_bits_to_float(got), O.half_bits_to_float(want)
         r = strict(name, got, want, explainable=m, half=half)
         r.at_risk = at_risk
+        if r.unexplained and "oracle_at_unexplained" in diag:
+            idx, obase, omargin = diag.pop("oracle_at_unexplained")
+            g, w = as_float(got), as_float(want)
+            for k, (y, x) in enumerate(idx):
+                c = slice(0, g.shape[-1]) if obase.shape[-1] == g.shape[-1] else slice(0, 0)
+                log("    unexplained (y %d, x %d) margin %.3g\n      impl   %s\n      ref    %s\n      oracle %s" % (
+                    y, x, omargin[k], np.array2string(g[y, x], precision=6), np.array2string(w[y, x], precision=6),
+                    np.array2string(obase[k], precision=6)))
+        diag.clear()
         reports.append(r)
         log(r.line())
         return r
