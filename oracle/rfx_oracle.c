@@ -54,10 +54,13 @@ static inline float pert_sign(void) {
 }
 static inline float pert_rel(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * g_pert_rel) : v; }
 static inline float pert_ang(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * 2.4e-7f) + pert_sign() * g_pert_abs : v; }
-/* the fragment's vUv: a rasteriser interpolates the varying from plane equations and lands within an ulp of (x + 0.5) / W — measured on
- * the reference GL: off by one ulp on 40-75 % of the rows (resolutionScale).  One ulp of u is one ulp of u * W: up to
- * 5e-4 texel at 8K, which is what a LINEAR fetch at a pixel centre (K4, K3's later passes) turns into a weight error */
-static inline float pert_uv(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * 1.1920929e-7f) : v; }
+/* the fragment's vUv: a rasteriser interpolates the varying from plane equations in fp32.  Measured on the reference GL at 1080p / 4K / 8K
+ * (oracle/glref/probes/probe_varying.py): vUv is exact on only 23-74 % of the positions and off by up to 2^-24 ABSOLUTE (one ulp of the
+ * [0.5, 1) binade, at any u) = 1.1e-4 / 2.3e-4 / 4.6e-4 texel.  Every fetch at a vUv-derived coordinate inherits it: a NEAREST tap that
+ * close to a texel boundary flips (K3's rotated taps: 8 taps x 2 axes -> ~0.2 % of the pixels, the measured pass-0 flip rate), a LINEAR
+ * fetch turns it into a weight error (K4, K3's later passes, K2's history). */
+#define UV_ABS_ERR 5.9604645e-8f
+static inline float pert_uv(float v) { return (g_pert_seed && g_pert_state) ? v + pert_sign() * UV_ABS_ERR : v; }
 static inline float pert_sqrt(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * 2.4e-7f) : v; }
 /* function-like macros are not re-expanded inside their own expansion: (expf)(x) is libm's */
 #define expf(x) pert_rel((expf)(x))
@@ -191,12 +194,13 @@ static inline uint16_t float_to_half_rtz(float f) {
 /* texel-boundary margin of a nearest fetch at coordinate c (texels): the coordinate carries a few ulps of its own magnitude
  * plus whatever its inputs carry (rel_in, relative to the OFFSET that was added to a pixel centre, passed in texels) */
 static _Thread_local float g_fetch_rel = 0.0f, g_fetch_abs = 0.0f; /* what the coordinate's INPUTS carry (set by the caller that knows) */
+static const float g_uv_err = 5.9604645e-8f; /* the rasteriser's vUv error (UV_ABS_ERR below): in texels it scales with the texture size */
 static inline void margin_texel(float c, int size) {
     if (!(c > 0.0f && c < (float)size)) return; /* clamped region: flat */
     float fl = floorf(c), fr = c - fl;
     float dlo = fl >= 1.0f ? fr : 3.0e38f;                      /* the boundary at fl exists unless it is the clamp at 0 */
     float dhi = fl <= (float)(size - 2) ? 1.0f - fr : 3.0e38f;  /* the boundary at fl + 1 exists unless it is the clamp at size */
-    float scale = (4.0f * 1.1920929e-7f + g_fetch_rel) * fabsf(c) + g_fetch_abs;
+    float scale = (4.0f * 1.1920929e-7f + g_fetch_rel) * fabsf(c) + g_fetch_abs + g_uv_err * (float)size;
     margin_note(fminf(dlo, dhi) / fmaxf(scale, 1e-30f));
 }
 static inline int nearest_idx(float u, int size) {
