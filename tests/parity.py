@@ -51,10 +51,12 @@ class Report:
     worst_unexplained: tuple
 
     def line(self):
-        ar = "" if self.at_risk is None else ", at-risk %d (%.4f%%)" % (self.at_risk, 100.0 * self.at_risk / max(self.pixels, 1))
-        return "%-22s px %9d  Linf(all) %.3e  Linf(in-tol) %.3e  out-of-tol %6d (%.4f%%) = explained %d + UNEXPLAINED %d%s" % (
-            self.name, self.pixels, self.linf_abs, self.linf_abs_ok, self.bad, 100.0 * self.bad / max(self.pixels, 1), self.explained,
-            self.unexplained, ar)
+        head = "%-22s px %9d  Linf(all) %.3e  Linf(in-tol) %.3e  out-of-tol %6d (%.4f%%)" % (
+            self.name, self.pixels, self.linf_abs, self.linf_abs_ok, self.bad, 100.0 * self.bad / max(self.pixels, 1))
+        if self.at_risk is None:
+            return head + "  (bounded, not proven: no oracle run for this comparison)"
+        return head + " = explained %d + UNEXPLAINED %d, at-risk %d (%.4f%%)" % (
+            self.explained, self.unexplained, self.at_risk, 100.0 * self.at_risk / max(self.pixels, 1))
 
 
 def _errors(a, b, half):

@@ -154,31 +154,47 @@ def run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_
     def margins_of(fn, half, bad):
         """(explainable (H, W) bool, estimated at-risk pixel count): the oracle proves a pixel unstable — discontinuity margin < 1, or
         its output moves out of tolerance when the oracle's transcendental results are perturbed within the reference GL's measured
-        error (n_perturb seeded runs)"""
+        error (n_perturb seeded runs).  Only the pixels of `bad | sample` are evaluated AND compared (an 8K stage output is 0.5-1 GB)."""
         if ora is None:
             return None, None
-        with O.pixel_mask(bad | sample):
+        mask = bad | sample
+        sel = np.flatnonzero(mask)
+
+        def picked(outs):  # the selected pixels of a stage's outputs as one (n, C) float32 array
+            outs = outs if isinstance(outs, (list, tuple)) else [outs]
+            return np.concatenate([as_float(np.ascontiguousarray(o.reshape(H * W, -1)[sel])[None])[0] for o in outs], axis=-1)
+
+        unstable_sel = np.zeros(sel.size, bool)
+        with O.pixel_mask(mask):
             with O.margins(H, W) as mm:
-                base = as_float(fn())
-            unstable = mm.plane < 1.0
+                base = picked(fn())
+            unstable_sel |= mm.plane.reshape(-1)[sel] < 1.0
             for seed in range(1, n_perturb + 1):
                 with O.perturbation(seed):
-                    unstable |= out_of_tolerance(as_float(fn()), base, half)
-        unstable &= bad | sample
+                    unstable_sel |= out_of_tolerance(picked(fn())[None], base[None], half)[0]
         # an out-of-tolerance pixel the first seeds did not move gets more draws (random signs per call: a flip that needs one particular
         # combination of signs is found with probability < 1 per seed) — only those few pixels are re-evaluated
-        rest = bad & ~unstable
+        bad_sel = bad.reshape(-1)[sel]
         seed = n_perturb
-        while rest.any() and seed < n_perturb + extra_perturb:
-            with O.pixel_mask(rest):
+        while (bad_sel & ~unstable_sel).any() and seed < n_perturb + extra_perturb:
+            rest = np.zeros(H * W, bool)
+            rest[sel[bad_sel & ~unstable_sel]] = True
+            with O.pixel_mask(rest.reshape(H, W)):
                 for _ in range(8):
                     seed += 1
                     with O.perturbation(seed):
-                        unstable |= out_of_tolerance(as_float(fn()), base, half) & rest
-            rest = bad & ~unstable
-        if rest.any():  # diagnostics for the test log: what the oracle itself computes at the pixels nobody could explain
-            diag["oracle_at_unexplained"] = (np.argwhere(rest)[:6], base[rest][:6], mm.plane[rest][:6])
-        return unstable, int(round(float(unstable[sample].mean()) * H * W)) if sample.any() else 0
+                        moved = out_of_tolerance(picked(fn())[None], base[None], half)[0]
+                    unstable_sel |= moved & bad_sel  # (pixels outside `rest` were not re-evaluated: they compare equal)
+        unstable = np.zeros(H * W, bool)
+        unstable[sel] = unstable_sel
+        unstable = unstable.reshape(H, W)
+        left = bad & ~unstable
+        if left.any():  # diagnostics for the test log: what the oracle itself computes at the pixels nobody could explain
+            li = np.flatnonzero(left.reshape(-1))[:6]
+            pos = np.searchsorted(sel, li)
+            diag["oracle_at_unexplained"] = (np.stack([li // W, li % W], 1), base[pos], mm.plane.reshape(-1)[li])
+        n_sample = int(sample.sum())
+        return unstable, int(round(float(unstable[sample].sum()) / max(n_sample, 1) * H * W))
 
     def bad_of(gots, wants, half):
         gots = gots if isinstance(gots, (list, tuple)) else [gots]
