@@ -33,7 +33,7 @@ import numpy as np  # noqa: E402
 from rfx_amd import abi, tiling  # noqa: E402
 from rfx_amd.context import Context  # noqa: E402
 from rfx_amd.effect import SSGIEffect  # noqa: E402
-from rfx_amd.scene import AnalyticScene  # noqa: E402
+from rfx_amd.scene import synthetic_band_parallel  # noqa: E402
 
 W4K, H4K = 3840, 2160
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
@@ -115,18 +115,17 @@ def ctl_device(dist, dev):
     return dev if (dist is not None and dist.get_backend() == "nccl") else "cpu"
 
 
-def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, refine, iterations, vfov_rows=None, use_c=False):
+def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, refine, iterations, use_c=False):
     """Dump + context + effect of one benchmark case on this rank: frame W x H cut into `tiles` (one per rank).  Returns a dict with
     the step function, the context and what the JSON line reports about the case."""
     import torch
     y0, rows = tiles[rank]
     t0 = time.time()
-    scene_gen = AnalyticScene(1234)
+    nproc = max(1, min(32, len(os.sched_getaffinity(0)) // max(world, 1)))  # the dump is ray-cast on the host cores, split over the ranks
     opts = dict(width=W, height=H, steps=steps, refineSteps=refine, denoiseIterations=iterations)
     # frame 1 of the orbit: non-zero velocity (camera moved 0.5 deg since frame 0).  The tile is dumped first, the
     # velocity bound over ALL tiles fixes the halo width, then the halo rows are dumped and attached.
-    kw = dict(frame_height=H, vfov_rows=vfov_rows) if vfov_rows else dict(frame_height=H)
-    tile = scene_gen.render(W, rows, 1, row0=y0, rows=rows, **kw)
+    tile = synthetic_band_parallel(W, H, 1, y0, rows, workers=nproc)
     vmax = float(np.abs(tile.velocity[..., 1].view(np.float32)).max())
     if dist is not None:  # every rank must use the SAME halo: the neighbours' send/recv sizes have to match
         t = torch.tensor([vmax], dtype=torch.float64, device=ctl_device(dist, dev))
@@ -136,9 +135,9 @@ def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, 
     b0, b1 = max(0, y0 - halo), min(H, y0 + rows + halo)
     parts = [tile]
     if b0 < y0:
-        parts.insert(0, scene_gen.render(W, y0 - b0, 1, row0=b0, rows=y0 - b0, **kw))
+        parts.insert(0, synthetic_band_parallel(W, H, 1, b0, y0 - b0, workers=nproc))
     if b1 > y0 + rows:
-        parts.append(scene_gen.render(W, b1 - y0 - rows, 1, row0=y0 + rows, rows=b1 - y0 - rows, **kw))
+        parts.append(synthetic_band_parallel(W, H, 1, y0 + rows, b1 - y0 - rows, workers=nproc))
     band = types.SimpleNamespace(camera=tile.camera, **{k: np.concatenate([getattr(q, k) for q in parts], axis=0)
                                                          for k in ("depth", "gbuffer", "velocity", "direct")})
     log("[rank %d] dump band rows [%d,%d) of %dx%d generated in %.1fs (halo %d)" % (rank, b0, b1, W, H, time.time() - t0, halo))

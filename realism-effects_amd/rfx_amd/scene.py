@@ -453,20 +453,29 @@ def _render_band(args):
     return f.depth, f.gbuffer, f.velocity, f.direct, f.camera, f.prev_camera
 
 
-def synthetic_frame_parallel(width: int, height: int, frame_index: int = 0, seed: int = 1234, workers: int | None = None) -> Frame:
-    """synthetic_frame() ray-cast by a pool of processes, one horizontal band each — the same texels (every band is rendered against the
-    whole frame's camera), in a fraction of the wall time on a many-core host (a 4K dump takes ~13 s single-threaded)."""
+def synthetic_band_parallel(width: int, height: int, frame_index: int, row0: int, rows: int, seed: int = 1234, workers: int | None = None) -> Frame:
+    """Rows [row0, row0 + rows) of frame `frame_index` of a width x height frame, ray-cast by a pool of processes (one slice each) —
+    the same texels as AnalyticScene.render(..., row0, rows, frame_height=height) in a fraction of the wall time on a many-core host
+    (a 4K dump takes ~13 s single-threaded).  Returns a Frame whose planes hold just those rows."""
     import multiprocessing as mp
     import os
     workers = workers or max(1, min(len(os.sched_getaffinity(0)), 32))
-    if workers == 1 or height < 4 * workers:
-        return synthetic_frame(width, height, frame_index, seed)
-    edges = [height * i // workers for i in range(workers + 1)]
+    workers = max(1, min(workers, rows // 4))
+    if workers == 1:
+        return AnalyticScene(seed).render(width, rows, frame_index, row0=row0, rows=rows, frame_height=height)
+    edges = [row0 + rows * i // workers for i in range(workers + 1)]
     jobs = [(seed, width, height, frame_index, edges[i], edges[i + 1] - edges[i]) for i in range(workers) if edges[i + 1] > edges[i]]
     with mp.get_context("fork").Pool(len(jobs)) as pool:
         parts = pool.map(_render_band, jobs)
     cat = lambda k: np.ascontiguousarray(np.concatenate([p[k] for p in parts], axis=0))  # noqa: E731
-    return Frame(width, height, cat(0), cat(1), cat(2), cat(3), parts[0][4], parts[0][5], frame_index)
+    return Frame(width, rows, cat(0), cat(1), cat(2), cat(3), parts[0][4], parts[0][5], frame_index)
+
+
+def synthetic_frame_parallel(width: int, height: int, frame_index: int = 0, seed: int = 1234, workers: int | None = None) -> Frame:
+    """synthetic_frame() through synthetic_band_parallel: the same texels, ~10x sooner."""
+    if (workers or 2) == 1 or height < 16:
+        return synthetic_frame(width, height, frame_index, seed)
+    return synthetic_band_parallel(width, height, frame_index, 0, height, seed, workers)
 
 
 def synthetic_environment(width: int = 256, height: int = 128, seed: int = 1234) -> np.ndarray:
