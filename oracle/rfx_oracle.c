@@ -59,7 +59,10 @@ static inline float pert_ang(float v) { return (g_pert_seed && g_pert_state) ? v
  * [0.5, 1) binade, at any u) = 1.1e-4 / 2.3e-4 / 4.6e-4 texel.  Every fetch at a vUv-derived coordinate inherits it: a NEAREST tap that
  * close to a texel boundary flips (K3's rotated taps: 8 taps x 2 axes -> ~0.2 % of the pixels, the measured pass-0 flip rate), a LINEAR
  * fetch turns it into a weight error (K4, K3's later passes, K2's history). */
-#define UV_ABS_ERR 5.9604645e-8f
+/* ... plus what the sampler adds on its own: one rounding of u * size (half an ulp of the texel coordinate, 2.4e-4 texel at 8K).  Together:
+ * 2^-23.  At 8K that is ~1e-3 texel: a LINEAR fetch of a texture whose neighbouring texels differ by ~1 (K2's history AGE channel from the
+ * third frame on, when ages exceed 1) moves by ~1e-3 — the absolute tolerance sits at the resolution of an fp32 texture coordinate there. */
+#define UV_ABS_ERR 1.1920929e-7f
 static inline float pert_uv(float v) { return (g_pert_seed && g_pert_state) ? v + pert_sign() * UV_ABS_ERR : v; }
 static inline float pert_sqrt(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * 2.4e-7f) : v; }
 /* function-like macros are not re-expanded inside their own expansion: (expf)(x) is libm's */
@@ -114,7 +117,7 @@ static inline void margin_cmp(float a, float b, float rel) {
     margin_note(fabsf(a - b) / s);
 }
 /* scales (relative error an operand of the decision can carry between two implementations with ulp-accurate primitives) */
-#define MARGIN_REL_MARCH 5e-7f   /* ray position after <= 40 accumulated steps of dir * (1 - exp(..)), projected */
+#define MARGIN_REL_MARCH 1e-6f   /* ray position after <= 40 accumulated steps of dir * (1 - exp(..)), projected */
 #define MARGIN_REL_SHORT 4e-6f   /* a handful of fp32 operations incl. one transcendental */
 #define MARGIN_REL_WEIGHT 1e-4f  /* products of exp(-phi * diff): the exponents reach ~10 and carry their own rounding */
 
@@ -194,7 +197,7 @@ static inline uint16_t float_to_half_rtz(float f) {
 /* texel-boundary margin of a nearest fetch at coordinate c (texels): the coordinate carries a few ulps of its own magnitude
  * plus whatever its inputs carry (rel_in, relative to the OFFSET that was added to a pixel centre, passed in texels) */
 static _Thread_local float g_fetch_rel = 0.0f, g_fetch_abs = 0.0f; /* what the coordinate's INPUTS carry (set by the caller that knows) */
-static const float g_uv_err = 5.9604645e-8f; /* the rasteriser's vUv error (UV_ABS_ERR below): in texels it scales with the texture size */
+static const float g_uv_err = 1.1920929e-7f; /* the rasteriser's vUv error (UV_ABS_ERR below): in texels it scales with the texture size */
 static inline void margin_texel(float c, int size) {
     if (!(c > 0.0f && c < (float)size)) return; /* clamped region: flat */
     float fl = floorf(c), fr = c - fl;

@@ -125,7 +125,7 @@ def _h(t):  # RGBA16F target read back as float32 -> the half bit patterns (exac
 
 
 def run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start=1000, denoise_start=2000, shader_dir=None, log=print,
-        with_margins=True, n_perturb=6, sample_every=64, extra_perturb=96):
+        with_margins=True, n_perturb=6, sample_every=64, extra_perturb=96, compare_from=0):
     """Returns the list of parity.Report (one per stage output and frame).  frame_fn(i) -> dump frame i (rfx_amd.scene Frame)."""
     import chain
     ref = chain.GLRefChain(W, H, blue, shader_dir=shader_dir, steps=steps, refineSteps=refine, denoiseIterations=iterations)
@@ -233,6 +233,16 @@ def run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_
             ora.frame(f)
         sp, tp, dp, cp = stage_params(f.camera, prev_cam or f.camera, keep, steps, refine)
         tag = "f%d " % fi
+        if fi < compare_from:  # only advance the reference chain (its state after frame fi is what frame fi + 1 is compared on)
+            si = (ssgi_start + si + 1) % M31
+            ref.ssgi(f.camera, si)
+            ref.temporal(f.camera, camera_moved=True)
+            for pi in range(2 * iterations):
+                di = (denoise_start + di + 1) % M31
+                _one_denoise_pass(ref, f.camera, pi, di)
+            ref.compose(f.camera)
+            keep, prev_cam = 1.0, f.camera
+            continue
         # ---- K1 (history = the reference's composed GI of the previous frame)
         hist = ref.t_compose.read()
         si = (ssgi_start + si + 1) % M31

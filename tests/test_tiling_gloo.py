@@ -157,6 +157,27 @@ def test_tiled_renderer_rejects_geometry_it_cannot_exchange():
         tiling.exchanged_textures("temporal")
 
 
+def test_split_rows_is_one_rule_in_c_python_and_node():
+    """rfx_split_rows (the C ABI's tile rule, used by rfx_comm_init and the Node host) == tiling.split_rows (Python) == js splitRows."""
+    import json
+    import shutil
+    import subprocess
+    from rfx_amd import tiling
+    from rfx_amd.context import Context
+    cases = [(2160, 8), (2160, 3), (1080, 7), (4320, 8), (90, 4), (64, 1)]
+    for Hh, n in cases:
+        assert [Context.split_rows(Hh, n, r) for r in range(n)] == tiling.split_rows(Hh, n)
+    with pytest.raises(ValueError):
+        Context.split_rows(6, 8, 0)
+    node = shutil.which("node")
+    addon = os.path.join(HERE, "..", "realism-effects_amd", "napi", "rfx_napi.node")
+    if node and os.path.exists(addon):
+        js = "const a=require(%r);console.log(JSON.stringify(%s.map(c=>Array.from({length:c[1]},(_,r)=>a.splitRows(c[0],c[1],r)))))" % (
+            os.path.abspath(addon), json.dumps(cases))
+        got = json.loads(subprocess.check_output([node, "-e", js], text=True))
+        assert got == [[list(t) for t in tiling.split_rows(Hh, n)] for Hh, n in cases]
+
+
 def test_split_rows_even_boundaries_and_halo():
     from rfx_amd import tiling
     for Hh, n in ((2160, 8), (2160, 4), (1080, 8), (90, 4), (4320, 8)):

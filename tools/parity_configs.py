@@ -26,6 +26,7 @@ ap.add_argument("--refine", type=int, default=5)
 ap.add_argument("--it", type=int, default=1)
 ap.add_argument("--frames", type=int, default=2)
 ap.add_argument("--out", default=None)
+ap.add_argument("--compare-from", type=int, default=0, help="frames before this one only advance the reference chain (no comparison)")
 ap.add_argument("--perturb", type=int, default=16, help="perturbed oracle re-evaluations per stage (of the out-of-tolerance + sampled pixels)")
 a = ap.parse_args()
 W, H = [int(v) for v in a.size.split("x")]
@@ -50,7 +51,7 @@ def frame_fn(i):
     return frames[i]
 
 
-reports = S.run(S.HipStages if a.impl == "hip" else S.OracleStages, W, H, a.steps, a.refine, a.it, a.frames, load_blue_noise_table(), frame_fn, log=log, n_perturb=a.perturb)
+reports = S.run(S.HipStages if a.impl == "hip" else S.OracleStages, W, H, a.steps, a.refine, a.it, a.frames, load_blue_noise_table(), frame_fn, log=log, n_perturb=a.perturb, compare_from=a.compare_from)
 log("# summary (all frames)   kind: pixels, Linf(all), Linf(in-tol), out-of-tol, explained, UNEXPLAINED, at-risk")
 for kind, v in S.summarize(reports).items():
     log("#   %-18s %10d  %.3e  %.3e  %7d  %7d  %7d  %8d" % ((kind,) + tuple(v)))
