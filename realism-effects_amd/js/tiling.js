@@ -26,19 +26,27 @@ function requiredHalo(radius, maxAbsVelocityY, frameHeight, frameWidth) {
 class TiledRenderer {
 	// `uniqueId`: the 128-byte Buffer of commUniqueId() made by rank 0 and handed to every process
 	constructor(width, height, rank, nranks, haloRows, uniqueId, options) {
+		options = options || {}
 		const t = splitRows(height, nranks, rank)
 		this.rank = rank
 		this.nranks = nranks
-		this.inner = new Renderer(width, height, Object.assign({}, options || {}, { tileY0: t[0], tileRows: t[1], haloRows: nranks > 1 ? haloRows : 0 }))
+		// options.inner / options.comm: a stand-in tile renderer and exchange layer (tests record the call sequence without a GPU)
+		this.inner = options.inner || new Renderer(width, height, Object.assign({}, options, { tileY0: t[0], tileRows: t[1], haloRows: nranks > 1 ? haloRows : 0 }))
+		this._comm = options.comm || {
+			haloExchange: (tex, up, down) => addon.haloExchange(this.inner._h, tex, up, down),
+			allgatherHistory: tex => addon.allgatherHistory(this.inner._h, tex),
+			commWait: () => addon.commWait(this.inner._h)
+		}
 		this.width = width
 		this.height = height
 		this.tileY0 = t[0]
 		this.tileRows = t[1]
-		this.haloRows = this.inner.haloRows
-		addon.commInit(this.inner._h, uniqueId, rank, nranks)
+		this.haloRows = options.inner ? (nranks > 1 ? haloRows : 0) : this.inner.haloRows
+		if (!options.comm) addon.commInit(this.inner._h, uniqueId, rank, nranks)
 		this.gatherHistoryRGB = nranks > 1
 		this.overlapHistoryGather = nranks > 1
 		this._haloPending = false
+		this._gatherPending = false
 		this.exchangeCount = 0
 		// everything that is not intercepted below goes to the tile's renderer
 		return new Proxy(this, {
@@ -57,13 +65,14 @@ class TiledRenderer {
 	}
 	exchange(texs) {
 		if (this.nranks === 1 || this.haloRows === 0) return
-		for (const tex of texs) addon.haloExchange(this.inner._h, tex, this._up(), this._down())
+		for (const tex of texs) this._comm.haloExchange(tex, this._up(), this._down())
 		this._haloPending = true
 		this.exchangeCount++
 	}
 	commWait() {
-		addon.commWait(this.inner._h)
+		if (this._haloPending || this._gatherPending) this._comm.commWait()
 		this._haloPending = false
+		this._gatherPending = false
 	}
 	// hooks called by effects.js
 	afterTemporalPass() {
@@ -73,7 +82,10 @@ class TiledRenderer {
 		this.exchange(uniforms.writeToB ? [TEX.DENOISE_B0, TEX.DENOISE_B1] : [TEX.DENOISE_A0, TEX.DENOISE_A1])
 	}
 	afterComposePass() {
-		if (this.nranks > 1) addon.allgatherHistory(this.inner._h, TEX.COMPOSE_RGB)
+		if (this.nranks > 1) {
+			this._comm.allgatherHistory(TEX.COMPOSE_RGB)
+			this._gatherPending = true
+		}
 	}
 	afterCopyFramebuffer(tex) {
 		this.exchange([tex])

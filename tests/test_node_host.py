@@ -294,3 +294,108 @@ def test_node_host_drives_the_gpu_bit_identically(tmp_path):
         js = np.fromfile(os.path.join(out, "traa.bin"), np.float32).reshape(py.shape)
         assert np.array_equal(py.view(np.uint8), js.view(np.uint8)), mode
         ctx.close()
+
+
+TILED_RECORDER = r"""
+const fx = require(process.argv[1] + "/effects")
+const { TiledRenderer } = require(process.argv[1] + "/tiling")
+const cam = JSON.parse(process.argv[2])
+const calls = []
+const inner = {
+  uploadPlane() {}, heldRows() { return [0, 0] },
+  setRowWindow(a, b) { calls.push(["window", a, b]) },
+  ssgiMarch(u) { calls.push(["ssgi", u.historySource]) }, ssgiTrace(u) { calls.push(["trace", u.historySource]) }, ssgiShade(u) { calls.push(["shade", u.historySource]) },
+  temporalReproject(u) { calls.push(["temporal"]) }, poissonDenoise(u) { calls.push(["denoise", u.writeToB]) },
+  compose(u) { calls.push(["compose", u.writeHistoryRGB]) }, sync() { calls.push(["sync"]) }
+}
+const comm = { haloExchange(tex, up, down) { calls.push(["halo", tex, up, down]) }, allgatherHistory(tex) { calls.push(["gather", tex]) }, commWait() { calls.push(["wait"]) } }
+const out = {}
+for (const rn of [[0, 3], [1, 3], [2, 3], [0, 1]]) {
+  calls.length = 0
+  const r = new TiledRenderer(96, 66, rn[0], rn[1], 6, null, { inner, comm })
+  const e = new fx.SSGIEffect(null, { frame: {} }, cam, { width: 96, height: 66 }, { ssgi: 10, denoise: 20 })
+  e.update(r, null); e.update(r, null); r.sync()
+  out[rn.join("/")] = { calls: calls.slice(), tile: [r.tileY0, r.tileRows], exchanges: r.exchangeCount }
+}
+console.log(JSON.stringify(out))
+"""
+
+
+def test_node_tiled_renderer_call_sequence_equals_python(tmp_path):
+    """js/tiling.js TiledRenderer (the Node multi-process host's exchange protocol over the C ABI's RCCL entry points) against
+    rfx_amd.tiling.CommTiledRenderer, both on recording stand-ins for the tile renderer and the exchange layer: the same draws, windows
+    (interior first, then the boundary strips), halo exchanges, gathers and waits, in the same order, for a bottom, a middle and a top
+    rank of three and for a single rank."""
+    from rfx_amd import tiling
+    from rfx_amd.scene import synthetic_frame
+    f = synthetic_frame(32, 16, 0)
+    cam_json = json.dumps({k: [float(x) for x in np.asarray(getattr(f.camera, k)).ravel()] for k in
+                           ("projectionMatrix", "projectionMatrixInverse", "matrixWorld", "matrixWorldInverse", "position", "quaternion")} |
+                          dict(near=f.camera.near, far=f.camera.far))
+    js = json.loads(subprocess.check_output([node, "-e", TILED_RECORDER, JS, cam_json], text=True).strip().splitlines()[-1])
+
+    W, H, halo = 96, 66, 6
+
+    class RecCtx:
+        def __init__(self, rank, world):
+            self.W, self.H = W, H
+            self.tile_y0, self.tile_rows = tiling.split_rows(H, world)[rank]
+            self.halo = halo if world > 1 else 0
+            self.calls = []
+
+        def held_rows(self, tex):
+            return (0, 0)
+
+        def upload(self, *a, **k):
+            pass
+
+        def comm_init(self, *a):
+            pass
+
+        def set_row_window(self, a=0, b=0):
+            self.calls.append(["window", a, b])
+
+        def ssgi_march(self, p):
+            self.calls.append(["ssgi", p.historySource])
+
+        def ssgi_trace(self, p):
+            self.calls.append(["trace", p.historySource])
+
+        def ssgi_shade(self, p):
+            self.calls.append(["shade", p.historySource])
+
+        def temporal_reproject(self, p):
+            self.calls.append(["temporal"])
+
+        def poisson_denoise(self, p):
+            self.calls.append(["denoise", p.writeToB])
+
+        def compose(self, p):
+            self.calls.append(["compose", p.writeHistoryRGB])
+
+        def halo_exchange(self, tex, up, down):
+            self.calls.append(["halo", tex, up, down])
+
+        def allgather_history(self, tex):
+            self.calls.append(["gather", tex])
+
+        def comm_wait(self):
+            self.calls.append(["wait"])
+
+        def sync(self):
+            self.calls.append(["sync"])
+
+    for rank, world in ((0, 3), (1, 3), (2, 3), (0, 1)):
+        ctx = RecCtx(rank, world)
+        r = tiling.CommTiledRenderer(ctx, rank, world, b"\0" * 128)
+        scene = types.SimpleNamespace(frame=types.SimpleNamespace(depth=np.zeros((0, W), np.float32), gbuffer=np.zeros((0, W, 4), np.uint32),
+                                                                  velocity=np.zeros((0, W, 4), np.uint32), direct=np.zeros((0, W, 4), np.float32),
+                                                                  camera=f.camera, aov=None))
+        fx = effect.SSGIEffect(None, scene, f.camera, dict(width=W, height=H), seeds=dict(ssgi=10, denoise=20))
+        fx.update(r, None)
+        fx.update(r, None)
+        r.sync()
+        got = js["%d/%d" % (rank, world)]
+        assert got["tile"] == [ctx.tile_y0, ctx.tile_rows]
+        assert got["calls"] == json.loads(json.dumps(ctx.calls)), (rank, world, got["calls"][:12], ctx.calls[:12])
+        assert got["exchanges"] == r.exchange_count
