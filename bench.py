@@ -115,7 +115,7 @@ def ctl_device(dist, dev):
     return dev if (dist is not None and dist.get_backend() == "nccl") else "cpu"
 
 
-def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, refine, iterations, use_c=False):
+def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, refine, iterations, use_c=False, group=None):
     """Dump + context + effect of one benchmark case on this rank: frame W x H cut into `tiles` (one per rank).  Returns a dict with
     the step function, the context and what the JSON line reports about the case."""
     import torch
@@ -159,6 +159,12 @@ def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, 
             # the exchanges behind the C ABI: RCCL Send/Recv + all-gather on the context's own exchange stream (rfx.h "row-tiled runs")
             renderer = tiling.CommTiledRenderer(ctx, rank, world, uid)
             exchange = "C ABI: rfx_halo_exchange / rfx_allgather_history (RCCL, own stream, overlapped)"
+            bad = [verify_exchange(ctx, rank, world)]
+            flags = [None] * world
+            dist.all_gather_object(flags, bad[0])  # every rank must take the same path
+            if any(f is not None for f in flags):
+                ctx.close()
+                raise RuntimeError("exchange pre-flight check failed: %s" % [f for f in flags if f is not None][:2])
         else:
             # torch.distributed transport (gloo in the one-GPU functional mode, or the NCCL backend): kernels, collectives and torch's
             # copies share ONE created stream — handle 0 would mean "the context's own stream" to rfx_set_stream
@@ -166,13 +172,51 @@ def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, 
             torch.cuda.set_stream(stream)
             ctx.set_stream(stream.cuda_stream)
             ctx.uses_torch_stream = not one_gpu  # gloo stages device tensors through the host: drain the stream around every exchange there
-            renderer = tiling.TiledRenderer(ctx, tiling.bind_torch_buffers(ctx, dev), rank, world)
+            renderer = tiling.TiledRenderer(ctx, tiling.bind_torch_buffers(ctx, dev), rank, world, group=group)
             exchange = "torch.distributed (%s)" % ("gloo, one-GPU functional mode" if one_gpu else "nccl = RCCL")
     # static: the same dump every step, uploaded once before the timed region (the metric is quoted with inputs resident in HBM)
     frame = types.SimpleNamespace(depth=depth_full, gbuffer=band.gbuffer, velocity=band.velocity, direct=band.direct, camera=band.camera, static=True)
     scene = types.SimpleNamespace(frame=frame)
     fx = SSGIEffect(None, scene, band.camera, opts, seeds=dict(ssgi=1, denoise=2), half_store_rtz=True)
     return dict(ctx=ctx, renderer=renderer, fx=fx, frame=frame, halo=halo, rows=rows, W=W, H=H, exchange=exchange, steps=steps, refine=refine, it=iterations)
+
+
+def verify_exchange(ctx, rank, world):
+    """Pre-flight check of the C ABI's RCCL exchanges on this communicator, with known patterns (nothing the frame loop needs survives
+    it): every rank fills ITS tile rows of a K3 target with rank + 1, exchanges halos, and must find its upper / lower halo rows holding
+    the neighbour's value; then the same for the all-gather of the composed-GI twin.  Returns None, or a description of what is wrong."""
+    from rfx_amd import abi as A
+    y0, rows, h, H, W = ctx.tile_y0, ctx.tile_rows, ctx.halo, ctx.H, ctx.W
+    up, down = (rank + 1 if rank + 1 < world else -1), rank - 1
+    r0, n = ctx.held_rows(A.TEX_DENOISE_A0)
+    band = np.zeros((n, W, 4), np.uint16)
+    band[y0 - r0:y0 - r0 + rows] = rank + 1
+    ctx.upload(A.TEX_DENOISE_A0, band, r0, n)
+    ctx.halo_exchange(A.TEX_DENOISE_A0, up, down)
+    ctx.comm_wait()
+    ctx.sync()
+    got = ctx.download(A.TEX_DENOISE_A0, r0, n)
+    err = None
+    if up >= 0 and not (got[y0 - r0 + rows:y0 - r0 + rows + h] == rank + 2).all():
+        err = "halo rows above the tile do not hold rank %d's rows" % up
+    if down >= 0 and not (got[y0 - r0 - h:y0 - r0] == rank).all():
+        err = "halo rows below the tile do not hold rank %d's rows" % down
+    if not (got[y0 - r0:y0 - r0 + rows] == rank + 1).all():
+        err = "the tile's own rows were overwritten"
+    full = np.zeros((H, W, 3), np.float32)
+    full[y0:y0 + rows] = rank + 1
+    ctx.upload(A.TEX_COMPOSE_RGB, full, 0, H)
+    ctx.allgather_history(A.TEX_COMPOSE_RGB)
+    ctx.comm_wait()
+    ctx.sync()
+    g = ctx.download(A.TEX_COMPOSE_RGB, 0, H)
+    for k, (ky0, kn) in enumerate(tiling.split_rows(H, world)):
+        if not (g[ky0:ky0 + kn] == k + 1).all():
+            err = "gathered rows of rank %d are wrong" % k
+    ctx.clear(A.TEX_DENOISE_A0)
+    ctx.clear(A.TEX_COMPOSE_RGB)
+    ctx.sync()
+    return err
 
 
 def time_case(case, dist, n_steps, n_warmup, dev="cpu"):
@@ -287,7 +331,18 @@ def main():
     # ---- headline: N = 1 -> BASELINE configs[2] (the 4K frame on one GPU); N > 1 -> configs[3]: THE SAME 4K frame cut into N row
     # tiles (strong scaling: 1080 / 540 / 270 rows per GPU at N = 2 / 4 / 8), RCCL halo exchange + composed-GI all-gather
     tiles = [(0, H1)] if world == 1 else tiling.split_rows(H1, world)
-    case = build_case(world, rank, local_rank, dev, dist, one_gpu, W1, H1, tiles, 20, 5, 1, use_c=use_c)
+    group, fallback_note = None, None
+    try:
+        case = build_case(world, rank, local_rank, dev, dist, one_gpu, W1, H1, tiles, 20, 5, 1, use_c=use_c)
+    except RuntimeError as e:
+        if not (use_c and "pre-flight" in str(e)):
+            raise
+        # every rank saw the same verdict (all_gather_object): continue on the torch.distributed NCCL (= RCCL) transport, and say so
+        fallback_note = str(e)[:200]
+        log("[rank %d] %s -> torch.distributed NCCL transport" % (rank, fallback_note))
+        use_c = False
+        group = dist.new_group(backend="nccl")
+        case = build_case(world, rank, local_rank, dev, dist, one_gpu, W1, H1, tiles, 20, 5, 1, use_c=False, group=group)
     dt = time_case(case, dist, args.steps, args.warmup, dev)
     ctx = case["ctx"]
     ms_per_step = dt / args.steps * 1e3
@@ -313,14 +368,14 @@ def main():
             Ht = int(W1 * H1 / Ww) & ~1
             wtiles = [(r * Ht, Ht) for r in range(world)]
             if wtiles == tiling.split_rows(Ht * world, world):
-                wcase = build_case(world, rank, local_rank, dev, dist, one_gpu, Ww, Ht * world, wtiles, 20, 5, 1, use_c=use_c)
+                wcase = build_case(world, rank, local_rank, dev, dist, one_gpu, Ww, Ht * world, wtiles, 20, 5, 1, use_c=use_c, group=group)
                 wdt = time_case(wcase, dist, args.steps, args.warmup, dev)
                 extras["weak_scaling"] = {"frame": "%dx%d" % (Ww, Ht * world), "tile_rows": Ht, "halo_rows": wcase["halo"], "ms_per_step": round(wdt / args.steps * 1e3, 4),
                                           "value": round(Ww * Ht * world * args.steps / wdt / 1e6, 2), "unit": "Mpixels/s",
                                           "halo_violations": wcase["ctx"].halo_violations()}
                 wcase["ctx"].close()
             # (b) BASELINE configs[4]: 8K, steps 40, denoiseIterations 3, row-tiled (the 16-frame sequence re-renders one dumped frame)
-            c4 = build_case(world, rank, local_rank, dev, dist, one_gpu, 7680, 4320, tiling.split_rows(4320, world), 40, 5, 3, use_c=use_c)
+            c4 = build_case(world, rank, local_rank, dev, dist, one_gpu, 7680, 4320, tiling.split_rows(4320, world), 40, 5, 3, use_c=use_c, group=group)
             n4 = max(4, min(args.steps, 16))
             d4 = time_case(c4, dist, n4, 2, dev)
             extras["configs4_8k"] = {"frame": "7680x4320", "steps": 40, "refineSteps": 5, "denoiseIterations": 3, "frames_timed": n4, "halo_rows": c4["halo"],
@@ -374,6 +429,10 @@ def main():
                                           "frac": round(gen / chain_ms, 4),
                                           "note": "[fast, generic] issue-bound time: VALU + transcendental instructions per wave (%s/pmc_sq_l2.csv, git %s) priced at the issue rates measured by tools/microbench/valu_rates.hip — fast: every plain VALU at the v_add/v_mul rate (1.08 ns per wave64 instruction per SIMD), generic: at the rate of cvt/min/max/med3/shift/select (1.77 ns), transcendentals 3.4 ns; frac = generic / measured (the loops' static mix sits at the generic end)" % (
                                               PROFILE_DIR, prof.get("git_commit", "?"))}
+        if world > 1:
+            out["config"]["exchange_verified"] = bool(use_c)  # the C-ABI exchanges passed their pre-flight pattern check on every rank
+            if fallback_note:
+                out["config"]["exchange_fallback"] = fallback_note
         out.update(extras)
         if args.checksum:
             out["compose_sha1"], out["frame_rows"] = compose_sha1, H1
