@@ -146,10 +146,7 @@ int rfx_comm_unique_id(void *id128) {
 int rfx_comm_init(rfx_ctx *c, const void *id128, int rank, int nranks) {
     if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return RFX_EINVAL;
     Rccl *r = rccl();
-    if (!r) {
-        static Rccl probe;  // rccl() keeps the reason
-        return fail(c, RFX_EUNSUPPORTED, "rfx_comm_init: RCCL (librccl.so.1) cannot be loaded on this host");
-    }
+    if (!r) return fail(c, RFX_EUNSUPPORTED, "rfx_comm_init: RCCL (librccl.so.1) cannot be loaded on this host");
     if (c->comm) return fail(c, RFX_ESTATE, "rfx_comm_init: this context already has a communicator");
     int y0 = 0, rows = 0;
     if (rfx_split_rows(c->H, nranks, rank, &y0, &rows) != RFX_OK || y0 != c->tile_y0 || rows != c->tile_rows)
@@ -222,7 +219,7 @@ int rfx_allgather_history(rfx_ctx *c, rfx_tex id, void *nccl_comm) {
     if (!r) return fail(c, RFX_EUNSUPPORTED, "rfx_allgather_history: RCCL cannot be loaded on this host");
     NcclComm comm = nccl_comm ? nccl_comm : c->comm;
     if (!comm) return fail(c, RFX_ESTATE, "rfx_allgather_history: no communicator (rfx_comm_init, or pass one)");
-    const int n = c->comm_nranks, rank = c->comm_rank;
+    const int n = c->comm_nranks;
     if (nccl_comm && !c->comm) return fail(c, RFX_ESTATE, "rfx_allgather_history: rank and size come from rfx_comm_init");
     int rc = ensure_streams(c);
     if (rc) return rc;
@@ -249,7 +246,6 @@ int rfx_allgather_history(rfx_ctx *c, rfx_tex id, void *nccl_comm) {
         if (e) return nccl_fail(c, "rfx_allgather_history: ncclBroadcast", e);
         if (e2) return nccl_fail(c, "rfx_allgather_history: ncclGroupEnd", e2);
     }
-    (void)rank;
     return comm_end(c);
 }
 
