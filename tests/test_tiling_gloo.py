@@ -99,6 +99,95 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
+def _comm_worker(rank, world, port, outdir):
+    """CommTiledRenderer (the protocol over the C ABI's exchange entry points) on a stand-in context whose halo_exchange /
+    allgather_history are executed LAZILY, at comm_wait, over gloo: the adversarial schedule — rows arrive as late as the protocol
+    allows and are read from the sender's buffers as late as it allows.  A draw that touched halo rows before its wait, or rewrote
+    rows that were still to be sent, would change the result."""
+    sys.path.insert(0, HERE)
+    import conftest  # noqa: F401
+    from oracle_renderer import OracleRenderer
+    from rfx_amd import abi, tiling
+    from rfx_amd.scene import synthetic_frame
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class LazyCommCtx(OracleRenderer):
+        def __init__(self, *a):
+            super().__init__(*a)
+            self.queue, self.waits = [], 0
+
+        def comm_init(self, uid, r, n):
+            assert tiling.split_rows(self.H, n)[r] == (self.tile_y0, self.tile_rows)
+
+        def halo_exchange(self, tex, up, down):
+            self.queue.append(("halo", tex, up, down))
+
+        def allgather_history(self, tex):
+            self.queue.append(("gather", tex))
+
+        def comm_wait(self):
+            self.waits += 1
+            q, self.queue = self.queue, []
+            for op in q:  # same order on every rank
+                if op[0] == "halo":
+                    _, tex, up, down = op
+                    t = torch.from_numpy(self.tex[tex])
+                    y0, y1, h = self.tile_y0, self.tile_y0 + self.tile_rows, self.halo
+                    ops = []
+                    if up >= 0:
+                        ops += [dist.P2POp(dist.isend, t[y1 - h:y1].contiguous(), up), dist.P2POp(dist.irecv, t[y1:y1 + h], up)]
+                    if down >= 0:
+                        ops += [dist.P2POp(dist.isend, t[y0:y0 + h].contiguous(), down), dist.P2POp(dist.irecv, t[y0 - h:y0], down)]
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                else:
+                    t = torch.from_numpy(self.tex[op[1]])
+                    for r, (ty0, tn) in enumerate(tiling.split_rows(self.H, dist.get_world_size())):
+                        dist.broadcast(t[ty0:ty0 + tn], src=r)
+
+    frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
+    vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
+    halo = tiling.required_halo(3.0, vmax, H, W)
+    y0, rows = tiling.split_rows(H, world)[rank]
+    inner = LazyCommCtx(W, H, y0, rows, halo)
+    r = tiling.CommTiledRenderer(inner, rank, world, b"\0" * 128)
+    _chain(r, types.SimpleNamespace(frame=None), frames[0].camera, frames)
+    r.sync()
+    assert r.exchange_count == FRAMES * 3 and inner.waits >= FRAMES * 4 and not inner.queue
+    np.savez(os.path.join(outdir, "comm%d.npz" % rank), y0=y0, rows=rows,
+             **{abi.TEX_NAMES[t]: inner.tex[t][y0:y0 + rows] for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0,
+                                                                     abi.TEX_DENOISE_B1)},
+             compose_tile=inner.tex[abi.TEX_COMPOSE][y0:y0 + rows], compose_rgb_full=inner.tex[abi.TEX_COMPOSE_RGB])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_comm_tiled_protocol_is_bit_identical_under_the_latest_possible_delivery(tmp_path, world):
+    import socket
+    from oracle_renderer import OracleRenderer
+    from rfx_amd import abi
+    from rfx_amd.scene import synthetic_frame
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_comm_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
+    ref = OracleRenderer(W, H)
+    _chain(ref, types.SimpleNamespace(frame=None), frames[0].camera, frames)
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), "comm%d.npz" % rank))
+        y0, rows = int(z["y0"]), int(z["rows"])
+        for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1):
+            assert np.array_equal(z[abi.TEX_NAMES[t]], ref.tex[t][y0:y0 + rows]), "rank %d %s differs" % (rank, abi.TEX_NAMES[t])
+        assert np.array_equal(z["compose_rgb_full"], ref.tex[abi.TEX_COMPOSE][..., :3]), "rank %d gathered composed GI differs" % rank
+        assert np.array_equal(z["compose_tile"], ref.tex[abi.TEX_COMPOSE][y0:y0 + rows])
+
+
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("world", [2, 3])  # 3: a middle rank with two neighbours, a ragged last tile
 def test_tiled_chain_is_bit_identical(tmp_path, world):
