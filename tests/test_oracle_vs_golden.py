@@ -29,6 +29,23 @@ def stage_params(g, fi, keep):
     return sp, tp, dp, cp
 
 
+def assert_strict(name, rerun, want, half, max_fraction=0.01):
+    """Round-2 metric on one stage: `rerun()` evaluates the oracle stage (it is called again under the margin / perturbation machinery),
+    `want` is the reference's output.  Every out-of-tolerance pixel must be proven unstable by the oracle (see _unstable below)."""
+    from parity import strict
+
+    def fl(outs):
+        outs = outs if isinstance(outs, (list, tuple)) else [outs]
+        return np.concatenate([O.half_bits_to_float(np.ascontiguousarray(o).view(np.uint16)) if o.dtype in (np.uint16, np.uint32) else o for o in outs], axis=-1)
+    got, ref = fl(rerun()), fl(want)
+    H, W = got.shape[:2]
+    r = strict(name, got, ref, explainable=_unstable(rerun, half, H, W), half=half)
+    print(r.line())
+    assert r.unexplained == 0, r.line()
+    assert r.bad <= max_fraction * r.pixels, r.line()
+    return r
+
+
 @pytest.mark.parametrize("name", G.GOLDENS)
 def test_stagewise(name, blue_noise):
     """Every pass fed with the GOLDEN outputs of the previous passes."""
@@ -149,8 +166,15 @@ def test_stagewise_ssr_mode(blue_noise):
         # (raw fp32 output here: no half rounding to hide last-ulp transcendental differences, so no bit-identity claim)
         B0 = np.ascontiguousarray(g[kp + "B0"]) if fi else z16
         T0 = np.ascontiguousarray(g[kp + "temporal0"]) if fi else np.zeros((H, W, 4), np.float32)
+        T_init = T0.copy()
         O.temporal(np.ascontiguousarray(g[k + "ssgi"]), f.velocity, B0, B0, tp, T0, None)
         assert_close("ssr temporal0 f%d" % fi, T0, g[k + "temporal0"], FLIP["temporal"])
+
+        def k2(f=f, k=k, B0=B0, tp=tp, T_init=T_init):
+            t = T_init.copy()
+            O.temporal(np.ascontiguousarray(g[k + "ssgi"]), f.velocity, B0, B0, tp, t, None)
+            return t
+        assert_strict("ssr K2 f%d" % fi, k2, g[k + "temporal0"], False)
         A0 = np.ascontiguousarray(g[kp + "A0"]) if fi else z16.copy()
         dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = int(g[k + "denoise_index"][0]), 1, 0
         t0 = np.ascontiguousarray(g[k + "temporal0"])
@@ -354,6 +378,7 @@ def test_env_map_stagewise(name, blue_noise):
         oa, ob = O.unpack_ssgi(o)
         assert_close(name + " ssgi.diffuse f%d" % fi, oa, ga, FLIP["ssgi"])
         assert_close(name + " ssgi.specular f%d" % fi, ob, gb, FLIP["ssgi"])
+        assert_strict(name + " K1 env f%d" % fi, lambda: O.ssgi(f.depth, f.gbuffer, f.direct, hist, blue_noise, sp, env=env), g[k + "ssgi"], True)
         assert (o == g[k + "ssgi"]).all(axis=-1).mean() > 0.99
         # the environment really contributes: the same draw without it differs on a good part of the frame
         sp.useEnvMap = 0
@@ -486,15 +511,29 @@ def test_orthographic_camera_stagewise(blue_noise):
         oa, ob = O.unpack_ssgi(o)
         assert_close("ortho ssgi.diffuse f%d" % fi, oa, ga, FLIP["ssgi"])
         assert_close("ortho ssgi.specular f%d" % fi, ob, gb, FLIP["ssgi"])
+        assert_strict("ortho K1 f%d" % fi, lambda: O.ssgi(f.depth, f.gbuffer, f.direct, hist, blue_noise, sp), g[k + "ssgi"], True)
         assert (o == g[k + "ssgi"]).all(axis=-1).mean() > 0.99
         B = [np.ascontiguousarray(g[kp + "B%d" % j]) if fi else z16 for j in range(2)]
         T = [np.ascontiguousarray(g[kp + "temporal%d" % j]) if fi else zf.copy() for j in range(2)]
         O.temporal(np.ascontiguousarray(g[k + "ssgi"]), f.velocity, B[0], B[1], tp, T[0], T[1])
         for j in range(2):
             assert_close("ortho temporal%d f%d" % (j, fi), T[j], g[k + "temporal%d" % j], FLIP["temporal"])
+        T0 = [np.ascontiguousarray(g[kp + "temporal%d" % j]) if fi else zf.copy() for j in range(2)]
+
+        def k2():
+            Tn = [t.copy() for t in T0]
+            O.temporal(np.ascontiguousarray(g[k + "ssgi"]), f.velocity, B[0], B[1], tp, Tn[0], Tn[1])
+            return Tn
+        assert_strict("ortho K2 f%d" % fi, k2, [g[k + "temporal0"], g[k + "temporal1"]], False)
         comp = hist.copy()
         O.compose(f.depth, f.gbuffer, np.ascontiguousarray(g[k + "B0"]), np.ascontiguousarray(g[k + "B1"]), cp, comp)
         assert_close("ortho compose f%d" % fi, comp, g[k + "compose"], FLIP["compose"])
+
+        def k4():
+            c4 = hist.copy()
+            O.compose(f.depth, f.gbuffer, np.ascontiguousarray(g[k + "B0"]), np.ascontiguousarray(g[k + "B1"]), cp, c4)
+            return c4
+        assert_strict("ortho K4 f%d" % fi, k4, g[k + "compose"], False)
         fp = abi.FinalParams(camera=abi.Camera.from_scene(f.camera), fogMode=2, fogDensity=0.05)
         fp.fogColor[:] = [0.5, 0.6, 0.7]
         assert_close("ortho final fog f%d" % fi, O.final(f.depth, np.ascontiguousarray(g[k + "compose"]), f.direct, fp), g[k + "final_fog2"], 0.0)
@@ -524,6 +563,8 @@ def test_env_map_importance_sampling(blue_noise):
         oa, ob = O.unpack_ssgi(o)
         assert_close("envmis ssgi.diffuse f%d" % fi, oa, ga, FLIP["ssgi"] * 2)
         assert_close("envmis ssgi.specular f%d" % fi, ob, gb, FLIP["ssgi"] * 2)
+        sp.importanceSampling = 1
+        assert_strict("envmis K1 f%d" % fi, lambda: O.ssgi(f.depth, f.gbuffer, f.direct, hist, blue_noise, sp, env=env), g[k + "ssgi"], True)
         assert (o == g[k + "ssgi"]).all(axis=-1).mean() > 0.98
         # MIS changes a good part of the frame with respect to plain environment lighting
         sp.importanceSampling = 0
