@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 12
+#define RFX_ABI_VERSION 13
 
 enum {
     RFX_OK = 0,
@@ -198,6 +198,17 @@ int rfx_set_stream(rfx_ctx *, void *hip_stream);
  * interior of its tile while the halo rows of the input are still being exchanged, then the two boundary strips (rfx_amd/tiling.py).
  * Draws whose window is empty return RFX_OK without launching.  Ignored by rfx_ssgi_* with resolutionScale != 1 (whole-frame only). */
 int rfx_set_row_window(rfx_ctx *, int y0, int y1);
+/* Which vUv the draws' fragments see (every full-screen pass of the reference reads its inputs at the interpolated varying vUv,
+ * src/utils/shader/basic.vert; e.g. ssgi.frag:107, temporal_reproject.frag:118, poisson_denoise.frag:128, DenoiserComposePass.js:58).
+ *   RFX_UV_IDEAL         (default) (i + 0.5) / n, correctly rounded: the value the shader authors mean.
+ *   RFX_UV_REFERENCE_GL  the value the rasteriser of the reference's GL (Mesa llvmpipe, the oracle of the parity tests) interpolates, bit
+ *                        for bit: three's full-screen triangle is clipped into two triangles along the frame diagonal, each with its own
+ *                        fp32 plane equations (up to 2^-24 from the ideal value, different on either side of the diagonal).  With it the
+ *                        NEAREST taps of the denoiser and every LINEAR fetch at vUv land where the reference's land: what is left between
+ *                        the two implementations is transcendental rounding alone.
+ * Applies to every following draw; row-tiled contexts evaluate the whole frame's planes. */
+enum { RFX_UV_IDEAL = 0, RFX_UV_REFERENCE_GL = 1 };
+int rfx_set_uv_model(rfx_ctx *, int model);
 
 /* ---- textures.  `row0`/`rows` are FRAME rows of the band being transferred; the band must lie
  * inside the rows the context holds: [max(0,tile_y0-halo), min(H,tile_y0+tile_rows+halo)).

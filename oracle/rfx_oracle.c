@@ -63,8 +63,42 @@ static inline float pert_ang(float v) { return (g_pert_seed && g_pert_state) ? v
  * 2^-23.  At 8K that is ~1e-3 texel: a LINEAR fetch of a texture whose neighbouring texels differ by ~1 (K2's history AGE channel from the
  * third frame on, when ages exceed 1) moves by ~1e-3 — the absolute tolerance sits at the resolution of an fp32 texture coordinate there. */
 #define UV_ABS_ERR 1.1920929e-7f
-static inline float pert_uv(float v) { return (g_pert_seed && g_pert_state) ? v + pert_sign() * UV_ABS_ERR : v; }
+/* ... unless the fragments see the reference GL's own vUv (rfxo_set_uv_model(1), frag_u / frag_v below): then nothing is left to bound */
+static int g_uv_model = 0;
+static inline float uv_err(void) { return g_uv_model ? 0.0f : UV_ABS_ERR; }
+static inline float pert_uv(float v) { return (g_pert_seed && g_pert_state) ? v + pert_sign() * uv_err() : v; }
+/* Which vUv a fragment sees.  Model 0: (i + 0.5) / n, correctly rounded — what the HIP kernels compute.  Model 1: the reference GL's own
+ * value, bit for bit (oracle/glref/probes/probe_varying.py: exact on every fragment of every size tried, 55x97 ... 7680x4320).  three's
+ * full-screen triangle (-1,-1) (3,-1) (-1,3) leaves the guard band (|x| <= 2w), so Mesa's draw module clips it to the viewport: two
+ * triangles split along the diagonal (0,0)-(W,H), each with its own plane equations (lp_setup_coef: a0 = a(v0) - (dadx * x0c + dady * y0c),
+ * dadx = H * (1 / (W * H)), every product rounded) and provoking vertices (0,H) above the diagonal and (W,H) below it; the fragment then
+ * evaluates fma(dady, y, fma(dadx, x, a0)) on the integer pixel position (lp_bld_interp, pixel offset folded into a0).  The first has
+ * a0 = dadx / 2 for u, the second 1 - dadx * (W - 0.5); v's a0 = 1 - dady * (H - 0.5) in both.  A fragment centre on the diagonal belongs
+ * to the lower triangle. */
+void rfxo_set_uv_model(int m) { g_uv_model = m; }
+static inline float frag_u(int x, int y, int W, int H) {
+    if (!g_uv_model) return ((float)x + 0.5f) / (float)W;
+    float ooa = 1.0f / ((float)W * (float)H), dudx = (float)H * ooa;
+    int upper = (int64_t)(2 * y + 1) * W > (int64_t)(2 * x + 1) * H;
+    float far_side = dudx * ((float)W - 0.5f);
+    float a0 = upper ? 0.5f * dudx : 1.0f - far_side;
+    return fmaf(dudx, (float)x, a0);
+}
+static inline float frag_v(int y, int W, int H) {
+    if (!g_uv_model) return ((float)y + 0.5f) / (float)H;
+    float ooa = 1.0f / ((float)W * (float)H), dvdy = (float)W * ooa;
+    float far_side = dvdy * ((float)H - 0.5f);
+    return fmaf(dvdy, (float)y, 1.0f - far_side);
+}
 static inline float pert_sqrt(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * 2.4e-7f) : v; }
+/* test probe: the (u, v) planes of a W x H target under a model, interleaved */
+void rfxo_frag_uv(int model, int W, int H, float *out) {
+    int keep = g_uv_model;
+    g_uv_model = model;
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) { out[((size_t)y * W + x) * 2] = frag_u(x, y, W, H); out[((size_t)y * W + x) * 2 + 1] = frag_v(y, W, H); }
+    g_uv_model = keep;
+}
 /* function-like macros are not re-expanded inside their own expansion: (expf)(x) is libm's */
 #define expf(x) pert_rel((expf)(x))
 #define logf(x) pert_rel((logf)(x))
@@ -197,13 +231,12 @@ static inline uint16_t float_to_half_rtz(float f) {
 /* texel-boundary margin of a nearest fetch at coordinate c (texels): the coordinate carries a few ulps of its own magnitude
  * plus whatever its inputs carry (rel_in, relative to the OFFSET that was added to a pixel centre, passed in texels) */
 static _Thread_local float g_fetch_rel = 0.0f, g_fetch_abs = 0.0f; /* what the coordinate's INPUTS carry (set by the caller that knows) */
-static const float g_uv_err = 1.1920929e-7f; /* the rasteriser's vUv error (UV_ABS_ERR below): in texels it scales with the texture size */
 static inline void margin_texel(float c, int size) {
     if (!(c > 0.0f && c < (float)size)) return; /* clamped region: flat */
     float fl = floorf(c), fr = c - fl;
     float dlo = fl >= 1.0f ? fr : 3.0e38f;                      /* the boundary at fl exists unless it is the clamp at 0 */
     float dhi = fl <= (float)(size - 2) ? 1.0f - fr : 3.0e38f;  /* the boundary at fl + 1 exists unless it is the clamp at size */
-    float scale = (4.0f * 1.1920929e-7f + g_fetch_rel) * fabsf(c) + g_fetch_abs + g_uv_err * (float)size;
+    float scale = (4.0f * 1.1920929e-7f + g_fetch_rel) * fabsf(c) + g_fetch_abs + uv_err() * (float)size; /* the rasteriser's vUv error in texels scales with the texture size */
     margin_note(fminf(dlo, dhi) / fmaxf(scale, 1e-30f));
 }
 static inline int nearest_idx(float u, int size) {
@@ -620,14 +653,14 @@ static inline void k1_cdf_uv(const k1_ctx *c, int px, int py, float *u, float *v
          * on the oracle's GL its `random` still holds the zero initialisation, so it contributes the table entry of (0, 0) to the quad's
          * derivatives (GLSL leaves derivatives after a non-uniform return undefined; measured on llvmpipe, reproduced) */
         dims d = {c->W, c->H};
-        float pu = ((float)px + 0.5f) / (float)c->outW, pv = ((float)py + 0.5f) / (float)c->outH;
+        float pu = frag_u(px, py, c->outW, c->outH), pv = frag_v(py, c->outW, c->outH);
         if (px >= c->outW || py >= c->outH || fetch_r32f(c->depth, d, pu, pv) == 1.0f) {
             *v = c->marginal[0];
             *u = c->conditional[(size_t)nearest_idx(*v, c->env_h) * c->env_w + 0];
             return;
         }
     }
-    v4 r = blue_noise(c->blue, px, py, c->p->blueNoiseIndex, ((float)px + 0.5f) / (float)c->outW, ((float)py + 0.5f) / (float)c->outH, dres);
+    v4 r = blue_noise(c->blue, px, py, c->p->blueNoiseIndex, frag_u(px, py, c->outW, c->outH), frag_v(py, c->outW, c->outH), dres);
     *v = c->marginal[nearest_idx(r.x, c->env_h)];
     *u = c->conditional[(size_t)nearest_idx(*v, c->env_h) * c->env_w + nearest_idx(r.y, c->env_w)];
 }
@@ -637,7 +670,7 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
     const float *C = p->camera.matrixWorld, *Vw = p->camera.matrixWorldInverse;
     const float *P = p->camera.projectionMatrix, *Pi = p->camera.projectionMatrixInverse;
     dims d = {c->W, c->H};
-    float u = pert_uv(((float)x + 0.5f) / (float)c->outW), v = pert_uv(((float)y + 0.5f) / (float)c->outH); /* vUv of the (possibly smaller) target */
+    float u = pert_uv(frag_u(x, y, c->outW, c->outH)), v = pert_uv(frag_v(y, c->outW, c->outH)); /* vUv of the (possibly smaller) target */
     float depth = fetch_r32f(c->depth, d, u, v);
     if (depth == 1.0f) { /* :109-113 */
         v4 dl = fetch_f4(c->direct, d, u, v);
@@ -985,7 +1018,7 @@ static inline v4 k2_input_texel(const k2_ctx *c, float u, float v, int idx) {
 static void k2_pixel(const k2_ctx *c, int x, int y, float *out0, float *out1) {
     const rfx_temporal_params *p = c->p;
     const int tc = p->textureCount, lt = p->logTransform;
-    float u = pert_uv(((float)x + 0.5f) / (float)c->W), v = pert_uv(((float)y + 0.5f) / (float)c->H);
+    float u = pert_uv(frag_u(x, y, c->W, c->H)), v = pert_uv(frag_v(y, c->W, c->H));
     float velx, vely, depth; v3 worldNormal;
     k2_vnd(c, u, v, &velx, &vely, &worldNormal, &depth);
     /* getTexels + preprocessInput temporal_reproject.frag:124-145 */
@@ -999,8 +1032,8 @@ static void k2_pixel(const k2_ctx *c, int x, int y, float *out0, float *out1) {
     }
     /* quad partners for fwidth */
     int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
-    float fx0 = ((float)qx0 + 0.5f) / (float)c->W, fx1 = ((float)qx1 + 0.5f) / (float)c->W;
-    float fy0 = ((float)qy0 + 0.5f) / (float)c->H, fy1 = ((float)qy1 + 0.5f) / (float)c->H;
+    float fx0 = frag_u(qx0, y, c->W, c->H), fx1 = frag_u(qx1, y, c->W, c->H);
+    float fy0 = frag_v(qy0, c->W, c->H), fy1 = frag_v(qy1, c->W, c->H);
     float tvx, tvy, dxa, dxb, dya, dyb; v3 nxa, nxb, nya, nyb;
     k2_vnd(c, fx0, v, &tvx, &tvy, &nxa, &dxa); k2_vnd(c, fx1, v, &tvx, &tvy, &nxb, &dxb);
     k2_vnd(c, u, fy0, &tvx, &tvy, &nya, &dya); k2_vnd(c, u, fy1, &tvx, &tvy, &nyb, &dyb);
@@ -1140,11 +1173,11 @@ static void k3_pixel(const k3_ctx *c, int x, int y, uint16_t *out0, uint16_t *ou
     const rfx_denoise_params *p = c->p;
     dims d = {c->W, c->H};
     const int tc = p->textureCount;
-    float u = pert_uv(((float)x + 0.5f) / (float)c->W), v = pert_uv(((float)y + 0.5f) / (float)c->H);
+    float u = pert_uv(frag_u(x, y, c->W, c->H)), v = pert_uv(frag_v(y, c->W, c->H));
     float depth = fetch_r32f(c->depth, d, u, v);
     int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
-    float fx0 = ((float)qx0 + 0.5f) / (float)c->W, fx1 = ((float)qx1 + 0.5f) / (float)c->W;
-    float fy0 = ((float)qy0 + 0.5f) / (float)c->H, fy1 = ((float)qy1 + 0.5f) / (float)c->H;
+    float fx0 = frag_u(qx0, y, c->W, c->H), fx1 = frag_u(qx1, y, c->W, c->H);
+    float fy0 = frag_v(qy0, c->W, c->H), fy1 = frag_v(qy1, c->W, c->H);
     {
         float fw = fabsf(fetch_r32f(c->depth, d, fx1, v) - fetch_r32f(c->depth, d, fx0, v)) +
                    fabsf(fetch_r32f(c->depth, d, u, fy1) - fetch_r32f(c->depth, d, u, fy0));
@@ -1251,11 +1284,11 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
             if (g_pixel_mask && !g_pixel_mask[(size_t)y * W + x]) continue;
             g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
             if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
-            float u = pert_uv(((float)x + 0.5f) / (float)W), v = pert_uv(((float)y + 0.5f) / (float)H);
+            float u = pert_uv(frag_u(x, y, W, H)), v = pert_uv(frag_v(y, W, H));
             float dep = fetch_r32f(depth, d, u, v);
             int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
-            float fx0 = ((float)qx0 + 0.5f) / (float)W, fx1 = ((float)qx1 + 0.5f) / (float)W;
-            float fy0 = ((float)qy0 + 0.5f) / (float)H, fy1 = ((float)qy1 + 0.5f) / (float)H;
+            float fx0 = frag_u(qx0, y, W, H), fx1 = frag_u(qx1, y, W, H);
+            float fy0 = frag_v(qy0, W, H), fy1 = frag_v(qy1, W, H);
             float fw = fabsf(fetch_r32f(depth, d, fx1, v) - fetch_r32f(depth, d, fx0, v)) + fabsf(fetch_r32f(depth, d, u, fy1) - fetch_r32f(depth, d, u, fy0));
             if (dep == 1.0f && fw == 0.0f) continue; /* discard DenoiserComposePass.js:61-64 */
             material mat = get_material(fetch_u4(gbuffer, d, u, v));

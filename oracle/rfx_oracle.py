@@ -72,6 +72,41 @@ class pixel_mask:
         return False
 
 
+class uv_model:
+    """with uv_model("reference"): fragments see the vUv the reference GL's rasteriser interpolates, bit for bit (its clipped full-screen
+    triangle's two plane equations, rfx_oracle.c frag_u / frag_v); "ideal" (the default, what the HIP kernels compute): (i + 0.5) / n."""
+    MODELS = {"ideal": 0, "reference": 1}
+
+    def __init__(self, model):
+        self.model = self.MODELS[model]
+
+    def __enter__(self):
+        lib().rfxo_set_uv_model(self.model)
+        return self
+
+    def __exit__(self, *exc):
+        lib().rfxo_set_uv_model(0)
+        return False
+
+
+def frag_uv(W, H, model="reference"):
+    """(u, v) planes of an H x W target under a vUv model (numpy restatement of rfx_oracle.c frag_u / frag_v, for the probe and tests)."""
+    f32 = np.float32
+    x, y = np.arange(W, dtype=f32)[None, :], np.arange(H, dtype=f32)[:, None]
+    if model == "ideal":
+        return np.broadcast_to((x + f32(0.5)) / f32(W), (H, W)).copy(), np.broadcast_to((y + f32(0.5)) / f32(H), (H, W)).copy()
+
+    def fma(a, b, c):  # operands here are small integers times one rounded slope: the double product is exact, one rounding at the end
+        return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(f32)
+    ooa = f32(1) / (f32(W) * f32(H))
+    dudx, dvdy = f32(H) * ooa, f32(W) * ooa
+    xi, yi = np.arange(W, dtype=np.int64)[None, :], np.arange(H, dtype=np.int64)[:, None]
+    upper = (2 * yi + 1) * W > (2 * xi + 1) * H
+    u = np.where(upper, fma(dudx, x, f32(0.5) * dudx), fma(dudx, x, f32(1) - dudx * (f32(W) - f32(0.5))))
+    v = np.broadcast_to(fma(dvdy, y, f32(1) - dvdy * (f32(H) - f32(0.5))), (H, W)).copy()
+    return u.astype(f32), v
+
+
 class perturbation:
     """with perturbation(seed): every exp/log/pow/sqrt/sin/cos/atan result of the oracle is moved by (1 +- rel) (sin/cos/atan also by
     +- abs), signs drawn per call from a per-fragment generator seeded with `seed` (rfx_oracle.c "perturbed primitives")."""

@@ -286,7 +286,7 @@ RFX_DEV float3 k1_env_color(const K1Args &A, float3 l, float roughness, bool isD
 RFX_DEV float2 k1_cdf_uv(const K1Args &A, const FrameDims &d, int px, int py) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (px < A.out_w && py < A.out_h) {
-        const int sx = rfx_nearest_idx(((float)px + 0.5f) / (float)A.out_w, d.fW, d.W), sy = rfx_nearest_idx(((float)py + 0.5f) / (float)A.out_h, d.fH, d.H);
+        const int sx = rfx_nearest_idx(rfx_frag_u(A.out_uv, px, py), d.fW, d.W), sy = rfx_nearest_idx(rfx_frag_v(A.out_uv, py), d.fH, d.H);
         if (((const float *)A.depth.ptr)[rfx_xy_index(d, A.depth.row0, A.depth.rows, sx, sy)] != 1.0f)
             r = rfx_blue_noise((const uchar4 *)A.blue, px, py, A.shift_x, A.shift_y);
     }
@@ -375,7 +375,7 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
 
     // vUv of the (possibly smaller, resolutionScale) render target; the full-resolution inputs are fetched NEAREST at vUv
     const bool scaled = A.out_w != d.W || A.out_h != d.H;
-    const float u = ((float)x + 0.5f) / (float)A.out_w, v = ((float)y + 0.5f) / (float)A.out_h;
+    const float u = rfx_frag_u(A.out_uv, x, y), v = rfx_frag_v(A.out_uv, y);
     const int sx = scaled ? rfx_nearest_idx(u, d.fW, d.W) : x, sy = scaled ? rfx_nearest_idx(v, d.fH, d.H) : y;
     const float depth = ((const float *)A.depth.ptr)[rfx_xy_index(d, A.depth.row0, A.depth.rows, sx, sy)];
     const size_t out_idx = scaled ? (size_t)y * A.out_w + x : (size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x;

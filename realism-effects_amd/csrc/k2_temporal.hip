@@ -150,7 +150,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
         // smaller target at this pixel's vUv (whole-frame contexts only; the target is stored at the start of the slot, pitch in_w)
         uint4 t;
         if (A.in_w != d.W || A.in_h != d.H) {
-            const int ix = rfx_nearest_idx(((float)gx + 0.5f) / d.fW, (float)A.in_w, A.in_w), iy = rfx_nearest_idx(((float)gy + 0.5f) / d.fH, (float)A.in_h, A.in_h);
+            const int ix = rfx_nearest_idx(rfx_frag_u(d.uv, gx, gy), (float)A.in_w, A.in_w), iy = rfx_nearest_idx(rfx_frag_v(d.uv, gy), (float)A.in_h, A.in_h);
             t = ((const uint4 *)A.ssgi.ptr)[(size_t)iy * A.in_w + ix];
         } else {
             t = rfx_gather<uint4>(A.ssgi.ptr, (unsigned int)(__mul24(rfx_local_row(d, A.ssgi.row0, A.ssgi.rows, gy), d.W) + gx));
@@ -169,7 +169,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
     const int x = tx0 + threadIdx.x, y = ty0 + threadIdx.y;
     if (x >= d.W || y >= A.y1) return;
     const int cx = threadIdx.x + AP, cy = threadIdx.y + AP, ci = cy * LW + cx;
-    const float u = ((float)x + 0.5f) / d.fW, v = ((float)y + 0.5f) / d.fH;
+    const float u = rfx_frag_u(d.uv, x, y), v = rfx_frag_v(d.uv, y);
 
     const float4 cvn = s.vn[ci];
     const float2 cvel = s.vel[ci];

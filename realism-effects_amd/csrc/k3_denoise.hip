@@ -108,7 +108,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     if (x >= d.W || y >= A.y1) return;
     const int cx = threadIdx.x + Rx, cy = threadIdx.y + Ry;  // this pixel inside the staged tile
     const int ci = __mul24(cy, LW) + cx;
-    const float u = ((float)x + 0.5f) / d.fW, v = ((float)y + 0.5f) / d.fH;
+    const float u = rfx_frag_u(d.uv, x, y), v = rfx_frag_v(d.uv, y);
     const float depth = s_depth[ci];
 
     // fine 2x2 quad derivatives; a partner beyond the frame edge fetches the edge texel
@@ -234,7 +234,7 @@ RFX_DEV void k3_generic_body(const K3Args &A, const FrameDims &d) {
     const int y = A.y0 + blockIdx.y * 4 + threadIdx.y;
     if (x >= d.W || y >= A.y1) return;
     const rfx_denoise_params &p = A.p;
-    const float u = ((float)x + 0.5f) / d.fW, v = ((float)y + 0.5f) / d.fH;
+    const float u = rfx_frag_u(d.uv, x, y), v = rfx_frag_v(d.uv, y);
     const float *depthp = (const float *)A.depth.ptr;
     const uint4 *gbp = (const uint4 *)A.gbuffer.ptr;
     const float depth = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, y)];

@@ -13,7 +13,7 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
     if (x >= d.W || y >= A.y1) return;
     const float *C = A.p.camera.matrixWorld, *Vw = A.p.camera.matrixWorldInverse;
     const float *P = A.p.camera.projectionMatrix, *Pi = A.p.camera.projectionMatrixInverse;
-    const float u = ((float)x + 0.5f) / d.fW, v = ((float)y + 0.5f) / d.fH;
+    const float u = rfx_frag_u(d.uv, x, y), v = rfx_frag_v(d.uv, y);
     const float *depthp = (const float *)A.depth.ptr;
     const float depth = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, y)];
     {

@@ -116,6 +116,13 @@ int rfx_set_row_window(rfx_ctx *c, int y0, int y1) {
     return RFX_OK;
 }
 
+int rfx_set_uv_model(rfx_ctx *c, int model) {
+    if (!c) return RFX_EINVAL;
+    if (model != RFX_UV_IDEAL && model != RFX_UV_REFERENCE_GL) return fail(c, RFX_EINVAL, "rfx_set_uv_model: unknown model");
+    c->uv_model = model;
+    return RFX_OK;
+}
+
 int rfx_tex_held_rows(const rfx_ctx *c, rfx_tex id, int *row0, int *rows) {
     if (!c || id < 0 || id >= RFX_TEX_COUNT) return RFX_EINVAL;
     if (row0) *row0 = c->slots[id].row0;
@@ -269,9 +276,24 @@ static TexViewW wview(rfx_ctx *c, int id) {
     v.ptr = c->slots[id].ptr; v.row0 = c->slots[id].row0; v.rows = c->slots[id].rows;
     return v;
 }
+// The plane equations of a w x h render target's vUv (rfx_device.h UvPlanes; this file is compiled with -ffp-contract=off: every product
+// below is rounded on its own, as the reference GL's triangle setup rounds them)
+static UvPlanes rfx_uv_planes(int model, int w, int h) {
+    UvPlanes q;
+    q.model = model; q.W = w; q.H = h; q.fW = (float)w; q.fH = (float)h;
+    const float ooa = 1.0f / ((float)w * (float)h);
+    q.du = (float)h * ooa;
+    q.dv = (float)w * ooa;
+    const float far_u = q.du * ((float)w - 0.5f), far_v = q.dv * ((float)h - 0.5f);
+    q.u0_upper = 0.5f * q.du;
+    q.u0_lower = 1.0f - far_u;
+    q.v0 = 1.0f - far_v;
+    return q;
+}
 static FrameDims dims(rfx_ctx *c) {
     FrameDims d;
     d.W = c->W; d.H = c->H; d.fW = (float)c->W; d.fH = (float)c->H;
+    d.uv = rfx_uv_planes(c->uv_model, c->W, c->H);
     d.halo_violations = c->halo_violations;
     return d;
 }
@@ -499,6 +521,7 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
         A.y0 = 0; A.y1 = A.out_h;
         any = true;  // whole-frame contexts only: the row window does not apply to the scaled target
     }
+    A.out_uv = rfx_uv_planes(c->uv_model, A.out_w, A.out_h);
     A.depth = view(c, RFX_TEX_DEPTH); A.gbuffer = view(c, RFX_TEX_GBUFFER); A.direct = view(c, RFX_TEX_DIRECT_LIGHT);
     A.history = view(c, hist);
     A.blue = c->slots[RFX_TEX_BLUE_NOISE].ptr;

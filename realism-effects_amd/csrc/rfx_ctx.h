@@ -28,6 +28,7 @@ struct rfx_ctx {
     float4 *hits = nullptr;    // K1 trace -> shade hand-over (rfx_ssgi_trace), 2 texels per SSGI texel
     bool hits_traced = false;  // a trace is waiting for its shade
     int win_y0 = 0, win_y1 = 0x7fffffff;  // rfx_set_row_window: rows the draws may produce
+    int uv_model = RFX_UV_IDEAL;           // rfx_set_uv_model
     float2 *coarse = nullptr;  // K1 scratch: exact (min,max) view Z per 16x16 base cell
     unsigned int *cells = nullptr;  // K1 scratch: the march's half-packed (min,max) table
     float4 *env = nullptr;     // scene.environment: the whole mip chain, float4 texels

@@ -24,9 +24,34 @@ struct TexViewW {
     void *ptr;
     int row0, rows;
 };
+// ---------------------------------------------------------------- the fragment's vUv
+// RFX_UV_IDEAL: (i + 0.5) / n, correctly rounded.  RFX_UV_REFERENCE_GL: what the rasteriser of the reference's GL (Mesa llvmpipe, the
+// oracle of SURVEY.md 8c) interpolates for three's full-screen triangle, bit for bit: the triangle (-1,-1) (3,-1) (-1,3) leaves the guard
+// band and is clipped to the viewport, so the frame is drawn as two triangles split along the diagonal (0,0)-(W,H), each with its own
+// fp32 plane equations a0 + du * x (+ dv * y) evaluated with fma on the integer pixel position (oracle/rfx_oracle.c frag_u / frag_v,
+// oracle/glref/probes/probe_varying.py: exact on every fragment of every size tried).  The host fills the planes (rfx_uv_planes).
+struct UvPlanes {
+    int model;
+    int W, H;
+    float fW, fH;
+    float du, dv;            // H * (1 / (W * H)), W * (1 / (W * H)), every product rounded
+    float u0_upper, u0_lower;  // du / 2 above the diagonal (provoking vertex (0,H)); 1 - du * (W - 0.5) on and below it (vertex (W,H))
+    float v0;                // 1 - dv * (H - 0.5) in both triangles
+};
+__device__ __forceinline__ float rfx_frag_u(const UvPlanes &q, int x, int y) {
+    if (q.model == RFX_UV_IDEAL) return ((float)x + 0.5f) / q.fW;
+    const bool upper = __mul24(2 * y + 1, q.W) > __mul24(2 * x + 1, q.H);  // < 2^31: rfx_create bounds W, H
+    return __fmaf_rn(q.du, (float)x, upper ? q.u0_upper : q.u0_lower);
+}
+__device__ __forceinline__ float rfx_frag_v(const UvPlanes &q, int y) {
+    if (q.model == RFX_UV_IDEAL) return ((float)y + 0.5f) / q.fH;
+    return __fmaf_rn(q.dv, (float)y, q.v0);
+}
+
 struct FrameDims {
     int W, H;
     float fW, fH;
+    UvPlanes uv;  // vUv of a frame-sized render target
     unsigned int *halo_violations;  // device counter (may be null)
     mutable unsigned int viol;      // per-lane sticky flag, flushed once by rfx_flush_violations()
 };

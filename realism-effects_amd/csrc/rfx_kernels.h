@@ -28,6 +28,7 @@ struct K1Args {
     const float *env_marginal, *env_conditional;  // EquirectHdrInfo.marginalWeights (env_h) / conditionalWeights (env_w x env_h), importanceSampling
     float totalSumWhole, totalSumDecimal;
     int out_w, out_h;  // the pass's render target = `resolution` (frame size unless resolutionScale != 1)
+    UvPlanes out_uv;   // that target's vUv
     float4 *hits;      // trace -> shade hand-over (2 texels per output pixel, indexed like `out`); null for the fused launch
 };
 

@@ -156,6 +156,13 @@ class Renderer {
 	setRowWindow(y0, y1) {
 		addon.setRowWindow(this._h, y0 | 0, y1 | 0)
 	}
+	// which vUv the following draws' fragments see (rfx_set_uv_model): "ideal" = (i + 0.5) / n, "reference_gl" = what the reference GL's
+	// rasteriser interpolates for three's full-screen triangle, bit for bit
+	setUvModel(model) {
+		const m = { ideal: 0, reference_gl: 1 }[model]
+		if (m === undefined) throw new RangeError("setUvModel: \"ideal\" or \"reference_gl\"")
+		addon.setUvModel(this._h, m)
+	}
 	// the same draw in two launches (rfx_ssgi_trace / rfx_ssgi_shade): only the second reads last frame's composed GI
 	ssgiTrace(uniforms) {
 		addon.ssgiTrace(this._h, uniforms)

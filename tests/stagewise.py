@@ -80,6 +80,9 @@ class HipStages:
         from rfx_amd.context import Context
         self.ctx = Context(W, H)
 
+    def set_uv_model(self, model):
+        self.ctx.set_uv_model(model)
+
     def frame(self, f):
         self.ctx.upload_frame(f)
 
@@ -125,11 +128,22 @@ def _h(t):  # RGBA16F target read back as float32 -> the half bit patterns (exac
 
 
 def run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start=1000, denoise_start=2000, shader_dir=None, log=print,
-        with_margins=True, n_perturb=6, sample_every=64, extra_perturb=96, compare_from=0):
-    """Returns the list of parity.Report (one per stage output and frame).  frame_fn(i) -> dump frame i (rfx_amd.scene Frame)."""
+        with_margins=True, n_perturb=6, sample_every=64, extra_perturb=96, compare_from=0, uv_model="ideal"):
+    """Returns the list of parity.Report (one per stage output and frame).  frame_fn(i) -> dump frame i (rfx_amd.scene Frame).
+    uv_model "reference_gl": the implementation (rfx_set_uv_model / rfxo_set_uv_model) evaluates the reference GL's own vUv planes, and the
+    proving oracle then carries no vUv uncertainty at all."""
+    with O.uv_model({"ideal": "ideal", "reference_gl": "reference"}[uv_model]):
+        return _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start, denoise_start, shader_dir, log,
+                    with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model)
+
+
+def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start, denoise_start, shader_dir, log,
+         with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model):
     import chain
     ref = chain.GLRefChain(W, H, blue, shader_dir=shader_dir, steps=steps, refineSteps=refine, denoiseIterations=iterations)
     impl = impl_cls(W, H, blue)
+    if hasattr(impl, "set_uv_model"):
+        impl.set_uv_model(uv_model)
     ora = OracleStages(W, H, blue) if with_margins else None
     reports = []
     si = di = 0
