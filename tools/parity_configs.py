@@ -28,6 +28,7 @@ ap.add_argument("--frames", type=int, default=2)
 ap.add_argument("--out", default=None)
 ap.add_argument("--compare-from", type=int, default=0, help="frames before this one only advance the reference chain (no comparison)")
 ap.add_argument("--perturb", type=int, default=16, help="perturbed oracle re-evaluations per stage (of the out-of-tolerance + sampled pixels)")
+ap.add_argument("--uv-model", default="ideal", help="ideal | reference_gl (rfx_set_uv_model / rfxo_set_uv_model on the implementation and the proving oracle)")
 a = ap.parse_args()
 W, H = [int(v) for v in a.size.split("x")]
 lines = []
@@ -39,8 +40,8 @@ def log(s):
 
 
 t0 = time.time()
-log("# %s vs reference GLSL on llvmpipe, stage-wise on identical inputs: %dx%d steps %d/%d denoiseIterations %d, %d frames" % (
-    a.impl, W, H, a.steps, a.refine, a.it, a.frames))
+log("# %s vs reference GLSL on llvmpipe, stage-wise on identical inputs: %dx%d steps %d/%d denoiseIterations %d, %d frames, vUv model %s" % (
+    a.impl, W, H, a.steps, a.refine, a.it, a.frames, a.uv_model))
 frames = {}
 
 
@@ -51,7 +52,7 @@ def frame_fn(i):
     return frames[i]
 
 
-reports = S.run(S.HipStages if a.impl == "hip" else S.OracleStages, W, H, a.steps, a.refine, a.it, a.frames, load_blue_noise_table(), frame_fn, log=log, n_perturb=a.perturb, compare_from=a.compare_from)
+reports = S.run(S.HipStages if a.impl == "hip" else S.OracleStages, W, H, a.steps, a.refine, a.it, a.frames, load_blue_noise_table(), frame_fn, log=log, n_perturb=a.perturb, compare_from=a.compare_from, uv_model=a.uv_model)
 log("# summary (all frames)   kind: pixels, Linf(all), Linf(in-tol), out-of-tol, explained, UNEXPLAINED, at-risk")
 for kind, v in S.summarize(reports).items():
     log("#   %-18s %10d  %.3e  %.3e  %7d  %7d  %7d  %8d" % ((kind,) + tuple(v)))
