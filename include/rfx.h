@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 13
+#define RFX_ABI_VERSION 14
 
 enum {
     RFX_OK = 0,
@@ -264,6 +264,15 @@ int rfx_set_environment_importance(rfx_ctx *, const float *marginalWeights, size
 /* Read mip level `level` of the environment back (max(w>>level,1) x max(h>>level,1) RGBA float32); *levels (may be NULL) receives the
  * number of levels.  For inspection and for checking the chain against the driver's. */
 int rfx_download_environment(rfx_ctx *, int level, float *rgba, int *levels);
+/* CubeToEquirectEnvPass.generateEquirectEnvMap's draw + read-back (src/ssgi/pass/CubeToEquirectEnvPass.js:21-42,78-85; called from
+ * SSGIEffect.js:316-321 when scene.environment is a CubeTexture): `faces_rgba` = the six faces +X -X +Y -Y +Z -Z, each size x size RGBA
+ * float32 (linear values), row j = t as handed to glTexImage2D; `equirect_rgba` receives width x height RGBA float32 texels (the pass's
+ * FloatType render target as readRenderTargetPixels returns it: row 0 = bottom) — the DataTexture the effect then treats like any
+ * equirectangular environment: hand it to rfx_set_environment(…, halfFloatType = 0) and build the importance tables from it.
+ * generateMipmaps = 0: the cube is sampled LINEAR, seamless, at level 0 (minFilter LinearFilter: HDRCubeTextureLoader's set-up);
+ * 1: three's CubeTexture default, LinearMipmapLinearFilter over the chain glGenerateMipmap builds (size a power of two), with the
+ * implicit level of detail of `textureCube` (the pass minifies near the face edges: levels 0-2 take part). */
+int rfx_cube_to_equirect(rfx_ctx *, const float *faces_rgba, int size, int generateMipmaps, float *equirect_rgba, int width, int height);
 
 /* ---- the four draws (+ the framebuffer copy and the effect's own fragment) */
 int rfx_ssgi_march(rfx_ctx *, const rfx_ssgi_params *);

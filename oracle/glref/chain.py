@@ -310,6 +310,20 @@ class Tex:
         GL.lib().glref_tex_free(self.id)
 
 
+class CubeTex:
+    """six size x size faces (+X -X +Y -Y +Z -Z, row j = t as handed to glTexImage2D).  mipmaps: three's CubeTexture default
+    (LinearMipmapLinearFilter, chain from glGenerateMipmap); otherwise LinearFilter, level 0 only (HDRCubeTextureLoader's set-up)."""
+
+    def __init__(self, faces, mipmaps=False):
+        faces = np.ascontiguousarray(faces, np.float32)
+        self.w = self.h = faces.shape[1]
+        self.id = GL.lib().glref_cube_texture(self.w, FMT_RGBA32F, 2 if mipmaps else 1, faces.ctypes.data_as(ctypes.c_void_p))
+        assert self.id > 0, self.id
+
+    def free(self):
+        GL.lib().glref_tex_free(self.id)
+
+
 class Program:
     def __init__(self, src: str):
         log = ctypes.create_string_buffer(16384)
@@ -679,6 +693,35 @@ void main() {
 }
 """
     return three_prefix({}, True) + gb + main
+
+
+def assemble_cube_to_equirect() -> str:
+    """CubeToEquirectEnvPass.js:21-42 (inline template literal) under three's fragment prefix; the sampler precision is the one every
+    desktop GL gives a samplerCube (GLSL ES would default it to lowp, which Mesa lowers to fp16 fetches — not what any GPU runs)."""
+    js = _rd("ssgi/pass/CubeToEquirectEnvPass.js")
+    m = re.search(r"fragmentShader:\s*/\* glsl \*/\s*`([\s\S]*?)`,\s*vertexShader", js)
+    return three_prefix({}, False) + "precision highp samplerCube;\n" + m.group(1)
+
+
+def cube_equirect_size(face_size: int, max_width: int = 4096):
+    """generateEquirectEnvMap's target size (CubeToEquirectEnvPass.js:62-74)"""
+    import math
+    w = int(2 ** math.ceil(math.log2(2 * face_size * 3 ** 0.5)))
+    h = int(2 ** math.ceil(math.log2(face_size * 3 ** 0.5)))
+    return (max_width, max_width // 2) if w > max_width else (w, h)
+
+
+def run_cube_to_equirect(faces: np.ndarray, W: int, H: int, mipmaps: bool) -> np.ndarray:
+    """The pass on llvmpipe: (H, W, 4) float32, row 0 = bottom (what readRenderTargetPixels returns)."""
+    p = Program(assemble_cube_to_equirect())
+    c = CubeTex(faces, mipmaps)
+    p.sampler("cubeMap", c)
+    out = Tex(W, H, FMT_RGBA32F)
+    p.draw([out])
+    r = out.read()
+    out.free()
+    c.free()
+    return r
 
 
 def run_pack(aov: dict, depth: np.ndarray):

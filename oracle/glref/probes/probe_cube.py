@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from chain import GL, Program, Tex  # noqa: E402
 
 f32 = np.float32
-HEAD = "#version 300 es\nprecision highp float;\nprecision highp int;\nin vec2 vUv;\nout vec4 o;\nuniform samplerCube cubeMap;\n"
+HEAD = "#version 300 es\nprecision highp float;\nprecision highp int;\nprecision highp samplerCube;\nprecision highp sampler2D;\nin vec2 vUv;\nout vec4 o;\nuniform samplerCube cubeMap;\n"
 DIRS = """
 #define M_PI 3.1415926535897932384626433832795
 vec3 direction() {  // the pass's own arithmetic

@@ -864,6 +864,159 @@ int rfxo_pack_velocity(int n, const float *velocity, const float *normal, const 
     return 0;
 }
 
+/* ------------------------------------------------------------------ CubeToEquirectEnvPass (src/ssgi/pass/CubeToEquirectEnvPass.js:21-42)
+ * One `textureCube(cubeMap, dir)` per texel of the equirectangular target.  The cube lookup as the oracle's GL does it (measured on
+ * llvmpipe WITH three's `precision highp samplerCube;` — without it Mesa lowers the fetch to fp16 and the filter looks 8-bit;
+ * oracle/glref/probes/probe_cube.py): major axis by >= in x, y, z order; (s, t) = (sc * (1 / ma)) * 0.5 + 0.5 (bit-exact on every
+ * interior lookup); seamless: a footprint texel beyond the face edge is the texel of the neighbouring face the extended position
+ * projects to, a footprint texel beyond a CORNER (no such texel exists) is the average of the other three; blend = lerp in x, then
+ * in y, each lerp a fused a + w * (b - a).  Faces: +X -X +Y -Y +Z -Z, each S x S RGBA32F, row j = t index (as handed to glTexImage2D). */
+static inline void cube_face(float x, float y, float z, int *face, float *s, float *t) {
+    float ax = fabsf(x), ay = fabsf(y), az = fabsf(z), sc, tc, ma;
+    if (ax >= ay && ax >= az) { *face = x >= 0.0f ? 0 : 1; sc = x >= 0.0f ? -z : z; tc = -y; ma = ax; }
+    else if (ay >= az) { *face = y >= 0.0f ? 2 : 3; sc = x; tc = y >= 0.0f ? z : -z; ma = ay; }
+    else { *face = z >= 0.0f ? 4 : 5; sc = z >= 0.0f ? x : -x; tc = -y; ma = az; }
+    float ima = 1.0f / ma;
+    *s = (sc * ima) * 0.5f + 0.5f;
+    *t = (tc * ima) * 0.5f + 0.5f;
+}
+/* the point (a, b) of face `face` in its (sc / ma, tc / ma) coordinates, as a direction */
+static inline void cube_face_dir(int face, float a, float b, float *x, float *y, float *z) {
+    switch (face) {
+    case 0: *x = 1.0f; *y = -b; *z = -a; break;
+    case 1: *x = -1.0f; *y = -b; *z = a; break;
+    case 2: *x = a; *y = 1.0f; *z = b; break;
+    case 3: *x = a; *y = -1.0f; *z = -b; break;
+    case 4: *x = a; *y = -b; *z = 1.0f; break;
+    default: *x = -a; *y = -b; *z = -1.0f; break;
+    }
+}
+/* texel (i, j) of the footprint on `face`; NULL for the texel beyond a corner */
+static inline const float *cube_texel(const float *faces, int S, int face, int i, int j) {
+    const int oi = i < 0 || i >= S, oj = j < 0 || j >= S;
+    if (oi && oj) return NULL;
+    if (oi || oj) { /* the centre of the would-be texel, projected onto the neighbouring face */
+        float a = (((float)i + 0.5f) / (float)S) * 2.0f - 1.0f, b = (((float)j + 0.5f) / (float)S) * 2.0f - 1.0f, x, y, z, s, t;
+        cube_face_dir(face, a, b, &x, &y, &z);
+        cube_face(x, y, z, &face, &s, &t);
+        i = (int)floorf(s * (float)S); j = (int)floorf(t * (float)S);
+        i = i < 0 ? 0 : (i > S - 1 ? S - 1 : i); j = j < 0 ? 0 : (j > S - 1 ? S - 1 : j);
+    }
+    return faces + (((size_t)face * S + j) * S + i) * 4;
+}
+static void cube_linear(const float *faces, int S, float x, float y, float z, float *out) {
+    int face; float s, t;
+    cube_face(x, y, z, &face, &s, &t);
+    float u = s * (float)S - 0.5f, v = t * (float)S - 0.5f;
+    float fi = floorf(u), fj = floorf(v), fu = u - fi, fv = v - fj;
+    int i0 = (int)fi, j0 = (int)fj;
+    const float *q[4] = {cube_texel(faces, S, face, i0, j0), cube_texel(faces, S, face, i0 + 1, j0),
+                         cube_texel(faces, S, face, i0, j0 + 1), cube_texel(faces, S, face, i0 + 1, j0 + 1)};
+    for (int c = 0; c < 4; c++) {
+        float tx[4]; int missing = -1;
+        for (int k = 0; k < 4; k++) { if (q[k]) tx[k] = q[k][c]; else missing = k; }
+        if (missing >= 0) { /* beyond the corner: the average of the three texels that exist */
+            float sum = 0.0f;
+            for (int k = 0; k < 4; k++) if (k != missing) sum += tx[k];
+            tx[missing] = sum / 3.0f;
+        }
+        float top = fmaf(fu, tx[1] - tx[0], tx[0]), bot = fmaf(fu, tx[3] - tx[2], tx[2]);
+        out[c] = fmaf(fv, bot - top, top);
+    }
+}
+/* A CubeTexture with mipmaps (three's default: LinearMipmapLinearFilter + generateMipmaps): the chain glGenerateMipmap builds on the
+ * oracle's GL per face (the 2x2 bilinear-centre average, as for 2-D textures), the implicit level of detail of `textureCube` as llvmpipe
+ * derives it (measured to < 1e-6 in lod on a chain whose level l holds the constant l, probe_cube.py): PER PIXEL, from the differences
+ * of the direction within the pixel's own row and own column of its 2x2 quad, through the quotient rule on the pixel's own face
+ *   ds = (d(sc) * ma - sc * d(ma)) * (1 / ma)^2 * 0.5,   rho^2 = max(dsdx^2 + dtdx^2, dsdy^2 + dtdy^2) * S^2,
+ * lod = 0.5 * (exponent(rho^2) + mantissa(rho^2) - 1) (the linear-mantissa log2), clamped to the chain; two seamless bilinear lookups
+ * blended by fract(lod). */
+static inline void cube_components(int face, float x, float y, float z, float *sc, float *tc, float *ma) {
+    switch (face) {
+    case 0: *sc = -z; *tc = -y; *ma = x; break;
+    case 1: *sc = z; *tc = -y; *ma = -x; break;
+    case 2: *sc = x; *tc = z; *ma = y; break;
+    case 3: *sc = x; *tc = -z; *ma = -y; break;
+    case 4: *sc = x; *tc = -y; *ma = z; break;
+    default: *sc = -x; *tc = -y; *ma = -z; break;
+    }
+}
+static inline float cube_lod(const float p[3], const float ddx[3], const float ddy[3], int S) {
+    int face; float s, t;
+    cube_face(p[0], p[1], p[2], &face, &s, &t);
+    float sc, tc, ma, xsc, xtc, xma, ysc, ytc, yma;
+    cube_components(face, p[0], p[1], p[2], &sc, &tc, &ma);
+    cube_components(face, ddx[0], ddx[1], ddx[2], &xsc, &xtc, &xma);
+    cube_components(face, ddy[0], ddy[1], ddy[2], &ysc, &ytc, &yma);
+    float ima = 1.0f / ma, k = (ima * ima) * 0.5f;
+    float dsx = (xsc * ma - sc * xma) * k, dtx = (xtc * ma - tc * xma) * k;
+    float dsy = (ysc * ma - sc * yma) * k, dty = (ytc * ma - tc * yma) * k;
+    float rho2 = fmaxf(dsx * dsx + dtx * dtx, dsy * dsy + dty * dty) * ((float)S * (float)S);
+    uint32_t bits; memcpy(&bits, &rho2, 4);
+    uint32_t mb = (bits & 0x7fffffu) | 0x3f800000u; float mant; memcpy(&mant, &mb, 4);
+    return 0.5f * ((float)((int)((bits >> 23) & 0xffu) - 127) + (mant - 1.0f));
+}
+static inline void cube_pass_direction(int x, int y, int W, int H, float *d) {
+    const float PI = 3.1415926535897932384626433832795f;
+    float u = pert_uv(frag_u(x, y, W, H)), v = pert_uv(frag_v(y, W, H));
+    float longitude = ((u * 2.0f) * PI - PI) + PI / 2.0f;
+    float latitude = v * PI;
+    float sl = sinf(latitude);
+    d[0] = -sinf(longitude) * sl; d[1] = -cosf(latitude); d[2] = -cosf(longitude) * sl; /* dir.y = -dir.y */
+}
+/* the pass: W x H RGBA32F (FloatType render target), row y = vUv.y (row 0 = bottom, as readRenderTargetPixels returns it).
+ * mipmaps = 0: the cube has level 0 only (minFilter LinearFilter); 1: LinearMipmapLinearFilter over the generated chain (S a power of two) */
+int rfxo_cube_to_equirect(const float *faces, int S, int mipmaps, int W, int H, float *out) {
+    if (!faces || !out || S < 1 || W < 1 || H < 1) return -1;
+    if (mipmaps && (S & (S - 1))) return -1;
+    const float *lv[16] = {faces};
+    float *owned[16] = {0};
+    int sizes[16] = {S}, levels = 1;
+    while (mipmaps && sizes[levels - 1] > 1) {
+        int s0 = sizes[levels - 1], s1 = s0 >> 1;
+        float *dst = (float *)malloc((size_t)6 * s1 * s1 * 4 * sizeof(float));
+        const float *src = lv[levels - 1];
+        for (int f = 0; f < 6; f++)
+            for (int y = 0; y < s1; y++)
+                for (int x = 0; x < s1; x++)
+                    for (int k = 0; k < 4; k++) {
+                        const float *q = src + ((size_t)f * s0 * s0) * 4;
+                        float a = q[4 * ((size_t)(2 * y) * s0 + 2 * x) + k], b = q[4 * ((size_t)(2 * y) * s0 + 2 * x + 1) + k];
+                        float c = q[4 * ((size_t)(2 * y + 1) * s0 + 2 * x) + k], e = q[4 * ((size_t)(2 * y + 1) * s0 + 2 * x + 1) + k];
+                        dst[4 * (((size_t)f * s1 + y) * s1 + x) + k] = lerpf(0.5f, lerpf(0.5f, a, b), lerpf(0.5f, c, e));
+                    }
+        lv[levels] = owned[levels] = dst; sizes[levels] = s1; levels++;
+    }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            pert_begin(x, y);
+            float p[3];
+            cube_pass_direction(x, y, W, H, p);
+            float *o = out + ((size_t)y * W + x) * 4;
+            if (levels == 1) { cube_linear(faces, S, p[0], p[1], p[2], o); continue; }
+            /* the quad partners: the other pixel of the own row, the other pixel of the own column (a target is even-sized here; a
+             * partner outside an odd-sized target is extrapolated by the rasteriser: its planes evaluate there as well) */
+            float pr[3], pc[3], ddx[3], ddy[3];
+            cube_pass_direction(x ^ 1, y, W, H, pr);
+            cube_pass_direction(x, y ^ 1, W, H, pc);
+            for (int k = 0; k < 3; k++) {
+                ddx[k] = (x & 1) ? p[k] - pr[k] : pr[k] - p[k];
+                ddy[k] = (y & 1) ? p[k] - pc[k] : pc[k] - p[k];
+            }
+            float lod = cube_lod(p, ddx, ddy, S);
+            lod = fminf(fmaxf(lod, 0.0f), (float)(levels - 1));
+            float fl = floorf(lod), f = lod - fl;
+            int l0 = (int)fl, l1 = l0 + 1 > levels - 1 ? levels - 1 : l0 + 1;
+            float c0[4], c1[4];
+            cube_linear(lv[l0], sizes[l0], p[0], p[1], p[2], c0);
+            cube_linear(lv[l1], sizes[l1], p[0], p[1], p[2], c1);
+            for (int k = 0; k < 4; k++) o[k] = fmaf(f, c1[k] - c0[k], c0[k]);
+        }
+    for (int l = 1; l < levels; l++) free(owned[l]);
+    return 0;
+}
+
 /* The mip chain of scene.environment as glGenerateMipmap builds it on the oracle's GL (measured on llvmpipe): level 0 = the texels in the
  * texture's type, every further level the 2x2 bilinear-centre average lerp(.5, lerp(.5,a,b), lerp(.5,c,d)) stored in that type
  * (half: RTZ when `rtz`, as llvmpipe).  `out` receives all levels back to back; returns the number of levels. */

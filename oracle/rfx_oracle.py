@@ -263,6 +263,17 @@ def pack_velocity(aov: dict, depth) -> np.ndarray:
     return out
 
 
+def cube_to_equirect(faces, W, H, mipmaps=False):
+    """CubeToEquirectEnvPass's draw (rfx_oracle.c rfxo_cube_to_equirect): faces (6, S, S, 4) float32 (+X -X +Y -Y +Z -Z, row j = t as uploaded)
+    -> (H, W, 4) float32, row 0 = bottom.  mipmaps: the cube is sampled LinearMipmapLinear over the chain glGenerateMipmap builds."""
+    faces = np.ascontiguousarray(faces, np.float32)
+    assert faces.ndim == 4 and faces.shape[0] == 6 and faces.shape[1] == faces.shape[2] and faces.shape[3] == 4
+    out = np.zeros((H, W, 4), np.float32)
+    rc = lib().rfxo_cube_to_equirect(_p(faces), C.c_int(faces.shape[1]), C.c_int(int(bool(mipmaps))), C.c_int(W), C.c_int(H), _p(out))
+    assert rc == 0, rc
+    return out
+
+
 def half_bits_to_float(h: np.ndarray) -> np.ndarray:
     return h.view(np.float16).astype(np.float32)
 

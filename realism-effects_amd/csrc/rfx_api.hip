@@ -446,6 +446,34 @@ int rfx_set_environment(rfx_ctx *c, const float *rgba, int width, int height, in
     return RFX_OK;
 }
 
+int rfx_cube_to_equirect(rfx_ctx *c, const float *faces, int size, int generateMipmaps, float *equirect, int width, int height) {
+    if (!c || !faces || !equirect) return RFX_EINVAL;
+    if (size < 1 || size > 8192 || width < 1 || height < 1 || width > 16384 || height > 16384)
+        return fail(c, RFX_EINVAL, "rfx_cube_to_equirect: face size must be 1..8192, the target 1..16384 in each edge");
+    if (generateMipmaps && (size & (size - 1))) return fail(c, RFX_EUNSUPPORTED, "rfx_cube_to_equirect: a mip chain needs a power-of-two face size");
+    hipSetDevice(c->device);
+    int levels = 1;
+    size_t nchain = (size_t)6 * size * size;
+    if (generateMipmaps)
+        for (int s = size >> 1; s >= 1; s >>= 1) { nchain += (size_t)6 * s * s; levels++; }
+    const size_t nin = (size_t)6 * size * size, nout = (size_t)width * height;
+    float4 *din = nullptr, *dout = nullptr;
+    hipError_t e = hipMalloc((void **)&din, nchain * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void **)&dout, nout * sizeof(float4));
+    if (e != hipSuccess) {
+        if (din) hipFree(din);
+        return fail(c, RFX_ENOMEM, "hipMalloc(cube chain / equirect target)", e);
+    }
+    e = hipMemcpyAsync(din, faces, nin * sizeof(float4), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = rfx_launch_cube_to_equirect(din, size, levels, dout, width, height, rfx_uv_planes(c->uv_model, width, height), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(equirect, dout, nout * sizeof(float4), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(din);
+    hipFree(dout);
+    if (e != hipSuccess) return fail(c, RFX_EDEVICE, "rfx_cube_to_equirect", e);
+    return RFX_OK;
+}
+
 int rfx_set_environment_importance(rfx_ctx *c, const float *marginal, size_t marginalCount, const float *conditional, size_t conditionalCount,
                                    float totalSumWhole, float totalSumDecimal) {
     if (!c || !marginal || !conditional) return RFX_EINVAL;

@@ -73,6 +73,8 @@ struct K4Args {
 hipError_t rfx_launch_pack_gbuffer(int W, int rows, const float *diffuse, const float *normal, const float *roughness, const float *metalness,
                                    const float *emissive, const float *depth, void *out, hipStream_t);
 hipError_t rfx_launch_pack_velocity(int W, int rows, const float *velocity, const float *normal, const float *depth, void *out, hipStream_t);
+// CubeToEquirectEnvPass (k0_import.hip): six S x S RGBA32F faces -> a W x H RGBA32F equirectangular image
+hipError_t rfx_launch_cube_to_equirect(float4 *chain, int size, int levels, float4 *out, int W, int H, const UvPlanes &uv, hipStream_t);
 
 struct K5Args {
     FrameDims dims;

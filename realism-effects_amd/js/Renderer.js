@@ -156,6 +156,13 @@ class Renderer {
 	setRowWindow(y0, y1) {
 		addon.setRowWindow(this._h, y0 | 0, y1 | 0)
 	}
+	// CubeToEquirectEnvPass's draw + read-back (rfx_cube_to_equirect): faces = Float32Array(6 * size * size * 4), +X -X +Y -Y +Z -Z, row j = t
+	// as uploaded; returns Float32Array(width * height * 4), row 0 = bottom
+	cubeToEquirect(faces, size, width, height, generateMipmaps) {
+		const out = new Float32Array(width * height * 4)
+		addon.cubeToEquirect(this._h, faces, size | 0, generateMipmaps ? 1 : 0, out, width | 0, height | 0)
+		return out
+	}
 	// which vUv the following draws' fragments see (rfx_set_uv_model): "ideal" = (i + 0.5) / n, "reference_gl" = what the reference GL's
 	// rasteriser interpolates for three's full-screen triangle, bit for bit
 	setUvModel(model) {

@@ -501,6 +501,45 @@ class SSGIPass {
 }
 
 // src/ssgi/SSGIEffect.js:27-439
+// three.js texture filter constants (three/src/constants.js)
+const NearestFilter = 1003
+const LinearFilter = 1006
+const LinearMipmapLinearFilter = 1008
+
+// src/ssgi/pass/CubeToEquirectEnvPass.js: scene.environment given as a CubeTexture is rendered into an equirectangular FloatType target (one
+// textureCube lookup per texel), read back, and continues as a DataTexture.  The cube as dumped state: { isCubeTexture: true,
+// faces: Float32Array(6 * size * size * 4) linear values (+X -X +Y -Y +Z -Z, row j = t as uploaded), size, and the two sampler fields the
+// lookup depends on: minFilter (default LinearMipmapLinearFilter, three's Texture default) and generateMipmaps (default true) }.
+class CubeToEquirectEnvPass {
+	generateEquirectEnvMap(renderer, cubeMap, width = null, height = null, maxWidth = 4096) {
+		if (width === null && height === null) {
+			// :62-69
+			const w = cubeMap.size
+			width = 2 ** Math.ceil(Math.log2(2 * w * 3 ** 0.5))
+			height = 2 ** Math.ceil(Math.log2(w * 3 ** 0.5))
+		}
+		if (width > maxWidth) {
+			// :71-74
+			width = maxWidth
+			height = maxWidth / 2
+		}
+		const minFilter = cubeMap.minFilter === undefined || cubeMap.minFilter === null ? LinearMipmapLinearFilter : cubeMap.minFilter
+		let mips
+		if (minFilter === LinearMipmapLinearFilter) {
+			if (cubeMap.generateMipmaps === false) throw new Error("CubeToEquirectEnvPass: a LinearMipmapLinearFilter cube texture without generated mipmaps is incomplete (samples black)")
+			mips = true
+		} else if (minFilter === LinearFilter) {
+			mips = false
+		} else {
+			throw new Error("CubeToEquirectEnvPass: cube minFilter " + minFilter + " — LinearFilter and LinearMipmapLinearFilter are built")
+		}
+		// render + readRenderTargetPixels :76-85, then the DataTexture of :87-97 (FloatType, ClampToEdge, EquirectangularReflectionMapping)
+		const data = renderer.cubeToEquirect(cubeMap.faces, cubeMap.size, width, height, mips)
+		return { data, width, height, type: FloatType, isCubeTexture: false }
+	}
+	dispose() {}
+}
+
 class SSGIEffect {
 	// `seeds` ({ ssgi, denoise } blue-noise start indices) and `halfStoreRTZ` are additions for reproducible offline runs
 	constructor(composer, scene, camera, options, seeds, halfStoreRTZ) {
@@ -661,7 +700,12 @@ class SSGIEffect {
 		const u = this.ssgiPass.uniforms
 		if (env) {
 			if (this._envUuid !== env) {
-				if (env.isCubeTexture) throw new Error("cube environment maps (CubeToEquirectEnvPass, :316-321) are not built: pass an equirectangular map")
+				let env = this._scene.environment
+				if (env.isCubeTexture) {
+					// :316-321 convert it to an equirectangular texture so the pass can sample it and use MIS
+					if (!this.cubeToEquirectEnvPass) this.cubeToEquirectEnvPass = new CubeToEquirectEnvPass()
+					env = this.cubeToEquirectEnvPass.generateEquirectEnvMap(renderer, env)
+				}
 				const half = env.type === undefined || env.type === null || env.type === HalfFloatType
 				renderer.setEnvironment(env.data, env.width, env.height, half, this._halfStoreRTZ === undefined || this._halfStoreRTZ)
 				u.importanceSampling = 0
@@ -679,7 +723,7 @@ class SSGIEffect {
 					renderer.setEnvironmentImportance(imp.marginalWeights, imp.conditionalWeights, imp.totalSumValue)
 					u.importanceSampling = 1
 				}
-				this._envUuid = env
+				this._envUuid = this._scene.environment
 				u.useEnvMap = 1 // defines.USE_ENVMAP :344
 				this.reset() // :356
 			}
@@ -800,6 +844,10 @@ TRAAEffect.DefaultOptions = defaultTemporalReprojectPassOptions
 
 module.exports = {
 	SSGIEffect,
+	CubeToEquirectEnvPass,
+	NearestFilter,
+	LinearFilter,
+	LinearMipmapLinearFilter,
 	SSREffect,
 	TRAAEffect,
 	VelocityDepthNormalPass,

@@ -313,6 +313,32 @@ static napi_value n_set_environment(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
+/* cubeToEquirect(ctx, Float32Array faces[6 * size * size * 4], size, generateMipmaps, Float32Array out[width * height * 4], width, height):
+ * rfx_cube_to_equirect (CubeToEquirectEnvPass's draw + read-back) */
+static napi_value n_cube_to_equirect(napi_env env, napi_callback_info info) {
+    napi_value a[7];
+    if (!get_args(env, info, 7, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    int32_t size, mips, w, h;
+    if (!get_int(env, a[2], &size) || !get_int(env, a[3], &mips) || !get_int(env, a[5], &w) || !get_int(env, a[6], &h)) return NULL;
+    napi_typedarray_type tt;
+    size_t len_in, len_out;
+    void *pin, *pout;
+    if (napi_get_typedarray_info(env, a[1], &tt, &len_in, &pin, NULL, NULL) != napi_ok || tt != napi_float32_array ||
+        napi_get_typedarray_info(env, a[4], &tt, &len_out, &pout, NULL, NULL) != napi_ok || tt != napi_float32_array) {
+        napi_throw_type_error(env, NULL, "cubeToEquirect: Float32Array faces and Float32Array target expected");
+        return NULL;
+    }
+    if (size < 1 || w < 1 || h < 1 || (size_t)6 * (size_t)size * (size_t)size * 4 != len_in || (size_t)w * (size_t)h * 4 != len_out) {
+        napi_throw_range_error(env, NULL, "cubeToEquirect: faces length != 6 * size * size * 4 or target length != width * height * 4");
+        return NULL;
+    }
+    int rc = rfx_cube_to_equirect(c, (const float *)pin, size, mips, (float *)pout, w, h);
+    if (rc) return throw_rfx(env, c, "rfx_cube_to_equirect", rc);
+    return NULL;
+}
+
 /* setEnvironmentImportance(ctx, Float32Array marginal, Float32Array conditional, totalSumWhole, totalSumDecimal) */
 static napi_value n_set_environment_importance(napi_env env, napi_callback_info info) {
     napi_value a[5];
@@ -648,7 +674,7 @@ static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
         {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"setEnvironmentImportance", n_set_environment_importance}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"ssgiTrace", n_ssgi_trace}, {"ssgiShade", n_ssgi_shade}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
-        {"sync", n_sync}, {"setRowWindow", n_set_row_window}, {"setUvModel", n_set_uv_model}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
+        {"sync", n_sync}, {"setRowWindow", n_set_row_window}, {"setUvModel", n_set_uv_model}, {"cubeToEquirect", n_cube_to_equirect}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
         {"stageUpload", n_stage_upload}, {"stageFlip", n_stage_flip}, {"hostAlloc", n_host_alloc},
         {"splitRows", n_split_rows}, {"commUniqueId", n_comm_unique_id}, {"commInit", n_comm_init}, {"haloExchange", n_halo_exchange},
         {"allgatherHistory", n_allgather_history}, {"commWait", n_comm_wait}, {"commDestroy", n_comm_destroy},

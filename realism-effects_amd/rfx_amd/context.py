@@ -198,6 +198,17 @@ class Context:
         self._chk(self.lib.rfx_download_environment(self._h, level, out.ctypes.data_as(C.c_void_p), None), "rfx_download_environment")
         return out
 
+    def cube_to_equirect(self, faces, width: int, height: int, generate_mipmaps: bool = False) -> np.ndarray:
+        """CubeToEquirectEnvPass's draw + read-back (rfx_cube_to_equirect): faces (6, S, S, 4) float32 (+X -X +Y -Y +Z -Z, row j = t as
+        uploaded) -> (height, width, 4) float32, row 0 = bottom."""
+        faces = np.ascontiguousarray(faces, np.float32)
+        if faces.ndim != 4 or faces.shape[0] != 6 or faces.shape[1] != faces.shape[2] or faces.shape[3] != 4:
+            raise ValueError("cube_to_equirect: faces must be (6, S, S, 4) float32")
+        out = np.empty((int(height), int(width), 4), np.float32)
+        self._chk(self.lib.rfx_cube_to_equirect(self._h, faces.ctypes.data_as(C.c_void_p), faces.shape[1], 1 if generate_mipmaps else 0,
+                                                out.ctypes.data_as(C.c_void_p), int(width), int(height)), "rfx_cube_to_equirect")
+        return out
+
     def environment_levels(self) -> int:
         n = C.c_int()
         self._chk(self.lib.rfx_download_environment(self._h, 0, None, C.byref(n)), "rfx_download_environment")

@@ -450,6 +450,41 @@ class SSGIPass:
         pass
 
 
+NearestFilter, LinearFilter, LinearMipmapLinearFilter = 1003, 1006, 1008
+
+
+class CubeToEquirectEnvPass:
+    """src/ssgi/pass/CubeToEquirectEnvPass.js: `scene.environment` given as a CubeTexture is rendered into an equirectangular FloatType
+    target (one textureCube lookup per texel), read back, and continues as a DataTexture.  The cube as dumped state: an object/dict with
+    `isCubeTexture`, `faces` ((6, S, S, 4) float32 linear values, +X -X +Y -Y +Z -Z, row j = t as uploaded), and the two sampler fields
+    the lookup depends on: `minFilter` (default LinearMipmapLinearFilter, three's Texture default) and `generateMipmaps` (default True)."""
+
+    def generateEquirectEnvMap(self, renderer, cubeMap, width=None, height=None, maxWidth=4096):
+        get = (lambda k, d=None: cubeMap.get(k, d)) if isinstance(cubeMap, dict) else (lambda k, d=None: getattr(cubeMap, k, d))
+        faces = np.ascontiguousarray(get("faces"), np.float32)
+        if width is None and height is None:  # :62-69
+            w = faces.shape[1]
+            width = int(2 ** math.ceil(math.log2(2 * w * 3 ** 0.5)))
+            height = int(2 ** math.ceil(math.log2(w * 3 ** 0.5)))
+        if width > maxWidth:  # :71-74
+            width, height = maxWidth, maxWidth // 2
+        min_filter = get("minFilter", LinearMipmapLinearFilter)
+        if min_filter == LinearMipmapLinearFilter:
+            if not get("generateMipmaps", True):
+                raise ValueError("CubeToEquirectEnvPass: a LinearMipmapLinearFilter cube texture without generated mipmaps is incomplete (samples black)")
+            mips = True
+        elif min_filter == LinearFilter:
+            mips = False
+        else:
+            raise NotImplementedError("CubeToEquirectEnvPass: cube minFilter %r — LinearFilter and LinearMipmapLinearFilter are built" % (min_filter,))
+        data = renderer.cube_to_equirect(faces, width, height, generate_mipmaps=mips)  # render + readRenderTargetPixels :76-85
+        # :87-97 DataTexture(pixelBuffer, width, height, RGBAFormat, FloatType), ClampToEdge, EquirectangularReflectionMapping
+        return dict(data=data, type=FloatType, generateMipmaps=False, isCubeTexture=False)
+
+    def dispose(self):
+        pass
+
+
 class SSGIEffect:
     """src/ssgi/SSGIEffect.js:27-439 — owns SSGIPass + Denoiser, reactive options."""
 
@@ -574,8 +609,11 @@ class SSGIEffect:
         if env is not None:
             if self.__dict__.get("_env_uuid") is not env:
                 get = (lambda k, d=None: env.get(k, d)) if isinstance(env, dict) else (lambda k, d=None: getattr(env, k, d))
-                if get("isCubeTexture"):
-                    raise NotImplementedError("cube environment maps (CubeToEquirectEnvPass, :316-321) are not built: pass an equirectangular map")
+                if get("isCubeTexture"):  # :316-321 convert it to an equirectangular texture so the pass can sample it and use MIS
+                    if self.__dict__.get("cubeToEquirectEnvPass") is None:
+                        object.__setattr__(self, "cubeToEquirectEnvPass", CubeToEquirectEnvPass())
+                    converted = self.cubeToEquirectEnvPass.generateEquirectEnvMap(renderer, env)
+                    get = lambda k, d=None: converted.get(k, d)  # noqa: E731
                 t = get("type", HalfFloatType)
                 data = np.ascontiguousarray(get("data"), np.float32)
                 renderer.set_environment(data, half_float_type=(t == HalfFloatType), half_store_rtz=self._half_store_rtz)

@@ -168,6 +168,45 @@ def run_pack(name, W, H):
     print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
 
 
+def synthetic_cube(S, seed=21):
+    """An HDR cube environment: per-face sky gradient, a sun blob on +Y that spills over the edges onto its neighbours, a checker on -Z and
+    texel noise everywhere (every face, edge and corner carries contrast)."""
+    rng = np.random.RandomState(seed)
+    g = (np.arange(S, dtype=np.float32) + 0.5) / S * 2 - 1
+    a, b = np.meshgrid(g, g)  # a = sc / ma along i, b = tc / ma along j
+    one = np.ones_like(a)
+    dirs = [(one, -b, -a), (-one, -b, a), (a, one, b), (a, -one, -b), (a, -b, one), (-a, -b, -one)]
+    faces = np.zeros((6, S, S, 4), np.float32)
+    sun = np.array([0.35, 0.8, 0.45], np.float32)
+    sun /= np.linalg.norm(sun)
+    for f, (x, y, z) in enumerate(dirs):
+        n = np.sqrt(x * x + y * y + z * z)
+        x, y, z = x / n, y / n, z / n
+        sky = 0.3 + 0.7 * np.clip(y, 0, 1)
+        faces[f, ..., 0] = 0.4 * sky + 0.05 * (1 + x)
+        faces[f, ..., 1] = 0.6 * sky + 0.05 * (1 + z)
+        faces[f, ..., 2] = 1.0 * sky
+        c = np.clip(x * sun[0] + y * sun[1] + z * sun[2], 0, 1)
+        faces[f, ..., :3] += (40.0 * c ** 64)[..., None] * np.array([1.0, 0.9, 0.7], np.float32)
+        faces[f, ..., 3] = 1.0
+    faces[5, ..., :3] *= (0.6 + 0.4 * ((np.floor((a + 1) * 3) + np.floor((b + 1) * 3)) % 2))[..., None]
+    faces[..., :3] *= (0.9 + 0.2 * rng.rand(6, S, S, 1)).astype(np.float32)
+    return faces.astype(np.float32)
+
+
+def run_cube(name, S):
+    """CubeToEquirectEnvPass (src/ssgi/pass/CubeToEquirectEnvPass.js) on llvmpipe: the cube sampled LinearFilter (no mip chain) and as a
+    three CubeTexture by default (LinearMipmapLinearFilter over glGenerateMipmap's chain), at generateEquirectEnvMap's own target size."""
+    faces = synthetic_cube(S)
+    W, H = chain.cube_equirect_size(S)
+    out = dict(size=S, width=W, height=H, faces=faces, gl_info=chain.GL.info())
+    out["equirect_linear"] = chain.run_cube_to_equirect(faces, W, H, False)
+    out["equirect_mipmapped"] = chain.run_cube_to_equirect(faces, W, H, True)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KiB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     run("chain_160x90_s20r5_it1", 160, 90, frames=3, steps=20, refine=5, iterations=1)
     run("chain_97x55_s8r2_it2", 97, 55, frames=2, steps=8, refine=2, iterations=2)
@@ -190,3 +229,4 @@ if __name__ == "__main__":
     run_traa("traa_float_96x54", 96, 54, frames=3, half=False)
     run_final("final_112x63", 112, 63)
     run_pack("pack_96x54", 96, 54)
+    run_cube("cube_32", 32)

@@ -75,6 +75,10 @@ class OracleRenderer:
         self.calls.append(("set_environment", None if rgba is None else tuple(rgba.shape)))
         self.env = None if rgba is None else O.EnvMap(rgba, half=half_float_type, rtz=half_store_rtz)
 
+    def cube_to_equirect(self, faces, width, height, generate_mipmaps=False):
+        self.calls.append(("cube_to_equirect", (tuple(np.shape(faces)), width, height, bool(generate_mipmaps))))
+        return O.cube_to_equirect(faces, width, height, mipmaps=generate_mipmaps)
+
     def set_environment_importance(self, marginal, conditional, total_sum):
         self.calls.append(("set_environment_importance", float(total_sum)))
         self.env.set_importance(marginal, conditional, total_sum)

@@ -399,3 +399,80 @@ def test_node_tiled_renderer_call_sequence_equals_python(tmp_path):
         assert got["tile"] == [ctx.tile_y0, ctx.tile_rows]
         assert got["calls"] == json.loads(json.dumps(ctx.calls)), (rank, world, got["calls"][:12], ctx.calls[:12])
         assert got["exchanges"] == r.exchange_count
+
+
+CUBE_RECORDER = r"""
+const fx = require(process.argv[1] + "/effects")
+const cam = JSON.parse(process.argv[2])
+const calls = []
+const R = {
+  uploadPlane() {}, ssgiMarch(u) { calls.push(["ssgi", u.useEnvMap, u.importanceSampling]) }, temporalReproject() {}, poissonDenoise() {}, compose() {},
+  cubeToEquirect(faces, size, w, h, mips) { calls.push(["cube", faces.length, size, w, h, !!mips]); const o = new Float32Array(w * h * 4); for (let i = 0; i < o.length; i++) o[i] = 0.25 + (i % 7) * 0.125; return o },
+  setEnvironment(data, w, h, half, rtz) { calls.push(["env", data ? data.length : null, w, h, !!half]) },
+  setEnvironmentImportance(m, c, t) { calls.push(["imp", m.length, c.length]) }
+}
+const S = 32
+const scene = { frame: {}, environment: { isCubeTexture: true, faces: new Float32Array(6 * S * S * 4).fill(1), size: S } }
+const e = new fx.SSGIEffect(null, scene, cam, { width: 32, height: 16 }, { ssgi: 10, denoise: 20 })
+e.update(R, null); e.update(R, null)
+scene.environment = { isCubeTexture: true, faces: scene.environment.faces, size: S, minFilter: fx.LinearFilter, generateMipmaps: false }
+e.update(R, null)
+let refused = false
+scene.environment = { isCubeTexture: true, faces: scene.environment.faces, size: S, minFilter: fx.NearestFilter }
+try { e.update(R, null) } catch (err) { refused = /minFilter/.test(err.message) }
+const big = new fx.CubeToEquirectEnvPass().generateEquirectEnvMap({ cubeToEquirect: (f, s, w, h) => new Float32Array(4) }, { faces: null, size: 2048 })
+console.log(JSON.stringify({ calls, refused, big: [big.width, big.height] }))
+"""
+
+
+def test_cube_environment_js_and_python_hosts_issue_the_same_calls():
+    """scene.environment as a CubeTexture (SSGIEffect.js:316-321 -> CubeToEquirectEnvPass.generateEquirectEnvMap): both hosts convert once, at
+    the reference's target size, with the chain three's sampler state implies, and continue with a FloatType equirectangular map."""
+    from rfx_amd.scene import synthetic_frame
+    f = synthetic_frame(32, 16, 0)
+    camd = {k: [float(x) for x in np.asarray(getattr(f.camera, k)).ravel()] for k in
+            ("projectionMatrix", "projectionMatrixInverse", "matrixWorld", "matrixWorldInverse", "position", "quaternion")}
+    camd.update(near=f.camera.near, far=f.camera.far)
+    js = json.loads(subprocess.check_output([node, "-e", CUBE_RECORDER, JS, json.dumps(camd)], cwd=JS, text=True).strip().splitlines()[-1])
+
+    class RecCube(Rec):
+        def ssgi_march(self, p):
+            self.calls.append(["ssgi", p.useEnvMap, p.importanceSampling])
+
+        def temporal_reproject(self, p):
+            pass
+
+        def poisson_denoise(self, p):
+            pass
+
+        def compose(self, p):
+            pass
+
+        def cube_to_equirect(self, faces, w, h, generate_mipmaps=False):
+            self.calls.append(["cube", int(np.asarray(faces).size), int(np.asarray(faces).shape[1]), w, h, bool(generate_mipmaps)])
+            return (0.25 + (np.arange(w * h * 4) % 7) * 0.125).astype(np.float32).reshape(h, w, 4)
+
+        def set_environment(self, data, half_float_type=True, half_store_rtz=True):
+            self.calls.append(["env", None if data is None else int(data.size), data.shape[1], data.shape[0], bool(half_float_type)])
+
+        def set_environment_importance(self, m, c, t):
+            self.calls.append(["imp", int(np.asarray(m).size), int(np.asarray(c).size)])
+
+    S = 32
+    faces = np.ones((6, S, S, 4), np.float32)
+    scene = types.SimpleNamespace(frame=f, environment=dict(isCubeTexture=True, faces=faces))
+    fx = effect.SSGIEffect(None, scene, f.camera, dict(width=32, height=16), seeds=dict(ssgi=10, denoise=20))
+    r = RecCube()
+    fx.update(r, None)
+    fx.update(r, None)
+    scene.environment = dict(isCubeTexture=True, faces=faces, minFilter=effect.LinearFilter, generateMipmaps=False)
+    fx.update(r, None)
+    scene.environment = dict(isCubeTexture=True, faces=faces, minFilter=effect.NearestFilter)
+    with pytest.raises(NotImplementedError):
+        fx.update(r, None)
+    assert js["refused"] is True
+    assert js["calls"] == json.loads(json.dumps(r.calls))
+    assert ["cube", 6 * S * S * 4, S, 128, 64, True] in js["calls"] and ["cube", 6 * S * S * 4, S, 128, 64, False] in js["calls"]
+    assert js["big"] == [4096, 2048]  # maxWidth (:71-74)
+    assert effect.CubeToEquirectEnvPass().generateEquirectEnvMap(types.SimpleNamespace(cube_to_equirect=lambda fa, w, h, generate_mipmaps: np.zeros((h, w, 4), np.float32)),
+                                                                 dict(faces=np.zeros((6, 2048, 1, 4), np.float32)))["data"].shape == (2048, 4096, 4)

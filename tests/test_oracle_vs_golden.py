@@ -709,3 +709,61 @@ def test_stagewise_strict_metric_every_flip_proven(name, blue_noise):
         print(r.line())
     assert all(r.unexplained == 0 for r in reports), "\n".join(r.line() for r in reports if r.unexplained)
     assert all(r.bad <= 0.01 * r.pixels for r in reports)
+
+
+def _within(a, b):
+    """the fp32-output rule of tests/parity.py on raw arrays: |a - b| <= 1e-3 or <= 1e-5 |b|"""
+    e = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    return (e <= 1e-3) | (e <= 1e-5 * np.abs(b))
+
+
+@pytest.mark.parametrize("mipmaps", [False, True])
+def test_cube_to_equirect_vs_golden(mipmaps):
+    """CubeToEquirectEnvPass (src/ssgi/pass/CubeToEquirectEnvPass.js:21-42) — scene.environment given as a CubeTexture — against the pass's
+    own GLSL on llvmpipe: seamless bilinear cube lookups (edges from the neighbouring face, corners as the average of the three texels that
+    exist), and for three's default CubeTexture (LinearMipmapLinearFilter) glGenerateMipmap's chain and the GL's per-pixel cube level of
+    detail.  No out-of-tolerance texel on an HDR cube with a sun (values to 40) that spills over three faces."""
+    g = G.load("cube_32")
+    S, W, H = int(g["size"]), int(g["width"]), int(g["height"])
+    want = g["equirect_mipmapped" if mipmaps else "equirect_linear"]
+    got = O.cube_to_equirect(g["faces"], W, H, mipmaps=mipmaps)
+    ok = _within(got, want)
+    e = np.abs(got - want)
+    print("cube %d -> %dx%d mipmaps %d: max |err| %.3e, bit-identical %.3f" % (S, W, H, mipmaps, e.max(), (e == 0).mean()))
+    assert ok.all(), "%d texels out of tolerance, max %.3e" % (int((~ok).any(-1).sum()), e.max())
+    if mipmaps:  # the chain matters: the level-0-only lookup is NOT the mipmapped result near the face edges
+        assert not _within(O.cube_to_equirect(g["faces"], W, H, mipmaps=False), want).all()
+
+
+def test_cube_environment_through_the_effect():
+    """SSGIEffect.keepEnvMapUpdated with a CubeTexture (SSGIEffect.js:316-321): converted once through CubeToEquirectEnvPass at
+    generateEquirectEnvMap's size, continues as a FloatType equirectangular DataTexture (mip chain + importance tables built from it)."""
+    import types
+    from oracle_renderer import OracleRenderer
+    from rfx_amd.effect import FloatType, LinearFilter, NearestFilter, SSGIEffect
+
+    gc = G.load("cube_32")
+    g = G.load(G.GOLDEN_ENVMIS)
+    W, H = int(g["width"]), int(g["height"])
+    cube = dict(isCubeTexture=True, faces=np.ascontiguousarray(gc["faces"]))  # three's defaults: LinearMipmapLinearFilter + generateMipmaps
+    scene = types.SimpleNamespace(frame=G.frame(g, 0), environment=cube)
+    cam = G.camera(g, 0)
+    fx = SSGIEffect(None, scene, cam, dict(steps=4, refineSteps=1, denoiseIterations=1, width=W, height=H), seeds=dict(ssgi=1, denoise=2))
+    r = OracleRenderer(W, H)
+    fx.update(r, None)
+    calls = dict((c[0], c[1]) for c in r.calls if c[0] in ("cube_to_equirect", "set_environment", "set_environment_importance"))
+    assert calls["cube_to_equirect"] == ((6, 32, 32, 4), int(gc["width"]), int(gc["height"]), True)
+    assert calls["set_environment"] == (int(gc["height"]), int(gc["width"]), 4) and "set_environment_importance" in calls
+    assert fx.ssgiPass.uniforms.useEnvMap == 1 and fx.ssgiPass.uniforms.importanceSampling == 1
+    # the environment the device holds is the pass's output, stored FloatType (no half rounding of level 0)
+    assert _within(r.env.level(0).reshape(int(gc["height"]), int(gc["width"]), 4), gc["equirect_mipmapped"]).all()
+    r.calls.clear()
+    fx.update(r, None)  # same texture object: nothing is converted or uploaded again
+    assert not [c for c in r.calls if c[0] in ("cube_to_equirect", "set_environment")]
+    # HDRCubeTextureLoader's set-up: LinearFilter, no chain
+    scene.environment = dict(isCubeTexture=True, faces=cube["faces"], minFilter=LinearFilter, generateMipmaps=False)
+    fx.update(r, None)
+    assert [c[1][3] for c in r.calls if c[0] == "cube_to_equirect"] == [False]
+    scene.environment = dict(isCubeTexture=True, faces=cube["faces"], minFilter=NearestFilter)
+    with pytest.raises(NotImplementedError):
+        fx.update(r, None)
