@@ -1,11 +1,17 @@
-"""Probe (this container only — needs oracle/_ref/libglref.so): how does llvmpipe filter `textureCube` lookups, the one operation of
-CubeToEquirectEnvPass (src/ssgi/pass/CubeToEquirectEnvPass.js:21-42)?  Findings that DESIGN.md §6 cites:
+"""Probe (this container only — needs oracle/_ref/libglref.so): how does llvmpipe answer `textureCube` lookups, the one operation of
+CubeToEquirectEnvPass (src/ssgi/pass/CubeToEquirectEnvPass.js:21-42)?  What rfx_oracle.c cube_face / cube_texel / cube_linear / cube_lod restate:
 
-  * face selection and (s, t) follow the GL table exactly (NEAREST lookups of an index cube: 100 % as modelled);
-  * LINEAR lookups fed with llvmpipe's own direction vectors differ from the exact fp32 bilinear blend of the (seamlessly wrapped) texels:
-    the filter position is off by up to ~0.011 texel and the weights sit on a 1/256 grid (8-bit weights + an approximate reciprocal of the
-    major axis) -> a value error of up to ~0.011 x the local texel contrast, unbounded for an HDR cube; no bit-level restatement exists
-    short of emulating the host CPU's rcpps.
+  * face selection and (s, t) follow the GL table; (s, t) = (sc * (1 / ma)) * 0.5 + 0.5 reproduces the filter position of LINEAR lookups
+    BIT-EXACTLY on every interior position (this probe, "LINEAR");
+  * seamless edges: a footprint texel beyond the face edge is the neighbouring face's texel; beyond a corner: the average of the three texels
+    that exist; blend = fused lerp in x, then in y (tests/test_oracle_vs_golden.py::test_cube_to_equirect_vs_golden pins the whole pass);
+  * a mipmapped cube (three's CubeTexture default): the level of detail is PER PIXEL, from the direction differences within the pixel's own
+    row / own column of its 2x2 quad, through the quotient rule on the pixel's own face, then the linear-mantissa log2 — reproduced to < 1e-6
+    in lod on a chain whose level l holds the constant l (this probe, "LOD").
+
+Round 1's version of this probe concluded "8-bit weights and an approximate reciprocal: no restatement exists".  That was the probe, not the
+GL: its shaders lacked `precision highp samplerCube;`, GLSL ES defaults samplers to lowp, and Mesa lowers a lowp fetch to fp16 — every
+fetched value was rounded to 11 bits.  No GPU runs the pass that way; with the qualifier the lookup is plain fp32.
 
     python oracle/glref/probes/probe_cube.py
 """
@@ -48,7 +54,8 @@ def face_coords(d):
     sc = np.choose(face, [-z, z, x, x, x, -x])
     tc = np.choose(face, [-y, -y, z, -z, -y, -y])
     ma = np.choose(face, [ax[..., 0], ax[..., 0], ax[..., 1], ax[..., 1], ax[..., 2], ax[..., 2]])
-    return face, (f32(0.5) * (sc / ma + f32(1))).astype(f32), (f32(0.5) * (tc / ma + f32(1))).astype(f32)
+    ima = (f32(1) / ma).astype(f32)
+    return face, ((sc * ima) * f32(0.5) + f32(0.5)).astype(f32), ((tc * ima) * f32(0.5) + f32(0.5)).astype(f32)
 
 
 def main():
@@ -82,9 +89,52 @@ def main():
     inside = (np.floor(u) >= 0) & (np.floor(u) + 1 < S) & (np.floor(v) >= 0) & (np.floor(v) + 1 < S)
     du, dv = (r[..., 0] - u)[inside], (r[..., 1] - v)[inside]
     q = r[..., 0][inside] * 256
-    print("LINEAR: filter position off by up to %.4f / %.4f texel (u / v); %.0f %% of the positions sit on the 1/256 grid" % (
-        np.abs(du).max(), np.abs(dv).max(), 100 * (np.abs(q - np.round(q)) < 1e-3).mean()))
+    print("LINEAR: filter position off by up to %.2e / %.2e texel (u / v), bit-exact on %.2f %% of the interior positions" % (
+        np.abs(du).max(), np.abs(dv).max(), 100 * ((du == 0) & (dv == 0)).mean()))
+
+
+def lod_probe():
+    W, H, S = 256, 128, 64
+    pd = Program(HEAD + DIRS + "void main() { o = vec4(direction(), 1.); }")
+    dirs = Tex(W, H, 0)
+    pd.draw([dirs])
+    d = dirs.read()[..., :3].astype(np.float64)
+    pl = Program(HEAD + DIRS + "void main() { o = texture(cubeMap, direction()); }")
+    out = Tex(W, H, 0)
+    ct = CubeTex(S, 0, 3, np.zeros((6, S, S, 4), f32))  # mipmap filters, no generation: level l is uploaded as the constant l
+    lv, s_ = 0, S
+    while True:
+        for f in range(6):
+            data = np.full((s_, s_, 4), float(lv), f32)
+            GL.lib().glref_cube_upload_level(ct.id, f, lv, data.ctypes.data_as(ctypes.c_void_p))
+        if s_ == 1:
+            break
+        s_, lv = max(s_ >> 1, 1), lv + 1
+    pl.sampler("cubeMap", ct)
+    pl.draw([out])
+    lod = out.read()[..., 0]
+    face, _, _ = face_coords(d.astype(f32))
+
+    def comps(f, p):
+        x, y, z = p
+        return [(-z, -y, x), (z, -y, -x), (x, z, y), (x, -z, -y), (x, -y, z), (-x, -y, -z)][f]
+    model = np.zeros((H, W))
+    for y in range(H):
+        for x in range(W):
+            p = d[y, x]
+            ddx = d[y, x | 1] - d[y, x & ~1]
+            ddy = d[y | 1, x] - d[y & ~1, x]
+            f = int(face[y, x])
+            sc, tc, ma = comps(f, p)
+            xsc, xtc, xma = comps(f, ddx)
+            ysc, ytc, yma = comps(f, ddy)
+            k = 0.5 / (ma * ma)
+            r2 = max(((xsc * ma - sc * xma) * k) ** 2 + ((xtc * ma - tc * xma) * k) ** 2, ((ysc * ma - sc * yma) * k) ** 2 + ((ytc * ma - tc * yma) * k) ** 2) * S * S
+            m, e = np.frexp(r2)
+            model[y, x] = min(max(0.5 * ((e - 1) + (2 * m - 1)), 0.0), 6.0)
+    print("LOD: range %.3f .. %.3f over a %dx%d target of a %d^2 cube; model vs GL max |diff| %.2e" % (lod.min(), lod.max(), W, H, S, np.abs(model - lod).max()))
 
 
 if __name__ == "__main__":
     main()
+    lod_probe()
