@@ -171,6 +171,7 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
         error (n_perturb seeded runs).  Only the pixels of `bad | sample` are evaluated AND compared (an 8K stage output is 0.5-1 GB)."""
         if ora is None:
             return None, None
+        diag.clear()
         mask = bad | sample
         sel = np.flatnonzero(mask)
 
@@ -226,15 +227,14 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
             got, want = O.half_bits_to_float(got), O.half_bits_to_float(want)
         r = strict(name, got, want, explainable=m, half=half)
         r.at_risk = at_risk
-        if r.unexplained and "oracle_at_unexplained" in diag:
-            idx, obase, omargin = diag.pop("oracle_at_unexplained")
+        if r.unexplained and "oracle_at_unexplained" in diag:  # (kept for the stage's other outputs: margins_of clears it)
+            idx, obase, omargin = diag["oracle_at_unexplained"]
             g, w = as_float(got), as_float(want)
             for k, (y, x) in enumerate(idx):
                 c = slice(0, g.shape[-1]) if obase.shape[-1] == g.shape[-1] else slice(0, 0)
                 log("    unexplained (y %d, x %d) margin %.3g\n      impl   %s\n      ref    %s\n      oracle %s" % (
                     y, x, omargin[k], np.array2string(g[y, x], precision=6), np.array2string(w[y, x], precision=6),
                     np.array2string(obase[k], precision=6)))
-        diag.clear()
         reports.append(r)
         log(r.line())
         return r
