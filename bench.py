@@ -286,6 +286,7 @@ def main():
     ap.add_argument("--cpu-port", action="store_true", help="also time the C restatement (OpenMP) as a second, non-GL CPU line (+10 s)")
     ap.add_argument("--checksum", action="store_true", help="add sha1 of the final whole-frame composed GI to the JSON line (tiled == single check)")
     ap.add_argument("--exchange", choices=("c", "torch"), default="c", help="N > 1: exchanges through the C ABI's RCCL entry points (default) or torch.distributed")
+    ap.add_argument("--extras-timeout", type=int, default=480, help="seconds the N > 1 extras (weak scaling, configs[4]) may take before the headline line is printed without them")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: only the headline case (skip the weak-scaling and configs[4] extras)")
     args = ap.parse_args()
 
@@ -359,33 +360,10 @@ def main():
     rows, halo = case["rows"], case["halo"]
 
     extras = {}
-    if world > 1 and not args.no_extras:
-        ctx.close()
-        case = None
-        try:
-            # (a) weak scaling, the round-1 headline: the frame grows with N at constant aspect, every rank owns 8.29 Mpixel
-            Ww = int(round(W1 * world ** 0.5 / 64.0)) * 64
-            Ht = int(W1 * H1 / Ww) & ~1
-            wtiles = [(r * Ht, Ht) for r in range(world)]
-            if wtiles == tiling.split_rows(Ht * world, world):
-                wcase = build_case(world, rank, local_rank, dev, dist, one_gpu, Ww, Ht * world, wtiles, 20, 5, 1, use_c=use_c, group=group)
-                wdt = time_case(wcase, dist, args.steps, args.warmup, dev)
-                extras["weak_scaling"] = {"frame": "%dx%d" % (Ww, Ht * world), "tile_rows": Ht, "halo_rows": wcase["halo"], "ms_per_step": round(wdt / args.steps * 1e3, 4),
-                                          "value": round(Ww * Ht * world * args.steps / wdt / 1e6, 2), "unit": "Mpixels/s",
-                                          "halo_violations": wcase["ctx"].halo_violations()}
-                wcase["ctx"].close()
-            # (b) BASELINE configs[4]: 8K, steps 40, denoiseIterations 3, row-tiled (the 16-frame sequence re-renders one dumped frame)
-            c4 = build_case(world, rank, local_rank, dev, dist, one_gpu, 7680, 4320, tiling.split_rows(4320, world), 40, 5, 3, use_c=use_c, group=group)
-            n4 = max(4, min(args.steps, 16))
-            d4 = time_case(c4, dist, n4, 2, dev)
-            extras["configs4_8k"] = {"frame": "7680x4320", "steps": 40, "refineSteps": 5, "denoiseIterations": 3, "frames_timed": n4, "halo_rows": c4["halo"],
-                                     "ms_per_frame": round(d4 / n4 * 1e3, 4), "value": round(7680 * 4320 * n4 / d4 / 1e6, 2), "unit": "Mpixels/s",
-                                     "halo_violations": c4["ctx"].halo_violations()}
-            c4["ctx"].close()
-        except Exception as e:  # noqa: BLE001  the headline case above is already measured: report it, and what stopped the extras
-            extras["extras_error"] = repr(e)[:300]
 
-    if rank == 0:
+    def emit():
+        if rank != 0:
+            return
         px_tile = W1 * rows
         dom = max(kms, key=kms.get)
         achieved = BYTES_PER_PX[dom] * px_tile / (kms[dom] * 1e-3) / 1e9
@@ -439,6 +417,47 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(case["frame"], case["fx"], W1, H1, args.cpu_sample_rows, args.cpu_port)
         print(json.dumps(out), flush=True)
+
+    if world > 1 and not args.no_extras:
+        ctx.close()
+        case = None
+        # the headline is measured: a collective that hangs in the extras (their first run on a real multi-GPU node is the driver's) must
+        # not cost the line.  After --extras-timeout seconds rank 0 prints what it has and every rank leaves.
+        import threading
+
+        def give_up():
+            extras["extras_error"] = "timed out after %d s (a hung collective?); done so far: %s" % (args.extras_timeout, sorted(extras))
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+        watchdog = threading.Timer(args.extras_timeout + (0 if rank == 0 else 5), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            # (a) weak scaling, the round-1 headline: the frame grows with N at constant aspect, every rank owns 8.29 Mpixel
+            Ww = int(round(W1 * world ** 0.5 / 64.0)) * 64
+            Ht = int(W1 * H1 / Ww) & ~1
+            wtiles = [(r * Ht, Ht) for r in range(world)]
+            if wtiles == tiling.split_rows(Ht * world, world):
+                wcase = build_case(world, rank, local_rank, dev, dist, one_gpu, Ww, Ht * world, wtiles, 20, 5, 1, use_c=use_c, group=group)
+                wdt = time_case(wcase, dist, args.steps, args.warmup, dev)
+                extras["weak_scaling"] = {"frame": "%dx%d" % (Ww, Ht * world), "tile_rows": Ht, "halo_rows": wcase["halo"], "ms_per_step": round(wdt / args.steps * 1e3, 4),
+                                          "value": round(Ww * Ht * world * args.steps / wdt / 1e6, 2), "unit": "Mpixels/s",
+                                          "halo_violations": wcase["ctx"].halo_violations()}
+                wcase["ctx"].close()
+            # (b) BASELINE configs[4]: 8K, steps 40, denoiseIterations 3, row-tiled (the 16-frame sequence re-renders one dumped frame)
+            c4 = build_case(world, rank, local_rank, dev, dist, one_gpu, 7680, 4320, tiling.split_rows(4320, world), 40, 5, 3, use_c=use_c, group=group)
+            n4 = max(4, min(args.steps, 16))
+            d4 = time_case(c4, dist, n4, 2, dev)
+            extras["configs4_8k"] = {"frame": "7680x4320", "steps": 40, "refineSteps": 5, "denoiseIterations": 3, "frames_timed": n4, "halo_rows": c4["halo"],
+                                     "ms_per_frame": round(d4 / n4 * 1e3, 4), "value": round(7680 * 4320 * n4 / d4 / 1e6, 2), "unit": "Mpixels/s",
+                                     "halo_violations": c4["ctx"].halo_violations()}
+            c4["ctx"].close()
+        except Exception as e:  # noqa: BLE001  the headline case above is already measured: report it, and what stopped the extras
+            extras["extras_error"] = repr(e)[:300]
+        watchdog.cancel()
+
+    emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
