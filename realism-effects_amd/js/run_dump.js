@@ -7,6 +7,7 @@
 // input buffer (HalfFloatType / FloatType), and writes traa.bin (traa_compose output, RGBA32F) of the last frame.
 // --png <file> [--tonemap '"aces"'|'"linear"' --exposure X] / --exr <file> / --pfm <file>: also write final.bin as an image (tone-mapped
 // 8-bit sRGB PNG; scene-linear float OpenEXR / PFM) — js/imageio.js.
+// --uvModel '"reference_gl"': the reference GL's own vUv instead of (i + 0.5) / n (parity runs against the reference on llvmpipe).
 // --stream true: the dumps cross PCIe on the context's upload stream from pinned planes, frame n+1 while frame n is drawn
 // (rfx_stage_upload / rfx_stage_flip); same outputs.
 // With --ranks N (N > 1): the frame is cut into N row tiles, ONE NODE PROCESS PER GPU (this process spawns them: rank r drives
@@ -110,6 +111,8 @@ if (tiled) {
 	}
 	renderer = new rfx.TiledRenderer(first.width, first.height, tiled.rank, tiled.ranks, halo, id, { device: process.env.RFX_ONE_GPU === "1" ? 0 : tiled.rank })
 } else renderer = new rfx.Renderer(first.width, first.height)
+// --uvModel '"reference_gl"': every fragment sees the vUv the reference GL's rasteriser interpolates (rfx_set_uv_model) instead of (i + 0.5) / n
+if (opt.uvModel) (renderer.inner || renderer).setUvModel(opt.uvModel)
 if (opt.traa) {
 	const half = opt.traa === "half"
 	const traa = new rfx.TRAAEffect(scene, camera, new rfx.VelocityDepthNormalPass(scene, camera), { fullAccumulate: true }, true)
