@@ -767,3 +767,23 @@ def test_cube_environment_through_the_effect():
     scene.environment = dict(isCubeTexture=True, faces=cube["faces"], minFilter=NearestFilter)
     with pytest.raises(NotImplementedError):
         fx.update(r, None)
+
+
+@pytest.mark.parametrize("mipmaps", [False, True])
+def test_cube_to_equirect_properties(mipmaps):
+    """Size-independent properties of the cube lookup: a constant cube converts to that constant EXACTLY (the seamless weights — edges,
+    corners, two mip levels — always sum to one in fp32 lerp form), per-face constants come back as values inside the hull of the faces a
+    footprint can touch, and the six axis directions return the centre of their faces."""
+    for S, W, H in ((1, 8, 4), (4, 32, 16), (64, 256, 128), (6, 50, 26)):
+        if mipmaps and S & (S - 1):
+            continue
+        c = np.empty((6, S, S, 4), np.float32)
+        c[...] = np.array([0.3, 7.25, 1e-3, 1.0], np.float32)
+        out = O.cube_to_equirect(c, W, H, mipmaps=mipmaps)
+        assert (out == c[0, 0, 0]).all(), (S, np.abs(out - c[0, 0, 0]).max())
+        ids = np.zeros((6, S, S, 4), np.float32)
+        ids[..., 0] = np.arange(6, dtype=np.float32)[:, None, None]
+        out = O.cube_to_equirect(ids, W, H, mipmaps=mipmaps)[..., 0]
+        assert out.min() >= 0.0 and out.max() <= 5.0
+        # the pass's direction at vUv: the centre row looks at the horizon, column u = 0.25 / 0.5 / 0.75 / 0 at -Z... check through +Y / -Y rows
+        assert np.allclose(out[-1], 2.0, atol=0.51) and np.allclose(out[0], 3.0, atol=0.51)  # top rows see +Y (dir.y = -cos(lat) -> +1 at v = 1), bottom rows -Y

@@ -40,6 +40,11 @@ def test_cube_to_equirect_vs_oracle_and_reference(mipmaps):
         w2, h2 = 4 * max(S, 8), 2 * max(S, 8)
         a, b = ctx.cube_to_equirect(f2, w2, h2, generate_mipmaps=mipmaps), O.cube_to_equirect(f2, w2, h2, mipmaps=mipmaps)
         assert _within(a, b).all(), (S, np.abs(a - b).max())
+    # a constant cube converts to that constant exactly, whatever the face size (edges, corners and both mip levels blend weights that sum to one)
+    for S in ((1, 7, 256) if not mipmaps else (2, 256)):
+        c = np.empty((6, S, S, 4), np.float32)
+        c[...] = np.array([0.3, 7.25, 1e-3, 1.0], np.float32)
+        assert (ctx.cube_to_equirect(c, 64, 32, generate_mipmaps=mipmaps) == c[0, 0, 0]).all(), S
     ctx.close()
 
 
