@@ -154,6 +154,8 @@ static inline void margin_cmp(float a, float b, float rel) {
 #define MARGIN_REL_MARCH 1e-6f   /* ray position after <= 40 accumulated steps of dir * (1 - exp(..)), projected */
 #define MARGIN_REL_SHORT 4e-6f   /* a handful of fp32 operations incl. one transcendental */
 #define MARGIN_REL_WEIGHT 1e-4f  /* products of exp(-phi * diff): the exponents reach ~10 and carry their own rounding */
+#define MARGIN_REL_CURVATURE 2e-5f /* length(fwidth(normal)) against 0.05: a sum of |differences of unit-vector components| — each component carries
+                                   * ~1e-7 ABSOLUTE (oct decode + normalize), six of them against a threshold of 0.05: ~1e-5 relative, not a few ulps */
 
 static _Thread_local float g_unc_dir = 4e-7f; /* absolute uncertainty of the direction the next calc_angles() receives (set by the sampler) */
 
@@ -231,12 +233,17 @@ static inline uint16_t float_to_half_rtz(float f) {
 /* texel-boundary margin of a nearest fetch at coordinate c (texels): the coordinate carries a few ulps of its own magnitude
  * plus whatever its inputs carry (rel_in, relative to the OFFSET that was added to a pixel centre, passed in texels) */
 static _Thread_local float g_fetch_rel = 0.0f, g_fetch_abs = 0.0f; /* what the coordinate's INPUTS carry (set by the caller that knows) */
+/* ... and what a coordinate that was FORMED in uv space carries whatever its size in texels: u = ndc * 0.5 + 0.5 (a projected point) or
+ * u = vUv - velocity is rounded at the magnitude of 1, i.e. a few 2^-24 ABSOLUTE in uv = g_fetch_uv * size texels — near the left / bottom
+ * edge (small c) far more than any relative model of c allows.  (While the fragments' vUv itself is uncertain, uv_err() below carries the
+ * same kind of term; under the reference vUv model it is zero and this one is what remains.) */
+static _Thread_local float g_fetch_uv = 0.0f;
 static inline void margin_texel(float c, int size) {
     if (!(c > 0.0f && c < (float)size)) return; /* clamped region: flat */
     float fl = floorf(c), fr = c - fl;
     float dlo = fl >= 1.0f ? fr : 3.0e38f;                      /* the boundary at fl exists unless it is the clamp at 0 */
     float dhi = fl <= (float)(size - 2) ? 1.0f - fr : 3.0e38f;  /* the boundary at fl + 1 exists unless it is the clamp at size */
-    float scale = (4.0f * 1.1920929e-7f + g_fetch_rel) * fabsf(c) + g_fetch_abs + uv_err() * (float)size; /* the rasteriser's vUv error in texels scales with the texture size */
+    float scale = (4.0f * 1.1920929e-7f + g_fetch_rel) * fabsf(c) + g_fetch_abs + (uv_err() + g_fetch_uv) * (float)size; /* the rasteriser's vUv error in texels scales with the texture size */
     margin_note(fminf(dlo, dhi) / fmaxf(scale, 1e-30f));
 }
 static inline int nearest_idx(float u, int size) {
@@ -1067,7 +1074,7 @@ int rfxo_ssgi(int W, int H, int y0, int y1, const float *depth, const uint32_t *
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < oW; x++) {
             if (g_pixel_mask && !g_pixel_mask[(size_t)y * oW + x]) continue;
-            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
+            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; g_fetch_uv = 0.0f; pert_begin(x, y);
             k1_pixel(&c, x, y, out + 4 * ((size_t)y * oW + x));
             if (g_margin_plane) g_margin_plane[(size_t)y * oW + x] = g_margin;
         }
@@ -1206,11 +1213,13 @@ static void k2_pixel(const k2_ctx *c, int x, int y, float *out0, float *out1) {
     /* computeReprojectedUv temporal_reproject.frag:155-165 */
     float rd[3], rs[3] = {-1.0f, -1.0f, -1.0f};
     rd[0] = u - velx; rd[1] = v - vely;
+    g_fetch_uv = 1.1920929e-7f; /* one subtraction at the magnitude of 1 */
     rd[2] = k2_validate(c, rd[0], rd[1], worldPos, worldNormal, depth);
+    g_fetch_uv = 0.0f;
     if (p->inputType == 0 || p->inputType == 2) {
         /* reprojectHitPoint reproject.frag:169-193 */
         float hu, hv;
-        margin_cmp(curvature, 0.05f, MARGIN_REL_SHORT);
+        margin_cmp(curvature, 0.05f, MARGIN_REL_CURVATURE);
         if (curvature > 0.05f || rayLength < 0.01f) { hu = -1.0f; hv = -1.0f; }
         else {
             v3 camPos = V3(p->camera.position[0], p->camera.position[1], p->camera.position[2]);
@@ -1225,11 +1234,12 @@ static void k2_pixel(const k2_ctx *c, int x, int y, float *out0, float *out1) {
                                         A[3 * 4 + row] * Bm[col * 4 + 3];
             v4 r = mat_mul_v4(PV, hp.x, hp.y, hp.z, 1.0f);
             hu = (r.x / r.w) * 0.5f + 0.5f; hv = (r.y / r.w) * 0.5f + 0.5f;
-            g_fetch_rel = MARGIN_REL_SHORT; /* the validation fetch sits at a projected point (normalize, two matrix products, a division) */
+            g_fetch_rel = MARGIN_REL_SHORT; /* the validation fetch sits at a projected point (normalize, two matrix products, a division) ... */
+            g_fetch_uv = 4.0f * 1.1920929e-7f; /* ... whose ndc -> uv step rounds at the magnitude of 1 */
         }
         rs[0] = hu; rs[1] = hv;
         rs[2] = k2_validate(c, hu, hv, worldPos, worldNormal, depth);
-        g_fetch_rel = 0.0f;
+        g_fetch_rel = 0.0f; g_fetch_uv = 0.0f;
         if (rs[0] == -1.0f) { rs[0] = rd[0]; rs[1] = rd[1]; rs[2] = rd[2]; }
     }
     float moveFactor = fminf((velx * velx + vely * vely) * 10000.0f, 1.0f);
@@ -1303,7 +1313,7 @@ int rfxo_temporal(int W, int H, int y0, int y1, const uint32_t *ssgi, const uint
         for (int x = 0; x < W; x++) {
             size_t o = 4 * ((size_t)y * W + x);
             if (g_pixel_mask && !g_pixel_mask[(size_t)y * W + x]) continue;
-            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
+            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; g_fetch_uv = 0.0f; pert_begin(x, y);
             k2_pixel(&c, x, y, out0 + o, out1 ? out1 + o : NULL);
             if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
         }
@@ -1417,7 +1427,7 @@ int rfxo_denoise(int W, int H, int y0, int y1, const float *depth, const uint32_
         for (int x = 0; x < W; x++) {
             size_t o = 4 * ((size_t)y * W + x);
             if (g_pixel_mask && !g_pixel_mask[(size_t)y * W + x]) continue;
-            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
+            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; g_fetch_uv = 0.0f; pert_begin(x, y);
             k3_pixel(&c, x, y, out0 + o, out1 ? out1 + o : NULL);
             if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
         }
@@ -1438,7 +1448,7 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < W; x++) {
             if (g_pixel_mask && !g_pixel_mask[(size_t)y * W + x]) continue;
-            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; pert_begin(x, y);
+            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; g_fetch_uv = 0.0f; pert_begin(x, y);
             if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
             float u = pert_uv(frag_u(x, y, W, H)), v = pert_uv(frag_v(y, W, H));
             float dep = fetch_r32f(depth, d, u, v);

@@ -1,0 +1,175 @@
+// tests/hostsim/hip/hip_runtime.h — TEST INFRASTRUCTURE.  A host stand-in for <hip/hip_runtime.h> that lets the product's own kernel
+// sources (realism-effects_amd/csrc/*.hip, unmodified except for the five textual substitutions listed in tests/hostsim/Makefile) be
+// compiled for x86 and executed thread by thread on the CPU: `librfx_hostsim.so` exports the same C ABI as librfx_hip.so, so the `-m gpu`
+// tests can exercise the kernels' LOGIC (indexing, tiles and aprons, launch shapes, the C ABI's state handling) in a container without a
+// GPU.  It is NOT a fallback: nothing under realism-effects_amd/ knows it exists, it is built and loaded only by tests that ask for it
+// (RFX_HIP_LIB), it is ~1000x slower than the device, and the hardware transcendentals are replaced by libm (so it says nothing about the
+// device's bits — only about the program's structure).
+//
+// Execution model: hipLaunchKernelGGL runs the blocks of a grid on OpenMP threads; inside a block the threads run one after the other.
+// A kernel with ONE __syncthreads() (K2, K3: stage a tile, barrier, compute) is run in two phases: phase 0 executes every thread up to the
+// barrier (longjmp out of it), phase 1 re-executes every thread from the top with the barrier a no-op — correct because what precedes the
+// barrier is an idempotent, thread-private set of LDS stores.  Kernels that use wave shuffles (k1_prepare) are substituted in the Makefile.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <csetjmp>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __constant__ static
+#define __shared__ static thread_local
+#define __restrict__
+
+// ---------------------------------------------------------------- vector types
+struct alignas(8) float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) uint2 { unsigned int x, y; };
+struct alignas(16) uint4 { unsigned int x, y, z, w; };
+struct alignas(8) int2 { int x, y; };
+struct uchar4 { unsigned char x, y, z, w; };
+struct dim3 {
+    unsigned int x, y, z;
+    dim3(unsigned int x_ = 1, unsigned int y_ = 1, unsigned int z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline uint2 make_uint2(unsigned int x, unsigned int y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned int x, unsigned int y, unsigned int z, unsigned int w) { return uint4{x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char z, unsigned char w) { return uchar4{x, y, z, w}; }
+
+// ---------------------------------------------------------------- execution state
+struct hostsim_idx { unsigned int x, y, z; };
+extern thread_local hostsim_idx threadIdx, blockIdx, blockDim, gridDim;
+extern thread_local int hostsim_phase;          // 0: run to the barrier; 1: barrier is a no-op
+extern thread_local std::jmp_buf hostsim_barrier;
+extern thread_local unsigned char *hostsim_lds;  // dynamic shared memory of the running block
+static inline void __syncthreads() {
+    if (hostsim_phase == 0) std::longjmp(hostsim_barrier, 1);
+}
+template <class F>
+static void hostsim_launch(dim3 grid, dim3 block, size_t shmem, F body) {
+    const long nblocks = (long)grid.x * grid.y * grid.z;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long b = 0; b < nblocks; b++) {
+        static thread_local unsigned char *lds = nullptr;
+        static thread_local size_t lds_size = 0;
+        if (shmem > lds_size) { std::free(lds); lds = (unsigned char *)std::aligned_alloc(64, (shmem + 63) & ~(size_t)63); lds_size = shmem; }
+        hostsim_lds = lds;
+        gridDim = {grid.x, grid.y, grid.z};
+        blockDim = {block.x, block.y, block.z};
+        blockIdx = {(unsigned int)(b % grid.x), (unsigned int)((b / grid.x) % grid.y), (unsigned int)(b / ((long)grid.x * grid.y))};
+        for (int phase = 0; phase < 2; phase++) {
+            hostsim_phase = phase;
+            volatile bool hit_barrier = false;
+            for (unsigned int tz = 0; tz < block.z; tz++)
+                for (unsigned int ty = 0; ty < block.y; ty++)
+                    for (unsigned int tx = 0; tx < block.x; tx++) {
+                        threadIdx = {tx, ty, tz};
+                        if (setjmp(hostsim_barrier) == 0) body();
+                        else hit_barrier = true;
+                    }
+            if (!hit_barrier) break;  // no barrier in this kernel (or every thread left before it): one pass was the whole kernel
+        }
+    }
+}
+// the kernel name may arrive parenthesised (`(k3_tiled<T, C>)`: a template-id with a comma) or bare: strip one pair of parentheses if present
+#define HOSTSIM_EXTRACT(...) HOSTSIM_EXTRACT __VA_ARGS__
+#define HOSTSIM_NOTHING_HOSTSIM_EXTRACT
+#define HOSTSIM_PASTE(x, ...) x##__VA_ARGS__
+#define HOSTSIM_EVAL_PASTE(x, ...) HOSTSIM_PASTE(x, __VA_ARGS__)
+#define HOSTSIM_STRIP(x) HOSTSIM_EVAL_PASTE(HOSTSIM_NOTHING_, HOSTSIM_EXTRACT x)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hostsim_launch((grid), (block), (size_t)(shmem), [&]() { HOSTSIM_STRIP(kernel)(__VA_ARGS__); })
+
+// ---------------------------------------------------------------- device intrinsics (hardware approximations -> libm)
+static inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
+static inline float __builtin_amdgcn_logf(float x) { return std::log2(x); }
+static inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
+static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / std::sqrt(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_sinf(float rev) { return (float)std::sin((double)rev * 6.283185307179586476925); }
+static inline float __builtin_amdgcn_cosf(float rev) { return (float)std::cos((double)rev * 6.283185307179586476925); }
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
+typedef __fp16 hostsim_half2 __attribute__((ext_vector_type(2)));
+static inline unsigned short hostsim_f2h_rtz(float f) {  // v_cvt_pkrtz_f16_f32: truncate, finite overflow saturates at 65504
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u, mag = u & 0x7fffffffu;
+    if (mag > 0x7f800000u) return (unsigned short)(sign | 0x7e00u);           // NaN
+    if (mag == 0x7f800000u) return (unsigned short)(sign | 0x7c00u);          // inf
+    if (mag >= 0x477fe000u) return (unsigned short)(sign | 0x7bffu);          // >= 65504: saturate
+    if (mag < 0x33800000u) return (unsigned short)sign;                       // < 2^-24: zero
+    const int e = (int)(mag >> 23) - 127;
+    const uint32_t man = (mag & 0x7fffffu) | 0x800000u;
+    if (e < -14) return (unsigned short)(sign | (man >> (13 + (-14 - e))));   // subnormal half, truncated
+    return (unsigned short)(sign | ((uint32_t)(e + 15) << 10) | ((man & 0x7fffffu) >> 13));
+}
+static inline hostsim_half2 __builtin_amdgcn_cvt_pkrtz(float a, float b) {
+    const uint32_t bits = (uint32_t)hostsim_f2h_rtz(a) | ((uint32_t)hostsim_f2h_rtz(b) << 16);
+    hostsim_half2 r;
+    std::memcpy(&r, &bits, 4);
+    return r;
+}
+static inline float hostsim_vmin(float a, float b) { return std::fmin(a, b); }  // v_min_f32 / v_max_f32 in IEEE mode: the non-NaN operand
+static inline float hostsim_vmax(float a, float b) { return std::fmax(a, b); }
+static inline int __mul24(int a, int b) { return a * b; }
+static inline float __fmaf_rn(float a, float b, float c) { return std::fma(a, b, c); }
+static inline unsigned int __float_as_uint(float f) { unsigned int u; std::memcpy(&u, &f, 4); return u; }
+static inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned int u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline float __builtin_inff_hostsim() { return __builtin_inff(); }
+using std::max;
+using std::min;
+static inline int min(int a, unsigned int b) { return a < (int)b ? a : (int)b; }
+static inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned int atomicOr(unsigned int *p, unsigned int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+
+// ---------------------------------------------------------------- runtime API (host memory stands for device memory; streams are immediate)
+typedef int hipError_t;
+typedef struct hostsim_stream *hipStream_t;
+typedef struct hostsim_event *hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char *hipGetErrorString(hipError_t) { return "hostsim"; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned int = 0) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { std::memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t = nullptr) { std::memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned int) { *s = (hipStream_t)std::malloc(8); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { std::free(s); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int = 0) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)std::malloc(8); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned int) { return hipEventCreate(e); }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+template <class K>
+static inline hipError_t hipFuncSetAttribute(K, int, int) { return hipSuccess; }
+struct float2;
+void hostsim_k1_prepare(int base_cell, const float *depth, float *viewz, float2 *base, int W, int H, int base_w, float nearMulFar, float farMinusNear,
+                        float cameraFar, float nearMinusFar, float cameraNear, int perspective);
+static inline float __shfl_xor(float v, int) { return v; }  // only k1_prepare shuffles, and it is substituted
