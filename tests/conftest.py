@@ -9,9 +9,35 @@ for p in (os.path.join(ROOT, "realism-effects_amd"), os.path.join(ROOT, "oracle"
         sys.path.insert(0, p)
 
 
+# -m gpu tests that need the real device / RCCL / the N-API addon (which links librfx_hip.so itself): not runnable under --hostsim
+HOSTSIM_NEEDS_HARDWARE = ("test_comm_entry_points_on_a_single_rank_ring", "test_bench_multi_rank_flow_on_one_gpu", "test_node_host_drives_the_gpu_bit_identically",
+                          "test_node_", "test_streamed_dumps_equal_uploaded_dumps")
+
+
+def pytest_addoption(parser):
+    parser.addoption("--hostsim", action="store_true", default=False,
+                     help="run the -m gpu tests against tests/hostsim (the product's kernel sources compiled for x86: kernel LOGIC on the CPU, "
+                          "no statement about the device's bits) instead of librfx_hip.so on a GPU")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference + llvmpipe (build container only)")
+    if config.getoption("--hostsim"):
+        import subprocess
+        sim = os.path.join(ROOT, "tests", "hostsim")
+        subprocess.check_call(["make", "-s", "-C", sim])
+        os.environ["RFX_HIP_LIB"] = os.path.join(sim, "_build", "librfx_hostsim.so")
+        os.environ["RFX_HOSTSIM"] = "1"
+
+
+def pytest_collection_modifyitems(config, items):
+    if not config.getoption("--hostsim"):
+        return
+    skip = pytest.mark.skip(reason="--hostsim: needs the device / RCCL / the N-API addon")
+    for it in items:
+        if any(n in it.nodeid for n in HOSTSIM_NEEDS_HARDWARE):
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,26 @@
+"""CPU: the kernels' LOGIC, executed.  tests/hostsim compiles the product's own kernel sources (realism-effects_amd/csrc/*.hip) for x86
+against a stand-in <hip/hip_runtime.h> and runs them thread by thread; a subset of the `-m gpu` tests is run against that library here
+(the whole `-m gpu` suite runs the same way with `pytest tests -m gpu --hostsim`, a few minutes).  What this proves: indexing, tiles and
+aprons, launch shapes, the C ABI's state handling, the host drivers on top.  What it does not: anything about the device's bits (the
+hardware transcendentals are libm here) or speed.  The library under test is test infrastructure: nothing in the product can load it."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG) or shutil.which("make") is None, reason="no host clang++ / make")
+def test_gpu_tests_subset_passes_under_host_simulation():
+    sel = ("cube or chain_stagewise_vs_oracle or row_tiled_chain_is_bit_identical or denoise_variants or traa_end_to_end or ssgi_trace_plus_shade "
+           "or row_windowed_draws or reference_vuv_model_on_device or resolution_scale")
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_zz_gpu_cube_environment.py", "tests/test_gpu_parity.py", "tests/test_gpu_baseline_configs.py",
+                        "-m", "gpu", "--hostsim", "-q", "-x", "-k", sel, "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    tail = "\n".join((p.stdout + p.stderr).splitlines()[-25:])
+    assert p.returncode == 0, tail
+    assert " passed" in p.stdout and "failed" not in p.stdout, tail
+    print(tail.splitlines()[-1])
