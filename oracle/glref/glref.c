@@ -101,8 +101,8 @@ static void (*pDisable)(GLenum);
 static void (*pPixelStorei)(GLenum, GLint);
 static void (*pDeleteTextures)(GLsizei, const GLuint *);
 
-#define MAX_TEX 256
-#define MAX_PROG 32
+#define MAX_TEX 16384
+#define MAX_PROG 2048
 #define MAX_SAMP 24
 
 typedef struct {
