@@ -1,0 +1,66 @@
+"""CPU: bench.py's control flow with the device work mocked — the one JSON line for N = 1, for N = 2 with its extras, and the watchdog that
+prints the headline when a collective in the extras hangs (their first run on a real multi-GPU node is the driver's)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+MOCK = textwrap.dedent('''
+    import sys, os, json, time
+    sys.path.insert(0, %r)
+    import bench, torch
+    import torch.distributed as dist
+    torch.cuda.set_device = lambda *_: None
+    dist.init_process_group = lambda *a, **k: None
+    dist.barrier = lambda *a, **k: None
+    dist.destroy_process_group = lambda *a, **k: None
+    class FakeCtx:
+        def halo_violations(self): return 0
+        def close(self): pass
+    kms = {"k1_ssgi_march": 0.61, "k2_temporal_reproject": 0.45, "k3_poisson_denoise_pass0": 0.24, "k3_poisson_denoise_pass1": 0.38, "k4_compose": 0.11}
+    bench.build_case = lambda world, rank, lr, dev, d, one, W, H, tiles, *a, **k: dict(ctx=FakeCtx(), rows=tiles[rank][1], halo=0 if world == 1 else 12,
+                                                                                       frame=None, fx=None, renderer=None)
+    calls = [0]
+    def time_case(*a, **k):
+        calls[0] += 1
+        if os.environ.get("HANG_AT") and calls[0] >= int(os.environ["HANG_AT"]):
+            time.sleep(3600)
+        return 0.0366
+    bench.time_case = time_case
+    bench.kernel_times = lambda *a, **k: dict(kms)
+    bench.cpu_baseline = lambda *a, **k: {"value": 10.4, "unit": "Mpixels/s", "cores": 32, "kind": "reference", "sample": "mock"}
+    bench.main()
+''') % ROOT
+
+
+def _run(argv, env=None, timeout=120):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RFX_BENCH_ONE_GPU", "HANG_AT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, "-c", "import sys; sys.argv = %r\n%s" % (["bench.py"] + argv, MOCK)], capture_output=True, text=True, timeout=timeout, env=e)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_line_single_gpu():
+    j = _run(["--steps", "20", "--warmup", "5"])
+    assert j["n_gpus"] == 1 and j["scaling"] == "weak" and j["vs_baseline"] is None and j["unit"] == "Mpixels/s"
+    assert abs(j["value"] - 3840 * 2160 * 20 / 0.0366 / 1e6) < 0.01 and abs(j["ms_per_step"] - 1.83) < 1e-6
+    assert j["roofline"]["bound"] == "hbm" and j["roofline"]["kernel"] == "k1_ssgi_march" and 0 < j["roofline"]["frac"] < 1
+    assert j["cpu_baseline"]["kind"] == "reference" and j["config"]["workload"].startswith("configs[2]")
+
+
+def test_bench_line_row_tiled_with_extras_and_watchdog():
+    env = dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", RFX_BENCH_ONE_GPU="1")
+    j = _run(["--gpus", "2", "--steps", "4", "--warmup", "1"], env)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["tile_rows"] == 1080 and j["config"]["workload"].startswith("configs[3]")
+    assert "weak_scaling" in j and "configs4_8k" in j and "cpu_baseline" not in j
+    # the second extra hangs: after --extras-timeout the headline is printed with what was done, and the process leaves
+    j = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--extras-timeout", "2"], dict(env, HANG_AT="3"))
+    assert j["n_gpus"] == 2 and "weak_scaling" in j and "configs4_8k" not in j and "timed out" in j["extras_error"]
