@@ -9,9 +9,8 @@ for p in (os.path.join(ROOT, "realism-effects_amd"), os.path.join(ROOT, "oracle"
         sys.path.insert(0, p)
 
 
-# -m gpu tests that need the real device / RCCL / the N-API addon (which links librfx_hip.so itself): not runnable under --hostsim
-HOSTSIM_NEEDS_HARDWARE = ("test_comm_entry_points_on_a_single_rank_ring", "test_bench_multi_rank_flow_on_one_gpu", "test_node_host_drives_the_gpu_bit_identically",
-                          "test_node_", "test_streamed_dumps_equal_uploaded_dumps")
+# -m gpu tests that need the real device (RCCL, torch.cuda): not runnable under --hostsim
+HOSTSIM_NEEDS_HARDWARE = ("test_comm_entry_points_on_a_single_rank_ring", "test_bench_multi_rank_flow_on_one_gpu")
 
 
 def pytest_addoption(parser):
@@ -29,12 +28,14 @@ def pytest_configure(config):
         subprocess.check_call(["make", "-s", "-C", sim])
         os.environ["RFX_HIP_LIB"] = os.path.join(sim, "_build", "librfx_hostsim.so")
         os.environ["RFX_HOSTSIM"] = "1"
+        # child processes (node + the N-API addon, which links librfx_hip.so by rpath): the simulator's rfx_* symbols interpose
+        os.environ["LD_PRELOAD"] = os.environ["RFX_HIP_LIB"]
 
 
 def pytest_collection_modifyitems(config, items):
     if not config.getoption("--hostsim"):
         return
-    skip = pytest.mark.skip(reason="--hostsim: needs the device / RCCL / the N-API addon")
+    skip = pytest.mark.skip(reason="--hostsim: needs the device (RCCL / torch.cuda)")
     for it in items:
         if any(n in it.nodeid for n in HOSTSIM_NEEDS_HARDWARE):
             it.add_marker(skip)
