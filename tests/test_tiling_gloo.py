@@ -276,3 +276,59 @@ def test_split_rows_even_boundaries_and_halo():
     assert tiling.required_halo(3.0, 0.0, 2160, 3840) == 5
     assert tiling.required_halo(3.0, 0.005, 2160, 3840) == 15
     assert tiling.required_halo(3.0, 0.0, 3840, 2160) == 8  # portrait: the UV-space rotation stretches the tap footprint vertically
+
+
+# ---------------------------------------------------------------- the same, with the product's KERNELS under the tiles (pytest --hostsim)
+def _kernel_worker(rank, world, port, outdir):
+    """one process per tile, each with its own rfx context (tests/hostsim: the kernel sources on the CPU), exchanging through the product's
+    rfx_amd.tiling over gloo — the device memory the tensors are bound to IS host memory there"""
+    sys.path.insert(0, HERE)
+    import conftest  # noqa: F401
+    from rfx_amd import abi, tiling
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_frame
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
+    vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
+    halo = tiling.required_halo(3.0, vmax, H, W)
+    y0, rows = tiling.split_rows(H, world)[rank]
+    ctx = Context(W, H, tile_y0=y0, tile_rows=rows, halo_rows=halo)
+    r = tiling.TiledRenderer(ctx, tiling.bind_torch_buffers(ctx, "cpu"), rank, world)
+    _chain(r, types.SimpleNamespace(frame=None), frames[0].camera, frames)
+    r.finish_pending()
+    r.finish_halo()
+    assert ctx.halo_violations() == 0
+    np.savez(os.path.join(outdir, "k%d.npz" % rank), y0=y0, rows=rows,
+             **{abi.TEX_NAMES[t]: ctx.download(t, y0, rows) for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1, abi.TEX_COMPOSE)},
+             compose_rgb_full=ctx.download(abi.TEX_COMPOSE_RGB))
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("RFX_HOSTSIM") != "1", reason="the kernels under gloo tiles: pytest --hostsim (on a GPU box the multi-rank flow test of test_gpu_parity.py does this)")
+@pytest.mark.parametrize("world", [2, 3])
+def test_tiled_kernels_are_bit_identical_to_one_context(tmp_path, world):
+    import socket
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_frame
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_kernel_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
+    ref = Context(W, H)
+    _chain(ref, types.SimpleNamespace(frame=None), frames[0].camera, frames)
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), "k%d.npz" % rank))
+        y0, rows = int(z["y0"]), int(z["rows"])
+        for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1, abi.TEX_COMPOSE):
+            assert np.array_equal(z[abi.TEX_NAMES[t]], ref.download(t, y0, rows)), "rank %d %s differs" % (rank, abi.TEX_NAMES[t])
+        assert np.array_equal(z["compose_rgb_full"], ref.download(abi.TEX_COMPOSE)[..., :3]), "rank %d gathered composed GI differs" % rank
+    ref.close()
