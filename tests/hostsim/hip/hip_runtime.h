@@ -3,13 +3,15 @@
 // compiled for x86 and executed thread by thread on the CPU: `librfx_hostsim.so` exports the same C ABI as librfx_hip.so, so the `-m gpu`
 // tests can exercise the kernels' LOGIC (indexing, tiles and aprons, launch shapes, the C ABI's state handling) in a container without a
 // GPU.  It is NOT a fallback: nothing under realism-effects_amd/ knows it exists, it is built and loaded only by tests that ask for it
-// (RFX_HIP_LIB), it is ~1000x slower than the device, and the hardware transcendentals are replaced by libm (so it says nothing about the
+// (RFX_HIP_LIB), it is orders of magnitude slower than the device, and the hardware transcendentals are replaced by libm (so it says nothing about the
 // device's bits — only about the program's structure).
 //
 // Execution model: hipLaunchKernelGGL runs the blocks of a grid on OpenMP threads; inside a block the threads run one after the other.
-// A kernel with ONE __syncthreads() (K2, K3: stage a tile, barrier, compute) is run in two phases: phase 0 executes every thread up to the
-// barrier (longjmp out of it), phase 1 re-executes every thread from the top with the barrier a no-op — correct because what precedes the
-// barrier is an idempotent, thread-private set of LDS stores.  Kernels that use wave shuffles (k1_prepare) are substituted in the Makefile.
+// Synchronisation points — __syncthreads() and the wave shuffles — are honoured by REPLAY: pass p runs every thread of the block from the
+// top until it reaches its p-th synchronisation point and stops there (longjmp); a thread passing an earlier shuffle takes its partner's
+// value as recorded when that partner stopped at the same point.  Correct for kernels whose threads all meet the same sequence of points
+// and whose side effects before a point are idempotent (K2 / K3: stage a tile, barrier, compute; k1_prepare: 8 shuffles + a barrier) —
+// which is every kernel of this library.
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -52,11 +54,26 @@ static inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char
 // ---------------------------------------------------------------- execution state
 struct hostsim_idx { unsigned int x, y, z; };
 extern thread_local hostsim_idx threadIdx, blockIdx, blockDim, gridDim;
-extern thread_local int hostsim_phase;          // 0: run to the barrier; 1: barrier is a no-op
+extern thread_local int hostsim_phase;          // the synchronisation point this pass stops at
+extern thread_local int hostsim_sync_count;     // points the running thread has reached in this pass
 extern thread_local std::jmp_buf hostsim_barrier;
 extern thread_local unsigned char *hostsim_lds;  // dynamic shared memory of the running block
+extern thread_local float *hostsim_shfl;         // [point][thread of the block]: the value a thread offered at a shuffle
+extern thread_local unsigned int hostsim_nthreads;
+enum { HOSTSIM_MAX_SYNC = 64 };
+static inline unsigned int hostsim_tid() { return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); }
 static inline void __syncthreads() {
-    if (hostsim_phase == 0) std::longjmp(hostsim_barrier, 1);
+    if (hostsim_sync_count++ == hostsim_phase) std::longjmp(hostsim_barrier, 1);
+}
+static inline float __shfl_xor(float v, int lane_mask) {  // wave64: the partner is lane ^ mask of the same wavefront
+    const int c = hostsim_sync_count++;
+    const unsigned int tid = hostsim_tid();
+    if (c == hostsim_phase) {
+        hostsim_shfl[(size_t)c * hostsim_nthreads + tid] = v;
+        std::longjmp(hostsim_barrier, 1);
+    }
+    const unsigned int partner = (tid & ~63u) | ((tid ^ (unsigned int)lane_mask) & 63u);
+    return partner < hostsim_nthreads ? hostsim_shfl[(size_t)c * hostsim_nthreads + partner] : v;
 }
 template <class F>
 static void hostsim_launch(dim3 grid, dim3 block, size_t shmem, F body) {
@@ -70,17 +87,24 @@ static void hostsim_launch(dim3 grid, dim3 block, size_t shmem, F body) {
         gridDim = {grid.x, grid.y, grid.z};
         blockDim = {block.x, block.y, block.z};
         blockIdx = {(unsigned int)(b % grid.x), (unsigned int)((b / grid.x) % grid.y), (unsigned int)(b / ((long)grid.x * grid.y))};
-        for (int phase = 0; phase < 2; phase++) {
+        static thread_local float *shfl = nullptr;
+        static thread_local size_t shfl_size = 0;
+        const size_t nthreads = (size_t)block.x * block.y * block.z, need = nthreads * HOSTSIM_MAX_SYNC;
+        if (need > shfl_size) { std::free(shfl); shfl = (float *)std::malloc(need * sizeof(float)); shfl_size = need; }
+        hostsim_shfl = shfl;
+        hostsim_nthreads = (unsigned int)nthreads;
+        for (int phase = 0; phase < HOSTSIM_MAX_SYNC; phase++) {
             hostsim_phase = phase;
-            volatile bool hit_barrier = false;
+            volatile bool stopped = false;
             for (unsigned int tz = 0; tz < block.z; tz++)
                 for (unsigned int ty = 0; ty < block.y; ty++)
                     for (unsigned int tx = 0; tx < block.x; tx++) {
                         threadIdx = {tx, ty, tz};
+                        hostsim_sync_count = 0;
                         if (setjmp(hostsim_barrier) == 0) body();
-                        else hit_barrier = true;
+                        else stopped = true;
                     }
-            if (!hit_barrier) break;  // no barrier in this kernel (or every thread left before it): one pass was the whole kernel
+            if (!stopped) break;  // every thread ran to the end: this pass was the whole kernel
         }
     }
 }
@@ -169,7 +193,4 @@ static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 template <class K>
 static inline hipError_t hipFuncSetAttribute(K, int, int) { return hipSuccess; }
-struct float2;
-void hostsim_k1_prepare(int base_cell, const float *depth, float *viewz, float2 *base, int W, int H, int base_w, float nearMulFar, float farMinusNear,
-                        float cameraFar, float nearMinusFar, float cameraNear, int perspective);
-static inline float __shfl_xor(float v, int) { return v; }  // only k1_prepare shuffles, and it is substituted
+
