@@ -10,7 +10,7 @@ for p in (os.path.join(ROOT, "realism-effects_amd"), os.path.join(ROOT, "oracle"
 
 
 # -m gpu tests that need the real device (RCCL, torch.cuda): not runnable under --hostsim
-HOSTSIM_NEEDS_HARDWARE = ("test_comm_entry_points_on_a_single_rank_ring", "test_bench_multi_rank_flow_on_one_gpu")
+HOSTSIM_NEEDS_HARDWARE = ("test_bench_multi_rank_flow_on_one_gpu",)
 
 
 def pytest_addoption(parser):
@@ -30,6 +30,11 @@ def pytest_configure(config):
         os.environ["RFX_HOSTSIM"] = "1"
         # child processes (node + the N-API addon, which links librfx_hip.so by rpath): the simulator's rfx_* symbols interpose
         os.environ["LD_PRELOAD"] = os.environ["RFX_HIP_LIB"]
+        # rfx_comm.hip binds RCCL at run time (dlopen "librccl.so.1"): tests/hostsim/fakerccl.c moves the bytes over unix sockets instead
+        import ctypes
+        fake = os.path.join(sim, "_build", "fakerccl")
+        ctypes.CDLL(os.path.join(fake, "librccl.so.1"), mode=ctypes.RTLD_GLOBAL)  # this process: found by soname (RTLD_NOLOAD)
+        os.environ["LD_LIBRARY_PATH"] = fake + os.pathsep + os.environ.get("LD_LIBRARY_PATH", "")  # child processes
 
 
 def pytest_collection_modifyitems(config, items):

@@ -476,3 +476,30 @@ def test_cube_environment_js_and_python_hosts_issue_the_same_calls():
     assert js["big"] == [4096, 2048]  # maxWidth (:71-74)
     assert effect.CubeToEquirectEnvPass().generateEquirectEnvMap(types.SimpleNamespace(cube_to_equirect=lambda fa, w, h, generate_mipmaps: np.zeros((h, w, 4), np.float32)),
                                                                  dict(faces=np.zeros((6, 2048, 1, 4), np.float32)))["data"].shape == (2048, 4096, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("RFX_HOSTSIM") != "1", reason="one Node process per tile without RCCL / without N GPUs: pytest --hostsim")
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_node_row_tiled_run_equals_single_process(tmp_path, ranks):
+    """`run_dump.js --ranks N`: N Node processes, each driving its tile through the N-API addon, exchanging halo rows and the composed GI
+    through the C ABI (rfx_comm_* / rfx_halo_exchange / rfx_allgather_history — under --hostsim over tests/hostsim/fakerccl.c), stitched by
+    the parent: the same bytes as one process rendering the whole frame."""
+    from rfx_amd.dump import write_dump
+    from rfx_amd.scene import synthetic_frame
+    W, H = 160, 96
+    dirs = []
+    for i in range(3):
+        d = str(tmp_path / ("dump%d" % i))
+        write_dump(d, synthetic_frame(W, H, i))
+        dirs.append(d)
+    env = dict(os.environ, RFX_ONE_GPU="1")
+    one, many = str(tmp_path / "one"), str(tmp_path / "many")
+    subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", one, "--steps", "12", "--refineSteps", "3"], text=True, env=env)
+    res = subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", many, "--steps", "12", "--refineSteps", "3", "--ranks", str(ranks)],
+                                  text=True, env=env, timeout=600)
+    info = json.loads(res.strip().splitlines()[-1])
+    assert info["ranks"] == ranks and info["haloViolations"] == 0 and info["frames"] == 3
+    for name in ("final", "compose", "denoise_b0", "denoise_b1", "temporal0", "ssgi"):
+        a, b = open(os.path.join(one, name + ".bin"), "rb").read(), open(os.path.join(many, name + ".bin"), "rb").read()
+        assert a == b, name

@@ -332,3 +332,33 @@ def test_tiled_kernels_are_bit_identical_to_one_context(tmp_path, world):
             assert np.array_equal(z[abi.TEX_NAMES[t]], ref.download(t, y0, rows)), "rank %d %s differs" % (rank, abi.TEX_NAMES[t])
         assert np.array_equal(z["compose_rgb_full"], ref.download(abi.TEX_COMPOSE)[..., :3]), "rank %d gathered composed GI differs" % rank
     ref.close()
+
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("RFX_HOSTSIM") != "1", reason="the C ABI's exchanges between processes without RCCL: pytest --hostsim")
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_tiled_kernels_with_c_abi_exchanges_are_bit_identical_to_one_context(tmp_path, world):
+    """The same tiles with the exchanges BEHIND THE C ABI (rfx_comm_init / rfx_halo_exchange / rfx_allgather_history / rfx_comm_wait), one
+    process per tile (tests/comm_tile_worker.py — no torch in them: a torch process maps the real librccl.so.1, which rfx_comm.hip would
+    rightly reuse).  Under --hostsim the librccl.so.1 that rfx_comm.hip binds is tests/hostsim/fakerccl.c: unix sockets between these
+    processes.  Ragged tiles at 3 ranks (the grouped-broadcast form of the gather), even ones at 2 and 4 (the in-place all-gather)."""
+    import subprocess
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_frame
+
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "comm_tile_worker.py"), str(r), str(world), str(tmp_path), str(W), str(H), str(FRAMES)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
+    ref = Context(W, H)
+    _chain(ref, types.SimpleNamespace(frame=None), frames[0].camera, frames)
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), "c%d.npz" % rank))
+        y0, rows = int(z["y0"]), int(z["rows"])
+        for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1, abi.TEX_COMPOSE):
+            assert np.array_equal(z[abi.TEX_NAMES[t]], ref.download(t, y0, rows)), "rank %d %s differs" % (rank, abi.TEX_NAMES[t])
+        assert np.array_equal(z["compose_rgb_full"], ref.download(abi.TEX_COMPOSE)[..., :3]), "rank %d gathered composed GI differs" % rank
+    ref.close()
