@@ -291,6 +291,8 @@ def main():
     args = ap.parse_args()
 
     import torch
+    if os.environ.get("RFX_HOSTSIM") == "1":  # functional test hook (tests/hostsim: the kernel sources on the CPU): there is no device to select or drain
+        torch.cuda.set_device = torch.cuda.synchronize = lambda *a, **k: None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

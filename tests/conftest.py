@@ -30,10 +30,11 @@ def pytest_configure(config):
         os.environ["RFX_HOSTSIM"] = "1"
         # child processes (node + the N-API addon, which links librfx_hip.so by rpath): the simulator's rfx_* symbols interpose
         os.environ["LD_PRELOAD"] = os.environ["RFX_HIP_LIB"]
-        # rfx_comm.hip binds RCCL at run time (dlopen "librccl.so.1"): tests/hostsim/fakerccl.c moves the bytes over unix sockets instead
+        # rfx_comm.hip binds RCCL at run time (dlopen; the simulator build looks for librccl_hostsim.so.1): tests/hostsim/fakerccl.c moves the
+        # bytes over unix sockets instead
         import ctypes
         fake = os.path.join(sim, "_build", "fakerccl")
-        ctypes.CDLL(os.path.join(fake, "librccl.so.1"), mode=ctypes.RTLD_GLOBAL)  # this process: found by soname (RTLD_NOLOAD)
+        ctypes.CDLL(os.path.join(fake, "librccl_hostsim.so.1"), mode=ctypes.RTLD_GLOBAL)  # this process: found by soname (RTLD_NOLOAD)
         os.environ["LD_LIBRARY_PATH"] = fake + os.pathsep + os.environ.get("LD_LIBRARY_PATH", "")  # child processes
 
 

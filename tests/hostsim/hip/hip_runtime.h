@@ -1,5 +1,5 @@
 // tests/hostsim/hip/hip_runtime.h — TEST INFRASTRUCTURE.  A host stand-in for <hip/hip_runtime.h> that lets the product's own kernel
-// sources (realism-effects_amd/csrc/*.hip, unmodified except for the five textual substitutions listed in tests/hostsim/Makefile) be
+// sources (realism-effects_amd/csrc/*.hip, unmodified except for the six textual substitutions listed in tests/hostsim/Makefile) be
 // compiled for x86 and executed thread by thread on the CPU: `librfx_hostsim.so` exports the same C ABI as librfx_hip.so, so the `-m gpu`
 // tests can exercise the kernels' LOGIC (indexing, tiles and aprons, launch shapes, the C ABI's state handling) in a container without a
 // GPU.  It is NOT a fallback: nothing under realism-effects_amd/ knows it exists, it is built and loaded only by tests that ask for it
@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <type_traits>
 
 #define __host__
@@ -172,7 +173,7 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "hostsim"; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 16; return hipSuccess; }  // every "device" is this host: one rank per device index works
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned int = 0) { return hipMalloc(p, n); }
@@ -185,12 +186,14 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned int) 
 static inline hipError_t hipStreamDestroy(hipStream_t s) { std::free(s); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned int = 0) { return hipSuccess; }
-static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)std::malloc(8); return hipSuccess; }
+// events carry the wall-clock time of their record (streams are immediate): rfx_time_begin / rfx_time_end report the simulator's own speed
+static inline double hostsim_now_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)std::calloc(1, sizeof(double)); return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned int) { return hipEventCreate(e); }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { *(double *)e = hostsim_now_ms(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(*(double *)b - *(double *)a); return hipSuccess; }
 template <class K>
 static inline hipError_t hipFuncSetAttribute(K, int, int) { return hipSuccess; }
 

@@ -64,3 +64,37 @@ def test_bench_line_row_tiled_with_extras_and_watchdog():
     # the second extra hangs: after --extras-timeout the headline is printed with what was done, and the process leaves
     j = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--extras-timeout", "2"], dict(env, HANG_AT="3"))
     assert j["n_gpus"] == 2 and "weak_scaling" in j and "configs4_8k" not in j and "timed out" in j["extras_error"]
+
+
+def test_bench_row_tiled_for_real_under_the_host_simulator(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), nothing mocked: the dump bands, the halo
+    from the velocity bound, the depth all-reduce, the C-ABI communicator with its pre-flight pattern check (verify_exchange), the timed
+    steps through CommTiledRenderer, the per-kernel timing, the JSON line — on a small frame, with tests/hostsim under the C ABI (the kernel
+    sources on the CPU, a socket stand-in for the RCCL slice).  N = 1 the same way."""
+    import shutil
+    import socket
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++") or shutil.which("make") is None:
+        import pytest
+        pytest.skip("no host clang++ / make")
+    sim = os.path.join(ROOT, "tests", "hostsim")
+    subprocess.check_call(["make", "-s", "-C", sim])
+    env = dict(os.environ, RFX_HIP_LIB=os.path.join(sim, "_build", "librfx_hostsim.so"), RFX_HOSTSIM="1",
+               LD_LIBRARY_PATH=os.path.join(sim, "_build", "fakerccl") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RFX_BENCH_ONE_GPU"):
+        env.pop(k, None)
+    common = ["--steps", "2", "--warmup", "1", "--width", "192", "--height", "128", "--no-cpu-baseline", "--checksum"]
+    p1 = subprocess.run([sys.executable, "bench.py"] + common, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    one = json.loads([ln for ln in p1.stdout.splitlines() if ln.startswith("{")][-1])
+    for n in (2, 3):  # 3: ragged tiles (128 rows over three ranks), a middle rank with two neighbours
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                             "bench.py", "--gpus", str(n), "--no-extras"] + common, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        assert p2.returncode == 0, (p2.stdout + p2.stderr)[-3000:]
+        many = json.loads([ln for ln in p2.stdout.splitlines() if ln.startswith("{")][-1])
+        assert many["n_gpus"] == n and many["config"]["tile_rows"] in ((64,) if n == 2 else (42, 43)) and many["halo_violations"] == 0 and many["scaling"] == "strong"
+        assert many["config"]["exchange_verified"] is True and "exchange_fallback" not in many["config"]  # the C-ABI exchanges passed their pre-flight check
+        assert many["compose_sha1"] == one["compose_sha1"]  # the tiled run's composed frame == the single-context run's, bit for bit
