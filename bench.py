@@ -287,6 +287,7 @@ def main():
     ap.add_argument("--checksum", action="store_true", help="add sha1 of the final whole-frame composed GI to the JSON line (tiled == single check)")
     ap.add_argument("--exchange", choices=("c", "torch"), default="c", help="N > 1: exchanges through the C ABI's RCCL entry points (default) or torch.distributed")
     ap.add_argument("--extras-timeout", type=int, default=480, help="seconds the N > 1 extras (weak scaling, configs[4]) may take before the headline line is printed without them")
+    ap.add_argument("--configs4-size", default="7680x4320", help="N > 1 extras: frame of the BASELINE configs[4] case (tests shrink it)")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: only the headline case (skip the weak-scaling and configs[4] extras)")
     args = ap.parse_args()
 
@@ -448,11 +449,12 @@ def main():
                                           "halo_violations": wcase["ctx"].halo_violations()}
                 wcase["ctx"].close()
             # (b) BASELINE configs[4]: 8K, steps 40, denoiseIterations 3, row-tiled (the 16-frame sequence re-renders one dumped frame)
-            c4 = build_case(world, rank, local_rank, dev, dist, one_gpu, 7680, 4320, tiling.split_rows(4320, world), 40, 5, 3, use_c=use_c, group=group)
+            W8, H8 = (int(v) for v in args.configs4_size.split("x"))
+            c4 = build_case(world, rank, local_rank, dev, dist, one_gpu, W8, H8, tiling.split_rows(H8, world), 40, 5, 3, use_c=use_c, group=group)
             n4 = max(4, min(args.steps, 16))
             d4 = time_case(c4, dist, n4, 2, dev)
-            extras["configs4_8k"] = {"frame": "7680x4320", "steps": 40, "refineSteps": 5, "denoiseIterations": 3, "frames_timed": n4, "halo_rows": c4["halo"],
-                                     "ms_per_frame": round(d4 / n4 * 1e3, 4), "value": round(7680 * 4320 * n4 / d4 / 1e6, 2), "unit": "Mpixels/s",
+            extras["configs4_8k"] = {"frame": "%dx%d" % (W8, H8), "steps": 40, "refineSteps": 5, "denoiseIterations": 3, "frames_timed": n4, "halo_rows": c4["halo"],
+                                     "ms_per_frame": round(d4 / n4 * 1e3, 4), "value": round(W8 * H8 * n4 / d4 / 1e6, 2), "unit": "Mpixels/s",
                                      "halo_violations": c4["ctx"].halo_violations()}
             c4["ctx"].close()
         except Exception as e:  # noqa: BLE001  the headline case above is already measured: report it, and what stopped the extras

@@ -92,9 +92,13 @@ def test_bench_row_tiled_for_real_under_the_host_simulator(tmp_path):
         port = s.getsockname()[1]
         s.close()
         p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
-                             "bench.py", "--gpus", str(n), "--no-extras"] + common, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+                             "bench.py", "--gpus", str(n)] + (["--no-extras"] if n == 3 else ["--configs4-size", "160x96"]) + common,
+                            cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
         assert p2.returncode == 0, (p2.stdout + p2.stderr)[-3000:]
         many = json.loads([ln for ln in p2.stdout.splitlines() if ln.startswith("{")][-1])
         assert many["n_gpus"] == n and many["config"]["tile_rows"] in ((64,) if n == 2 else (42, 43)) and many["halo_violations"] == 0 and many["scaling"] == "strong"
         assert many["config"]["exchange_verified"] is True and "exchange_fallback" not in many["config"]  # the C-ABI exchanges passed their pre-flight check
         assert many["compose_sha1"] == one["compose_sha1"]  # the tiled run's composed frame == the single-context run's, bit for bit
+        if n == 2:  # the extras ran too: the weak-scaling frame and the configs[4] options (steps 40, six K3 passes), both row-tiled
+            assert "extras_error" not in many, many.get("extras_error")
+            assert many["weak_scaling"]["halo_violations"] == 0 and many["configs4_8k"]["halo_violations"] == 0 and many["configs4_8k"]["frame"] == "160x96"
