@@ -90,6 +90,9 @@ static inline float frag_v(int y, int W, int H) {
     float far_side = dvdy * ((float)H - 0.5f);
     return fmaf(dvdy, (float)y, 1.0f - far_side);
 }
+/* a coordinate FORMED in uv space by a chain of fp32 operations (a projected point: normalize, matrix products, a division, * 0.5 + 0.5)
+ * carries a few 2^-24 ABSOLUTE between two correct implementations (operation order, fused or not): the perturbed runs move it by `a` */
+static inline float pert_coord(float v, float a) { return (g_pert_seed && g_pert_state) ? v + pert_sign() * a : v; }
 static inline float pert_sqrt(float v) { return (g_pert_seed && g_pert_state) ? v * (1.0f + pert_sign() * 2.4e-7f) : v; }
 /* test probe: the (u, v) planes of a W x H target under a model, interleaved */
 void rfxo_frag_uv(int model, int W, int H, float *out) {
@@ -1233,7 +1236,7 @@ static void k2_pixel(const k2_ctx *c, int x, int y, float *out0, float *out1) {
                     PV[col * 4 + row] = ((A[0 * 4 + row] * Bm[col * 4 + 0] + A[1 * 4 + row] * Bm[col * 4 + 1]) + A[2 * 4 + row] * Bm[col * 4 + 2]) +
                                         A[3 * 4 + row] * Bm[col * 4 + 3];
             v4 r = mat_mul_v4(PV, hp.x, hp.y, hp.z, 1.0f);
-            hu = (r.x / r.w) * 0.5f + 0.5f; hv = (r.y / r.w) * 0.5f + 0.5f;
+            hu = pert_coord((r.x / r.w) * 0.5f + 0.5f, 4.0f * 5.9604645e-8f); hv = pert_coord((r.y / r.w) * 0.5f + 0.5f, 4.0f * 5.9604645e-8f);
             g_fetch_rel = MARGIN_REL_SHORT; /* the validation fetch sits at a projected point (normalize, two matrix products, a division) ... */
             g_fetch_uv = 4.0f * 1.1920929e-7f; /* ... whose ndc -> uv step rounds at the magnitude of 1 */
         }

@@ -59,8 +59,10 @@ class Report:
             self.explained, self.unexplained, self.at_risk, 100.0 * self.at_risk / max(self.pixels, 1))
 
 
-def _errors(a, b, half):
-    """(per-channel abs error with NaN/inf conventions applied, (H, W) bool out-of-tolerance) — float32 throughout (8K frames)"""
+def _errors(a, b, half, tol_scale=1.0):
+    """(per-channel abs error with NaN/inf conventions applied, (H, W) bool out-of-tolerance) — float32 throughout (8K frames).
+    tol_scale < 1 tightens the absolute and relative bounds (binary16 neighbours still count as equal: a value cannot sit next to both of
+    its rounding boundaries)."""
     a = np.asarray(a, np.float32)
     b = np.asarray(b, np.float32)
     if a.ndim == 2:
@@ -72,19 +74,25 @@ def _errors(a, b, half):
             na, nb = np.isnan(a), np.isnan(b)
             same = (na & nb) | (np.isinf(a) & np.isinf(b) & (np.sign(a) == np.sign(b)))
             err = np.where(same, np.float32(0.0), np.where(special, np.float32(np.inf), err))
-        ok = err <= np.float32(ATOL)
+        ok = err <= np.float32(ATOL * tol_scale)
         if half:
             rest = ~ok
             if rest.any():  # adjacent binary16 values: only looked at where the absolute rule failed
                 ok[rest] = _half_ulp_distance(a[rest], b[rest]) <= 1
         else:
-            ok |= err <= np.float32(RTOL_F32) * np.abs(b)
+            ok |= err <= np.float32(RTOL_F32 * tol_scale) * np.abs(b)
     return err, ~ok.all(axis=-1)
 
 
-def out_of_tolerance(a, b, half):
+def out_of_tolerance(a, b, half, tol_scale=1.0):
     """(H, W) bool: some channel of the pixel is outside the metric"""
-    return _errors(a, b, half)[1]
+    return _errors(a, b, half, tol_scale)[1]
+
+
+# The instability test of the flip proofs asks whether perturbing the oracle's primitives within the reference GL's measured error moves a
+# pixel by HALF the tolerance: the two implementations being compared each sit somewhere inside that error model, possibly on opposite
+# sides of the unperturbed evaluation, so what separates them can be twice what separates either from it.
+UNSTABLE_TOL_SCALE = 0.5
 
 
 def strict(name, a, b, explainable=None, half=False, ignore=None):

@@ -20,7 +20,7 @@ for _p in (os.path.join(ROOT, "realism-effects_amd"), os.path.join(ROOT, "oracle
         sys.path.insert(0, _p)
 
 import rfx_oracle as O  # noqa: E402
-from parity import out_of_tolerance, strict  # noqa: E402
+from parity import UNSTABLE_TOL_SCALE, out_of_tolerance, strict  # noqa: E402
 from rfx_amd import abi  # noqa: E402
 
 M31 = 0x7FFFFFFF
@@ -186,7 +186,7 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
             unstable_sel |= mm.plane.reshape(-1)[sel] < 1.0
             for seed in range(1, n_perturb + 1):
                 with O.perturbation(seed):
-                    unstable_sel |= out_of_tolerance(picked(fn())[None], base[None], half)[0]
+                    unstable_sel |= out_of_tolerance(picked(fn())[None], base[None], half, UNSTABLE_TOL_SCALE)[0]
         # an out-of-tolerance pixel the first seeds did not move gets more draws (random signs per call: a flip that needs one particular
         # combination of signs is found with probability < 1 per seed) — only those few pixels are re-evaluated
         bad_sel = bad.reshape(-1)[sel]
@@ -198,7 +198,7 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
                 for _ in range(8):
                     seed += 1
                     with O.perturbation(seed):
-                        moved = out_of_tolerance(picked(fn())[None], base[None], half)[0]
+                        moved = out_of_tolerance(picked(fn())[None], base[None], half, UNSTABLE_TOL_SCALE)[0]
                     unstable_sel |= moved & bad_sel  # (pixels outside `rest` were not re-evaluated: they compare equal)
         unstable = np.zeros(H * W, bool)
         unstable[sel] = unstable_sel

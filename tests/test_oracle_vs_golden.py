@@ -624,7 +624,7 @@ def test_env_map_importance_sampling_through_effect():
 def _unstable(fn, half, H, W, seeds=24):
     """(H, W) bool: the oracle proves the pixel may flip — discontinuity margin < 1, or its output leaves the tolerance when the
     oracle's primitives are perturbed within the reference GL's measured error (tests/parity.py, oracle/rfx_oracle.c)."""
-    from parity import out_of_tolerance
+    from parity import UNSTABLE_TOL_SCALE, out_of_tolerance
 
     def flat(outs):
         outs = outs if isinstance(outs, (list, tuple)) else [outs]
@@ -639,7 +639,7 @@ def _unstable(fn, half, H, W, seeds=24):
     u = mm.plane < 1.0
     for seed in range(1, seeds + 1):
         with O.perturbation(seed):
-            u |= out_of_tolerance(flat(fn()), base, half)
+            u |= out_of_tolerance(flat(fn()), base, half, UNSTABLE_TOL_SCALE)
     return u
 
 
