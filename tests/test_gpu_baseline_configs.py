@@ -29,12 +29,17 @@ pytestmark = pytest.mark.gpu
 FLIP = {"K1 ssgi": 5e-4, "K2 temporal0": 3e-5, "K2 temporal1": 3e-5, "K3 pass0": 5.4e-3, "K3 passN": 8e-5, "K4 compose": 5e-5}
 
 
-def _bound(kind):
+# ... and with both sides on the reference GL's vUv (measured on MI355X at 480x270: K3 pass 0 1.0e-4, later passes 5e-6): ~5x that
+FLIP_REFERENCE_UV = dict(FLIP, **{"K3 pass0": 6e-4, "K3 passN": 3e-5})
+
+
+def _bound(kind, uv_model="ideal"):
+    table = FLIP_REFERENCE_UV if uv_model == "reference_gl" else FLIP
     if kind.startswith("K3 pass0"):
-        return FLIP["K3 pass0"]
+        return table["K3 pass0"]
     if kind.startswith("K3"):
-        return FLIP["K3 passN"]
-    return FLIP[kind]
+        return table["K3 passN"]
+    return table[kind]
 
 
 def _frames(W, H):
@@ -82,8 +87,8 @@ def test_baseline_config_stagewise_vs_reference_glsl(blue_noise, name, W, H, ste
         allowed = int(2e-6 * r.pixels) if W >= 7680 else 0
         assert r.unexplained <= allowed, "%s %s: %d out-of-tolerance pixels the oracle cannot prove unstable, worst (y, x, err) %s\n%s" % (
             name, r.name, r.unexplained, r.worst_unexplained, r.line())
-        assert r.bad <= _bound(kind) * r.pixels + 2, "%s %s: %d flipped pixels of %d exceed the bound %.4f%%\n%s" % (
-            name, r.name, r.bad, r.pixels, 100 * _bound(kind), r.line())
+        assert r.bad <= _bound(kind, uv_model) * r.pixels + 2, "%s %s: %d flipped pixels of %d exceed the bound %.4f%%\n%s" % (
+            name, r.name, r.bad, r.pixels, 100 * _bound(kind, uv_model), r.line())
     # K1's packed texels are overwhelmingly BIT-identical to the reference's
     for r in reports:
         if hasattr(r, "bit_identical"):
