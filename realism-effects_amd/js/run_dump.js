@@ -84,6 +84,17 @@ if (opt.env) {
 	delete opt.envWidth
 	delete opt.envHeight
 }
+// --envCube <file.bin> --envCubeSize S [--envCubeMipmaps false]: scene.environment as a CubeTexture — six S x S Float32 RGBA faces (+X -X +Y -Y
+// +Z -Z, row j = t as uploaded), converted once through CubeToEquirectEnvPass (three's default sampler state unless --envCubeMipmaps false:
+// LinearFilter, no chain)
+if (opt.envCube) {
+	const b = fs.readFileSync(opt.envCube)
+	scene.environment = { isCubeTexture: true, faces: new Float32Array(b.buffer, b.byteOffset, b.length / 4), size: opt.envCubeSize }
+	if (opt.envCubeMipmaps === false) Object.assign(scene.environment, { minFilter: rfx.LinearFilter, generateMipmaps: false })
+	delete opt.envCube
+	delete opt.envCubeSize
+	delete opt.envCubeMipmaps
+}
 const camera = Object.assign({}, first.camera)
 let renderer
 if (tiled) {

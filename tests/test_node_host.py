@@ -503,3 +503,38 @@ def test_node_row_tiled_run_equals_single_process(tmp_path, ranks):
     for name in ("final", "compose", "denoise_b0", "denoise_b1", "temporal0", "ssgi"):
         a, b = open(os.path.join(one, name + ".bin"), "rb").read(), open(os.path.join(many, name + ".bin"), "rb").read()
         assert a == b, name
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("RFX_HOSTSIM") != "1", reason="written after the round's GPU budget: runs under pytest --hostsim until it has been seen on the device")
+@pytest.mark.parametrize("mipmaps", [True, False])
+def test_node_cube_environment_equals_python_host(tmp_path, mipmaps):
+    """`run_dump.js --envCube`: scene.environment as a CubeTexture through the Node host (CubeToEquirectEnvPass -> rfx_cube_to_equirect, the
+    importance tables from the converted map) drives the same bytes as the Python host."""
+    import golden_util as G
+    from rfx_amd.context import Context
+    from rfx_amd.dump import write_dump
+    from rfx_amd.scene import synthetic_frame
+    W, H = 160, 96
+    f = synthetic_frame(W, H, 0)
+    d = str(tmp_path / "dump0")
+    write_dump(d, f)
+    faces = np.ascontiguousarray(G.load("cube_32")["faces"])
+    cf = str(tmp_path / "cube.bin")
+    faces.tofile(cf)
+    out = str(tmp_path / "js_out")
+    subprocess.check_output([node, os.path.join(JS, "run_dump.js"), d, "--out", out, "--steps", "12", "--refineSteps", "3", "--envCube", json.dumps(cf), "--envCubeSize", "32"]
+                            + ([] if mipmaps else ["--envCubeMipmaps", "false"]), text=True)
+    cube = dict(isCubeTexture=True, faces=faces)
+    if not mipmaps:
+        cube.update(minFilter=effect.LinearFilter, generateMipmaps=False)
+    scene = types.SimpleNamespace(frame=f, environment=cube)
+    cam = types.SimpleNamespace(**vars(f.camera))
+    fx = effect.SSGIEffect(None, scene, cam, dict(width=W, height=H, steps=12, refineSteps=3), seeds=dict(ssgi=11, denoise=22), half_store_rtz=True)
+    ctx = Context(W, H)
+    fx.update(ctx, None)
+    for name, tex in (("compose", abi.TEX_COMPOSE), ("ssgi", abi.TEX_SSGI)):
+        py = ctx.download(tex)
+        js = np.fromfile(os.path.join(out, name + ".bin"), py.dtype).reshape(py.shape)
+        assert np.array_equal(py.view(np.uint8), js.view(np.uint8)), name
+    ctx.close()
