@@ -506,7 +506,8 @@ def test_node_row_tiled_run_equals_single_process(tmp_path, ranks):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("RFX_HOSTSIM") != "1", reason="written after the round's GPU budget: runs under pytest --hostsim until it has been seen on the device")
+@pytest.mark.skipif(os.environ.get("RFX_HOSTSIM") != "1" and os.environ.get("RFX_TEST_UNSEEN") != "1",
+                    reason="written after the round's GPU budget: runs under pytest --hostsim, and on the device with RFX_TEST_UNSEEN=1 until it has been seen green there")
 @pytest.mark.parametrize("mipmaps", [True, False])
 def test_node_cube_environment_equals_python_host(tmp_path, mipmaps):
     """`run_dump.js --envCube`: scene.environment as a CubeTexture through the Node host (CubeToEquirectEnvPass -> rfx_cube_to_equirect, the

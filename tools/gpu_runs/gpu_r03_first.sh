@@ -9,12 +9,13 @@
 # last GPU minute to that); the ids of the reference-vUv cases contain "vUv".
 set -x
 mkdir -p gpurun_out/r03_a
-export RFX_TEST_UV_REFERENCE=1
+export RFX_TEST_UV_REFERENCE=1 RFX_TEST_UNSEEN=1   # UNSEEN: tests written after round 2's GPU budget (Node host with a cube environment)
 timeout 300 python -m pytest tests/test_gpu_baseline_configs.py -m gpu -s -v -k "vUv" --durations=5 > gpurun_out/r03_a/uv_reference_1080p.txt 2>&1
+timeout 200 python -m pytest tests/test_node_host.py tests/test_zz_gpu_cube_environment.py -m gpu -q -k "cube" > gpurun_out/r03_a/cube.txt 2>&1; tail -3 gpurun_out/r03_a/cube.txt
 grep -E "PASSED|FAILED|passed|failed|UNEXPLAINED [1-9]" gpurun_out/r03_a/uv_reference_1080p.txt | tail -20
 timeout 400 python tools/parity_configs.py --impl hip --size 3840x2160 --steps 20 --it 1 --frames 2 --uv-model reference_gl --out gpurun_out/r03_a/parity_configs2_reference_uv.txt > /dev/null 2>&1
 tail -12 gpurun_out/r03_a/parity_configs2_reference_uv.txt
-unset RFX_TEST_UV_REFERENCE
+unset RFX_TEST_UV_REFERENCE RFX_TEST_UNSEEN
 timeout 600 python -m pytest tests -m gpu -q -x --durations=8 > gpurun_out/r03_a/pytest_gpu.log 2>&1
 grep -E "passed|failed" gpurun_out/r03_a/pytest_gpu.log | tail -3
 timeout 300 python bench.py > gpurun_out/r03_a/bench.json 2> gpurun_out/r03_a/bench.err
