@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzzing of the kernels' logic in the build container: random frame sizes (odd, tiny, portrait) and option values; every stage of the chain on the host simulator (tests/hostsim: the kernel sources compiled for x86) against the C restatement
+"""Differential fuzzing of the kernels' logic in the build container: random frame sizes (odd, tiny, portrait), option values and row tilings; every stage of the chain on the host simulator (tests/hostsim: the kernel sources compiled for x86) against the C restatement
 on the same inputs.  Both sides use libm-grade primitives, so they agree to a handful of flipped pixels: a stage that differs on more
 than a fraction of a percent of its pixels is a logic bug (apron, halo, launch shape, an option the kernel and the oracle read differently).
 
@@ -98,6 +98,61 @@ for it in range(a.n):
                     print("MISMATCH %s frame %d: %.3f%% of pixels (in-tolerance max %.2e)  cfg %s" % (name, o["fi"], 100 * frac, mx, cfg), flush=True)
         assert ctx.halo_violations() == 0, "halo violations"
         ctx.close()
+        # ... and cut into row tiles (ragged, as thin as the halo allows): every tile's own rows, each stage fed the oracle's whole-frame
+        # outputs of the previous stage — what a row-tiled run holds after its exchanges
+        from rfx_amd import tiling
+        ntiles = int(rng.choice([2, 3, 5]))
+        vmax = max(float(np.abs(o["f"].velocity[..., 1].view(np.float32)).max()) for o in outs)
+        halo = tiling.required_halo(radius, vmax, H, W)
+        split = tiling.split_rows(H, ntiles) if H >= 2 * ntiles else []
+        if split and min(r for _, r in split) >= max(halo, 1):
+            for (y0, rows) in split:
+                c = Context(W, H, tile_y0=y0, tile_rows=rows, halo_rows=halo)
+                c.set_uv_model(uvm)
+
+                def up(tex, full):
+                    h0, hn = c.held_rows(tex)
+                    c.upload(tex, full[h0:h0 + hn], h0, hn)
+
+                def own(tex):
+                    return c.download(tex, y0, rows)
+                for o in outs:
+                    f = o["f"]
+                    c.upload_frame(f)
+                    dp = S.stage_params(f.camera, f.camera, 1.0, steps, refine)[2]
+                    dp.phi, dp.lumaPhi, dp.depthPhi, dp.normalPhi, dp.halfStoreRTZ = opt["phi"], opt["lumaPhi"], opt["depthPhi"], opt["normalPhi"], opt["rtz"]
+                    dp.radius = radius
+                    up(abi.TEX_COMPOSE, o["hist"])
+                    c.ssgi_march(o["sp"])
+                    k1 = own(abi.TEX_SSGI)
+                    up(abi.TEX_SSGI, o["k1"]); up(abi.TEX_DENOISE_B0, o["B"][0]); up(abi.TEX_DENOISE_B1, o["B"][1])
+                    up(abi.TEX_TEMPORAL0, o["T"][0]); up(abi.TEX_TEMPORAL1, o["T"][1])
+                    c.temporal_reproject(o["tp"])
+                    T = [own(abi.TEX_TEMPORAL0), own(abi.TEX_TEMPORAL1)]
+                    up(abi.TEX_TEMPORAL0, o["Tn"][0]); up(abi.TEX_TEMPORAL1, o["Tn"][1]); up(abi.TEX_DENOISE_A0, z16); up(abi.TEX_DENOISE_A1, z16)
+                    dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 200 + 2 * o["fi"], 1, 0
+                    c.poisson_denoise(dp)
+                    A = [own(abi.TEX_DENOISE_A0), own(abi.TEX_DENOISE_A1)]
+                    up(abi.TEX_DENOISE_A0, o["A"][0]); up(abi.TEX_DENOISE_A1, o["A"][1]); up(abi.TEX_DENOISE_B0, o["B"][0]); up(abi.TEX_DENOISE_B1, o["B"][1])
+                    dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 201 + 2 * o["fi"], 0, 1
+                    c.poisson_denoise(dp)
+                    Bn = [own(abi.TEX_DENOISE_B0), own(abi.TEX_DENOISE_B1)]
+                    up(abi.TEX_DENOISE_B0, o["Bn"][0]); up(abi.TEX_DENOISE_B1, o["Bn"][1]); up(abi.TEX_COMPOSE, o["hist"])
+                    c.compose(o["cp"])
+                    comp = own(abi.TEX_COMPOSE)
+                    sl = slice(y0, y0 + rows)
+                    for name, g, w, lim in (("K1", h8(k1), h8(o["k1"][sl]), 5e-3), ("K2.0", T[0], o["Tn"][0][sl], 5e-3), ("K2.1", T[1], o["Tn"][1][sl], 5e-3),
+                                            ("K3a.0", h8(A[0]), h8(o["A"][0][sl]), 1e-2), ("K3b.0", h8(Bn[0]), h8(o["Bn"][0][sl]), 1e-2),
+                                            ("K3b.1", h8(Bn[1]), h8(o["Bn"][1][sl]), 1e-2), ("K4", comp, o["comp"][sl], 5e-3)):
+                        frac, mx = compare(g, w)
+                        nchecks += 1
+                        if frac > lim + 2.0 / (W * rows):
+                            fails += 1
+                            print("MISMATCH tile [%d,+%d) halo %d %s frame %d: %.3f%% of pixels  cfg %s" % (y0, rows, halo, name, o["fi"], 100 * frac, cfg), flush=True)
+                if c.halo_violations():
+                    fails += 1
+                    print("HALO VIOLATIONS %d tile [%d,+%d) halo %d cfg %s" % (c.halo_violations(), y0, rows, halo, cfg), flush=True)
+                c.close()
     except Exception as e:  # noqa: BLE001
         fails += 1
         print("ERROR %r cfg %s" % (e, cfg), flush=True)
