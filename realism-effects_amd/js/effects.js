@@ -700,30 +700,30 @@ class SSGIEffect {
 		const u = this.ssgiPass.uniforms
 		if (env) {
 			if (this._envUuid !== env) {
-				let env = this._scene.environment
-				if (env.isCubeTexture) {
+				let map = env
+				if (map.isCubeTexture) {
 					// :316-321 convert it to an equirectangular texture so the pass can sample it and use MIS
 					if (!this.cubeToEquirectEnvPass) this.cubeToEquirectEnvPass = new CubeToEquirectEnvPass()
-					env = this.cubeToEquirectEnvPass.generateEquirectEnvMap(renderer, env)
+					map = this.cubeToEquirectEnvPass.generateEquirectEnvMap(renderer, map)
 				}
-				const half = env.type === undefined || env.type === null || env.type === HalfFloatType
-				renderer.setEnvironment(env.data, env.width, env.height, half, this._halfStoreRTZ === undefined || this._halfStoreRTZ)
+				const half = map.type === undefined || map.type === null || map.type === HalfFloatType
+				renderer.setEnvironment(map.data, map.width, map.height, half, this._halfStoreRTZ === undefined || this._halfStoreRTZ)
 				u.importanceSampling = 0
 				if (this._options.importanceSampling) {
 					// :348-351 EquirectHdrInfoUniform.updateFrom, then the define.  The worker sees the half-float texels (fromHalfFloat); `data` is
 					// in GL row order (row 0 = bottom): with texture.flipY the reference's array is the other way up and the worker "un-flips" it
-					let texels = half ? toHalfPrecision(env.data) : env.data
-					if (env.flipY) {
+					let texels = half ? toHalfPrecision(map.data) : map.data
+					if (map.flipY) {
 						const r = new Float32Array(texels.length)
-						const rowLen = env.width * 4
-						for (let y = 0; y < env.height; y++) r.set(texels.subarray(y * rowLen, (y + 1) * rowLen), (env.height - 1 - y) * rowLen)
+						const rowLen = map.width * 4
+						for (let y = 0; y < map.height; y++) r.set(texels.subarray(y * rowLen, (y + 1) * rowLen), (map.height - 1 - y) * rowLen)
 						texels = r
 					}
-					const imp = buildImportance(texels, env.width, env.height, !!env.flipY)
+					const imp = buildImportance(texels, map.width, map.height, !!map.flipY)
 					renderer.setEnvironmentImportance(imp.marginalWeights, imp.conditionalWeights, imp.totalSumValue)
 					u.importanceSampling = 1
 				}
-				this._envUuid = this._scene.environment
+				this._envUuid = env
 				u.useEnvMap = 1 // defines.USE_ENVMAP :344
 				this.reset() // :356
 			}
