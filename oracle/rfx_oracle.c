@@ -1374,7 +1374,9 @@ static void k3_pixel(const k3_ctx *c, int x, int y, uint16_t *out0, uint16_t *ou
     v4 random = blue_noise(c->blue, x, y, p->blueNoiseIndex, u, v, d);
     float r = p->radius;
     float angle = random.x * 2.0f * 3.141592653589793f;
-    float s = sinf(angle), co = cosf(angle);
+    /* 256 possible angles (an 8-bit blue-noise channel): the correctly rounded values, which is what the kernel's table holds
+     * (csrc/k3_rotation_table.h) and what the reference GL returns at the two angles that decide taps (bytes 85, 170) */
+    float s = pert_ang((float)sin((double)angle)), co = pert_ang((float)cos((double)angle));
     /* mat2 rm = r * flatness * mat2(c, -s, s, c): columns (c,-s), (s,c) */
     float rf = r * flatness;
     float m00 = rf * co, m01 = rf * -s, m10 = rf * s, m11 = rf * co; /* m<col><row> */

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include "rfx_device.h"
 #include "rfx_kernels.h"
+#include "k3_rotation_table.h"
 
 namespace {
 
@@ -173,10 +174,10 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         c[i].total = 1.0f;
     }
 
-    const float4 rnd = rfx_blue_noise((const uchar4 *)A.blue, x, y, A.shift_x, A.shift_y);
-    const float angle = rnd.x * 2.0f * 3.141592653589793f;
-    float sn, co;
-    rfx_sincos(angle, sn, co);
+    // angle = blueNoise.r * 2 pi takes 256 values: (sin, cos) from the correctly rounded table (k3_rotation_table.h).  At 120 / 240 degrees
+    // (bytes 85, 170) a radius-3 tap of a flat surface sits exactly on a texel boundary and the last bit of cos decides its texel
+    const float2 rot = K3_ROTATION[rfx_blue_noise_texel((const uchar4 *)A.blue, x, y, A.shift_x, A.shift_y).x];
+    const float sn = rot.x, co = rot.y;
     const float rf = p.radius * flatness;
     const float m00 = rf * co, m01 = rf * -sn, m10 = rf * sn, m11 = rf * co;  // mat2 rm = r*flatness*mat2(c,-s,s,c) :183
 
@@ -274,10 +275,10 @@ RFX_DEV void k3_generic_body(const K3Args &A, const FrameDims &d) {
         flatness = 1.0f - fminf(rfx_length(fw), 1.0f);
         flatness = (flatness * flatness) * 0.75f + 0.25f;
     }
-    const float4 rnd = rfx_blue_noise((const uchar4 *)A.blue, x, y, A.shift_x, A.shift_y);
-    const float angle = rnd.x * 2.0f * 3.141592653589793f;
-    float sn, co;
-    rfx_sincos(angle, sn, co);
+    // angle = blueNoise.r * 2 pi takes 256 values: (sin, cos) from the correctly rounded table (k3_rotation_table.h).  At 120 / 240 degrees
+    // (bytes 85, 170) a radius-3 tap of a flat surface sits exactly on a texel boundary and the last bit of cos decides its texel
+    const float2 rot = K3_ROTATION[rfx_blue_noise_texel((const uchar4 *)A.blue, x, y, A.shift_x, A.shift_y).x];
+    const float sn = rot.x, co = rot.y;
     const float rf = p.radius * flatness;
     const float m00 = rf * co, m01 = rf * -sn, m10 = rf * sn, m11 = rf * co;
     for (int k = 0; k < 8; k++) {

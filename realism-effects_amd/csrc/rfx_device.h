@@ -360,9 +360,12 @@ RFX_DEV void rfx_pcg4d(uint32_t &x, uint32_t &y, uint32_t &z, uint32_t &w) {
     x += y * w; y += z * x; z += x * y; w += y * z;
 }
 // RGBA8 -> float as the sampler does it: float(byte) * (1/255)
-RFX_DEV float4 rfx_blue_noise(const uchar4 *table, int px, int py, int shift_x, int shift_y) {
+RFX_DEV uchar4 rfx_blue_noise_texel(const uchar4 *table, int px, int py, int shift_x, int shift_y) {
     int sx = (px + shift_x) & 127, sy = (py + shift_y) & 127; // (pixel + shift) % 128, operands >= 0
-    uchar4 t = table[sy * 128 + sx];
+    return table[sy * 128 + sx];
+}
+RFX_DEV float4 rfx_blue_noise(const uchar4 *table, int px, int py, int shift_x, int shift_y) {
+    uchar4 t = rfx_blue_noise_texel(table, px, py, shift_x, shift_y);
     const float k = (float)(1.0 / 255.0);
     return make_float4(t.x * k, t.y * k, t.z * k, t.w * k);
 }
