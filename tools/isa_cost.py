@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Static issue-cost model of a gfx950 kernel's ISA (development helper, runs in the build container).
+
+    hipcc ... -S --cuda-device-only k3_denoise.hip -o k3.s
+    python tools/isa_cost.py k3.s k3_tiledILb0ELi2 [--loops]
+
+Every VALU instruction is priced with the issue rate MEASURED on MI355X (tools/microbench/valu_rates.hip,
+profiles/r0N_*/valu_rates.txt, cycles per wave64 instruction per SIMD at 8 waves/SIMD): these kernels run with their VALU pipes
+saturated (SQ_ACTIVE_INST_VALU*4 / (SIMDs * cycles) = 0.9-1.1), so a kernel's time is, to first order, the sum of its
+executed VALU instructions' issue cycles.  The tool prints that sum per basic block / loop so that an edit's effect on a loop body can
+be read before spending GPU minutes; trip counts are the reader's business (--trip LABEL=N).
+"""
+import re
+import sys
+from collections import Counter, OrderedDict
+
+# cycles per wave64 instruction (profiles/r03_*/valu_rates.txt once collected; r02 values otherwise)
+RATES = OrderedDict([
+    ("trans", 8.3),    # v_exp/log/rcp/rsq/sqrt/sin/cos_f32
+    ("pk", 4.8),       # v_pk_{fma,mul,add}_f32
+    ("addmul", 2.6),   # v_add/sub/subrev/mul_f32 (VOP2 forms)
+    ("generic", 4.15), # everything else on the VALU
+])
+TRANS = re.compile(r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)_(f32|f16|legacy_f32)")
+PK = re.compile(r"^v_pk_")
+ADDMUL = re.compile(r"^v_(add|sub|subrev|mul)_f32")
+
+
+def classify(op):
+    if TRANS.match(op):
+        return "trans"
+    if PK.match(op):
+        return "pk"
+    if ADDMUL.match(op):
+        return "addmul"
+    return "generic"
+
+
+def parse(path, kernel_substr):
+    """-> ordered {label: [ops]} of the first kernel whose mangled name contains kernel_substr"""
+    blocks = OrderedDict()
+    cur = None
+    inside = False
+    for line in open(path):
+        s = line.strip()
+        if not inside:
+            if s.endswith(":") or re.match(r"^[_A-Za-z0-9.$]+:", s):
+                name = s.split(":")[0]
+                if kernel_substr in name and not name.startswith("."):
+                    inside = True
+                    cur = "entry"
+                    blocks[cur] = []
+            continue
+        if s.startswith(".Lfunc_end") or s.startswith("s_endpgm") and False:
+            break
+        m = re.match(r"^(\.LBB[0-9_]+):", s)
+        if m:
+            cur = m.group(1)
+            blocks[cur] = []
+            continue
+        if not s or s.startswith(";") or s.startswith("."):
+            if s.startswith(".section") or s.startswith(".rodata"):
+                break
+            continue
+        op = s.split()[0]
+        blocks[cur].append((op, s))
+    return blocks
+
+
+def cost(ops):
+    c = Counter()
+    for op, _ in ops:
+        if op.startswith("v_") and not op.startswith("v_readlane") and not op.startswith("v_readfirstlane"):
+            c[classify(op)] += 1
+        elif op.startswith("ds_"):
+            c["lds"] += 1
+        elif op.startswith("global_") or op.startswith("buffer_") or op.startswith("flat_") or op.startswith("scratch_"):
+            c["vmem"] += 1
+        elif op.startswith("s_waitcnt") or op.startswith("s_nop"):
+            c["wait/nop"] += 1
+        elif op.startswith("s_cbranch") or op.startswith("s_branch"):
+            c["branch"] += 1
+        elif op.startswith("s_"):
+            c["salu"] += 1
+    cyc = sum(RATES[k] * c[k] for k in RATES)
+    return c, cyc
+
+
+def main():
+    if len(sys.argv) < 3:
+        print(__doc__)
+        sys.exit(2)
+    blocks = parse(sys.argv[1], sys.argv[2])
+    if not blocks:
+        sys.exit("kernel not found")
+    trips = {}
+    for a in sys.argv[3:]:
+        if a.startswith("--trip"):
+            continue
+        if "=" in a:
+            k, v = a.split("=")
+            trips[k] = float(v)
+    tot = Counter()
+    totc = 0.0
+    wsum = 0.0
+    print("%-12s %5s %5s %5s %5s %5s | %4s %4s %4s %4s | %8s" % ("block", "valu", "trans", "pk", "a/m", "gen", "lds", "vmem", "salu", "br", "cycles"))
+    for lab, ops in blocks.items():
+        c, cyc = cost(ops)
+        nv = sum(c[k] for k in RATES)
+        if nv == 0 and c["lds"] + c["vmem"] == 0:
+            continue
+        t = trips.get(lab, 1.0)
+        print("%-12s %5d %5d %5d %5d %5d | %4d %4d %4d %4d | %8.0f%s" % (lab, nv, c["trans"], c["pk"], c["addmul"], c["generic"], c["lds"], c["vmem"], c["salu"],
+                                                                       c["branch"], cyc, ("  x%g" % t) if t != 1 else ""))
+        tot.update(c)
+        totc += cyc
+        wsum += cyc * t
+    nv = sum(tot[k] for k in RATES)
+    print("%-12s %5d %5d %5d %5d %5d | %4d %4d %4d %4d | %8.0f   weighted %.0f" % ("static sum", nv, tot["trans"], tot["pk"], tot["addmul"], tot["generic"], tot["lds"],
+                                                                                  tot["vmem"], tot["salu"], tot["branch"], totc, wsum))
+
+
+if __name__ == "__main__":
+    main()
