@@ -64,10 +64,17 @@ RFX_DEV float k1_div(float x, float w, float r) {
     const float q = x * r;
     return __builtin_fmaf(__builtin_fmaf(-w, q, x), r, q);
 }
-template <bool PERSP>
+// PROJ 2: additionally P[8] == P[9] == 0 (a centred frustum: every three.js PerspectiveCamera without a view offset) — the products
+// P8 z, P9 z are zeros and adding them changes at most the sign of a zero numerator, which the * 0.5 + 0.5 below erases.
+constexpr int PROJ_GENERAL = 0, PROJ_PERSPECTIVE = 1, PROJ_CENTRED = 2;
+template <int PROJ>
 RFX_DEV float2 k1_project(const MarchCtx &m, float3 p) {
     float px, py, pw;
-    if (PERSP) {
+    if (PROJ == PROJ_CENTRED) {
+        px = m.P[0] * p.x;
+        py = m.P[5] * p.y;
+        pw = -p.z;
+    } else if (PROJ == PROJ_PERSPECTIVE) {
         px = m.P[0] * p.x + m.P[8] * p.z;
         py = m.P[5] * p.y + m.P[9] * p.z;
         pw = -p.z;
@@ -83,12 +90,30 @@ struct Tap {
     unsigned int idx;   // texel index into the view-Z plane (32-bit byte offsets from the wave-uniform base: the plane is < 4 GiB)
     unsigned int cell;  // index into the (min, max) table
 };
-RFX_DEV Tap k1_tap(const MarchCtx &m, const FrameDims &d, float2 uv) {
-    const int xi = rfx_nearest_idx(uv.x, d.fW, d.W), yi = rfx_nearest_idx(uv.y, d.fH, d.H);
+RFX_DEV Tap k1_tap_at(const MarchCtx &m, const FrameDims &d, int xi, int yi) {
     Tap t;
     t.idx = (unsigned int)(__mul24(yi, d.W) + xi);  // rows and widths are < 2^23: the full-rate 24-bit multiply-add
     t.cell = (unsigned int)(__mul24(yi >> m.cell_shift, m.coarse_w) + (xi >> m.cell_shift));
     return t;
+}
+RFX_DEV Tap k1_tap(const MarchCtx &m, const FrameDims &d, float2 uv) {
+    return k1_tap_at(m, d, rfx_nearest_idx(uv.x, d.fW, d.W), rfx_nearest_idx(uv.y, d.fH, d.H));
+}
+// The taps of both rays of a march step.  rfx_nearest_idx guards every coordinate against |u * size| >= 2^31 (texel 0 in the reference: x86
+// cvttss2si) with a compare and a select; a projected uv is that large only when a sample falls within ~1e-6 of the
+// camera plane, so the test is made ONCE per step for the whole wavefront (three v_max on the four coordinates, one compare) and the guarded
+// form runs in the wavefronts that need it.  v_med3_f32 sends a NaN to 0 as the guard does.  Same indices in every case.
+RFX_DEV void k1_taps(const MarchCtx &m, const FrameDims &d, const float2 (&uv)[2], Tap (&tap)[2]) {
+    const float cx0 = uv[0].x * d.fW, cy0 = uv[0].y * d.fH, cx1 = uv[1].x * d.fW, cy1 = uv[1].y * d.fH;
+    const float big = fmaxf(fmaxf(fabsf(cx0), fabsf(cy0)), fmaxf(fabsf(cx1), fabsf(cy1)));
+    if (__builtin_amdgcn_ballot_w64(big >= 2147483648.0f) != 0) {
+        tap[0] = k1_tap(m, d, uv[0]);
+        tap[1] = k1_tap(m, d, uv[1]);
+    } else {
+        const float wm1 = (float)(d.W - 1), hm1 = (float)(d.H - 1);
+        tap[0] = k1_tap_at(m, d, (int)__builtin_amdgcn_fmed3f(cx0, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy0, 0.0f, hm1));
+        tap[1] = k1_tap_at(m, d, (int)__builtin_amdgcn_fmed3f(cx1, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy1, 0.0f, hm1));
+    }
 }
 // RayMarch (:441-475) + BinarySearch (:477-503) for the pixel's TWO rays at once (slot 0 = optional diffuse ray,
 // slot 1 = specular ray), restructured for the SIMT machine without changing any per-ray arithmetic:
@@ -101,7 +126,7 @@ struct Ray {
     float2 uv;
     bool active, hit;
 };
-template <bool PERSP>
+template <int PROJ>
 RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2], float random_b) {
     const float scale = m.rayDistance / (float)m.steps;
 #pragma unroll
@@ -115,19 +140,21 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         const float cs = 1.0f - rfx_exp(-0.25f * (t * t));
 #pragma unroll
         for (int r = 0; r < 2; r++) {
-            // straight-line: a stopped ray keeps its position (select) and re-derives the same uv — no exec-mask region per ray
-            // (measured 0.654 vs 0.666 ms at 4K, same texels)
-            const float3 np = rays[r].pos + rays[r].dir * cs;
-            rays[r].pos = make_float3(rays[r].active ? np.x : rays[r].pos.x, rays[r].active ? np.y : rays[r].pos.y, rays[r].active ? np.z : rays[r].pos.z);
-            rays[r].uv = k1_project<PERSP>(m, rays[r].pos);
+            // straight-line: a stopped ray advances by dir * 0 (pos + (+-0) == pos: one select on the step instead of three on the position)
+            // and re-derives the same uv — no exec-mask region per ray (measured 0.654 vs 0.666 ms at 4K, same texels)
+            const float csr = rays[r].active ? cs : 0.0f;
+            rays[r].pos = rays[r].pos + rays[r].dir * csr;
+            rays[r].uv = k1_project<PROJ>(m, rays[r].pos);
         }
         // taps of both rays in flight together: the two coarse cells first, then the exact texels of the cells that cannot
         // rule a hit out (a hit needs 0 <= z - h < thickness; the cell range rules it out when max - h < 0 or min - h >= thickness)
         Tap tap[2];
         float2 mm[2];
         bool need[2];
-#pragma unroll
-        for (int r = 0; r < 2; r++) tap[r] = k1_tap(m, d, rays[r].uv);
+        {
+            const float2 uvs[2] = {rays[0].uv, rays[1].uv};
+            k1_taps(m, d, uvs, tap);
+        }
 #pragma unroll
         for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
 #pragma unroll
@@ -148,16 +175,16 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         }
     }
     if (m.refineSteps > 0) {
+        // (a ray that did not hit takes steps of dir * 0: its position is replaced below anyway, its direction is not read again)
 #pragma unroll
-        for (int r = 0; r < 2; r++)
-            if (rays[r].hit) {
-                rays[r].dir = rays[r].dir * 0.5f;
-                rays[r].pos = rays[r].pos - rays[r].dir;
-            }
+        for (int r = 0; r < 2; r++) {
+            rays[r].dir = rays[r].dir * 0.5f;
+            rays[r].pos = rays[r].pos + rays[r].dir * (rays[r].hit ? -1.0f : 0.0f);  // pos - dir, exactly
+        }
         for (int k = 0; k < m.refineSteps; k++) {
 #pragma unroll
             for (int r = 0; r < 2; r++)
-                if (rays[r].hit) rays[r].uv = k1_project<PERSP>(m, rays[r].pos);
+                if (rays[r].hit) rays[r].uv = k1_project<PROJ>(m, rays[r].pos);
             // BinarySearch only tests the sign of z_tap - h (:493): decided by the cell when max - h < 0 or min - h >= 0
             Tap tap[2];
             float2 mm[2];
@@ -183,24 +210,26 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
 #pragma unroll
             for (int r = 0; r < 2; r++) z[r] = need[r] ? rfx_gather<float>(m.viewz, tap[r].idx) : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 2; r++)
-                if (rays[r].hit) {
-                    if (need[r]) behind[r] = z[r] - rays[r].pos.z >= 0.0f;
-                    rays[r].dir = rays[r].dir * 0.5f;
-                    rays[r].pos = behind[r] ? rays[r].pos - rays[r].dir : rays[r].pos + rays[r].dir;
-                }
+            for (int r = 0; r < 2; r++) {
+                if (need[r]) behind[r] = z[r] - rays[r].pos.z >= 0.0f;
+                rays[r].dir = rays[r].dir * 0.5f;
+                // pos -+ dir as pos + dir * (-+1): the product is exact, so the sum rounds as the difference does
+                rays[r].pos = rays[r].pos + rays[r].dir * (rays[r].hit ? (behind[r] ? -1.0f : 1.0f) : 0.0f);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 2; r++)
-            if (rays[r].hit) rays[r].uv = k1_project<PERSP>(m, rays[r].pos);
+            if (rays[r].hit) rays[r].uv = k1_project<PROJ>(m, rays[r].pos);
     }
 #pragma unroll
     for (int r = 0; r < 2; r++)
         if (!rays[r].hit) rays[r].pos = make_float3(10.0e9f, 10.0e9f, 10.0e9f);  // :472
 }
 
-RFX_DEV float k1_smoothstep(float e0, float e1, float x) {
-    float t = rfx_clamp((x - e0) / (e1 - e0), 0.0f, 1.0f);
+// smoothstep with constant edges: the divisor e1 - e0 is a constant, the quotient the correctly rounded one (RFX_DIV_CONST)
+#define K1_SMOOTHSTEP(e0, e1, x) k1_smoothstep_q(RFX_DIV_CONST((x) - (e0), (e1) - (e0)))
+RFX_DEV float k1_smoothstep_q(float q) {
+    const float t = rfx_clamp(q, 0.0f, 1.0f);
     return t * t * (3.0f - 2.0f * t);
 }
 
@@ -225,7 +254,7 @@ RFX_DEV float k1_brdf_over_pdf_parts(const Material &mat, float3 viewNormal, flo
     float brdf;
     if (isDiffuseSample) {
         brdf = rfx_eval_disney_diffuse(an.NoL, NoV, an.LoH, roughness, mat.metalness);
-        pdf = an.NoL / RFX_PI;
+        pdf = RFX_DIV_CONST(an.NoL, RFX_PI);
     } else {
         brdf = rfx_eval_disney_specular(roughness, an.NoH, NoV, an.NoL);
         pdf = rfx_ggx_vndf_pdf(an.NoH, NoV, roughness);
@@ -266,14 +295,14 @@ RFX_DEV float3 k1_env_trilinear(const K1Args &A, float u, float v, float lod_unc
 RFX_DEV float3 k1_env_color(const K1Args &A, float3 l, float roughness, bool isDiffuseSample, bool isEnvSample) {
     const float3 dir = rfx_normalize(rfx_vec_mul_mat(A.p.camera.matrixWorldInverse, l, 0.0f));  // (vec4(l, 0.) * viewMatrix).xyz :315
     float mip = A.p.envBlur * A.maxEnvMapMipLevel;
-    if (!isDiffuseSample && roughness < 0.15f) mip *= roughness / 0.15f;
+    if (!isDiffuseSample && roughness < 0.15f) mip *= RFX_DIV_CONST(roughness, 0.15f);
     // equirectDirectionToUv ssgi_utils.frag:64-74
-    float u = atan2f(dir.z, dir.x) / (2.0f * 3.1415926535897932384626433832795f), v = k1_acos(dir.y) / 3.1415926535897932384626433832795f;
+    float u = RFX_DIV_CONST(atan2f(dir.z, dir.x), 2.0f * 3.1415926535897932384626433832795f), v = RFX_DIV_CONST(k1_acos(dir.y), 3.1415926535897932384626433832795f);
     u += 0.5f;
     v = 1.0f - v;
     float3 c = k1_env_trilinear(A, u, v, mip);
     const float maxEnvLum = isEnvSample ? 100.0f : 25.0f, envLum = rfx_lum(c);  // :328-340
-    if (envLum > maxEnvLum) c = c * (maxEnvLum / envLum);
+    if (envLum > maxEnvLum) c = c * rfx_div_pos(maxEnvLum, envLum);
     return c;
 }
 
@@ -310,7 +339,7 @@ struct EnvMis {  // EnvMisSample ssgi.frag:79-83
     float pdf;
     bool isEnvSample;
 };
-RFX_DEV float k1_mis_heuristic(float a, float b) { return (a * a) / (a * a + b * b); }  // misHeuristic ssgi_utils.frag:227-231
+RFX_DEV float k1_mis_heuristic(float a, float b) { return rfx_div_pos(a * a, a * a + b * b); }  // misHeuristic ssgi_utils.frag:227-231
 
 // ... and the shading of the marched ray: gi * brdf / pdf
 template <bool ENV, bool MIS>
@@ -338,12 +367,12 @@ RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat
             }
             const float mx = fmaxf(fmaxf(mat.diffuse.x, mat.diffuse.y), mat.diffuse.z);
             const float mn = fminf(fminf(mat.diffuse.x, mat.diffuse.y), mat.diffuse.z);
-            const float sat = (mx == mn) ? 0.0f : (mx - mn) / mx;  // getSaturation :348-360
+            const float sat = (mx == mn) ? 0.0f : rfx_div_pos(mx - mn, mx);  // getSaturation :348-360 (mx > mn >= 0: a byte / 255 - 1e-4, at least 0.0038)
             const float L = rfx_lum(gi);
             gi = rfx_mix(gi, make_float3(L, L, L), (1.0f - roughness) * sat * 0.4f);
             const float border = 0.15f;
-            float bf = k1_smoothstep(0.0f, border, coords.x) * k1_smoothstep(1.0f, 1.0f - border, coords.x) * k1_smoothstep(0.0f, border, coords.y) *
-                       k1_smoothstep(1.0f, 1.0f - border, coords.y);
+            float bf = K1_SMOOTHSTEP(0.0f, border, coords.x) * K1_SMOOTHSTEP(1.0f, 1.0f - border, coords.x) * K1_SMOOTHSTEP(0.0f, border, coords.y) *
+                       K1_SMOOTHSTEP(1.0f, 1.0f - border, coords.y);
             bf = rfx_sqrt(bf);
             ssgi = rfx_mix(env, gi, bf);  // :424
             if (allowMissed && 0.0f > rfx_lum(ssgi)) ssgi = make_float3(0.f, 0.f, 0.f);  // :430-436: `envMapSample` is never assigned -> 0
@@ -352,7 +381,10 @@ RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat
     }
     ssgi = ssgi * brdf;  // :236-244 / :256-264
     if (MIS && ems.isEnvSample) ssgi = ssgi * k1_mis_heuristic(ems.pdf, pdf);
-    else ssgi = make_float3(ssgi.x / pdf, ssgi.y / pdf, ssgi.z / pdf);
+    else {  // pdf >= 1e-5 (k1_brdf_over_pdf_parts): one refined reciprocal for the three quotients
+        const float r = rfx_rcp_rn(pdf);
+        ssgi = make_float3(rfx_div_const_impl(ssgi.x, pdf, r), rfx_div_const_impl(ssgi.y, pdf, r), rfx_div_const_impl(ssgi.z, pdf, r));
+    }
     if (MIS) ssgi = make_float3(ssgi.x / ems.pdf, ssgi.y / ems.pdf, ssgi.z / ems.pdf);  // without MIS ems.pdf == 1
     return ssgi;
 }
@@ -362,12 +394,10 @@ RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat
 // from A.hits instead of marching and finishes the fragment.  Only the shading reads last frame's composed GI anywhere on
 // screen, so a row-tiled run can let that texture's all-gather overlap the march (rfx.h rfx_ssgi_trace / rfx_ssgi_shade).
 // Same arithmetic in the same order either way (no contraction in this file): split == fused bit for bit (tests).
-template <bool PERSP, bool ENV, bool MIS, int STAGE>
+template <int PROJ, bool ENV, bool MIS, int STAGE>
 RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
-    const int nbx = (A.out_w + 63) / 64;
-    const int lb = blockIdx.x;
-    const int x = (lb % nbx) * 64 + threadIdx.x;
-    const int y = A.y0 + (lb / nbx) * 4 + threadIdx.y;
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = A.y0 + blockIdx.y * 4 + threadIdx.y;
     if (x >= A.out_w || y >= A.y1) return;
     const rfx_ssgi_params &p = A.p;
     const float *C = p.camera.matrixWorld, *Vw = p.camera.matrixWorldInverse;
@@ -500,7 +530,7 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
         rays[0].pos = make_float3(h1.x, h1.x, h1.x);  // only "missed" (pos.x == 10.0e9) is read of the diffuse ray
         rays[1].pos = make_float3(h1.y, h1.z, h1.w);
     } else {
-        k1_march_rays<PERSP>(m, d, rays, rnd.z);
+        k1_march_rays<PROJ>(m, d, rays, rnd.z);
     }
     if (STAGE == 1) {
         A.hits[2 * out_idx] = make_float4(rays[0].uv.x, rays[0].uv.y, rays[1].uv.x, rays[1].uv.y);
@@ -526,11 +556,11 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     }
 }
 
-template <bool PERSP, bool ENV, bool MIS, int STAGE>
+template <int PROJ, bool ENV, bool MIS, int STAGE>
 __global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-    k1_ssgi_march_body<PERSP, ENV, MIS, STAGE>(A, d);
+    k1_ssgi_march_body<PROJ, ENV, MIS, STAGE>(A, d);
     rfx_flush_violations(d);
 }
 
@@ -636,8 +666,7 @@ hipError_t rfx_launch_k1_prepare(const K1Args &A, hipStream_t stream) {
 
 hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
     const int nbx = (A.out_w + 63) / 64, nby = (A.y1 - A.y0 + 3) / 4;
-    const int nblocks = nbx * nby;
-    dim3 block(64, 4), grid(nblocks);
+    dim3 block(64, 4), grid(nbx, nby);  // dispatched x-fastest: tiles in launch order, as a 1-D grid would
     const float *P = A.p.camera.projectionMatrix;
     const bool persp = P[1] == 0.f && P[2] == 0.f && P[3] == 0.f && P[4] == 0.f && P[6] == 0.f && P[7] == 0.f && P[12] == 0.f && P[13] == 0.f &&
                        P[15] == 0.f && P[11] == -1.f;
@@ -648,8 +677,12 @@ hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
         else if (stage == 1) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 1>), grid, block, 0, stream, A); \
         else hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 2>), grid, block, 0, stream, A);                 \
     } while (0)
-    if (persp) { if (mis) K1_GO(true, true, true); else if (env) K1_GO(true, true, false); else K1_GO(true, false, false); }
-    else { if (mis) K1_GO(false, true, true); else if (env) K1_GO(false, true, false); else K1_GO(false, false, false); }
+    const bool centred = persp && P[8] == 0.f && P[9] == 0.f;
+#define K1_GO_P(PJ) do { if (mis) K1_GO(PJ, true, true); else if (env) K1_GO(PJ, true, false); else K1_GO(PJ, false, false); } while (0)
+    if (centred) K1_GO_P(PROJ_CENTRED);
+    else if (persp) K1_GO_P(PROJ_PERSPECTIVE);
+    else K1_GO_P(PROJ_GENERAL);
+#undef K1_GO_P
 #undef K1_GO
     return hipGetLastError();
 }

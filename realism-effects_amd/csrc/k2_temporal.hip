@@ -42,9 +42,12 @@ RFX_DEV float3 k2_ss_to_ws(float u, float v, float depth, const float *matWorld,
     return make_float3(w.x, w.y, w.z);
 }
 // validateReprojectedUV reproject.frag:130-167 (the angleMix / lastViewAngle computation is dead code)
+template <bool WHOLE>
 RFX_DEV float k2_validate(const K2Args &A, const FrameDims &d, float ru, float rv, float3 worldPos, float3 worldNormal, float distFactor) {
     if (ru > 1.0f || ru < 0.0f || rv > 1.0f || rv < 0.0f) return 0.0f;
-    const VND last = k2_vnd(rfx_fetch_u4(A.velocity, d, ru, rv));  // NB: the CURRENT velocity texture
+    // NB: the CURRENT velocity texture, NEAREST
+    const int vx = rfx_nearest_idx(ru, d.fW, d.W), vy = rfx_nearest_idx(rv, d.fH, d.H);
+    const VND last = k2_vnd(rfx_gather<uint4>(A.velocity.ptr, (unsigned int)(__mul24(rfx_view_row<WHOLE>(d, A.velocity, vy), d.W) + vx)));
     const float3 lastWorldPos = k2_ss_to_ws(ru, rv, last.depth, A.p.prevCamera.matrixWorld, A.p.prevCamera.projectionMatrixInverse);
     const float3 dp = worldPos - lastWorldPos;
     float disoccl = 0.0f;
@@ -56,11 +59,13 @@ RFX_DEV float k2_validate(const K2Args &A, const FrameDims &d, float ru, float r
 }
 
 // BiCubicCatmullRom5Tap reproject.frag:212-255 — five hardware-bilinear taps of the RGBA16F (or RGBA32F) history
-template <bool HIST_F32>
+// (RGBA16F: the sampler's lerps fused, on the half texels themselves — rfx_fetch_h4_linear_fused; what the oracle GL does)
+template <bool HIST_F32, bool WHOLE>
 RFX_DEV float4 k2_history_tap(const TexView &tex, const FrameDims &d, float u, float v) {
-    return HIST_F32 ? rfx_fetch_f4_linear(tex, d, u, v) : rfx_fetch_h4_linear(tex, d, u, v);
+    if constexpr (HIST_F32) return rfx_fetch_f4_linear(tex, d, u, v);
+    else return rfx_fetch_h4_linear_fused<WHOLE>(tex, d, u, v);
 }
-template <bool HIST_F32>
+template <bool HIST_F32, bool WHOLE>
 RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &tex, float pu, float pv) {
     float Wa[2], Wb[2], Wc[2], S0[2], S1[2], S2[2];
     const float its[2] = {A.invW, A.invH}, P[2] = {pu, pv};
@@ -85,16 +90,19 @@ RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &te
     // (40 VGPRs, 147 in total -> 3 waves/SIMD); fenced, the kernel fits 125 VGPRs -> 4 waves/SIMD: 0.48 -> 0.445 ms, same texels.
     // (Ablation, same build: one tap instead of five 0.316 ms / 74 VGPRs, no history fetch 0.272, no neighbourhood AABB 0.467,
     // staging + reprojection alone 0.176 — the five-tap fetch is 38 % of K2, by arithmetic and registers, not by its addresses.)
-#define K2_TAP_FENCE(k) do { if (((k) % 2) == 0) asm volatile("" ::: "memory"); } while (0)  // after every 2nd tap (1, 2, 3 compile alike)
-    const float4 Ct = k2_history_tap<HIST_F32>(tex, d, S1[0], S0[1]);
+#ifndef RFX_K2_FENCE
+#define RFX_K2_FENCE 2  // build knob: fence after every n-th tap, 0 = none
+#endif
+#define K2_TAP_FENCE(k) do { if (RFX_K2_FENCE && ((k) % RFX_K2_FENCE) == 0) asm volatile("" ::: "memory"); } while (0)  // after every 2nd tap (1, 2, 3 compile alike)
+    const float4 Ct = k2_history_tap<HIST_F32, WHOLE>(tex, d, S1[0], S0[1]);
     K2_TAP_FENCE(1);
-    const float4 Cl = k2_history_tap<HIST_F32>(tex, d, S0[0], S1[1]);
+    const float4 Cl = k2_history_tap<HIST_F32, WHOLE>(tex, d, S0[0], S1[1]);
     K2_TAP_FENCE(2);
-    const float4 Cc = k2_history_tap<HIST_F32>(tex, d, S1[0], S1[1]);
+    const float4 Cc = k2_history_tap<HIST_F32, WHOLE>(tex, d, S1[0], S1[1]);
     K2_TAP_FENCE(3);
-    const float4 Cr = k2_history_tap<HIST_F32>(tex, d, S2[0], S1[1]);
+    const float4 Cr = k2_history_tap<HIST_F32, WHOLE>(tex, d, S2[0], S1[1]);
     K2_TAP_FENCE(4);
-    const float4 Cb = k2_history_tap<HIST_F32>(tex, d, S1[0], S2[1]);
+    const float4 Cb = k2_history_tap<HIST_F32, WHOLE>(tex, d, S1[0], S2[1]);
 #undef K2_TAP_FENCE
     const float wm = rfx_rcp((((sw0 + sw1) + sw2) + sw3) + sw4);
     float4 r;
@@ -132,7 +140,7 @@ struct Tile {
     float2 vel[LH * LW];     // velocity.xy
 };
 
-template <int INPUT_TYPE, int TC, bool LOGT, bool HIST_F32>
+template <int INPUT_TYPE, int TC, bool LOGT, bool HIST_F32, bool WHOLE>
 RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
     __shared__ Tile s;
     const rfx_temporal_params &p = A.p;
@@ -153,14 +161,14 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
             const int ix = rfx_nearest_idx(rfx_frag_u(d.uv, gx, gy), (float)A.in_w, A.in_w), iy = rfx_nearest_idx(rfx_frag_v(d.uv, gy), (float)A.in_h, A.in_h);
             t = ((const uint4 *)A.ssgi.ptr)[(size_t)iy * A.in_w + ix];
         } else {
-            t = rfx_gather<uint4>(A.ssgi.ptr, (unsigned int)(__mul24(rfx_local_row(d, A.ssgi.row0, A.ssgi.rows, gy), d.W) + gx));
+            t = rfx_gather<uint4>(A.ssgi.ptr, (unsigned int)(__mul24(rfx_view_row<WHOLE>(d, A.ssgi, gy), d.W) + gx));
         }
         // a texel that was not sampled (`!(t.r >= 0.)`) takes no part in any neighbourhood AABB (reproject.frag:66) and its
         // colour is never read as a centre texel either: stage its rgb as quiet NaNs, which v_min/v_max skip, so the
         // 25-tap loops below need no per-tap test.  .a (roughness / ray length) is kept.
         s.tex[0][i] = k2_mask_unsampled(k2_unpack<INPUT_TYPE>(t, 0));
         if (INPUT_TYPE == 0) s.tex[1][i] = k2_mask_unsampled(k2_unpack<INPUT_TYPE>(t, 1));
-        const VND vd = k2_vnd(rfx_gather<uint4>(A.velocity.ptr, (unsigned int)(__mul24(rfx_local_row(d, A.velocity.row0, A.velocity.rows, gy), d.W) + gx)));
+        const VND vd = k2_vnd(rfx_gather<uint4>(A.velocity.ptr, (unsigned int)(__mul24(rfx_view_row<WHOLE>(d, A.velocity, gy), d.W) + gx)));
         s.vn[i] = make_float4(vd.normal.x, vd.normal.y, vd.normal.z, vd.depth);
         s.vel[i] = make_float2(vd.vx, vd.vy);
     }
@@ -207,7 +215,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
     float3 rd, rs;
     rd.x = u - cvel.x;
     rd.y = v - cvel.y;
-    rd.z = k2_validate(A, d, rd.x, rd.y, worldPos, worldNormal, distFactor);
+    rd.z = k2_validate<WHOLE>(A, d, rd.x, rd.y, worldPos, worldNormal, distFactor);
     rs = rd;
     if (INPUT_TYPE != 1) {
         if (!(curvature > 0.05f || rayLength < 0.01f)) {  // reprojectHitPoint reproject.frag:169-193
@@ -217,12 +225,12 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
             const float4 r = rfx_mat_mul(A.prevPV, hp.x, hp.y, hp.z, 1.0f);
             // IEEE divisions: this uv addresses a NEAREST fetch (the validation texel)
             const float hu = (r.x / r.w) * 0.5f + 0.5f, hv = (r.y / r.w) * 0.5f + 0.5f;
-            const float conf = k2_validate(A, d, hu, hv, worldPos, worldNormal, distFactor);
+            const float conf = k2_validate<WHOLE>(A, d, hu, hv, worldPos, worldNormal, distFactor);
             if (hu != -1.0f) rs = make_float3(hu, hv, conf);  // :161-163 falls back to the diffuse triple
         }
     }
     const float moveFactor = fminf((cvel.x * cvel.x + cvel.y * cvel.y) * 10000.0f, 1.0f);
-    const size_t oi = (size_t)(unsigned int)(__mul24(rfx_local_row(d, A.out0.row0, A.out0.rows, y), d.W) + x);
+    const size_t oi = (size_t)(unsigned int)(__mul24(WHOLE ? y : rfx_local_row(d, A.out0.row0, A.out0.rows, y), d.W) + x);
 
     // neighbourhood columns with CLAMP_TO_EDGE, as LDS offsets
     int nxo[5];
@@ -236,7 +244,7 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
         // reproject() :83-122.  The 5 bilinear history fetches of THIS texture (sampleReprojectedTexture, reproject.frag:257-263)
         // are issued here, ahead of the LDS neighbourhood reduction that hides their latency; fetching both textures' taps
         // up front held 80 VGPRs of texels and capped the kernel at one workgroup per CU.
-        const float4 acc = k2_bicubic<HIST_F32>(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
+        const float4 acc = k2_bicubic<HIST_F32, WHOLE>(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
         float3 accrgb = k2_to_log<LOGT>(make_float3(acc.x, acc.y, acc.z));
         float acca = acc.w;
         const float4 inp = s.tex[i][ci];  // preprocessInput :124-128 (an unsampled texel was staged with NaN rgb: !(NaN >= 0))
@@ -315,11 +323,11 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
     }
 }
 
-template <int INPUT_TYPE, int TC, bool LOGT, bool HIST_F32>
+template <int INPUT_TYPE, int TC, bool LOGT, bool HIST_F32, bool WHOLE>
 __global__ __launch_bounds__(NT) void k2_temporal_reproject(K2Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-    k2_body<INPUT_TYPE, TC, LOGT, HIST_F32>(A, d);
+    k2_body<INPUT_TYPE, TC, LOGT, HIST_F32, WHOLE>(A, d);
     rfx_flush_violations(d);
 }
 
@@ -351,20 +359,31 @@ hipError_t rfx_launch_copy_fb(const FrameDims &d, int y0, int y1, TexView src, T
 hipError_t rfx_launch_k2(const K2Args &A, hipStream_t stream) {
     dim3 block(TW, TH), grid(rfx_xcd_grid(RFX_K2_XCD_G, (A.dims.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH));
     const bool lt = A.p.logTransform != 0;
-#define K2_LAUNCH(IT, TC)                                                                                                   \
+    // every view is the whole frame (a context that owns no row tile): no row rebasing, no halo accounting in the kernel
+    const auto whole_view = [&](const void *ptr, int row0, int rows) { return ptr == nullptr || (row0 == 0 && rows == A.dims.H); };
+    const bool whole = whole_view(A.ssgi.ptr, A.ssgi.row0, A.ssgi.rows) && whole_view(A.velocity.ptr, A.velocity.row0, A.velocity.rows) &&
+                       whole_view(A.hist0.ptr, A.hist0.row0, A.hist0.rows) && whole_view(A.hist1.ptr, A.hist1.row0, A.hist1.rows) &&
+                       whole_view(A.out0.ptr, A.out0.row0, A.out0.rows) && whole_view(A.out1.ptr, A.out1.row0, A.out1.rows);
+#define K2_LAUNCH_W(IT, TC, LT, HF)                                                                                         \
     do {                                                                                                                    \
-        if (A.hist_f32) {                                                                                                   \
-            if (lt) hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, true, true>), grid, block, 0, stream, A);             \
-            else hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, false, true>), grid, block, 0, stream, A);              \
-        } else {                                                                                                            \
-            if (lt) hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, true, false>), grid, block, 0, stream, A);            \
-            else hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, false, false>), grid, block, 0, stream, A);             \
-        }                                                                                                                   \
+        if (whole) hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, LT, HF, true>), grid, block, 0, stream, A);            \
+        else hipLaunchKernelGGL((k2_temporal_reproject<IT, TC, LT, HF, false>), grid, block, 0, stream, A);                 \
+    } while (0)
+#define K2_LAUNCH(IT, TC)                               \
+    do {                                                \
+        if (A.hist_f32) {                               \
+            if (lt) K2_LAUNCH_W(IT, TC, true, true);    \
+            else K2_LAUNCH_W(IT, TC, false, true);      \
+        } else {                                        \
+            if (lt) K2_LAUNCH_W(IT, TC, true, false);   \
+            else K2_LAUNCH_W(IT, TC, false, false);     \
+        }                                               \
     } while (0)
     if (A.p.inputType == 0 && A.p.textureCount == 2) K2_LAUNCH(0, 2);
     else if (A.p.inputType == 1 && A.p.textureCount == 1) K2_LAUNCH(1, 1);
     else if (A.p.inputType == 2 && A.p.textureCount == 1) K2_LAUNCH(2, 1);
     else return hipErrorInvalidValue;
 #undef K2_LAUNCH
+#undef K2_LAUNCH_W
     return hipGetLastError();
 }

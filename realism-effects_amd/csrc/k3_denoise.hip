@@ -54,16 +54,21 @@ RFX_DEV void k3_apply(CenterTexel &c, float l2w, float3 tl, float tapLuma, float
     c.total += w;
 }
 
-// dynamic LDS carve-up (all 16-byte aligned: LW*LH is padded to a multiple of 4 texels):
+// dynamic LDS carve-up (all 16-byte aligned: the row pitch is a multiple of 8 texels), n = PITCH * LH texels:
 //   float4 geom[n]          normal.xyz, roughness
 //   pass 0 : float4 in[2][n] log(rgb+1), luma^(1/8)     pass >= 1 : uint2 in[2][n] raw RGBA16F
 //   float  depth[n]
+// The tile is staged WITH the sampler's CLAMP_TO_EDGE built in: a staged position beyond the frame holds a copy of the edge texel.  A tap
+// then needs no clamp of its own in LDS space, and the upper texels of a bilinear footprint are always the +1 / +PITCH neighbours of the
+// lower one (at the frame edge the reference fetches the edge texel twice, min(i0 + 1, size - 1): lerp(w, a, a) == a exactly, which is
+// what the copy gives) — one LDS address per footprint, its four texels at compile-time offsets (two ds_read2_b64).
+// PITCH is a template parameter for that reason: LW = 64 + 2 Rx rounded up to 72 / 80 / 96 texels (Rx <= 4 / 8 / 16).
 
-template <bool IN_TEMPORAL, int TC>
+template <bool IN_TEMPORAL, int TC, int PITCH>
 RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     extern __shared__ float4 lds[];
     const int Rx = A.tile.Rx, Ry = A.tile.Ry, LW = A.tile.LW, LH = A.tile.LH;
-    const int ntex = (LW * LH + 3) & ~3;
+    const int ntex = PITCH * LH;
     float4 *s_geom = lds;
     float4 *s_in0 = lds + ntex;                                   // pass 0 view
     uint2 *s_inN = reinterpret_cast<uint2 *>(lds + ntex);         // pass >= 1 view
@@ -76,20 +81,22 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     const float *depthp = (const float *)A.depth.ptr;
     const uint4 *gbp = (const uint4 *)A.gbuffer.ptr;
 
-    // ---- stage the tile + apron (texels outside the frame are never addressed: taps clamp to the edge first)
+    // ---- stage the tile + apron, CLAMP_TO_EDGE applied to the staged position
     const float invLW = 1.0f / (float)LW;
     for (int i = tid; i < LW * LH; i += NT) {
         // i / LW without the integer-division sequence: (i + 0.5) / LW is at least 0.5 / LW away from an integer, far above the
         // rounding error of the product for these sizes (i < 2^16, LW < 2^8)
         const int ly = (int)(((float)i + 0.5f) * invLW), lx = i - __mul24(ly, LW);
-        const int gx = tx0 - Rx + lx, gy = ty0 - Ry + ly;
-        // skip texels no tap of a PRODUCED pixel can address: outside the frame (taps clamp to the edge first) or
-        // beyond the apron of the last produced row (the workgroup may overhang the launch's row range)
-        if (gx < 0 || gx >= d.W || gy < 0 || gy >= d.H || gy > A.y1 - 1 + Ry) continue;
+        const int li = __mul24(ly, PITCH) + lx;
+        const int uy = ty0 - Ry + ly;
+        // rows beyond the apron of the last produced row are never addressed (the workgroup may overhang the launch's row range; a
+        // row-tiled context does not hold them)
+        if (uy > A.y1 - 1 + Ry) continue;
+        const int gx = min(max(tx0 - Rx + lx, 0), d.W - 1), gy = min(max(uy, 0), d.H - 1);
         const uint4 g = rfx_gather<uint4>(gbp, (unsigned int)(__mul24(rfx_local_row(d, A.gbuffer.row0, A.gbuffer.rows, gy), d.W) + gx));
         const float3 n = rfx_unpack_normal(g.y);
-        s_geom[i] = make_float4(n.x, n.y, n.z, rfx_decode_roughness(g.z));
-        s_depth[i] = rfx_gather<float>(depthp, (unsigned int)(__mul24(rfx_local_row(d, A.depth.row0, A.depth.rows, gy), d.W) + gx));
+        s_geom[li] = make_float4(n.x, n.y, n.z, rfx_decode_roughness(g.z));
+        s_depth[li] = rfx_gather<float>(depthp, (unsigned int)(__mul24(rfx_local_row(d, A.depth.row0, A.depth.rows, gy), d.W) + gx));
 #pragma unroll
         for (int t = 0; t < TC; t++) {
             const TexView &src = t ? A.in1 : A.in0;
@@ -97,9 +104,9 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
             if constexpr (IN_TEMPORAL) {
                 const float4 v = rfx_gather<float4>(src.ptr, idx);
                 const float3 l = k3_log3(v.x, v.y, v.z);
-                s_in0[t * ntex + i] = make_float4(l.x, l.y, l.z, k3_luma(l));
+                s_in0[t * ntex + li] = make_float4(l.x, l.y, l.z, k3_luma(l));
             } else {
-                s_inN[t * ntex + i] = rfx_gather<uint2>(src.ptr, idx);
+                s_inN[t * ntex + li] = rfx_gather<uint2>(src.ptr, idx);
             }
         }
     }
@@ -108,13 +115,13 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     const int x = tx0 + threadIdx.x, y = ty0 + threadIdx.y;
     if (x >= d.W || y >= A.y1) return;
     const int cx = threadIdx.x + Rx, cy = threadIdx.y + Ry;  // this pixel inside the staged tile
-    const int ci = __mul24(cy, LW) + cx;
+    const int ci = __mul24(cy, PITCH) + cx;
     const float u = rfx_frag_u(d.uv, x, y), v = rfx_frag_v(d.uv, y);
     const float depth = s_depth[ci];
 
-    // fine 2x2 quad derivatives; a partner beyond the frame edge fetches the edge texel
-    const int qx0 = __mul24(cy, LW) + min(x & ~1, d.W - 1) - tx0 + Rx, qx1 = __mul24(cy, LW) + min(x | 1, d.W - 1) - tx0 + Rx;
-    const int qy0 = __mul24(min(y & ~1, d.H - 1) - ty0 + Ry, LW) + cx, qy1 = __mul24(min(y | 1, d.H - 1) - ty0 + Ry, LW) + cx;
+    // fine 2x2 quad derivatives; a partner beyond the frame edge fetches the edge texel (staged there)
+    const int qx0 = ci - (x & 1), qx1 = qx0 + 1;
+    const int qy0 = ci - __mul24(y & 1, PITCH), qy1 = qy0 + PITCH;
     {
         const float fw = fabsf(s_depth[qx1] - s_depth[qx0]) + fabsf(s_depth[qy1] - s_depth[qy0]);
         if (depth == 1.0f && fw == 0.0f) return;  // discard (:129-132): target keeps its contents
@@ -134,37 +141,37 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         flatness = (flatness * flatness) * 0.75f + 0.25f;  // :172-173
     }
 
-    // bilinear blend of four staged RGBA16F texels, exactly as rfx_fetch_h4_linear does from global
-    auto lds_linear = [&](int t, float fu, float fv) -> float4 {
-        int x0, x1, y0, y1;
-        float wx, wy;
-        rfx_linear_coord(fu, d.fW, d.W, x0, x1, wx);
-        rfx_linear_coord(fv, d.fH, d.H, y0, y1, wy);
-        x0 = min(max(x0 - tx0 + Rx, 0), LW - 1); x1 = min(max(x1 - tx0 + Rx, 0), LW - 1);
-        y0 = __mul24(min(max(y0 - ty0 + Ry, 0), LH - 1), LW); y1 = __mul24(min(max(y1 - ty0 + Ry, 0), LH - 1), LW);
-        const uint2 *sn = s_inN + t * ntex;
-        const float4 t00 = rfx_load_half4(sn[y0 + x0]), t10 = rfx_load_half4(sn[y0 + x1]);
-        const float4 t01 = rfx_load_half4(sn[y1 + x0]), t11 = rfx_load_half4(sn[y1 + x1]);
-        float4 r;
-        r.x = rfx_lerp(wy, rfx_lerp(wx, t00.x, t10.x), rfx_lerp(wx, t01.x, t11.x));
-        r.y = rfx_lerp(wy, rfx_lerp(wx, t00.y, t10.y), rfx_lerp(wx, t01.y, t11.y));
-        r.z = rfx_lerp(wy, rfx_lerp(wx, t00.z, t10.z), rfx_lerp(wx, t01.z, t11.z));
-        r.w = rfx_lerp(wy, rfx_lerp(wx, t00.w, t10.w), rfx_lerp(wx, t01.w, t11.w));
-        return r;
-    };
+    // frame -> tile coordinates folded into the array bases: a tap's texel (ix, iy) of the frame sits at base[iy * PITCH + ix]
+    const int koff = __mul24(Ry - ty0, PITCH) + (Rx - tx0);
+    const float4 *g_geom = s_geom + koff;
+    const float *g_depth = s_depth + koff;
+    const float wm1 = (float)(d.W - 1), hm1 = (float)(d.H - 1), wmh = d.fW - 0.5f, hmh = d.fH - 0.5f;
 
     CenterTexel c[TC];
-    bool isSpec[TC];
+    float l2spec_i[TC];      // log2 of the extra specular factor of accumulator i (0 for a diffuse texture)
+    const float4 *g_in0[TC];  // the staged input accumulator i reads, rebased like g_geom
+    const uint2 *g_inN[TC];
 #pragma unroll
     for (int i = 0; i < TC; i++) {  // :137-165
-        isSpec[i] = p.isTextureSpecular[i] != 0;
-        const int ti = (TC == 2 && isSpec[i]) ? 1 : 0;
+        const bool isSpec = p.isTextureSpecular[i] != 0;
+        const int ti = (TC == 2 && isSpec) ? 1 : 0;
+        l2spec_i[i] = isSpec ? l2spec : 0.0f;
+        g_in0[i] = s_in0 + ti * ntex + koff;
+        g_inN[i] = s_inN + ti * ntex + koff;
         float4 t;
         if constexpr (IN_TEMPORAL) {
             const TexView &src = ti ? A.in1 : A.in0;
             t = rfx_gather<float4>(src.ptr, (unsigned int)(__mul24(rfx_local_row(d, src.row0, src.rows, y), d.W) + x));
-        } else {
-            t = lds_linear(ti, u, v);
+        } else {  // the sampler's bilinear fetch at the pixel's own vUv
+            float fx, fy;
+            {
+#pragma clang fp contract(off)
+                fx = u * d.fW;
+                fy = v * d.fH;
+            }
+            const LinearCoord lx = rfx_linear_coord_fast(fx, wmh), ly = rfx_linear_coord_fast(fy, hmh);
+            const uint2 *q = g_inN[i] + (__mul24(ly.i0, PITCH) + lx.i0);
+            t = rfx_bilerp_half_rgba(q[0], q[1], q[PITCH], q[PITCH + 1], lx.w, ly.w);
         }
         c[i].w = rfx_rcp(rfx_pow(t.w + 1.0f, 1.2f * p.phi));
         const float3 col = k3_log3(t.x * 1.0003f, t.y * 1.0003f, t.z * 1.0003f);
@@ -181,33 +188,43 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     const float rf = p.radius * flatness;
     const float m00 = rf * co, m01 = rf * -sn, m10 = rf * sn, m11 = rf * co;  // mat2 rm = r*flatness*mat2(c,-s,s,c) :183
 
-    // no unrolling: the bilinear variant carries 8 half4 texels per tap; occupancy beats ILP here (116 -> 78 VGPRs, -6 %)
+    // no unrolling: occupancy beats ILP here
 #pragma unroll 1
     for (int k = 0; k < 8; k++) {
         const float ox = A.tap_ox[k], oy = A.tap_oy[k];  // POISSON[k] / resolution (:91-92,:189), divided once on the host
-        const float nu = u + (m00 * ox + m10 * oy), nv = v + (m01 * ox + m11 * oy);
-        const int nx = min(max(rfx_nearest_idx(nu, d.fW, d.W) - tx0 + Rx, 0), LW - 1);
-        const int ny = min(max(rfx_nearest_idx(nv, d.fH, d.H) - ty0 + Ry, 0), LH - 1);
-        const int ni = __mul24(ny, LW) + nx;
+        // the tap's texture coordinate, every product and sum rounded on its own as in the GLSL (it addresses NEAREST fetches)
+        float fx, fy;
+        {
+#pragma clang fp contract(off)
+            const float nu = u + (m00 * ox + m10 * oy), nv = v + (m01 * ox + m11 * oy);
+            fx = nu * d.fW;
+            fy = nv * d.fH;
+        }
+        // nearest CLAMP_TO_EDGE texel of the tap (rfx_nearest_idx without its NaN / 2^31 guard: the coordinates are finite and O(size) here)
+        const int ni = __mul24((int)__builtin_amdgcn_fmed3f(fy, 0.0f, hm1), PITCH) + (int)__builtin_amdgcn_fmed3f(fx, 0.0f, wm1);
         // getBasicNeighborWeight :52-78
-        const float nd = s_depth[ni];
-        const float4 ng = s_geom[ni];
+        const float nd = g_depth[ni];
+        const float4 ng = g_geom[ni];
         const float normalDiff = 1.0f - fmaxf(rfx_dot(normal, make_float3(ng.x, ng.y, ng.z)), 0.0f);
         const float depthDiff = 10000.0f * fabsf(depth - nd);
         const float roughDiff = fabsf(roughness - ng.w);
         float l2basic = (-normalDiff * p.normalPhi - depthDiff * p.depthPhi - roughDiff * p.roughnessPhi) * K3_LOG2E;
         l2basic = (nd != 1.0f) ? l2basic : -__builtin_inff();
+        if constexpr (IN_TEMPORAL) {
 #pragma unroll
-        for (int i = 0; i < TC; i++) {
-            const int ti = (TC == 2 && isSpec[i]) ? 1 : 0;
-            const float l2w = isSpec[i] ? l2basic + l2spec : l2basic;
-            if constexpr (IN_TEMPORAL) {
-                const float4 tl = s_in0[ti * ntex + ni];
-                k3_apply(c[i], l2w, make_float3(tl.x, tl.y, tl.z), tl.w, lumaPhiL2);
-            } else {
-                const float4 t = lds_linear(ti, nu, nv);
+            for (int i = 0; i < TC; i++) {
+                const float4 tl = g_in0[i][ni];
+                k3_apply(c[i], l2basic + l2spec_i[i], make_float3(tl.x, tl.y, tl.z), tl.w, lumaPhiL2);
+            }
+        } else {
+            const LinearCoord lx = rfx_linear_coord_fast(fx, wmh), ly = rfx_linear_coord_fast(fy, hmh);
+            const int li = __mul24(ly.i0, PITCH) + lx.i0;
+#pragma unroll
+            for (int i = 0; i < TC; i++) {
+                const uint2 *q = g_inN[i] + li;
+                const float3 t = rfx_bilerp_half_rgb(q[0], q[1], q[PITCH], q[PITCH + 1], lx.w, ly.w);
                 const float3 tl = k3_log3(t.x, t.y, t.z);
-                k3_apply(c[i], l2w, tl, k3_luma(tl), lumaPhiL2);
+                k3_apply(c[i], l2basic + l2spec_i[i], tl, k3_luma(tl), lumaPhiL2);
             }
         }
     }
@@ -313,11 +330,11 @@ RFX_DEV void k3_generic_body(const K3Args &A, const FrameDims &d) {
     }
 }
 
-template <bool IN_TEMPORAL, int TC>
+template <bool IN_TEMPORAL, int TC, int PITCH>
 __global__ __launch_bounds__(NT) void k3_tiled(K3Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-    k3_tiled_body<IN_TEMPORAL, TC>(A, d);
+    k3_tiled_body<IN_TEMPORAL, TC, PITCH>(A, d);
     rfx_flush_violations(d);
 }
 template <bool IN_TEMPORAL, int TC>
@@ -350,31 +367,39 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream) {
     A.tile.Ry = (int)ceilf(ry) + 1;
     A.tile.LW = TW + 2 * A.tile.Rx;
     A.tile.LH = TH + 2 * A.tile.Ry;
-    const int ntex = (A.tile.LW * A.tile.LH + 3) & ~3;
-    const size_t lds = (size_t)ntex * (16 + 4 + 2 * (temporal ? 16 : 8));
+    // LDS row pitch: a compile-time constant of the tiled kernels (the footprint's second row is an immediate offset)
+    const int pitch = A.tile.LW <= 72 ? 72 : A.tile.LW <= 80 ? 80 : A.tile.LW <= 96 ? 96 : 0;
+    const size_t lds = (size_t)pitch * A.tile.LH * (16 + 4 + 2 * (temporal ? 16 : 8));
     // two workgroups per CU (160 KiB LDS) keep the staging of one tile under the arithmetic of another
-    const bool tiled = A.p.radius >= 0.0f && lds <= 80 * 1024;
+    const bool tiled = A.p.radius >= 0.0f && pitch != 0 && lds <= 80 * 1024;
     if (tiled) {
         dim3 block(TW, TH), grid(rfx_xcd_grid(RFX_K3_XCD_G, (A.dims.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH));
         // the attribute is per device (a process may hold contexts on several): remembered per device ordinal
-#define K3_TILED(T, C)                                                                                                       \
+#define K3_TILED(T, C, P)                                                                                                    \
     do {                                                                                                                     \
         static bool attr_set[64] = {false};                                                                                  \
         int dev = 0;                                                                                                         \
         hipGetDevice(&dev);                                                                                                  \
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                                        \
-            hipFuncSetAttribute((const void *)k3_tiled<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);        \
+            hipFuncSetAttribute((const void *)k3_tiled<T, C, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);     \
             if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                                  \
         }                                                                                                                    \
-        hipLaunchKernelGGL((k3_tiled<T, C>), grid, block, lds, stream, A);                                                   \
+        hipLaunchKernelGGL((k3_tiled<T, C, P>), grid, block, lds, stream, A);                                                \
+    } while (0)
+#define K3_TILED_P(T, C)                    \
+    do {                                    \
+        if (pitch == 72) K3_TILED(T, C, 72); \
+        else if (pitch == 80) K3_TILED(T, C, 80); \
+        else K3_TILED(T, C, 96);            \
     } while (0)
         if (A.p.textureCount == 2) {
-            if (temporal) K3_TILED(true, 2);
-            else K3_TILED(false, 2);
+            if (temporal) K3_TILED_P(true, 2);
+            else K3_TILED_P(false, 2);
         } else {
-            if (temporal) K3_TILED(true, 1);
-            else K3_TILED(false, 1);
+            if (temporal) K3_TILED_P(true, 1);
+            else K3_TILED_P(false, 1);
         }
+#undef K3_TILED_P
 #undef K3_TILED
     } else {
         dim3 block(64, 4), grid((A.dims.W + 63) / 64, (A.y1 - A.y0 + 3) / 4);

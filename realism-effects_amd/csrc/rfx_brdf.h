@@ -18,24 +18,24 @@ RFX_DEV float rfx_f_schlick(float f0, float f90, float theta) { return f0 + (f90
 RFX_DEV float rfx_d_gtr2(float roughness, float NoH) {
     float a2 = roughness * roughness;
     float t = (NoH * NoH) * (a2 * a2 - 1.0f) + 1.0f;
-    return a2 / (RFX_PI * (t * t));
+    return rfx_div_pos(a2, RFX_PI * (t * t));  // t >= 1 - NoH^2 > 0 (NoH is clamped below 1)
 }
 // SmithG  :117-121
 RFX_DEV float rfx_smith_g(float NDotV, float alphaG) {
     float a = alphaG * alphaG, b = NDotV * NDotV;
-    return (2.0f * NDotV) / (NDotV + rfx_sqrt(a + b - a * b));
+    return rfx_div_pos(2.0f * NDotV, NDotV + rfx_sqrt(a + b - a * b));  // NDotV >= 1e-5
 }
 // GGXVNDFPdf  :123-127
 RFX_DEV float rfx_ggx_vndf_pdf(float NoH, float NoV, float roughness) {
     float D = rfx_d_gtr2(roughness, NoH);
     float G1 = rfx_smith_g(NoV, roughness * roughness);
-    return (D * G1) / fmaxf(0.00001f, 4.0f * NoV);
+    return rfx_div_pos(D * G1, fmaxf(0.00001f, 4.0f * NoV));
 }
 // evalDisneyDiffuse  :136-142 (all three channels are equal)
 RFX_DEV float rfx_eval_disney_diffuse(float NoL, float NoV, float LoH, float roughness, float metalness) {
     float FD90 = 0.5f + 2.0f * roughness * (LoH * LoH);
     float a = rfx_f_schlick(1.0f, FD90, NoL), b = rfx_f_schlick(1.0f, FD90, NoV);
-    return (a * b / RFX_PI) * (1.0f - metalness);
+    return RFX_DIV_CONST(a * b, RFX_PI) * (1.0f - metalness);
 }
 // evalDisneySpecular  :144-151 with GeometryTerm :129-134
 RFX_DEV float rfx_eval_disney_specular(float roughness, float NoH, float NoV, float NoL) {
@@ -44,7 +44,7 @@ RFX_DEV float rfx_eval_disney_specular(float roughness, float NoH, float NoV, fl
     r2 = r2 * r2;
     float a2 = r2 * r2;
     float G = rfx_smith_g(NoV, a2) * rfx_smith_g(NoL, a2);
-    return D * G / (4.0f * NoL * NoV);
+    return rfx_div_pos(D * G, 4.0f * NoL * NoV);  // NoL, NoV >= 1e-5
 }
 // SampleGGXVNDF  :153-170
 RFX_DEV float3 rfx_sample_ggx_vndf(float3 V, float ax, float ay, float r1, float r2) {

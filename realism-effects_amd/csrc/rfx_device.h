@@ -179,6 +179,53 @@ RFX_DEV void rfx_linear_coord(float u, float fsize, int size, int &i0, int &i1, 
     i1 = min(i0 + 1, size - 1);
 }
 RFX_DEV float rfx_lerp(float w, float a, float b) { return a + w * (b - a); }
+// ... and the form the LDS-tiled kernels use: one v_med3 + v_cvt + v_fract per axis instead of min, sub, max, floor, cvt, sub.
+// c = u * size (the caller shares the product with its nearest taps).  Identical to rfx_linear_coord's (i0, w) for every finite c:
+// x -> x - 0.5 is monotonic, so min(c, size) - 0.5 == min(c - 0.5, size - 0.5) (size - 0.5 is exact); c2 >= 0, so the truncating
+// conversion is the floor; c2 - floor(c2) is exact in fp32, which is what v_fract_f32 returns.
+struct LinearCoord {
+    int i0;   // lower texel; the upper one is min(i0 + 1, size - 1)
+    float w;  // weight of the upper texel
+};
+RFX_DEV LinearCoord rfx_linear_coord_fast(float c, float size_minus_half) {
+#pragma clang fp contract(off)  // c - 0.5 must not fuse with the product that formed c (K3 / K4 are compiled with contraction on)
+    const float c2 = __builtin_amdgcn_fmed3f(c - 0.5f, 0.0f, size_minus_half);
+    LinearCoord r;
+    r.i0 = (int)c2;
+    r.w = __builtin_amdgcn_fractf(c2);
+    return r;
+}
+// The sampler's lerp on HALF texels without converting them first: v_fma_mix_f32 reads either half of a 32-bit register as an f16
+// source of an fp32 fma.  d = fp32(b) - fp32(a) (one rounding, as v_sub_f32 on the converted values), then fma(w, d, fp32(a)) — the fused
+// lerp of the oracle GL's sampler (oracle/rfx_oracle.c fetch_h4_linear).  Two instructions per channel instead of two v_cvt_f32_f16,
+// a subtraction and an fma.  SEL: 0 = low half of the word, 1 = high half.
+template <int SEL>
+RFX_DEV float rfx_half_diff(uint32_t b, uint32_t a) {
+    float r;
+    if (SEL == 0) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(b), "v"(a));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(b), "v"(a));
+    return r;
+}
+template <int SEL>
+RFX_DEV float rfx_half_fma(float w, float d, uint32_t a) {
+    float r;
+    if (SEL == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(w), "v"(d), "v"(a));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(w), "v"(d), "v"(a));
+    return r;
+}
+template <int SEL>
+RFX_DEV float rfx_half_lerp(float w, uint32_t a, uint32_t b) { return rfx_half_fma<SEL>(w, rfx_half_diff<SEL>(b, a), a); }
+// bilinear blend of four RGBA16F texels (two 32-bit words each: r|g, b|a): lerp in x on both rows, then in y, every lerp fused
+RFX_DEV float3 rfx_bilerp_half_rgb(uint2 t00, uint2 t10, uint2 t01, uint2 t11, float wx, float wy) {
+    const float r0 = rfx_half_lerp<0>(wx, t00.x, t10.x), g0 = rfx_half_lerp<1>(wx, t00.x, t10.x), b0 = rfx_half_lerp<0>(wx, t00.y, t10.y);
+    const float r1 = rfx_half_lerp<0>(wx, t01.x, t11.x), g1 = rfx_half_lerp<1>(wx, t01.x, t11.x), b1 = rfx_half_lerp<0>(wx, t01.y, t11.y);
+    return make_float3(__builtin_fmaf(wy, r1 - r0, r0), __builtin_fmaf(wy, g1 - g0, g0), __builtin_fmaf(wy, b1 - b0, b0));
+}
+RFX_DEV float4 rfx_bilerp_half_rgba(uint2 t00, uint2 t10, uint2 t01, uint2 t11, float wx, float wy) {
+    const float3 c = rfx_bilerp_half_rgb(t00, t10, t01, t11, wx, wy);
+    const float a0 = rfx_half_lerp<1>(wx, t00.y, t10.y), a1 = rfx_half_lerp<1>(wx, t01.y, t11.y);
+    return make_float4(c.x, c.y, c.z, __builtin_fmaf(wy, a1 - a0, a0));
+}
 // gather with a 32-bit BYTE offset from a wave-uniform base (one plane is < 4 GiB: 8K RGBA32F = 0.53 GB): the
 // compiler keeps the base in SGPRs and the offset in one VGPR instead of a 64-bit add per lane per tap
 template <typename T>
@@ -199,6 +246,29 @@ RFX_DEV float4 rfx_fetch_h4_linear(const TexView &t, const FrameDims &d, float u
     r.z = rfx_lerp(wy, rfx_lerp(wx, t00.z, t10.z), rfx_lerp(wx, t01.z, t11.z));
     r.w = rfx_lerp(wy, rfx_lerp(wx, t00.w, t10.w), rfx_lerp(wx, t01.w, t11.w));
     return r;
+}
+
+// row of a view that may be the whole frame (WHOLE: row0 == 0 and rows == H — nothing to rebase and nothing to count) or a held band
+template <bool WHOLE>
+RFX_DEV int rfx_view_row(const FrameDims &d, const TexView &t, int y) {
+    return WHOLE ? y : rfx_local_row(d, t.row0, t.rows, y);
+}
+// the bilinear RGBA16F fetch again, as the LDS-tiled kernels and K2's history taps issue it: three instructions per coordinate
+// (rfx_linear_coord_fast) and the sampler's fused lerps on the half texels themselves (rfx_bilerp_half_rgba)
+template <bool WHOLE>
+RFX_DEV float4 rfx_fetch_h4_linear_fused(const TexView &t, const FrameDims &d, float u, float v) {
+    float cx, cy;
+    {
+#pragma clang fp contract(off)
+        cx = u * d.fW;
+        cy = v * d.fH;
+    }
+    const LinearCoord lx = rfx_linear_coord_fast(cx, d.fW - 0.5f), ly = rfx_linear_coord_fast(cy, d.fH - 0.5f);
+    const int x1 = min(lx.i0 + 1, d.W - 1), y1 = min(ly.i0 + 1, d.H - 1);
+    const unsigned int r0 = (unsigned int)__mul24(rfx_view_row<WHOLE>(d, t, ly.i0), d.W), r1 = (unsigned int)__mul24(rfx_view_row<WHOLE>(d, t, y1), d.W);
+    const uint2 t00 = rfx_gather<uint2>(t.ptr, r0 + lx.i0), t10 = rfx_gather<uint2>(t.ptr, r0 + x1);
+    const uint2 t01 = rfx_gather<uint2>(t.ptr, r1 + lx.i0), t11 = rfx_gather<uint2>(t.ptr, r1 + x1);
+    return rfx_bilerp_half_rgba(t00, t10, t01, t11, lx.w, ly.w);
 }
 
 // the same sampler over an RGBA32F texture (FloatType framebuffer copy, TemporalReprojectPass.js:137-142)
@@ -283,6 +353,26 @@ RFX_DEV float3 rfx_vec_mul_mat(const float *M, float3 v, float w) {
     return r;
 }
 
+// x / D for a constant D, CORRECTLY ROUNDED — the IEEE quotient the GLSL's `/` yields — in three instructions instead of the
+// v_div_scale / v_rcp / v_fma x4 / v_div_fmas / v_div_fixup sequence hipcc emits for `/`: q = RN(x * R) with R = RN(1 / D) is a faithful
+// quotient, the residual x - D q is exact in an fma, and RN(q + residual * R) is the correctly rounded quotient (Markstein 1990; holds
+// for every x whose quotient neither overflows nor is subnormal, D's significand not all ones).  Checked against `/` on all 2^24 integers
+// and 1.5e8 random floats for every divisor used below.
+RFX_DEV float rfx_div_const_impl(float x, float d, float r) {
+    const float q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-d, q, x), r, q);
+}
+#define RFX_DIV_CONST(x, D) rfx_div_const_impl((x), (D), 1.0f / (D))
+// ... and for a variable divisor KNOWN to be a positive normal number well inside the exponent range (a pdf clamped from below, a sum of
+// squares, a luminance that passed a `>` test): v_rcp_f32 (1 ulp) refined by one Newton step is RN(1 / d) except for ~1e-6 of the divisors,
+// and the corrected quotient is the IEEE one (0 mismatches in 1e8 random trials with a +-1 ulp starting reciprocal).  One reciprocal serves
+// every numerator over the same divisor.  No scaling and no special-case fix-up: NOT for divisors that may be 0, infinite or subnormal.
+RFX_DEV float rfx_rcp_rn(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
+RFX_DEV float rfx_div_pos(float x, float d) { return rfx_div_const_impl(x, d, rfx_rcp_rn(d)); }
+
 // ---------------------------------------------------------------- G-buffer codec (decode side)
 struct Material {
     float3 diffuse;
@@ -303,17 +393,17 @@ RFX_DEV float3 rfx_unpack_normal(uint32_t bits) {
     return rfx_normalize(n);
 }
 // floatToVec4, gbuffer_packing.glsl:151-164 (one byte)
-RFX_DEV float rfx_byte_unorm(uint32_t b) { return fmaxf((float)b / 255.0f - 0.0001f, 0.0f); }
+RFX_DEV float rfx_byte_unorm(uint32_t b) { return fmaxf(RFX_DIV_CONST((float)b, 255.0f) - 0.0001f, 0.0f); }
 // float2color .r (roughness), gbuffer_packing.glsl:24-34
 RFX_DEV float rfx_decode_roughness(uint32_t bits) {
     float value = __uint_as_float(bits);
-    float q = value / 257.0f;
+    float q = RFX_DIV_CONST(value, 257.0f);
     float cr = (value - 257.0f * floorf(q)) / 256.0f; // mod(value, 257) / 256
     return fmaxf(cr - 0.0001f, 0.0f);
 }
 RFX_DEV float rfx_decode_metalness(uint32_t bits) {
     float value = __uint_as_float(bits);
-    float cg = floorf(value / (257.0f * 257.0f)) / 256.0f;
+    float cg = floorf(RFX_DIV_CONST(value, 257.0f * 257.0f)) / 256.0f;
     return fmaxf(cg - 0.0001f, 0.0f);
 }
 template <bool WITH_EMISSIVE>

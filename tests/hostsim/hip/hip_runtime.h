@@ -147,6 +147,19 @@ static inline hostsim_half2 __builtin_amdgcn_cvt_pkrtz(float a, float b) {
     std::memcpy(&r, &bits, 4);
     return r;
 }
+// ballot: the kernels use it only to choose between two forms of the SAME computation for a whole wavefront (a rare guarded path vs the
+// common unguarded one) — here every thread decides for itself, which exercises both forms against the oracle
+static inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) { return p ? 1ull : 0ull; }
+static inline float __builtin_amdgcn_fractf(float x) { return x - std::floor(x); }  // v_fract_f32 (arguments >= 0 here)
+static inline float hostsim_half_word(uint32_t w, int sel) {  // one half of a 32-bit word as fp32 (exact)
+    const unsigned short h = (unsigned short)(sel ? (w >> 16) : (w & 0xffffu));
+    __fp16 v;
+    std::memcpy(&v, &h, 2);
+    return (float)v;
+}
+// v_fma_mix_f32 as rfx_device.h uses it: fp32(b.half) - fp32(a.half), one rounding; fma(w, d, fp32(a.half)), one rounding
+static inline float hostsim_half_diff(uint32_t b, uint32_t a, int sel) { return hostsim_half_word(b, sel) - hostsim_half_word(a, sel); }
+static inline float hostsim_half_fma(float w, float d, uint32_t a, int sel) { return std::fma(w, d, hostsim_half_word(a, sel)); }
 static inline float hostsim_vmin(float a, float b) { return std::fmin(a, b); }  // v_min_f32 / v_max_f32 in IEEE mode: the non-NaN operand
 static inline float hostsim_vmax(float a, float b) { return std::fmax(a, b); }
 static inline int __mul24(int a, int b) { return a * b; }

@@ -14,16 +14,19 @@ import re
 import sys
 from collections import Counter, OrderedDict
 
-# cycles per wave64 instruction (profiles/r03_*/valu_rates.txt once collected; r02 values otherwise)
+# cycles per wave64 instruction per SIMD at 8 waves / SIMD (profiles/r03_microbench/valu_rates2.txt; r02's table had v_fma_f32 at 4.0 —
+# its operands were (a, s, s): the same register twice costs a second read cycle; with distinct sources fma issues like add / mul)
 RATES = OrderedDict([
     ("trans", 8.3),    # v_exp/log/rcp/rsq/sqrt/sin/cos_f32
-    ("pk", 4.8),       # v_pk_{fma,mul,add}_f32
-    ("addmul", 2.6),   # v_add/sub/subrev/mul_f32 (VOP2 forms)
-    ("generic", 4.15), # everything else on the VALU
+    ("pk", 4.55),      # v_pk_{fma,mul,add}_f32, v_pk_mov_b32
+    ("fast", 2.7),     # v_add/sub/mul/fma/fmac/fmamk/fmaak_f32, v_mov/and/or/xor_b32, v_add/sub_u32, v_cmp_*
+    ("cndmask", 11.0), # v_cndmask_b32 (measured 10.8 behind a fresh v_cmp, 22 with a loop-invariant VCC: see profiles/r03_microbench)
+    ("generic", 4.2),  # everything else: v_cvt_*, v_min/max/med3, v_floor/fract, v_mad_i32_i24, v_lshl_add, v_fma_mix_f32, v_bfe, v_perm ...
 ])
 TRANS = re.compile(r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)_(f32|f16|legacy_f32)")
 PK = re.compile(r"^v_pk_")
-ADDMUL = re.compile(r"^v_(add|sub|subrev|mul)_f32")
+FAST = re.compile(r"^v_((add|sub|subrev|mul|fma|fmac|fmamk|fmaak)_f32|(mov|and|or|xor)_b32|(add|sub|subrev)_u32|cmp_)")
+CND = re.compile(r"^v_cndmask_b32")
 
 
 def classify(op):
@@ -31,8 +34,10 @@ def classify(op):
         return "trans"
     if PK.match(op):
         return "pk"
-    if ADDMUL.match(op):
-        return "addmul"
+    if CND.match(op):
+        return "cndmask"
+    if FAST.match(op):
+        return "fast"
     return "generic"
 
 
@@ -103,20 +108,20 @@ def main():
     tot = Counter()
     totc = 0.0
     wsum = 0.0
-    print("%-12s %5s %5s %5s %5s %5s | %4s %4s %4s %4s | %8s" % ("block", "valu", "trans", "pk", "a/m", "gen", "lds", "vmem", "salu", "br", "cycles"))
+    print("%-12s %5s %5s %5s %5s %5s %5s | %4s %4s %4s %4s | %8s" % ("block", "valu", "trans", "pk", "fast", "cnd", "gen", "lds", "vmem", "salu", "br", "cycles"))
     for lab, ops in blocks.items():
         c, cyc = cost(ops)
         nv = sum(c[k] for k in RATES)
         if nv == 0 and c["lds"] + c["vmem"] == 0:
             continue
         t = trips.get(lab, 1.0)
-        print("%-12s %5d %5d %5d %5d %5d | %4d %4d %4d %4d | %8.0f%s" % (lab, nv, c["trans"], c["pk"], c["addmul"], c["generic"], c["lds"], c["vmem"], c["salu"],
+        print("%-12s %5d %5d %5d %5d %5d %5d | %4d %4d %4d %4d | %8.0f%s" % (lab, nv, c["trans"], c["pk"], c["fast"], c["cndmask"], c["generic"], c["lds"], c["vmem"], c["salu"],
                                                                        c["branch"], cyc, ("  x%g" % t) if t != 1 else ""))
         tot.update(c)
         totc += cyc
         wsum += cyc * t
     nv = sum(tot[k] for k in RATES)
-    print("%-12s %5d %5d %5d %5d %5d | %4d %4d %4d %4d | %8.0f   weighted %.0f" % ("static sum", nv, tot["trans"], tot["pk"], tot["addmul"], tot["generic"], tot["lds"],
+    print("%-12s %5d %5d %5d %5d %5d %5d | %4d %4d %4d %4d | %8.0f   weighted %.0f" % ("static sum", nv, tot["trans"], tot["pk"], tot["fast"], tot["cndmask"], tot["generic"], tot["lds"],
                                                                                   tot["vmem"], tot["salu"], tot["branch"], totc, wsum))
 
 

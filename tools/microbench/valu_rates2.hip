@@ -13,7 +13,7 @@
         float a[8];                                                                        \
         _Pragma("unroll") for (int i = 0; i < 8; i++) a[i] = seed + threadIdx.x * 1e-6f + i; \
         float b = seed * 0.5f, c = seed * 0.25f;                                           \
-        asm volatile("v_cmp_gt_f32 vcc, %0, %1" ::"v"(b), "v"(c) : "vcc");                \
+        asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_cmp_gt_f32_e64 s[10:11], %0, %1" ::"v"(b), "v"(c) : "vcc", "s10", "s11"); \
         for (int it = 0; it < ITERS; it++) {                                               \
             _Pragma("unroll") for (int i = 0; i < 8; i++) { asm volatile(ASM_STR : "+v"(a[i]) : "v"(b), "v"(c)__VA_ARGS__); } \
         }                                                                                  \
@@ -58,6 +58,22 @@ DEF_KERNEL(k_mul_lo, "v_mul_lo_u32 %0, %0, %1")
 DEF_KERNEL(k_cvt_i32, "v_cvt_i32_f32 %0, %0")
 DEF_KERNEL(k_exp, "v_exp_f32 %0, %0")
 DEF_KERNEL(k_dpp_add, "v_add_f32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+// select idioms (round 3: v_cndmask_b32 measured ~22 cycles with a loop-invariant VCC — which form of a select is cheap?)
+DEF_KERNEL(k_cndmask_e64, "v_cndmask_b32_e64 %0, %0, %1, s[10:11]", : "s10", "s11")
+DEF_KERNEL(k_cndmask_src2, "v_cndmask_b32 %0, %1, %0, vcc")
+DEF_KERNEL(k_cndmask_lit, "v_cndmask_b32 %0, 0, %0, vcc")
+DEF_KERNEL(k_cmp_cndmask, "v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc", : "vcc")
+DEF_KERNEL(k_cmp_add_cndmask, "v_cmp_gt_f32 vcc, %0, %1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc", : "vcc")
+DEF_KERNEL(k_cmp_e64_cndmask_e64, "v_cmp_gt_f32_e64 s[10:11], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %2, s[10:11]", : "s10", "s11")
+DEF_KERNEL(k_sel_bits, "v_sub_u32 %0, %1, %0\n\tv_ashrrev_i32 %0, 31, %0\n\tv_and_b32 %0, %0, %2")
+DEF_KERNEL(k_max_f32, "v_max_f32 %0, %0, %1")
+DEF_KERNEL(k_med3_f32, "v_med3_f32 %0, %0, %1, %2")
+DEF_KERNEL(k_fract, "v_fract_f32 %0, %0")
+DEF_KERNEL(k_ashr, "v_ashrrev_i32 %0, 3, %0")
+DEF_KERNEL(k_fma_same, "v_fma_f32 %0, %0, %1, %1")
+DEF_KERNEL(k_bfi, "v_bfi_b32 %0, %1, %0, %2")
+DEF_KERNEL(k_cmp_class, "v_cmp_class_f32 vcc, %0, %1\n\tv_add_f32 %0, %0, %2", : "vcc")
+DEF_KERNEL(k_mul_legacy, "v_mul_legacy_f32 %0, %0, %1")
 // mixes: does a transcendental overlap with plain VALU of the SAME wave / other waves?  (trans + 3 add) vs the sum of parts
 DEF_KERNEL(k_mix_exp_3add, "v_exp_f32 %0, %0\n\tv_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2\n\tv_add_f32 %0, %0, %1")
 DEF_KERNEL(k_mix_exp_3fma, "v_exp_f32 %0, %0\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %2, %1\n\tv_fma_f32 %0, %0, %1, %2")
@@ -166,6 +182,9 @@ int main() {
         RUN(k_add_u32, 1); RUN(k_mad_i24, 1); RUN(k_lshl_add, 1); RUN(k_add_lshl, 1); RUN(k_min_i32, 1); RUN(k_med3_i32, 1); RUN(k_min_f32, 1);
         RUN(k_floor, 1); RUN(k_mov, 1); RUN(k_and, 1); RUN(k_bfe, 1); RUN(k_perm, 1); RUN(k_pkrtz, 1); RUN(k_ldexp, 1); RUN(k_mul_lo, 1);
         RUN(k_cvt_i32, 1); RUN(k_exp, 1); RUN(k_dpp_add, 1);
+        RUN(k_cndmask_e64, 1); RUN(k_cndmask_src2, 1); RUN(k_cndmask_lit, 1); RUN(k_cmp_cndmask, 2); RUN(k_cmp_add_cndmask, 4); RUN(k_cmp_e64_cndmask_e64, 2);
+        RUN(k_sel_bits, 3); RUN(k_max_f32, 1); RUN(k_med3_f32, 1); RUN(k_fract, 1); RUN(k_ashr, 1); RUN(k_fma_same, 1); RUN(k_bfi, 1); RUN(k_cmp_class, 2);
+        RUN(k_mul_legacy, 1);
         RUN(k_mix_exp_3add, 4); RUN(k_mix_exp_3fma, 4); RUN(k_mix_add_fma, 2); RUN(k_mix_add_cvt, 2);
         RUN(k_pk_fma, 1); RUN(k_pk_fma_bcast, 1); RUN(k_pk_mul, 1); RUN(k_pk_add, 1); RUN(k_pk_add_neg, 1); RUN(k_pk_mov, 1);
     }
