@@ -292,7 +292,8 @@ def main():
     args = ap.parse_args()
 
     import torch
-    if os.environ.get("RFX_HOSTSIM") == "1":  # functional test hook (tests/hostsim: the kernel sources on the CPU): there is no device to select or drain
+    from rfx_amd import abi as _abi
+    if hasattr(_abi.load_library(), "rfx_hostsim_build"):  # the library is tests/hostsim (the kernel sources on the CPU, injected by the tests): no device to select or drain
         torch.cuda.set_device = torch.cuda.synchronize = lambda *a, **k: None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -383,7 +384,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload + ", steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step",
-                       "frame": "%dx%d" % (W1, H1), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz", "uv_model": "ideal",
+                       "frame": "%dx%d" % (W1, H1), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz", "uv_model": "reference_gl",
                        "parallelism": "row-tiles x%d, RCCL halo send/recv after K2 and every K3 pass + composed-GI all-gather (async, under the next frame's K1 trace); exchange: %s" % (
                            world, case_exchange(use_c, one_gpu, args)) if world > 1 else "single GPU"},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},

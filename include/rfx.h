@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 14
+#define RFX_ABI_VERSION 15
 
 enum {
     RFX_OK = 0,
@@ -200,12 +200,13 @@ int rfx_set_stream(rfx_ctx *, void *hip_stream);
 int rfx_set_row_window(rfx_ctx *, int y0, int y1);
 /* Which vUv the draws' fragments see (every full-screen pass of the reference reads its inputs at the interpolated varying vUv,
  * src/utils/shader/basic.vert; e.g. ssgi.frag:107, temporal_reproject.frag:118, poisson_denoise.frag:128, DenoiserComposePass.js:58).
- *   RFX_UV_IDEAL         (default) (i + 0.5) / n, correctly rounded: the value the shader authors mean.
- *   RFX_UV_REFERENCE_GL  the value the rasteriser of the reference's GL (Mesa llvmpipe, the oracle of the parity tests) interpolates, bit
- *                        for bit: three's full-screen triangle is clipped into two triangles along the frame diagonal, each with its own
- *                        fp32 plane equations (up to 2^-24 from the ideal value, different on either side of the diagonal).  With it the
- *                        NEAREST taps of the denoiser and every LINEAR fetch at vUv land where the reference's land: what is left between
- *                        the two implementations is transcendental rounding alone.
+ *   RFX_UV_REFERENCE_GL  (default since ABI 15) the value the rasteriser of the reference's GL (Mesa llvmpipe, the oracle of the parity
+ *                        tests) interpolates, bit for bit: three's full-screen triangle is clipped into two triangles along the frame
+ *                        diagonal, each with its own fp32 plane equations (up to 2^-24 from the ideal value, different on either side of
+ *                        the diagonal).  With it the NEAREST taps of the denoiser and every LINEAR fetch at vUv land where the
+ *                        reference's land: what is left between the two implementations is transcendental rounding alone.
+ *   RFX_UV_IDEAL         (i + 0.5) / n, correctly rounded: the value the shader authors mean, and what a GL that does not clip the
+ *                        triangle is closest to.  Costs two IEEE divisions per fragment instead of an fma.
  * Applies to every following draw; row-tiled contexts evaluate the whole frame's planes. */
 enum { RFX_UV_IDEAL = 0, RFX_UV_REFERENCE_GL = 1 };
 int rfx_set_uv_model(rfx_ctx *, int model);
@@ -305,9 +306,10 @@ int rfx_sync(rfx_ctx *);
  * upload stream and returns; rfx_stage_flip makes everything staged since the last flip current — draws enqueued after it wait for
  * those copies, and copies staged after it wait for the draws enqueued before it (they overwrite the buffer those draws read).
  *     stage(frame 0); flip();   loop: stage(frame n+1); draws of frame n; flip()
- * `host` must stay valid and unchanged until the flip that publishes it has been followed by rfx_sync, or come from rfx_host_alloc
- * and not be rewritten before the next-but-one flip.  Pinned memory (rfx_host_alloc = hipHostMalloc) is what makes the copy
- * asynchronous; a pageable plane is accepted and simply does not overlap. */
+ * `host` must stay valid and unchanged until the flip AFTER the one that publishes it has returned: rfx_stage_flip returns only when
+ * the copies published by the previous flip have executed (host-side back pressure — a host with two alternating sets of pinned planes
+ * can refill a set as soon as the next flip is back, and never runs more than two frames ahead of the device).  Pinned memory
+ * (rfx_host_alloc = hipHostMalloc) is what makes the copy asynchronous; a pageable plane is accepted and simply does not overlap. */
 void *rfx_host_alloc(size_t bytes);
 void rfx_host_free(void *);
 int rfx_stage_upload(rfx_ctx *, rfx_tex id, const void *host, int row0, int rows);

@@ -64,7 +64,7 @@ static inline float pert_ang(float v) { return (g_pert_seed && g_pert_state) ? v
  * third frame on, when ages exceed 1) moves by ~1e-3 — the absolute tolerance sits at the resolution of an fp32 texture coordinate there. */
 #define UV_ABS_ERR 1.1920929e-7f
 /* ... unless the fragments see the reference GL's own vUv (rfxo_set_uv_model(1), frag_u / frag_v below): then nothing is left to bound */
-static int g_uv_model = 0;
+static int g_uv_model = 1; /* the default on both sides of every parity test since round 3 (rfx_ctx.h uv_model) */
 static inline float uv_err(void) { return g_uv_model ? 0.0f : UV_ABS_ERR; }
 static inline float pert_uv(float v) { return (g_pert_seed && g_pert_state) ? v + pert_sign() * uv_err() : v; }
 /* Which vUv a fragment sees.  Model 0: (i + 0.5) / n, correctly rounded — what the HIP kernels compute.  Model 1: the reference GL's own
@@ -76,6 +76,7 @@ static inline float pert_uv(float v) { return (g_pert_seed && g_pert_state) ? v 
  * a0 = dadx / 2 for u, the second 1 - dadx * (W - 0.5); v's a0 = 1 - dady * (H - 0.5) in both.  A fragment centre on the diagonal belongs
  * to the lower triangle. */
 void rfxo_set_uv_model(int m) { g_uv_model = m; }
+int rfxo_get_uv_model(void) { return g_uv_model; }
 static inline float frag_u(int x, int y, int W, int H) {
     if (!g_uv_model) return ((float)x + 0.5f) / (float)W;
     float ooa = 1.0f / ((float)W * (float)H), dudx = (float)H * ooa;

@@ -74,18 +74,20 @@ class pixel_mask:
 
 class uv_model:
     """with uv_model("reference"): fragments see the vUv the reference GL's rasteriser interpolates, bit for bit (its clipped full-screen
-    triangle's two plane equations, rfx_oracle.c frag_u / frag_v); "ideal" (the default, what the HIP kernels compute): (i + 0.5) / n."""
+    triangle's two plane equations, rfx_oracle.c frag_u / frag_v) — the default on both sides since round 3, as in librfx_hip.so;
+    "ideal": (i + 0.5) / n.  The model in force before the block is restored on exit."""
     MODELS = {"ideal": 0, "reference": 1}
 
     def __init__(self, model):
         self.model = self.MODELS[model]
 
     def __enter__(self):
+        self.keep = lib().rfxo_get_uv_model()
         lib().rfxo_set_uv_model(self.model)
         return self
 
     def __exit__(self, *exc):
-        lib().rfxo_set_uv_model(0)
+        lib().rfxo_set_uv_model(self.keep)
         return False
 
 

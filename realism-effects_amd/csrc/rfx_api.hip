@@ -67,11 +67,14 @@ void rfx_destroy(rfx_ctx *c) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     rfx_comm_release(c);
+    // a staged copy may still be writing a back buffer: drain the upload stream before any buffer goes
+    if (c->upload_stream) { hipStreamSynchronize(c->upload_stream); hipStreamDestroy(c->upload_stream); }
     for (int i = 0; i < RFX_TEX_COUNT; i++) {
         if (c->slots[i].owned && c->slots[i].ptr) hipFree(c->slots[i].ptr);
         if (c->slots[i].back) hipFree(c->slots[i].back);
     }
-    if (c->upload_stream) { hipStreamSynchronize(c->upload_stream); hipStreamDestroy(c->upload_stream); }
+    for (hipEvent_t e : c->ev_batch)
+        if (e) hipEventDestroy(e);
     if (c->ev_staged) hipEventDestroy(c->ev_staged);
     if (c->ev_frame_done) hipEventDestroy(c->ev_frame_done);
     if (c->halo_violations) hipFree(c->halo_violations);
@@ -203,6 +206,8 @@ int rfx_stage_upload(rfx_ctx *c, rfx_tex id, const void *host, int row0, int row
         hipError_t e = hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_staged, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_frame_done, hipEventDisableTiming);
+        for (hipEvent_t &b : c->ev_batch)
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
         if (e != hipSuccess) return fail(c, RFX_EDEVICE, "rfx_stage_upload: stream/event creation", e);
         // nothing of an earlier frame can still be reading a back buffer: there is none yet
         HIPCHK(c, hipEventRecord(c->ev_frame_done, c->stream));
@@ -226,6 +231,13 @@ int rfx_stage_flip(rfx_ctx *c) {
     HIPCHK(c, hipEventRecord(c->ev_staged, c->upload_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_staged, 0));
     HIPCHK(c, hipEventRecord(c->ev_frame_done, c->stream));
+    // Host-side back pressure.  Neither rfx_stage_upload nor the flip waits for the GPU, and a staged copy executes only once the
+    // draws of two frames earlier have finished — a host running ahead (two alternating sets of pinned planes) could refill a set
+    // before the copy that reads it has run.  So this flip returns only when the copies published by the PREVIOUS flip have
+    // executed: the planes staged before that flip are free to be rewritten, and the host is never more than two frames ahead.
+    const unsigned int k = c->flips++;
+    HIPCHK(c, hipEventRecord(c->ev_batch[k & 1], c->upload_stream));
+    if (k >= 1) HIPCHK(c, hipEventSynchronize(c->ev_batch[(k - 1) & 1]));
     for (int id = 0; id < RFX_TEX_COUNT; id++) {
         Slot &s = c->slots[id];
         if (!s.back_filled) continue;

@@ -47,7 +47,8 @@ Rccl *rccl() {
             if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (!r.handle) r.handle = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!r.handle) {
-            r.why = std::string("librccl.so.1 not loadable: ") + (dlerror() ? dlerror() : "?");
+            const char *e = dlerror();  // one call: dlerror() clears the message it returns
+            r.why = std::string("librccl.so.1 not loadable: ") + (e ? e : "?");
             return;
         }
 #define RFX_SYM(field, name)                                          \

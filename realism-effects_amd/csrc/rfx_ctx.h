@@ -28,7 +28,7 @@ struct rfx_ctx {
     float4 *hits = nullptr;    // K1 trace -> shade hand-over (rfx_ssgi_trace), 2 texels per SSGI texel
     bool hits_traced = false;  // a trace is waiting for its shade
     int win_y0 = 0, win_y1 = 0x7fffffff;  // rfx_set_row_window: rows the draws may produce
-    int uv_model = RFX_UV_IDEAL;           // rfx_set_uv_model
+    int uv_model = RFX_UV_REFERENCE_GL;    // rfx_set_uv_model (the default: the vUv the parity oracle's GL interpolates)
     float2 *coarse = nullptr;  // K1 scratch: exact (min,max) view Z per 16x16 base cell
     unsigned int *cells = nullptr;  // K1 scratch: the march's half-packed (min,max) table
     float4 *env = nullptr;     // scene.environment: the whole mip chain, float4 texels
@@ -48,6 +48,8 @@ struct rfx_ctx {
     // streaming dumps: a third stream for the host-to-device copies of the NEXT frame and the two events that order it against the draws
     hipStream_t upload_stream = nullptr;
     hipEvent_t ev_staged = nullptr, ev_frame_done = nullptr;
+    hipEvent_t ev_batch[2] = {nullptr, nullptr};  // the copies published by the last two flips (recorded on upload_stream)
+    unsigned int flips = 0;
     std::string err;
 };
 void rfx_comm_release(rfx_ctx *c);  // rfx_comm.hip: called by rfx_destroy

@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "..", "csrc", "librfx_hip.so")
 
-RFX_ABI_VERSION = 14
+RFX_ABI_VERSION = 15
 RFX_UV_IDEAL, RFX_UV_REFERENCE_GL = 0, 1  # rfx_set_uv_model
 RFX_OK, RFX_EINVAL, RFX_ENOMEM, RFX_EDEVICE, RFX_ESTATE, RFX_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 
@@ -100,6 +100,14 @@ EXPORTS = [
 ]
 
 _lib = None
+_lib_path = None  # set_library_path(): an explicit path instead of the in-tree librfx_hip.so
+
+
+def set_library_path(path: str | None) -> None:
+    """Load `path` instead of the in-tree csrc/librfx_hip.so from now on (development: a tuning variant of the library; tests: the host
+    simulator, injected by tests/conftest.py).  Explicit on purpose — nothing in this package reads a library path from the environment."""
+    global _lib, _lib_path
+    _lib, _lib_path = None, (os.path.abspath(path) if path else None)
 
 
 def load_library(path: str | None = None) -> C.CDLL:
@@ -107,7 +115,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = os.path.abspath(path or os.environ.get("RFX_HIP_LIB", LIB_PATH))
+    p = os.path.abspath(path or _lib_path or LIB_PATH)
     if not os.path.exists(p):
         raise ImportError(
             "librfx_hip.so not found at %s — build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "

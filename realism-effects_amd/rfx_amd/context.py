@@ -218,7 +218,7 @@ class Context:
         """Restrict the rows the following draws produce to [y0, y1); no arguments (or y1 <= y0) resets (rfx_set_row_window)."""
         self._chk(self.lib.rfx_set_row_window(self._h, int(y0), int(y1)), "rfx_set_row_window")
 
-    def set_uv_model(self, model="ideal"):
+    def set_uv_model(self, model="reference_gl"):
         """Which vUv the following draws' fragments see: "ideal" = (i + 0.5) / n; "reference_gl" = the reference GL's rasteriser value, bit
         for bit (include/rfx.h rfx_set_uv_model; what the parity tests against the reference GLSL on llvmpipe are tightest under)."""
         m = {"ideal": abi.RFX_UV_IDEAL, "reference_gl": abi.RFX_UV_REFERENCE_GL}.get(model, model)

@@ -11,12 +11,24 @@ for p in (os.path.join(ROOT, "realism-effects_amd"), os.path.join(ROOT, "oracle"
 
 # -m gpu tests that need the real device (RCCL, torch.cuda): not runnable under --hostsim
 HOSTSIM_NEEDS_HARDWARE = ("test_bench_multi_rank_flow_on_one_gpu",)
+# ... and the ones whose frame is too large for kernels executed thread by thread on the CPU (minutes per draw)
+HOSTSIM_TOO_LARGE = ("configs[4] 8K",)
+
+
+def hostsim_child_env(sim, build="_build"):
+    """Environment of a python child process that must load the host simulator: tests/hostsim/inject/sitecustomize.py (found through
+    PYTHONPATH at interpreter start) calls rfx_amd.abi.set_library_path(RFX_TEST_LIB)."""
+    return {"RFX_TEST_LIB": os.path.join(sim, build, "librfx_hostsim.so"),
+            "PYTHONPATH": os.path.join(sim, "inject") + os.pathsep + os.environ.get("PYTHONPATH", "")}
 
 
 def pytest_addoption(parser):
     parser.addoption("--hostsim", action="store_true", default=False,
                      help="run the -m gpu tests against tests/hostsim (the product's kernel sources compiled for x86: kernel LOGIC on the CPU, "
                           "no statement about the device's bits) instead of librfx_hip.so on a GPU")
+    parser.addoption("--hostsim-build", default="_build",
+                     help="with --hostsim: the build of tests/hostsim to load (_build; _asan / _ubsan after `make -C tests/hostsim asan|ubsan`, with the "
+                          "sanitizer runtime in LD_PRELOAD)")
 
 
 def pytest_configure(config):
@@ -25,11 +37,17 @@ def pytest_configure(config):
     if config.getoption("--hostsim"):
         import subprocess
         sim = os.path.join(ROOT, "tests", "hostsim")
-        subprocess.check_call(["make", "-s", "-C", sim])
-        os.environ["RFX_HIP_LIB"] = os.path.join(sim, "_build", "librfx_hostsim.so")
-        os.environ["RFX_HOSTSIM"] = "1"
+        build = config.getoption("--hostsim-build")
+        if build == "_build":
+            subprocess.check_call(["make", "-s", "-C", sim])
+        lib = os.path.join(sim, build, "librfx_hostsim.so")
+        from rfx_amd import abi
+        abi.set_library_path(lib)  # this process: explicit injection (the product loader reads no environment variable)
+        for k, v in hostsim_child_env(sim, build).items():  # the processes the tests spawn
+            os.environ[k] = v
+        os.environ["RFX_HOSTSIM"] = "1"  # read by tests only (skip conditions)
         # child processes (node + the N-API addon, which links librfx_hip.so by rpath): the simulator's rfx_* symbols interpose
-        os.environ["LD_PRELOAD"] = os.environ["RFX_HIP_LIB"]
+        os.environ["LD_PRELOAD"] = (os.environ["LD_PRELOAD"] + os.pathsep if os.environ.get("LD_PRELOAD") else "") + lib
         # rfx_comm.hip binds RCCL at run time (dlopen; the simulator build looks for librccl_hostsim.so.1): tests/hostsim/fakerccl.c moves the
         # bytes over unix sockets instead
         import ctypes
@@ -42,9 +60,12 @@ def pytest_collection_modifyitems(config, items):
     if not config.getoption("--hostsim"):
         return
     skip = pytest.mark.skip(reason="--hostsim: needs the device (RCCL / torch.cuda)")
+    big = pytest.mark.skip(reason="--hostsim: an 8K frame on the simulator takes minutes per draw")
     for it in items:
         if any(n in it.nodeid for n in HOSTSIM_NEEDS_HARDWARE):
             it.add_marker(skip)
+        if any(n in it.nodeid for n in HOSTSIM_TOO_LARGE):
+            it.add_marker(big)
 
 
 @pytest.fixture(scope="session")

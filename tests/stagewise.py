@@ -128,18 +128,22 @@ def _h(t):  # RGBA16F target read back as float32 -> the half bit patterns (exac
 
 
 def run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start=1000, denoise_start=2000, shader_dir=None, log=print,
-        with_margins=True, n_perturb=6, sample_every=64, extra_perturb=96, compare_from=0, uv_model="ideal"):
+        with_margins=True, n_perturb=6, sample_every=64, extra_perturb=96, compare_from=0, uv_model="reference_gl", rows=None):
     """Returns the list of parity.Report (one per stage output and frame).  frame_fn(i) -> dump frame i (rfx_amd.scene Frame).
-    uv_model "reference_gl": the implementation (rfx_set_uv_model / rfxo_set_uv_model) evaluates the reference GL's own vUv planes, and the
-    proving oracle then carries no vUv uncertainty at all."""
+    uv_model "reference_gl" (the default of the library and of this harness): the implementation (rfx_set_uv_model / rfxo_set_uv_model)
+    evaluates the reference GL's own vUv planes, and the proving oracle then carries no vUv uncertainty at all; "ideal": (i + 0.5) / n on the
+    implementation's side, the vUv uncertainty in the proofs.
+    rows (y0, y1): every draw still covers the whole frame on both sides, but only that band of rows is compared and proven — what makes an
+    8K frame affordable in the default suite (the numpy side of a whole 33 Mpixel stage output costs minutes)."""
     with O.uv_model({"ideal": "ideal", "reference_gl": "reference"}[uv_model]):
         return _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start, denoise_start, shader_dir, log,
-                    with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model)
+                    with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model, rows)
 
 
 def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start, denoise_start, shader_dir, log,
-         with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model):
+         with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model, rows=None):
     import chain
+    y0, y1 = (0, H) if rows is None else (max(0, int(rows[0])), min(H, int(rows[1])))
     ref = chain.GLRefChain(W, H, blue, shader_dir=shader_dir, steps=steps, refineSteps=refine, denoiseIterations=iterations)
     impl = impl_cls(W, H, blue)
     if hasattr(impl, "set_uv_model"):
@@ -164,6 +168,8 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
     # the oracle re-evaluates only the out-of-tolerance pixels and a fixed random sample (1 pixel in `sample_every`) of the frame:
     # the sample estimates the at-risk population without 1 + n_perturb whole-frame oracle runs per stage (minutes at 8K)
     sample = np.random.RandomState(12345).rand(H, W) < 1.0 / sample_every
+    sample[:y0] = False
+    sample[y1:] = False
 
     def margins_of(fn, half, bad):
         """(explainable (H, W) bool, estimated at-risk pixel count): the oracle proves a pixel unstable — discontinuity margin < 1, or
@@ -209,20 +215,21 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
             pos = np.searchsorted(sel, li)
             diag["oracle_at_unexplained"] = (np.stack([li // W, li % W], 1), base[pos], mm.plane.reshape(-1)[li])
         n_sample = int(sample.sum())
-        return unstable, int(round(float(unstable[sample].sum()) / max(n_sample, 1) * H * W))
+        return unstable, int(round(float(unstable[sample].sum()) / max(n_sample, 1) * (y1 - y0) * W))
 
     def bad_of(gots, wants, half):
         gots = gots if isinstance(gots, (list, tuple)) else [gots]
         wants = wants if isinstance(wants, (list, tuple)) else [wants]
         b = np.zeros((H, W), bool)
         for g, w in zip(gots, wants):
-            b |= out_of_tolerance(as_float(g), as_float(w), half)
+            b[y0:y1] |= out_of_tolerance(as_float(g[y0:y1]), as_float(w[y0:y1]), half)
         return b
 
     diag = {}
 
     def check(name, got, want, mr, half):
         m, at_risk = mr
+        got, want, m = got[y0:y1], want[y0:y1], (None if m is None else m[y0:y1])  # the compared band (the whole frame by default)
         if isinstance(got, np.ndarray) and got.dtype == np.uint16:
             got, want = O.half_bits_to_float(got), O.half_bits_to_float(want)
         r = strict(name, got, want, explainable=m, half=half)
@@ -233,7 +240,7 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
             for k, (y, x) in enumerate(idx):
                 c = slice(0, g.shape[-1]) if obase.shape[-1] == g.shape[-1] else slice(0, 0)
                 log("    unexplained (y %d, x %d) margin %.3g\n      impl   %s\n      ref    %s\n      oracle %s" % (
-                    y, x, omargin[k], np.array2string(g[y, x], precision=6), np.array2string(w[y, x], precision=6),
+                    y, x, omargin[k], np.array2string(g[y - y0, x], precision=6), np.array2string(w[y - y0, x], precision=6),
                     np.array2string(obase[k], precision=6)))
         reports.append(r)
         log(r.line())
@@ -265,9 +272,14 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
         R = np.ascontiguousarray(ref.t_ssgi.read().view(np.uint32))
         I = impl.ssgi(hist, sp)
         # the packed texel's 8 halfs as stored (unpackTwoVec4 subtracts the same 1e-4 from both sides)
-        got, want = as_float(np.ascontiguousarray(I)), as_float(R)
+        I = np.ascontiguousarray(I)
+        if rows is None:
+            got, want = as_float(I), as_float(R)
+        else:  # decode the band only, at its place in a frame-sized array of zeros
+            got, want = np.zeros((H, W, 8), np.float32), np.zeros((H, W, 8), np.float32)
+            got[y0:y1], want[y0:y1] = as_float(I[y0:y1]), as_float(R[y0:y1])
         r = check(tag + "K1 ssgi", got, want, margins_of(lambda: ora.ssgi(hist, sp), True, bad_of(got, want, True)), half=True)
-        r.bit_identical = float((I == R).all(axis=-1).mean())
+        r.bit_identical = float((I[y0:y1] == R[y0:y1]).all(axis=-1).mean())
         # ---- K2 (input: the reference's K1 output; history: its K3 target B of the previous frame; targets keep discarded texels)
         B_prev = [_h(t) for t in ref.t_B]
         T_prev = [np.ascontiguousarray(t.read()) for t in ref.t_temporal]

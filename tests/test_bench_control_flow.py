@@ -78,8 +78,9 @@ def test_bench_row_tiled_for_real_under_the_host_simulator(tmp_path):
         pytest.skip("no host clang++ / make")
     sim = os.path.join(ROOT, "tests", "hostsim")
     subprocess.check_call(["make", "-s", "-C", sim])
-    env = dict(os.environ, RFX_HIP_LIB=os.path.join(sim, "_build", "librfx_hostsim.so"), RFX_HOSTSIM="1",
-               LD_LIBRARY_PATH=os.path.join(sim, "_build", "fakerccl") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    from conftest import hostsim_child_env
+    env = dict(os.environ, **hostsim_child_env(sim))
+    env.update(LD_LIBRARY_PATH=os.path.join(sim, "_build", "fakerccl") + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RFX_BENCH_ONE_GPU"):
         env.pop(k, None)
     common = ["--steps", "2", "--warmup", "1", "--width", "192", "--height", "128", "--no-cpu-baseline", "--checksum"]

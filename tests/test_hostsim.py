@@ -32,7 +32,36 @@ def test_differential_fuzz_of_the_kernels_against_the_oracle():
     simulated kernels against the C restatement (80 cases here; 500 under AddressSanitizer were clean when this was written)."""
     sim = os.path.join(ROOT, "tests", "hostsim")
     subprocess.check_call(["make", "-s", "-C", sim])
-    env = dict(os.environ, RFX_HIP_LIB=os.path.join(sim, "_build", "librfx_hostsim.so"))
+    from conftest import hostsim_child_env
+    env = dict(os.environ, **hostsim_child_env(sim))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_hostsim.py"), "--n", "80", "--seed", "3"], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     assert "0 problems" in p.stdout.splitlines()[-1]
+
+
+def test_comm_entry_points_without_a_loadable_rccl_report_unsupported():
+    """rfx_comm.hip binds RCCL with dlopen at first use; a host without it must get RFX_EUNSUPPORTED from every exchange entry point, not a
+    crash (round 2's loader built its message from two dlerror() calls: the second returns NULL -> std::string + nullptr).  The simulator
+    build looks for librccl_hostsim.so.1 only; this process does not put tests/hostsim/_build/fakerccl on its library path."""
+    sim = os.path.join(ROOT, "tests", "hostsim")
+    subprocess.check_call(["make", "-s", "-C", sim])
+    code = (
+        "import ctypes, sys\n"
+        "lib = ctypes.CDLL(sys.argv[1])\n"
+        "buf = ctypes.create_string_buffer(128)\n"
+        "rc = lib.rfx_comm_unique_id(buf)\n"
+        "lib.rfx_create.restype = ctypes.c_void_p\n"
+        "lib.rfx_create.argtypes = [ctypes.c_int] * 6\n"
+        "ctx = lib.rfx_create(0, 64, 32, 0, 32, 0)\n"
+        "lib.rfx_comm_init.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]\n"
+        "rc2 = lib.rfx_comm_init(ctx, buf, 0, 1)\n"
+        "lib.rfx_last_error.restype = ctypes.c_char_p\n"
+        "lib.rfx_last_error.argtypes = [ctypes.c_void_p]\n"
+        "print(rc, rc2, lib.rfx_last_error(ctx).decode())\n"
+    )
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_LIBRARY_PATH", "LD_PRELOAD")}
+    p = subprocess.run([sys.executable, "-c", code, os.path.join(sim, "_build", "librfx_hostsim.so")], capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    rc, rc2, msg = p.stdout.strip().split(" ", 2)
+    assert int(rc) == -5 and int(rc2) == -5, p.stdout  # RFX_EUNSUPPORTED
+    assert "RCCL" in msg

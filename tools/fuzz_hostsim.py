@@ -3,7 +3,7 @@
 on the same inputs.  Both sides use libm-grade primitives, so they agree to a handful of flipped pixels: a stage that differs on more
 than a fraction of a percent of its pixels is a logic bug (apron, halo, launch shape, an option the kernel and the oracle read differently).
 
-    make -C tests/hostsim && RFX_HIP_LIB=tests/hostsim/_build/librfx_hostsim.so python tools/fuzz_hostsim.py [--n 200] [--seed 1]
+    make -C tests/hostsim && python tools/fuzz_hostsim.py --lib tests/hostsim/_build/librfx_hostsim.so [--n 200] [--seed 1]
 """
 import argparse
 import os
@@ -24,8 +24,11 @@ from rfx_amd.scene import synthetic_frame  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=100)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--lib", default=None, help="tests/hostsim/_build/librfx_hostsim.so (not needed in a child of pytest --hostsim)")
 a = ap.parse_args()
-assert "hostsim" in os.environ.get("RFX_HIP_LIB", ""), "point RFX_HIP_LIB at tests/hostsim/_build/librfx_hostsim.so"
+if a.lib:
+    abi.set_library_path(a.lib)
+assert hasattr(abi.load_library(), "rfx_hostsim_build"), "run with --lib tests/hostsim/_build/librfx_hostsim.so (or under pytest --hostsim's child environment)"
 rng = np.random.RandomState(a.seed)
 blue = load_blue_noise_table()
 fails = nchecks = 0

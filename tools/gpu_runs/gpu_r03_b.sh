@@ -10,7 +10,7 @@ timeout 200 python tools/quick_time.py 3840 2160 20 > $O/quick_time_4k.txt 2>&1;
 for so in realism-effects_amd/csrc/variants/librfx_*.so; do
   [ -f "$so" ] || continue
   echo "== $so"
-  RFX_HIP_LIB=$PWD/$so timeout 200 python tools/quick_time.py 3840 2160 20 2>&1 | grep -v "^scene" | tee -a $O/variants.txt
+  timeout 200 python tools/quick_time.py --lib $PWD/$so 3840 2160 20 2>&1 | grep -v "^scene" | tee -a $O/variants.txt
 done
 timeout 200 python tools/gpu_runs/uv_model_check.py > $O/uv_model_check.txt 2>&1; tail -24 $O/uv_model_check.txt
 export RFX_TEST_UV_REFERENCE=1

@@ -28,7 +28,7 @@ ap.add_argument("--frames", type=int, default=2)
 ap.add_argument("--out", default=None)
 ap.add_argument("--compare-from", type=int, default=0, help="frames before this one only advance the reference chain (no comparison)")
 ap.add_argument("--perturb", type=int, default=16, help="perturbed oracle re-evaluations per stage (of the out-of-tolerance + sampled pixels)")
-ap.add_argument("--uv-model", default="ideal", help="ideal | reference_gl (rfx_set_uv_model / rfxo_set_uv_model on the implementation and the proving oracle)")
+ap.add_argument("--uv-model", default="reference_gl", help="ideal | reference_gl (rfx_set_uv_model / rfxo_set_uv_model on the implementation and the proving oracle)")
 a = ap.parse_args()
 W, H = [int(v) for v in a.size.split("x")]
 lines = []

@@ -8,6 +8,10 @@ from rfx_amd import abi
 from rfx_amd.context import Context
 from rfx_amd.scene import synthetic_frame
 
+if "--lib" in sys.argv:  # a tuning variant of the library (csrc/build_variants.sh) instead of the in-tree build
+    i = sys.argv.index("--lib")
+    abi.set_library_path(sys.argv[i + 1])
+    del sys.argv[i:i + 2]
 W, H = int(sys.argv[1]), int(sys.argv[2])
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 only = sys.argv[4] if len(sys.argv) > 4 else ""  # e.g. "K1": time only the stages whose name starts with this

@@ -3,5 +3,5 @@
 cd "$(dirname "$0")/.."
 for so in realism-effects_amd/csrc/librfx_hip.so realism-effects_amd/csrc/variants/librfx_*.so; do
   echo "== $so"
-  RFX_HIP_LIB=$PWD/$so timeout 300 python tools/quick_time.py 3840 2160 20 ${1:-} | grep -v "^scene"
+  timeout 300 python tools/quick_time.py --lib $PWD/$so 3840 2160 20 ${1:-} | grep -v "^scene"
 done
