@@ -2,21 +2,26 @@
 """bench.py — the hot path's headline metric on MI355X: Mpixels/s of the SSGI chain at 4K.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no RANK in the environment the command launches itself, one rank per GPU, as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+(which is also how the driver may launch it directly).
 
 One "step" = one frame through SSGIEffect.update(): K1 SSGI march (steps 20 / refineSteps 5) ->
 K2 temporal reprojection -> 2 x K3 Poisson denoise (denoiseIterations 1) -> K4 compose, over a
 3840x2160 synthetic G-buffer dump (seed 1234) that is ALREADY RESIDENT in HBM when the timed
-region starts.  N > 1: weak scaling — the frame keeps its 16:9 aspect and grows to N x 8.29 Mpixel
-(e.g. 7680x4320 for N = 4), is cut into N row tiles (one per GPU, 8.29 Mpixel each) which exchange
-halo rows with their neighbours over RCCL after K2 and after every K3 pass, plus an all-gather of
-the composed GI that runs asynchronously under the next frame's depth pre-pass + ray march (K1 is
-split into rfx_ssgi_trace / rfx_ssgi_shade for that; rfx_amd/tiling.py).
+region starts.
+  N = 1: BASELINE.json configs[2], the 4K frame on one GPU.
+  N > 1: configs[3] — THE SAME 4K frame cut into N row tiles (STRONG scaling: 1080 / 540 / 270 rows per GPU), which exchange halo rows
+         with their neighbours over RCCL after K2 and after every K3 pass, plus the gather of the composed GI that the next frame's K1
+         shading reads (asynchronous, under the next frame's depth pre-pass + ray march: K1 runs as rfx_ssgi_trace / rfx_ssgi_shade).
+         The round-1 weak-scaling case and configs[4] (8K, steps 40, denoiseIterations 3) ride along as extra keys.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (largest share of the
-step), measured live with hipEvents on the stream the kernels run on; `cpu_baseline` is the
-oracle (the C restatement, OpenMP) timed on this box's host cores on the same frame.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (largest share of the step), its launches timed live with hipEvents
+on the stream the kernels run on, next to a device-to-device stream-copy rate measured in the same process; `valu` is the measured VALU
+occupancy of every kernel (rocprofv3 counters of this same command, committed under PROFILE_DIR) — the bound that actually binds;
+`cpu_baseline` is the REFERENCE's own GLSL on Mesa llvmpipe on this box's host cores over the same frame (kind "reference"; the C
+restatement is the fallback when no GL is available).
 """
 import argparse
 import json
@@ -46,7 +51,7 @@ PMC_KERNEL = {"k1_ssgi_march": "k1_ssgi_march", "k2_temporal_reproject": "k2_tem
               "k3_poisson_denoise_pass1": "k3_tiled<false", "k4_compose": "k4_compose"}
 
 
-PROFILE_DIR = "profiles/r02_final"  # the committed rocprofv3 collection the static counter figures are read from
+PROFILE_DIR = "profiles/r03_final"  # the committed rocprofv3 collection (tools/collect_profiles.sh) the counter-derived figures are read from
 
 
 def profile_meta():
@@ -75,21 +80,16 @@ def pmc_traffic(kernel_key):
     return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
 
 
-# measured on MI355X by tools/microbench/valu_rates.hip (profiles/r02_final/valu_rates.txt), 8 waves/SIMD, ns per wave64 instruction per SIMD:
-#   v_add_f32 / v_mul_f32 1.08 (2.6 cycles)   v_fma_f32 1.65   v_cvt / v_med3 / v_min3 / v_max / shifts / v_mul_i24 1.72-1.81 (4.1-4.3 cycles)
-#   v_pk_fma/mul/add_f32 (two results per lane) 1.9-2.1   v_exp / v_log / v_rcp / v_sqrt / v_sin 3.4-3.5 (8.1-8.5 cycles)
-# (Round 1 priced EVERY VALU instruction at 1.03 ns: its "v_fma_f32" loop had been auto-packed into v_pk_fma_f32, i.e. it measured two fma
-# per 2.05 ns.)  The PMC counters give instruction counts per wave but not their classes, so the issue-bound time is bracketed:
-# `fast` prices every non-transcendental at the add/mul rate, `generic` at the rate of everything that is not an add/mul (the static
-# mix of the kernels' loops — e.g. K3's tap loop: 17 % packed, 16 % add/mul, 5 % fma, 15 % cvt, 40 % other, 7 % transcendental —
-# averages 4.3 cycles, i.e. sits at the generic end).
-VALU_FAST_NS, VALU_NS, TRANS_NS, N_SIMD = 1.08, 1.77, 3.4, 256 * 4
+N_SIMD, N_XCD = 256 * 4, 8
 
 
-def valu_floor_ms(kernel_key, pixels):
-    """(fast, generic) issue-bound times of a kernel: its VALU instruction counts per wavefront (committed PMC summary,
-    PROFILE_DIR/pmc_sq_l2.csv: SQ_INSTS_VALU, SQ_INSTS_VALU_TRANS_F32, SQ_WAVES — a property of the code, not of the run) priced at the
-    measured issue rates."""
+def valu_occupancy(kernel_key):
+    """Measured VALU occupancy of a kernel, from the committed counter collection of this same command (PROFILE_DIR/pmc_sq_l2.csv):
+        valu_busy      = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)   (quad-cycles -> cycles; 1.0 = every SIMD issues VALU every cycle)
+        valu_per_px    = SQ_INSTS_VALU / SQ_WAVES  (wave64 instructions per wavefront = per pixel: one pixel per lane)
+        cycles_per_valu = SQ_ACTIVE_INST_VALU * 4 / SQ_INSTS_VALU  (what one wave64 VALU instruction occupies its SIMD for)
+    The floor the prescribed arithmetic implies on this part is valu_per_px * cycles_per_valu * waves_per_SIMD / clock — these kernels sit on
+    it (valu_busy ~ 1): the lever is the instruction count, not bytes.  None when the collection is missing."""
     import csv
     path = os.path.join(ROOT, PROFILE_DIR, "pmc_sq_l2.csv")
     if not os.path.exists(path):
@@ -98,12 +98,38 @@ def valu_floor_ms(kernel_key, pixels):
     for r in csv.DictReader(open(path)):
         if PMC_KERNEL[kernel_key] in r["kernel"]:
             c[r["counter"]] = float(r["mean_value"])
-    if not all(k in c for k in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_TRANS_F32", "SQ_WAVES")):
+    need = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE")
+    if not all(k in c for k in need):
         return None
-    valu, trans = c["SQ_INSTS_VALU"] / c["SQ_WAVES"], c["SQ_INSTS_VALU_TRANS_F32"] / c["SQ_WAVES"]
-    waves_per_simd = pixels / 64.0 / N_SIMD
-    return (((valu - trans) * VALU_FAST_NS + trans * TRANS_NS) * waves_per_simd * 1e-6,
-            ((valu - trans) * VALU_NS + trans * TRANS_NS) * waves_per_simd * 1e-6)
+    out = {"valu_busy": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * c["GRBM_GUI_ACTIVE"] / N_XCD), 3),
+           "valu_per_px": round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1),
+           "cycles_per_valu": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"], 2)}
+    if "SQ_INSTS_VALU_TRANS_F32" in c:
+        out["transcendental_per_px"] = round(c["SQ_INSTS_VALU_TRANS_F32"] / c["SQ_WAVES"], 1)
+    return out
+
+
+def stream_copy_gbs(dev, nbytes=1 << 30, iters=10):
+    """Device-to-device copy rate measured here and now (read + write bytes / time): the practical HBM ceiling next to the 8 TB/s spec."""
+    import torch
+    try:
+        a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        del a, b
+        torch.cuda.empty_cache()
+        return round(2.0 * nbytes / (ms * 1e-3) / 1e9, 1)
+    except Exception as e:  # noqa: BLE001  (the host simulator has no device allocator)
+        log("stream copy not measured: %r" % (e,))
+        return None
 
 
 def log(*a):
@@ -291,6 +317,18 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="N > 1: only the headline case (skip the weak-scaling and configs[4] extras)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # launched plainly (the way the driver launches N = 1): become the launcher — one rank per GPU of this node under torch.distributed.run
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+        log("bench.py: --gpus %d without RANK in the environment -> %s" % (args.gpus, " ".join(cmd[1:9])))
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
     from rfx_amd import abi as _abi
     if hasattr(_abi.load_library(), "rfx_hostsim_build"):  # the library is tests/hostsim (the kernel sources on the CPU, injected by the tests): no device to select or drain
@@ -362,6 +400,7 @@ def main():
         compose_sha1 = hashlib.sha1(np.ascontiguousarray(rgb).tobytes()).hexdigest()
     kms = kernel_times(case, max(5, min(args.steps, 20)))
     rows, halo = case["rows"], case["halo"]
+    copy_gbs = stream_copy_gbs(dev) if rank == 0 else None  # measured here, after the timed region
 
     extras = {}
 
@@ -395,22 +434,22 @@ def main():
                                  "achieved_GBs": round(ns_bytes * px_tile / (ns_ms * 1e-3) / 1e9, 1),
                                  "frac_of_peak": round(ns_bytes * px_tile / (ns_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "target_frac": 0.70},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "stream_copy_GBs": copy_gbs,
+                         "frac_of_stream_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                          "traffic": pmc_traffic(dom) if (W1, rows) == (W4K, H4K) else None,
                          "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 from %s/pmc_hbm.csv (rocprofv3 --pmc, this command at 4K; collected at git %s)" % (
                              PROFILE_DIR, prof.get("git_commit", "?")),
                          "algorithmic_bytes_per_launch": BYTES_PER_PX[dom] * px_tile, "avg_launch_ms": round(kms[dom], 4)},
             "halo_violations": viol,
         }
-        # the bound that actually binds: VALU issue — reported next to the HBM roofline the metric asks for
-        floors = {k: valu_floor_ms(k, px_tile) for k in kms}
-        if all(v is not None for v in floors.values()):
-            gen, fast = sum(v[1] for v in floors.values()), sum(v[0] for v in floors.values())
-            out["valu_issue_roofline"] = {"issue_bound_ms": {k: [round(v[0], 4), round(v[1], 4)] for k, v in floors.items()},
-                                          "sum_issue_bound_ms": [round(fast, 4), round(gen, 4)], "measured_sum_kernel_ms": round(chain_ms, 4),
-                                          "frac": round(gen / chain_ms, 4),
-                                          "note": "[fast, generic] issue-bound time: VALU + transcendental instructions per wave (%s/pmc_sq_l2.csv, git %s) priced at the issue rates measured by tools/microbench/valu_rates.hip — fast: every plain VALU at the v_add/v_mul rate (1.08 ns per wave64 instruction per SIMD), generic: at the rate of cvt/min/max/med3/shift/select (1.77 ns), transcendentals 3.4 ns; frac = generic / measured (the loops' static mix sits at the generic end)" % (
-                                              PROFILE_DIR, prof.get("git_commit", "?"))}
+        # the bound that actually binds: VALU issue — the measured VALU occupancy of every kernel, next to the HBM roofline the
+        # metric asks for.  Only quoted for the frame the collection was taken on (the whole 4K frame on one GPU).
+        if (W1, rows) == (W4K, H4K):
+            occ = {k: valu_occupancy(k) for k in kms}
+            if all(v is not None for v in occ.values()):
+                out["valu"] = dict(occ, note="per kernel: valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8); valu_per_px = SQ_INSTS_VALU / SQ_WAVES; "
+                                             "cycles_per_valu = SQ_ACTIVE_INST_VALU*4 / SQ_INSTS_VALU — %s/pmc_sq_l2.csv (rocprofv3 --pmc, this command; collected at git %s)" % (
+                                                 PROFILE_DIR, prof.get("git_commit", "?")))
         if world > 1:
             out["config"]["exchange_verified"] = bool(use_c)  # the C-ABI exchanges passed their pre-flight pattern check on every rank
             if fallback_note:

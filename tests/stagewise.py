@@ -123,6 +123,29 @@ class HipStages:
         self.ctx.close()
 
 
+def prove_flips(fn, outs_to_float, bad, half, n_perturb=8, extra_perturb=48):
+    """The flip proof of the strict metric for a handful of pixels, without a reference chain: `fn()` re-evaluates a stage on the ORACLE
+    (OracleStages), `outs_to_float(outs)` turns its outputs into one (H, W, C) float array, `bad` (H, W) marks the out-of-tolerance pixels.
+    Returns the (H, W) bool of pixels the oracle proves unstable: a decision margin < 1, or the output moves by half the tolerance when
+    the oracle's primitives are perturbed within the reference GL's measured error (seeded runs).  Only the pixels of `bad` are evaluated."""
+    H, W = bad.shape
+    unstable = np.zeros((H, W), bool)
+    if not bad.any():
+        return unstable
+    with O.pixel_mask(bad):
+        with O.margins(H, W) as mm:
+            base = outs_to_float(fn())
+        unstable |= bad & (mm.plane < 1.0)
+        seed = 0
+        while seed < n_perturb + extra_perturb and (bad & ~unstable).any():
+            seed += 1
+            with O.perturbation(seed):
+                unstable |= bad & out_of_tolerance(outs_to_float(fn()), base, half, UNSTABLE_TOL_SCALE)
+            if seed >= n_perturb and not (bad & ~unstable).any():
+                break
+    return unstable
+
+
 def _h(t):  # RGBA16F target read back as float32 -> the half bit patterns (exactly representable)
     return np.ascontiguousarray(t.read().astype(np.float16).view(np.uint16))
 

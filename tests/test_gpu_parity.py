@@ -1139,3 +1139,15 @@ def test_row_windowed_draws_are_bit_identical(blue_noise):
             assert np.array_equal(ctx.download(t), want[t]), "%s: windowed != whole" % name
     assert ctx.halo_violations() == 0
     ctx.close()
+
+
+def test_smoke_fallback_against_the_oracle_proves_every_flip(blue_noise):
+    """__graft_entry__.smoke() checks the chain against the reference GLSL on llvmpipe; on a box without a GL it falls back to the C
+    restatement as the reference.  That path must hold the same line — every out-of-tolerance pixel PROVEN unstable by the oracle
+    (stagewise.prove_flips), not waved through — so it is run here directly."""
+    import __graft_entry__ as G  # (tests/conftest.py puts the repository root on sys.path)
+    reports = G._smoke_vs_oracle(160, 90, blue_noise)
+    assert len(reports) == 2 * (1 + 2 + 2 + 2 + 1)
+    for r in reports:
+        assert r.unexplained == 0, r.line()
+        assert r.bad <= 0.002 * r.pixels + 3, r.line()
