@@ -395,9 +395,22 @@ def main():
     if args.checksum:  # before the per-kernel timing below re-runs kernels on this rank's tile only
         import hashlib
         renderer = case["renderer"]
+        if getattr(renderer, "history_gather", "all") == "bounded":  # the ranks hold only the rows their own rays needed: complete the frame
+            renderer.gather_whole_history()
         # .rgb of the whole composed frame: what a tiled run gathers (RFX_TEX_COMPOSE_RGB) and what the next frame's K1 reads
         rgb = ctx.download(abi.TEX_COMPOSE_RGB) if getattr(renderer, "gather_history_rgb", False) else ctx.download(abi.TEX_COMPOSE)[..., :3]
         compose_sha1 = hashlib.sha1(np.ascontiguousarray(rgb).tobytes()).hexdigest()
+    # the composed-GI exchange of a row-tiled run: what every rank RECEIVES per frame (bounded gather: rfx_gather_history_rows reports it;
+    # the whole-frame all-gather: the other tiles' rows, always), max over ranks
+    history = None
+    if world > 1:
+        got = getattr(case["renderer"], "history_bytes_received", None)
+        mode = getattr(case["renderer"], "history_gather", "all")
+        mine = float(np.mean(got[-args.steps:])) if (mode == "bounded" and got) else float((H1 - case["rows"]) * W1 * 12)
+        t = torch.tensor([mine], dtype=torch.float64, device=ctl_device(dist, dev))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        history = {"mode": mode, "MB_received_per_frame_max_over_ranks": round(float(t.item()) / 1e6, 3),
+                   "whole_frame_allgather_MB": round((H1 - min(n for _, n in tiles)) * W1 * 12 / 1e6, 3)}
     kms = kernel_times(case, max(5, min(args.steps, 20)))
     rows, halo = case["rows"], case["halo"]
     copy_gbs = stream_copy_gbs(dev) if rank == 0 else None  # measured here, after the timed region
@@ -424,7 +437,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload + ", steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step",
                        "frame": "%dx%d" % (W1, H1), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz", "uv_model": "reference_gl",
-                       "parallelism": "row-tiles x%d, RCCL halo send/recv after K2 and every K3 pass + composed-GI all-gather (async, under the next frame's K1 trace); exchange: %s" % (
+                       "parallelism": "row-tiles x%d, RCCL halo send/recv after K2 and every K3 pass + composed GI: only the rows the traced rays read, between K1's trace and shade (rfx_gather_history_rows); exchange: %s" % (
                            world, case_exchange(use_c, one_gpu, args)) if world > 1 else "single GPU"},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
             "chain": {"algorithmic_bytes_per_px": chain_bytes, "sum_kernel_ms": round(chain_ms, 4),
@@ -452,6 +465,7 @@ def main():
                                                  PROFILE_DIR, prof.get("git_commit", "?")))
         if world > 1:
             out["config"]["exchange_verified"] = bool(use_c)  # the C-ABI exchanges passed their pre-flight pattern check on every rank
+            out["config"]["history_exchange"] = history
             if fallback_note:
                 out["config"]["exchange_fallback"] = fallback_note
         out.update(extras)

@@ -564,6 +564,43 @@ __global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
     rfx_flush_violations(d);
 }
 
+// Row-tiled runs, between trace and shade: the rows of the history texture (last frame's composed GI) that the shading of THESE rays will
+// fetch — k1_shade reads it NEAREST at a ray's final uv when that uv is on screen and the ray hit (or missed rays are allowed), ssgi.frag:396-427.
+// rows[0] / rows[1] take the min / max row over the launch's pixels (preset INT_MAX / -1 by the caller); a superset is harmless, a miss is
+// not: the tests hold the bounded gather bit-identical to the whole-frame all-gather.  One wave = 64 pixels of a row: shuffle reduction,
+// one atomic pair per wave that can still move the bounds.
+__global__ __launch_bounds__(256) void k1_hit_rows(FrameDims d, int y0, int y1, TexView depth, TexViewW out, const float4 *hits, int allow_missed, int *rows) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = y0 + blockIdx.y * 4 + threadIdx.y;
+    d.viol = 0;
+    float lo = 16777216.0f, hi = -1.0f;  // rows are < 2^23: exact in fp32 (the shuffle moves floats)
+    if (x < d.W && y < y1) {
+        const float dp = ((const float *)depth.ptr)[rfx_xy_index(d, depth.row0, depth.rows, x, y)];
+        if (dp != 1.0f) {  // background fragments return before tracing (their hand-over texels are stale)
+            const size_t i = (size_t)rfx_local_row(d, out.row0, out.rows, y) * d.W + x;
+            const float4 h0 = hits[2 * i], h1 = hits[2 * i + 1];
+            const float u[2] = {h0.x, h0.z}, v[2] = {h0.y, h0.w}, px[2] = {h1.x, h1.y};
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const bool missed = px[r] == 10.0e9f;
+                if ((allow_missed || !missed) && u[r] >= 0.0f && u[r] <= 1.0f && v[r] >= 0.0f && v[r] <= 1.0f) {
+                    const float row = (float)rfx_nearest_idx(v[r], d.fH, d.H);
+                    lo = fminf(lo, row);
+                    hi = fmaxf(hi, row);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o));
+        hi = fmaxf(hi, __shfl_xor(hi, o));
+    }
+    if (threadIdx.x == 0 && hi >= 0.0f) {
+        if ((int)lo < rows[0]) atomicMin(&rows[0], (int)lo);  // (a stale read only costs a redundant atomic)
+        if ((int)hi > rows[1]) atomicMax(&rows[1], (int)hi);
+    }
+}
+
 // Pre-pass: view-space Z per texel (getViewZ, ssgi_utils.frag:9: nearMulFar / (farMinusNear * depth - cameraFar), IEEE)
 // and its (min, max) per 8x8 cell.  64x8-pixel workgroups = 8 cells; 8-lane shuffles reduce a row segment, LDS the rows.
 __global__ __launch_bounds__(64 * BASE) void k1_prepare(const float *depth, float *viewz, float2 *base, int W, int H, int base_w, float nearMulFar,
@@ -651,6 +688,12 @@ hipError_t rfx_launch_env_mip(const float4 *src, float4 *dst, int sw, int sh, in
 }
 
 int rfx_k1_base_cell() { return BASE; }
+
+hipError_t rfx_launch_k1_hit_rows(const FrameDims &d, int y0, int y1, TexView depth, TexViewW out, const float4 *hits, bool allow_missed, int *rows, hipStream_t stream) {
+    dim3 block(64, 4), grid((d.W + 63) / 64, (y1 - y0 + 3) / 4);
+    hipLaunchKernelGGL(k1_hit_rows, grid, block, 0, stream, d, y0, y1, depth, out, hits, allow_missed ? 1 : 0, rows);
+    return hipGetLastError();
+}
 
 hipError_t rfx_launch_k1_prepare(const K1Args &A, hipStream_t stream) {
     dim3 block(64, BASE), grid((A.dims.W + 63) / 64, (A.dims.H + BASE - 1) / BASE);

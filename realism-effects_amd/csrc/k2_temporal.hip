@@ -68,10 +68,15 @@ RFX_DEV float4 k2_history_tap(const TexView &tex, const FrameDims &d, float u, f
 template <bool HIST_F32, bool WHOLE>
 RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &tex, float pu, float pv) {
     float Wa[2], Wb[2], Wc[2], S0[2], S1[2], S2[2];
-    const float its[2] = {A.invW, A.invH}, P[2] = {pu, pv};
+    // The three quotients of the GLSL are the IEEE ones here: UV = P / invTexSize decides the texel (tc) and the weights (f) — at 8K one
+    // ulp of a v_rcp-based quotient is 5e-4 texel, which an age channel that differs by ~2 between neighbouring texels turns into 1e-3
+    // (measured: round 2's 8K frame-2 K2 population; the rgb channels never showed it).  invTexSize is a uniform, so the exact quotient
+    // costs three instructions with the host's RN(1 / invTexSize) (rfx_div_const_impl); w2 / (w1 + w2) and 1 / sum take the refined
+    // reciprocal (both divisors are ~1).
+    const float its[2] = {A.invW, A.invH}, rits[2] = {A.rcpInvW, A.rcpInvH}, P[2] = {pu, pv};
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const float UV = P[k] * rfx_rcp(its[k]);
+        const float UV = rfx_div_const_impl(P[k], its[k], rits[k]);
         const float tc = floorf(UV - 0.5f) + 0.5f;
         const float f = UV - tc, f2 = f * f, f3 = f2 * f;
         const float w0 = f2 - 0.5f * (f3 + f);
@@ -82,7 +87,7 @@ RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &te
         Wb[k] = w1 + w2;
         Wc[k] = w3;
         S0[k] = (tc - 1.0f) * its[k];
-        S1[k] = (tc + w2 * rfx_rcp(Wb[k])) * its[k];
+        S1[k] = (tc + rfx_div_pos(w2, Wb[k])) * its[k];  // Wb = w1 + w2 in [1, 1.125]
         S2[k] = (tc + 2.0f) * its[k];
     }
     const float sw0 = Wb[0] * Wa[1], sw1 = Wa[0] * Wb[1], sw2 = Wb[0] * Wb[1], sw3 = Wc[0] * Wb[1], sw4 = Wb[0] * Wc[1];
@@ -104,7 +109,7 @@ RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &te
     K2_TAP_FENCE(4);
     const float4 Cb = k2_history_tap<HIST_F32, WHOLE>(tex, d, S1[0], S2[1]);
 #undef K2_TAP_FENCE
-    const float wm = rfx_rcp((((sw0 + sw1) + sw2) + sw3) + sw4);
+    const float wm = rfx_rcp_rn((((sw0 + sw1) + sw2) + sw3) + sw4);  // 1. / sum, sum ~ 1
     float4 r;
     r.x = fmaxf(((((Ct.x * sw0 + Cl.x * sw1) + Cc.x * sw2) + Cr.x * sw3) + Cb.x * sw4) * wm, 0.0f);
     r.y = fmaxf(((((Ct.y * sw0 + Cl.y * sw1) + Cc.y * sw2) + Cr.y * sw3) + Cb.y * sw4) * wm, 0.0f);

@@ -80,6 +80,8 @@ void rfx_destroy(rfx_ctx *c) {
     if (c->halo_violations) hipFree(c->halo_violations);
     if (c->viewz) hipFree(c->viewz);
     if (c->hits) hipFree(c->hits);
+    if (c->hit_rows_dev) hipFree(c->hit_rows_dev);
+    if (c->hit_rows_host) hipHostFree(c->hit_rows_host);
     if (c->coarse) hipFree(c->coarse);
     if (c->cells) hipFree(c->cells);
     if (c->env) hipFree(c->env);
@@ -624,6 +626,35 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
     if (stage != 2) HIPCHK(c, rfx_launch_k1_prepare(A, c->stream));
     if (any) HIPCHK(c, rfx_launch_k1(A, stage, c->stream));
     c->hits_traced = stage == 1;
+    if (stage == 1) { c->trace_y0 = A.y0; c->trace_y1 = any ? A.y1 : A.y0; c->trace_missed = p->missedRays; }
+    return RFX_OK;
+}
+
+// between rfx_ssgi_trace and rfx_ssgi_shade (rfx_gather_history_rows): which rows of last frame's composed GI will the shade read?
+int rfx_internal_hit_rows_enqueue(rfx_ctx *c, int *rows_dev) {
+    if (!c->hits || !c->hits_traced) return fail(c, RFX_ESTATE, "rfx_gather_history_rows: no rfx_ssgi_trace of this frame is waiting for its shade");
+    hipSetDevice(c->device);
+    static const int preset[2] = {0x7fffffff, -1};
+    HIPCHK(c, hipMemcpyAsync(rows_dev, preset, sizeof preset, hipMemcpyHostToDevice, c->stream));
+    if (c->trace_y1 > c->trace_y0)
+        HIPCHK(c, rfx_launch_k1_hit_rows(dims(c), c->trace_y0, c->trace_y1, view(c, RFX_TEX_DEPTH), wview(c, RFX_TEX_SSGI), c->hits, c->trace_missed != 0, rows_dev, c->stream));
+    return RFX_OK;
+}
+
+int rfx_ssgi_hit_rows(rfx_ctx *c, int *row_lo, int *row_hi) {
+    if (!c || !row_lo || !row_hi) return RFX_EINVAL;
+    hipSetDevice(c->device);
+    if (!c->hit_rows_dev) {  // sized for any communicator this context may get later: 2 + 2 * 64 ranks
+        hipError_t e = hipMalloc((void **)&c->hit_rows_dev, sizeof(int) * 130);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&c->hit_rows_host, sizeof(int) * 128, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(c, RFX_ENOMEM, "rfx_ssgi_hit_rows: scratch", e);
+    }
+    int rc = rfx_internal_hit_rows_enqueue(c, c->hit_rows_dev);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->hit_rows_host, c->hit_rows_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *row_lo = c->hit_rows_host[0];
+    *row_hi = c->hit_rows_host[1];
     return RFX_OK;
 }
 
@@ -662,6 +693,10 @@ int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
     A.p = *p;
     // TemporalReprojectPass.js:135: invTexSize.set(1 / width, 1 / height) in doubles
     A.invW = (float)(1.0 / (double)c->W); A.invH = (float)(1.0 / (double)c->H);
+    {   // IEEE fp32 reciprocals of those two uniforms (volatile: no folding into double arithmetic)
+        volatile float iw = A.invW, ih = A.invH;
+        A.rcpInvW = 1.0f / iw; A.rcpInvH = 1.0f / ih;
+    }
     // prevProjectionMatrix * prevViewMatrix (reproject.frag:183), fp32, column by column like GLSL
     const float *Pm = p->prevCamera.projectionMatrix, *Vm = p->prevCamera.matrixWorldInverse;
     for (int col = 0; col < 4; col++)

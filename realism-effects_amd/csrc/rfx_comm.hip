@@ -18,7 +18,7 @@ namespace {
 struct NcclUniqueId { char internal[128]; };
 typedef void *NcclComm;
 typedef int NcclResult;
-constexpr int kNcclUint8 = 1;
+constexpr int kNcclUint8 = 1, kNcclInt32 = 2;
 
 struct Rccl {
     void *handle = nullptr;
@@ -247,6 +247,64 @@ int rfx_allgather_history(rfx_ctx *c, rfx_tex id, void *nccl_comm) {
         if (e) return nccl_fail(c, "rfx_allgather_history: ncclBroadcast", e);
         if (e2) return nccl_fail(c, "rfx_allgather_history: ncclGroupEnd", e2);
     }
+    return comm_end(c);
+}
+
+int rfx_gather_history_rows(rfx_ctx *c, rfx_tex id, void *nccl_comm, size_t *bytes_received) {
+    if (!c) return RFX_EINVAL;
+    if (bytes_received) *bytes_received = 0;
+    if (id != RFX_TEX_COMPOSE && id != RFX_TEX_COMPOSE_RGB) return fail(c, RFX_EINVAL, "rfx_gather_history_rows: RFX_TEX_COMPOSE or RFX_TEX_COMPOSE_RGB");
+    Rccl *r = rccl();
+    if (!r) return fail(c, RFX_EUNSUPPORTED, "rfx_gather_history_rows: RCCL cannot be loaded on this host");
+    NcclComm comm = nccl_comm ? nccl_comm : c->comm;
+    if (!comm) return fail(c, RFX_ESTATE, "rfx_gather_history_rows: no communicator (rfx_comm_init, or pass one)");
+    if (nccl_comm && !c->comm) return fail(c, RFX_ESTATE, "rfx_gather_history_rows: rank and size come from rfx_comm_init");
+    const int n = c->comm_nranks, me = c->comm_rank;
+    int rc = ensure_streams(c);
+    if (rc) return rc;
+    hipSetDevice(c->device);
+    if (n > 64) return fail(c, RFX_EUNSUPPORTED, "rfx_gather_history_rows: more than 64 ranks");
+    if (!c->hit_rows_dev) {  // (the same scratch as rfx_ssgi_hit_rows: 2 + 2 * 64 ints)
+        hipError_t e = hipMalloc((void **)&c->hit_rows_dev, sizeof(int) * 130);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&c->hit_rows_host, sizeof(int) * 128, hipHostMallocDefault);
+        if (e != hipSuccess) return fail(c, RFX_ENOMEM, "rfx_gather_history_rows: scratch", e);
+    }
+    char *base = (char *)rfx_tex_device_ptr(c, id);  // held whole: frame row y at y * pitch
+    if (!base) return RFX_ENOMEM;
+    const Slot &s = c->slots[id];
+    const size_t pitch = (size_t)s.width * s.texel;
+    // 1. this tile's needed rows (device reduction over the trace's hand-over plane), on the draw stream
+    if ((rc = rfx_internal_hit_rows_enqueue(c, c->hit_rows_dev))) return rc;
+    // 2. every rank's needed rows -> host.  The one host-side wait of the exchange: the plan below needs the numbers (2 ints per rank).
+    if ((rc = comm_begin(c))) return rc;
+    NCCLCHK(c, r->AllGather(c->hit_rows_dev, c->hit_rows_dev + 2, 2, kNcclInt32, comm, c->comm_stream));
+    HIPCHK(c, hipMemcpyAsync(c->hit_rows_host, c->hit_rows_dev + 2, sizeof(int) * (size_t)(2 * n), hipMemcpyDeviceToHost, c->comm_stream));
+    HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+    // 3. rank p needs rows [lo_p, hi_p]; whoever owns a part of them sends that part (the owner's rows of last frame's composed GI are
+    //    current: K4 wrote them).  Both ends compute the same intersection, so every Send has its Recv; empty ones are skipped on both.
+    size_t got = 0;
+    NCCLCHK(c, r->GroupStart());
+    NcclResult e = 0;
+    for (int p = 0; p < n && !e; p++) {
+        if (p == me) continue;
+        int py0 = 0, prows = 0;
+        rfx_split_rows(c->H, n, p, &py0, &prows);
+        // what p needs of MY rows
+        int a = c->hit_rows_host[2 * p] > c->tile_y0 ? c->hit_rows_host[2 * p] : c->tile_y0;
+        int b = c->hit_rows_host[2 * p + 1] + 1 < c->tile_y0 + c->tile_rows ? c->hit_rows_host[2 * p + 1] + 1 : c->tile_y0 + c->tile_rows;
+        if (b > a) e = r->Send(base + (size_t)a * pitch, (size_t)(b - a) * pitch, kNcclUint8, p, comm, c->comm_stream);
+        // what I need of p's rows
+        a = c->hit_rows_host[2 * me] > py0 ? c->hit_rows_host[2 * me] : py0;
+        b = c->hit_rows_host[2 * me + 1] + 1 < py0 + prows ? c->hit_rows_host[2 * me + 1] + 1 : py0 + prows;
+        if (b > a && !e) {
+            e = r->Recv(base + (size_t)a * pitch, (size_t)(b - a) * pitch, kNcclUint8, p, comm, c->comm_stream);
+            got += (size_t)(b - a) * pitch;
+        }
+    }
+    NcclResult e2 = r->GroupEnd();
+    if (e) return nccl_fail(c, "rfx_gather_history_rows: ncclSend/ncclRecv", e);
+    if (e2) return nccl_fail(c, "rfx_gather_history_rows: ncclGroupEnd", e2);
+    if (bytes_received) *bytes_received = got;
     return comm_end(c);
 }
 

@@ -27,6 +27,9 @@ struct rfx_ctx {
     float *viewz = nullptr;    // K1 scratch: view-space Z plane (full frame)
     float4 *hits = nullptr;    // K1 trace -> shade hand-over (rfx_ssgi_trace), 2 texels per SSGI texel
     bool hits_traced = false;  // a trace is waiting for its shade
+    int trace_y0 = 0, trace_y1 = 0, trace_missed = 0;  // the rows and the missedRays option of that trace (rfx_gather_history_rows)
+    int *hit_rows_dev = nullptr;   // device: [0..1] this tile's (min, max) needed history row, [2..2n+1] every rank's
+    int *hit_rows_host = nullptr;  // pinned mirror of the gathered part
     int win_y0 = 0, win_y1 = 0x7fffffff;  // rfx_set_row_window: rows the draws may produce
     int uv_model = RFX_UV_REFERENCE_GL;    // rfx_set_uv_model (the default: the vUv the parity oracle's GL interpolates)
     float2 *coarse = nullptr;  // K1 scratch: exact (min,max) view Z per 16x16 base cell
@@ -53,6 +56,8 @@ struct rfx_ctx {
     std::string err;
 };
 void rfx_comm_release(rfx_ctx *c);  // rfx_comm.hip: called by rfx_destroy
+// rfx_api.hip, for rfx_comm.hip: enqueue on the draw stream the reduction of the traced rays' history rows into rows_dev[0..1] (min, max)
+extern "C" int rfx_internal_hit_rows_enqueue(rfx_ctx *c, int *rows_dev);  // (internal: not part of include/rfx.h)
 
 extern thread_local std::string g_create_err;
 

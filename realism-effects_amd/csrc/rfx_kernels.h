@@ -43,7 +43,8 @@ struct K2Args {
     int in_w, in_h;                        // size of the input texture (smaller than the frame when K1 ran with resolutionScale < 1)
     TexViewW out0, out1;
     rfx_temporal_params p;
-    float invW, invH;
+    float invW, invH;        // invTexSize (TemporalReprojectPass.js:135)
+    float rcpInvW, rcpInvH;  // RN(1 / invTexSize): the constant of the exact quotient P / invTexSize (RFX_DIV_CONST's form, k2_bicubic)
     float prevPV[16];  // prevProjectionMatrix * prevViewMatrix, multiplied in fp32 like the shader does per fragment
 };
 
@@ -88,6 +89,8 @@ hipError_t rfx_launch_k5(const K5Args &, hipStream_t);
 int rfx_k1_base_cell();  // edge of k1_prepare's base cells in texels
 hipError_t rfx_launch_k1_prepare(const K1Args &, hipStream_t);
 hipError_t rfx_launch_k1(const K1Args &, int stage /* 0 fused, 1 trace, 2 shade */, hipStream_t);
+// rows[0] = min, rows[1] = max history row the shade stage of the traced rays of rows [y0, y1) will read (device ints, preset INT_MAX / -1)
+hipError_t rfx_launch_k1_hit_rows(const FrameDims &, int y0, int y1, TexView depth, TexViewW out, const float4 *hits, bool allow_missed, int *rows, hipStream_t);
 hipError_t rfx_launch_k2(const K2Args &, hipStream_t);
 hipError_t rfx_launch_k3(const K3Args &, hipStream_t);
 hipError_t rfx_launch_k4(const K4Args &, hipStream_t);

@@ -5,9 +5,10 @@
 //   after K2 and after every K3 pass : halo Send/Recv of the textures just written with the row neighbours, issued on the
 //                                      context's exchange stream; the next draw (K3 pass, K4) first produces the tile INTERIOR
 //                                      (setRowWindow), then waits, then draws the two boundary strips
-//   after K4                         : all-gather of .rgb of the composed GI (RFX_TEX_COMPOSE_RGB) — next frame's K1 gathers it
-//                                      anywhere; only its shading half reads it, so K1 runs as ssgiTrace / ssgiShade with the
-//                                      wait in between
+//   the composed GI                  : next frame's K1 gathers it anywhere on screen, but only its SHADING half reads it, so K1 runs as
+//                                      ssgiTrace / ssgiShade and between the two rfx_gather_history_rows moves exactly the rows of
+//                                      .rgb (RFX_TEX_COMPOSE_RGB) that the traced rays will read, from their owners (historyGather
+//                                      "bounded", the default); "all" = the whole-frame all-gather after K4, waited for at that point
 const addon = require("../napi/rfx_napi.node")
 const { Renderer, TEX } = require("./Renderer")
 
@@ -35,6 +36,7 @@ class TiledRenderer {
 		this._comm = options.comm || {
 			haloExchange: (tex, up, down) => addon.haloExchange(this.inner._h, tex, up, down),
 			allgatherHistory: tex => addon.allgatherHistory(this.inner._h, tex),
+			gatherHistoryRows: tex => addon.gatherHistoryRows(this.inner._h, tex),
 			commWait: () => addon.commWait(this.inner._h)
 		}
 		this.width = width
@@ -45,6 +47,11 @@ class TiledRenderer {
 		if (!options.comm) addon.commInit(this.inner._h, uniqueId, rank, nranks)
 		this.gatherHistoryRGB = nranks > 1
 		this.overlapHistoryGather = nranks > 1
+		// "bounded" (default): no all-gather after K4; between a frame's trace and its shade only the rows of the composed GI that the
+		// tiles' rays will read travel (rfx_gather_history_rows).  "all": the whole-frame all-gather, under the next frame's trace.
+		this.historyGather = nranks > 1 ? (options.historyGather || "bounded") : "all"
+		if (this.historyGather !== "bounded" && this.historyGather !== "all") throw new RangeError("historyGather: \"bounded\" or \"all\"")
+		this.historyBytesReceived = []
 		this._haloPending = false
 		this._gatherPending = false
 		this.exchangeCount = 0
@@ -82,7 +89,7 @@ class TiledRenderer {
 		this.exchange(uniforms.writeToB ? [TEX.DENOISE_B0, TEX.DENOISE_B1] : [TEX.DENOISE_A0, TEX.DENOISE_A1])
 	}
 	afterComposePass() {
-		if (this.nranks > 1) {
+		if (this.nranks > 1 && this.historyGather === "all") {
 			this._comm.allgatherHistory(TEX.COMPOSE_RGB)
 			this._gatherPending = true
 		}
@@ -91,9 +98,14 @@ class TiledRenderer {
 		this.exchange([tex])
 	}
 	beforeSsgiShade() {
+		if (this.nranks > 1 && this.historyGather === "bounded") {
+			this.historyBytesReceived.push(this._comm.gatherHistoryRows(TEX.COMPOSE_RGB))
+			this._gatherPending = true
+		}
 		this.commWait()
 	}
 	ssgiMarch(u) {
+		if (this.nranks > 1 && this.historyGather === "bounded") throw new Error("TiledRenderer (historyGather \"bounded\"): K1 must run as ssgiTrace / ssgiShade")
 		this.commWait()
 		this.inner.ssgiMarch(u)
 	}

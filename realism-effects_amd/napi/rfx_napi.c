@@ -525,6 +525,19 @@ static napi_value n_allgather_history(napi_env env, napi_callback_info info) {
     if (rc) return throw_rfx(env, c, "rfx_allgather_history", rc);
     return NULL;
 }
+/* gatherHistoryRows(ctx, tex) -> bytes this rank receives (rfx_gather_history_rows: between ssgiTrace and ssgiShade) */
+static napi_value n_gather_history_rows(napi_env env, napi_callback_info info) {
+    napi_value a[2], out;
+    int32_t tex;
+    size_t got = 0;
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[1], &tex)) return NULL;
+    int rc = rfx_gather_history_rows(c, (rfx_tex)tex, NULL, &got);
+    if (rc) return throw_rfx(env, c, "rfx_gather_history_rows", rc);
+    napi_create_double(env, (double)got, &out);
+    return out;
+}
 /* commWait(ctx) / commDestroy(ctx) */
 static napi_value n_comm_wait(napi_env env, napi_callback_info info) {
     napi_value a[1];
@@ -677,7 +690,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"sync", n_sync}, {"setRowWindow", n_set_row_window}, {"setUvModel", n_set_uv_model}, {"cubeToEquirect", n_cube_to_equirect}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
         {"stageUpload", n_stage_upload}, {"stageFlip", n_stage_flip}, {"hostAlloc", n_host_alloc},
         {"splitRows", n_split_rows}, {"commUniqueId", n_comm_unique_id}, {"commInit", n_comm_init}, {"haloExchange", n_halo_exchange},
-        {"allgatherHistory", n_allgather_history}, {"commWait", n_comm_wait}, {"commDestroy", n_comm_destroy},
+        {"allgatherHistory", n_allgather_history}, {"gatherHistoryRows", n_gather_history_rows}, {"commWait", n_comm_wait}, {"commDestroy", n_comm_destroy},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

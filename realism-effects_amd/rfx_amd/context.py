@@ -284,6 +284,19 @@ class Context:
     def allgather_history(self, tex: int):
         self._chk(self.lib.rfx_allgather_history(self._h, tex, None), "rfx_allgather_history")
 
+    def ssgi_hit_rows(self):
+        """rfx_ssgi_hit_rows: after ssgi_trace, the inclusive (lo, hi) range of history rows the shade will read (hi < lo: none)."""
+        lo, hi = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.rfx_ssgi_hit_rows(self._h, C.byref(lo), C.byref(hi)), "rfx_ssgi_hit_rows")
+        return int(lo.value), int(hi.value)
+
+    def gather_history_rows(self, tex: int) -> int:
+        """rfx_gather_history_rows (between ssgi_trace and ssgi_shade): only the rows of last frame's composed GI that some tile's rays
+        will read travel, from their owners.  Returns the bytes this rank receives."""
+        n = C.c_size_t(0)
+        self._chk(self.lib.rfx_gather_history_rows(self._h, tex, None, C.byref(n)), "rfx_gather_history_rows")
+        return int(n.value)
+
     def comm_wait(self):
         self._chk(self.lib.rfx_comm_wait(self._h), "rfx_comm_wait")
 

@@ -261,11 +261,18 @@ class CommTiledRenderer(TiledRenderer):
     far; rfx_comm_wait orders the following draws after them.  No torch, no bound external buffers: the textures stay the
     context's own.  `unique_id`: the 128 bytes of Context.comm_unique_id() made by rank 0 and handed to every rank."""
 
-    def __init__(self, ctx, rank: int, world: int, unique_id: bytes, denoise_mode: str = "full"):
+    def __init__(self, ctx, rank: int, world: int, unique_id: bytes, denoise_mode: str = "full", history_gather: str = "bounded"):
+        """history_gather "bounded" (default): the composed GI is NOT all-gathered after K4; between a frame's trace and its shade
+        rfx_gather_history_rows moves only the rows the tiles' rays will read (include/rfx.h).  "all": the whole-frame all-gather after
+        K4, overlapped with the next frame's trace.  Same pixels either way."""
+        if history_gather not in ("bounded", "all"):
+            raise ValueError("history_gather: \"bounded\" or \"all\"")
         self._dist = None
         self._setup(ctx, {t: None for t in (exchanged_textures(denoise_mode) if world > 1 else ())}, rank, world)
         ctx.comm_init(unique_id, rank, world)
         self._comm_pending = False
+        self.history_gather = history_gather if (world > 1 and self.overlap_history_gather) else "all"
+        self.history_bytes_received = []  # per frame, "bounded" mode (what "all" receives: the other tiles, every frame)
 
     def exchange(self, texs):
         if self.world == 1 or self.halo == 0:
@@ -279,11 +286,32 @@ class CommTiledRenderer(TiledRenderer):
         self._halo_pending = [True]
         self.exchange_count += 1
 
+    def _history_tex(self):
+        return abi.TEX_COMPOSE_RGB if self.gather_history_rgb else abi.TEX_COMPOSE
+
     def allgather_compose(self):
-        if self.world == 1:
-            return
-        self.inner.allgather_history(abi.TEX_COMPOSE_RGB if self.gather_history_rgb else abi.TEX_COMPOSE)
+        if self.world == 1 or self.history_gather == "bounded":
+            return  # bounded: the rows travel on demand, in before_ssgi_shade
+        self.inner.allgather_history(self._history_tex())
         self._pending = [True]
+
+    def before_ssgi_shade(self):
+        if self.world > 1 and self.history_gather == "bounded":
+            self.history_bytes_received.append(self.inner.gather_history_rows(self._history_tex()))
+            self._pending = [True]
+        self.finish_pending()
+
+    def ssgi_march(self, p):
+        if self.world > 1 and self.history_gather == "bounded":
+            raise RuntimeError("CommTiledRenderer(history_gather=\"bounded\"): K1 must run as ssgi_trace / ssgi_shade (the gather sits between them)")
+        return super().ssgi_march(p)
+
+    def gather_whole_history(self):
+        """every rank's rows of the composed GI to every rank, now (a host that wants the whole frame on one rank — bench.py's checksum)"""
+        if self.world > 1:
+            self.inner.allgather_history(self._history_tex())
+            self._pending = [True]
+            self.finish_pending()
 
     def finish_halo(self):
         if self._halo_pending or self._pending:

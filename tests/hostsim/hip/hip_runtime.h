@@ -174,6 +174,16 @@ using std::min;
 static inline int min(int a, unsigned int b) { return a < (int)b ? a : (int)b; }
 static inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned int atomicOr(unsigned int *p, unsigned int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+static inline int atomicMin(int *p, int v) {  // (idempotent: safe under the replay of a block's passes)
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+static inline int atomicMax(int *p, int v) {
+    int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 
 // ---------------------------------------------------------------- runtime API (host memory stands for device memory; streams are immediate)
 typedef int hipError_t;

@@ -17,6 +17,8 @@ MOCK = textwrap.dedent('''
     dist.init_process_group = lambda *a, **k: None
     dist.barrier = lambda *a, **k: None
     dist.destroy_process_group = lambda *a, **k: None
+    dist.all_reduce = lambda *a, **k: None
+    dist.get_backend = lambda *a, **k: "gloo"
     class FakeCtx:
         def halo_violations(self): return 0
         def close(self): pass
@@ -61,6 +63,7 @@ def test_bench_line_row_tiled_with_extras_and_watchdog():
     j = _run(["--gpus", "2", "--steps", "4", "--warmup", "1"], env)
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["tile_rows"] == 1080 and j["config"]["workload"].startswith("configs[3]")
     assert "weak_scaling" in j and "configs4_8k" in j and "cpu_baseline" not in j
+    assert j["config"]["history_exchange"]["mode"] == "all" and j["config"]["history_exchange"]["whole_frame_allgather_MB"] == round(1080 * 3840 * 12 / 1e6, 3)
     # the second extra hangs: after --extras-timeout the headline is printed with what was done, and the process leaves
     j = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--extras-timeout", "2"], dict(env, HANG_AT="3"))
     assert j["n_gpus"] == 2 and "weak_scaling" in j and "configs4_8k" not in j and "timed out" in j["extras_error"]
@@ -105,6 +108,8 @@ def test_bench_row_tiled_for_real_under_the_host_simulator(tmp_path):
         assert many["n_gpus"] == n and many["config"]["tile_rows"] in ((64,) if n == 2 else (42, 43)) and many["halo_violations"] == 0 and many["scaling"] == "strong"
         assert many["config"]["exchange_verified"] is True and "exchange_fallback" not in many["config"]  # the C-ABI exchanges passed their pre-flight check
         assert many["compose_sha1"] == one["compose_sha1"]  # the tiled run's composed frame == the single-context run's, bit for bit
+        hx = many["config"]["history_exchange"]  # the composed GI travelled through the bounded gather (rfx_gather_history_rows)
+        assert hx["mode"] == "bounded" and 0 < hx["MB_received_per_frame_max_over_ranks"] <= hx["whole_frame_allgather_MB"], hx
         if n == 2:  # the extras ran too: the weak-scaling frame and the configs[4] options (steps 40, six K3 passes), both row-tiled
             assert "extras_error" not in many, many.get("extras_error")
             assert many["weak_scaling"]["halo_violations"] == 0 and many["configs4_8k"]["halo_violations"] == 0 and many["configs4_8k"]["frame"] == "160x96"

@@ -1151,3 +1151,49 @@ def test_smoke_fallback_against_the_oracle_proves_every_flip(blue_noise):
     for r in reports:
         assert r.unexplained == 0, r.line()
         assert r.bad <= 0.002 * r.pixels + 3, r.line()
+
+
+@pytest.mark.parametrize("missed", [0, 1])
+def test_hit_rows_bound_what_the_shade_reads(blue_noise, missed):
+    """rfx_ssgi_hit_rows / rfx_gather_history_rows: after the trace, the (min, max) history row the shading of a tile's rays will fetch
+    (ssgi.frag:396-427 — NEAREST at the ray's final uv, when it is on screen and the ray hit or missed rays are allowed).  The bounded gather
+    of a row-tiled run moves only those rows, so the range must cover every fetch: the history is corrupted everywhere OUTSIDE a tile's
+    range and that tile's shade must not notice (bit-identical rows), for every tile of a 1-, 2- and 5-way split."""
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_frame
+
+    W, H = 224, 126
+    f = synthetic_frame(W, H, 1)
+    ctx = Context(W, H)
+    ctx.upload_frame(f)
+    sp, _, _, _ = _params(abi, f, f.prev_camera, 1.0, missed=missed)
+    sp.blueNoiseIndex = 4242
+    rng = np.random.RandomState(3)
+    hist = rng.rand(H, W, 4).astype(np.float32) * 3.0
+    ctx.upload(abi.TEX_COMPOSE, hist)
+    ctx.ssgi_march(sp)
+    want = ctx.download(abi.TEX_SSGI)
+    seen_partial = False
+    for tiles in ([(0, H)], [(0, 62), (62, 64)], [(0, 24), (24, 24), (48, 24), (72, 24), (96, 30)]):
+        for y0, rows in tiles:
+            ctx.set_row_window(y0, y0 + rows)
+            ctx.upload(abi.TEX_COMPOSE, hist)
+            ctx.ssgi_trace(sp)
+            lo, hi = ctx.ssgi_hit_rows()
+            assert (hi < lo) or (0 <= lo <= hi < H), (lo, hi)
+            bad = hist.copy()
+            if hi < lo:
+                bad[:] = 1e6
+            else:
+                bad[:lo] = 1e6
+                bad[hi + 1:] = np.nan
+                seen_partial |= (lo > 0 or hi < H - 1)
+            ctx.upload(abi.TEX_COMPOSE, bad)   # between trace and shade: exactly where the bounded gather delivers the rows
+            ctx.ssgi_shade(sp)
+            got = ctx.download(abi.TEX_SSGI, y0, rows)
+            assert np.array_equal(got, want[y0:y0 + rows]), "tile rows [%d, %d): the shade read a history row outside [%d, %d]" % (y0, y0 + rows, lo, hi)
+    ctx.set_row_window(0, 0)
+    assert seen_partial  # (the test would be vacuous if every range were the whole frame)
+    assert ctx.halo_violations() == 0
+    ctx.close()

@@ -308,11 +308,12 @@ const inner = {
   temporalReproject(u) { calls.push(["temporal"]) }, poissonDenoise(u) { calls.push(["denoise", u.writeToB]) },
   compose(u) { calls.push(["compose", u.writeHistoryRGB]) }, sync() { calls.push(["sync"]) }
 }
-const comm = { haloExchange(tex, up, down) { calls.push(["halo", tex, up, down]) }, allgatherHistory(tex) { calls.push(["gather", tex]) }, commWait() { calls.push(["wait"]) } }
+const comm = { haloExchange(tex, up, down) { calls.push(["halo", tex, up, down]) }, allgatherHistory(tex) { calls.push(["gather", tex]) },
+  gatherHistoryRows(tex) { calls.push(["gather_rows", tex]); return 0 }, commWait() { calls.push(["wait"]) } }
 const out = {}
-for (const rn of [[0, 3], [1, 3], [2, 3], [0, 1]]) {
+for (const rn of [[0, 3, "bounded"], [1, 3, "bounded"], [2, 3, "bounded"], [0, 1, "bounded"], [1, 3, "all"]]) {
   calls.length = 0
-  const r = new TiledRenderer(96, 66, rn[0], rn[1], 6, null, { inner, comm })
+  const r = new TiledRenderer(96, 66, rn[0], rn[1], 6, null, { inner, comm, historyGather: rn[2] })
   const e = new fx.SSGIEffect(null, { frame: {} }, cam, { width: 96, height: 66 }, { ssgi: 10, denoise: 20 })
   e.update(r, null); e.update(r, null); r.sync()
   out[rn.join("/")] = { calls: calls.slice(), tile: [r.tileY0, r.tileRows], exchanges: r.exchangeCount }
@@ -379,15 +380,19 @@ def test_node_tiled_renderer_call_sequence_equals_python(tmp_path):
         def allgather_history(self, tex):
             self.calls.append(["gather", tex])
 
+        def gather_history_rows(self, tex):
+            self.calls.append(["gather_rows", tex])
+            return 0
+
         def comm_wait(self):
             self.calls.append(["wait"])
 
         def sync(self):
             self.calls.append(["sync"])
 
-    for rank, world in ((0, 3), (1, 3), (2, 3), (0, 1)):
+    for rank, world, mode in ((0, 3, "bounded"), (1, 3, "bounded"), (2, 3, "bounded"), (0, 1, "bounded"), (1, 3, "all")):
         ctx = RecCtx(rank, world)
-        r = tiling.CommTiledRenderer(ctx, rank, world, b"\0" * 128)
+        r = tiling.CommTiledRenderer(ctx, rank, world, b"\0" * 128, history_gather=mode)
         scene = types.SimpleNamespace(frame=types.SimpleNamespace(depth=np.zeros((0, W), np.float32), gbuffer=np.zeros((0, W, 4), np.uint32),
                                                                   velocity=np.zeros((0, W, 4), np.uint32), direct=np.zeros((0, W, 4), np.float32),
                                                                   camera=f.camera, aov=None))
@@ -395,8 +400,11 @@ def test_node_tiled_renderer_call_sequence_equals_python(tmp_path):
         fx.update(r, None)
         fx.update(r, None)
         r.sync()
-        got = js["%d/%d" % (rank, world)]
+        got = js["%d/%d/%s" % (rank, world, mode)]
         assert got["tile"] == [ctx.tile_y0, ctx.tile_rows]
+        if world > 1:  # the composed GI travels either between trace and shade (bounded) or after K4 (all), never both
+            kinds = {c[0] for c in ctx.calls}
+            assert ("gather_rows" in kinds) == (mode == "bounded") and ("gather" in kinds) == (mode == "all"), kinds
         assert got["calls"] == json.loads(json.dumps(ctx.calls)), (rank, world, got["calls"][:12], ctx.calls[:12])
         assert got["exchanges"] == r.exchange_count
 

@@ -337,18 +337,20 @@ def test_tiled_kernels_are_bit_identical_to_one_context(tmp_path, world):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(os.environ.get("RFX_HOSTSIM") != "1", reason="the C ABI's exchanges between processes without RCCL: pytest --hostsim")
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_tiled_kernels_with_c_abi_exchanges_are_bit_identical_to_one_context(tmp_path, world):
+@pytest.mark.parametrize("world,mode", [(2, "bounded"), (3, "bounded"), (4, "bounded"), (3, "all"), (4, "all")])
+def test_tiled_kernels_with_c_abi_exchanges_are_bit_identical_to_one_context(tmp_path, world, mode):
     """The same tiles with the exchanges BEHIND THE C ABI (rfx_comm_init / rfx_halo_exchange / rfx_allgather_history / rfx_comm_wait), one
     process per tile (tests/comm_tile_worker.py — no torch in them: a torch process maps the real librccl.so.1, which rfx_comm.hip would
     rightly reuse).  Under --hostsim the librccl.so.1 that rfx_comm.hip binds is tests/hostsim/fakerccl.c: unix sockets between these
-    processes.  Ragged tiles at 3 ranks (the grouped-broadcast form of the gather), even ones at 2 and 4 (the in-place all-gather)."""
+    processes.  Ragged tiles at 3 ranks (the grouped-broadcast form of the gather), even ones at 2 and 4 (the in-place all-gather).
+    mode "bounded" (the default): no all-gather of the composed GI; between a frame's trace and its shade rfx_gather_history_rows moves only
+    the rows the tiles' rays will read — same pixels, fewer bytes; "all": the whole-frame all-gather after K4."""
     import subprocess
     from rfx_amd import abi
     from rfx_amd.context import Context
     from rfx_amd.scene import synthetic_frame
 
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "comm_tile_worker.py"), str(r), str(world), str(tmp_path), str(W), str(H), str(FRAMES)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "comm_tile_worker.py"), str(r), str(world), str(tmp_path), str(W), str(H), str(FRAMES), mode],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
@@ -361,4 +363,7 @@ def test_tiled_kernels_with_c_abi_exchanges_are_bit_identical_to_one_context(tmp
         for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1, abi.TEX_COMPOSE):
             assert np.array_equal(z[abi.TEX_NAMES[t]], ref.download(t, y0, rows)), "rank %d %s differs" % (rank, abi.TEX_NAMES[t])
         assert np.array_equal(z["compose_rgb_full"], ref.download(abi.TEX_COMPOSE)[..., :3]), "rank %d gathered composed GI differs" % rank
+        if mode == "bounded":  # never more than the all-gather would deliver (the other tiles' rows), and recorded once per frame
+            assert len(z["history_bytes"]) == FRAMES and (z["history_bytes"] <= (H - rows) * W * 12).all(), z["history_bytes"]
+            print("rank %d of %d receives %s bytes of composed GI per frame (all-gather: %d)" % (rank, world, list(z["history_bytes"]), (H - rows) * W * 12))
     ref.close()
