@@ -41,6 +41,7 @@ from rfx_amd.effect import SSGIEffect  # noqa: E402
 from rfx_amd.scene import synthetic_band_parallel  # noqa: E402
 
 W4K, H4K = 3840, 2160
+HISTORY_GATHER = ["all"]  # --history-gather
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 # algorithmic bytes per pixel per launch, reference texel formats (SURVEY.md §8d / DESIGN.md)
 BYTES_PER_PX = {"k1_ssgi_march": 68, "k2_temporal_reproject": 80, "k3_poisson_denoise_pass0": 68, "k3_poisson_denoise_pass1": 52, "k4_compose": 52}
@@ -183,7 +184,7 @@ def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, 
             dist.broadcast_object_list(box, src=0)
             uid = box[0]
             # the exchanges behind the C ABI: RCCL Send/Recv + all-gather on the context's own exchange stream (rfx.h "row-tiled runs")
-            renderer = tiling.CommTiledRenderer(ctx, rank, world, uid)
+            renderer = tiling.CommTiledRenderer(ctx, rank, world, uid, history_gather=HISTORY_GATHER[0])
             exchange = "C ABI: rfx_halo_exchange / rfx_allgather_history (RCCL, own stream, overlapped)"
             bad = [verify_exchange(ctx, rank, world)]
             flags = [None] * world
@@ -315,7 +316,10 @@ def main():
     ap.add_argument("--extras-timeout", type=int, default=480, help="seconds the N > 1 extras (weak scaling, configs[4]) may take before the headline line is printed without them")
     ap.add_argument("--configs4-size", default="7680x4320", help="N > 1 extras: frame of the BASELINE configs[4] case (tests shrink it)")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: only the headline case (skip the weak-scaling and configs[4] extras)")
+    ap.add_argument("--history-gather", choices=("all", "bounded"), default="all",
+                    help="N > 1: the composed GI as a whole-frame all-gather under the next frame's trace (default), or only the rows the traced rays read, between trace and shade (rfx_gather_history_rows)")
     args = ap.parse_args()
+    HISTORY_GATHER[0] = args.history_gather
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # launched plainly (the way the driver launches N = 1): become the launcher — one rank per GPU of this node under torch.distributed.run
@@ -437,7 +441,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload + ", steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step",
                        "frame": "%dx%d" % (W1, H1), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz", "uv_model": "reference_gl",
-                       "parallelism": "row-tiles x%d, RCCL halo send/recv after K2 and every K3 pass + composed GI: only the rows the traced rays read, between K1's trace and shade (rfx_gather_history_rows); exchange: %s" % (
+                       "parallelism": "row-tiles x%d, RCCL halo send/recv after K2 and every K3 pass + composed GI (see history_exchange); exchange: %s" % (
                            world, case_exchange(use_c, one_gpu, args)) if world > 1 else "single GPU"},
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
             "chain": {"algorithmic_bytes_per_px": chain_bytes, "sum_kernel_ms": round(chain_ms, 4),

@@ -6,9 +6,9 @@
 //                                      context's exchange stream; the next draw (K3 pass, K4) first produces the tile INTERIOR
 //                                      (setRowWindow), then waits, then draws the two boundary strips
 //   the composed GI                  : next frame's K1 gathers it anywhere on screen, but only its SHADING half reads it, so K1 runs as
-//                                      ssgiTrace / ssgiShade and between the two rfx_gather_history_rows moves exactly the rows of
-//                                      .rgb (RFX_TEX_COMPOSE_RGB) that the traced rays will read, from their owners (historyGather
-//                                      "bounded", the default); "all" = the whole-frame all-gather after K4, waited for at that point
+//                                      ssgiTrace / ssgiShade: historyGather "all" (default) all-gathers .rgb (RFX_TEX_COMPOSE_RGB)
+//                                      after K4 and waits between the two halves; "bounded" moves, between the two, exactly the rows
+//                                      the traced rays will read, from their owners (rfx_gather_history_rows)
 const addon = require("../napi/rfx_napi.node")
 const { Renderer, TEX } = require("./Renderer")
 
@@ -47,9 +47,10 @@ class TiledRenderer {
 		if (!options.comm) addon.commInit(this.inner._h, uniqueId, rank, nranks)
 		this.gatherHistoryRGB = nranks > 1
 		this.overlapHistoryGather = nranks > 1
-		// "bounded" (default): no all-gather after K4; between a frame's trace and its shade only the rows of the composed GI that the
-		// tiles' rays will read travel (rfx_gather_history_rows).  "all": the whole-frame all-gather, under the next frame's trace.
-		this.historyGather = nranks > 1 ? (options.historyGather || "bounded") : "all"
+		// "all" (default): the whole-frame all-gather after K4, under the next frame's trace.  "bounded": no all-gather; between a frame's
+		// trace and its shade only the rows of the composed GI that the tiles' rays will read travel (rfx_gather_history_rows) — fewer
+		// bytes (scene dependent: 67-71 % at N = 4 / 8 on the synthetic orbit at 4K), but on the critical path (rfx_amd/tiling.py).
+		this.historyGather = nranks > 1 ? (options.historyGather || "all") : "all"
 		if (this.historyGather !== "bounded" && this.historyGather !== "all") throw new RangeError("historyGather: \"bounded\" or \"all\"")
 		this.historyBytesReceived = []
 		this._haloPending = false

@@ -16,7 +16,7 @@ from rfx_amd.effect import SSGIEffect  # noqa: E402
 from rfx_amd.scene import synthetic_frame  # noqa: E402
 
 rank, world, outdir, W, H, FRAMES = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
-MODE = sys.argv[7] if len(sys.argv) > 7 else "bounded"  # CommTiledRenderer history_gather
+MODE = sys.argv[7] if len(sys.argv) > 7 else "all"  # CommTiledRenderer history_gather
 frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
 vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
 halo = tiling.required_halo(3.0, vmax, H, W)
