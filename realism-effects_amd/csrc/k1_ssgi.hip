@@ -174,7 +174,8 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
             }
         }
     }
-    if (m.refineSteps > 0) {
+    // (a wavefront none of whose rays hit — sky above the horizon, a wall facing away — has nothing to refine)
+    if (m.refineSteps > 0 && __builtin_amdgcn_ballot_w64(rays[0].hit | rays[1].hit) != 0) {
         // (a ray that did not hit takes steps of dir * 0: its position is replaced below anyway, its direction is not read again)
 #pragma unroll
         for (int r = 0; r < 2; r++) {

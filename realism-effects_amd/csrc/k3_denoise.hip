@@ -44,14 +44,18 @@ RFX_DEV float3 k3_log3(float x, float y, float z) { return make_float3(rfx_log(x
 // needs w * exp(-lumaDiff * lumaPhi) and pow(w, 0.1) — i.e. exp2(l2w + l2luma) and exp2(0.1 * l2w): two v_exp_f32 instead of
 // exp, log, exp, exp.  l2w = -inf (background tap, :60) gives 0 for both, as w = 0 does in the reference.
 constexpr float K3_LOG2E = 1.4426950408889634f;
-RFX_DEV void k3_apply(CenterTexel &c, float l2w, float3 tl, float tapLuma, float lumaPhiL2) {
-    const float disocclW = rfx_exp2(0.1f * l2w);
+// `disocclW` = pow(w, 0.1) = exp2(0.1 * l2w).  The tiled kernels form it as exp2(0.1 * l2basic) * exp2(0.1 * l2spec): the first factor is
+// shared by the pixel's textures, the second is a per-pixel constant — one v_exp_f32 per tap instead of one per tap and texture.
+RFX_DEV void k3_apply_d(CenterTexel &c, float l2w, float disocclW, float3 tl, float tapLuma, float lumaPhiL2) {
     const float lumaDiff = fminf(fabsf(c.lumaPow - tapLuma), 0.5f);
     const float wl = rfx_exp2(l2w - lumaDiff * lumaPhiL2);  // w * lumaFactor
     float w = rfx_mix(wl, disocclW, c.w) * c.w;
     w = (w < 0.0001f) ? 0.0f : w;  // w *= step(0.0001, w)
     c.rgb = c.rgb + tl * w;
     c.total += w;
+}
+RFX_DEV void k3_apply(CenterTexel &c, float l2w, float3 tl, float tapLuma, float lumaPhiL2) {
+    k3_apply_d(c, l2w, rfx_exp2(0.1f * l2w), tl, tapLuma, lumaPhiL2);
 }
 
 // dynamic LDS carve-up (all 16-byte aligned: the row pitch is a multiple of 8 texels), n = PITCH * LH texels:
@@ -149,6 +153,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
 
     CenterTexel c[TC];
     float l2spec_i[TC];      // log2 of the extra specular factor of accumulator i (0 for a diffuse texture)
+    float dspec_i[TC];       // that factor ^ 0.1: exp2(0.1 * l2spec_i) (1 for a diffuse texture)
     const float4 *g_in0[TC];  // the staged input accumulator i reads, rebased like g_geom
     const uint2 *g_inN[TC];
 #pragma unroll
@@ -156,6 +161,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         const bool isSpec = p.isTextureSpecular[i] != 0;
         const int ti = (TC == 2 && isSpec) ? 1 : 0;
         l2spec_i[i] = isSpec ? l2spec : 0.0f;
+        dspec_i[i] = isSpec ? rfx_exp2(0.1f * l2spec) : 1.0f;
         g_in0[i] = s_in0 + ti * ntex + koff;
         g_inN[i] = s_inN + ti * ntex + koff;
         float4 t;
@@ -210,11 +216,12 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         const float roughDiff = fabsf(roughness - ng.w);
         float l2basic = (-normalDiff * p.normalPhi - depthDiff * p.depthPhi - roughDiff * p.roughnessPhi) * K3_LOG2E;
         l2basic = (nd != 1.0f) ? l2basic : -__builtin_inff();
+        const float dbasic = rfx_exp2(0.1f * l2basic);  // pow(basic weight, 0.1), shared by the textures
         if constexpr (IN_TEMPORAL) {
 #pragma unroll
             for (int i = 0; i < TC; i++) {
                 const float4 tl = g_in0[i][ni];
-                k3_apply(c[i], l2basic + l2spec_i[i], make_float3(tl.x, tl.y, tl.z), tl.w, lumaPhiL2);
+                k3_apply_d(c[i], l2basic + l2spec_i[i], dbasic * dspec_i[i], make_float3(tl.x, tl.y, tl.z), tl.w, lumaPhiL2);
             }
         } else {
             const LinearCoord lx = rfx_linear_coord_fast(fx, wmh), ly = rfx_linear_coord_fast(fy, hmh);
@@ -224,7 +231,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
                 const uint2 *q = g_inN[i] + li;
                 const float3 t = rfx_bilerp_half_rgb(q[0], q[1], q[PITCH], q[PITCH + 1], lx.w, ly.w);
                 const float3 tl = k3_log3(t.x, t.y, t.z);
-                k3_apply(c[i], l2basic + l2spec_i[i], tl, k3_luma(tl), lumaPhiL2);
+                k3_apply_d(c[i], l2basic + l2spec_i[i], dbasic * dspec_i[i], tl, k3_luma(tl), lumaPhiL2);
             }
         }
     }
