@@ -3,7 +3,7 @@ offline run leaves on disk (HDR and tone-mapped images).  Pure Python + numpy + 
 
   read_hdr          Radiance RGBE (.hdr): the format of the reference example's environments (example/public/hdr/*.hdr, loaded there
                     by three's RGBELoader) -> scene.environment for rfx_set_environment
-  read_exr/write_exr  OpenEXR, scanline, compression NONE / ZIPS / ZIP, HALF / FLOAT / UINT channels, arbitrary layer.channel names —
+  read_exr/write_exr  OpenEXR, scanline, compression NONE / ZIPS / ZIP / PIZ, HALF / FLOAT / UINT channels, arbitrary layer.channel names —
                     the usual container of renderer AOVs; `exr_to_dump_planes` maps its layers onto the dump's attribute planes
   read_pfm/write_pfm  Portable Float Map (the simplest HDR interchange format)
   write_png         8-bit RGB(A) PNG
@@ -189,7 +189,340 @@ def tonemap(linear: np.ndarray, operator: str = "aces", exposure: float = 1.0) -
 # ------------------------------------------------------------------------------------------------ OpenEXR (scanline)
 _PT_UINT, _PT_HALF, _PT_FLOAT = 0, 1, 2
 _PT_DTYPE = {_PT_UINT: "<u4", _PT_HALF: "<f2", _PT_FLOAT: "<f4"}
-_COMP_NONE, _COMP_ZIPS, _COMP_ZIP = 0, 2, 3
+_COMP_NONE, _COMP_ZIPS, _COMP_ZIP, _COMP_PIZ = 0, 2, 3, 4
+
+
+# ---- PIZ (OpenEXR's default for renderer output): per 32-scanline block, the samples as 16-bit words, channel-planar; (1) a bitmap of
+# the values that occur + a lookup table onto a dense range, (2) a 2-D Haar-like wavelet per channel plane (14-bit or modulo-16-bit
+# arithmetic), (3) canonical Huffman coding of all words with a run-length escape symbol.  Restated from the published format (OpenEXR
+# "Technical Introduction" and the reference implementation's ImfPizCompressor / ImfWav / ImfHuf, named for the reader: nothing copied).
+_PIZ_BITMAP = 8192
+_HUF_ENCSIZE = (1 << 16) + 1  # 65536 word values + the run-length symbol
+_SHORT_ZERO, _LONG_ZERO = 59, 63
+_SHORTEST_LONG = 2 + _LONG_ZERO - _SHORT_ZERO  # 6
+_LONGEST_LONG = 255 + _SHORTEST_LONG
+
+
+def _wav_pairs(a, b, w14, decode):
+    """the 1-D wavelet step on two equally shaped uint16 arrays -> (l, h) when encoding, (a, b) when decoding"""
+    if w14:
+        if not decode:  # wenc14: m = (a + b) >> 1 (signed 16-bit), d = a - b
+            sa, sb = a.astype(np.int16).astype(np.int32), b.astype(np.int16).astype(np.int32)
+            return ((sa + sb) >> 1).astype(np.int16).view(np.uint16), (sa - sb).astype(np.int16).view(np.uint16)
+        ls, hi = a.astype(np.int16).astype(np.int32), b.astype(np.int16).astype(np.int32)
+        ai = ls + (hi & 1) + (hi >> 1)
+        return ai.astype(np.int16).view(np.uint16), (ai - hi).astype(np.int16).view(np.uint16)
+    a32, b32 = a.astype(np.int32), b.astype(np.int32)
+    if not decode:  # wenc16: modulo arithmetic
+        ao = (a32 + 32768) & 65535
+        m = (ao + b32) >> 1
+        d = ao - b32
+        m = np.where(d < 0, (m + 32768) & 65535, m)
+        return m.astype(np.uint16), (d & 65535).astype(np.uint16)
+    bb = (a32 - (b32 >> 1)) & 65535
+    aa = (b32 + bb - 32768) & 65535
+    return aa.astype(np.uint16), bb.astype(np.uint16)
+
+
+def _wav2(plane, mx, decode):
+    """in-place 2-D wavelet transform of one (ny, nx) uint16 plane (a view: strides carry a FLOAT channel's interleaving)"""
+    ny, nx = plane.shape
+    w14 = mx < (1 << 14)
+    n = min(nx, ny)
+    levels = []
+    p = 1
+    while 2 * p <= n:
+        levels.append(p)
+        p *= 2
+    for p in (reversed(levels) if decode else levels):
+        p2 = 2 * p
+        ys, xs = ny - ny % p2 if ny % p2 < p else ny - ny % p2, None  # (rows / columns taking part are derived below)
+        yq = np.arange(0, ny - p2 + 1, p2) if ny >= p2 else np.zeros(0, int)
+        xq = np.arange(0, nx - p2 + 1, p2) if nx >= p2 else np.zeros(0, int)
+        if yq.size and xq.size:
+            i00 = plane[np.ix_(yq, xq)]; i01 = plane[np.ix_(yq, xq + p)]; i10 = plane[np.ix_(yq + p, xq)]; i11 = plane[np.ix_(yq + p, xq + p)]
+            if not decode:
+                a, b = _wav_pairs(i00, i01, w14, False); c, d = _wav_pairs(i10, i11, w14, False)
+                o00, o10 = _wav_pairs(a, c, w14, False); o01, o11 = _wav_pairs(b, d, w14, False)
+            else:
+                a, c = _wav_pairs(i00, i10, w14, True); b, d = _wav_pairs(i01, i11, w14, True)
+                o00, o01 = _wav_pairs(a, b, w14, True); o10, o11 = _wav_pairs(c, d, w14, True)
+            plane[np.ix_(yq, xq)] = o00; plane[np.ix_(yq, xq + p)] = o01; plane[np.ix_(yq + p, xq)] = o10; plane[np.ix_(yq + p, xq + p)] = o11
+        if (nx & p) and yq.size:  # odd column: 1-D in y
+            x = xq[-1] + p2 if xq.size else 0
+            lo, hi = _wav_pairs(plane[yq, x], plane[yq + p, x], w14, decode)
+            plane[yq, x], plane[yq + p, x] = lo, hi
+        if ny & p:  # odd line: 1-D in x
+            y = yq[-1] + p2 if yq.size else 0
+            if xq.size:
+                lo, hi = _wav_pairs(plane[y, xq], plane[y, xq + p], w14, decode)
+                plane[y, xq], plane[y, xq + p] = lo, hi
+
+
+def _huf_canonical(lengths):
+    """code lengths (0 = unused) -> codes, assigned as the format prescribes: numerically ascending within a length, LONGER codes first"""
+    lengths = np.asarray(lengths, np.int64)
+    count = np.bincount(lengths, minlength=59)
+    start = np.zeros(59, np.int64)
+    c = 0
+    for i in range(58, 0, -1):
+        start[i] = c
+        c = (c + count[i]) >> 1
+    codes = np.zeros(lengths.size, np.int64)
+    for ln in np.nonzero(count[1:])[0] + 1:
+        idx = np.nonzero(lengths == ln)[0]
+        codes[idx] = start[ln] + np.arange(idx.size)
+    return codes
+
+
+class _BitWriter:
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def put(self, nbits, value):
+        self.acc = (self.acc << nbits) | int(value)
+        self.n += nbits
+        while self.n >= 8:
+            self.n -= 8
+            self.out.append((self.acc >> self.n) & 255)
+        self.acc &= (1 << self.n) - 1
+
+    def finish(self):
+        nbits = len(self.out) * 8 + self.n
+        if self.n:
+            self.out.append((self.acc << (8 - self.n)) & 255)
+            self.acc, self.n = 0, 0
+        return bytes(self.out), nbits
+
+
+def _huf_compress(words):
+    """uint16 words -> the Huffman block (20-byte header, packed code-length table, bit stream)"""
+    import heapq
+    words = np.asarray(words, np.uint16)
+    if words.size == 0:
+        return b""
+    freq = np.bincount(words, minlength=_HUF_ENCSIZE).astype(np.int64)
+    used = np.nonzero(freq)[0]
+    im, iM = int(used[0]), int(used[-1]) + 1
+    freq[iM] = 1  # the run-length symbol
+    syms = np.nonzero(freq)[0]
+    lengths = np.zeros(_HUF_ENCSIZE, np.int64)
+    if syms.size == 1:
+        lengths[syms[0]] = 1
+    else:  # plain Huffman: repeatedly join the two rarest subtrees, every symbol under a join gets one bit longer
+        heap = [(int(freq[s]), int(s), [int(s)]) for s in syms]
+        heapq.heapify(heap)
+        while len(heap) > 1:
+            fa, ka, la = heapq.heappop(heap)
+            fb, kb, lb = heapq.heappop(heap)
+            for s in la:
+                lengths[s] += 1
+            for s in lb:
+                lengths[s] += 1
+            heapq.heappush(heap, (fa + fb, min(ka, kb), la + lb))
+    if lengths.max() > 58:
+        raise ValueError("PIZ: Huffman code longer than 58 bits")
+    codes = _huf_canonical(lengths)
+    tw = _BitWriter()  # code lengths of im..iM, 6 bits each, runs of zeros collapsed
+    i = im
+    while i <= iM:
+        ln = int(lengths[i])
+        if ln == 0:
+            run = 1
+            while i < iM and run < _LONGEST_LONG and lengths[i + 1] == 0:
+                i += 1
+                run += 1
+            if run >= 2:
+                if run >= _SHORTEST_LONG:
+                    tw.put(6, _LONG_ZERO)
+                    tw.put(8, run - _SHORTEST_LONG)
+                else:
+                    tw.put(6, _SHORT_ZERO + run - 2)
+                i += 1
+                continue
+        tw.put(6, ln)
+        i += 1
+    table, _ = tw.finish()
+    bw = _BitWriter()
+    rl_len, rl_code = int(lengths[iM]), int(codes[iM])
+    w = words.astype(np.int64)
+    change = np.nonzero(np.diff(w))[0] + 1  # run starts
+    starts = np.concatenate([[0], change])
+    ends = np.concatenate([change, [w.size]])
+    for s0, e0 in zip(starts, ends):
+        sym = int(w[s0]); ln, code = int(lengths[sym]), int(codes[sym])
+        left = int(e0 - s0)
+        while left > 0:  # a run of `cs` ADDITIONAL repeats, at most 255 per escape
+            cs = min(left - 1, 255)
+            if ln + rl_len + 8 < ln * cs:
+                bw.put(ln, code); bw.put(rl_len, rl_code); bw.put(8, cs)
+            else:
+                for _ in range(cs + 1):
+                    bw.put(ln, code)
+            left -= cs + 1
+    data, nbits = bw.finish()
+    return struct.pack("<IIIII", im, iM, len(table), nbits, 0) + table + data
+
+
+def _huf_uncompress(buf, nwords):
+    """the Huffman block -> nwords uint16 words"""
+    out = np.zeros(nwords, np.uint16)
+    if nwords == 0 or len(buf) == 0:
+        return out
+    im, iM, tlen, nbits, _ = struct.unpack("<IIIII", buf[:20])
+    if im >= _HUF_ENCSIZE or iM >= _HUF_ENCSIZE:
+        raise ValueError("PIZ: corrupt Huffman header")
+    table = buf[20:20 + tlen]
+    tb = int.from_bytes(table, "big")
+    tbits = len(table) * 8
+    pos = 0
+
+    def get(n):
+        nonlocal pos
+        v = (tb >> (tbits - pos - n)) & ((1 << n) - 1)
+        pos += n
+        return v
+
+    lengths = np.zeros(_HUF_ENCSIZE, np.int64)
+    i = im
+    while i <= iM:
+        ln = get(6)
+        if ln == _LONG_ZERO:
+            i += get(8) + _SHORTEST_LONG
+        elif ln >= _SHORT_ZERO:
+            i += ln - _SHORT_ZERO + 2
+        else:
+            lengths[i] = ln
+            i += 1
+    codes = _huf_canonical(lengths)
+    # decoding table on the first 14 bits (every code of <= 14 bits fills its range), longer codes by (length, code) lookup
+    DEC = 14
+    fast_sym = np.full(1 << DEC, -1, np.int64)
+    fast_len = np.zeros(1 << DEC, np.int64)
+    long_codes = {}
+    for sym in np.nonzero(lengths)[0]:
+        ln, code = int(lengths[sym]), int(codes[sym])
+        if ln <= DEC:
+            lo = code << (DEC - ln)
+            fast_sym[lo:lo + (1 << (DEC - ln))] = sym
+            fast_len[lo:lo + (1 << (DEC - ln))] = ln
+        else:
+            long_codes[(ln, code)] = int(sym)
+    max_len = int(lengths.max())
+    data = buf[20 + tlen:20 + tlen + (nbits + 7) // 8]
+    db = int.from_bytes(data + b"\0" * 8, "big")  # (8 bytes of slack: the 14-bit window may run past the last code)
+    total = (len(data) + 8) * 8
+    fs, fl = fast_sym.tolist(), fast_len.tolist()
+    bp, n, res = 0, 0, out  # bit position, words produced
+    outl = [0] * nwords
+    mask = (1 << DEC) - 1
+    while bp < nbits and n <= nwords:
+        window = (db >> (total - bp - DEC)) & mask
+        sym = fs[window]
+        if sym >= 0:
+            bp += fl[window]
+        else:
+            ln = DEC + 1
+            while True:
+                if ln > max_len:
+                    raise ValueError("PIZ: invalid Huffman code")
+                code = (db >> (total - bp - ln)) & ((1 << ln) - 1)
+                sym = long_codes.get((ln, code), -1)
+                if sym >= 0:
+                    break
+                ln += 1
+            bp += ln
+        if sym == iM:  # run-length escape: repeat the previous word
+            cs = (db >> (total - bp - 8)) & 255
+            bp += 8
+            if n == 0 or n + cs > nwords:
+                raise ValueError("PIZ: corrupt run")
+            outl[n:n + cs] = [outl[n - 1]] * cs
+            n += cs
+        else:
+            if n >= nwords:
+                raise ValueError("PIZ: more words than the block holds")
+            outl[n] = sym
+            n += 1
+    if n != nwords:
+        raise ValueError("PIZ: %d of %d words decoded" % (n, nwords))
+    res[:] = outl
+    return res
+
+
+def _piz_channel_views(words, chans, W, rows):
+    """per channel: the (rows, W) uint16 planes of its words inside a block's channel-planar buffer (FLOAT / UINT: two interleaved planes)"""
+    views, p = [], 0
+    for _, pt in chans:
+        size = 1 if pt == _PT_HALF else 2
+        block = words[p:p + rows * W * size].reshape(rows, W * size)
+        views.append([block[:, j::size] for j in range(size)])
+        p += rows * W * size
+    return views
+
+
+def _piz_compress_block(raw, chans, W, rows):
+    """raw: the block's scanline-interleaved bytes (per line: every channel's W samples) -> PIZ bytes"""
+    lines = np.frombuffer(raw, "<u2")
+    sizes = [1 if pt == _PT_HALF else 2 for _, pt in chans]
+    per_line = W * sum(sizes)
+    words = np.empty(lines.size, np.uint16)
+    p = 0
+    for ci, size in enumerate(sizes):  # channel-planar order
+        off = W * sum(sizes[:ci])
+        words[p:p + rows * W * size] = lines.reshape(rows, per_line)[:, off:off + W * size].reshape(-1)
+        p += rows * W * size
+    bitmap = np.zeros(65536, bool)
+    bitmap[words] = True
+    bitmap[0] = False
+    lut = np.zeros(65536, np.uint16)
+    keep = bitmap.copy()
+    keep[0] = True
+    lut[keep] = np.arange(int(keep.sum()), dtype=np.uint16)
+    mx = int(keep.sum()) - 1
+    words = lut[words]
+    packed = np.packbits(bitmap.reshape(_PIZ_BITMAP, 8)[:, ::-1], axis=1).reshape(-1)  # bit i of byte i >> 3 (LSB first)
+    nz = np.nonzero(packed)[0]
+    mn, mxb = (int(nz[0]), int(nz[-1])) if nz.size else (_PIZ_BITMAP - 1, 0)
+    head = struct.pack("<HH", mn, mxb) + (packed[mn:mxb + 1].tobytes() if mn <= mxb else b"")
+    for planes in _piz_channel_views(words, chans, W, rows):
+        for pl in planes:
+            _wav2(pl, mx, False)
+    huf = _huf_compress(words)
+    return head + struct.pack("<i", len(huf)) + huf
+
+
+def _piz_uncompress_block(buf, chans, W, rows):
+    """PIZ bytes -> the block's scanline-interleaved bytes"""
+    sizes = [1 if pt == _PT_HALF else 2 for _, pt in chans]
+    nwords = rows * W * sum(sizes)
+    mn, mxb = struct.unpack("<HH", buf[:4])
+    pos = 4
+    packed = np.zeros(_PIZ_BITMAP, np.uint8)
+    if mn <= mxb:
+        packed[mn:mxb + 1] = np.frombuffer(buf, np.uint8, mxb - mn + 1, pos)
+        pos += mxb - mn + 1
+    bitmap = np.unpackbits(packed.reshape(-1, 1), axis=1)[:, ::-1].reshape(-1).astype(bool)
+    bitmap[0] = True
+    rev = np.zeros(65536, np.uint16)
+    vals = np.nonzero(bitmap)[0]
+    rev[:vals.size] = vals
+    mx = vals.size - 1
+    (hlen,) = struct.unpack("<i", buf[pos:pos + 4])
+    pos += 4
+    words = _huf_uncompress(buf[pos:pos + hlen], nwords)
+    for planes in _piz_channel_views(words, chans, W, rows):
+        for pl in planes:
+            _wav2(pl, mx, True)
+    words = rev[words]
+    per_line = W * sum(sizes)
+    lines = np.empty((rows, per_line), np.uint16)
+    p = 0
+    for ci, size in enumerate(sizes):
+        off = W * sum(sizes[:ci])
+        lines[:, off:off + W * size] = words[p:p + rows * W * size].reshape(rows, W * size)
+        p += rows * W * size
+    return lines.astype("<u2").tobytes()
 
 
 def _exr_attr(name: bytes, typ: bytes, payload: bytes) -> bytes:
@@ -198,12 +531,12 @@ def _exr_attr(name: bytes, typ: bytes, payload: bytes) -> bytes:
 
 def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = False):
     """channels: name -> (H, W) array (row 0 = bottom); e.g. {"R": .., "G": .., "B": ..} or layered AOVs {"normal.X": .., "depth.Z": ..}.
-    float32 (or half=True: binary16) samples, scanline file, compression "none" | "zips" | "zip"."""
+    float32 (or half=True: binary16) samples, scanline file, compression "none" | "zips" | "zip" | "piz"."""
     names = sorted(channels)  # the format requires alphabetical channel order
     planes = [np.asarray(channels[n]) for n in names]
     H, W = planes[0].shape
     pt = _PT_HALF if half else _PT_FLOAT
-    comp = {"none": _COMP_NONE, "zips": _COMP_ZIPS, "zip": _COMP_ZIP}[compression]
+    comp = {"none": _COMP_NONE, "zips": _COMP_ZIPS, "zip": _COMP_ZIP, "piz": _COMP_PIZ}[compression]
     chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", pt, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
     box = struct.pack("<iiii", 0, 0, W - 1, H - 1)
     header = (b"\x76\x2f\x31\x01" + struct.pack("<i", 2) +
@@ -211,14 +544,19 @@ def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = 
               _exr_attr(b"dataWindow", b"box2i", box) + _exr_attr(b"displayWindow", b"box2i", box) +
               _exr_attr(b"lineOrder", b"lineOrder", b"\0") + _exr_attr(b"pixelAspectRatio", b"float", struct.pack("<f", 1.0)) +
               _exr_attr(b"screenWindowCenter", b"v2f", struct.pack("<ff", 0.0, 0.0)) + _exr_attr(b"screenWindowWidth", b"float", struct.pack("<f", 1.0)) + b"\0")
-    per_block = {_COMP_NONE: 1, _COMP_ZIPS: 1, _COMP_ZIP: 16}[comp]
+    per_block = {_COMP_NONE: 1, _COMP_ZIPS: 1, _COMP_ZIP: 16, _COMP_PIZ: 32}[comp]
     dt = _PT_DTYPE[pt]
+    chans = [(n, pt) for n in names]
     top_down = [np.ascontiguousarray(p[::-1].astype(dt)) for p in planes]  # EXR y = 0 is the TOP row
     blocks = []
     for y0 in range(0, H, per_block):
         y1 = min(H, y0 + per_block)
         raw = b"".join(tp[y].tobytes() for y in range(y0, y1) for tp in top_down)
-        if comp != _COMP_NONE:
+        if comp == _COMP_PIZ:
+            packed = _piz_compress_block(raw, chans, W, y1 - y0)
+            if len(packed) < len(raw):
+                raw = packed
+        elif comp != _COMP_NONE:
             a = np.frombuffer(raw, np.uint8)
             re = np.concatenate([a[0::2], a[1::2]])  # reorder: even bytes, then odd bytes
             d = re.astype(np.int16)
@@ -240,8 +578,8 @@ def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = 
 
 
 def read_exr(path: str) -> dict:
-    """-> {channel name: (H, W) float32 (UINT channels: uint32)}, row 0 = bottom.  Single-part scanline files, compression NONE / ZIPS / ZIP,
-    no subsampling — what renderers write for AOV passes by default."""
+    """-> {channel name: (H, W) float32 (UINT channels: uint32)}, row 0 = bottom.  Single-part scanline files, compression NONE / ZIPS / ZIP /
+    PIZ (the format's default), no subsampling — what renderers write for AOV passes by default."""
     with open(path, "rb") as f:
         d = f.read()
     if d[:4] != b"\x76\x2f\x31\x01":
@@ -264,11 +602,11 @@ def read_exr(path: str) -> dict:
             raise ValueError("%s: subsampled channels are not supported" % path)
         chans.append((nm, pt))
     comp = attrs[b"compression"][1][0]
-    if comp not in (_COMP_NONE, _COMP_ZIPS, _COMP_ZIP):
-        raise ValueError("%s: compression %d not supported (NONE / ZIPS / ZIP are)" % (path, comp))
+    if comp not in (_COMP_NONE, _COMP_ZIPS, _COMP_ZIP, _COMP_PIZ):
+        raise ValueError("%s: compression %d not supported (NONE / ZIPS / ZIP / PIZ are)" % (path, comp))
     x0, y0, x1, y1 = struct.unpack("<iiii", attrs[b"dataWindow"][1])
     W, H = x1 - x0 + 1, y1 - y0 + 1
-    per_block = 16 if comp == _COMP_ZIP else 1
+    per_block = {_COMP_ZIP: 16, _COMP_PIZ: 32}.get(comp, 1)
     nblocks = (H + per_block - 1) // per_block
     offs = struct.unpack("<%dQ" % nblocks, d[pos:pos + 8 * nblocks])
     out = {nm: np.empty((H, W), np.uint32 if pt == _PT_UINT else np.float32) for nm, pt in chans}
@@ -277,7 +615,9 @@ def read_exr(path: str) -> dict:
         by, n = struct.unpack("<ii", d[o:o + 8])
         rows = min(per_block, y1 - by + 1)
         raw = d[o + 8:o + 8 + n]
-        if comp != _COMP_NONE and n < rows * line_bytes:
+        if comp == _COMP_PIZ and n < rows * line_bytes:
+            raw = _piz_uncompress_block(raw, chans, W, rows)
+        elif comp != _COMP_NONE and n < rows * line_bytes:
             a = np.frombuffer(zlib.decompress(raw), np.uint8).astype(np.int32)
             a = ((np.cumsum(a - 128) + 128) & 255).astype(np.uint8)  # undo the predictor: t[i] = t[i-1] + d[i] - 128, t[0] = d[0]
             half_n = (a.size + 1) // 2

@@ -96,7 +96,8 @@ def test_baseline_config_stagewise_vs_reference_glsl(blue_noise, name, W, H, ste
 def test_config0_through_the_effect_no_denoise_pass(blue_noise):
     """configs[0] end to end through SSGIEffect (denoiseIterations = 0): PoissonDenoisePass.render draws nothing, so K2's history and
     K4's inputs are the pass's never-written target B (zeros) — `/root/reference/src/denoise/pass/PoissonDenoisePass.js:135-149`,
-    `Denoiser.js:97-107`, SURVEY Appendix D-7.  Parity taps: K1 and K2 outputs and the composed GI, against the reference chain."""
+    `Denoiser.js:97-107`, SURVEY Appendix D-7.  Parity taps: K1 and K2 outputs and the composed GI, against the reference chain, with the
+    strict metric: every out-of-tolerance pixel is proven by the oracle (K1, K2) or lies within the 5x5 clamp footprint of a proven K1 flip (K2)."""
     if not _have_reference_gl():
         pytest.skip("oracle/_ref/shaders missing")
     import types
@@ -119,36 +120,59 @@ def test_config0_through_the_effect_no_denoise_pass(blue_noise):
     cam = types.SimpleNamespace(**vars(f0.camera))
     fx = SSGIEffect(None, scene, cam, dict(width=W, height=H, steps=8, refineSteps=2, denoiseIterations=0), seeds=dict(ssgi=1000, denoise=2000),
                     half_store_rtz=True)
+    from parity import out_of_tolerance
+    ora = S.OracleStages(W, H, blue_noise)
     si = 0
+    h8 = lambda o: O.half_bits_to_float(np.ascontiguousarray(o).view(np.uint16))  # noqa: E731
+    zeros16 = [np.zeros((H, W, 4), np.uint16) for _ in range(2)]
     for fi in range(2):
         f = frame_fn(fi)
         scene.frame = f
         for k, v in vars(f.camera).items():
             setattr(cam, k, v)
+        hist_prev = ctx.download(abi.TEX_COMPOSE)           # what this frame's K1 reads (zeros before the first frame)
+        t_prev = [ctx.download(t) for t in (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1)]  # K2's targets keep discarded texels
         fx.update(ctx, None)
         ref.upload_frame(f)
+        ora.frame(f)
         si = (1000 + si + 1) % S.M31
         ref.ssgi(f.camera, si)
         ref.temporal(f.camera, camera_moved=True)
         ref.denoise(f.camera, [])
         ref.compose(f.camera)
-        # frame 0 has no feedback at all (history zero, target B never written): every stage must agree within the metric except flips;
-        # frame 1 feeds K4's output back into K1, so K1 flips of frame 0 cannot reach it either (B stays zero -> compose = emissive only)
+        # frame 0 has no feedback at all (history zero, target B never written); frame 1 feeds K4's output back into K1 — the composed GI
+        # is emissive-only here (B stays zero) and is asserted equal below, so the two chains' K1 inputs are the same in both frames.
+        # K1: every out-of-tolerance pixel PROVEN unstable by the oracle, re-evaluated with the effect's own uniforms of this frame
         I = ctx.download(abi.TEX_SSGI)
         R = np.ascontiguousarray(ref.t_ssgi.read().view(np.uint32))
-        h8 = lambda o: O.half_bits_to_float(np.ascontiguousarray(o).view(np.uint16))  # noqa: E731
-        r = strict("f%d effect K1" % fi, h8(I), h8(R), half=True)
+        sp = fx.ssgiPass.uniforms
+        k1_bad = out_of_tolerance(h8(I), h8(R), True)
+        r = strict("f%d effect K1" % fi, h8(I), h8(R), explainable=S.prove_flips(lambda: ora.ssgi(hist_prev, sp), h8, k1_bad, True), half=True)
         print(r.line())
-        assert r.bad <= 3e-4 * r.pixels + 2, r.line()
+        assert r.unexplained == 0 and r.bad <= 5e-4 * r.pixels + 2, r.line()
         assert (O.half_bits_to_float(ctx.download(abi.TEX_DENOISE_B0)) == 0).all()  # never written
         rc = strict("f%d effect K4" % fi, ctx.download(abi.TEX_COMPOSE), ref.t_compose.read(), half=False)
         print(rc.line())
         assert rc.bad == 0 and rc.linf_abs <= 1e-3, rc.line()
-        for j, tex in enumerate((abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1)):
-            rt = strict("f%d effect K2 tex%d" % (fi, j), ctx.download(tex), ref.t_temporal[j].read(), half=False)
-            print(rt.line())
-            # K2 consumes K1's output: a K1 flip moves the pixel itself and is spread by the 5x5 neighbourhood clamp
-            assert rt.bad <= 25 * 3e-4 * rt.pixels + 50, rt.line()
+        # K2 consumes K1's output: a flipped K1 texel moves its own pixel and every pixel whose 5x5 neighbourhood clamp (reproject.frag:53-95)
+        # contains it.  So an out-of-tolerance K2 pixel is explained by a K1 flip within +-2 texels, or else must be proven unstable by the
+        # oracle on the implementation's own K1 output
+        near_flip = np.zeros((H, W), bool)
+        ys, xs = np.nonzero(k1_bad)
+        for y, x in zip(ys, xs):
+            near_flip[max(0, y - 2):y + 3, max(0, x - 2):x + 3] = True
+        tp = fx.denoiser.temporalReprojectPass.uniforms
+        got = [ctx.download(t) for t in (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1)]
+        want = [np.ascontiguousarray(t.read()) for t in ref.t_temporal]
+        k2_bad = np.zeros((H, W), bool)
+        for g, w in zip(got, want):
+            k2_bad |= out_of_tolerance(g, w, False)
+        proven = S.prove_flips(lambda: ora.temporal(I, zeros16, t_prev, tp), lambda outs: np.concatenate(list(outs), -1), k2_bad & ~near_flip, False)
+        for j in range(2):
+            rt = strict("f%d effect K2 tex%d" % (fi, j), got[j], want[j], explainable=near_flip | proven, half=False)
+            print(rt.line() + "  (%d of them within 2 texels of a K1 flip)" % int((out_of_tolerance(got[j], want[j], False) & near_flip).sum()))
+            assert rt.unexplained == 0, rt.line()
+            assert rt.bad <= 25 * 5e-4 * rt.pixels + 50, rt.line()
     assert ctx.halo_violations() == 0
     ctx.close()
 

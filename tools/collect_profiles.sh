@@ -17,7 +17,7 @@ json.dump({"profile": os.path.basename(sys.argv[1]), "git_commit": commit, "coll
            "command": "tools/collect_profiles.sh (bench.py at 3840x2160, steps 20/5, denoiseIterations 1; rocprofv3 --kernel-trace --stats; one --pmc set per pass)"},
           open(os.path.join(sys.argv[1], "meta.json"), "w"))
 PY
-$ROOT/tools/microbench/bin/valu_rates > $OUT/valu_rates.txt 2>&1
+$ROOT/tools/microbench/bin/valu_rates2 > $OUT/valu_rates2.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
 # 1. the bench line itself (un-profiled, with the CPU baselines)
