@@ -309,6 +309,7 @@ def main():
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K, help="frame rows (N = 1) / rows of the 4K frame that is cut into N tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream-copy", action="store_true", help="skip the device-to-device copy measurement (profiling passes: only the path's own kernels)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame the CPU port baseline processes (0 = auto)")
     ap.add_argument("--cpu-port", action="store_true", help="also time the C restatement (OpenMP) as a second, non-GL CPU line (+10 s)")
     ap.add_argument("--checksum", action="store_true", help="add sha1 of the final whole-frame composed GI to the JSON line (tiled == single check)")
@@ -417,7 +418,7 @@ def main():
                    "whole_frame_allgather_MB": round((H1 - min(n for _, n in tiles)) * W1 * 12 / 1e6, 3)}
     kms = kernel_times(case, max(5, min(args.steps, 20)))
     rows, halo = case["rows"], case["halo"]
-    copy_gbs = stream_copy_gbs(dev) if rank == 0 else None  # measured here, after the timed region
+    copy_gbs = stream_copy_gbs(dev) if (rank == 0 and not args.no_stream_copy) else None  # measured here, after the timed region
 
     extras = {}
 

@@ -79,6 +79,9 @@ void rfx_destroy(rfx_ctx *c) {
     if (c->ev_frame_done) hipEventDestroy(c->ev_frame_done);
     if (c->halo_violations) hipFree(c->halo_violations);
     if (c->viewz) hipFree(c->viewz);
+    if (c->prep_stream) { hipStreamSynchronize(c->prep_stream); hipStreamDestroy(c->prep_stream); }
+    for (hipEvent_t e : {c->ev_depth, c->ev_k1_done, c->ev_prep_done})
+        if (e) hipEventDestroy(e);
     if (c->hits) hipFree(c->hits);
     if (c->hit_rows_dev) hipFree(c->hit_rows_dev);
     if (c->hit_rows_host) hipHostFree(c->hit_rows_host);
@@ -167,6 +170,7 @@ int rfx_upload(rfx_ctx *c, rfx_tex id, const void *host, int row0, int rows) {
     HIPCHK(c, hipMemcpyAsync((char *)s.ptr + (size_t)(row0 - s.row0) * pitch, host, (size_t)rows * pitch, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // the caller may free `host` as soon as we return
     s.uploaded = true;
+    if (id == RFX_TEX_DEPTH) c->depth_event_set = false;  // complete: nothing for the depth pre-pass to wait for
     return RFX_OK;
 }
 
@@ -243,6 +247,10 @@ int rfx_stage_flip(rfx_ctx *c) {
     for (int id = 0; id < RFX_TEX_COUNT; id++) {
         Slot &s = c->slots[id];
         if (!s.back_filled) continue;
+        if (id == RFX_TEX_DEPTH && c->ev_depth) {  // the depth pre-pass of the next K1 waits for this copy on its own stream
+            HIPCHK(c, hipEventRecord(c->ev_depth, c->upload_stream));
+            c->depth_event_set = true;
+        }
         void *t = s.ptr; s.ptr = s.back; s.back = t;
         s.back_filled = false;
         s.uploaded = true;
@@ -257,6 +265,10 @@ int rfx_clear(rfx_ctx *c, rfx_tex id) {
     hipSetDevice(c->device);
     Slot &s = c->slots[id];
     HIPCHK(c, hipMemsetAsync(s.ptr, 0, (size_t)s.rows * s.width * s.texel, c->stream));
+    if (id == RFX_TEX_DEPTH && c->ev_depth) {
+        HIPCHK(c, hipEventRecord(c->ev_depth, c->stream));
+        c->depth_event_set = true;
+    }
     return RFX_OK;
 }
 
@@ -277,6 +289,7 @@ int rfx_bind_external(rfx_ctx *c, rfx_tex id, void *device_ptr) {
     s.ptr = device_ptr;
     s.owned = false;
     s.uploaded = true;
+    if (id == RFX_TEX_DEPTH) c->depth_external = true;  // written by whoever owns the buffer, ordered against the draw stream only
     return RFX_OK;
 }
 
@@ -622,9 +635,32 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
         }
         A.hits = c->hits;
     }
-    // the pre-pass runs on EVERY draw: the depth plane is an input that changes every frame (the shade stage reuses the trace's)
-    if (stage != 2) HIPCHK(c, rfx_launch_k1_prepare(A, c->stream));
+    // the pre-pass runs on EVERY draw: the depth plane is an input that changes every frame (the shade stage reuses the trace's).
+    // On its own stream (rfx_ctx.h prep_stream) unless the depth plane lives in a caller's buffer: after the depth plane's last writer and
+    // after the previous K1 launch (which read the scratch planes), NOT after the draws queued since — it overlaps them.
+    if (stage != 2) {
+        if (!c->prep_stream && !c->depth_external) {
+            hipError_t e = hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_depth, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k1_done, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_prep_done, hipEventDisableTiming);
+            if (e != hipSuccess) return fail(c, RFX_EDEVICE, "K1 pre-pass stream", e);
+        }
+        if (c->depth_external) {
+            HIPCHK(c, rfx_launch_k1_prepare(A, c->stream));
+        } else {
+            if (c->depth_event_set) HIPCHK(c, hipStreamWaitEvent(c->prep_stream, c->ev_depth, 0));
+            if (c->k1_event_set) HIPCHK(c, hipStreamWaitEvent(c->prep_stream, c->ev_k1_done, 0));
+            HIPCHK(c, rfx_launch_k1_prepare(A, c->prep_stream));
+            HIPCHK(c, hipEventRecord(c->ev_prep_done, c->prep_stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_prep_done, 0));
+        }
+    }
     if (any) HIPCHK(c, rfx_launch_k1(A, stage, c->stream));
+    if (c->ev_k1_done) {  // the next pre-pass overwrites what this launch reads
+        HIPCHK(c, hipEventRecord(c->ev_k1_done, c->stream));
+        c->k1_event_set = true;
+    }
     c->hits_traced = stage == 1;
     if (stage == 1) { c->trace_y0 = A.y0; c->trace_y1 = any ? A.y1 : A.y0; c->trace_missed = p->missedRays; }
     return RFX_OK;

@@ -30,6 +30,12 @@ struct rfx_ctx {
     int trace_y0 = 0, trace_y1 = 0, trace_missed = 0;  // the rows and the missedRays option of that trace (rfx_gather_history_rows)
     int *hit_rows_dev = nullptr;   // device: [0..1] this tile's (min, max) needed history row, [2..2n+1] every rank's
     int *hit_rows_host = nullptr;  // pinned mirror of the gathered part
+    // K1's depth pre-pass (view-Z plane + (min, max) cells) depends on the frame's depth plane only: it runs on its own stream, after
+    // the PREVIOUS frame's K1 (the last reader of the scratch it overwrites) and under that frame's K2 / K3 / K4, which are still queued
+    // or executing when the host issues the next frame.  ev_depth: the depth slot's last asynchronous writer (rfx_stage_flip / rfx_clear).
+    hipStream_t prep_stream = nullptr;
+    hipEvent_t ev_depth = nullptr, ev_k1_done = nullptr, ev_prep_done = nullptr;
+    bool depth_event_set = false, k1_event_set = false, depth_external = false;
     int win_y0 = 0, win_y1 = 0x7fffffff;  // rfx_set_row_window: rows the draws may produce
     int uv_model = RFX_UV_REFERENCE_GL;    // rfx_set_uv_model (the default: the vUv the parity oracle's GL interpolates)
     float2 *coarse = nullptr;  // K1 scratch: exact (min,max) view Z per 16x16 base cell

@@ -19,7 +19,7 @@ json.dump({"profile": os.path.basename(sys.argv[1]), "git_commit": commit, "coll
 PY
 $ROOT/tools/microbench/bin/valu_rates2 > $OUT/valu_rates2.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-stream-copy"
 # 1. the bench line itself (un-profiled, with the CPU baselines)
 python $ROOT/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 # 2. kernel trace + stats
@@ -31,7 +31,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAI
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS_F32" "TCC_HIT_sum TCC_MISS_sum" "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc$i -o p --output-format csv -- $BENCH > $OUT/pmc$i.log 2>&1 || echo "pmc set $i failed: $set" >> $OUT/errors.txt
+  timeout ${PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc$i -o p --output-format csv -- $BENCH > $OUT/pmc$i.log 2>&1 || echo "pmc set $i failed: $set" >> $OUT/errors.txt
 done
 python - "$OUT" <<'PY'
 import csv, collections, glob, sys
