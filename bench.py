@@ -336,7 +336,8 @@ def main():
 
     import torch
     from rfx_amd import abi as _abi
-    if hasattr(_abi.load_library(), "rfx_hostsim_build"):  # the library is tests/hostsim (the kernel sources on the CPU, injected by the tests): no device to select or drain
+    # (only an INJECTED library is looked at this early: the in-tree one loads with the first context, after torch has initialised the device)
+    if _abi.injected_library_path() and hasattr(_abi.load_library(), "rfx_hostsim_build"):  # tests/hostsim (the kernel sources on the CPU): no device to select or drain
         torch.cuda.set_device = torch.cuda.synchronize = lambda *a, **k: None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -27,6 +27,10 @@ namespace {
 // cells (1 MiB) 0.789 ms, half cells 0.749, 16-texel 0.727, 32/64-texel 0.694-0.712; a per-workgroup LDS copy of the table
 // measured 0.700 — no better than the cached global lookup, so there is none.
 constexpr int BASE = 16;  // edge of the pre-pass's exact (float) cells, reduced to the final cells by k1_pack_cells
+#ifndef RFX_K1_TH
+#define RFX_K1_TH 4  // build knob: rows of 64 pixels per workgroup of the march kernel
+#endif
+constexpr int K1_TH = RFX_K1_TH;
 typedef uint32_t k1_cell_t;
 RFX_DEV uint32_t k1_half_toward(float v, bool up) {  // nearest half not below (up) / not above (!up) v
     uint32_t h = rfx_f2h_rne(v) & 0xffffu;
@@ -398,7 +402,7 @@ RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat
 template <int PROJ, bool ENV, bool MIS, int STAGE>
 RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = A.y0 + blockIdx.y * 4 + threadIdx.y;
+    const int y = A.y0 + blockIdx.y * K1_TH + threadIdx.y;
     if (x >= A.out_w || y >= A.y1) return;
     const rfx_ssgi_params &p = A.p;
     const float *C = p.camera.matrixWorld, *Vw = p.camera.matrixWorldInverse;
@@ -558,7 +562,7 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
 }
 
 template <int PROJ, bool ENV, bool MIS, int STAGE>
-__global__ __launch_bounds__(256) void k1_ssgi_march(K1Args A) {
+__global__ __launch_bounds__(64 * K1_TH) void k1_ssgi_march(K1Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
     k1_ssgi_march_body<PROJ, ENV, MIS, STAGE>(A, d);
@@ -709,8 +713,8 @@ hipError_t rfx_launch_k1_prepare(const K1Args &A, hipStream_t stream) {
 }
 
 hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
-    const int nbx = (A.out_w + 63) / 64, nby = (A.y1 - A.y0 + 3) / 4;
-    dim3 block(64, 4), grid(nbx, nby);  // dispatched x-fastest: tiles in launch order, as a 1-D grid would
+    const int nbx = (A.out_w + 63) / 64, nby = (A.y1 - A.y0 + K1_TH - 1) / K1_TH;
+    dim3 block(64, K1_TH), grid(nbx, nby);  // dispatched x-fastest: tiles in launch order, as a 1-D grid would
     const float *P = A.p.camera.projectionMatrix;
     const bool persp = P[1] == 0.f && P[2] == 0.f && P[3] == 0.f && P[4] == 0.f && P[6] == 0.f && P[7] == 0.f && P[12] == 0.f && P[13] == 0.f &&
                        P[15] == 0.f && P[11] == -1.f;

@@ -17,7 +17,10 @@ namespace {
 #ifndef RFX_K2_XCD_G
 #define RFX_K2_XCD_G 0  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major.  Measured at 4K: 0: 0.445 ms, 2: 0.450, 4: 0.461, 8: 0.489, 16: 0.500, 32: 0.517
 #endif
-constexpr int TW = 64, TH = 4, AP = 2;    // tile, apron (neighbourhood radius <= 2)
+#ifndef RFX_K2_TH
+#define RFX_K2_TH 4  // build knob: tile rows (4 waves per workgroup; 8 halves the apron's share of the staging)
+#endif
+constexpr int TW = 64, TH = RFX_K2_TH, AP = 2;    // tile, apron (neighbourhood radius <= 2)
 constexpr int LW = TW + 2 * AP, LH = TH + 2 * AP;  // 68 x 8 staged texels
 constexpr int NT = TW * TH;
 

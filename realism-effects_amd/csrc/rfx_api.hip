@@ -646,7 +646,10 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
             if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_prep_done, hipEventDisableTiming);
             if (e != hipSuccess) return fail(c, RFX_EDEVICE, "K1 pre-pass stream", e);
         }
-        if (c->depth_external) {
+#ifndef RFX_K1_PREP_STREAM
+#define RFX_K1_PREP_STREAM 1  // build knob: 0 = the pre-pass in the draw stream (A/B measurements)
+#endif
+        if (c->depth_external || !RFX_K1_PREP_STREAM) {
             HIPCHK(c, rfx_launch_k1_prepare(A, c->stream));
         } else {
             if (c->depth_event_set) HIPCHK(c, hipStreamWaitEvent(c->prep_stream, c->ev_depth, 0));

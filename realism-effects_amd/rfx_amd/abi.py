@@ -110,6 +110,11 @@ def set_library_path(path: str | None) -> None:
     _lib, _lib_path = None, (os.path.abspath(path) if path else None)
 
 
+def injected_library_path() -> str | None:
+    """the path set_library_path() installed, or None when the in-tree library is in use"""
+    return _lib_path
+
+
 def load_library(path: str | None = None) -> C.CDLL:
     """dlopen librfx_hip.so and declare prototypes.  Raises if it is missing (no fallback)."""
     global _lib

@@ -61,6 +61,20 @@ for name, fn, bpp in stages:
     print("%-12s %8.3f ms  %8.1f Mpix/s  algorithmic %6.1f GB/s (%.1f%% of 8 TB/s)" % (name, ms, W * H / ms / 1e3, gbs, gbs / 80), flush=True)
     if not name.startswith("K4") and not name.startswith("K1t") and not name.startswith("K1s"): tot += ms
 print("K1+K2+2xK3: %.3f ms  -> %.1f Mpix/s; 268 B/px -> %.1f GB/s (%.1f%% of 8 TB/s)" % (tot, W * H / tot / 1e3, 268 * W * H / tot / 1e6, 268 * W * H / tot / 1e6 / 80))
+# the whole frame back to back, as a host issues it (launch gaps and the pre-pass overlap included): hipEvents around `iters` frames
+if not only:
+    def frame():
+        ctx.ssgi_march(sp); ctx.temporal_reproject(tp); d0(); d1(); ctx.compose(cp)
+    for _ in range(3):
+        frame()
+    ctx.sync()
+    best = 1e9
+    for _rep in range(3):
+        ctx.time_begin()
+        for _ in range(iters):
+            frame()
+        best = min(best, ctx.time_end() / iters)
+    print("frame (K1+K2+2xK3+K4 back to back): %.4f ms  -> %.1f Mpix/s" % (best, W * H / best / 1e3), flush=True)
 print("halo violations", ctx.halo_violations())
 if only.startswith("K1") or not only:  # variants of the exact kernel must not change a single texel
     import hashlib
