@@ -48,7 +48,7 @@ BYTES_PER_PX = {"k1_ssgi_march": 68, "k2_temporal_reproject": 80, "k3_poisson_de
 
 
 # rocprofv3 kernel-name fragments of bench.py's kernel keys (profiles/*/pmc_hbm.csv)
-PMC_KERNEL = {"k1_ssgi_march": "k1_ssgi_march", "k2_temporal_reproject": "k2_temporal_reproject", "k3_poisson_denoise_pass0": "k3_tiled<true",
+PMC_KERNEL = {"k1_ssgi_march": "false, 0>(K1Args)", "k2_temporal_reproject": "k2_temporal_reproject", "k3_poisson_denoise_pass0": "k3_tiled<true",
               "k3_poisson_denoise_pass1": "k3_tiled<false", "k4_compose": "k4_compose"}
 
 
@@ -304,8 +304,8 @@ def kernel_times(case, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)   # 100 frames = 0.16 s of device time: the fixed costs of the timed region's
+    ap.add_argument("--warmup", type=int, default=10)   # barriers and the clock ramp after the idle set-up phase amortise to < 0.5 %
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K, help="frame rows (N = 1) / rows of the 4K frame that is cut into N tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")

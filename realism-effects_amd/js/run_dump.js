@@ -35,7 +35,12 @@ if (opt.ranks > 1 && opt.rank === undefined) {
 	const cp = require("child_process")
 	const os = require("os")
 	fs.mkdirSync(out, { recursive: true })
-	const idFile = path.join(fs.mkdtempSync(path.join(os.tmpdir(), "rfx-")), "nccl_id")
+	const idDir = fs.mkdtempSync(path.join(os.tmpdir(), "rfx-"))
+	const idFile = path.join(idDir, "nccl_id")
+	const cleanup = () => {
+		try { fs.unlinkSync(idFile) } catch (e) { /* never written */ }
+		try { fs.rmdirSync(idDir) } catch (e) { /* not empty: leave it */ }
+	}
 	const kids = []
 	for (let r = 0; r < opt.ranks; r++)
 		kids.push(cp.spawn(process.execPath, [__filename].concat(args, ["--rank", String(r), "--idFile", JSON.stringify(idFile)]), { stdio: ["ignore", "pipe", "inherit"] }))
@@ -44,12 +49,15 @@ if (opt.ranks > 1 && opt.rank === undefined) {
 	kids.forEach((k, r) => {
 		k.stdout.on("data", d => (lines[r] += d))
 		k.on("exit", code => {
-			if (code !== 0) failed = true
-			if (--left) return
-			if (failed) {
-				console.error("a rank failed")
-				process.exit(1)
+			if (code !== 0 && !failed) {
+				// a rank that dies before the communicator exists leaves the others waiting for it (ncclCommInitRank, the id file): stop them now
+				failed = true
+				console.error("rank " + r + " exited with code " + code + ": stopping the other ranks")
+				kids.forEach((q, i) => { if (i !== r && q.exitCode === null) q.kill() })
 			}
+			if (--left) return
+			cleanup()
+			if (failed) process.exit(1)
 			// stitch the row tiles (rank order = ascending rows)
 			for (const name of ["final", "compose", "denoise_b0", "denoise_b1", "temporal0", "ssgi"]) {
 				const parts = kids.map((_, q) => fs.readFileSync(path.join(out, name + ".rank" + q + ".bin")))

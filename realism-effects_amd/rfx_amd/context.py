@@ -41,8 +41,7 @@ class Context:
         if getattr(self, "_h", None):
             self.lib.rfx_destroy(self._h)
             self._h = None
-            for p in self.__dict__.pop("_pinned", []):
-                self.lib.rfx_host_free(p)
+            self.__dict__.pop("_staged_keepalive", None)
 
     def __del__(self):
         try:
@@ -90,13 +89,16 @@ class Context:
 
     # -- streaming dumps (rfx.h "streaming dumps"): the next frame's planes cross PCIe while the current frame is drawn
     def host_alloc(self, shape, dtype) -> np.ndarray:
-        """A pinned (hipHostMalloc) numpy array: what makes rfx_stage_upload asynchronous.  Freed with the context."""
+        """A pinned (hipHostMalloc) numpy array: what makes rfx_stage_upload asynchronous.  The memory lives as long as the array (or any
+        view of it) does: it is freed by a finalizer of the buffer object the array is built on, not with the context."""
+        import weakref
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         p = self.lib.rfx_host_alloc(n)
         if not p:
             raise RfxError("rfx_host_alloc(%d bytes) failed" % n)
-        self.__dict__.setdefault("_pinned", []).append(p)
-        return np.frombuffer((C.c_char * n).from_address(p), dtype=dtype).reshape(shape)
+        buf = (C.c_char * n).from_address(p)
+        weakref.finalize(buf, self.lib.rfx_host_free, p)  # numpy keeps `buf` alive as the base of every view
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def stage_upload(self, tex: int, array: np.ndarray, row0: int | None = None, rows: int | None = None):
         """Asynchronous upload of rows [row0, row0+rows) into the slot's BACK buffer; published by stage_flip()."""
@@ -107,7 +109,7 @@ class Context:
         a = array if array.flags["C_CONTIGUOUS"] else np.ascontiguousarray(array)
         if a.nbytes != rows * self.W * ch * np.dtype(dtype).itemsize:
             raise ValueError("texture %s: %d bytes do not cover %d rows" % (abi.TEX_NAMES[tex], a.nbytes, rows))
-        self.__dict__.setdefault("_staged_keepalive", []).append(a)
+        self.__dict__.setdefault("_staged_now", []).append(a)  # kept alive until the copies of this batch have executed
         self._chk(self.lib.rfx_stage_upload(self._h, tex, a.ctypes.data_as(C.c_void_p), row0, rows), "rfx_stage_upload")
 
     def stage_frame(self, frame):
@@ -118,8 +120,10 @@ class Context:
 
     def stage_flip(self):
         self._chk(self.lib.rfx_stage_flip(self._h), "rfx_stage_flip")
-        keep = self.__dict__.get("_staged_keepalive", [])
-        self.__dict__["_staged_keepalive"] = keep[-8:]  # the planes of the two frames that can still be in flight
+        # rfx_stage_flip returns when the copies published by the PREVIOUS flip have executed: keep this batch's planes and the one before
+        gens = self.__dict__.setdefault("_staged_keepalive", [])
+        gens.append(self.__dict__.pop("_staged_now", []))
+        del gens[:-2]
 
     def clear(self, tex: int):
         self._chk(self.lib.rfx_clear(self._h, tex), "rfx_clear")

@@ -14,24 +14,27 @@ try:
 except Exception:
     commit = "unknown"
 json.dump({"profile": os.path.basename(sys.argv[1]), "git_commit": commit, "collected": time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime()),
-           "command": "tools/collect_profiles.sh (bench.py at 3840x2160, steps 20/5, denoiseIterations 1; rocprofv3 --kernel-trace --stats; one --pmc set per pass)"},
+           "command": "tools/collect_profiles.sh (3840x2160, steps 20/5, denoiseIterations 1; rocprofv3 --kernel-trace --stats of bench.py; one --pmc set per pass over tools/quick_time.py: the same kernels and arguments without torch in the process)"},
           open(os.path.join(sys.argv[1], "meta.json"), "w"))
 PY
 $ROOT/tools/microbench/bin/valu_rates2 > $OUT/valu_rates2.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-stream-copy"
 # 1. the bench line itself (un-profiled, with the CPU baselines)
-python $ROOT/bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 # 2. kernel trace + stats
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- $BENCH > $OUT/trace.log 2>&1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
-# 3. counters, one set per pass (never combined with other trace domains)
+# 3. counters, one set per pass (never combined with other trace domains).  Target: tools/quick_time.py — the same kernels with the same
+#    arguments on the same 4K frame through the C ABI, WITHOUT torch in the process: bench.py under `--pmc` stops answering on this pool
+#    since round 3 (two calls timed out; the kernel trace above is fine), a process that only maps librfx_hip.so does not.
+PMC_TARGET="python $ROOT/tools/quick_time.py 3840 2160 3"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS_F32" "TCC_HIT_sum TCC_MISS_sum" "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
-  timeout ${PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc$i -o p --output-format csv -- $BENCH > $OUT/pmc$i.log 2>&1 || echo "pmc set $i failed: $set" >> $OUT/errors.txt
+  timeout ${PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc$i -o p --output-format csv -- $PMC_TARGET > $OUT/pmc$i.log 2>&1 || echo "pmc set $i failed: $set" >> $OUT/errors.txt
 done
 python - "$OUT" <<'PY'
 import csv, collections, glob, sys
