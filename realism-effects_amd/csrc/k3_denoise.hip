@@ -68,7 +68,8 @@ RFX_DEV void k3_apply(CenterTexel &c, float l2w, float3 tl, float tapLuma, float
 // what the copy gives) — one LDS address per footprint, its four texels at compile-time offsets (two ds_read2_b64).
 // PITCH is a template parameter for that reason: LW = 64 + 2 Rx rounded up to 72 / 80 / 96 texels (Rx <= 4 / 8 / 16).
 
-template <bool IN_TEMPORAL, int TC, int PITCH>
+// WHOLE: every view is the whole frame (a context that owns no row tile): rows need no rebasing and no halo accounting
+template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE>
 RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     extern __shared__ float4 lds[];
     const int Rx = A.tile.Rx, Ry = A.tile.Ry, LW = A.tile.LW, LH = A.tile.LH;
@@ -97,14 +98,14 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         // row-tiled context does not hold them)
         if (uy > A.y1 - 1 + Ry) continue;
         const int gx = min(max(tx0 - Rx + lx, 0), d.W - 1), gy = min(max(uy, 0), d.H - 1);
-        const uint4 g = rfx_gather<uint4>(gbp, (unsigned int)(__mul24(rfx_local_row(d, A.gbuffer.row0, A.gbuffer.rows, gy), d.W) + gx));
+        const uint4 g = rfx_gather<uint4>(gbp, (unsigned int)(__mul24(rfx_view_row<WHOLE>(d, A.gbuffer, gy), d.W) + gx));
         const float3 n = rfx_unpack_normal(g.y);
         s_geom[li] = make_float4(n.x, n.y, n.z, rfx_decode_roughness(g.z));
-        s_depth[li] = rfx_gather<float>(depthp, (unsigned int)(__mul24(rfx_local_row(d, A.depth.row0, A.depth.rows, gy), d.W) + gx));
+        s_depth[li] = rfx_gather<float>(depthp, (unsigned int)(__mul24(rfx_view_row<WHOLE>(d, A.depth, gy), d.W) + gx));
 #pragma unroll
         for (int t = 0; t < TC; t++) {
             const TexView &src = t ? A.in1 : A.in0;
-            const unsigned int idx = (unsigned int)(__mul24(rfx_local_row(d, src.row0, src.rows, gy), d.W) + gx);
+            const unsigned int idx = (unsigned int)(__mul24(rfx_view_row<WHOLE>(d, src, gy), d.W) + gx);
             if constexpr (IN_TEMPORAL) {
                 const float4 v = rfx_gather<float4>(src.ptr, idx);
                 const float3 l = k3_log3(v.x, v.y, v.z);
@@ -167,7 +168,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         float4 t;
         if constexpr (IN_TEMPORAL) {
             const TexView &src = ti ? A.in1 : A.in0;
-            t = rfx_gather<float4>(src.ptr, (unsigned int)(__mul24(rfx_local_row(d, src.row0, src.rows, y), d.W) + x));
+            t = rfx_gather<float4>(src.ptr, (unsigned int)(__mul24(rfx_view_row<WHOLE>(d, src, y), d.W) + x));
         } else {  // the sampler's bilinear fetch at the pixel's own vUv
             float fx, fy;
             {
@@ -236,7 +237,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         }
     }
 
-    const size_t oi = (size_t)(unsigned int)(__mul24(rfx_local_row(d, A.out0.row0, A.out0.rows, y), d.W) + x);
+    const size_t oi = (size_t)(unsigned int)(__mul24(WHOLE ? y : rfx_local_row(d, A.out0.row0, A.out0.rows, y), d.W) + x);
 #pragma unroll
     for (int i = 0; i < TC; i++) {  // outputTexel :94-100
         const float inv = rfx_rcp(c[i].total);
@@ -337,11 +338,11 @@ RFX_DEV void k3_generic_body(const K3Args &A, const FrameDims &d) {
     }
 }
 
-template <bool IN_TEMPORAL, int TC, int PITCH>
+template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE>
 __global__ __launch_bounds__(NT) void k3_tiled(K3Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-    k3_tiled_body<IN_TEMPORAL, TC, PITCH>(A, d);
+    k3_tiled_body<IN_TEMPORAL, TC, PITCH, WHOLE>(A, d);
     rfx_flush_violations(d);
 }
 template <bool IN_TEMPORAL, int TC>
@@ -379,25 +380,31 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream) {
     const size_t lds = (size_t)pitch * A.tile.LH * (16 + 4 + 2 * (temporal ? 16 : 8));
     // two workgroups per CU (160 KiB LDS) keep the staging of one tile under the arithmetic of another
     const bool tiled = A.p.radius >= 0.0f && pitch != 0 && lds <= 80 * 1024;
+    // every view the whole frame (a context that owns no row tile): the kernels skip row rebasing and halo accounting
+    const auto whole_view = [&](const void *ptr, int row0, int rows) { return ptr == nullptr || (row0 == 0 && rows == A.dims.H); };
+    const bool whole = whole_view(A.depth.ptr, A.depth.row0, A.depth.rows) && whole_view(A.gbuffer.ptr, A.gbuffer.row0, A.gbuffer.rows) &&
+                       whole_view(A.in0.ptr, A.in0.row0, A.in0.rows) && whole_view(A.in1.ptr, A.in1.row0, A.in1.rows) &&
+                       whole_view(A.out0.ptr, A.out0.row0, A.out0.rows) && whole_view(A.out1.ptr, A.out1.row0, A.out1.rows);
     if (tiled) {
         dim3 block(TW, TH), grid(rfx_xcd_grid(RFX_K3_XCD_G, (A.dims.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH));
         // the attribute is per device (a process may hold contexts on several): remembered per device ordinal
-#define K3_TILED(T, C, P)                                                                                                    \
+#define K3_TILED(T, C, P, WH)                                                                                                \
     do {                                                                                                                     \
         static bool attr_set[64] = {false};                                                                                  \
         int dev = 0;                                                                                                         \
         hipGetDevice(&dev);                                                                                                  \
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                                        \
-            hipFuncSetAttribute((const void *)k3_tiled<T, C, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);     \
+            hipFuncSetAttribute((const void *)k3_tiled<T, C, P, WH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
             if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                                  \
         }                                                                                                                    \
-        hipLaunchKernelGGL((k3_tiled<T, C, P>), grid, block, lds, stream, A);                                                \
+        hipLaunchKernelGGL((k3_tiled<T, C, P, WH>), grid, block, lds, stream, A);                                            \
     } while (0)
+#define K3_TILED_W(T, C, P) do { if (whole) K3_TILED(T, C, P, true); else K3_TILED(T, C, P, false); } while (0)
 #define K3_TILED_P(T, C)                    \
     do {                                    \
-        if (pitch == 72) K3_TILED(T, C, 72); \
-        else if (pitch == 80) K3_TILED(T, C, 80); \
-        else K3_TILED(T, C, 96);            \
+        if (pitch == 72) K3_TILED_W(T, C, 72); \
+        else if (pitch == 80) K3_TILED_W(T, C, 80); \
+        else K3_TILED_W(T, C, 96);          \
     } while (0)
         if (A.p.textureCount == 2) {
             if (temporal) K3_TILED_P(true, 2);
@@ -407,6 +414,7 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream) {
             else K3_TILED_P(false, 1);
         }
 #undef K3_TILED_P
+#undef K3_TILED_W
 #undef K3_TILED
     } else {
         dim3 block(64, 4), grid((A.dims.W + 63) / 64, (A.y1 - A.y0 + 3) / 4);

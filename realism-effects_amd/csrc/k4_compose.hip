@@ -7,6 +7,7 @@
 
 namespace {
 
+template <bool WHOLE>  // WHOLE: the GI views are the whole frame (no row rebasing / halo accounting in the bilinear fetches)
 RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = A.y0 + blockIdx.y * 4 + threadIdx.y;
@@ -48,10 +49,10 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
             sgi = ((const float4 *)A.gi0.ptr)[gi];
         }
     } else if (A.p.inputType == 0) {
-        dgi = rfx_fetch_h4_linear(A.gi0, d, u, v);
-        sgi = rfx_fetch_h4_linear(A.gi1, d, u, v);
+        dgi = rfx_fetch_h4_linear_fused<WHOLE>(A.gi0, d, u, v);  // the sampler's fused lerps on the half texels (rfx_device.h), as in K2 / K3
+        sgi = rfx_fetch_h4_linear_fused<WHOLE>(A.gi1, d, u, v);
     } else {
-        sgi = rfx_fetch_h4_linear(A.gi0, d, u, v);
+        sgi = rfx_fetch_h4_linear_fused<WHOLE>(A.gi0, d, u, v);
     }
 
     // constructGlobalIllumination
@@ -90,10 +91,11 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
     }
 }
 
+template <bool WHOLE>
 __global__ __launch_bounds__(256) void k4_compose(K4Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-    k4_compose_body(A, d);
+    k4_compose_body<WHOLE>(A, d);
     rfx_flush_violations(d);
 }
 
@@ -151,6 +153,8 @@ hipError_t rfx_launch_k5(const K5Args &A, hipStream_t stream) {
 
 hipError_t rfx_launch_k4(const K4Args &A, hipStream_t stream) {
     dim3 block(64, 4), grid((A.dims.W + 63) / 64, (A.y1 - A.y0 + 3) / 4);
-    hipLaunchKernelGGL(k4_compose, grid, block, 0, stream, A);
+    const auto whole_view = [&](const void *ptr, int row0, int rows) { return ptr == nullptr || (row0 == 0 && rows == A.dims.H); };
+    if (whole_view(A.gi0.ptr, A.gi0.row0, A.gi0.rows) && whole_view(A.gi1.ptr, A.gi1.row0, A.gi1.rows)) hipLaunchKernelGGL(k4_compose<true>, grid, block, 0, stream, A);
+    else hipLaunchKernelGGL(k4_compose<false>, grid, block, 0, stream, A);
     return hipGetLastError();
 }
