@@ -82,7 +82,11 @@ int nccl_fail(rfx_ctx *c, const char *what, NcclResult rc) {
         if (rc__ != 0) return nccl_fail(c, #call, rc__);   \
     } while (0)
 
-// the exchange stream starts after everything enqueued on the draw stream so far
+// the exchange stream starts after everything enqueued on the draw stream so far.
+// ONE ev_draws / ev_comm pair per context serves every exchange: each call re-records both.  That is correct because the exchange stream is
+// in-order — an exchange enqueued later also runs later, so waiting for the LAST recorded ev_comm (rfx_comm_wait) covers every exchange
+// issued before it, and a re-recorded ev_draws only ever moves the exchange stream's starting point forward.  (A host that wanted to wait for
+// an EARLIER exchange while a later one is still in flight would need one event per exchange; the protocols here never do.)
 int comm_begin(rfx_ctx *c) {
     hipSetDevice(c->device);
     hipError_t e = hipEventRecord(c->ev_draws, c->stream);

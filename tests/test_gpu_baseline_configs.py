@@ -97,7 +97,8 @@ def test_config0_through_the_effect_no_denoise_pass(blue_noise):
     """configs[0] end to end through SSGIEffect (denoiseIterations = 0): PoissonDenoisePass.render draws nothing, so K2's history and
     K4's inputs are the pass's never-written target B (zeros) — `/root/reference/src/denoise/pass/PoissonDenoisePass.js:135-149`,
     `Denoiser.js:97-107`, SURVEY Appendix D-7.  Parity taps: K1 and K2 outputs and the composed GI, against the reference chain, with the
-    strict metric: every out-of-tolerance pixel is proven by the oracle (K1, K2) or lies within the 5x5 clamp footprint of a proven K1 flip (K2)."""
+    strict metric: every out-of-tolerance pixel is proven by the oracle (K1, K2), or (K2) sits where the two chains' K1 outputs differ
+    within the clamp footprint AND the implementation's K2 agrees with the oracle run on the implementation's own K1 output."""
     if not _have_reference_gl():
         pytest.skip("oracle/_ref/shaders missing")
     import types
@@ -122,6 +123,13 @@ def test_config0_through_the_effect_no_denoise_pass(blue_noise):
                     half_store_rtz=True)
     from parity import out_of_tolerance
     ora = S.OracleStages(W, H, blue_noise)
+    # the uniforms AS DRAWN (the drivers change some right after the draw, e.g. keepData: TemporalReprojectPass.js:195)
+    drawn = {}
+    for name in ("ssgi_march", "temporal_reproject"):
+        def capture(p, _orig=getattr(ctx, name), _name=name):
+            drawn[_name] = type(p).from_buffer_copy(bytes(p))
+            return _orig(p)
+        setattr(ctx, name, capture)
     si = 0
     h8 = lambda o: O.half_bits_to_float(np.ascontiguousarray(o).view(np.uint16))  # noqa: E731
     zeros16 = [np.zeros((H, W, 4), np.uint16) for _ in range(2)]
@@ -145,7 +153,7 @@ def test_config0_through_the_effect_no_denoise_pass(blue_noise):
         # K1: every out-of-tolerance pixel PROVEN unstable by the oracle, re-evaluated with the effect's own uniforms of this frame
         I = ctx.download(abi.TEX_SSGI)
         R = np.ascontiguousarray(ref.t_ssgi.read().view(np.uint32))
-        sp = fx.ssgiPass.uniforms
+        sp = drawn["ssgi_march"]
         k1_bad = out_of_tolerance(h8(I), h8(R), True)
         r = strict("f%d effect K1" % fi, h8(I), h8(R), explainable=S.prove_flips(lambda: ora.ssgi(hist_prev, sp), h8, k1_bad, True), half=True)
         print(r.line())
@@ -154,23 +162,37 @@ def test_config0_through_the_effect_no_denoise_pass(blue_noise):
         rc = strict("f%d effect K4" % fi, ctx.download(abi.TEX_COMPOSE), ref.t_compose.read(), half=False)
         print(rc.line())
         assert rc.bad == 0 and rc.linf_abs <= 1e-3, rc.line()
-        # K2 consumes K1's output: a flipped K1 texel moves its own pixel and every pixel whose 5x5 neighbourhood clamp (reproject.frag:53-95)
-        # contains it.  So an out-of-tolerance K2 pixel is explained by a K1 flip within +-2 texels, or else must be proven unstable by the
-        # oracle on the implementation's own K1 output
-        near_flip = np.zeros((H, W), bool)
-        ys, xs = np.nonzero(k1_bad)
+        # K2 consumes K1's output — the implementation's here, the reference's there.  Wherever the two K1 outputs differ AT ALL within the
+        # 5x5 footprint of K2's neighbourhood clamp (reproject.frag:53-95; K1's packed texels are > 99.9 % bit-identical, the rest differ by a
+        # flip or by a half-ulp, which K2's own thresholds — rayLength < 0.01, roughness < 0.25 — can amplify), K2 legitimately differs: such
+        # a pixel is explained when the implementation's K2 is RIGHT FOR ITS OWN INPUT, i.e. agrees with the oracle evaluated on the
+        # implementation's K1 output.  Every other out-of-tolerance pixel must be proven unstable by the oracle (perturbed primitives).
+        k1_diff = (I != R).any(axis=-1)
+        near_diff = np.zeros((H, W), bool)
+        ys, xs = np.nonzero(k1_diff)
         for y, x in zip(ys, xs):
-            near_flip[max(0, y - 2):y + 3, max(0, x - 2):x + 3] = True
-        tp = fx.denoiser.temporalReprojectPass.uniforms
+            near_diff[max(0, y - 2):y + 3, max(0, x - 2):x + 3] = True
+        tp = drawn["temporal_reproject"]
         got = [ctx.download(t) for t in (abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1)]
         want = [np.ascontiguousarray(t.read()) for t in ref.t_temporal]
         k2_bad = np.zeros((H, W), bool)
         for g, w in zip(got, want):
             k2_bad |= out_of_tolerance(g, w, False)
-        proven = S.prove_flips(lambda: ora.temporal(I, zeros16, t_prev, tp), lambda outs: np.concatenate(list(outs), -1), k2_bad & ~near_flip, False)
+        right_for_own_input = np.zeros((H, W), bool)
+        cand = k2_bad & near_diff
+        print("    K1 texels that differ at all: %d; K2 out-of-tolerance: %d, of them inside the footprint of a K1 difference: %d" % (int(k1_diff.sum()), int(k2_bad.sum()), int(cand.sum())))
+        if cand.any():
+            with O.pixel_mask(cand):
+                own = ora.temporal(I, zeros16, t_prev, tp)
+            ok = np.ones((H, W), bool)
+            for g, o in zip(got, own):
+                ok &= ~out_of_tolerance(g, o, False)
+            right_for_own_input = cand & ok
+        proven = S.prove_flips(lambda: ora.temporal(I, zeros16, t_prev, tp), lambda outs: np.concatenate(list(outs), -1), k2_bad & ~right_for_own_input, False)
         for j in range(2):
-            rt = strict("f%d effect K2 tex%d" % (fi, j), got[j], want[j], explainable=near_flip | proven, half=False)
-            print(rt.line() + "  (%d of them within 2 texels of a K1 flip)" % int((out_of_tolerance(got[j], want[j], False) & near_flip).sum()))
+            rt = strict("f%d effect K2 tex%d" % (fi, j), got[j], want[j], explainable=right_for_own_input | proven, half=False)
+            print(rt.line() + "  (%d of them: K1 inputs differ within the clamp footprint and the oracle on the implementation's input agrees)" % int(
+                (out_of_tolerance(got[j], want[j], False) & right_for_own_input).sum()))
             assert rt.unexplained == 0, rt.line()
             assert rt.bad <= 25 * 5e-4 * rt.pixels + 50, rt.line()
     assert ctx.halo_violations() == 0

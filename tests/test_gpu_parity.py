@@ -764,6 +764,15 @@ def test_comm_entry_points_on_a_single_rank_ring(blue_noise):
                 ctx.halo_exchange(abi.TEX_DENOISE_B0, -1, -1)
                 ctx.allgather_history(abi.TEX_COMPOSE)
                 ctx.comm_wait()
+                # ... and the bounded form on the real RCCL: trace, the device reduction of the needed history rows, the all-gather of the
+                # (one) pair with its host-side wait, no row transfers on a ring of one, then the shade — the frame's K1 output again
+                sp = fx.ssgiPass.uniforms
+                ctx.ssgi_trace(sp)
+                lo, hi = ctx.ssgi_hit_rows()
+                assert hi < lo or 0 <= lo <= hi < H
+                assert ctx.gather_history_rows(abi.TEX_COMPOSE) == 0
+                ctx.comm_wait()
+                ctx.ssgi_shade(sp)
         outs.append((ctx.download(abi.TEX_COMPOSE), ctx.download(abi.TEX_DENOISE_B1)))
         if tiled:
             with pytest.raises(RfxError):
