@@ -6,16 +6,16 @@
 // (RFX_HIP_LIB), it is orders of magnitude slower than the device, and the hardware transcendentals are replaced by libm (so it says nothing about the
 // device's bits — only about the program's structure).
 //
-// Execution model: hipLaunchKernelGGL runs the blocks of a grid on OpenMP threads; inside a block the threads run one after the other.
-// Synchronisation points — __syncthreads() and the wave shuffles — are honoured by REPLAY: pass p runs every thread of the block from the
-// top until it reaches its p-th synchronisation point and stops there (longjmp); a thread passing an earlier shuffle takes its partner's
-// value as recorded when that partner stopped at the same point.  Correct for kernels whose threads all meet the same sequence of points
-// and whose side effects before a point are idempotent (K2 / K3: stage a tile, barrier, compute; k1_prepare: 8 shuffles + a barrier) —
-// which is every kernel of this library.
+// Execution model: hipLaunchKernelGGL runs the blocks of a grid on OpenMP threads; inside a block every thread is a FIBER with its own stack
+// (hostsim.cpp: a cooperative scheduler, one context switch = six pushes and a stack-pointer swap).  A fiber runs until it reaches a
+// synchronisation point — __syncthreads(), a wave shuffle, __ballot — and yields; a wave operation completes when every lane of the
+// wavefront (64 consecutive linear thread ids) is blocked or finished (lanes that are not AT the operation do not take part: the
+// device's exec mask), a barrier when every unfinished thread of the block waits at it.  That is the device's semantics for any valid
+// kernel — no idempotence requirement on what a thread did before a point (the round-1..3 simulator REPLAYED threads from the top and
+// needed one), so LDS may be re-used across phases and counters may be bumped with atomics.
 #pragma once
 #include <algorithm>
 #include <cmath>
-#include <csetjmp>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -52,29 +52,36 @@ static inline uint4 make_uint4(unsigned int x, unsigned int y, unsigned int z, u
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 static inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char z, unsigned char w) { return uchar4{x, y, z, w}; }
 
-// ---------------------------------------------------------------- execution state
+// ---------------------------------------------------------------- execution state (hostsim.cpp)
 struct hostsim_idx { unsigned int x, y, z; };
 extern thread_local hostsim_idx threadIdx, blockIdx, blockDim, gridDim;
-extern thread_local int hostsim_phase;          // the synchronisation point this pass stops at
-extern thread_local int hostsim_sync_count;     // points the running thread has reached in this pass
-extern thread_local std::jmp_buf hostsim_barrier;
 extern thread_local unsigned char *hostsim_lds;  // dynamic shared memory of the running block
-extern thread_local float *hostsim_shfl;         // [point][thread of the block]: the value a thread offered at a shuffle
-extern thread_local unsigned int hostsim_nthreads;
-enum { HOSTSIM_MAX_SYNC = 64 };
 static inline unsigned int hostsim_tid() { return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); }
-static inline void __syncthreads() {
-    if (hostsim_sync_count++ == hostsim_phase) std::longjmp(hostsim_barrier, 1);
+enum { HOSTSIM_BALLOT = 1, HOSTSIM_SHFL_XOR = 2, HOSTSIM_READFIRST = 3, HOSTSIM_SHFL = 4 };
+void hostsim_barrier_wait();                                                         // the running fiber waits for its block
+unsigned long long hostsim_wave_exchange(int kind, unsigned long long payload, int arg);  // ... for its wavefront; returns the lane's result
+void hostsim_run_block(unsigned int nthreads, unsigned int bx, unsigned int by, void (*call)(void *), void *ctx);
+static inline void __syncthreads() { hostsim_barrier_wait(); }
+static inline float __shfl_xor(float v, int lane_mask) {  // wave64: the partner is lane ^ mask of the same wavefront (own value if it does not take part)
+    unsigned int u;
+    std::memcpy(&u, &v, 4);
+    u = (unsigned int)hostsim_wave_exchange(HOSTSIM_SHFL_XOR, u, lane_mask);
+    std::memcpy(&v, &u, 4);
+    return v;
 }
-static inline float __shfl_xor(float v, int lane_mask) {  // wave64: the partner is lane ^ mask of the same wavefront
-    const int c = hostsim_sync_count++;
-    const unsigned int tid = hostsim_tid();
-    if (c == hostsim_phase) {
-        hostsim_shfl[(size_t)c * hostsim_nthreads + tid] = v;
-        std::longjmp(hostsim_barrier, 1);
-    }
-    const unsigned int partner = (tid & ~63u) | ((tid ^ (unsigned int)lane_mask) & 63u);
-    return partner < hostsim_nthreads ? hostsim_shfl[(size_t)c * hostsim_nthreads + partner] : v;
+static inline int __shfl_xor(int v, int lane_mask) { return (int)(unsigned int)hostsim_wave_exchange(HOSTSIM_SHFL_XOR, (unsigned int)v, lane_mask); }
+static inline int __shfl(int v, int src_lane) { return (int)(unsigned int)hostsim_wave_exchange(HOSTSIM_SHFL, (unsigned int)v, src_lane & 63); }
+// HIP's __ballot: the TRUE wave-wide ballot (bit i = lane i's predicate; lanes that are not here contribute 0)
+static inline unsigned long long __ballot(int p) { return hostsim_wave_exchange(HOSTSIM_BALLOT, p != 0, 0); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+// v_mbcnt_lo/hi: bits of `mask` below the calling lane (+ base)
+static inline unsigned int __builtin_amdgcn_mbcnt_lo(unsigned int mask, unsigned int base) {
+    const unsigned int lane = hostsim_tid() & 63u;
+    return base + (unsigned int)__builtin_popcount(lane >= 32 ? mask : (mask & ((1u << lane) - 1u)));
+}
+static inline unsigned int __builtin_amdgcn_mbcnt_hi(unsigned int mask, unsigned int base) {
+    const unsigned int lane = hostsim_tid() & 63u;
+    return base + (lane > 32 ? (unsigned int)__builtin_popcount(mask & ((1u << (lane - 32)) - 1u)) : 0u);
 }
 template <class F>
 static void hostsim_launch(dim3 grid, dim3 block, size_t shmem, F body) {
@@ -88,25 +95,8 @@ static void hostsim_launch(dim3 grid, dim3 block, size_t shmem, F body) {
         gridDim = {grid.x, grid.y, grid.z};
         blockDim = {block.x, block.y, block.z};
         blockIdx = {(unsigned int)(b % grid.x), (unsigned int)((b / grid.x) % grid.y), (unsigned int)(b / ((long)grid.x * grid.y))};
-        static thread_local float *shfl = nullptr;
-        static thread_local size_t shfl_size = 0;
-        const size_t nthreads = (size_t)block.x * block.y * block.z, need = nthreads * HOSTSIM_MAX_SYNC;
-        if (need > shfl_size) { std::free(shfl); shfl = (float *)std::malloc(need * sizeof(float)); shfl_size = need; }
-        hostsim_shfl = shfl;
-        hostsim_nthreads = (unsigned int)nthreads;
-        for (int phase = 0; phase < HOSTSIM_MAX_SYNC; phase++) {
-            hostsim_phase = phase;
-            volatile bool stopped = false;
-            for (unsigned int tz = 0; tz < block.z; tz++)
-                for (unsigned int ty = 0; ty < block.y; ty++)
-                    for (unsigned int tx = 0; tx < block.x; tx++) {
-                        threadIdx = {tx, ty, tz};
-                        hostsim_sync_count = 0;
-                        if (setjmp(hostsim_barrier) == 0) body();
-                        else stopped = true;
-                    }
-            if (!stopped) break;  // every thread ran to the end: this pass was the whole kernel
-        }
+        F *bp = &body;
+        hostsim_run_block(block.x * block.y * block.z, block.x, block.y, [](void *c) { (*(F *)c)(); }, (void *)bp);
     }
 }
 // the kernel name may arrive parenthesised (`(k3_tiled<T, C>)`: a template-id with a comma) or bare: strip one pair of parentheses if present
