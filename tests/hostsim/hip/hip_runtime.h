@@ -73,6 +73,7 @@ static inline int __shfl_xor(int v, int lane_mask) { return (int)(unsigned int)h
 static inline int __shfl(int v, int src_lane) { return (int)(unsigned int)hostsim_wave_exchange(HOSTSIM_SHFL, (unsigned int)v, src_lane & 63); }
 // HIP's __ballot: the TRUE wave-wide ballot (bit i = lane i's predicate; lanes that are not here contribute 0)
 static inline unsigned long long __ballot(int p) { return hostsim_wave_exchange(HOSTSIM_BALLOT, p != 0, 0); }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(unsigned int)hostsim_wave_exchange(HOSTSIM_READFIRST, (unsigned int)v, 0); }  // the first lane that is here
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 // v_mbcnt_lo/hi: bits of `mask` below the calling lane (+ base)
 static inline unsigned int __builtin_amdgcn_mbcnt_lo(unsigned int mask, unsigned int base) {
