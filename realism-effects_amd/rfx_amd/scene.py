@@ -453,6 +453,13 @@ def _render_band(args):
     return f.depth, f.gbuffer, f.velocity, f.direct, f.camera, f.prev_camera
 
 
+def _pool_worker_init():
+    # a tool preloaded into the parent (rocprofv3 --pmc) leaves its SIGTERM handler in the forked workers: Pool.terminate() then waits
+    # forever for a profiler finalisation in processes that never touched the device (round 3: bench.py "hung" under --pmc right here)
+    import signal
+    signal.signal(signal.SIGTERM, signal.SIG_DFL)
+
+
 def synthetic_band_parallel(width: int, height: int, frame_index: int, row0: int, rows: int, seed: int = 1234, workers: int | None = None) -> Frame:
     """Rows [row0, row0 + rows) of frame `frame_index` of a width x height frame, ray-cast by a pool of processes (one slice each) —
     the same texels as AnalyticScene.render(..., row0, rows, frame_height=height) in a fraction of the wall time on a many-core host
@@ -465,8 +472,17 @@ def synthetic_band_parallel(width: int, height: int, frame_index: int, row0: int
         return AnalyticScene(seed).render(width, rows, frame_index, row0=row0, rows=rows, frame_height=height)
     edges = [row0 + rows * i // workers for i in range(workers + 1)]
     jobs = [(seed, width, height, frame_index, edges[i], edges[i + 1] - edges[i]) for i in range(workers) if edges[i + 1] > edges[i]]
-    with mp.get_context("fork").Pool(len(jobs)) as pool:
+    # close() + join(): the workers leave through os._exit after their last task.  Pool.__exit__ would terminate() them with SIGTERM, and a
+    # profiler preloaded into the parent (rocprofv3 --pmc) keeps ITS handler for that signal in the forked workers (it also wraps
+    # sigaction, so the initializer's reset is best effort): the workers then "finalise" a profiler session forever and join() never returns.
+    pool = mp.get_context("fork").Pool(len(jobs), initializer=_pool_worker_init)
+    try:
         parts = pool.map(_render_band, jobs)
+        pool.close()
+        pool.join()
+    except BaseException:
+        pool.terminate()
+        raise
     cat = lambda k: np.ascontiguousarray(np.concatenate([p[k] for p in parts], axis=0))  # noqa: E731
     return Frame(width, rows, cat(0), cat(1), cat(2), cat(3), parts[0][4], parts[0][5], frame_index)
 

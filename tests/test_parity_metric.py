@@ -33,6 +33,27 @@ def test_parallel_dump_equals_serial():
         assert (getattr(a, k) == getattr(b, k)).all(), k
 
 
+def test_parallel_dump_workers_leave_without_sigterm(tmp_path, monkeypatch):
+    """A profiler preloaded into the parent (rocprofv3 --pmc) keeps its SIGTERM handler in the pool's forked workers; Pool.terminate()
+    then waits for a profiler finalisation forever — bench.py "hung" under --pmc exactly there in round 3.  The pool therefore closes and
+    joins: no worker may ever receive SIGTERM (here: a handler inherited across the fork that leaves a mark)."""
+    import os
+    import signal
+    import rfx_amd.scene as scene
+    mark = str(tmp_path / "sigterm")
+
+    def leave_mark(signum, frame):
+        open(mark + ".%d" % os.getpid(), "w").close()
+        os._exit(0)
+    monkeypatch.setattr(scene, "_pool_worker_init", lambda: None)  # (the initializer's reset would hide the signal)
+    old = signal.signal(signal.SIGTERM, leave_mark)
+    try:
+        scene.synthetic_frame_parallel(96, 64, 0, workers=4)
+    finally:
+        signal.signal(signal.SIGTERM, old)
+    assert not [n for n in os.listdir(str(tmp_path)) if n.startswith("sigterm")]
+
+
 def test_oracle_margins_and_perturbation(blue_noise):
     """Unperturbed runs are reproducible; a perturbed run moves only a small unstable population; rim samples of the GGX VNDF sampler
     (blueNoise.r == 1: sqrt(1 - t1^2 - t2^2) cancels, h = normalize(v + l) with v + l -> 0) are flagged by the margin."""

@@ -14,7 +14,7 @@ try:
 except Exception:
     commit = "unknown"
 json.dump({"profile": os.path.basename(sys.argv[1]), "git_commit": commit, "collected": time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime()),
-           "command": "tools/collect_profiles.sh (3840x2160, steps 20/5, denoiseIterations 1; rocprofv3 --kernel-trace --stats of bench.py; one --pmc set per pass over tools/quick_time.py: the same kernels and arguments without torch in the process)"},
+           "command": "tools/collect_profiles.sh (3840x2160, steps 20/5, denoiseIterations 1; rocprofv3 --kernel-trace --stats of bench.py; one --pmc set per pass over the same bench.py command)"},
           open(os.path.join(sys.argv[1], "meta.json"), "w"))
 PY
 $ROOT/tools/microbench/bin/valu_rates2 > $OUT/valu_rates2.txt 2>&1
@@ -25,10 +25,11 @@ python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 # 2. kernel trace + stats
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- $BENCH > $OUT/trace.log 2>&1
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
-# 3. counters, one set per pass (never combined with other trace domains).  Target: tools/quick_time.py — the same kernels with the same
-#    arguments on the same 4K frame through the C ABI, WITHOUT torch in the process: bench.py under `--pmc` stops answering on this pool
-#    since round 3 (two calls timed out; the kernel trace above is fine), a process that only maps librfx_hip.so does not.
-PMC_TARGET="python $ROOT/tools/quick_time.py 3840 2160 3"
+# 3. counters, one set per pass (never combined with other trace domains), over the bench command itself.  (Round 3's profile took them over
+#    tools/quick_time.py — same kernels and arguments, no torch — because bench.py "stopped answering" under --pmc: its scene pool's forked
+#    workers inherited rocprofv3's SIGTERM handler and never finished Pool.terminate(); fixed in rfx_amd/scene.py, and the bench command's
+#    FETCH_SIZE agrees with that collection to 0.1 % (K2: 2 %): profiles/r03_final/fetch_size_bench_command.csv.)
+PMC_TARGET="$BENCH"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS_F32" "TCC_HIT_sum TCC_MISS_sum" "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" \
