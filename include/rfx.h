@@ -317,8 +317,7 @@ int rfx_stage_flip(rfx_ctx *);
 
 /* ---- row-tiled runs: the exchanges, one process per GPU, RCCL over xGMI.  RCCL is bound at run time (a
  * single-GPU host needs none; a process that already maps an RCCL — e.g. torch's — shares it).
- * Tiles: rank r of n owns rfx_split_rows(height, n, r) — boundaries on even rows, the last tile takes the remainder; every tile
- * must be at least halo_rows high.  The exchanges run on a second stream of the context: each call orders itself AFTER all draws
+ * Tiles: rank r of n owns rfx_split_rows(height, n, r) — boundaries on even rows, the last tile takes the remainder.  The exchanges run on a second stream of the context: each call orders itself AFTER all draws
  * enqueued so far and returns; rfx_comm_wait orders all LATER draws after the exchanges issued so far.  In between the host may
  * enqueue draws that do not touch the rows in flight (the tile interior through rfx_set_row_window; rfx_ssgi_trace while the
  * composed GI is gathered), which is how their time is hidden.
@@ -328,7 +327,10 @@ int rfx_comm_unique_id(void *id128);                                            
 int rfx_comm_init(rfx_ctx *, const void *id128, int rank, int nranks);          /* ncclCommInitRank on the context's device (collective) */
 int rfx_comm_destroy(rfx_ctx *);
 /* ncclGroupStart; ncclSend/ncclRecv of halo_rows rows of texture `id` with the tile above (`up_rank`, higher frame rows) and
- * below (`down_rank`); ncclGroupEnd — -1 = no such neighbour.  `ncclComm` (an ncclComm_t) may be NULL: the context's own. */
+ * below (`down_rank`); ncclGroupEnd — -1 = no such neighbour.  `ncclComm` (an ncclComm_t) may be NULL: the context's own.
+ * halo_rows taller than the split's tiles (many ranks, a fast camera: the band around a tile then reaches past its neighbours): every
+ * tile whose rows lie inside this tile's band sends them directly, in the same group — that form needs rfx_comm_init on the context
+ * (rank and size) and up / down = rank + 1 / rank - 1 (or -1). */
 int rfx_halo_exchange(rfx_ctx *, rfx_tex id, void *ncclComm, int up_rank, int down_rank);
 /* every rank's tile rows of RFX_TEX_COMPOSE or RFX_TEX_COMPOSE_RGB (held whole) to every rank, in place: next frame's K1 gathers
  * last frame's composed GI anywhere on screen.  ncclAllGather (equal tiles) or one ncclBroadcast per owner in a group (ragged). */

@@ -156,12 +156,6 @@ int rfx_comm_init(rfx_ctx *c, const void *id128, int rank, int nranks) {
     int y0 = 0, rows = 0;
     if (rfx_split_rows(c->H, nranks, rank, &y0, &rows) != RFX_OK || y0 != c->tile_y0 || rows != c->tile_rows)
         return fail(c, RFX_EINVAL, "rfx_comm_init: the context's tile is not rfx_split_rows(height, nranks, rank)");
-    if (nranks > 1) {
-        int smallest = 0;
-        rfx_split_rows(c->H, nranks, 0, nullptr, &smallest);
-        // a tile forwards its OWN boundary rows to its neighbour: it must be at least `halo` rows high (multi-hop exchanges are not built)
-        if (c->halo > smallest) return fail(c, RFX_EINVAL, "rfx_comm_init: halo_rows exceeds the smallest tile of this split");
-    }
     int rc = ensure_streams(c);
     if (rc) return rc;
     hipSetDevice(c->device);
@@ -197,19 +191,49 @@ int rfx_halo_exchange(rfx_ctx *c, rfx_tex id, void *nccl_comm, int up_rank, int 
     const Slot &s = c->slots[id];
     const size_t pitch = (size_t)s.width * s.texel;
     const int h = c->halo, lo = c->tile_y0 - s.row0, hi = lo + c->tile_rows;  // tile rows inside the held band
-    if (h > c->tile_rows || (down_rank >= 0 && lo < h) || (up_rank >= 0 && hi + h > s.rows))
-        return fail(c, RFX_EINVAL, "rfx_halo_exchange: the held band does not contain halo_rows rows around the tile (whole-frame slot, or halo > tile)");
+    const int y0 = c->tile_y0, y1 = y0 + c->tile_rows;
+    // the rows of the band around the tile that other tiles own must be held
+    const int bl = (down_rank >= 0 && y0 - h > 0) ? y0 - h : (down_rank >= 0 ? 0 : y0), bh = (up_rank >= 0 && y1 + h < c->H) ? y1 + h : (up_rank >= 0 ? c->H : y1);
+    if (bl < s.row0 || bh > s.row0 + s.rows)
+        return fail(c, RFX_EINVAL, "rfx_halo_exchange: the held band does not contain halo_rows rows around the tile (whole-frame slot?)");
+    // halo_rows up to the neighbours' height: each neighbour's boundary rows, one Send/Recv pair per direction.  A taller halo reaches past
+    // the neighbour (N = 8 at 8K under a fast camera): then every tile whose rows fall inside this tile's band sends them directly, and
+    // this tile sends its rows to every tile whose band they fall into — both ends derive the same row intervals from rfx_split_rows, so
+    // every Send has its Recv.  That needs rank and size (rfx_comm_init) and the split's neighbours.
+    // (the decision must be the same on every rank: the split's smallest tile — tile 0 — against halo_rows, not this rank's neighbourhood)
+    const bool known = c->comm && c->comm_nranks > 0;
+    int smallest = c->tile_rows;
+    if (known) rfx_split_rows(c->H, c->comm_nranks, 0, nullptr, &smallest);
+    const bool multi_hop = h > smallest;
+    if (multi_hop) {
+        if (!known) return fail(c, RFX_EINVAL, "rfx_halo_exchange: halo_rows taller than a tile needs rfx_comm_init (rank and size) on this context");
+        if ((up_rank >= 0 && up_rank != c->comm_rank + 1) || (down_rank >= 0 && down_rank != c->comm_rank - 1))
+            return fail(c, RFX_EINVAL, "rfx_halo_exchange: halo_rows taller than a tile: up / down must be the split's neighbours (rank + 1 / rank - 1) or -1");
+    }
     if ((rc = comm_begin(c))) return rc;
     const size_t bytes = (size_t)h * pitch;
     NCCLCHK(c, r->GroupStart());
     NcclResult e = 0;
-    if (up_rank >= 0) {  // `up` owns the rows above this tile: it needs our top rows, we need its bottom rows
-        if (!e) e = r->Send(base + (size_t)(hi - h) * pitch, bytes, kNcclUint8, up_rank, comm, c->comm_stream);
-        if (!e) e = r->Recv(base + (size_t)hi * pitch, bytes, kNcclUint8, up_rank, comm, c->comm_stream);
-    }
-    if (down_rank >= 0) {
-        if (!e) e = r->Send(base + (size_t)lo * pitch, bytes, kNcclUint8, down_rank, comm, c->comm_stream);
-        if (!e) e = r->Recv(base + (size_t)(lo - h) * pitch, bytes, kNcclUint8, down_rank, comm, c->comm_stream);
+    if (multi_hop) {
+        for (int p = 0; p < c->comm_nranks && !e; p++) {
+            if (p == c->comm_rank || (p > c->comm_rank && up_rank < 0) || (p < c->comm_rank && down_rank < 0)) continue;
+            int py0 = 0, pn = 0;
+            rfx_split_rows(c->H, c->comm_nranks, p, &py0, &pn);
+            const int py1 = py0 + pn;
+            int a = y0 > py0 - h ? y0 : py0 - h, b = y1 < py1 + h ? y1 : py1 + h;  // my rows inside p's band
+            if (b > a) e = r->Send(base + (size_t)(a - s.row0) * pitch, (size_t)(b - a) * pitch, kNcclUint8, p, comm, c->comm_stream);
+            a = py0 > y0 - h ? py0 : y0 - h, b = py1 < y1 + h ? py1 : y1 + h;          // p's rows inside my band
+            if (b > a && !e) e = r->Recv(base + (size_t)(a - s.row0) * pitch, (size_t)(b - a) * pitch, kNcclUint8, p, comm, c->comm_stream);
+        }
+    } else {
+        if (up_rank >= 0) {  // `up` owns the rows above this tile: it needs our top rows, we need its bottom rows
+            if (!e) e = r->Send(base + (size_t)(hi - h) * pitch, bytes, kNcclUint8, up_rank, comm, c->comm_stream);
+            if (!e) e = r->Recv(base + (size_t)hi * pitch, bytes, kNcclUint8, up_rank, comm, c->comm_stream);
+        }
+        if (down_rank >= 0) {
+            if (!e) e = r->Send(base + (size_t)lo * pitch, bytes, kNcclUint8, down_rank, comm, c->comm_stream);
+            if (!e) e = r->Recv(base + (size_t)(lo - h) * pitch, bytes, kNcclUint8, down_rank, comm, c->comm_stream);
+        }
     }
     NcclResult e2 = r->GroupEnd();
     if (e) return nccl_fail(c, "rfx_halo_exchange: ncclSend/ncclRecv", e);

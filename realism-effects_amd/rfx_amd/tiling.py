@@ -4,7 +4,8 @@ Rank r owns frame rows [r*H/N, (r+1)*H/N).  Pixels are independent inside every 
 coupling is only through gathers from previous-stage textures, so the tile holds `halo` extra
 rows above and below and three exchange steps keep them current:
 
-  after K2 and after every K3 pass : neighbour Send/Recv of `halo` rows of the textures just
+  after K2 and after every K3 pass : Send/Recv of the `halo` rows around each tile (the two row neighbours' boundary rows; with a halo
+                                     taller than the tiles also rows of tiles further away: halo_plan) of the textures just
                                      written (RCCL over xGMI; message = halo*W*texel bytes per
                                      texture and direction — latency-bound).
                                      Issued asynchronously: the next draw (K3 pass, K4) first
@@ -64,6 +65,28 @@ def required_halo(radius: float, max_abs_velocity_y: float, frame_height: int, f
     return max(k3, k2, 2)
 
 
+def halo_plan(height: int, world: int, rank: int, halo: int):
+    """One halo exchange as row intervals of the frame: [(peer, send, recv)] with send = the rows of THIS tile that lie inside the peer's
+    band (tile +- halo), recv = the peer's rows inside this tile's band; None where empty.  With halo <= the tiles' height that is the two
+    neighbours' boundary rows; a taller halo (many ranks, a fast camera) reaches past them and more peers appear.  Every rank derives
+    the same intervals from split_rows, so every send has its receive (rfx_halo_exchange in csrc/rfx_comm.hip follows the same rule)."""
+    tiles = split_rows(height, world)
+    y0, n = tiles[rank]
+    y1 = y0 + n
+    plan = []
+    for p, (py0, pn) in enumerate(tiles):
+        if p == rank:
+            continue
+        py1 = py0 + pn
+        send = (max(y0, py0 - halo), min(y1, py1 + halo))
+        recv = (max(py0, y0 - halo), min(py1, y1 + halo))
+        send = send if send[1] > send[0] else None
+        recv = recv if recv[1] > recv[0] else None
+        if send or recv:
+            plan.append((p, send, recv))
+    return plan
+
+
 class TiledRenderer:
     """Wraps the per-tile renderer (an rfx Context, or the oracle double in tests) and performs the
     exchange steps through torch.distributed.  `tensors[tex]` is a torch tensor over the rows the
@@ -79,16 +102,11 @@ class TiledRenderer:
         self.W, self.H = inner.W, inner.H
         self.tile_y0, self.tile_rows, self.halo = inner.tile_y0, inner.tile_rows, inner.halo
         if world > 1:
-            # the exchange forwards a tile's OWN boundary rows to its neighbour: the tile must be the rank's share of the even split and
-            # every tile must be at least `halo` rows high, or a neighbour would be sent rows this rank only holds as (stale) halo —
-            # silently wrong pixels, not an error (multi-hop exchanges are not built: use fewer ranks or a smaller halo)
+            # every rank derives the exchange's row intervals from the even split (halo_plan): the tile must be the rank's share of it
             tiles = split_rows(self.H, world)
             if (self.tile_y0, self.tile_rows) != tiles[rank]:
                 raise ValueError("TiledRenderer: rank %d of %d holds rows [%d, %d), split_rows() assigns [%d, %d)" % (
                     rank, world, self.tile_y0, self.tile_y0 + self.tile_rows, tiles[rank][0], tiles[rank][0] + tiles[rank][1]))
-            if self.halo > min(n for _, n in tiles):
-                raise ValueError("TiledRenderer: halo %d rows exceeds the smallest tile (%d rows) of a %d-way split of %d rows" % (
-                    self.halo, min(n for _, n in tiles), world, self.H))
         self.exchange_count = 0
         self._pending = []  # (works, tensor) of the composed-GI all-gather in flight
         self._halo_pending = []  # (works, tensor) of halo Send/Recvs in flight
@@ -195,25 +213,21 @@ class TiledRenderer:
             return
         dist = self._dist
         ops = []
-        up, down = self.rank + 1, self.rank - 1  # up = higher frame rows
+        plan = halo_plan(self.H, self.world, self.rank, self.halo)
         for tex in texs:
             if tex not in self.tensors:
                 raise KeyError("TiledRenderer.exchange: texture %s is not bound for exchange — pass it to bind_torch_buffers(texs=...) "
                                "(exchanged_textures(denoise_mode) lists what a configuration needs)" % abi.TEX_NAMES[tex])
             t = self.tensors[tex]
             b0, bn = self.inner.held_rows(tex)
-            lo = self.tile_y0 - b0  # first tile row inside the held band
-            hi = lo + self.tile_rows
-            h = self.halo
-            if (down >= 0 and lo < h) or (up < self.world and hi + h > bn):
+            if b0 > max(0, self.tile_y0 - self.halo) or b0 + bn < min(self.H, self.tile_y0 + self.tile_rows + self.halo):
                 raise ValueError("TiledRenderer.exchange: the held band of %s [%d, %d) does not contain %d halo rows around the tile" % (
-                    abi.TEX_NAMES[tex], b0, b0 + bn, h))
-            if up < self.world:
-                ops.append(dist.P2POp(dist.isend, t[hi - h:hi], up, self.group))
-                ops.append(dist.P2POp(dist.irecv, t[hi:hi + h], up, self.group))
-            if down >= 0:
-                ops.append(dist.P2POp(dist.isend, t[lo:lo + h], down, self.group))
-                ops.append(dist.P2POp(dist.irecv, t[lo - h:lo], down, self.group))
+                    abi.TEX_NAMES[tex], b0, b0 + bn, self.halo))
+            for peer, send, recv in plan:
+                if send:
+                    ops.append(dist.P2POp(dist.isend, t[send[0] - b0:send[1] - b0], peer, self.group))
+                if recv:
+                    ops.append(dist.P2POp(dist.irecv, t[recv[0] - b0:recv[1] - b0], peer, self.group))
         self.finish_halo()  # one exchange in flight at a time (and the same order on every rank)
         self._sync_before_comm()
         self._halo_pending.append((dist.batch_isend_irecv(ops), self.tensors[texs[0]]))

@@ -19,7 +19,7 @@ rank, world, outdir, W, H, FRAMES = int(sys.argv[1]), int(sys.argv[2]), sys.argv
 MODE = sys.argv[7] if len(sys.argv) > 7 else "all"  # CommTiledRenderer history_gather
 frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
 vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
-halo = tiling.required_halo(3.0, vmax, H, W)
+halo = (int(sys.argv[8]) if len(sys.argv) > 8 else 0) or tiling.required_halo(3.0, vmax, H, W)  # an override taller than the tiles: multi-hop exchange
 y0, rows = tiling.split_rows(H, world)[rank]
 ctx = Context(W, H, tile_y0=y0, tile_rows=rows, halo_rows=halo)
 idf = os.path.join(outdir, "nccl_id")

@@ -35,7 +35,7 @@ def _traa(renderer, scene, cam, frames):
         fx.update(renderer, dict(texture=dict(type=HalfFloatType), width=W, height=H, data=f.direct))
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, halo_override=0):
     sys.path.insert(0, HERE)
     import conftest  # noqa: F401  (sys.path setup)
     from oracle_renderer import OracleRenderer
@@ -46,7 +46,7 @@ def _worker(rank, world, port, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
     vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
-    halo = tiling.required_halo(3.0, vmax, H, W)
+    halo = halo_override or tiling.required_halo(3.0, vmax, H, W)
     y0, rows = tiling.split_rows(H, world)[rank]
     inner = OracleRenderer(W, H, y0, rows, halo)
     tensors = {}
@@ -62,7 +62,8 @@ def _worker(rank, world, port, outdir):
     assert len(r._pending) == 1
     r.finish_pending()
     # the halo exchanges are asynchronous too: K3 passes and K4 drew their interior first (windowed launches), then the boundary strips
-    assert r.overlap_halo_exchange and sum(1 for c in inner.calls if c[0] == "set_row_window") >= FRAMES * 3 * 3
+    # (a halo of half the tile or more leaves no interior: the draw then simply waits first)
+    assert r.overlap_halo_exchange and (2 * halo >= rows or sum(1 for c in inner.calls if c[0] == "set_row_window") >= FRAMES * 3 * 3)
     r.finish_halo()
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), y0=y0, rows=rows, halo=halo,
              **{abi.TEX_NAMES[t]: inner.tex[t][y0:y0 + rows] for t in (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_B0,
@@ -99,7 +100,7 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def _comm_worker(rank, world, port, outdir):
+def _comm_worker(rank, world, port, outdir, halo_override=0):
     """CommTiledRenderer (the protocol over the C ABI's exchange entry points) on a stand-in context whose halo_exchange /
     allgather_history are executed LAZILY, at comm_wait, over gloo: the adversarial schedule — rows arrive as late as the protocol
     allows and are read from the sender's buffers as late as it allows.  A draw that touched halo rows before its wait, or rewrote
@@ -134,12 +135,14 @@ def _comm_worker(rank, world, port, outdir):
                 if op[0] == "halo":
                     _, tex, up, down = op
                     t = torch.from_numpy(self.tex[tex])
-                    y0, y1, h = self.tile_y0, self.tile_y0 + self.tile_rows, self.halo
-                    ops = []
-                    if up >= 0:
-                        ops += [dist.P2POp(dist.isend, t[y1 - h:y1].contiguous(), up), dist.P2POp(dist.irecv, t[y1:y1 + h], up)]
-                    if down >= 0:
-                        ops += [dist.P2POp(dist.isend, t[y0:y0 + h].contiguous(), down), dist.P2POp(dist.irecv, t[y0 - h:y0], down)]
+                    ops = []  # what rfx_halo_exchange does (csrc/rfx_comm.hip): the rows of every tile inside this tile's band, both ways
+                    for peer, send, recv in tiling.halo_plan(self.H, dist.get_world_size(), dist.get_rank(), self.halo):
+                        if (peer > dist.get_rank() and up < 0) or (peer < dist.get_rank() and down < 0):
+                            continue
+                        if send:
+                            ops.append(dist.P2POp(dist.isend, t[send[0]:send[1]].contiguous(), peer))
+                        if recv:
+                            ops.append(dist.P2POp(dist.irecv, t[recv[0]:recv[1]], peer))
                     for w in dist.batch_isend_irecv(ops):
                         w.wait()
                 else:
@@ -149,7 +152,7 @@ def _comm_worker(rank, world, port, outdir):
 
     frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
     vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
-    halo = tiling.required_halo(3.0, vmax, H, W)
+    halo = halo_override or tiling.required_halo(3.0, vmax, H, W)
     y0, rows = tiling.split_rows(H, world)[rank]
     inner = LazyCommCtx(W, H, y0, rows, halo)
     r = tiling.CommTiledRenderer(inner, rank, world, b"\0" * 128)
@@ -165,8 +168,8 @@ def _comm_worker(rank, world, port, outdir):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])
-def test_comm_tiled_protocol_is_bit_identical_under_the_latest_possible_delivery(tmp_path, world):
+@pytest.mark.parametrize("world,halo", [(2, 0), (3, 0), (4, 20)])  # (4, 20): 16-row tiles under a 20-row halo — rows from two tiles away
+def test_comm_tiled_protocol_is_bit_identical_under_the_latest_possible_delivery(tmp_path, world, halo):
     import socket
     from oracle_renderer import OracleRenderer
     from rfx_amd import abi
@@ -175,7 +178,7 @@ def test_comm_tiled_protocol_is_bit_identical_under_the_latest_possible_delivery
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_comm_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_comm_worker, args=(world, port, str(tmp_path), halo), nprocs=world, join=True)
     frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
     ref = OracleRenderer(W, H)
     _chain(ref, types.SimpleNamespace(frame=None), frames[0].camera, frames)
@@ -189,8 +192,8 @@ def test_comm_tiled_protocol_is_bit_identical_under_the_latest_possible_delivery
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])  # 3: a middle rank with two neighbours, a ragged last tile
-def test_tiled_chain_is_bit_identical(tmp_path, world):
+@pytest.mark.parametrize("world,halo", [(2, 0), (3, 0), (4, 20)])  # 3: a middle rank with two neighbours, a ragged last tile; (4, 20): a halo taller than the 16-row tiles
+def test_tiled_chain_is_bit_identical(tmp_path, world, halo):
     import socket
     from oracle_renderer import OracleRenderer
     from rfx_amd import abi
@@ -200,7 +203,7 @@ def test_tiled_chain_is_bit_identical(tmp_path, world):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), halo), nprocs=world, join=True)
 
     frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
     ref = OracleRenderer(W, H)
@@ -231,12 +234,35 @@ def test_tiled_chain_is_bit_identical(tmp_path, world):
         assert np.array_equal(ft["compose"], ref3.tex[abi.TEX_COMPOSE][y0:y0 + rows]), "rank %d full_temporal compose differs" % rank
 
 
-def test_tiled_renderer_rejects_geometry_it_cannot_exchange():
-    """a halo taller than a tile, or a tile that is not the rank's share of the split, must be refused, not silently wrong."""
+def test_halo_plan_covers_every_band_and_pairs_every_send():
+    """tiling.halo_plan (and rfx_halo_exchange, which follows the same rule): for any split and halo, what a rank receives is exactly its
+    band minus its tile, from the owners; every send has the matching receive on the peer; halo <= tile height = the two neighbours only."""
     from rfx_amd import tiling
-    inner = types.SimpleNamespace(W=64, H=64, tile_y0=16, tile_rows=16, halo=20)
-    with pytest.raises(ValueError, match="exceeds the smallest tile"):
-        tiling.TiledRenderer(inner, {}, 1, 4)
+    for H, world, halo in [(64, 4, 5), (64, 4, 16), (64, 4, 20), (64, 4, 40), (70, 3, 30), (128, 8, 50), (64, 2, 100)]:
+        tiles = tiling.split_rows(H, world)
+        plans = [tiling.halo_plan(H, world, r, halo) for r in range(world)]
+        for r, (y0, n) in enumerate(tiles):
+            got = np.zeros(H, int)
+            for peer, send, recv in plans[r]:
+                if recv:
+                    assert tiles[peer][0] <= recv[0] and recv[1] <= tiles[peer][0] + tiles[peer][1]  # the owner's rows
+                    got[recv[0]:recv[1]] += 1
+                    assert (r, recv, None) in [(q, s, None) for q, s, _ in plans[peer]], "no send for a receive"
+                if send:
+                    assert y0 <= send[0] and send[1] <= y0 + n
+                    assert any(q == r and rc == send for q, _, rc in plans[peer]), "no receive for a send"
+            want = np.zeros(H, int)
+            want[max(0, y0 - halo):min(H, y0 + n + halo)] = 1
+            want[y0:y0 + n] = 0
+            assert np.array_equal(got, want), (H, world, halo, r)
+            if halo <= min(m for _, m in tiles):
+                assert {p for p, _, _ in plans[r]} <= {r - 1, r + 1}
+
+
+def test_tiled_renderer_rejects_geometry_it_cannot_exchange():
+    """a tile that is not the rank's share of the split must be refused, not silently wrong (a halo taller than a tile is
+    exchanged since round 3: test_tiled_chain_is_bit_identical[4-20])."""
+    from rfx_amd import tiling
     inner = types.SimpleNamespace(W=64, H=64, tile_y0=10, tile_rows=16, halo=2)
     with pytest.raises(ValueError, match="split_rows"):
         tiling.TiledRenderer(inner, {}, 1, 4)
@@ -337,20 +363,21 @@ def test_tiled_kernels_are_bit_identical_to_one_context(tmp_path, world):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(os.environ.get("RFX_HOSTSIM") != "1", reason="the C ABI's exchanges between processes without RCCL: pytest --hostsim")
-@pytest.mark.parametrize("world,mode", [(2, "bounded"), (3, "bounded"), (4, "bounded"), (3, "all"), (4, "all")])
-def test_tiled_kernels_with_c_abi_exchanges_are_bit_identical_to_one_context(tmp_path, world, mode):
+@pytest.mark.parametrize("world,mode,halo", [(2, "bounded", 0), (3, "bounded", 0), (4, "bounded", 0), (3, "all", 0), (4, "all", 0), (4, "all", 20), (3, "bounded", 30)])
+def test_tiled_kernels_with_c_abi_exchanges_are_bit_identical_to_one_context(tmp_path, world, mode, halo):
     """The same tiles with the exchanges BEHIND THE C ABI (rfx_comm_init / rfx_halo_exchange / rfx_allgather_history / rfx_comm_wait), one
     process per tile (tests/comm_tile_worker.py — no torch in them: a torch process maps the real librccl.so.1, which rfx_comm.hip would
     rightly reuse).  Under --hostsim the librccl.so.1 that rfx_comm.hip binds is tests/hostsim/fakerccl.c: unix sockets between these
     processes.  Ragged tiles at 3 ranks (the grouped-broadcast form of the gather), even ones at 2 and 4 (the in-place all-gather).
     mode "bounded" (the default): no all-gather of the composed GI; between a frame's trace and its shade rfx_gather_history_rows moves only
-    the rows the tiles' rays will read — same pixels, fewer bytes; "all": the whole-frame all-gather after K4."""
+    the rows the tiles' rays will read — same pixels, fewer bytes; "all": the whole-frame all-gather after K4.
+    halo > 0: a halo taller than the tiles (16 / 20 rows here): rfx_halo_exchange then moves rows between tiles that are not neighbours."""
     import subprocess
     from rfx_amd import abi
     from rfx_amd.context import Context
     from rfx_amd.scene import synthetic_frame
 
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "comm_tile_worker.py"), str(r), str(world), str(tmp_path), str(W), str(H), str(FRAMES), mode],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "comm_tile_worker.py"), str(r), str(world), str(tmp_path), str(W), str(H), str(FRAMES), mode, str(halo)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]

@@ -9,4 +9,4 @@ for so in realism-effects_amd/csrc/variants/librfx_k1_ssgi_*.so; do
   echo "== $so" >> $OUT
   timeout 150 python tools/quick_time.py --lib $PWD/$so 3840 2160 20 ${ONLY:-} >> $OUT 2>&1 || echo "FAILED rc=$?" >> $OUT
 done
-grep "^==\|^K1 ssgi\|^K1t\|^frame\|ssgi sha1\|FAILED" $OUT
+grep "^==\|^K1 ssgi\|^K2\|^K3\|^K4\|^frame\|sha1\|FAILED" $OUT
