@@ -210,8 +210,8 @@ def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, 
 
 def verify_exchange(ctx, rank, world):
     """Pre-flight check of the C ABI's RCCL exchanges on this communicator, with known patterns (nothing the frame loop needs survives
-    it): every rank fills ITS tile rows of a K3 target with rank + 1, exchanges halos, and must find its upper / lower halo rows holding
-    the neighbour's value; then the same for the all-gather of the composed-GI twin.  Returns None, or a description of what is wrong."""
+    it): every rank fills ITS tile rows of a K3 target with rank + 1, exchanges halos, and must find every halo row holding its owner's
+    value; then the same for the all-gather of the composed-GI twin.  Returns None, or a description of what is wrong."""
     from rfx_amd import abi as A
     y0, rows, h, H, W = ctx.tile_y0, ctx.tile_rows, ctx.halo, ctx.H, ctx.W
     up, down = (rank + 1 if rank + 1 < world else -1), rank - 1
@@ -224,10 +224,11 @@ def verify_exchange(ctx, rank, world):
     ctx.sync()
     got = ctx.download(A.TEX_DENOISE_A0, r0, n)
     err = None
-    if up >= 0 and not (got[y0 - r0 + rows:y0 - r0 + rows + h] == rank + 2).all():
-        err = "halo rows above the tile do not hold rank %d's rows" % up
-    if down >= 0 and not (got[y0 - r0 - h:y0 - r0] == rank).all():
-        err = "halo rows below the tile do not hold rank %d's rows" % down
+    # every held row must hold its OWNER's value (the neighbours', or — under a halo taller than the tiles — tiles further away)
+    for k, (ky0, kn) in enumerate(tiling.split_rows(H, world)):
+        a, b = max(ky0, r0), min(ky0 + kn, r0 + n)
+        if k != rank and b > a and not (got[a - r0:b - r0] == k + 1).all():
+            err = "halo rows %s the tile do not hold rank %d's rows" % ("above" if k > rank else "below", k)
     if not (got[y0 - r0:y0 - r0 + rows] == rank + 1).all():
         err = "the tile's own rows were overwritten"
     full = np.zeros((H, W, 3), np.float32)
