@@ -51,7 +51,7 @@ hostsim_switch:
 namespace {
 enum { RUNNABLE = 0, AT_BARRIER = 1, AT_WAVEOP = 2, DONE = 3 };
 #ifdef HOSTSIM_ASAN
-constexpr size_t STACK_BYTES = 2u << 20;
+constexpr size_t STACK_BYTES = 256u << 10;
 #else
 constexpr size_t STACK_BYTES = 512u << 10;
 #endif
