@@ -3,7 +3,7 @@ offline run leaves on disk (HDR and tone-mapped images).  Pure Python + numpy + 
 
   read_hdr          Radiance RGBE (.hdr): the format of the reference example's environments (example/public/hdr/*.hdr, loaded there
                     by three's RGBELoader) -> scene.environment for rfx_set_environment
-  read_exr/write_exr  OpenEXR, scanline, compression NONE / ZIPS / ZIP / PIZ, HALF / FLOAT / UINT channels, arbitrary layer.channel names —
+  read_exr/write_exr  OpenEXR, scanline, compression NONE / RLE / ZIPS / ZIP / PIZ / PXR24, HALF / FLOAT / UINT channels, arbitrary layer.channel names —
                     the usual container of renderer AOVs; `exr_to_dump_planes` maps its layers onto the dump's attribute planes
   read_pfm/write_pfm  Portable Float Map (the simplest HDR interchange format)
   write_png         8-bit RGB(A) PNG
@@ -189,7 +189,7 @@ def tonemap(linear: np.ndarray, operator: str = "aces", exposure: float = 1.0) -
 # ------------------------------------------------------------------------------------------------ OpenEXR (scanline)
 _PT_UINT, _PT_HALF, _PT_FLOAT = 0, 1, 2
 _PT_DTYPE = {_PT_UINT: "<u4", _PT_HALF: "<f2", _PT_FLOAT: "<f4"}
-_COMP_NONE, _COMP_ZIPS, _COMP_ZIP, _COMP_PIZ = 0, 2, 3, 4
+_COMP_NONE, _COMP_RLE, _COMP_ZIPS, _COMP_ZIP, _COMP_PIZ, _COMP_PXR24 = 0, 1, 2, 3, 4, 5
 
 
 # ---- PIZ (OpenEXR's default for renderer output): per 32-scanline block, the samples as 16-bit words, channel-planar; (1) a bitmap of
@@ -525,18 +525,133 @@ def _piz_uncompress_block(buf, chans, W, rows):
     return lines.astype("<u2").tobytes()
 
 
+# ---- the byte shuffle ZIP / ZIPS / RLE share: even bytes then odd bytes, each byte replaced by its difference to its predecessor + 128
+def _exr_predict(raw: bytes) -> bytes:
+    a = np.frombuffer(raw, np.uint8)
+    re = np.concatenate([a[0::2], a[1::2]])
+    d = re.astype(np.int16)
+    d[1:] = d[1:] - re[:-1].astype(np.int16) + 128
+    return (d & 255).astype(np.uint8).tobytes()
+
+
+def _exr_unpredict(buf: bytes) -> bytes:
+    a = np.frombuffer(buf, np.uint8).astype(np.int32)
+    a = ((np.cumsum(a - 128) + 128) & 255).astype(np.uint8)  # t[i] = t[i-1] + d[i] - 128, t[0] = d[0]
+    half_n = (a.size + 1) // 2
+    re = np.empty(a.size, np.uint8)
+    re[0::2], re[1::2] = a[:half_n], a[half_n:]
+    return re.tobytes()
+
+
+# ---- RLE: signed count bytes — n >= 0: the next byte n + 1 times; n < 0: -n literal bytes (runs of 3..128, literals up to 127)
+def _rle_compress(buf: bytes) -> bytes:
+    out, i, n = bytearray(), 0, len(buf)
+    while i < n:
+        j = i + 1
+        while j < n and buf[j] == buf[i] and j - i < 128:
+            j += 1
+        if j - i >= 3:
+            out += bytes([j - i - 1, buf[i]])
+            i = j
+            continue
+        j = i  # a literal stretch: up to the next run of three, at most 127 bytes
+        while j < n and j - i < 127 and not (j + 2 < n and buf[j] == buf[j + 1] == buf[j + 2]):
+            j += 1
+        out += bytes([(i - j) & 255]) + buf[i:j]
+        i = j
+    return bytes(out)
+
+
+def _rle_uncompress(buf: bytes, nbytes: int) -> bytes:
+    out, i = bytearray(), 0
+    while i < len(buf):
+        c = buf[i] - 256 if buf[i] > 127 else buf[i]
+        i += 1
+        if c < 0:
+            out += buf[i:i - c]
+            i += -c
+        else:
+            out += bytes([buf[i]]) * (c + 1)
+            i += 1
+        if len(out) > nbytes:
+            raise ValueError("RLE: more bytes than the block holds")
+    if len(out) != nbytes:
+        raise ValueError("RLE: %d of %d bytes decoded" % (len(out), nbytes))
+    return bytes(out)
+
+
+# ---- PXR24: per 16-scanline block, zlib over byte PLANES of pixel-to-pixel differences, per scanline and channel: HALF 2 planes, UINT 4,
+# FLOAT 3 — a float is first cut to 24 bits (sign, exponent, 15 mantissa bits, rounded): lossy for FLOAT, exact for HALF / UINT
+def _float_to_f24(f: np.ndarray) -> np.ndarray:
+    u = f.astype(np.float32).view(np.uint32).astype(np.uint64)
+    one, eight = np.uint64(1), np.uint64(8)
+    s, e, m = u & np.uint64(0x80000000), u & np.uint64(0x7F800000), u & np.uint64(0x007FFFFF)
+    rounded = ((e | m) + (m & np.uint64(0x80))) >> eight      # round the mantissa half up; may carry into the exponent ...
+    rounded = np.where(rounded >= np.uint64(0x7F8000), (e | m) >> eight, rounded)  # ... but never into infinity: truncate instead
+    nan = (e >> eight) | (m >> eight) | np.where((m >> eight) == 0, one, np.uint64(0))  # a NaN keeps a mantissa bit
+    r = np.where(e == np.uint64(0x7F800000), np.where(m != 0, nan, e >> eight), rounded)
+    return ((s >> eight) | r).astype(np.uint32)
+
+
+def _pxr24_planes(pt):
+    return {_PT_UINT: 4, _PT_HALF: 2, _PT_FLOAT: 3}[pt]
+
+
+def _pxr24_compress_block(raw: bytes, chans, W: int, rows: int) -> bytes:
+    planes, p = [], 0
+    for _ in range(rows):
+        for _, pt in chans:
+            dt = np.dtype(_PT_DTYPE[pt])
+            v = np.frombuffer(raw, dt, W, p)
+            p += W * dt.itemsize
+            k = _pxr24_planes(pt)
+            if pt == _PT_FLOAT:
+                px = _float_to_f24(v).astype(np.int64)
+            else:
+                px = v.view(np.uint16 if pt == _PT_HALF else np.uint32).astype(np.int64)
+            diff = (np.diff(px, prepend=0) & ((1 << (8 * k)) - 1)).astype(np.uint64)
+            for b in range(k - 1, -1, -1):
+                planes.append(((diff >> np.uint64(8 * b)) & np.uint64(255)).astype(np.uint8))
+    return zlib.compress(np.concatenate(planes).tobytes(), 4)
+
+
+def _pxr24_uncompress_block(buf: bytes, chans, W: int, rows: int) -> bytes:
+    a = np.frombuffer(zlib.decompress(buf), np.uint8)
+    out, p = [], 0
+    for _ in range(rows):
+        for _, pt in chans:
+            k = _pxr24_planes(pt)
+            if p + k * W > a.size:
+                raise ValueError("PXR24: block too short")
+            diff = np.zeros(W, np.uint64)
+            for b in range(k):
+                diff = (diff << np.uint64(8)) | a[p:p + W].astype(np.uint64)
+                p += W
+            px = np.cumsum(diff) & np.uint64((1 << (8 * k)) - 1)
+            if pt == _PT_FLOAT:
+                out.append((px.astype(np.uint32) << np.uint32(8)).tobytes())
+            elif pt == _PT_HALF:
+                out.append(px.astype(np.uint16).tobytes())
+            else:
+                out.append(px.astype(np.uint32).tobytes())
+    if p != a.size:
+        raise ValueError("PXR24: %d bytes left over" % (a.size - p))
+    return b"".join(out)
+
+
 def _exr_attr(name: bytes, typ: bytes, payload: bytes) -> bytes:
     return name + b"\0" + typ + b"\0" + struct.pack("<i", len(payload)) + payload
 
 
 def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = False):
     """channels: name -> (H, W) array (row 0 = bottom); e.g. {"R": .., "G": .., "B": ..} or layered AOVs {"normal.X": .., "depth.Z": ..}.
-    float32 (or half=True: binary16) samples, scanline file, compression "none" | "zips" | "zip" | "piz"."""
+    float32 (or half=True: binary16) samples, scanline file, compression "none" | "rle" | "zips" | "zip" | "piz" | "pxr24" (the last one
+    keeps 24 bits of a float32 sample: lossy)."""
     names = sorted(channels)  # the format requires alphabetical channel order
     planes = [np.asarray(channels[n]) for n in names]
     H, W = planes[0].shape
     pt = _PT_HALF if half else _PT_FLOAT
-    comp = {"none": _COMP_NONE, "zips": _COMP_ZIPS, "zip": _COMP_ZIP, "piz": _COMP_PIZ}[compression]
+    comp = {"none": _COMP_NONE, "rle": _COMP_RLE, "zips": _COMP_ZIPS, "zip": _COMP_ZIP, "piz": _COMP_PIZ, "pxr24": _COMP_PXR24}[compression]
     chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", pt, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
     box = struct.pack("<iiii", 0, 0, W - 1, H - 1)
     header = (b"\x76\x2f\x31\x01" + struct.pack("<i", 2) +
@@ -544,7 +659,7 @@ def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = 
               _exr_attr(b"dataWindow", b"box2i", box) + _exr_attr(b"displayWindow", b"box2i", box) +
               _exr_attr(b"lineOrder", b"lineOrder", b"\0") + _exr_attr(b"pixelAspectRatio", b"float", struct.pack("<f", 1.0)) +
               _exr_attr(b"screenWindowCenter", b"v2f", struct.pack("<ff", 0.0, 0.0)) + _exr_attr(b"screenWindowWidth", b"float", struct.pack("<f", 1.0)) + b"\0")
-    per_block = {_COMP_NONE: 1, _COMP_ZIPS: 1, _COMP_ZIP: 16, _COMP_PIZ: 32}[comp]
+    per_block = {_COMP_NONE: 1, _COMP_RLE: 1, _COMP_ZIPS: 1, _COMP_ZIP: 16, _COMP_PIZ: 32, _COMP_PXR24: 16}[comp]
     dt = _PT_DTYPE[pt]
     chans = [(n, pt) for n in names]
     top_down = [np.ascontiguousarray(p[::-1].astype(dt)) for p in planes]  # EXR y = 0 is the TOP row
@@ -557,11 +672,12 @@ def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = 
             if len(packed) < len(raw):
                 raw = packed
         elif comp != _COMP_NONE:
-            a = np.frombuffer(raw, np.uint8)
-            re = np.concatenate([a[0::2], a[1::2]])  # reorder: even bytes, then odd bytes
-            d = re.astype(np.int16)
-            d[1:] = d[1:] - re[:-1].astype(np.int16) + 128  # predictor
-            packed = zlib.compress((d & 255).astype(np.uint8).tobytes(), 4)
+            if comp == _COMP_PXR24:
+                packed = _pxr24_compress_block(raw, chans, W, y1 - y0)
+            elif comp == _COMP_RLE:
+                packed = _rle_compress(_exr_predict(raw))
+            else:
+                packed = zlib.compress(_exr_predict(raw), 4)
             if len(packed) < len(raw):
                 raw = packed
         blocks.append(struct.pack("<ii", y0, len(raw)) + raw)
@@ -578,8 +694,9 @@ def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = 
 
 
 def read_exr(path: str) -> dict:
-    """-> {channel name: (H, W) float32 (UINT channels: uint32)}, row 0 = bottom.  Single-part scanline files, compression NONE / ZIPS / ZIP /
-    PIZ (the format's default), no subsampling — what renderers write for AOV passes by default."""
+    """-> {channel name: (H, W) float32 (UINT channels: uint32)}, row 0 = bottom.  Single-part scanline files, compression NONE / RLE / ZIPS /
+    ZIP / PIZ (the format's default) / PXR24, no subsampling — every lossless scheme of the format plus PXR24; the lossy block codecs for
+    beauty passes (B44, DWA) are refused."""
     with open(path, "rb") as f:
         d = f.read()
     if d[:4] != b"\x76\x2f\x31\x01":
@@ -602,11 +719,11 @@ def read_exr(path: str) -> dict:
             raise ValueError("%s: subsampled channels are not supported" % path)
         chans.append((nm, pt))
     comp = attrs[b"compression"][1][0]
-    if comp not in (_COMP_NONE, _COMP_ZIPS, _COMP_ZIP, _COMP_PIZ):
-        raise ValueError("%s: compression %d not supported (NONE / ZIPS / ZIP / PIZ are)" % (path, comp))
+    if comp not in (_COMP_NONE, _COMP_RLE, _COMP_ZIPS, _COMP_ZIP, _COMP_PIZ, _COMP_PXR24):
+        raise ValueError("%s: compression %d not supported (NONE / RLE / ZIPS / ZIP / PIZ / PXR24 are)" % (path, comp))
     x0, y0, x1, y1 = struct.unpack("<iiii", attrs[b"dataWindow"][1])
     W, H = x1 - x0 + 1, y1 - y0 + 1
-    per_block = {_COMP_ZIP: 16, _COMP_PIZ: 32}.get(comp, 1)
+    per_block = {_COMP_ZIP: 16, _COMP_PIZ: 32, _COMP_PXR24: 16}.get(comp, 1)
     nblocks = (H + per_block - 1) // per_block
     offs = struct.unpack("<%dQ" % nblocks, d[pos:pos + 8 * nblocks])
     out = {nm: np.empty((H, W), np.uint32 if pt == _PT_UINT else np.float32) for nm, pt in chans}
@@ -617,13 +734,12 @@ def read_exr(path: str) -> dict:
         raw = d[o + 8:o + 8 + n]
         if comp == _COMP_PIZ and n < rows * line_bytes:
             raw = _piz_uncompress_block(raw, chans, W, rows)
+        elif comp == _COMP_PXR24 and n < rows * line_bytes:
+            raw = _pxr24_uncompress_block(raw, chans, W, rows)
+        elif comp == _COMP_RLE and n < rows * line_bytes:
+            raw = _exr_unpredict(_rle_uncompress(raw, rows * line_bytes))
         elif comp != _COMP_NONE and n < rows * line_bytes:
-            a = np.frombuffer(zlib.decompress(raw), np.uint8).astype(np.int32)
-            a = ((np.cumsum(a - 128) + 128) & 255).astype(np.uint8)  # undo the predictor: t[i] = t[i-1] + d[i] - 128, t[0] = d[0]
-            half_n = (a.size + 1) // 2
-            re = np.empty(a.size, np.uint8)
-            re[0::2], re[1::2] = a[:half_n], a[half_n:]
-            raw = re.tobytes()
+            raw = _exr_unpredict(zlib.decompress(raw))
         p = 0
         for r in range(rows):
             y = by - y0 + r

@@ -16,7 +16,8 @@ def test_exr_round_trip_all_compressions(tmp_path):
     H, W = 37, 53
     ch = {"diffuse.R": rng.rand(H, W).astype(np.float32), "normal.X": rng.rand(H, W).astype(np.float32) * 2 - 1,
           "depth.Z": rng.rand(H, W).astype(np.float32) * 1e3}
-    for comp in ("none", "zips", "zip", "piz"):
+    ch["normal.X"][4:9, 10:40] = 0.25  # constant stretches: the run-length paths
+    for comp in ("none", "rle", "zips", "zip", "piz", "pxr24"):
         for half in (False, True):
             p = str(tmp_path / "t.exr")
             imageio.write_exr(p, ch, comp, half)
@@ -24,7 +25,29 @@ def test_exr_round_trip_all_compressions(tmp_path):
             assert sorted(r) == sorted(ch)
             for k in ch:
                 want = ch[k].astype(np.float16).astype(np.float32) if half else ch[k]
+                if comp == "pxr24" and not half:  # the one lossy case: a float32 sample keeps 24 bits (15 of mantissa), rounded
+                    want = (imageio._float_to_f24(ch[k]) << np.uint32(8)).view(np.float32)
+                    assert (np.abs(want - ch[k]) <= np.abs(ch[k]) * 2.0 ** -15).all()
                 assert np.array_equal(r[k], want), (comp, half, k)
+
+
+def test_exr_rle_and_pxr24_known_answers():
+    """The two simple codecs against hand-made streams (the formats' definitions, not this module's encoders)."""
+    # RLE: a count byte n >= 0 repeats the next byte n + 1 times, n < 0 copies -n literal bytes
+    stream = bytes([2, 7, 0xFD, 1, 2, 3, 0, 9, 127, 5])
+    assert imageio._rle_uncompress(stream, 3 + 3 + 1 + 128) == bytes([7, 7, 7, 1, 2, 3, 9] + [5] * 128)
+    with pytest.raises(ValueError):
+        imageio._rle_uncompress(stream, 10)
+    data = bytes([1, 1, 1, 1, 2, 3, 3, 4, 4, 4] + [8] * 300 + [1, 2])
+    assert imageio._rle_uncompress(imageio._rle_compress(data), len(data)) == data
+    # float -> 24 bits: sign, exponent, 15 mantissa bits rounded half up; never rounds a finite value into infinity; NaN stays NaN
+    f = np.array([1.0, -2.0, np.inf, -np.inf, np.nan, 3.4028234e38, 1.0 + 2.0 ** -16, 1.0 + 2.0 ** -17], np.float32)
+    assert [hex(v) for v in imageio._float_to_f24(f)] == ["0x3f8000", "0xc00000", "0x7f8000", "0xff8000", "0x7fc000", "0x7f7fff", "0x3f8001", "0x3f8000"]
+    # one scanline, one HALF channel of 4 samples 1, 3, 3, 0x0102: differences 1, 2, 0, 0x00ff as a high-byte plane then a low-byte plane
+    import zlib
+    blk = zlib.compress(bytes([0, 0, 0, 0, 1, 2, 0, 0xFF]))
+    raw = imageio._pxr24_uncompress_block(blk, [("c", imageio._PT_HALF)], 4, 1)
+    assert np.array_equal(np.frombuffer(raw, np.uint16), [1, 3, 3, 0x0102])
 
 
 def test_exr_piz_codec(tmp_path):
