@@ -639,14 +639,42 @@ def _pxr24_uncompress_block(buf: bytes, chans, W: int, rows: int) -> bytes:
     return b"".join(out)
 
 
+def _exr_pack_block(raw: bytes, comp: int, chans, W: int, rows: int) -> bytes:
+    """one chunk's scanline-interleaved samples (per line: every channel's W samples) -> what the file stores (raw when that is not smaller)"""
+    if comp == _COMP_NONE:
+        return raw
+    if comp == _COMP_PIZ:
+        packed = _piz_compress_block(raw, chans, W, rows)
+    elif comp == _COMP_PXR24:
+        packed = _pxr24_compress_block(raw, chans, W, rows)
+    elif comp == _COMP_RLE:
+        packed = _rle_compress(_exr_predict(raw))
+    else:
+        packed = zlib.compress(_exr_predict(raw), 4)
+    return packed if len(packed) < len(raw) else raw
+
+
+def _exr_unpack_block(buf: bytes, comp: int, chans, W: int, rows: int, nbytes: int) -> bytes:
+    if comp == _COMP_NONE or len(buf) >= nbytes:  # (a chunk that did not shrink is stored as it is)
+        return buf
+    if comp == _COMP_PIZ:
+        return _piz_uncompress_block(buf, chans, W, rows)
+    if comp == _COMP_PXR24:
+        return _pxr24_uncompress_block(buf, chans, W, rows)
+    if comp == _COMP_RLE:
+        return _exr_unpredict(_rle_uncompress(buf, nbytes))
+    return _exr_unpredict(zlib.decompress(buf))
+
+
 def _exr_attr(name: bytes, typ: bytes, payload: bytes) -> bytes:
     return name + b"\0" + typ + b"\0" + struct.pack("<i", len(payload)) + payload
 
 
-def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = False):
+def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = False, tiles=None):
     """channels: name -> (H, W) array (row 0 = bottom); e.g. {"R": .., "G": .., "B": ..} or layered AOVs {"normal.X": .., "depth.Z": ..}.
-    float32 (or half=True: binary16) samples, scanline file, compression "none" | "rle" | "zips" | "zip" | "piz" | "pxr24" (the last one
-    keeps 24 bits of a float32 sample: lossy)."""
+    float32 (or half=True: binary16) samples, compression "none" | "rle" | "zips" | "zip" | "piz" | "pxr24" (the last one keeps 24 bits
+    of a float32 sample: lossy).  A scanline file, or with tiles=(tile_w, tile_h) a single-level tiled one (what some renderers write
+    by default)."""
     names = sorted(channels)  # the format requires alphabetical channel order
     planes = [np.asarray(channels[n]) for n in names]
     H, W = planes[0].shape
@@ -654,33 +682,31 @@ def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = 
     comp = {"none": _COMP_NONE, "rle": _COMP_RLE, "zips": _COMP_ZIPS, "zip": _COMP_ZIP, "piz": _COMP_PIZ, "pxr24": _COMP_PXR24}[compression]
     chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", pt, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
     box = struct.pack("<iiii", 0, 0, W - 1, H - 1)
-    header = (b"\x76\x2f\x31\x01" + struct.pack("<i", 2) +
+    header = (b"\x76\x2f\x31\x01" + struct.pack("<i", 2 | (0x200 if tiles else 0)) +
               _exr_attr(b"channels", b"chlist", chlist) + _exr_attr(b"compression", b"compression", bytes([comp])) +
               _exr_attr(b"dataWindow", b"box2i", box) + _exr_attr(b"displayWindow", b"box2i", box) +
               _exr_attr(b"lineOrder", b"lineOrder", b"\0") + _exr_attr(b"pixelAspectRatio", b"float", struct.pack("<f", 1.0)) +
-              _exr_attr(b"screenWindowCenter", b"v2f", struct.pack("<ff", 0.0, 0.0)) + _exr_attr(b"screenWindowWidth", b"float", struct.pack("<f", 1.0)) + b"\0")
-    per_block = {_COMP_NONE: 1, _COMP_RLE: 1, _COMP_ZIPS: 1, _COMP_ZIP: 16, _COMP_PIZ: 32, _COMP_PXR24: 16}[comp]
+              _exr_attr(b"screenWindowCenter", b"v2f", struct.pack("<ff", 0.0, 0.0)) + _exr_attr(b"screenWindowWidth", b"float", struct.pack("<f", 1.0)) +
+              (_exr_attr(b"tiles", b"tiledesc", struct.pack("<IIB", tiles[0], tiles[1], 0)) if tiles else b"") + b"\0")
     dt = _PT_DTYPE[pt]
     chans = [(n, pt) for n in names]
     top_down = [np.ascontiguousarray(p[::-1].astype(dt)) for p in planes]  # EXR y = 0 is the TOP row
     blocks = []
-    for y0 in range(0, H, per_block):
-        y1 = min(H, y0 + per_block)
-        raw = b"".join(tp[y].tobytes() for y in range(y0, y1) for tp in top_down)
-        if comp == _COMP_PIZ:
-            packed = _piz_compress_block(raw, chans, W, y1 - y0)
-            if len(packed) < len(raw):
-                raw = packed
-        elif comp != _COMP_NONE:
-            if comp == _COMP_PXR24:
-                packed = _pxr24_compress_block(raw, chans, W, y1 - y0)
-            elif comp == _COMP_RLE:
-                packed = _rle_compress(_exr_predict(raw))
-            else:
-                packed = zlib.compress(_exr_predict(raw), 4)
-            if len(packed) < len(raw):
-                raw = packed
-        blocks.append(struct.pack("<ii", y0, len(raw)) + raw)
+    if tiles:
+        tw, th = tiles
+        for ty in range((H + th - 1) // th):
+            for tx in range((W + tw - 1) // tw):
+                y0, y1, x0, x1 = ty * th, min(H, ty * th + th), tx * tw, min(W, tx * tw + tw)
+                raw = b"".join(tp[y, x0:x1].tobytes() for y in range(y0, y1) for tp in top_down)
+                raw = _exr_pack_block(raw, comp, chans, x1 - x0, y1 - y0)
+                blocks.append(struct.pack("<iiiii", tx, ty, 0, 0, len(raw)) + raw)
+    else:
+        per_block = {_COMP_NONE: 1, _COMP_RLE: 1, _COMP_ZIPS: 1, _COMP_ZIP: 16, _COMP_PIZ: 32, _COMP_PXR24: 16}[comp]
+        for y0 in range(0, H, per_block):
+            y1 = min(H, y0 + per_block)
+            raw = b"".join(tp[y].tobytes() for y in range(y0, y1) for tp in top_down)
+            raw = _exr_pack_block(raw, comp, chans, W, y1 - y0)
+            blocks.append(struct.pack("<ii", y0, len(raw)) + raw)
     table_pos = len(header)
     offs, pos = [], table_pos + 8 * len(blocks)
     for b in blocks:
@@ -694,16 +720,17 @@ def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = 
 
 
 def read_exr(path: str) -> dict:
-    """-> {channel name: (H, W) float32 (UINT channels: uint32)}, row 0 = bottom.  Single-part scanline files, compression NONE / RLE / ZIPS /
-    ZIP / PIZ (the format's default) / PXR24, no subsampling — every lossless scheme of the format plus PXR24; the lossy block codecs for
+    """-> {channel name: (H, W) float32 (UINT channels: uint32)}, row 0 = bottom.  Single-part scanline or tiled files (level 0 of a
+    mip-mapped one), compression NONE / RLE / ZIPS / ZIP / PIZ (the format's default) / PXR24, no subsampling — every lossless scheme of the format plus PXR24; the lossy block codecs for
     beauty passes (B44, DWA) are refused."""
     with open(path, "rb") as f:
         d = f.read()
     if d[:4] != b"\x76\x2f\x31\x01":
         raise ValueError("%s: not an OpenEXR file" % path)
     version = struct.unpack("<i", d[4:8])[0]
-    if version & 0x1A00:  # tiled / deep / multipart bits
-        raise ValueError("%s: only single-part scanline EXR is supported" % path)
+    if version & 0x1800:  # deep / multipart bits
+        raise ValueError("%s: only single-part flat EXR (scanline or tiled) is supported" % path)
+    tiled = bool(version & 0x200)
     pos, attrs = 8, {}
     while d[pos] != 0:
         e = d.index(b"\0", pos); name = d[pos:e]; pos = e + 1
@@ -723,30 +750,35 @@ def read_exr(path: str) -> dict:
         raise ValueError("%s: compression %d not supported (NONE / RLE / ZIPS / ZIP / PIZ / PXR24 are)" % (path, comp))
     x0, y0, x1, y1 = struct.unpack("<iiii", attrs[b"dataWindow"][1])
     W, H = x1 - x0 + 1, y1 - y0 + 1
-    per_block = {_COMP_ZIP: 16, _COMP_PIZ: 32, _COMP_PXR24: 16}.get(comp, 1)
-    nblocks = (H + per_block - 1) // per_block
-    offs = struct.unpack("<%dQ" % nblocks, d[pos:pos + 8 * nblocks])
     out = {nm: np.empty((H, W), np.uint32 if pt == _PT_UINT else np.float32) for nm, pt in chans}
-    line_bytes = sum(W * np.dtype(_PT_DTYPE[pt]).itemsize for _, pt in chans)
-    for o in offs:
-        by, n = struct.unpack("<ii", d[o:o + 8])
-        rows = min(per_block, y1 - by + 1)
-        raw = d[o + 8:o + 8 + n]
-        if comp == _COMP_PIZ and n < rows * line_bytes:
-            raw = _piz_uncompress_block(raw, chans, W, rows)
-        elif comp == _COMP_PXR24 and n < rows * line_bytes:
-            raw = _pxr24_uncompress_block(raw, chans, W, rows)
-        elif comp == _COMP_RLE and n < rows * line_bytes:
-            raw = _exr_unpredict(_rle_uncompress(raw, rows * line_bytes))
-        elif comp != _COMP_NONE and n < rows * line_bytes:
-            raw = _exr_unpredict(zlib.decompress(raw))
+    px_bytes = sum(np.dtype(_PT_DTYPE[pt]).itemsize for _, pt in chans)
+
+    def scatter(raw, bx, by, cols, rows):  # a chunk's samples (per line: every channel's `cols` samples) into the planes
         p = 0
         for r in range(rows):
-            y = by - y0 + r
             for nm, pt in chans:
                 dt = np.dtype(_PT_DTYPE[pt])
-                out[nm][H - 1 - y] = np.frombuffer(raw, dt, W, p)
-                p += W * dt.itemsize
+                out[nm][H - 1 - (by + r), bx:bx + cols] = np.frombuffer(raw, dt, cols, p)
+                p += cols * dt.itemsize
+
+    if tiled:
+        tw, th, mode = struct.unpack("<IIB", attrs[b"tiles"][1][:9])
+        if mode & 15 == 2:
+            raise ValueError("%s: rip-mapped tiles are not supported" % path)
+        ntx, nty = (W + tw - 1) // tw, (H + th - 1) // th  # level 0 comes first in the offset table (the only level, or the mip chain's base)
+        for o in struct.unpack("<%dQ" % (ntx * nty), d[pos:pos + 8 * ntx * nty]):
+            tx, ty, lx, ly, n = struct.unpack("<iiiii", d[o:o + 20])
+            if lx or ly or not (0 <= tx < ntx and 0 <= ty < nty):
+                raise ValueError("%s: unexpected tile (%d, %d) of level (%d, %d)" % (path, tx, ty, lx, ly))
+            cols, rows = min(tw, W - tx * tw), min(th, H - ty * th)
+            scatter(_exr_unpack_block(d[o + 20:o + 20 + n], comp, chans, cols, rows, cols * rows * px_bytes), tx * tw, ty * th, cols, rows)
+        return out
+    per_block = {_COMP_ZIP: 16, _COMP_PIZ: 32, _COMP_PXR24: 16}.get(comp, 1)
+    nblocks = (H + per_block - 1) // per_block
+    for o in struct.unpack("<%dQ" % nblocks, d[pos:pos + 8 * nblocks]):
+        by, n = struct.unpack("<ii", d[o:o + 8])
+        rows = min(per_block, y1 - by + 1)
+        scatter(_exr_unpack_block(d[o + 8:o + 8 + n], comp, chans, W, rows, rows * W * px_bytes), 0, by - y0, W, rows)
     return out
 
 

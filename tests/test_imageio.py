@@ -31,6 +31,22 @@ def test_exr_round_trip_all_compressions(tmp_path):
                 assert np.array_equal(r[k], want), (comp, half, k)
 
 
+def test_exr_tiled_round_trip(tmp_path):
+    """single-level tiled files (some renderers' default): ragged last tiles in both directions, every codec, tile chunks in file order"""
+    rng = np.random.RandomState(2)
+    H, W = 37, 53
+    ch = {"depth.Z": rng.rand(H, W).astype(np.float32), "id.Y": np.repeat(rng.rand(H, 1).astype(np.float32), W, axis=1)}
+    for comp in ("none", "rle", "zips", "zip", "piz", "pxr24"):
+        for tiles in ((16, 8), (64, 64), (5, 37)):
+            p = str(tmp_path / "t.exr")
+            imageio.write_exr(p, ch, comp, half=True, tiles=tiles)
+            r = imageio.read_exr(p)
+            for k in ch:
+                assert np.array_equal(r[k], ch[k].astype(np.float16).astype(np.float32)), (comp, tiles, k)
+    imageio.write_exr(p, ch, "zip", tiles=(16, 16))
+    assert np.array_equal(imageio.read_exr(p)["depth.Z"], ch["depth.Z"])
+
+
 def test_exr_rle_and_pxr24_known_answers():
     """The two simple codecs against hand-made streams (the formats' definitions, not this module's encoders)."""
     # RLE: a count byte n >= 0 repeats the next byte n + 1 times, n < 0 copies -n literal bytes
