@@ -719,25 +719,18 @@ def write_exr(path: str, channels: dict, compression: str = "zip", half: bool = 
             f.write(b)
 
 
-def read_exr(path: str) -> dict:
-    """-> {channel name: (H, W) float32 (UINT channels: uint32)}, row 0 = bottom.  Single-part scanline or tiled files (level 0 of a
-    mip-mapped one), compression NONE / RLE / ZIPS / ZIP / PIZ (the format's default) / PXR24, no subsampling — every lossless scheme of the format plus PXR24; the lossy block codecs for
-    beauty passes (B44, DWA) are refused."""
-    with open(path, "rb") as f:
-        d = f.read()
-    if d[:4] != b"\x76\x2f\x31\x01":
-        raise ValueError("%s: not an OpenEXR file" % path)
-    version = struct.unpack("<i", d[4:8])[0]
-    if version & 0x1800:  # deep / multipart bits
-        raise ValueError("%s: only single-part flat EXR (scanline or tiled) is supported" % path)
-    tiled = bool(version & 0x200)
-    pos, attrs = 8, {}
+def _exr_parse_header(d: bytes, pos: int):
+    """-> (attributes {name: (type, payload)}, position after the header's terminating zero)"""
+    attrs = {}
     while d[pos] != 0:
         e = d.index(b"\0", pos); name = d[pos:e]; pos = e + 1
         e = d.index(b"\0", pos); typ = d[pos:e]; pos = e + 1
         n = struct.unpack("<i", d[pos:pos + 4])[0]; pos += 4
         attrs[name] = (typ, d[pos:pos + n]); pos += n
-    pos += 1
+    return attrs, pos + 1
+
+
+def _exr_part_layout(path, attrs, tiled):
     chans, p, cl = [], 0, attrs[b"channels"][1]
     while cl[p] != 0:
         e = cl.index(b"\0", p); nm = cl[p:e].decode(); p = e + 1
@@ -750,6 +743,30 @@ def read_exr(path: str) -> dict:
         raise ValueError("%s: compression %d not supported (NONE / RLE / ZIPS / ZIP / PIZ / PXR24 are)" % (path, comp))
     x0, y0, x1, y1 = struct.unpack("<iiii", attrs[b"dataWindow"][1])
     W, H = x1 - x0 + 1, y1 - y0 + 1
+    lay = dict(chans=chans, comp=comp, W=W, H=H, y0=y0, y1=y1, tiled=tiled)
+    if tiled:
+        tw, th, mode = struct.unpack("<IIB", attrs[b"tiles"][1][:9])
+        if mode & 15 == 2:
+            raise ValueError("%s: rip-mapped tiles are not supported" % path)
+        lay.update(tw=tw, th=th, ntx=(W + tw - 1) // tw, nty=(H + th - 1) // th)
+        lay["level0_chunks"] = lay["ntx"] * lay["nty"]  # level 0 comes first in the offset table (the only level, or the mip chain's base)
+        lay["chunks"] = struct.unpack("<i", attrs[b"chunkCount"][1])[0] if b"chunkCount" in attrs else lay["level0_chunks"]
+        if (mode & 15) and b"chunkCount" not in attrs:  # a single-part mip-mapped file: the table's length follows from the level sizes
+            n, w, h, up = 0, W, H, mode >> 4
+            while True:
+                n += ((w + tw - 1) // tw) * ((h + th - 1) // th)
+                if w == 1 and h == 1:
+                    break
+                w, h = max(1, (w + up) // 2), max(1, (h + up) // 2)
+            lay["chunks"] = n
+    else:
+        lay["per_block"] = {_COMP_ZIP: 16, _COMP_PIZ: 32, _COMP_PXR24: 16}.get(comp, 1)
+        lay["chunks"] = lay["level0_chunks"] = (H + lay["per_block"] - 1) // lay["per_block"]
+    return lay
+
+
+def _exr_read_part(path, d, lay, table_pos, part_prefix):
+    chans, comp, W, H = lay["chans"], lay["comp"], lay["W"], lay["H"]
     out = {nm: np.empty((H, W), np.uint32 if pt == _PT_UINT else np.float32) for nm, pt in chans}
     px_bytes = sum(np.dtype(_PT_DTYPE[pt]).itemsize for _, pt in chans)
 
@@ -761,25 +778,97 @@ def read_exr(path: str) -> dict:
                 out[nm][H - 1 - (by + r), bx:bx + cols] = np.frombuffer(raw, dt, cols, p)
                 p += cols * dt.itemsize
 
-    if tiled:
-        tw, th, mode = struct.unpack("<IIB", attrs[b"tiles"][1][:9])
-        if mode & 15 == 2:
-            raise ValueError("%s: rip-mapped tiles are not supported" % path)
-        ntx, nty = (W + tw - 1) // tw, (H + th - 1) // th  # level 0 comes first in the offset table (the only level, or the mip chain's base)
-        for o in struct.unpack("<%dQ" % (ntx * nty), d[pos:pos + 8 * ntx * nty]):
+    for o in struct.unpack("<%dQ" % lay["level0_chunks"], d[table_pos:table_pos + 8 * lay["level0_chunks"]]):
+        o += part_prefix  # (multi-part files: every chunk starts with its part number)
+        if lay["tiled"]:
             tx, ty, lx, ly, n = struct.unpack("<iiiii", d[o:o + 20])
-            if lx or ly or not (0 <= tx < ntx and 0 <= ty < nty):
+            if lx or ly or not (0 <= tx < lay["ntx"] and 0 <= ty < lay["nty"]):
                 raise ValueError("%s: unexpected tile (%d, %d) of level (%d, %d)" % (path, tx, ty, lx, ly))
-            cols, rows = min(tw, W - tx * tw), min(th, H - ty * th)
-            scatter(_exr_unpack_block(d[o + 20:o + 20 + n], comp, chans, cols, rows, cols * rows * px_bytes), tx * tw, ty * th, cols, rows)
-        return out
-    per_block = {_COMP_ZIP: 16, _COMP_PIZ: 32, _COMP_PXR24: 16}.get(comp, 1)
-    nblocks = (H + per_block - 1) // per_block
-    for o in struct.unpack("<%dQ" % nblocks, d[pos:pos + 8 * nblocks]):
-        by, n = struct.unpack("<ii", d[o:o + 8])
-        rows = min(per_block, y1 - by + 1)
-        scatter(_exr_unpack_block(d[o + 8:o + 8 + n], comp, chans, W, rows, rows * W * px_bytes), 0, by - y0, W, rows)
+            cols, rows = min(lay["tw"], W - tx * lay["tw"]), min(lay["th"], H - ty * lay["th"])
+            scatter(_exr_unpack_block(d[o + 20:o + 20 + n], comp, chans, cols, rows, cols * rows * px_bytes), tx * lay["tw"], ty * lay["th"], cols, rows)
+        else:
+            by, n = struct.unpack("<ii", d[o:o + 8])
+            rows = min(lay["per_block"], lay["y1"] - by + 1)
+            scatter(_exr_unpack_block(d[o + 8:o + 8 + n], comp, chans, W, rows, rows * W * px_bytes), 0, by - lay["y0"], W, rows)
     return out
+
+
+def read_exr(path: str) -> dict:
+    """-> {channel name: (H, W) float32 (UINT channels: uint32)}, row 0 = bottom.  Flat images: scanline or tiled (level 0 of a mip-mapped
+    one), single-part or multi-part, compression NONE / RLE / ZIPS / ZIP / PIZ (the format's default) / PXR24, no subsampling — every
+    lossless scheme of the format plus PXR24; the lossy block codecs for beauty passes (B44, DWA) and deep data are refused.
+    Multi-part files (one AOV per part is common): a part's channels come back as "<part name>.<channel>" unless the channel name already
+    carries a layer prefix; all parts must have the same size."""
+    with open(path, "rb") as f:
+        d = f.read()
+    if d[:4] != b"\x76\x2f\x31\x01":
+        raise ValueError("%s: not an OpenEXR file" % path)
+    version = struct.unpack("<i", d[4:8])[0]
+    if version & 0x800:
+        raise ValueError("%s: deep data is not supported" % path)
+    if not version & 0x1000:  # single part
+        attrs, pos = _exr_parse_header(d, 8)
+        return _exr_read_part(path, d, _exr_part_layout(path, attrs, bool(version & 0x200)), pos, 0)
+    parts, pos = [], 8
+    while d[pos] != 0:  # headers until the empty one
+        attrs, pos = _exr_parse_header(d, pos)
+        typ = attrs.get(b"type", (b"", b"scanlineimage"))[1].rstrip(b"\0")
+        if typ not in (b"scanlineimage", b"tiledimage"):
+            raise ValueError("%s: part type %r is not supported" % (path, typ))
+        parts.append((attrs[b"name"][1].rstrip(b"\0").decode(), _exr_part_layout(path, attrs, typ == b"tiledimage")))
+    pos += 1
+    out = {}
+    for name, lay in parts:
+        planes = _exr_read_part(path, d, lay, pos, 4)
+        pos += 8 * lay["chunks"]
+        for ch, v in planes.items():
+            key = ch if ("." in ch or not name) else name + "." + ch
+            if key in out:
+                raise ValueError("%s: channel %s appears in two parts" % (path, key))
+            if out and v.shape != next(iter(out.values())).shape:
+                raise ValueError("%s: parts of different sizes" % path)
+            out[key] = v
+    return out
+
+
+def write_exr_multipart(path: str, parts: dict, compression: str = "zip", half: bool = False):
+    """parts: part name -> {channel: (H, W) array}: one scanline part per entry (how several renderers lay out AOVs)."""
+    comp = {"none": _COMP_NONE, "rle": _COMP_RLE, "zips": _COMP_ZIPS, "zip": _COMP_ZIP, "piz": _COMP_PIZ, "pxr24": _COMP_PXR24}[compression]
+    pt = _PT_HALF if half else _PT_FLOAT
+    dt = _PT_DTYPE[pt]
+    per_block = {_COMP_NONE: 1, _COMP_RLE: 1, _COMP_ZIPS: 1, _COMP_ZIP: 16, _COMP_PIZ: 32, _COMP_PXR24: 16}[comp]
+    headers, chunk_lists = b"", []
+    for k, (pname, channels) in enumerate(parts.items()):
+        names = sorted(channels)
+        planes = [np.ascontiguousarray(np.asarray(channels[n])[::-1].astype(dt)) for n in names]
+        H, W = planes[0].shape
+        chans = [(n, pt) for n in names]
+        chunks = []
+        for y0 in range(0, H, per_block):
+            y1 = min(H, y0 + per_block)
+            raw = _exr_pack_block(b"".join(tp[y].tobytes() for y in range(y0, y1) for tp in planes), comp, chans, W, y1 - y0)
+            chunks.append(struct.pack("<iii", k, y0, len(raw)) + raw)
+        chunk_lists.append(chunks)
+        chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", pt, 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+        box = struct.pack("<iiii", 0, 0, W - 1, H - 1)
+        headers += (_exr_attr(b"channels", b"chlist", chlist) + _exr_attr(b"chunkCount", b"int", struct.pack("<i", len(chunks))) +
+                    _exr_attr(b"compression", b"compression", bytes([comp])) + _exr_attr(b"dataWindow", b"box2i", box) +
+                    _exr_attr(b"displayWindow", b"box2i", box) + _exr_attr(b"lineOrder", b"lineOrder", b"\0") +
+                    _exr_attr(b"name", b"string", pname.encode()) + _exr_attr(b"pixelAspectRatio", b"float", struct.pack("<f", 1.0)) +
+                    _exr_attr(b"screenWindowCenter", b"v2f", struct.pack("<ff", 0.0, 0.0)) +
+                    _exr_attr(b"screenWindowWidth", b"float", struct.pack("<f", 1.0)) + _exr_attr(b"type", b"string", b"scanlineimage") + b"\0")
+    head = b"\x76\x2f\x31\x01" + struct.pack("<i", 2 | 0x1000) + headers + b"\0"
+    pos = len(head) + 8 * sum(len(c) for c in chunk_lists)
+    table = b""
+    for chunks in chunk_lists:
+        for c in chunks:
+            table += struct.pack("<Q", pos)
+            pos += len(c)
+    with open(path, "wb") as f:
+        f.write(head + table)
+        for chunks in chunk_lists:
+            for c in chunks:
+                f.write(c)
 
 
 # ------------------------------------------------------------------------------------------------ AOV EXR -> dump planes

@@ -47,6 +47,26 @@ def test_exr_tiled_round_trip(tmp_path):
     assert np.array_equal(imageio.read_exr(p)["depth.Z"], ch["depth.Z"])
 
 
+def test_exr_multipart_round_trip(tmp_path):
+    """one AOV per part: the parts' channels come back under "<part>.<channel>" (or as they are when they already carry a layer)"""
+    rng = np.random.RandomState(4)
+    H, W = 40, 33
+    parts = {"normal": {c: rng.rand(H, W).astype(np.float32) for c in "XYZ"}, "depth": {"Z": rng.rand(H, W).astype(np.float32)},
+             "extra": {"diffuse.R": rng.rand(H, W).astype(np.float32)}}
+    for comp in ("none", "zip", "piz"):
+        p = str(tmp_path / "m.exr")
+        imageio.write_exr_multipart(p, parts, comp)
+        r = imageio.read_exr(p)
+        assert sorted(r) == ["depth.Z", "diffuse.R", "normal.X", "normal.Y", "normal.Z"]
+        assert np.array_equal(r["normal.Y"], parts["normal"]["Y"]) and np.array_equal(r["depth.Z"], parts["depth"]["Z"])
+        assert np.array_equal(r["diffuse.R"], parts["extra"]["diffuse.R"])
+    with open(p, "r+b") as f:  # deep data stays refused
+        f.seek(4)
+        f.write((2 | 0x1800).to_bytes(4, "little"))
+    with pytest.raises(ValueError, match="deep"):
+        imageio.read_exr(p)
+
+
 def test_exr_rle_and_pxr24_known_answers():
     """The two simple codecs against hand-made streams (the formats' definitions, not this module's encoders)."""
     # RLE: a count byte n >= 0 repeats the next byte n + 1 times, n < 0 copies -n literal bytes
