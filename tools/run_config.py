@@ -25,8 +25,11 @@ def frame(i):
     fx.update(ctx, None)
 frame(0); frame(1); ctx.sync()
 ctx.time_begin()
+t = time.perf_counter()
 for i in range(nf): frame(1)
+host_ms = (time.perf_counter() - t) / nf * 1e3  # what the host needs to ISSUE a frame (the calls are asynchronous): above the device time = host-bound
 ms = ctx.time_end() / nf
+print("host issue time %.3f ms/frame" % host_ms)
 out = ctx.download(abi.TEX_COMPOSE)
 print("%dx%d steps %d/%d it %d: %.3f ms/frame  %.1f Mpix/s   compose finite=%s mean=%.4f  halo_violations=%d" % (
     W, H, steps, refine, it, ms, W * H / ms / 1e3, bool(np.isfinite(out).all()), float(out[..., :3].mean()), ctx.halo_violations()))
