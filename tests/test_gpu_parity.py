@@ -798,7 +798,7 @@ def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RFX_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
-    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--checksum", "--no-extras"]
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--checksum", "--no-extras", "--spinup", "0"]
     p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                          "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--width", "960", "--height", "540"] + common,
                         env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
