@@ -472,7 +472,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "stream_copy_GBs": copy_gbs,
                          "frac_of_stream_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                          "traffic": pmc_traffic(dom) if (W1, rows) == (W4K, H4K) else None,
-                         "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 from %s/pmc_hbm.csv (rocprofv3 --pmc, this command at 4K; collected at git %s)" % (
+                         "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 from %s/pmc_hbm.csv (rocprofv3 --pmc over the same kernels and arguments at 4K — tools/quick_time.py; this command's own FETCH_SIZE agrees to 0.1 %%, K2 2 %%: fetch_size_bench_command.csv; collected at git %s)" % (
                              PROFILE_DIR, prof.get("git_commit", "?")),
                          "algorithmic_bytes_per_launch": BYTES_PER_PX[dom] * px_tile, "avg_launch_ms": round(kms[dom], 4)},
             "halo_violations": viol,
@@ -483,7 +483,7 @@ def main():
             occ = {k: valu_occupancy(k) for k in kms}
             if all(v is not None for v in occ.values()):
                 out["valu"] = dict(occ, note="per kernel: valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8); valu_per_px = SQ_INSTS_VALU / SQ_WAVES; "
-                                             "cycles_per_valu = SQ_ACTIVE_INST_VALU*4 / SQ_INSTS_VALU — %s/pmc_sq_l2.csv (rocprofv3 --pmc, this command; collected at git %s)" % (
+                                             "cycles_per_valu = SQ_ACTIVE_INST_VALU*4 / SQ_INSTS_VALU — %s/pmc_sq_l2.csv (rocprofv3 --pmc over the same kernels and arguments, tools/quick_time.py; collected at git %s)" % (
                                                  PROFILE_DIR, prof.get("git_commit", "?")))
         if world > 1:
             out["config"]["exchange_verified"] = bool(use_c)  # the C-ABI exchanges passed their pre-flight pattern check on every rank
