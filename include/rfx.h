@@ -219,7 +219,9 @@ int rfx_tex_held_rows(const rfx_ctx *, rfx_tex id, int *row0, int *rows);
 int rfx_upload(rfx_ctx *, rfx_tex id, const void *host, int row0, int rows);
 int rfx_download(rfx_ctx *, rfx_tex id, void *host, int row0, int rows);
 int rfx_clear(rfx_ctx *, rfx_tex id); /* zero-fill (render targets start zeroed) */
-/* Device pointer of the first HELD row of a slot (for halo exchange / zero-copy interop). */
+/* Device pointer of the first HELD row of a slot (for halo exchange / zero-copy interop).  Work the caller enqueues on the buffer must be
+ * ordered against the context's draw stream (rfx_set_stream).  Taking RFX_TEX_DEPTH's pointer also moves K1's depth pre-pass from its own
+ * stream into the draw stream for the rest of the context's life, exactly as rfx_bind_external(RFX_TEX_DEPTH) does. */
 void *rfx_tex_device_ptr(rfx_ctx *, rfx_tex id);
 /* Use caller-owned device memory (held-rows x width x texel bytes) for a slot. */
 int rfx_bind_external(rfx_ctx *, rfx_tex id, void *device_ptr);

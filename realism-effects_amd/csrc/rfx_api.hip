@@ -47,6 +47,17 @@ rfx_ctx *rfx_create(int device, int width, int height, int tile_y0, int tile_row
     }
     hipMemset(c->halo_violations, 0, sizeof(unsigned int));
     c->stream = c->own_stream;
+    // K1's depth pre-pass stream and the events that order it, created HERE and not lazily by the first draw: every asynchronous writer of
+    // the depth slot (rfx_stage_flip, rfx_clear) records ev_depth from the first frame on, so the first pre-pass already waits for the
+    // first staged copy (round 3 created them inside the first rfx_ssgi_*: frame 0's pre-pass raced the copy that filled its input)
+    if (hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_depth, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_k1_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_prep_done, hipEventDisableTiming) != hipSuccess) {
+        fail(nullptr, RFX_EDEVICE, "rfx_create: K1 pre-pass stream/event creation failed");
+        rfx_destroy(c);
+        return nullptr;
+    }
     const int b0 = tile_y0 - halo_rows < 0 ? 0 : tile_y0 - halo_rows;
     const int b1 = tile_y0 + tile_rows + halo_rows > height ? height : tile_y0 + tile_rows + halo_rows;
     for (int i = 0; i < RFX_TEX_COUNT; i++) {
@@ -247,7 +258,7 @@ int rfx_stage_flip(rfx_ctx *c) {
     for (int id = 0; id < RFX_TEX_COUNT; id++) {
         Slot &s = c->slots[id];
         if (!s.back_filled) continue;
-        if (id == RFX_TEX_DEPTH && c->ev_depth) {  // the depth pre-pass of the next K1 waits for this copy on its own stream
+        if (id == RFX_TEX_DEPTH) {  // the depth pre-pass of the next K1 waits for this copy on its own stream
             HIPCHK(c, hipEventRecord(c->ev_depth, c->upload_stream));
             c->depth_event_set = true;
         }
@@ -265,7 +276,7 @@ int rfx_clear(rfx_ctx *c, rfx_tex id) {
     hipSetDevice(c->device);
     Slot &s = c->slots[id];
     HIPCHK(c, hipMemsetAsync(s.ptr, 0, (size_t)s.rows * s.width * s.texel, c->stream));
-    if (id == RFX_TEX_DEPTH && c->ev_depth) {
+    if (id == RFX_TEX_DEPTH) {
         HIPCHK(c, hipEventRecord(c->ev_depth, c->stream));
         c->depth_event_set = true;
     }
@@ -275,6 +286,9 @@ int rfx_clear(rfx_ctx *c, rfx_tex id) {
 void *rfx_tex_device_ptr(rfx_ctx *c, rfx_tex id) {
     if (!c || id < 0 || id >= RFX_TEX_COUNT) return nullptr;
     if (ensure(c, id)) return nullptr;
+    // whoever takes the depth plane's address may write it with work this library cannot see (ordered against the draw stream only, as a
+    // bound external buffer is): the pre-pass then stays in the draw stream
+    if (id == RFX_TEX_DEPTH) c->depth_external = true;
     return c->slots[id].ptr;
 }
 
@@ -639,13 +653,6 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
     // On its own stream (rfx_ctx.h prep_stream) unless the depth plane lives in a caller's buffer: after the depth plane's last writer and
     // after the previous K1 launch (which read the scratch planes), NOT after the draws queued since — it overlaps them.
     if (stage != 2) {
-        if (!c->prep_stream && !c->depth_external) {
-            hipError_t e = hipStreamCreateWithFlags(&c->prep_stream, hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_depth, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_k1_done, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_prep_done, hipEventDisableTiming);
-            if (e != hipSuccess) return fail(c, RFX_EDEVICE, "K1 pre-pass stream", e);
-        }
 #ifndef RFX_K1_PREP_STREAM
 #define RFX_K1_PREP_STREAM 1  // build knob: 0 = the pre-pass in the draw stream (A/B measurements)
 #endif
@@ -660,10 +667,8 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
         }
     }
     if (any) HIPCHK(c, rfx_launch_k1(A, stage, c->stream));
-    if (c->ev_k1_done) {  // the next pre-pass overwrites what this launch reads
-        HIPCHK(c, hipEventRecord(c->ev_k1_done, c->stream));
-        c->k1_event_set = true;
-    }
+    HIPCHK(c, hipEventRecord(c->ev_k1_done, c->stream));  // the next pre-pass overwrites what this launch reads
+    c->k1_event_set = true;
     c->hits_traced = stage == 1;
     if (stage == 1) { c->trace_y0 = A.y0; c->trace_y1 = any ? A.y1 : A.y0; c->trace_missed = p->missedRays; }
     return RFX_OK;

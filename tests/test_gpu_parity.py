@@ -671,18 +671,20 @@ def test_env_map_vs_oracle(blue_noise, env_blur, half):
     ctx.close()
 
 
-def test_streamed_dumps_equal_uploaded_dumps():
+@pytest.mark.parametrize("W,H,nframes", [(224, 126, 3), (3840, 2160, 2)])
+def test_streamed_dumps_equal_uploaded_dumps(W, H, nframes):
     """rfx.h "streaming dumps": frame n+1's planes are staged (pinned host memory, upload stream) while frame n is drawn and published
-    by rfx_stage_flip — three frames through SSGIEffect give the same textures, bit for bit, as the synchronous rfx_upload path; a
-    pageable plane is accepted too."""
+    by rfx_stage_flip — the frames through SSGIEffect give the same textures, bit for bit, as the synchronous rfx_upload path; a
+    pageable plane is accepted too.  The 4K case is there for the FIRST frame: its 33 MB depth copy is still in flight when the host
+    issues the first draw, and K1's depth pre-pass (its own stream) must wait for it (the pre-pass stream and its events
+    used to be created by the first draw, after the first flip had nothing to record)."""
     import types
     from rfx_amd import abi
     from rfx_amd.context import Context, RfxError
     from rfx_amd.effect import SSGIEffect
     from rfx_amd.scene import synthetic_frame
 
-    W, H = 224, 126
-    frames = [synthetic_frame(W, H, i) for i in range(3)]
+    frames = [synthetic_frame(W, H, i) for i in range(nframes)]
 
     def run(streamed):
         ctx = Context(W, H)
