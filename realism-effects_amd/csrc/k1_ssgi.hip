@@ -87,7 +87,9 @@ RFX_DEV float2 k1_project(const MarchCtx &m, float3 p) {
         px = pc.x; py = pc.y; pw = pc.w;
     }
     const float r = rfx_rcp(pw);
-    return make_float2(k1_div(px, pw, r) * 0.5f + 0.5f, k1_div(py, pw, r) * 0.5f + 0.5f);
+    // q * 0.5 + 0.5 as ONE fma: the product by 0.5 is exact (or so small that the sum is 0.5 either way), so the fused form rounds once, to
+    // the same value (this file is compiled without contraction: the compiler may not make that step itself)
+    return make_float2(__builtin_fmaf(k1_div(px, pw, r), 0.5f, 0.5f), __builtin_fmaf(k1_div(py, pw, r), 0.5f, 0.5f));
 }
 
 struct Tap {
@@ -119,67 +121,101 @@ RFX_DEV void k1_taps(const MarchCtx &m, const FrameDims &d, const float2 (&uv)[2
         tap[1] = k1_tap_at(m, d, (int)__builtin_amdgcn_fmed3f(cx1, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy1, 0.0f, hm1));
     }
 }
-// RayMarch (:441-475) + BinarySearch (:477-503) for the pixel's TWO rays at once (slot 0 = optional diffuse ray,
-// slot 1 = specular ray), restructured for the SIMT machine without changing any per-ray arithmetic:
-//   * both rays advance in the same loop iteration (they share cs(i), and their taps are in flight together);
-//   * a ray that finds a hit only RECORDS it and stops marching; the binary search runs ONCE after the march loop for
-//     every ray that hit.  In the GLSL the search is nested in the march loop, so a wavefront whose lanes hit at k
-//     different steps executes the 5-step search k times with mostly idle lanes — here it is 19 + 5 iterations, always.
 struct Ray {
     float3 pos, dir;
     float2 uv;
-    bool active, hit;
+    float live;  // 1.0f while the ray marches, 0.0f once it has hit (or never existed): the step's scale factor, see k1_march_rays
+    bool hit;
 };
+#ifndef RFX_K1_CS1
+#define RFX_K1_CS1 1  // build knob: 0 = evaluate cs(i) in every step (A/B measurements; same texels either way)
+#endif
+#ifndef RFX_K1_WAVE_LOOP
+#define RFX_K1_WAVE_LOOP 1  // build knob: 1 = the march loops are wave-uniform (every lane steps until no lane of the wavefront has a live ray), 0 = per lane
+#endif
+#if RFX_K1_WAVE_LOOP
+#define K1_ANY_LIVE(rays) (__builtin_amdgcn_ballot_w64(((rays)[0].live != 0.0f) | ((rays)[1].live != 0.0f)) != 0)
+#else
+#define K1_ANY_LIVE(rays) (((rays)[0].live != 0.0f) | ((rays)[1].live != 0.0f))
+#endif
+#ifndef RFX_K1_GATHER_ALWAYS
+#define RFX_K1_GATHER_ALWAYS 0  // build knob: 1 = the exact texel is loaded in every step (texel 0 when the cell decides) instead of under an exec mask
+#endif
+// One march step of both rays.  CS1: the step's cs is exactly 1 (see below) — the position update is then pos + dir * live with an exact
+// product, i.e. ONE fma per coordinate with the same bits.
+template <int PROJ, bool CS1>
+RFX_DEV void k1_march_step(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2], float cs) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        // straight-line: a stopped ray advances by dir * 0 (pos + (+-0) == pos) and re-derives the same uv — no exec-mask region per ray
+        // (measured 0.654 vs 0.666 ms at 4K, same texels).  `live` is the select as a product: cs * 1 == cs, cs * 0 == +0 (cs is in [0, 1]).
+        if (CS1) {
+            rays[r].pos = make_float3(__builtin_fmaf(rays[r].dir.x, rays[r].live, rays[r].pos.x), __builtin_fmaf(rays[r].dir.y, rays[r].live, rays[r].pos.y),
+                                      __builtin_fmaf(rays[r].dir.z, rays[r].live, rays[r].pos.z));
+        } else {
+            const float csr = cs * rays[r].live;
+            rays[r].pos = rays[r].pos + rays[r].dir * csr;
+        }
+        rays[r].uv = k1_project<PROJ>(m, rays[r].pos);
+    }
+    // taps of both rays in flight together: the two coarse cells first, then the exact texels of the cells that cannot
+    // rule a hit out (a hit needs 0 <= z - h < thickness; the cell range rules it out when max - h < 0 or min - h >= thickness)
+    Tap tap[2];
+    float2 mm[2];
+    bool need[2];
+    {
+        const float2 uvs[2] = {rays[0].uv, rays[1].uv};
+        k1_taps(m, d, uvs, tap);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {  // (bitwise on purpose: no short-circuit branches in the loop)
+        const float h = rays[r].pos.z;
+        need[r] = (rays[r].live != 0.0f) & !((mm[r].y - h < 0.0f) | (mm[r].x - h >= m.thickness));
+    }
+    float z[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (RFX_K1_GATHER_ALWAYS) z[r] = rfx_gather<float>(m.viewz, need[r] ? tap[r].idx : 0u);
+        else z[r] = need[r] ? rfx_gather<float>(m.viewz, tap[r].idx) : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const float diff = z[r] - rays[r].pos.z;
+        rays[r].live = (need[r] & (diff >= 0.0f) & (diff < m.thickness)) ? 0.0f : rays[r].live;  // a hit: the ray stops here
+    }
+}
+// RayMarch (:441-475) + BinarySearch (:477-503) for the pixel's TWO rays at once (slot 0 = optional diffuse ray,
+// slot 1 = specular ray), restructured for the SIMT machine without changing any per-ray arithmetic:
+//   * both rays advance in the same loop iteration (they share cs(i), and their taps are in flight together);
+//   * a ray that finds a hit only stops marching (live = 0; "hit" = started and no longer live, derived once after the loop); the binary
+//     search runs ONCE after the march loop for every ray that hit.  In the GLSL the search is nested in the march loop, so a wavefront
+//     whose lanes hit at k different steps executes the 5-step search k times with mostly idle lanes — here it is 19 + 5 iterations, always;
+//   * cs(i) = 1 - exp(-t^2 / 4) with t = i + random.b - 0.5 >= i - 0.5 (:453-454): from i = 9 on, t >= 8.5 and exp(-t^2 / 4) <= 1.5e-8 <
+//     2^-25, so the subtraction rounds to exactly 1.0f — in the reference's fp32 as here — and `dir * cs` is `dir`: the second loop below
+//     evaluates no cs at all (no v_exp, no products), the same bits.
 template <int PROJ>
 RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2], float random_b) {
     const float scale = m.rayDistance / (float)m.steps;
+    const bool started[2] = {rays[0].live != 0.0f, true};  // (the specular ray always marches)
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         rays[r].dir = rays[r].dir * scale;
         rays[r].uv = make_float2(0.f, 0.f);
-        rays[r].hit = false;
     }
-    for (int i = 1; i < m.steps && (rays[0].active || rays[1].active); i++) {
+    const int split = RFX_K1_CS1 ? min(m.steps, 9) : m.steps;
+    int i = 1;
+    for (; i < split && K1_ANY_LIVE(rays); i++) {
         const float t = (float)i + random_b - 0.5f;
         // exp(-0.25 t^2) = exp2((-0.25 t^2) log2e): the scaling by -1/4 is exact, so it folds into the constant (one product instead of two,
         // the same bits)
         const float cs = 1.0f - rfx_exp2((t * t) * (-0.25f * 1.4426950408889634f));
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            // straight-line: a stopped ray advances by dir * 0 (pos + (+-0) == pos: one select on the step instead of three on the position)
-            // and re-derives the same uv — no exec-mask region per ray (measured 0.654 vs 0.666 ms at 4K, same texels)
-            const float csr = rays[r].active ? cs : 0.0f;
-            rays[r].pos = rays[r].pos + rays[r].dir * csr;
-            rays[r].uv = k1_project<PROJ>(m, rays[r].pos);
-        }
-        // taps of both rays in flight together: the two coarse cells first, then the exact texels of the cells that cannot
-        // rule a hit out (a hit needs 0 <= z - h < thickness; the cell range rules it out when max - h < 0 or min - h >= thickness)
-        Tap tap[2];
-        float2 mm[2];
-        bool need[2];
-        {
-            const float2 uvs[2] = {rays[0].uv, rays[1].uv};
-            k1_taps(m, d, uvs, tap);
-        }
-#pragma unroll
-        for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
-#pragma unroll
-        for (int r = 0; r < 2; r++) {  // (bitwise on purpose: no short-circuit branches in the loop)
-            const float h = rays[r].pos.z;
-            need[r] = rays[r].active & !((mm[r].y - h < 0.0f) | (mm[r].x - h >= m.thickness));
-        }
-        float z[2];
-#pragma unroll
-        for (int r = 0; r < 2; r++) z[r] = need[r] ? rfx_gather<float>(m.viewz, tap[r].idx) : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const float diff = z[r] - rays[r].pos.z;
-            if (need[r] && diff >= 0.0f && diff < m.thickness) {
-                rays[r].active = false;
-                rays[r].hit = true;
-            }
-        }
+        k1_march_step<PROJ, false>(m, d, rays, cs);
     }
+    for (; i < m.steps && K1_ANY_LIVE(rays); i++) k1_march_step<PROJ, true>(m, d, rays, 1.0f);
+#pragma unroll
+    for (int r = 0; r < 2; r++) rays[r].hit = started[r] & (rays[r].live == 0.0f);
     // (a wavefront none of whose rays hit — sky above the horizon, a wall facing away — has nothing to refine)
     if (m.refineSteps > 0 && __builtin_amdgcn_ballot_w64(rays[0].hit | rays[1].hit) != 0) {
         // (a ray that did not hit takes steps of dir * 0: its position is replaced below anyway, its direction is not read again)
@@ -514,7 +550,7 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     Ray rays[2];
     float3 diffuseRayDir = make_float3(0.f, 0.f, 0.f);
     float brdfD = 0.f, pdfD = 1.f, brdfS, pdfS;
-    rays[0].active = isDiffuseSample;
+    rays[0].live = isDiffuseSample ? 1.0f : 0.0f;
     rays[0].pos = viewPos;
     rays[0].dir = make_float3(0.f, 0.f, 0.f);
     if (isDiffuseSample) {  // :222-242
@@ -527,7 +563,7 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     // specular ray, traced every frame — evaluated with the SAME isDiffuseSample flag (:246-265)
     an = k1_angles(specularRay, vv, n);
     brdfS = k1_brdf_over_pdf_parts(mat, viewNormal, roughnessSq, isDiffuseSample, NoV, an, specularRay, pdfS);
-    rays[1].active = true;
+    rays[1].live = 1.0f;
     rays[1].pos = viewPos;
     rays[1].dir = specularRay;
     if (STAGE == 2) {
@@ -564,7 +600,8 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
 }
 
 template <int PROJ, bool ENV, bool MIS, int STAGE>
-__global__ __launch_bounds__(64 * K1_TH) void k1_ssgi_march(K1Args A) {
+// (without an environment map the fragment fits 64 VGPRs = the hardware's 8 waves per SIMD; the bound keeps the register allocator there)
+__global__ __launch_bounds__(64 * K1_TH) RFX_WAVES_PER_EU(ENV ? 1 : 8) void k1_ssgi_march(K1Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
     k1_ssgi_march_body<PROJ, ENV, MIS, STAGE>(A, d);

@@ -10,6 +10,10 @@
 #include "../../include/rfx.h"
 
 #define RFX_DEV __device__ __forceinline__
+// register-allocation bound of a kernel: at least n waves per SIMD (n = 8: at most 64 VGPRs)
+#ifndef RFX_WAVES_PER_EU
+#define RFX_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
 
 // ---------------------------------------------------------------- texture views
 // A view addresses rows [row0, row0+rows) of a W x H frame held contiguously in HBM.

@@ -28,6 +28,7 @@
 #define __global__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define RFX_WAVES_PER_EU(n)  /* a register-allocation hint of the device compiler: nothing to simulate */
 #define __constant__ static
 #define __shared__ static thread_local
 #define __restrict__
