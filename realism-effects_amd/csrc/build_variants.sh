@@ -7,7 +7,7 @@ cd "$(dirname "$0")"
 make -s
 mkdir -p variants
 stem=$1; shift
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-value -Wno-unused-result"
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -Wno-unused-function -Wno-unused-value -Wno-unused-result"
 case $stem in k3_denoise|k4_compose) F="$F -ffp-contract=fast-honor-pragmas";; *) F="$F -ffp-contract=off";; esac
 for spec in "$@"; do
   name=${spec%%:*}; defs=${spec#*:}

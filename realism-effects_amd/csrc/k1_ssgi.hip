@@ -14,7 +14,11 @@
 //     `0 <= z - hitPos.z < thickness` (RayMarch :463) — or fixes the sign BinarySearch tests (:493) — the
 //     exact texel is never fetched.  The decision is exact, not approximate: fp subtraction is monotonic,
 //     so the cell bounds bound the per-texel difference.
-// Workgroups take tiles in launch order (a band-per-XCD mapping measured slower: sky bands idle their XCD).
+// The march kernel is PERSISTENT (round 4): as many 8-wave workgroups as the chip holds at once are launched, each copies the (min, max)
+// table into LDS once, and every WAVEFRONT then takes 64x4-pixel tiles from a device counter until none is left — no barrier after the copy,
+// no workgroup waits for its slowest wave, and the cell lookups (two per march step and ray, 64 unrelated addresses each: ~30 cache lines
+// per instruction, which kept the CUs' L1 tag pipelines 80 % busy — the kernel's real bound in rounds 1-3, profiles/r04_k1/) become LDS reads.
+// Tiles are handed out in launch order (a band-per-XCD mapping measured slower: sky bands idle their XCD).
 #include "rfx_brdf.h"
 #include "rfx_kernels.h"
 
@@ -28,10 +32,19 @@ namespace {
 // measured 0.700 — no better than the cached global lookup, so there is none.
 constexpr int BASE = 16;  // edge of the pre-pass's exact (float) cells, reduced to the final cells by k1_pack_cells
 #ifndef RFX_K1_TH
-#define RFX_K1_TH 4  // build knob: rows of 64 pixels per workgroup of the march kernel
+#define RFX_K1_TH 1  // build knob: rows of 64 pixels per tile a wavefront takes from its queue (measured at 4K, 64 queues: 1: 0.620 ms, 2: 0.618, 4: 0.660)
 #endif
 constexpr int K1_TH = RFX_K1_TH;
 typedef uint32_t k1_cell_t;
+constexpr int K1_WAVES = 8;            // wavefronts per workgroup of the persistent march kernel
+#ifndef RFX_K1_COUNTERS
+#define RFX_K1_COUNTERS 64  // build knob: tile queues of the persistent march kernel (power of two, <= 64)
+#endif
+#ifndef RFX_K1_STATIC_TILES
+#define RFX_K1_STATIC_TILES 0  // build knob: 1 = no counters, wave w takes tiles w, w + nwaves, ... (A/B measurements)
+#endif
+constexpr int K1_COUNTERS = RFX_K1_COUNTERS;
+constexpr int K1_TABLE_CELLS = 8192;   // 32 KiB: rfx_api keeps the table within it for every frame size (cell edge doubled until it fits)
 RFX_DEV uint32_t k1_half_toward(float v, bool up) {  // nearest half not below (up) / not above (!up) v
     uint32_t h = rfx_f2h_rne(v) & 0xffffu;
     const float f = rfx_h2f((unsigned short)h);
@@ -43,15 +56,15 @@ RFX_DEV uint32_t k1_half_toward(float v, bool up) {  // nearest half not below (
     return h;
 }
 RFX_DEV k1_cell_t k1_cell_pack(float mn, float mx) { return k1_half_toward(mn, false) | (k1_half_toward(mx, true) << 16); }
-RFX_DEV float2 k1_cell_load(const k1_cell_t *t, unsigned int i) {
-    const uint32_t v = rfx_gather<uint32_t>(t, i);
+RFX_DEV float2 k1_cell_load(const k1_cell_t *t, unsigned int i) {  // t: the workgroup's LDS copy of the table
+    const uint32_t v = t[i];
     return make_float2(rfx_h2f((unsigned short)(v & 0xffffu)), rfx_h2f((unsigned short)(v >> 16)));
 }
 
 struct MarchCtx {
     const float *P;            // projectionMatrix (column-major)
     const float *viewz;        // full-frame view-space Z plane (k1_prepare)
-    const k1_cell_t *coarse;   // (min, max) view Z per 2^cell_shift-texel cell
+    const k1_cell_t *coarse;   // (min, max) view Z per 2^cell_shift-texel cell: the LDS copy
     int coarse_w, cell_shift;
     float rayDistance, thickness;
     int steps, refineSteps;
@@ -131,12 +144,18 @@ struct Ray {
 #define RFX_K1_CS1 1  // build knob: 0 = evaluate cs(i) in every step (A/B measurements; same texels either way)
 #endif
 #ifndef RFX_K1_WAVE_LOOP
-#define RFX_K1_WAVE_LOOP 1  // build knob: 1 = the march loops are wave-uniform (every lane steps until no lane of the wavefront has a live ray), 0 = per lane
+#define RFX_K1_WAVE_LOOP 0  // build knob: 1 = the march loops are wave-uniform (every lane steps until no lane of the wavefront has a live ray), 0 = per lane
 #endif
 #if RFX_K1_WAVE_LOOP
 #define K1_ANY_LIVE(rays) (__builtin_amdgcn_ballot_w64(((rays)[0].live != 0.0f) | ((rays)[1].live != 0.0f)) != 0)
 #else
 #define K1_ANY_LIVE(rays) (((rays)[0].live != 0.0f) | ((rays)[1].live != 0.0f))
+#endif
+#ifndef RFX_K1_MERGE_GATHERS
+#define RFX_K1_MERGE_GATHERS 1  // build knob: both rays' exact-texel fetches of a step under one exec mask, one wait
+#endif
+#ifndef RFX_K1_ABLATE
+#define RFX_K1_ABLATE 0  // measurement knob (WRONG pixels): 1 = never fetch an exact texel, 2 = ... nor a cell, 3 = no march at all
 #endif
 #ifndef RFX_K1_GATHER_ALWAYS
 #define RFX_K1_GATHER_ALWAYS 0  // build knob: 1 = the exact texel is loaded in every step (texel 0 when the cell decides) instead of under an exec mask
@@ -168,18 +187,32 @@ RFX_DEV void k1_march_step(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         k1_taps(m, d, uvs, tap);
     }
 #pragma unroll
-    for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
+    for (int r = 0; r < 2; r++) mm[r] = RFX_K1_ABLATE >= 2 ? make_float2(__uint_as_float(tap[r].cell), rays[r].uv.x) : k1_cell_load(m.coarse, tap[r].cell);
 #pragma unroll
     for (int r = 0; r < 2; r++) {  // (bitwise on purpose: no short-circuit branches in the loop)
         const float h = rays[r].pos.z;
         need[r] = (rays[r].live != 0.0f) & !((mm[r].y - h < 0.0f) | (mm[r].x - h >= m.thickness));
+        if (RFX_K1_ABLATE >= 1) need[r] = need[r] & (h == 12345.0f);
     }
-    float z[2];
+    float z[2] = {0.0f, 0.0f};
+#if RFX_K1_MERGE_GATHERS
+    // ONE exec region and ONE wait for both rays' exact texels (a random 4-byte gather over a 33 MB plane each) instead of a region and a
+    // wait per ray.  A lane that needs only one of its two texels fetches that one twice (the same address: no extra cache line).  Measured
+    // 0.545 against 0.549 ms at 4K — the waits are not what the exact fetches cost; kept because it is not slower.  (Round 4 also put a second
+    // look in front of the fetch — the pre-pass's exact 16x16-texel (min, max), an L2-sized table: slower, 0.590 against 0.560 ms, as the
+    // extra hierarchy level of round 1 was.)
+    if (need[0] | need[1]) {
+        const unsigned int i0 = need[0] ? tap[0].idx : tap[1].idx, i1 = need[1] ? tap[1].idx : tap[0].idx;
+        z[0] = rfx_gather<float>(m.viewz, i0);
+        z[1] = rfx_gather<float>(m.viewz, i1);
+    }
+#else
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         if (RFX_K1_GATHER_ALWAYS) z[r] = rfx_gather<float>(m.viewz, need[r] ? tap[r].idx : 0u);
         else z[r] = need[r] ? rfx_gather<float>(m.viewz, tap[r].idx) : 0.0f;
     }
+#endif
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const float diff = z[r] - rays[r].pos.z;
@@ -205,7 +238,7 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         rays[r].uv = make_float2(0.f, 0.f);
     }
     const int split = RFX_K1_CS1 ? min(m.steps, 9) : m.steps;
-    int i = 1;
+    int i = RFX_K1_ABLATE >= 3 ? m.steps : 1;
     for (; i < split && K1_ANY_LIVE(rays); i++) {
         const float t = (float)i + random_b - 0.5f;
         // exp(-0.25 t^2) = exp2((-0.25 t^2) log2e): the scaling by -1/4 is exact, so it folds into the constant (one product instead of two,
@@ -438,9 +471,7 @@ RFX_DEV float3 k1_shade(const FrameDims &d, const K1Args &A, const Material &mat
 // screen, so a row-tiled run can let that texture's all-gather overlap the march (rfx.h rfx_ssgi_trace / rfx_ssgi_shade).
 // Same arithmetic in the same order either way (no contraction in this file): split == fused bit for bit (tests).
 template <int PROJ, bool ENV, bool MIS, int STAGE>
-RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = A.y0 + blockIdx.y * K1_TH + threadIdx.y;
+RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d, const k1_cell_t *s_cells, int x, int y) {
     if (x >= A.out_w || y >= A.y1) return;
     const rfx_ssgi_params &p = A.p;
     const float *C = p.camera.matrixWorld, *Vw = p.camera.matrixWorldInverse;
@@ -467,7 +498,7 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     MarchCtx m;
     m.P = P;
     m.viewz = A.viewz;
-    m.coarse = (const k1_cell_t *)A.cells;
+    m.coarse = s_cells;
     m.coarse_w = A.cells_w;
     m.cell_shift = A.cell_shift;
     m.rayDistance = p.rayDistance;
@@ -599,12 +630,50 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d) {
     }
 }
 
-template <int PROJ, bool ENV, bool MIS, int STAGE>
 // (without an environment map the fragment fits 64 VGPRs = the hardware's 8 waves per SIMD; the bound keeps the register allocator there)
-__global__ __launch_bounds__(64 * K1_TH) RFX_WAVES_PER_EU(ENV ? 1 : 8) void k1_ssgi_march(K1Args A) {
+template <int PROJ, bool ENV, bool MIS, int STAGE>
+__global__ __launch_bounds__(64 * K1_WAVES) RFX_WAVES_PER_EU(ENV ? 1 : 8) void k1_ssgi_march(K1Args A) {
+    __shared__ k1_cell_t s_cells[K1_TABLE_CELLS];
+    if (STAGE != 2) {  // (the shade stage marches nothing)
+        for (int i = threadIdx.x; i < A.cells_vec4; i += 64 * K1_WAVES) ((uint4 *)s_cells)[i] = ((const uint4 *)A.cells)[i];
+        __syncthreads();  // the only barrier: from here on every wavefront runs on its own
+    }
     FrameDims d = A.dims;
     d.viol = 0;
-    k1_ssgi_march_body<PROJ, ENV, MIS, STAGE>(A, d);
+    const int lane = threadIdx.x & 63;
+    const unsigned int nbx = (unsigned int)(A.out_w + 63) / 64u, ntiles = nbx * ((unsigned int)(A.y1 - A.y0 + K1_TH - 1) / (unsigned int)K1_TH);
+    // Tiles in launch order, dealt round-robin to K1_COUNTERS queues; workgroup b serves queue b % K1_COUNTERS (hardware workgroup b runs on XCD
+    // b % 8: a queue's counter is bumped from one XCD's share of the waves, and the same-address atomics of the whole chip are spread over
+    // K1_COUNTERS cache lines — one counter for all 8192 waves measured 0.81 ms for the launch, 7 ns per atomic being the whole difference to the
+    // non-persistent kernel).  Every queue holds tiles of every image region, so the queues drain together.  The next tile's number is
+    // requested before this tile's work: the wavefront never waits for the atomic.
+    const unsigned int nq = min((unsigned int)K1_COUNTERS, gridDim.x);  // (a small launch has fewer workgroups than queues: every queue needs a server)
+    const unsigned int first = blockIdx.x % nq;
+    unsigned int *counter = A.tile_counter + first * 32u;  // 128 bytes apart
+#if RFX_K1_STATIC_TILES
+    const unsigned int nwaves = gridDim.x * (unsigned int)K1_WAVES;
+    unsigned int tile = blockIdx.x * (unsigned int)K1_WAVES + (threadIdx.x >> 6);
+#define K1_NEXT_TILE(t) ((t) + nwaves)
+#else
+    unsigned int tile = 0;
+    if (lane == 0) tile = atomicAdd(counter, 1u);
+    tile = (unsigned int)__builtin_amdgcn_readfirstlane((int)tile) * nq + first;
+#endif
+    while (tile < ntiles) {
+#if !RFX_K1_STATIC_TILES
+        unsigned int next = 0;
+        if (lane == 0) next = atomicAdd(counter, 1u);
+#endif
+        const unsigned int by = tile / nbx, bx = tile - by * nbx;
+        const int x = (int)bx * 64 + lane, y0 = A.y0 + (int)by * K1_TH;
+#pragma unroll 1
+        for (int r = 0; r < K1_TH; r++) k1_ssgi_march_body<PROJ, ENV, MIS, STAGE>(RFX_KERNARGS_IN_LOOP(A), d, s_cells, x, y0 + r);
+#if RFX_K1_STATIC_TILES
+        tile = K1_NEXT_TILE(tile);
+#else
+        tile = (unsigned int)__builtin_amdgcn_readfirstlane((int)next) * nq + first;
+#endif
+    }
     rfx_flush_violations(d);
 }
 
@@ -684,8 +753,9 @@ __global__ __launch_bounds__(64 * BASE) void k1_prepare(const float *depth, floa
 
 // ... and the march's table: cell (cx, cy) of edge BASE << up = the (min, max) of its (1 << up)^2 base cells, packed to two halfs
 __global__ __launch_bounds__(256) void k1_pack_cells(const float2 *base, int base_w, int base_h, k1_cell_t *cells, int cells_w, int cells_h, int up,
-                                                     int cells_padded) {
+                                                     int cells_padded, unsigned int *tile_counter) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 64) tile_counter[i * 32] = 0u;  // the march launch that follows this pre-pass hands its tiles out from 0 (64 counters, 128 bytes apart)
     if (i >= cells_padded) return;
     if (i >= cells_w * cells_h) {  // padding up to a whole 16-byte vector (the LDS copy moves uint4s)
         cells[i] = 0u;
@@ -747,13 +817,16 @@ hipError_t rfx_launch_k1_prepare(const K1Args &A, hipStream_t stream) {
     while ((BASE << up) < (1 << A.cell_shift)) up++;
     const int padded = A.cells_vec4 * 4;
     hipLaunchKernelGGL(k1_pack_cells, dim3((padded + 255) / 256), dim3(256), 0, stream, (const float2 *)A.coarse, A.coarse_w, A.coarse_h,
-                       (k1_cell_t *)A.cells, A.cells_w, A.cells_h, up, padded);
+                       (k1_cell_t *)A.cells, A.cells_w, A.cells_h, up, padded, A.tile_counter);
     return hipGetLastError();
 }
 
 hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
+    // persistent: what the chip holds at once (4 workgroups of 8 waves per CU at <= 64 VGPRs; fewer fit with an environment map — the
+    // surplus workgroups start late and find the counter exhausted), never more workgroups than there are tiles for their waves
     const int nbx = (A.out_w + 63) / 64, nby = (A.y1 - A.y0 + K1_TH - 1) / K1_TH;
-    dim3 block(64, K1_TH), grid(nbx, nby);  // dispatched x-fastest: tiles in launch order, as a 1-D grid would
+    const int want = (nbx * nby + K1_WAVES - 1) / K1_WAVES, fit = (A.n_cu > 0 ? A.n_cu : 256) * (32 / K1_WAVES);
+    dim3 block(64 * K1_WAVES), grid(want < fit ? want : fit);
     const float *P = A.p.camera.projectionMatrix;
     const bool persp = P[1] == 0.f && P[2] == 0.f && P[3] == 0.f && P[4] == 0.f && P[6] == 0.f && P[7] == 0.f && P[12] == 0.f && P[13] == 0.f &&
                        P[15] == 0.f && P[11] == -1.f;

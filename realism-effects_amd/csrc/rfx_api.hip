@@ -47,6 +47,7 @@ rfx_ctx *rfx_create(int device, int width, int height, int tile_y0, int tile_row
     }
     hipMemset(c->halo_violations, 0, sizeof(unsigned int));
     c->stream = c->own_stream;
+    if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu <= 0) c->n_cu = 256;
     // K1's depth pre-pass stream and the events that order it, created HERE and not lazily by the first draw: every asynchronous writer of
     // the depth slot (rfx_stage_flip, rfx_clear) records ev_depth from the first frame on, so the first pre-pass already waits for the
     // first staged copy (round 3 created them inside the first rfx_ssgi_*: frame 0's pre-pass raced the copy that filled its input)
@@ -98,6 +99,7 @@ void rfx_destroy(rfx_ctx *c) {
     if (c->hit_rows_host) hipHostFree(c->hit_rows_host);
     if (c->coarse) hipFree(c->coarse);
     if (c->cells) hipFree(c->cells);
+    if (c->k1_tiles) hipFree(c->k1_tiles);
     if (c->env) hipFree(c->env);
     if (c->env_marginal) hipFree(c->env_marginal);
     if (c->env_conditional) hipFree(c->env_conditional);
@@ -616,17 +618,21 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
         hipError_t e = hipMalloc((void **)&c->viewz, (size_t)c->W * c->H * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&c->coarse, (size_t)A.coarse_w * A.coarse_h * sizeof(float2));
         if (e == hipSuccess) e = hipMalloc((void **)&c->cells, (size_t)A.cells_vec4 * 16);
-        if (e != hipSuccess) {  // all three or none: a later draw must not find viewz set and the tables missing
+        if (e == hipSuccess) e = hipMalloc((void **)&c->k1_tiles, 64 * 128);
+        if (e != hipSuccess) {  // all four or none: a later draw must not find viewz set and the tables missing
             if (c->viewz) hipFree(c->viewz);
             if (c->coarse) hipFree(c->coarse);
             if (c->cells) hipFree(c->cells);
-            c->viewz = nullptr; c->coarse = nullptr; c->cells = nullptr;
+            if (c->k1_tiles) hipFree(c->k1_tiles);
+            c->viewz = nullptr; c->coarse = nullptr; c->cells = nullptr; c->k1_tiles = nullptr;
             return fail(c, RFX_ENOMEM, "hipMalloc(K1 scratch)", e);
         }
     }
     A.viewz = c->viewz;
     A.coarse = c->coarse;
     A.cells = c->cells;
+    A.tile_counter = c->k1_tiles;
+    A.n_cu = c->n_cu;
     A.env = c->env;
     A.env_w = c->env_w; A.env_h = c->env_h; A.env_levels = c->env_levels;
     A.env_marginal = c->env_marginal; A.env_conditional = c->env_conditional;
@@ -666,6 +672,8 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_prep_done, 0));
         }
     }
+    // the march kernel hands its tiles out from a counter: the pre-pass zeroes it; the shade stage has no pre-pass of its own
+    if (any && stage == 2) HIPCHK(c, hipMemsetAsync(c->k1_tiles, 0, 64 * 128, c->stream));
     if (any) HIPCHK(c, rfx_launch_k1(A, stage, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_k1_done, c->stream));  // the next pre-pass overwrites what this launch reads
     c->k1_event_set = true;

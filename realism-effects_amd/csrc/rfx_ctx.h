@@ -40,6 +40,8 @@ struct rfx_ctx {
     int uv_model = RFX_UV_REFERENCE_GL;    // rfx_set_uv_model (the default: the vUv the parity oracle's GL interpolates)
     float2 *coarse = nullptr;  // K1 scratch: exact (min,max) view Z per 16x16 base cell
     unsigned int *cells = nullptr;  // K1 scratch: the march's half-packed (min,max) table
+    unsigned int *k1_tiles = nullptr;  // K1 scratch: the persistent march kernel's tile counter
+    int n_cu = 0;                      // compute units of the device
     float4 *env = nullptr;     // scene.environment: the whole mip chain, float4 texels
     float *env_marginal = nullptr, *env_conditional = nullptr;  // EquirectHdrInfo inverse-CDF tables (importanceSampling)
     float env_sum_whole = 1.0f, env_sum_decimal = 0.0f;

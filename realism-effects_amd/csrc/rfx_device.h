@@ -15,6 +15,21 @@
 #define RFX_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
 #endif
 
+// A persistent kernel runs its per-pixel body in a loop; left alone, the compiler hoists every scalar load of the argument block (four camera
+// matrices, the views, the options) out of that loop and keeps them live across the whole body — far more than the 102 SGPRs there are, so
+// they spill into VGPR lanes and from there to scratch.  This returns the kernel's argument block (the FIRST kernel parameter, passed by value:
+// offset 0 of the kernarg segment) through a pointer the optimiser cannot see through, once per loop iteration: the loads stay scalar loads
+// next to their uses, as in a kernel without the loop.
+#ifndef RFX_KERNARGS_IN_LOOP
+template <class T>
+__device__ __forceinline__ const T &rfx_kernargs_in_loop(const T &) {
+    auto p = __builtin_amdgcn_kernarg_segment_ptr();  // (a pointer into the constant address space)
+    asm volatile("" : "+s"(p));
+    return *(const T *)p;
+}
+#define RFX_KERNARGS_IN_LOOP(A) rfx_kernargs_in_loop(A)
+#endif
+
 // ---------------------------------------------------------------- texture views
 // A view addresses rows [row0, row0+rows) of a W x H frame held contiguously in HBM.
 // Fetch coordinates are FRAME coordinates: CLAMP_TO_EDGE happens against the frame, then the

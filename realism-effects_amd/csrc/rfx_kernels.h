@@ -30,6 +30,8 @@ struct K1Args {
     int out_w, out_h;  // the pass's render target = `resolution` (frame size unless resolutionScale != 1)
     UvPlanes out_uv;   // that target's vUv
     float4 *hits;      // trace -> shade hand-over (2 texels per output pixel, indexed like `out`); null for the fused launch
+    unsigned int *tile_counter;  // the persistent march kernel's work counter (context scratch; zero when the launch starts)
+    int n_cu;                    // compute units of the device (sizes the persistent grid)
 };
 
 // one level of the environment's mip chain from the one above (glGenerateMipmap on the oracle's GL: 2x2 bilinear centre)

@@ -28,6 +28,7 @@
 #define __global__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#define RFX_KERNARGS_IN_LOOP(A) (A)  /* an optimiser fence of the device build (rfx_device.h): the argument block itself */
 #define RFX_WAVES_PER_EU(n)  /* a register-allocation hint of the device compiler: nothing to simulate */
 #define __constant__ static
 #define __shared__ static thread_local
@@ -188,6 +189,8 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "hostsim"; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 2; return hipSuccess; }  // a small "chip": the persistent K1 grid is 8 workgroups
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 16; return hipSuccess; }  // every "device" is this host: one rank per device index works
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
