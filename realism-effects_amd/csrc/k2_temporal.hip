@@ -3,7 +3,7 @@
 // src/temporal-reproject/TemporalReprojectPass.js:192-193 with the fragment program
 // src/temporal-reproject/shader/temporal_reproject.frag (+ reproject.frag), PERSPECTIVE_CAMERA.
 //
-// A 64x4-pixel workgroup tile (four waves; at 149 VGPRs three such tiles are resident per CU) with a 2-texel apron is staged through LDS once: the packed K1 output
+// A 64x8-pixel workgroup tile (eight waves) with a 2-texel apron is staged through LDS once: the packed K1 output
 // is unpacked (8 halfs -> two float4) and the velocity texel is decoded (normal + depth) ONE time per
 // texel, so the (2r+1)^2 neighbourhood AABB of both textures (up to 50 taps per pixel) and the 2x2-quad
 // derivatives read LDS instead of re-fetching and re-unpacking global texels.  The history taps
@@ -18,10 +18,12 @@ namespace {
 #define RFX_K2_XCD_G 0  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major.  Measured at 4K: 0: 0.445 ms, 2: 0.450, 4: 0.461, 8: 0.489, 16: 0.500, 32: 0.517
 #endif
 #ifndef RFX_K2_TH
-#define RFX_K2_TH 4  // build knob: tile rows (4 waves per workgroup; 8 halves the apron's share of the staging)
+#define RFX_K2_TH 8  // build knob: tile rows.  8 (eight waves per workgroup) stages 1.6 texels per pixel instead of 2.1 and, at the no-SLP build's 70 VGPRs, keeps
+                     // 6 waves per SIMD resident (46 KB of LDS per workgroup) against 5 with 4 rows: measured 0.325 against 0.353 ms at 4K (round 4; round 3's
+                     // 90-VGPR kernel was register-bound at 5 waves either way and measured 8 rows +0.6 %); 2 rows: 0.424 ms
 #endif
 constexpr int TW = 64, TH = RFX_K2_TH, AP = 2;    // tile, apron (neighbourhood radius <= 2)
-constexpr int LW = TW + 2 * AP, LH = TH + 2 * AP;  // 68 x 8 staged texels
+constexpr int LW = TW + 2 * AP, LH = TH + 2 * AP;  // 68 x 12 staged texels
 constexpr int NT = TW * TH;
 
 struct VND {
