@@ -290,7 +290,7 @@ def test_config0_through_the_effect_no_denoise_pass(blue_noise):
             print(rt.line() + "  (%d of them: K1 inputs differ within the clamp footprint and the oracle on the implementation's input agrees)" % int(
                 (out_of_tolerance(got[j], want[j], False) & right_for_own_input).sum()))
             assert rt.unexplained == 0, rt.line()
-            assert rt.bad <= 25 * 5e-4 * rt.pixels + 50, rt.line()
+            assert rt.bad <= 5e-5 * rt.pixels + 10, rt.line()  # measured on MI355X: 13 of 2.07 M pixels (6e-6)
     assert ctx.halo_violations() == 0
     ctx.close()
 

@@ -1,15 +1,57 @@
 """-m gpu: the HIP path (through the C ABI) against the C restatement oracle, stage by stage,
 on the same seeded synthetic dumps.  Each stage is fed the ORACLE's previous-stage output so
-that flipped pixels do not compound across stages."""
+that flipped pixels do not compound across stages.
+
+The metric is the STRICT one of tests/parity.py (round 4; rounds 1-3 ran these variant tests on the round-1 metric — relative above 1.0,
+flips bounded at 0.2-0.6 %): a channel is in tolerance within 1e-3 absolute, or — half-stored outputs — when the two values are the same or
+adjacent binary16 numbers, or — fp32 outputs — within 1e-5 relative.  Out-of-tolerance pixels are bounded per stage kind at ~3x the largest
+fraction measured on MI355X (BOUND below) and, wherever the test can re-run the oracle stage (`prove=`), every one of them must be PROVEN
+unstable by the oracle (stagewise.prove_flips: a decision margin < 1, or the output moves under primitives perturbed within the reference
+GL's measured error): `unexplained == 0`."""
 import numpy as np
 import pytest
 
-from parity import assert_close
+from parity import out_of_tolerance, strict
 
 pytestmark = pytest.mark.gpu
 
-# allowed fraction of discontinuity-flipped pixels per stage (measured: <= 0.03% K1, <= 0.3% K3 pass 0)
-FLIP = dict(ssgi=2e-3, temporal=2e-3, denoise=6e-3, compose=1e-3)
+
+class Bound(float):
+    """allowed fraction of out-of-tolerance pixels of a stage kind + whether its output is half-stored"""
+    def __new__(cls, v, half):
+        o = float.__new__(cls, v)
+        o.half = half
+        return o
+
+
+# HIP vs the C restatement on the synthetic dumps, strict metric; measured on MI355X (profiles/r04_parity/variant_twins.txt):
+# K1 <= 1.7e-4, K2 <= 2e-5, K3 <= 5e-5 (random-texel inputs of the variant tests: 2e-4), K4 <= 2e-5
+FLIP = dict(ssgi=Bound(5e-4, True), temporal=Bound(6e-5, False), denoise=Bound(6e-4, True), compose=Bound(6e-5, False))
+# K1 with an environment map: the equirect lookup (atan2 / acos -> a texel of the level the roughness picks) adds decisions; measured 8e-4
+FLIP_ENV = Bound(2.5e-3, True)
+MEASURED = []  # (name, fraction) of every comparison of the session: printed at the end (conftest) for the bounds above
+
+
+def assert_close(name, got, want, bound, prove=None, half=None):
+    """strict metric; `bound`: a Bound (or a plain fraction with `half=`); prove: () -> the oracle's output for the same stage as a float
+    array shaped like `want` (it is called under rfx_oracle.pixel_mask: only the out-of-tolerance pixels are re-evaluated) — when given,
+    every out-of-tolerance pixel must be proven unstable."""
+    import stagewise as S
+    half = getattr(bound, "half", False) if half is None else half
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    bad = out_of_tolerance(got, want, half)
+    expl = None
+    if prove is not None:
+        expl = S.prove_flips(prove, lambda o: np.asarray(o, np.float32), bad, half) if bad.any() else np.zeros(bad.shape, bool)
+    r = strict(name, got, want, explainable=expl, half=half)
+    MEASURED.append((name, r.bad / max(r.pixels, 1)))
+    print(r.line())
+    if prove is not None:
+        assert r.unexplained == 0, "%s: %d out-of-tolerance pixels the oracle cannot prove unstable, worst (y, x, err) %s\n%s" % (name, r.unexplained, r.worst_unexplained, r.line())
+    if float(bound) == 0.0:
+        assert r.bad == 0, r.line()
+    assert r.bad <= float(bound) * r.pixels + 2, "%s: %d of %d pixels outside the metric (bound %.4f%% + 2)\n%s" % (name, r.bad, r.pixels, 100 * float(bound), r.line())
+    return r.bad / max(r.pixels, 1), r.linf_abs_ok
 
 
 def _params(abi, frame, prev_cam, keep, steps=20, refine=5, missed=0):
@@ -29,69 +71,53 @@ def _params(abi, frame, prev_cam, keep, steps=20, refine=5, missed=0):
 
 @pytest.mark.parametrize("size,steps,refine,missed", [((320, 180), 20, 5, 0), ((250, 141), 8, 2, 0), ((200, 112), 12, 3, 1)])
 def test_chain_stagewise_vs_oracle(blue_noise, size, steps, refine, missed):
+    """K1 -> K2 -> 2 x K3 -> K4 over three frames, every stage fed the oracle's previous-stage output; every out-of-tolerance pixel proven."""
     from rfx_amd import abi
-    from rfx_amd.context import Context
     from rfx_amd.scene import synthetic_frame
     import rfx_oracle as O
+    import stagewise as S
 
     W, H = size
-    ctx = Context(W, H)
+    hip, ora = S.HipStages(W, H, blue_noise), S.OracleStages(W, H, blue_noise)
     comp = np.zeros((H, W, 4), np.float32)
     A = [np.zeros((H, W, 4), np.uint16) for _ in range(2)]
     B = [np.zeros((H, W, 4), np.uint16) for _ in range(2)]
     T = [np.zeros((H, W, 4), np.float32) for _ in range(2)]
     prev_cam, keep = None, 0.0
+    h8 = lambda o: O.half_bits_to_float(np.ascontiguousarray(o).view(np.uint16))  # noqa: E731
     for fi in range(3):
         f = synthetic_frame(W, H, fi)
         sp, tp, dp, cp = _params(abi, f, prev_cam or f.camera, keep, steps, refine, missed)
-        ctx.upload_frame(f)
-        # ---- K1
+        hip.frame(f)
+        ora.frame(f)
+        # ---- K1 (the packed texel's eight halfs)
         sp.blueNoiseIndex = 1000 + fi
-        ctx.upload(abi.TEX_COMPOSE, comp)
-        ctx.ssgi_march(sp)
-        g = ctx.download(abi.TEX_SSGI)
-        o = O.ssgi(f.depth, f.gbuffer, f.direct, comp, blue_noise, sp)
-        ga, gb = O.unpack_ssgi(g)
-        oa, ob = O.unpack_ssgi(o)
-        assert_close("ssgi.diffuse f%d" % fi, ga, oa, FLIP["ssgi"])
-        assert_close("ssgi.specular f%d" % fi, gb, ob, FLIP["ssgi"])
+        o = ora.ssgi(comp, sp)
+        assert_close("ssgi f%d" % fi, h8(hip.ssgi(comp, sp)), h8(o), FLIP["ssgi"], prove=lambda: h8(ora.ssgi(comp, sp)))
         # ---- K2 (input: oracle's K1 output; history: oracle's B)
-        ctx.upload(abi.TEX_SSGI, o)
-        ctx.upload(abi.TEX_DENOISE_B0, B[0])
-        ctx.upload(abi.TEX_DENOISE_B1, B[1])
-        ctx.upload(abi.TEX_TEMPORAL0, T[0])
-        ctx.upload(abi.TEX_TEMPORAL1, T[1])
-        ctx.temporal_reproject(tp)
-        O.temporal(o, f.velocity, B[0], B[1], tp, T[0], T[1])
-        assert_close("temporal0 f%d" % fi, ctx.download(abi.TEX_TEMPORAL0), T[0], FLIP["temporal"])
-        assert_close("temporal1 f%d" % fi, ctx.download(abi.TEX_TEMPORAL1), T[1], FLIP["temporal"])
-        keep, prev_cam = 1.0, f.camera
+        Tn = ora.temporal(o, B, T, tp)
+        got = hip.temporal(o, B, T, tp)
+        for j in range(2):
+            assert_close("temporal%d f%d" % (j, fi), got[j], Tn[j], FLIP["temporal"], prove=lambda j=j, T=T: ora.temporal(o, B, T, tp)[j])
+        T, keep, prev_cam = Tn, 1.0, f.camera
         # ---- K3 pass 0 (temporal -> A) and pass 1 (A -> B)
-        ctx.upload(abi.TEX_TEMPORAL0, T[0])
-        ctx.upload(abi.TEX_TEMPORAL1, T[1])
-        ctx.upload(abi.TEX_DENOISE_A0, A[0])
-        ctx.upload(abi.TEX_DENOISE_A1, A[1])
         dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 2000 + 2 * fi, 1, 0
-        ctx.poisson_denoise(dp)
-        O.denoise(f.depth, f.gbuffer, T[0], T[1], blue_noise, dp, A[0], A[1])
-        assert_close("denoiseA0 f%d" % fi, O.half_bits_to_float(ctx.download(abi.TEX_DENOISE_A0)), O.half_bits_to_float(A[0]), FLIP["denoise"])
-        assert_close("denoiseA1 f%d" % fi, O.half_bits_to_float(ctx.download(abi.TEX_DENOISE_A1)), O.half_bits_to_float(A[1]), FLIP["denoise"])
-        ctx.upload(abi.TEX_DENOISE_A0, A[0])
-        ctx.upload(abi.TEX_DENOISE_A1, A[1])
+        An = ora.denoise(T, A, dp)
+        got = hip.denoise(T, A, dp)
+        for j in range(2):
+            assert_close("denoiseA%d f%d" % (j, fi), h8(got[j]), h8(An[j]), FLIP["denoise"], prove=lambda j=j, A=A: h8(ora.denoise(T, A, dp)[j]))
+        A = An
         dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 2001 + 2 * fi, 0, 1
-        ctx.poisson_denoise(dp)
-        O.denoise(f.depth, f.gbuffer, A[0], A[1], blue_noise, dp, B[0], B[1])
-        assert_close("denoiseB0 f%d" % fi, O.half_bits_to_float(ctx.download(abi.TEX_DENOISE_B0)), O.half_bits_to_float(B[0]), FLIP["denoise"])
-        assert_close("denoiseB1 f%d" % fi, O.half_bits_to_float(ctx.download(abi.TEX_DENOISE_B1)), O.half_bits_to_float(B[1]), FLIP["denoise"])
+        Bn = ora.denoise(A, B, dp)
+        got = hip.denoise(A, B, dp)
+        for j in range(2):
+            assert_close("denoiseB%d f%d" % (j, fi), h8(got[j]), h8(Bn[j]), FLIP["denoise"], prove=lambda j=j, B=B: h8(ora.denoise(A, B, dp)[j]))
+        B = Bn
         # ---- K4
-        ctx.upload(abi.TEX_DENOISE_B0, B[0])
-        ctx.upload(abi.TEX_DENOISE_B1, B[1])
-        ctx.upload(abi.TEX_COMPOSE, comp)
-        ctx.compose(cp)
-        O.compose(f.depth, f.gbuffer, B[0], B[1], cp, comp)
-        assert_close("compose f%d" % fi, ctx.download(abi.TEX_COMPOSE), comp, FLIP["compose"])
-    assert ctx.halo_violations() == 0
-    ctx.close()
+        cn = ora.compose(B, comp, cp)
+        assert_close("compose f%d" % fi, hip.compose(B, comp, cp), cn, FLIP["compose"], prove=lambda comp=comp: ora.compose(B, comp, cp))
+        comp = cn
+    hip.close()
 
 
 class _LocalTiles:
@@ -466,7 +492,11 @@ def test_traa_end_to_end_vs_oracle(half):
         want = np.zeros((H, W, 4), np.float32)
         O.temporal(np.ascontiguousarray(inp.view(np.uint32)), f.velocity, hist, hist, tp, want, None)
         got = ctx.download(abi.TEX_TEMPORAL0)
-        assert_close("traa(%s) f%d" % ("half" if half else "float", fi), got, want, FLIP["temporal"])
+        def again(f=f, tp=tp, inp=inp, hist=hist):
+            w = np.zeros((H, W, 4), np.float32)
+            O.temporal(np.ascontiguousarray(inp.view(np.uint32)), f.velocity, hist, hist, tp, w, None)
+            return w
+        assert_close("traa(%s) f%d" % ("half" if half else "float", fi), got, want, FLIP["temporal"], prove=again, half=bool(half))  # (a HalfFloatType target stores halfs)
         ctx.copy_framebuffer(fb)
         cp = ctx.download(fb)
         if half:
@@ -494,7 +524,7 @@ def test_traa_end_to_end_vs_oracle(half):
     dev = Context(W, H)
     a, b = run(dev), run(OracleRenderer(W, H))
     for fi in range(NF):
-        assert_close("traa effect f%d" % fi, a[fi], b[fi], FLIP["temporal"] * (fi + 1))
+        assert_close("traa effect f%d" % fi, a[fi], b[fi], 4e-3 * (fi + 1), half=False)  # free-running effects: an earlier flip stays in both histories
     # row tiles (the multi-GPU decomposition) reproduce the single context bit for bit
     from rfx_amd import tiling
     vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
@@ -561,7 +591,7 @@ def test_denoise_modes_vs_oracle(dm, blue_noise):
     dev, ora = Context(W, H), OracleRenderer(W, H)
     slots = (abi.TEX_SSGI, abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1, abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1, abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1,
              abi.TEX_COMPOSE, abi.TEX_FBCOPY_F32, abi.TEX_FINAL)
-    lim = dict(ssgi=FLIP["ssgi"], temporal=FLIP["temporal"], denoise=FLIP["denoise"], compose=FLIP["compose"], final=FLIP["denoise"], copy_framebuffer=0.0)
+    lim = dict(ssgi=FLIP["ssgi"], temporal=FLIP["temporal"], denoise=FLIP["denoise"], compose=FLIP["compose"], final=FLIP["denoise"], copy_framebuffer=0.0)  # (half-ness is decided per texture below)
     out_tex = dict(ssgi=(abi.TEX_SSGI,), temporal=(abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1), compose=(abi.TEX_COMPOSE,), final=(abi.TEX_FINAL,),
                    copy_framebuffer=(abi.TEX_FBCOPY_F32,))
 
@@ -584,13 +614,14 @@ def test_denoise_modes_vs_oracle(dm, blue_noise):
             self.seen.append(key)
             for t in texs:
                 got, want = dev.download(t), ora.tex[t]
+                is_half = got.dtype == np.uint16 or t == abi.TEX_SSGI
                 if got.dtype == np.uint16:
                     got, want = O.half_bits_to_float(got), O.half_bits_to_float(want)
                 elif t == abi.TEX_SSGI:
                     ga, gb = O.unpack_ssgi(got)
                     wa, wb = O.unpack_ssgi(want)
                     got, want = np.concatenate([ga, gb], -1), np.concatenate([wa, wb], -1)
-                assert_close("%s %s %s" % (dm, key, abi.TEX_NAMES[t]), got, want, lim[key])
+                assert_close("%s %s %s" % (dm, key, abi.TEX_NAMES[t]), got, want, lim[key], half=is_half)
                 dev.upload(t, ora.tex[t])
 
         def ssgi_march(self, p):
@@ -657,8 +688,9 @@ def test_env_map_vs_oracle(blue_noise, env_blur, half):
         o = O.ssgi(f.depth, f.gbuffer, f.direct, comp, blue_noise, sp, env=env)
         ga, gb = O.unpack_ssgi(g)
         oa, ob = O.unpack_ssgi(o)
-        assert_close("env ssgi.diffuse f%d" % fi, ga, oa, FLIP["ssgi"])
-        assert_close("env ssgi.specular f%d" % fi, gb, ob, FLIP["ssgi"])
+        again = lambda k, f=f, sp=sp: O.unpack_ssgi(O.ssgi(f.depth, f.gbuffer, f.direct, comp, blue_noise, sp, env=env))[k]  # noqa: E731
+        assert_close("env ssgi.diffuse f%d" % fi, ga, oa, FLIP_ENV, prove=lambda: again(0))
+        assert_close("env ssgi.specular f%d" % fi, gb, ob, FLIP_ENV, prove=lambda: again(1))
         assert (g == o).all(axis=-1).mean() > 0.99
         sp.useEnvMap = 0
         ctx.ssgi_march(sp)
@@ -873,7 +905,7 @@ def test_resolution_scale_vs_oracle(blue_noise, rs):
         return renderer.download(abi.TEX_COMPOSE)
 
     dev = Context(W, H)
-    assert_close("rs%g chain compose" % rs, run(dev), run(OracleRenderer(W, H)), 0.06)
+    assert_close("rs%g chain compose" % rs, run(dev), run(OracleRenderer(W, H)), 0.02, half=False)  # two free-running frames (not stage-wise): flips compound
     dev.close()
 
 
@@ -1008,8 +1040,9 @@ def test_env_map_importance_sampling_vs_oracle(blue_noise, half, size):
     o = O.ssgi(f.depth, f.gbuffer, f.direct, comp, blue_noise, sp, env=env)
     ga, gb = O.unpack_ssgi(g)
     oa, ob = O.unpack_ssgi(o)
-    assert_close("envmis ssgi.diffuse", ga, oa, FLIP["ssgi"])
-    assert_close("envmis ssgi.specular", gb, ob, FLIP["ssgi"])
+    again = lambda k: O.unpack_ssgi(O.ssgi(f.depth, f.gbuffer, f.direct, comp, blue_noise, sp, env=env))[k]  # noqa: E731
+    assert_close("envmis ssgi.diffuse", ga, oa, FLIP_ENV, prove=lambda: again(0))
+    assert_close("envmis ssgi.specular", gb, ob, FLIP_ENV, prove=lambda: again(1))
     assert (g == o).all(axis=-1).mean() > 0.985
     sp.importanceSampling = 0
     ctx.ssgi_march(sp)
@@ -1208,3 +1241,12 @@ def test_hit_rows_bound_what_the_shade_reads(blue_noise, missed):
     assert seen_partial  # (the test would be vacuous if every range were the whole frame)
     assert ctx.halo_violations() == 0
     ctx.close()
+
+
+def test_zz_measured_out_of_tolerance_fractions():
+    """prints what every comparison of this file measured (the numbers BOUND / FLIP_ENV are ~3x of), largest first"""
+    worst = {}
+    for name, frac in MEASURED:
+        worst[name] = max(worst.get(name, 0.0), frac)
+    for name, frac in sorted(worst.items(), key=lambda kv: -kv[1])[:40]:
+        print("  %-40s %.5f %%" % (name, 100 * frac))
