@@ -22,10 +22,11 @@ milliseconds run below the sustained clock — with --steps 20 --warmup 5 alone 
 untimed warm-up steps, then EXACTLY K timed steps between barriers and device synchronisation, max over ranks.  The line says `spinup_frames`.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (largest share of the step), its launches timed live with hipEvents
-on the stream the kernels run on, next to a device-to-device stream-copy rate measured in the same process; `valu` is the measured VALU
-occupancy of every kernel (rocprofv3 counters of this same command, committed under PROFILE_DIR) — the bound that actually binds;
-`cpu_baseline` is the REFERENCE's own GLSL on Mesa llvmpipe on this box's host cores over the same frame (kind "reference"; the C
-restatement is the fallback when no GL is available).
+on the stream the kernels run on, next to a device-to-device stream-copy rate measured in the same process; `issue_model` is, per kernel, the
+absolute time its measured instruction mix costs to issue next to the time it took (rocprofv3 counters of this same command, committed under
+PROFILE_DIR; tools/issue_model.py) — the bound that actually binds; `ms_per_step_cold` is the same W + K protocol before the spin-up;
+`cpu_baseline` is the REFERENCE's own GLSL on Mesa llvmpipe on this box's host cores over the same frame (kind "reference"), with the C
+restatement under OpenMP on all cores as `cpu_baseline.port` (SURVEY.md §8d's second baseline; alone when no GL is available).
 """
 import argparse
 import json
@@ -56,7 +57,7 @@ PMC_KERNEL = {"k1_ssgi_march": "false, 0>(K1Args)", "k2_temporal_reproject": "k2
               "k3_poisson_denoise_pass1": "k3_tiled<false", "k4_compose": "k4_compose"}
 
 
-PROFILE_DIR = "profiles/r03_final"  # the committed rocprofv3 collection (tools/collect_profiles.sh) the counter-derived figures are read from
+PROFILE_DIR = "profiles/r04_final"  # the committed rocprofv3 collection (tools/collect_profiles.sh) the counter-derived figures are read from
 
 
 def profile_meta():
@@ -85,33 +86,21 @@ def pmc_traffic(kernel_key):
     return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
 
 
-N_SIMD, N_XCD = 256 * 4, 8
-
-
-def valu_occupancy(kernel_key):
-    """Measured VALU occupancy of a kernel, from the committed counter collection of this same command (PROFILE_DIR/pmc_sq_l2.csv):
-        valu_busy      = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)   (quad-cycles -> cycles; 1.0 = every SIMD issues VALU every cycle)
-        valu_per_px    = SQ_INSTS_VALU / SQ_WAVES  (wave64 instructions per wavefront = per pixel: one pixel per lane)
-        cycles_per_valu = SQ_ACTIVE_INST_VALU * 4 / SQ_INSTS_VALU  (what one wave64 VALU instruction occupies its SIMD for)
-    The floor the prescribed arithmetic implies on this part is valu_per_px * cycles_per_valu * waves_per_SIMD / clock — these kernels sit on
-    it (valu_busy ~ 1): the lever is the instruction count, not bytes.  None when the collection is missing."""
-    import csv
-    path = os.path.join(ROOT, PROFILE_DIR, "pmc_sq_l2.csv")
-    if not os.path.exists(path):
+def issue_model():
+    """kernel key -> tools/issue_model.py's figures from the committed collection (None when the class counters are not there)"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import issue_model as IM
+        rows = IM.table(os.path.join(ROOT, PROFILE_DIR))
+    except Exception as e:  # noqa: BLE001
+        log("issue model not available: %r" % (e,))
         return None
-    c = {}
-    for r in csv.DictReader(open(path)):
-        if PMC_KERNEL[kernel_key] in r["kernel"]:
-            c[r["counter"]] = float(r["mean_value"])
-    need = ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVES", "GRBM_GUI_ACTIVE")
-    if not all(k in c for k in need):
-        return None
-    out = {"valu_busy": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (N_SIMD * c["GRBM_GUI_ACTIVE"] / N_XCD), 3),
-           "valu_per_px": round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1),
-           "cycles_per_valu": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"], 2)}
-    if "SQ_INSTS_VALU_TRANS_F32" in c:
-        out["transcendental_per_px"] = round(c["SQ_INSTS_VALU_TRANS_F32"] / c["SQ_WAVES"], 1)
-    return out
+    out = {}
+    for key, frag in PMC_KERNEL.items():
+        for name, m in rows.items():
+            if frag in name:
+                out[key] = {k: m[k] for k in ("valu_per_px", "predicted_issue_ms", "measured_ms", "issue_share_of_measured", "clock_GHz") if k in m}
+    return out or None
 
 
 def stream_copy_gbs(dev, nbytes=1 << 30, iters=10):
@@ -251,7 +240,7 @@ def verify_exchange(ctx, rank, world):
     return err
 
 
-def time_case(case, dist, n_steps, n_warmup, dev="cpu", spinup=0):
+def time_case(case, dist, n_steps, n_warmup, dev="cpu", spinup=0, cold=False):
     """W untimed steps, then exactly K timed steps between barriers + device synchronisation; max over ranks.
     `spinup`: untimed frames BEFORE the W warm-up steps — the device sat idle through ~20 s of dump generation and set-up, and the
     first tens of milliseconds after that run below the sustained clock (same frames, same work; measured with the driver's --steps 20
@@ -270,24 +259,30 @@ def time_case(case, dist, n_steps, n_warmup, dev="cpu", spinup=0):
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fx.update(renderer, None)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=ctl_device(dist, dev))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     fx.update(renderer, None)  # first frame: uploads the dump (not timed), keepData = 0
+    dt_cold = None
+    if cold:  # the driver's own W + K protocol straight after the idle set-up phase, BEFORE any spin-up: reported beside the sustained figure
+        for _ in range(n_warmup):
+            fx.update(renderer, None)
+        dt_cold = timed(n_steps)
     for _ in range(spinup):
         fx.update(renderer, None)
-    if spinup:
-        barrier()
     for _ in range(n_warmup):
         fx.update(renderer, None)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(n_steps):
-        fx.update(renderer, None)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=ctl_device(dist, dev))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    return timed(n_steps), dt_cold
 
 
 def kernel_times(case, iters):
@@ -324,7 +319,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-copy", action="store_true", help="skip the device-to-device copy measurement (profiling passes: only the path's own kernels)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0, help="rows of the frame the CPU port baseline processes (0 = auto)")
-    ap.add_argument("--cpu-port", action="store_true", help="also time the C restatement (OpenMP) as a second, non-GL CPU line (+10 s)")
+    ap.add_argument("--cpu-port", action="store_true", help="(default since round 4) also time the C restatement (OpenMP) as a second, non-GL CPU line")
+    ap.add_argument("--no-cpu-port", action="store_true", help="skip the C restatement's CPU line (~10 s)")
+    ap.add_argument("--no-cold", action="store_true", help="skip the un-spun-up measurement (ms_per_step_cold)")
     ap.add_argument("--checksum", action="store_true", help="add sha1 of the final whole-frame composed GI to the JSON line (tiled == single check)")
     ap.add_argument("--exchange", choices=("c", "torch"), default="c", help="N > 1: exchanges through the C ABI's RCCL entry points (default) or torch.distributed")
     ap.add_argument("--extras-timeout", type=int, default=480, help="seconds the N > 1 extras (weak scaling, configs[4]) may take before the headline line is printed without them")
@@ -408,7 +405,7 @@ def main():
         use_c = False
         group = dist.new_group(backend="nccl")
         case = build_case(world, rank, local_rank, dev, dist, one_gpu, W1, H1, tiles, 20, 5, 1, use_c=False, group=group)
-    dt = time_case(case, dist, args.steps, args.warmup, dev, spinup=args.spinup)
+    dt, dt_cold = time_case(case, dist, args.steps, args.warmup, dev, spinup=args.spinup, cold=bool(args.spinup) and not args.no_cold)
     ctx = case["ctx"]
     ms_per_step = dt / args.steps * 1e3
     value = W1 * H1 * args.steps / dt / 1e6  # Mpixels/s, whole job
@@ -455,7 +452,11 @@ def main():
         out = {
             "metric": "Mpixels/s SSGI+denoise @4K steps=20; achieved HBM GB/s vs peak",
             "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_frames": args.spinup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4),
+            # the same W + K protocol run once BEFORE the spin-up frames, straight after the ~20 s of host-side set-up (device below its sustained clock)
+            "ms_per_step_cold": round(dt_cold / args.steps * 1e3, 4) if dt_cold else None,
+            # the job is the same 4K frame at every N (N > 1 cuts it into N row tiles): total work fixed
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload + ", steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step",
                        "frame": "%dx%d" % (W1, H1), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz", "uv_model": "reference_gl",
@@ -477,14 +478,18 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_PX[dom] * px_tile, "avg_launch_ms": round(kms[dom], 4)},
             "halo_violations": viol,
         }
-        # the bound that actually binds: VALU issue — the measured VALU occupancy of every kernel, next to the HBM roofline the
-        # metric asks for.  Only quoted for the frame the collection was taken on (the whole 4K frame on one GPU).
+        # what binds: instruction issue.  Per kernel, the ABSOLUTE time its measured dynamic instruction mix costs to issue
+        # (tools/issue_model.py: class counts from rocprofv3 --pmc x the per-class issue cost measured on this part) next to the time the kernel took
+        # in the same collection.  Only quoted for the frame the collection was taken on (the whole 4K frame on one GPU).
         if (W1, rows) == (W4K, H4K):
-            occ = {k: valu_occupancy(k) for k in kms}
-            if all(v is not None for v in occ.values()):
-                out["valu"] = dict(occ, note="per kernel: valu_busy = SQ_ACTIVE_INST_VALU*4 / (1024 SIMDs * GRBM_GUI_ACTIVE/8); valu_per_px = SQ_INSTS_VALU / SQ_WAVES; "
-                                             "cycles_per_valu = SQ_ACTIVE_INST_VALU*4 / SQ_INSTS_VALU — %s/pmc_sq_l2.csv (rocprofv3 --pmc over the same kernels and arguments, tools/quick_time.py; collected at git %s)" % (
-                                                 PROFILE_DIR, prof.get("git_commit", "?")))
+            im = issue_model()
+            if im:
+                out["issue_model"] = dict(im, note="per kernel: predicted_issue_ms = sum(class count x measured issue cycles) x waves per SIMD / clock; measured_ms = the kernel's "
+                                                   "average duration in the same rocprofv3 collection — %s/{pmc_sq_l2.csv, kernel_stats.csv, issue_model.txt} (collected at git %s)" % (
+                                                       PROFILE_DIR, prof.get("git_commit", "?")))
+        out["kernel_ms_note"] = ("kernel_ms: every kernel timed on its own (hipEvents, back-to-back launches of the same kernel); inside a frame K1's depth pre-pass "
+                                 "(k1_prepare + k1_pack_cells, its own stream) runs under the previous frame's K2-K4, so a kernel trace of whole frames shows those "
+                                 "three a few percent longer and K1 shorter, and sum_kernel_ms exceeds ms_per_step")
         if world > 1:
             out["config"]["exchange_verified"] = bool(use_c)  # the C-ABI exchanges passed their pre-flight pattern check on every rank
             out["config"]["history_exchange"] = history
@@ -494,7 +499,7 @@ def main():
         if args.checksum:
             out["compose_sha1"], out["frame_rows"] = compose_sha1, H1
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(case["frame"], case["fx"], W1, H1, args.cpu_sample_rows, args.cpu_port)
+            out["cpu_baseline"] = cpu_baseline(case["frame"], case["fx"], W1, H1, args.cpu_sample_rows, not args.no_cpu_port)
         print(json.dumps(out), flush=True)
 
     if world > 1 and not args.no_extras:
@@ -519,7 +524,7 @@ def main():
             wtiles = [(r * Ht, Ht) for r in range(world)]
             if wtiles == tiling.split_rows(Ht * world, world):
                 wcase = build_case(world, rank, local_rank, dev, dist, one_gpu, Ww, Ht * world, wtiles, 20, 5, 1, use_c=use_c, group=group)
-                wdt = time_case(wcase, dist, args.steps, args.warmup, dev)
+                wdt, _ = time_case(wcase, dist, args.steps, args.warmup, dev)
                 extras["weak_scaling"] = {"frame": "%dx%d" % (Ww, Ht * world), "tile_rows": Ht, "halo_rows": wcase["halo"], "ms_per_step": round(wdt / args.steps * 1e3, 4),
                                           "value": round(Ww * Ht * world * args.steps / wdt / 1e6, 2), "unit": "Mpixels/s",
                                           "halo_violations": wcase["ctx"].halo_violations()}
@@ -528,7 +533,7 @@ def main():
             W8, H8 = (int(v) for v in args.configs4_size.split("x"))
             c4 = build_case(world, rank, local_rank, dev, dist, one_gpu, W8, H8, tiling.split_rows(H8, world), 40, 5, 3, use_c=use_c, group=group)
             n4 = max(4, min(args.steps, 16))
-            d4 = time_case(c4, dist, n4, 2, dev)
+            d4, _ = time_case(c4, dist, n4, 2, dev)
             extras["configs4_8k"] = {"frame": "%dx%d" % (W8, H8), "steps": 40, "refineSteps": 5, "denoiseIterations": 3, "frames_timed": n4, "halo_rows": c4["halo"],
                                      "ms_per_frame": round(d4 / n4 * 1e3, 4), "value": round(W8 * H8 * n4 / d4 / 1e6, 2), "unit": "Mpixels/s",
                                      "halo_violations": c4["ctx"].halo_violations()}
@@ -606,7 +611,7 @@ def cpu_baseline_port(frame, fx, W, H, sample_rows):
     cores = len(os.sched_getaffinity(0))
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     blue = load_blue_noise_table()
-    rows = sample_rows or H
+    rows = sample_rows or min(H, 540)  # a quarter of the 4K frame through its middle: ~1 s per pass of the chain on this box's cores
     y0 = max(0, (H - rows) // 2) & ~1
     band = (y0, y0 + rows)
     z16 = lambda: np.zeros((H, W, 4), np.uint16)  # noqa: E731
@@ -631,7 +636,7 @@ def cpu_baseline_port(frame, fx, W, H, sample_rows):
         chain()
         n += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or n >= 20:
+        if dt > 8.0 or n >= 20:
             break
     return {"value": round(W * rows * n / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "sample": "%d x (K1+K2+2xK3+K4) over rows [%d,%d) of the same %dx%d frame, %.1f s of wall time, OMP threads=%s" % (

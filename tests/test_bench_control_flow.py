@@ -30,7 +30,7 @@ MOCK = textwrap.dedent('''
         calls[0] += 1
         if os.environ.get("HANG_AT") and calls[0] >= int(os.environ["HANG_AT"]):
             time.sleep(3600)
-        return 0.0366
+        return 0.0366, (0.0380 if k.get("cold") else None)
     bench.time_case = time_case
     bench.kernel_times = lambda *a, **k: dict(kms)
     bench.cpu_baseline = lambda *a, **k: {"value": 10.4, "unit": "Mpixels/s", "cores": 32, "kind": "reference", "sample": "mock"}
@@ -52,7 +52,8 @@ def _run(argv, env=None, timeout=120):
 
 def test_bench_line_single_gpu():
     j = _run(["--steps", "20", "--warmup", "5"])
-    assert j["n_gpus"] == 1 and j["scaling"] == "weak" and j["vs_baseline"] is None and j["unit"] == "Mpixels/s"
+    assert j["n_gpus"] == 1 and j["scaling"] == "strong" and j["vs_baseline"] is None and j["unit"] == "Mpixels/s"  # the same 4K frame at every N
+    assert abs(j["ms_per_step_cold"] - 1.9) < 1e-6  # the W + K protocol before the spin-up, reported beside the sustained figure
     assert abs(j["value"] - 3840 * 2160 * 20 / 0.0366 / 1e6) < 0.01 and abs(j["ms_per_step"] - 1.83) < 1e-6
     assert j["roofline"]["bound"] == "hbm" and j["roofline"]["kernel"] == "k1_ssgi_march" and 0 < j["roofline"]["frac"] < 1
     assert j["cpu_baseline"]["kind"] == "reference" and j["config"]["workload"].startswith("configs[2]")

@@ -19,7 +19,8 @@ json.dump({"profile": os.path.basename(sys.argv[1]), "git_commit": commit, "coll
 PY
 $ROOT/tools/microbench/bin/valu_rates2 > $OUT/valu_rates2.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-stream-copy"
+# the profiled command: the bench's own loop after its spin-up (--spinup 50: the device at its sustained clock, as in the line), 20 timed frames
+BENCH="python $ROOT/bench.py --steps 20 --warmup 2 --spinup 50 --no-cpu-baseline --no-stream-copy --no-cold"
 # 1. the bench line itself (un-profiled, with the CPU baselines)
 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 # 2. kernel trace + stats
@@ -33,7 +34,8 @@ PMC_TARGET="$BENCH"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS_F32" "TCC_HIT_sum TCC_MISS_sum" "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" \
-           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_INT32" "SQ_INSTS_VALU_CVT SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU"; do
   i=$((i+1))
   timeout ${PMC_TIMEOUT:-150} rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc$i -o p --output-format csv -- $PMC_TARGET > $OUT/pmc$i.log 2>&1 || echo "pmc set $i failed: $set" >> $OUT/errors.txt
 done
@@ -60,6 +62,7 @@ with open(out + "/pmc_sq_l2.csv", "w") as fh:
         for k, v in sorted(acc[c].items()):
             w.writerow([k, c, len(v), "%.4g" % (sum(v) / len(v))])
 PY
+python $ROOT/tools/issue_model.py $OUT > $OUT/issue_model.txt 2>&1
 rm -rf $OUT/trace $OUT/pmc[0-9]* 
 ls -la $OUT
 tail -1 $OUT/bench.json | cut -c1-300
