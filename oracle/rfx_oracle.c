@@ -77,6 +77,10 @@ static inline float pert_uv(float v) { return (g_pert_seed && g_pert_state) ? v 
  * to the lower triangle. */
 void rfxo_set_uv_model(int m) { g_uv_model = m; }
 int rfxo_get_uv_model(void) { return g_uv_model; }
+/* K3's tap rotation: 0 (default) = the correctly rounded (sin, cos) of the 256 possible angles — what the kernel's table holds; 1 = libm
+ * sinf / cosf of the fp32 angle, the restatement's form before round 3.  Kept so that a test can bound what the choice moves. */
+static int g_k3_rotation_libm = 0;
+void rfxo_set_k3_rotation_libm(int on) { g_k3_rotation_libm = on; }
 static inline float frag_u(int x, int y, int W, int H) {
     if (!g_uv_model) return ((float)x + 0.5f) / (float)W;
     float ooa = 1.0f / ((float)W * (float)H), dudx = (float)H * ooa;
@@ -1377,7 +1381,9 @@ static void k3_pixel(const k3_ctx *c, int x, int y, uint16_t *out0, uint16_t *ou
     float angle = random.x * 2.0f * 3.141592653589793f;
     /* 256 possible angles (an 8-bit blue-noise channel): the correctly rounded values, which is what the kernel's table holds
      * (csrc/k3_rotation_table.h) and what the reference GL returns at the two angles that decide taps (bytes 85, 170) */
-    float s = pert_ang((float)sin((double)angle)), co = pert_ang((float)cos((double)angle));
+    float s, co;
+    if (g_k3_rotation_libm) { s = sinf(angle); co = cosf(angle); }  /* (the macros above perturb these too) */
+    else { s = pert_ang((float)sin((double)angle)); co = pert_ang((float)cos((double)angle)); }
     /* mat2 rm = r * flatness * mat2(c, -s, s, c): columns (c,-s), (s,c) */
     float rf = r * flatness;
     float m00 = rf * co, m01 = rf * -s, m10 = rf * s, m11 = rf * co; /* m<col><row> */

@@ -91,6 +91,17 @@ class uv_model:
         return False
 
 
+class k3_rotation_libm:
+    """with k3_rotation_libm(): K3's tap rotation from libm sinf / cosf of the fp32 angle instead of the correctly rounded table values"""
+
+    def __enter__(self):
+        lib().rfxo_set_k3_rotation_libm(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().rfxo_set_k3_rotation_libm(0)
+
+
 def frag_uv(W, H, model="reference"):
     """(u, v) planes of an H x W target under a vUv model (numpy restatement of rfx_oracle.c frag_u / frag_v, for the probe and tests)."""
     f32 = np.float32

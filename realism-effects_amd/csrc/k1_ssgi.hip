@@ -378,7 +378,8 @@ RFX_DEV float3 k1_env_color(const K1Args &A, float3 l, float roughness, bool isD
     v = 1.0f - v;
     float3 c = k1_env_trilinear(A, u, v, mip);
     const float maxEnvLum = isEnvSample ? 100.0f : 25.0f, envLum = rfx_lum(c);  // :328-340
-    if (envLum > maxEnvLum) c = c * rfx_div_pos(maxEnvLum, envLum);
+    // (an HDR texel can be huge or infinite: rfx_div_pos needs a divisor well inside the exponent range, IEEE `/` gives 0 for inf)
+    if (envLum > maxEnvLum) c = c * (envLum < 1.0e30f ? rfx_div_pos(maxEnvLum, envLum) : maxEnvLum / envLum);
     return c;
 }
 
@@ -415,7 +416,10 @@ struct EnvMis {  // EnvMisSample ssgi.frag:79-83
     float pdf;
     bool isEnvSample;
 };
-RFX_DEV float k1_mis_heuristic(float a, float b) { return rfx_div_pos(a * a, a * a + b * b); }  // misHeuristic ssgi_utils.frag:227-231
+RFX_DEV float k1_mis_heuristic(float a, float b) {  // misHeuristic ssgi_utils.frag:227-231 (the pdfs are unbounded: the refined reciprocal only inside its range)
+    const float n = a * a, d = a * a + b * b;
+    return (d > 1.0e-30f && d < 1.0e30f) ? rfx_div_pos(n, d) : n / d;
+}
 
 // ... and the shading of the marched ray: gi * brdf / pdf
 template <bool ENV, bool MIS>

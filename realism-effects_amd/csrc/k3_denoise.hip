@@ -150,7 +150,15 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     const int koff = __mul24(Ry - ty0, PITCH) + (Rx - tx0);
     const float4 *g_geom = s_geom + koff;
     const float *g_depth = s_depth + koff;
-    const float wm1 = (float)(d.W - 1), hm1 = (float)(d.H - 1), wmh = d.fW - 0.5f, hmh = d.fH - 0.5f;
+    // CLAMP_TO_EDGE bounds of the taps, as floats: the FRAME's, intersected with the staged window.  For every finite tap coordinate the frame's
+    // bounds alone give the same texel (the apron is the tap footprint, so the clamped texel is staged); the intersection only matters for a
+    // coordinate that is not a number (a NaN depth or normal in the dump): v_med3_f32 then returns the lower bound, which is inside the tile —
+    // with the frame's bounds it was frame texel (0, 0), an LDS address far outside most tiles.  Same instruction count.
+    const int lastx = tx0 + TW - 1 + Rx, lasty = min(ty0 + TH - 1 + Ry, A.y1 - 1 + Ry);  // last staged column / row (frame coordinates; may lie beyond the frame)
+    const float xlo = (float)max(tx0 - Rx, 0), ylo = (float)max(ty0 - Ry, 0);
+    const float wm1 = (float)min(d.W - 1, lastx), hm1 = (float)min(d.H - 1, lasty);
+    // ... and of the lower texel of a bilinear footprint (rfx_linear_coord_fast): its +1 neighbour must be staged too
+    const float wmh = fminf(d.fW - 0.5f, (float)lastx - 0.5f), hmh = fminf(d.fH - 0.5f, (float)lasty - 0.5f);
 
     CenterTexel c[TC];
     float l2spec_i[TC];      // log2 of the extra specular factor of accumulator i (0 for a diffuse texture)
@@ -176,7 +184,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
                 fx = u * d.fW;
                 fy = v * d.fH;
             }
-            const LinearCoord lx = rfx_linear_coord_fast(fx, wmh), ly = rfx_linear_coord_fast(fy, hmh);
+            const LinearCoord lx = rfx_linear_coord_fast(fx, xlo, wmh), ly = rfx_linear_coord_fast(fy, ylo, hmh);
             const uint2 *q = g_inN[i] + (__mul24(ly.i0, PITCH) + lx.i0);
             t = rfx_bilerp_half_rgba(q[0], q[1], q[PITCH], q[PITCH + 1], lx.w, ly.w);
         }
@@ -208,7 +216,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
             fy = nv * d.fH;
         }
         // nearest CLAMP_TO_EDGE texel of the tap (rfx_nearest_idx without its NaN / 2^31 guard: the coordinates are finite and O(size) here)
-        const int ni = __mul24((int)__builtin_amdgcn_fmed3f(fy, 0.0f, hm1), PITCH) + (int)__builtin_amdgcn_fmed3f(fx, 0.0f, wm1);
+        const int ni = __mul24((int)__builtin_amdgcn_fmed3f(fy, ylo, hm1), PITCH) + (int)__builtin_amdgcn_fmed3f(fx, xlo, wm1);
         // getBasicNeighborWeight :52-78
         const float nd = g_depth[ni];
         const float4 ng = g_geom[ni];
@@ -225,7 +233,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
                 k3_apply_d(c[i], l2basic + l2spec_i[i], dbasic * dspec_i[i], make_float3(tl.x, tl.y, tl.z), tl.w, lumaPhiL2);
             }
         } else {
-            const LinearCoord lx = rfx_linear_coord_fast(fx, wmh), ly = rfx_linear_coord_fast(fy, hmh);
+            const LinearCoord lx = rfx_linear_coord_fast(fx, xlo, wmh), ly = rfx_linear_coord_fast(fy, ylo, hmh);
             const int li = __mul24(ly.i0, PITCH) + lx.i0;
 #pragma unroll
             for (int i = 0; i < TC; i++) {

@@ -678,13 +678,16 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
     HIPCHK(c, hipEventRecord(c->ev_k1_done, c->stream));  // the next pre-pass overwrites what this launch reads
     c->k1_event_set = true;
     c->hits_traced = stage == 1;
-    if (stage == 1) { c->trace_y0 = A.y0; c->trace_y1 = any ? A.y1 : A.y0; c->trace_missed = p->missedRays; }
+    if (stage == 1) { c->trace_y0 = A.y0; c->trace_y1 = any ? A.y1 : A.y0; c->trace_missed = p->missedRays; c->trace_scaled = rs != 1.0f; }
     return RFX_OK;
 }
 
 // between rfx_ssgi_trace and rfx_ssgi_shade (rfx_gather_history_rows): which rows of last frame's composed GI will the shade read?
 int rfx_internal_hit_rows_enqueue(rfx_ctx *c, int *rows_dev) {
     if (!c->hits || !c->hits_traced) return fail(c, RFX_ESTATE, "rfx_gather_history_rows: no rfx_ssgi_trace of this frame is waiting for its shade");
+    // the hand-over plane of a resolutionScale != 1 trace is indexed by the SMALLER target (and such a trace needs a whole-frame context, which
+    // has no history to gather): the row reduction below reads it with the frame's pitch
+    if (c->trace_scaled) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_hit_rows / rfx_gather_history_rows: the last rfx_ssgi_trace ran with resolutionScale != 1");
     hipSetDevice(c->device);
     static const int preset[2] = {0x7fffffff, -1};
     HIPCHK(c, hipMemcpyAsync(rows_dev, preset, sizeof preset, hipMemcpyHostToDevice, c->stream));

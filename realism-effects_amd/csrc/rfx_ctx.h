@@ -28,6 +28,7 @@ struct rfx_ctx {
     float4 *hits = nullptr;    // K1 trace -> shade hand-over (rfx_ssgi_trace), 2 texels per SSGI texel
     bool hits_traced = false;  // a trace is waiting for its shade
     int trace_y0 = 0, trace_y1 = 0, trace_missed = 0;  // the rows and the missedRays option of that trace (rfx_gather_history_rows)
+    bool trace_scaled = false;                         // ... and whether it drew a smaller target (resolutionScale != 1)
     int *hit_rows_dev = nullptr;   // device: [0..1] this tile's (min, max) needed history row, [2..2n+1] every rank's
     int *hit_rows_host = nullptr;  // pinned mirror of the gathered part
     // K1's depth pre-pass (view-Z plane + (min, max) cells) depends on the frame's depth plane only: it runs on its own stream, after

@@ -206,14 +206,17 @@ struct LinearCoord {
     int i0;   // lower texel; the upper one is min(i0 + 1, size - 1)
     float w;  // weight of the upper texel
 };
-RFX_DEV LinearCoord rfx_linear_coord_fast(float c, float size_minus_half) {
+// lo: 0 for a frame; a tile kernel passes its staged window's first texel so that a NaN coordinate (v_med3 returns the lower bound) stays inside
+// the window — for finite coordinates whose footprint the window holds, the same (i0, w)
+RFX_DEV LinearCoord rfx_linear_coord_fast(float c, float lo, float size_minus_half) {
 #pragma clang fp contract(off)  // c - 0.5 must not fuse with the product that formed c (K3 / K4 are compiled with contraction on)
-    const float c2 = __builtin_amdgcn_fmed3f(c - 0.5f, 0.0f, size_minus_half);
+    const float c2 = __builtin_amdgcn_fmed3f(c - 0.5f, lo, size_minus_half);
     LinearCoord r;
     r.i0 = (int)c2;
     r.w = __builtin_amdgcn_fractf(c2);
     return r;
 }
+RFX_DEV LinearCoord rfx_linear_coord_fast(float c, float size_minus_half) { return rfx_linear_coord_fast(c, 0.0f, size_minus_half); }
 // The sampler's lerp on HALF texels without converting them first: v_fma_mix_f32 reads either half of a 32-bit register as an f16
 // source of an fp32 fma.  d = fp32(b) - fp32(a) (one rounding, as v_sub_f32 on the converted values), then fma(w, d, fp32(a)) — the fused
 // lerp of the oracle GL's sampler (oracle/rfx_oracle.c fetch_h4_linear).  Two instructions per channel instead of two v_cvt_f32_f16,

@@ -1250,3 +1250,52 @@ def test_zz_measured_out_of_tolerance_fractions():
         worst[name] = max(worst.get(name, 0.0), frac)
     for name, frac in sorted(worst.items(), key=lambda kv: -kv[1])[:40]:
         print("  %-40s %.5f %%" % (name, 100 * frac))
+
+
+def test_denoise_with_nan_texels_stays_inside_its_tile(blue_noise):
+    """A dump with texels that are not numbers (NaN depth, NaN packed normal): the tiled K3's tap coordinates of the pixels around them are NaN.
+    The taps' CLAMP_TO_EDGE bounds are the frame's intersected with the staged window, so such a tap reads a texel of its own tile instead of
+    frame texel (0, 0) far outside it (run under `--hostsim --hostsim-build _asan` this is an address check).  Pixels whose
+    footprint holds no NaN texel are unaffected: they agree with the oracle as always."""
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_frame
+    import rfx_oracle as O
+
+    W, H = 256, 144
+    f = synthetic_frame(W, H, 0)
+    depth, gb = f.depth.copy(), f.gbuffer.copy()
+    rng = np.random.RandomState(11)
+    ys, xs = rng.randint(8, H - 8, 12), rng.randint(8, W - 8, 12)
+    depth[ys[:6], xs[:6]] = np.nan
+    gb[ys[6:], xs[6:], 1] = 0x7e007e00  # packed half2 normal: two NaN halfs
+    poisoned = np.zeros((H, W), bool)
+    for y, x in zip(ys, xs):
+        poisoned[max(0, y - 6):y + 7, max(0, x - 12):x + 13] = True  # radius 3 taps (x 16/9 horizontally), the quad derivatives, the bilinear footprint
+    _, _, dp, _ = _params(abi, f, f.camera, 1.0)
+    T = [(rng.rand(H, W, 4).astype(np.float32) * np.array([2, 2, 2, 6], np.float32)) for _ in range(2)]
+    ctx = Context(W, H)
+    ctx.upload_frame(f)
+    ctx.upload(abi.TEX_DEPTH, depth)
+    ctx.upload(abi.TEX_GBUFFER, gb)
+    ctx.upload(abi.TEX_TEMPORAL0, T[0])
+    ctx.upload(abi.TEX_TEMPORAL1, T[1])
+    A = [np.zeros((H, W, 4), np.uint16) for _ in range(2)]
+    B = [np.zeros((H, W, 4), np.uint16) for _ in range(2)]
+    dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 31, 1, 0
+    ctx.poisson_denoise(dp)
+    O.denoise(depth, gb, T[0], T[1], blue_noise, dp, A[0], A[1])
+    gotA = [ctx.download(t) for t in (abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1)]
+    ctx.upload(abi.TEX_DENOISE_A0, A[0])
+    ctx.upload(abi.TEX_DENOISE_A1, A[1])
+    dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 32, 0, 1
+    ctx.poisson_denoise(dp)
+    O.denoise(depth, gb, A[0], A[1], blue_noise, dp, B[0], B[1])
+    gotB = [ctx.download(t) for t in (abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1)]
+    assert ctx.halo_violations() == 0
+    ctx.close()
+    clean = ~poisoned
+    for name, got, want in (("nan A", gotA, A), ("nan B", gotB, B)):
+        for j in range(2):
+            g, w = O.half_bits_to_float(got[j])[clean][None], O.half_bits_to_float(want[j])[clean][None]
+            assert_close("%s%d (pixels away from the NaN texels)" % (name, j), g, w, FLIP["denoise"])

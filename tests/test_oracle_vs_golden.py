@@ -63,6 +63,35 @@ def assert_strict(name, rerun, want, half, max_fraction=0.01):
     return r
 
 
+def test_k3_rotation_table_against_libm_sincos(blue_noise):
+    """Round 3 moved K3's tap rotation — in the kernel AND in this restatement — from sinf / cosf of the fp32 angle to the correctly rounded
+    (sin, cos) of the 256 possible angles.  The two forms, each against the reference's golden K3 outputs: both inside the stage's bound, and
+    what the choice moves is a handful of texels (a radius-3 tap of a flat surface at 120 / 240 degrees sits on a texel boundary; the table's
+    last bit of cos is the reference GL's there, libm's is not) — the kernel's choice is checked independently of the restatement's default."""
+    g = G.load("chain_160x90_s20r5_it1")
+    W, H = int(g["width"]), int(g["height"])
+    f = G.frame(g, 1)
+    _, _, dp, _ = stage_params(g, 1, 1.0)
+    dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = int(g["f1_denoise_index"][0]), 1, 0
+
+    def run():
+        A = [np.ascontiguousarray(g["f0_A%d" % j]).copy() for j in range(2)]
+        O.denoise(f.depth, f.gbuffer, np.ascontiguousarray(g["f1_temporal0"]), np.ascontiguousarray(g["f1_temporal1"]), blue_noise, dp, A[0], A[1])
+        return [O.half_bits_to_float(a) for a in A]
+    table = run()
+    with O.k3_rotation_libm():
+        libm = run()
+    moved = 0
+    for j in range(2):
+        want = O.half_bits_to_float(g["f1_A%d" % j])
+        ft, _ = assert_close("table A%d" % j, table[j], want, FLIP["denoise0"])
+        fl, _ = assert_close("libm  A%d" % j, libm[j], want, FLIP["denoise0"])
+        moved += int((table[j] != libm[j]).any(axis=-1).sum())
+        print("K3 pass 0 tex%d vs golden: table %.4f %%, libm %.4f %% of the texels outside 1e-3" % (j, 100 * ft, 100 * fl))
+    print("texels the rotation form moves at all: %d of %d" % (moved, 2 * W * H))
+    assert moved <= 0.01 * 2 * W * H
+
+
 @pytest.mark.parametrize("name", G.GOLDENS)
 def test_stagewise(name, blue_noise):
     """Every pass fed with the GOLDEN outputs of the previous passes."""
