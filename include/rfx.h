@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 15
+#define RFX_ABI_VERSION 16
 
 enum {
     RFX_OK = 0,
@@ -339,15 +339,21 @@ int rfx_halo_exchange(rfx_ctx *, rfx_tex id, void *ncclComm, int up_rank, int do
 int rfx_allgather_history(rfx_ctx *, rfx_tex id, void *ncclComm);
 /* The bounded form of that gather (ABI 15), called BETWEEN rfx_ssgi_trace and rfx_ssgi_shade: only the shading of a ray reads last
  * frame's composed GI, NEAREST at the ray's final uv (ssgi.frag:396-427), and after the trace those uvs are known.  The call reduces, on
- * the device, the (min, max) history row this tile's rays will read, all-gathers the N pairs, and moves with grouped ncclSend / ncclRecv
- * only the rows some rank needs from their owners (whose rows are current: K4 wrote them) — instead of every rank receiving the other
- * N - 1 tiles.  Bit-identical to the all-gather form.  It waits on the host for the 2 N integers (i.e. for the trace to finish); the row
+ * the device, the ROW MASK of the history texels this tile's rays will read (ABI 16: one word per frame row, see rfx_ssgi_hit_mask; ABI 15
+ * reduced one (min, max) row interval, which also moved every row between two needed ones), all-gathers the N masks, and moves with grouped
+ * ncclSend / ncclRecv only the rows some rank needs from their owners (whose rows are current: K4 wrote them), in runs of consecutive
+ * rows — instead of every rank receiving the other N - 1 tiles.  Bit-identical to the all-gather form.  It waits on the host for the N
+ * masks (height words each; i.e. for the trace to finish); the row
  * transfers are asynchronous like the other exchanges (rfx_comm_wait before rfx_ssgi_shade).  `bytes_received` (may be NULL): what this
  * rank receives this frame.  A host uses EITHER this or rfx_allgather_history after K4. */
 int rfx_gather_history_rows(rfx_ctx *, rfx_tex id, void *ncclComm, size_t *bytes_received);
 /* The reduction on its own (any context, no communicator): after rfx_ssgi_trace, the inclusive range of history rows the shade of the
  * traced rows will read; row_hi < row_lo when it reads none.  Blocks until the trace has finished. */
 int rfx_ssgi_hit_rows(rfx_ctx *, int *row_lo, int *row_hi);
+/* ... and the mask form (ABI 16): row_mask[y], y in [0, height), gets bit b set when the shade of the traced rows reads a history texel of
+ * frame row y in column block b (32 equal blocks across the frame: texel x is in block x * 32 / width); a row that is not read at all
+ * gets 0.  `rows` must be the frame height.  Blocks until the trace has finished. */
+int rfx_ssgi_hit_mask(rfx_ctx *, unsigned int *row_mask, int rows);
 int rfx_comm_wait(rfx_ctx *);
 
 /* Number of texel fetches that fell outside the rows a tile context holds since creation

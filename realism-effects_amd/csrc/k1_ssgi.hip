@@ -718,6 +718,29 @@ __global__ __launch_bounds__(256) void k1_hit_rows(FrameDims d, int y0, int y1, 
     }
 }
 
+// ... and the finer form the bounded gather uses since round 4: ONE 32-bit word per frame row, bit b = some ray of the launch reads column block
+// b of that row (32 equal blocks across the frame).  A row whose word is 0 is not read at all — the (min, max) interval above also covers every
+// row between two rows that are.  Guarded atomics: a set bit is never set again (a stale read only costs a redundant atomic).
+__global__ __launch_bounds__(256) void k1_hit_mask(FrameDims d, int y0, int y1, TexView depth, TexViewW out, const float4 *hits, int allow_missed, unsigned int *mask) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = y0 + blockIdx.y * 4 + threadIdx.y;
+    d.viol = 0;
+    if (x >= d.W || y >= y1) return;
+    const float dp = ((const float *)depth.ptr)[rfx_xy_index(d, depth.row0, depth.rows, x, y)];
+    if (dp == 1.0f) return;  // background fragments return before tracing (their hand-over texels are stale)
+    const size_t i = (size_t)rfx_local_row(d, out.row0, out.rows, y) * d.W + x;
+    const float4 h0 = hits[2 * i], h1 = hits[2 * i + 1];
+    const float u[2] = {h0.x, h0.z}, v[2] = {h0.y, h0.w}, px[2] = {h1.x, h1.y};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const bool missed = px[r] == 10.0e9f;
+        if ((allow_missed || !missed) && u[r] >= 0.0f && u[r] <= 1.0f && v[r] >= 0.0f && v[r] <= 1.0f) {
+            const int row = rfx_nearest_idx(v[r], d.fH, d.H), col = rfx_nearest_idx(u[r], d.fW, d.W);
+            const unsigned int bit = 1u << ((unsigned int)(col * 32) / (unsigned int)d.W);
+            if (!(mask[row] & bit)) atomicOr(&mask[row], bit);
+        }
+    }
+}
+
 // Pre-pass: view-space Z per texel (getViewZ, ssgi_utils.frag:9: nearMulFar / (farMinusNear * depth - cameraFar), IEEE)
 // and its (min, max) per 8x8 cell.  64x8-pixel workgroups = 8 cells; 8-lane shuffles reduce a row segment, LDS the rows.
 __global__ __launch_bounds__(64 * BASE) void k1_prepare(const float *depth, float *viewz, float2 *base, int W, int H, int base_w, float nearMulFar,
@@ -810,6 +833,12 @@ int rfx_k1_base_cell() { return BASE; }
 hipError_t rfx_launch_k1_hit_rows(const FrameDims &d, int y0, int y1, TexView depth, TexViewW out, const float4 *hits, bool allow_missed, int *rows, hipStream_t stream) {
     dim3 block(64, 4), grid((d.W + 63) / 64, (y1 - y0 + 3) / 4);
     hipLaunchKernelGGL(k1_hit_rows, grid, block, 0, stream, d, y0, y1, depth, out, hits, allow_missed ? 1 : 0, rows);
+    return hipGetLastError();
+}
+
+hipError_t rfx_launch_k1_hit_mask(const FrameDims &d, int y0, int y1, TexView depth, TexViewW out, const float4 *hits, bool allow_missed, unsigned int *mask, hipStream_t stream) {
+    dim3 block(64, 4), grid((d.W + 63) / 64, (y1 - y0 + 3) / 4);
+    hipLaunchKernelGGL(k1_hit_mask, grid, block, 0, stream, d, y0, y1, depth, out, hits, allow_missed ? 1 : 0, mask);
     return hipGetLastError();
 }
 

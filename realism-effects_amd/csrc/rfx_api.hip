@@ -97,6 +97,9 @@ void rfx_destroy(rfx_ctx *c) {
     if (c->hits) hipFree(c->hits);
     if (c->hit_rows_dev) hipFree(c->hit_rows_dev);
     if (c->hit_rows_host) hipHostFree(c->hit_rows_host);
+    if (c->hit_mask_dev) hipFree(c->hit_mask_dev);
+    if (c->hit_mask_host) hipHostFree(c->hit_mask_host);
+    if (c->hist_staging) hipFree(c->hist_staging);
     if (c->coarse) hipFree(c->coarse);
     if (c->cells) hipFree(c->cells);
     if (c->k1_tiles) hipFree(c->k1_tiles);
@@ -693,6 +696,36 @@ int rfx_internal_hit_rows_enqueue(rfx_ctx *c, int *rows_dev) {
     HIPCHK(c, hipMemcpyAsync(rows_dev, preset, sizeof preset, hipMemcpyHostToDevice, c->stream));
     if (c->trace_y1 > c->trace_y0)
         HIPCHK(c, rfx_launch_k1_hit_rows(dims(c), c->trace_y0, c->trace_y1, view(c, RFX_TEX_DEPTH), wview(c, RFX_TEX_SSGI), c->hits, c->trace_missed != 0, rows_dev, c->stream));
+    return RFX_OK;
+}
+
+int rfx_internal_hit_mask_enqueue(rfx_ctx *c, int ranks) {
+    if (!c->hits || !c->hits_traced) return fail(c, RFX_ESTATE, "rfx_gather_history_rows / rfx_ssgi_hit_mask: no rfx_ssgi_trace of this frame is waiting for its shade");
+    if (c->trace_scaled) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_hit_mask / rfx_gather_history_rows: the last rfx_ssgi_trace ran with resolutionScale != 1");
+    hipSetDevice(c->device);
+    if (ranks < 1) ranks = 1;
+    if (!c->hit_mask_dev || c->hit_mask_ranks < ranks) {
+        if (c->hit_mask_dev) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->hit_mask_dev); hipHostFree(c->hit_mask_host); c->hit_mask_dev = nullptr; c->hit_mask_host = nullptr; }
+        const size_t words = (size_t)(2 * ranks + 2) * c->H;  // [0, H) this tile's mask, [H, (n + 1) H) every rank's, then (n + 1) H row offsets
+        hipError_t e = hipMalloc((void **)&c->hit_mask_dev, words * sizeof(unsigned int));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&c->hit_mask_host, words * sizeof(unsigned int), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(c, RFX_ENOMEM, "rfx_ssgi_hit_mask: scratch", e);
+        c->hit_mask_ranks = ranks;
+    }
+    HIPCHK(c, hipMemsetAsync(c->hit_mask_dev, 0, (size_t)c->H * sizeof(unsigned int), c->stream));
+    if (c->trace_y1 > c->trace_y0)
+        HIPCHK(c, rfx_launch_k1_hit_mask(dims(c), c->trace_y0, c->trace_y1, view(c, RFX_TEX_DEPTH), wview(c, RFX_TEX_SSGI), c->hits, c->trace_missed != 0, c->hit_mask_dev, c->stream));
+    return RFX_OK;
+}
+
+int rfx_ssgi_hit_mask(rfx_ctx *c, unsigned int *row_mask, int rows) {
+    if (!c || !row_mask) return RFX_EINVAL;
+    if (rows != c->H) return fail(c, RFX_EINVAL, "rfx_ssgi_hit_mask: one word per frame row (rows == height)");
+    int rc = rfx_internal_hit_mask_enqueue(c, 1);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->hit_mask_host, c->hit_mask_dev, (size_t)c->H * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    memcpy(row_mask, c->hit_mask_host, (size_t)c->H * sizeof(unsigned int));
     return RFX_OK;
 }
 

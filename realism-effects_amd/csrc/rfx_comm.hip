@@ -18,7 +18,7 @@ namespace {
 struct NcclUniqueId { char internal[128]; };
 typedef void *NcclComm;
 typedef int NcclResult;
-constexpr int kNcclUint8 = 1, kNcclInt32 = 2;
+constexpr int kNcclUint8 = 1, kNcclUint32 = 3;
 
 struct Rccl {
     void *handle = nullptr;
@@ -106,6 +106,45 @@ int ensure_streams(rfx_ctx *c) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_draws, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming);
     return e == hipSuccess ? RFX_OK : fail(c, RFX_EDEVICE, "rfx_comm: stream/event creation", e);
+}
+
+
+// ---- the bounded gather's packed transfer (rfx_gather_history_rows): the history texels a rank needs are column blocks of rows (a bit per
+// block in the row's mask word, 32 blocks across the frame).  The owner packs the blocks a peer's mask asks for, row by row and block by
+// block, into one contiguous message per peer; the receiver scatters them back.  Both ends derive the layout from the same gathered masks.
+__device__ __host__ inline int hist_block_x0(int b, int W) { return (b * W + 31) / 32; }  // first texel of column block b: texel x is in block x * 32 / W
+// texel offset of frame column x inside the packed form of a row whose mask is m (x's block bit is set)
+__device__ inline int hist_packed_x(unsigned int m, int x, int W) {
+    const int b = (x * 32) / W;
+    int off = x - hist_block_x0(b, W);
+    for (unsigned int below = m & ((1u << b) - 1u); below; below &= below - 1u) {
+        const int j = __builtin_ctz(below);
+        off += hist_block_x0(j + 1, W) - hist_block_x0(j, W);
+    }
+    return off;
+}
+// rows [y0, y1) of the frame-pitched plane `tex` (floats_per_texel floats per texel) <-> the packed staging of one peer.
+// row_off[y]: texel offset of row y's packed texels in `staging`, or -1 when nothing of row y travels.
+template <bool PACK>
+__global__ __launch_bounds__(256) void hist_pack_rows(float *tex, float *staging, const unsigned int *mask, const int *row_off, int W, int y0, int y1, int floats_per_texel) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = y0 + blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= y1) return;
+    const unsigned int m = mask[y];
+    if (!((m >> ((x * 32) / W)) & 1u) || row_off[y] < 0) return;
+    float *t = tex + ((size_t)y * W + x) * floats_per_texel;
+    float *q = staging + ((size_t)row_off[y] + hist_packed_x(m, x, W)) * floats_per_texel;
+    for (int k = 0; k < floats_per_texel; k++) {
+        if (PACK) q[k] = t[k];
+        else t[k] = q[k];
+    }
+}
+inline int hist_row_texels(unsigned int m, int W) {  // texels of a row the mask m selects
+    int n = 0;
+    for (; m; m &= m - 1u) {
+        const int j = __builtin_ctz(m);
+        n += hist_block_x0(j + 1, W) - hist_block_x0(j, W);
+    }
+    return n;
 }
 
 }  // namespace
@@ -291,47 +330,93 @@ int rfx_gather_history_rows(rfx_ctx *c, rfx_tex id, void *nccl_comm, size_t *byt
     int rc = ensure_streams(c);
     if (rc) return rc;
     hipSetDevice(c->device);
-    if (n > 64) return fail(c, RFX_EUNSUPPORTED, "rfx_gather_history_rows: more than 64 ranks");
-    if (!c->hit_rows_dev) {  // (the same scratch as rfx_ssgi_hit_rows: 2 + 2 * 64 ints)
-        hipError_t e = hipMalloc((void **)&c->hit_rows_dev, sizeof(int) * 130);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&c->hit_rows_host, sizeof(int) * 128, hipHostMallocDefault);
-        if (e != hipSuccess) return fail(c, RFX_ENOMEM, "rfx_gather_history_rows: scratch", e);
-    }
     char *base = (char *)rfx_tex_device_ptr(c, id);  // held whole: frame row y at y * pitch
     if (!base) return RFX_ENOMEM;
     const Slot &s = c->slots[id];
-    const size_t pitch = (size_t)s.width * s.texel;
-    // 1. this tile's needed rows (device reduction over the trace's hand-over plane), on the draw stream
-    if ((rc = rfx_internal_hit_rows_enqueue(c, c->hit_rows_dev))) return rc;
-    // 2. every rank's needed rows -> host.  The one host-side wait of the exchange: the plan below needs the numbers (2 ints per rank).
+    const int H = c->H;
+    if (n > 64) return fail(c, RFX_EUNSUPPORTED, "rfx_gather_history_rows: more than 64 ranks");
+    // 1. this tile's row mask (device reduction over the trace's hand-over plane: one word per frame row, a bit per column block), on the draw stream
+    if ((rc = rfx_internal_hit_mask_enqueue(c, n))) return rc;
+    // 2. every rank's mask -> host.  The one host-side wait of the exchange: the plan below needs them (H words per rank: 8.6 KB at 4K).
     if ((rc = comm_begin(c))) return rc;
-    NCCLCHK(c, r->AllGather(c->hit_rows_dev, c->hit_rows_dev + 2, 2, kNcclInt32, comm, c->comm_stream));
-    HIPCHK(c, hipMemcpyAsync(c->hit_rows_host, c->hit_rows_dev + 2, sizeof(int) * (size_t)(2 * n), hipMemcpyDeviceToHost, c->comm_stream));
+    NCCLCHK(c, r->AllGather(c->hit_mask_dev, c->hit_mask_dev + H, (size_t)H, kNcclUint32, comm, c->comm_stream));
+    HIPCHK(c, hipMemcpyAsync(c->hit_mask_host, c->hit_mask_dev + H, sizeof(unsigned int) * (size_t)n * H, hipMemcpyDeviceToHost, c->comm_stream));
     HIPCHK(c, hipStreamSynchronize(c->comm_stream));
-    // 3. rank p needs rows [lo_p, hi_p]; whoever owns a part of them sends that part (the owner's rows of last frame's composed GI are
-    //    current: K4 wrote them).  Both ends compute the same intersection, so every Send has its Recv; empty ones are skipped on both.
+    // 3. rank p needs the column blocks its mask names; whoever owns their rows packs them into ONE message for p (the owner's rows of last
+    //    frame's composed GI are current: K4 wrote them), p scatters them back.  Both ends walk the same masks in the same order (row by
+    //    row, block by block), so the two sides of every message agree on its size and layout.  Measured on the synthetic orbit
+    //    (tools/history_rows_report.py): the blocks are a quarter of the bytes of the rows they lie in — reflections reach most ROWS
+    //    below the horizon but only part of each.  (Round 3's plan was the (min, max) row interval per rank.)
+    const int W = c->W, fpt = (int)(s.texel / sizeof(float));
+    const unsigned int *mine = c->hit_mask_host + (size_t)me * H;
+    // row offsets (texels) into the per-peer segments of the two stagings; segment bases per peer
+    int *off_host = (int *)(c->hit_mask_host + (size_t)n * H);          // [0, n H): send offsets per peer; [n H, (n + 1) H): receive offsets
+    size_t send_base[65], recv_base[65], send_tex = 0, recv_tex = 0;  // [p]: first texel of peer p's segment, [n]: the total
+    for (int p = 0; p < n; p++) {
+        int py0 = 0, prows = 0;
+        rfx_split_rows(H, n, p, &py0, &prows);
+        const unsigned int *theirs = c->hit_mask_host + (size_t)p * H;
+        send_base[p] = send_tex;
+        recv_base[p] = recv_tex;
+        int *so = off_host + (size_t)p * H;
+        for (int y = 0; y < H; y++) so[y] = -1;
+        if (p == me) continue;
+        size_t k = 0;
+        for (int y = c->tile_y0; y < c->tile_y0 + c->tile_rows; y++)  // what p needs of MY rows
+            if (theirs[y]) { so[y] = (int)k; k += (size_t)hist_row_texels(theirs[y], W); }
+        send_tex += k;
+        k = 0;
+        int *ro = off_host + (size_t)n * H;
+        for (int y = py0; y < py0 + prows; y++) {  // what I need of p's rows
+            ro[y] = -1;
+            if (mine[y]) { ro[y] = (int)k; k += (size_t)hist_row_texels(mine[y], W); }
+        }
+        recv_tex += k;
+    }
+    for (int y = c->tile_y0; y < c->tile_y0 + c->tile_rows; y++) off_host[(size_t)n * H + y] = -1;  // (my own rows: nothing to receive)
+    send_base[n] = send_tex;
+    recv_base[n] = recv_tex;
+    const size_t need = (send_tex + recv_tex) * s.texel;
+    if (need > c->hist_staging_bytes) {
+        if (c->hist_staging) { HIPCHK(c, hipStreamSynchronize(c->comm_stream)); hipFree(c->hist_staging); c->hist_staging = nullptr; c->hist_staging_bytes = 0; }
+        const size_t cap = need + need / 4 + 4096;
+        hipError_t he = hipMalloc((void **)&c->hist_staging, cap);
+        if (he != hipSuccess) return fail(c, RFX_ENOMEM, "rfx_gather_history_rows: staging", he);
+        c->hist_staging_bytes = cap;
+    }
+    char *send_stage = (char *)c->hist_staging, *recv_stage = send_stage + send_tex * s.texel;
+    int *off_dev = (int *)(c->hit_mask_dev + (size_t)(n + 1) * H);
+    HIPCHK(c, hipMemcpyAsync(off_dev, off_host, sizeof(int) * (size_t)(n + 1) * H, hipMemcpyHostToDevice, c->comm_stream));
+    const dim3 blk(64, 4);
+    for (int p = 0; p < n; p++) {  // pack: one launch per peer over my tile's rows
+        const size_t cnt = send_base[p + 1] - send_base[p];
+        if (p == me || cnt == 0) continue;
+        hipLaunchKernelGGL(hist_pack_rows<true>, dim3((W + 63) / 64, (c->tile_rows + 3) / 4), blk, 0, c->comm_stream, (float *)base, (float *)(send_stage + send_base[p] * s.texel),
+                           (const unsigned int *)(c->hit_mask_dev + (size_t)(1 + p) * H), (const int *)(off_dev + (size_t)p * H), W, c->tile_y0, c->tile_y0 + c->tile_rows, fpt);
+    }
+    HIPCHK(c, hipGetLastError());
     size_t got = 0;
     NCCLCHK(c, r->GroupStart());
     NcclResult e = 0;
     for (int p = 0; p < n && !e; p++) {
         if (p == me) continue;
-        int py0 = 0, prows = 0;
-        rfx_split_rows(c->H, n, p, &py0, &prows);
-        // what p needs of MY rows
-        int a = c->hit_rows_host[2 * p] > c->tile_y0 ? c->hit_rows_host[2 * p] : c->tile_y0;
-        int b = c->hit_rows_host[2 * p + 1] + 1 < c->tile_y0 + c->tile_rows ? c->hit_rows_host[2 * p + 1] + 1 : c->tile_y0 + c->tile_rows;
-        if (b > a) e = r->Send(base + (size_t)a * pitch, (size_t)(b - a) * pitch, kNcclUint8, p, comm, c->comm_stream);
-        // what I need of p's rows
-        a = c->hit_rows_host[2 * me] > py0 ? c->hit_rows_host[2 * me] : py0;
-        b = c->hit_rows_host[2 * me + 1] + 1 < py0 + prows ? c->hit_rows_host[2 * me + 1] + 1 : py0 + prows;
-        if (b > a && !e) {
-            e = r->Recv(base + (size_t)a * pitch, (size_t)(b - a) * pitch, kNcclUint8, p, comm, c->comm_stream);
-            got += (size_t)(b - a) * pitch;
-        }
+        const size_t sb = (send_base[p + 1] - send_base[p]) * s.texel, rb = (recv_base[p + 1] - recv_base[p]) * s.texel;
+        if (sb) e = r->Send(send_stage + send_base[p] * s.texel, sb, kNcclUint8, p, comm, c->comm_stream);
+        if (rb && !e) e = r->Recv(recv_stage + recv_base[p] * s.texel, rb, kNcclUint8, p, comm, c->comm_stream);
+        got += rb;
     }
     NcclResult e2 = r->GroupEnd();
     if (e) return nccl_fail(c, "rfx_gather_history_rows: ncclSend/ncclRecv", e);
     if (e2) return nccl_fail(c, "rfx_gather_history_rows: ncclGroupEnd", e2);
+    for (int p = 0; p < n; p++) {  // scatter what arrived: one launch per owner over its rows
+        const size_t cnt = recv_base[p + 1] - recv_base[p];
+        if (p == me || cnt == 0) continue;
+        int py0 = 0, prows = 0;
+        rfx_split_rows(H, n, p, &py0, &prows);
+        hipLaunchKernelGGL(hist_pack_rows<false>, dim3((W + 63) / 64, (prows + 3) / 4), blk, 0, c->comm_stream, (float *)base, (float *)(recv_stage + recv_base[p] * s.texel),
+                           (const unsigned int *)(c->hit_mask_dev + (size_t)(1 + me) * H), (const int *)(off_dev + (size_t)n * H), W, py0, py0 + prows, fpt);
+    }
+    HIPCHK(c, hipGetLastError());
     if (bytes_received) *bytes_received = got;
     return comm_end(c);
 }

@@ -31,6 +31,11 @@ struct rfx_ctx {
     bool trace_scaled = false;                         // ... and whether it drew a smaller target (resolutionScale != 1)
     int *hit_rows_dev = nullptr;   // device: [0..1] this tile's (min, max) needed history row, [2..2n+1] every rank's
     int *hit_rows_host = nullptr;  // pinned mirror of the gathered part
+    // the bounded gather's row masks (rfx_gather_history_rows, rfx_ssgi_hit_mask): one word per frame row; device: [0, H) this tile's, [H, (n+1) H) every rank's
+    unsigned int *hit_mask_dev = nullptr, *hit_mask_host = nullptr;
+    int hit_mask_ranks = 0;  // ranks the two buffers are sized for (each holds (2 n + 2) H words: the masks, then the packed transfer's row offsets)
+    void *hist_staging = nullptr;      // the bounded gather's packed messages: what this rank sends, then what it receives
+    size_t hist_staging_bytes = 0;
     // K1's depth pre-pass (view-Z plane + (min, max) cells) depends on the frame's depth plane only: it runs on its own stream, after
     // the PREVIOUS frame's K1 (the last reader of the scratch it overwrites) and under that frame's K2 / K3 / K4, which are still queued
     // or executing when the host issues the next frame.  ev_depth: the depth slot's last asynchronous writer (rfx_stage_flip / rfx_clear).
@@ -67,6 +72,8 @@ struct rfx_ctx {
 void rfx_comm_release(rfx_ctx *c);  // rfx_comm.hip: called by rfx_destroy
 // rfx_api.hip, for rfx_comm.hip: enqueue on the draw stream the reduction of the traced rays' history rows into rows_dev[0..1] (min, max)
 extern "C" int rfx_internal_hit_rows_enqueue(rfx_ctx *c, int *rows_dev);  // (internal: not part of include/rfx.h)
+// ... and of the traced rays' row masks into the first H words of c->hit_mask_dev (allocated here for `ranks` gathered copies)
+extern "C" int rfx_internal_hit_mask_enqueue(rfx_ctx *c, int ranks);
 
 extern thread_local std::string g_create_err;
 

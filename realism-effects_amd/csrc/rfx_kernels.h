@@ -93,6 +93,8 @@ hipError_t rfx_launch_k1_prepare(const K1Args &, hipStream_t);
 hipError_t rfx_launch_k1(const K1Args &, int stage /* 0 fused, 1 trace, 2 shade */, hipStream_t);
 // rows[0] = min, rows[1] = max history row the shade stage of the traced rays of rows [y0, y1) will read (device ints, preset INT_MAX / -1)
 hipError_t rfx_launch_k1_hit_rows(const FrameDims &, int y0, int y1, TexView depth, TexViewW out, const float4 *hits, bool allow_missed, int *rows, hipStream_t);
+// mask[row] |= 1 << column block (32 blocks across the frame) for every history texel the shade stage of the traced rays of rows [y0, y1) will read (H words, zeroed)
+hipError_t rfx_launch_k1_hit_mask(const FrameDims &, int y0, int y1, TexView depth, TexViewW out, const float4 *hits, bool allow_missed, unsigned int *mask, hipStream_t);
 hipError_t rfx_launch_k2(const K2Args &, hipStream_t);
 hipError_t rfx_launch_k3(const K3Args &, hipStream_t);
 hipError_t rfx_launch_k4(const K4Args &, hipStream_t);

@@ -294,6 +294,13 @@ class Context:
         self._chk(self.lib.rfx_ssgi_hit_rows(self._h, C.byref(lo), C.byref(hi)), "rfx_ssgi_hit_rows")
         return int(lo.value), int(hi.value)
 
+    def ssgi_hit_mask(self) -> np.ndarray:
+        """rfx_ssgi_hit_mask: after ssgi_trace, one uint32 per frame row — bit b set when the shade reads a history texel of that row in column
+        block b (32 blocks across the frame); 0 = the row is not read."""
+        m = np.zeros(self.H, np.uint32)
+        self._chk(self.lib.rfx_ssgi_hit_mask(self._h, m.ctypes.data_as(C.POINTER(C.c_uint32)), self.H), "rfx_ssgi_hit_mask")
+        return m
+
     def gather_history_rows(self, tex: int) -> int:
         """rfx_gather_history_rows (between ssgi_trace and ssgi_shade): only the rows of last frame's composed GI that some tile's rays
         will read travel, from their owners.  Returns the bytes this rank receives."""

@@ -1218,7 +1218,7 @@ def test_hit_rows_bound_what_the_shade_reads(blue_noise, missed):
     ctx.upload(abi.TEX_COMPOSE, hist)
     ctx.ssgi_march(sp)
     want = ctx.download(abi.TEX_SSGI)
-    seen_partial = False
+    seen_partial = seen_gap = seen_sparse_row = False
     for tiles in ([(0, H)], [(0, 62), (62, 64)], [(0, 24), (24, 24), (48, 24), (72, 24), (96, 30)]):
         for y0, rows in tiles:
             ctx.set_row_window(y0, y0 + rows)
@@ -1237,8 +1237,26 @@ def test_hit_rows_bound_what_the_shade_reads(blue_noise, missed):
             ctx.ssgi_shade(sp)
             got = ctx.download(abi.TEX_SSGI, y0, rows)
             assert np.array_equal(got, want[y0:y0 + rows]), "tile rows [%d, %d): the shade read a history row outside [%d, %d]" % (y0, y0 + rows, lo, hi)
+            # the mask form (rfx_ssgi_hit_mask, what the bounded gather plans with since ABI 16): a word per row, a bit per column block.
+            # Its used rows span exactly [lo, hi]; everything whose bit is NOT set is corrupted and the shade must not notice.
+            ctx.upload(abi.TEX_COMPOSE, hist)
+            ctx.ssgi_trace(sp)
+            mask = ctx.ssgi_hit_mask()
+            used = np.flatnonzero(mask)
+            assert (used.size == 0) == (hi < lo) and (used.size == 0 or (used[0] == lo and used[-1] == hi)), (lo, hi, used[:1], used[-1:])
+            blocks = (np.arange(W, dtype=np.int64) * 32) // W
+            needed = ((mask[:, None] >> blocks[None, :].astype(np.uint32)) & 1).astype(bool)  # (H, W): the texel's block bit
+            bad = hist.copy()
+            bad[~needed] = np.nan
+            seen_gap |= bool(used.size and (mask[used[0]:used[-1] + 1] == 0).any())
+            seen_sparse_row |= bool(used.size and (needed[used].mean() < 0.9))
+            ctx.upload(abi.TEX_COMPOSE, bad)
+            ctx.ssgi_shade(sp)
+            got = ctx.download(abi.TEX_SSGI, y0, rows)
+            assert np.array_equal(got, want[y0:y0 + rows]), "tile rows [%d, %d): the shade read a history texel whose mask bit is clear" % (y0, y0 + rows)
     ctx.set_row_window(0, 0)
     assert seen_partial  # (the test would be vacuous if every range were the whole frame)
+    assert seen_sparse_row  # ... or if every used row had every block bit set
     assert ctx.halo_violations() == 0
     ctx.close()
 

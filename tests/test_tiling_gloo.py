@@ -363,7 +363,7 @@ def test_tiled_kernels_are_bit_identical_to_one_context(tmp_path, world):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(os.environ.get("RFX_HOSTSIM") != "1", reason="the C ABI's exchanges between processes without RCCL: pytest --hostsim")
-@pytest.mark.parametrize("world,mode,halo", [(2, "bounded", 0), (3, "bounded", 0), (4, "bounded", 0), (3, "all", 0), (4, "all", 0), (4, "all", 20), (3, "bounded", 30)])
+@pytest.mark.parametrize("world,mode,halo", [(2, "bounded", 0), (3, "bounded", 0), (4, "bounded", 0), (8, "bounded", 0), (3, "all", 0), (4, "all", 0), (4, "all", 20), (3, "bounded", 30)])
 def test_tiled_kernels_with_c_abi_exchanges_are_bit_identical_to_one_context(tmp_path, world, mode, halo):
     """The same tiles with the exchanges BEHIND THE C ABI (rfx_comm_init / rfx_halo_exchange / rfx_allgather_history / rfx_comm_wait), one
     process per tile (tests/comm_tile_worker.py — no torch in them: a torch process maps the real librccl.so.1, which rfx_comm.hip would
