@@ -384,7 +384,11 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream) {
     A.tile.LW = TW + 2 * A.tile.Rx;
     A.tile.LH = TH + 2 * A.tile.Ry;
     // LDS row pitch: a compile-time constant of the tiled kernels (the footprint's second row is an immediate offset)
-    const int pitch = A.tile.LW <= 72 ? 72 : A.tile.LW <= 80 ? 80 : A.tile.LW <= 96 ? 96 : 0;
+#ifndef RFX_K3_PAD
+#define RFX_K3_PAD 0  // build knob: extra texels per LDS row (bank-mapping experiments, profiles/r04_k3/)
+#endif
+    constexpr int PAD = RFX_K3_PAD;
+    const int pitch = A.tile.LW <= 72 ? 72 + PAD : A.tile.LW <= 80 ? 80 + PAD : A.tile.LW <= 96 ? 96 + PAD : 0;
     const size_t lds = (size_t)pitch * A.tile.LH * (16 + 4 + 2 * (temporal ? 16 : 8));
     // two workgroups per CU (160 KiB LDS) keep the staging of one tile under the arithmetic of another
     const bool tiled = A.p.radius >= 0.0f && pitch != 0 && lds <= 80 * 1024;
@@ -410,9 +414,9 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream) {
 #define K3_TILED_W(T, C, P) do { if (whole) K3_TILED(T, C, P, true); else K3_TILED(T, C, P, false); } while (0)
 #define K3_TILED_P(T, C)                    \
     do {                                    \
-        if (pitch == 72) K3_TILED_W(T, C, 72); \
-        else if (pitch == 80) K3_TILED_W(T, C, 80); \
-        else K3_TILED_W(T, C, 96);          \
+        if (pitch == 72 + PAD) K3_TILED_W(T, C, 72 + PAD); \
+        else if (pitch == 80 + PAD) K3_TILED_W(T, C, 80 + PAD); \
+        else K3_TILED_W(T, C, 96 + PAD);          \
     } while (0)
         if (A.p.textureCount == 2) {
             if (temporal) K3_TILED_P(true, 2);
