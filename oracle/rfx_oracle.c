@@ -512,8 +512,42 @@ static inline void k1_project(const k1_ctx *c, v3 pos, float *u, float *v) { /* 
     *u = (pc.x / pc.w) * 0.5f + 0.5f;
     *v = (pc.y / pc.w) * 0.5f + 0.5f;
 }
+/* The texel a march / refine tap lands in.  The tap's coordinate is the projection of a position that went through `n_updates` rounded
+ * updates (half an ulp each, relative to the position and so to the projected coordinate).  The reference GL's roundings are the
+ * restatement's IEEE ones almost everywhere (K1's packed texels are bit-identical on > 99.9 % of the pixels), but not everywhere —
+ * llvmpipe's code generator may contract and reorder — and what has accumulated by step n is of that size.  A tap closer than that to a
+ * texel boundary is only a DECISION when the texel across the boundary decides differently (a depth discontinuity: a silhouette), so that is
+ * what is tested: kind 0 = RayMarch's hit test (:463), kind 1 = BinarySearch's sign (:493).  Found by the 16-frame sequence of round 4: one
+ * pixel of 2 M at frame 10 (steps 40), a refine tap 2e-3 texel from the boundary between a surface at z = -8.6 and one at z = -14.3;
+ * restatement and kernel bit-identical, the GL on the other side; perturbed transcendentals cannot move a refined position that far. */
+static inline int k1_tap_decides(const k1_ctx *c, float z, float h, int kind) {
+    float diff = z - h;
+    return kind ? (diff >= 0.0f) : (diff >= 0.0f && diff < c->p->thickness);
+}
+static void margin_tap(const k1_ctx *c, float u, float v, float h, int n_updates, int kind) {
+    const float cc[2] = {u * (float)c->W, v * (float)c->H};
+    const int size[2] = {c->W, c->H};
+    int idx[2];
+    for (int a = 0; a < 2; a++) {
+        if (!(cc[a] > 0.0f && cc[a] < (float)size[a])) return; /* clamped region (or not a number): flat */
+        idx[a] = (int)cc[a];
+        if (idx[a] > size[a] - 1) idx[a] = size[a] - 1;
+    }
+    const int here = k1_tap_decides(c, k1_view_z(c, c->depth[(size_t)idx[1] * c->W + idx[0]]), h, kind);
+    for (int a = 0; a < 2; a++) {
+        const float fr = cc[a] - floorf(cc[a]);
+        const float slack = (4.0f + 0.5f * (float)n_updates) * 1.1920929e-7f * fabsf(cc[a]);
+        for (int side = -1; side <= 1; side += 2) {
+            const float dist = side < 0 ? fr : 1.0f - fr;
+            int n[2] = {idx[0], idx[1]};
+            n[a] += side;
+            if (dist >= slack || n[a] < 0 || n[a] > size[a] - 1) continue;
+            if (k1_tap_decides(c, k1_view_z(c, c->depth[(size_t)n[1] * c->W + n[0]]), h, kind) != here) margin_note(dist / fmaxf(slack, 1e-30f));
+        }
+    }
+}
 /* BinarySearch ssgi.frag:477-503 */
-static void k1_binary_search(const k1_ctx *c, v3 *dir, v3 *hitPos, float *u, float *v) {
+static void k1_binary_search(const k1_ctx *c, v3 *dir, v3 *hitPos, float *u, float *v, int n_updates) {
     dims d = {c->W, c->H};
     *dir = mul3(*dir, 0.5f);
     *hitPos = sub3(*hitPos, *dir);
@@ -522,6 +556,7 @@ static void k1_binary_search(const k1_ctx *c, v3 *dir, v3 *hitPos, float *u, flo
         float z = k1_view_z(c, fetch_r32f(c->depth, d, *u, *v));
         float diff = z - hitPos->z;
         margin_cmp(z, hitPos->z, MARGIN_REL_MARCH); /* :493 sign of diff */
+        margin_tap(c, *u, *v, hitPos->z, n_updates + i + 1, 1);
         *dir = mul3(*dir, 0.5f);
         if (diff >= 0.0f) *hitPos = sub3(*hitPos, *dir); else *hitPos = add3(*hitPos, *dir);
     }
@@ -543,9 +578,10 @@ static void k1_ray_march(const k1_ctx *c, v3 *dir, v3 *hitPos, float random_b, f
         float diff = z - hitPos->z;
         margin_cmp(z, hitPos->z, MARGIN_REL_MARCH);                                   /* :463 diff >= 0 */
         margin_cmp(z - c->p->thickness, hitPos->z, MARGIN_REL_MARCH);                 /* :463 diff < thickness */
+        margin_tap(c, *u, *v, hitPos->z, i, 0);
         if (diff >= 0.0f && diff < c->p->thickness) {
             if (c->p->refineSteps == 0) return;
-            k1_binary_search(c, dir, hitPos, u, v);
+            k1_binary_search(c, dir, hitPos, u, v, i);
             return;
         }
     }

@@ -258,11 +258,16 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
             got, want = O.half_bits_to_float(got), O.half_bits_to_float(want)
         r = strict(name, got, want, explainable=m, half=half)
         r.at_risk = at_risk
+        # of the unexplained pixels: how many does the implementation compute EXACTLY as the C restatement does (then the open question is
+        # the reference GL against the restatement at that pixel — the proof's reach — not the kernel)
+        r.unexplained_equal_to_restatement = 0
         if r.unexplained and "oracle_at_unexplained" in diag:  # (kept for the stage's other outputs: margins_of clears it)
             idx, obase, omargin = diag["oracle_at_unexplained"]
             g, w = as_float(got), as_float(want)
             for k, (y, x) in enumerate(idx):
                 c = slice(0, g.shape[-1]) if obase.shape[-1] == g.shape[-1] else slice(0, 0)
+                if obase.shape[-1] == g.shape[-1] and np.array_equal(g[y - y0, x], obase[k]):
+                    r.unexplained_equal_to_restatement += 1
                 log("    unexplained (y %d, x %d) margin %.3g\n      impl   %s\n      ref    %s\n      oracle %s" % (
                     y, x, omargin[k], np.array2string(g[y - y0, x], precision=6), np.array2string(w[y - y0, x], precision=6),
                     np.array2string(obase[k], precision=6)))
