@@ -219,6 +219,102 @@ RFX_DEV void k1_march_step(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         rays[r].live = (need[r] & (diff >= 0.0f) & (diff < m.thickness)) ? 0.0f : rays[r].live;  // a hit: the ray stops here
     }
 }
+// BinarySearch (:477-503) for the pixel's two rays in their two slots (rays that did not hit idle along): the form used when the wavefront's
+// hit rays do not fit one per lane
+template <int PROJ>
+RFX_DEV void k1_refine_pairs(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]) {
+    // (a ray that did not hit takes steps of dir * 0: its position is replaced below anyway, its direction is not read again)
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        rays[r].dir = rays[r].dir * 0.5f;
+        rays[r].pos = rays[r].pos + rays[r].dir * (rays[r].hit ? -1.0f : 0.0f);  // pos - dir, exactly
+    }
+    for (int k = 0; k < m.refineSteps; k++) {
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            if (rays[r].hit) rays[r].uv = k1_project<PROJ>(m, rays[r].pos);
+        // BinarySearch only tests the sign of z_tap - h (:493): decided by the cell when max - h < 0 or min - h >= 0
+        Tap tap[2];
+        float2 mm[2];
+        bool need[2], behind[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) tap[r] = k1_tap(m, d, rays[r].uv);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            need[r] = rays[r].hit;
+            behind[r] = false;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const float h = rays[r].pos.z;
+            const bool below = mm[r].y - h < 0.0f;          // diff < 0 everywhere in the cell
+            const bool above = !below & (mm[r].x - h >= 0.0f);  // diff >= 0 everywhere
+            need[r] = need[r] & !(below | above);
+            behind[r] = above;
+        }
+        float z[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) z[r] = need[r] ? rfx_gather<float>(m.viewz, tap[r].idx) : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            if (need[r]) behind[r] = z[r] - rays[r].pos.z >= 0.0f;
+            rays[r].dir = rays[r].dir * 0.5f;
+            // pos -+ dir as pos + dir * (-+1): the product is exact, so the sum rounds as the difference does
+            rays[r].pos = rays[r].pos + rays[r].dir * (rays[r].hit ? (behind[r] ? -1.0f : 1.0f) : 0.0f);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+        if (rays[r].hit) rays[r].uv = k1_project<PROJ>(m, rays[r].pos);
+}
+#ifndef RFX_K1_COMPACT_REFINE
+#define RFX_K1_COMPACT_REFINE 1  // build knob: 0 = always refine in the two slots (A/B measurements; same texels)
+#endif
+// ... and ONE ray per lane: of the 128 ray slots of a wavefront typically 35-45 hold a ray that hit, and the five refinement steps cost a
+// fifth of K1's instructions with most lanes idle in both slots.  When all 64 lanes are here and at most 63 rays hit, the hit rays are
+// packed into lanes 0 .. n-1 (ds_permute: lane i sends slot r's position and direction to lane rank_r; a lane without that ray sends to lane
+// 63, which no rank reaches), refined there with the same arithmetic, and fetched back by their owners (ds_bpermute from lane rank_r).
+// Nothing is staged in LDS memory (the permutes use the LDS crossbar only) and nothing waits: it is the wavefront's own business.
+RFX_DEV float k1_push(int dest_lane, float v) { return __int_as_float(__builtin_amdgcn_ds_permute(dest_lane << 2, __float_as_int(v))); }
+RFX_DEV float k1_pull(int src_lane, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v))); }
+template <int PROJ>
+RFX_DEV void k1_refine_packed(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2], unsigned long long h0, unsigned long long h1, int n0, int n1) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int rank0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(h0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)h0, 0u));
+    const int rank1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(h1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)h1, 0u));
+    const int dest0 = rays[0].hit ? rank0 : 63, dest1 = rays[1].hit ? rank1 : 63;
+    const bool from0 = lane < n0, mine = lane < n0 + n1;
+    float3 pos, dir;
+#define K1_PACK(dst, field) { const float a = k1_push(dest0, rays[0].field), b = k1_push(dest1, rays[1].field); dst = from0 ? a : b; }
+    K1_PACK(pos.x, pos.x) K1_PACK(pos.y, pos.y) K1_PACK(pos.z, pos.z) K1_PACK(dir.x, dir.x) K1_PACK(dir.y, dir.y) K1_PACK(dir.z, dir.z)
+#undef K1_PACK
+    // the same steps as k1_refine_pairs, for this lane's one ray (a lane beyond the last rank holds zeros and idles)
+    dir = dir * 0.5f;
+    pos = pos + dir * (mine ? -1.0f : 0.0f);  // pos - dir, exactly
+    float2 uv = make_float2(0.f, 0.f);
+    for (int k = 0; k < m.refineSteps; k++) {
+        if (mine) uv = k1_project<PROJ>(m, pos);
+        const Tap tap = k1_tap(m, d, uv);
+        const float2 mm = k1_cell_load(m.coarse, tap.cell);
+        const float h = pos.z;
+        const bool below = mm.y - h < 0.0f;             // diff < 0 everywhere in the cell
+        const bool above = !below & (mm.x - h >= 0.0f);  // diff >= 0 everywhere
+        const bool need = mine & !(below | above);
+        bool behind = above;
+        const float z = need ? rfx_gather<float>(m.viewz, tap.idx) : 0.0f;
+        if (need) behind = z - pos.z >= 0.0f;
+        dir = dir * 0.5f;
+        pos = pos + dir * (mine ? (behind ? -1.0f : 1.0f) : 0.0f);
+    }
+    if (mine) uv = k1_project<PROJ>(m, pos);
+    // every owner fetches its rays back (all lanes take part in the permutes; the value is kept only where the slot's ray hit)
+#define K1_UNPACK(val, f0, f1) { const float a = k1_pull(rank0, val), b = k1_pull(rank1, val); if (rays[0].hit) f0 = a; if (rays[1].hit) f1 = b; }
+    K1_UNPACK(pos.x, rays[0].pos.x, rays[1].pos.x) K1_UNPACK(pos.y, rays[0].pos.y, rays[1].pos.y) K1_UNPACK(pos.z, rays[0].pos.z, rays[1].pos.z)
+    K1_UNPACK(uv.x, rays[0].uv.x, rays[1].uv.x) K1_UNPACK(uv.y, rays[0].uv.y, rays[1].uv.y)
+#undef K1_UNPACK
+}
 // RayMarch (:441-475) + BinarySearch (:477-503) for the pixel's TWO rays at once (slot 0 = optional diffuse ray,
 // slot 1 = specular ray), restructured for the SIMT machine without changing any per-ray arithmetic:
 //   * both rays advance in the same loop iteration (they share cs(i), and their taps are in flight together);
@@ -250,52 +346,15 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
 #pragma unroll
     for (int r = 0; r < 2; r++) rays[r].hit = started[r] & (rays[r].live == 0.0f);
     // (a wavefront none of whose rays hit — sky above the horizon, a wall facing away — has nothing to refine)
-    if (m.refineSteps > 0 && __builtin_amdgcn_ballot_w64(rays[0].hit | rays[1].hit) != 0) {
-        // (a ray that did not hit takes steps of dir * 0: its position is replaced below anyway, its direction is not read again)
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            rays[r].dir = rays[r].dir * 0.5f;
-            rays[r].pos = rays[r].pos + rays[r].dir * (rays[r].hit ? -1.0f : 0.0f);  // pos - dir, exactly
+    if (m.refineSteps > 0) {
+        const unsigned long long h0 = __ballot(rays[0].hit), h1 = __ballot(rays[1].hit);
+        const int n0 = __popcll(h0), n1 = __popcll(h1);
+        if (n0 + n1 == 0) {
+        } else if (RFX_K1_COMPACT_REFINE && n0 + n1 <= 63 && __ballot(1) == ~0ull) {
+            k1_refine_packed<PROJ>(m, d, rays, h0, h1, n0, n1);
+        } else {
+            k1_refine_pairs<PROJ>(m, d, rays);
         }
-        for (int k = 0; k < m.refineSteps; k++) {
-#pragma unroll
-            for (int r = 0; r < 2; r++)
-                if (rays[r].hit) rays[r].uv = k1_project<PROJ>(m, rays[r].pos);
-            // BinarySearch only tests the sign of z_tap - h (:493): decided by the cell when max - h < 0 or min - h >= 0
-            Tap tap[2];
-            float2 mm[2];
-            bool need[2], behind[2];
-#pragma unroll
-            for (int r = 0; r < 2; r++) tap[r] = k1_tap(m, d, rays[r].uv);
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                need[r] = rays[r].hit;
-                behind[r] = false;
-            }
-#pragma unroll
-            for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const float h = rays[r].pos.z;
-                const bool below = mm[r].y - h < 0.0f;          // diff < 0 everywhere in the cell
-                const bool above = !below & (mm[r].x - h >= 0.0f);  // diff >= 0 everywhere
-                need[r] = need[r] & !(below | above);
-                behind[r] = above;
-            }
-            float z[2];
-#pragma unroll
-            for (int r = 0; r < 2; r++) z[r] = need[r] ? rfx_gather<float>(m.viewz, tap[r].idx) : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                if (need[r]) behind[r] = z[r] - rays[r].pos.z >= 0.0f;
-                rays[r].dir = rays[r].dir * 0.5f;
-                // pos -+ dir as pos + dir * (-+1): the product is exact, so the sum rounds as the difference does
-                rays[r].pos = rays[r].pos + rays[r].dir * (rays[r].hit ? (behind[r] ? -1.0f : 1.0f) : 0.0f);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 2; r++)
-            if (rays[r].hit) rays[r].uv = k1_project<PROJ>(m, rays[r].pos);
     }
 #pragma unroll
     for (int r = 0; r < 2; r++)
@@ -671,7 +730,10 @@ __global__ __launch_bounds__(64 * K1_WAVES) RFX_WAVES_PER_EU(ENV ? 1 : 8) void k
         const unsigned int by = tile / nbx, bx = tile - by * nbx;
         const int x = (int)bx * 64 + lane, y0 = A.y0 + (int)by * K1_TH;
 #pragma unroll 1
-        for (int r = 0; r < K1_TH; r++) k1_ssgi_march_body<PROJ, ENV, MIS, STAGE>(RFX_KERNARGS_IN_LOOP(A), d, s_cells, x, y0 + r);
+        for (int r = 0; r < K1_TH; r++) {
+            k1_ssgi_march_body<PROJ, ENV, MIS, STAGE>(RFX_KERNARGS_IN_LOOP(A), d, s_cells, x, y0 + r);
+            RFX_WAVE_JOIN();  // background / out-of-frame lanes left the body early: the wavefront is whole again here
+        }
 #if RFX_K1_STATIC_TILES
         tile = K1_NEXT_TILE(tile);
 #else

@@ -30,6 +30,13 @@ __device__ __forceinline__ const T &rfx_kernargs_in_loop(const T &) {
 #define RFX_KERNARGS_IN_LOOP(A) rfx_kernargs_in_loop(A)
 #endif
 
+// The point where the lanes of a wavefront meet again after a region some of them left early (a `return` out of an inlined per-pixel body that
+// runs in a loop).  The hardware's exec mask does this by itself — this is a compiler-level marker only (no instruction); it exists so that the
+// tests' host simulator, which runs lanes as independent fibers, can model the reconvergence when the region contains wave operations.
+#ifndef RFX_WAVE_JOIN
+#define RFX_WAVE_JOIN() __builtin_amdgcn_wave_barrier()
+#endif
+
 // ---------------------------------------------------------------- texture views
 // A view addresses rows [row0, row0+rows) of a W x H frame held contiguously in HBM.
 // Fetch coordinates are FRAME coordinates: CLAMP_TO_EDGE happens against the frame, then the

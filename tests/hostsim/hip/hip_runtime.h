@@ -29,6 +29,7 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define RFX_KERNARGS_IN_LOOP(A) (A)  /* an optimiser fence of the device build (rfx_device.h): the argument block itself */
+#define RFX_WAVE_JOIN() ((void)hostsim_wave_exchange(HOSTSIM_JOIN, 0, 0))  /* the reconvergence point after a divergent region (rfx_device.h) */
 #define RFX_WAVES_PER_EU(n)  /* a register-allocation hint of the device compiler: nothing to simulate */
 #define __constant__ static
 #define __shared__ static thread_local
@@ -59,7 +60,7 @@ struct hostsim_idx { unsigned int x, y, z; };
 extern thread_local hostsim_idx threadIdx, blockIdx, blockDim, gridDim;
 extern thread_local unsigned char *hostsim_lds;  // dynamic shared memory of the running block
 static inline unsigned int hostsim_tid() { return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); }
-enum { HOSTSIM_BALLOT = 1, HOSTSIM_SHFL_XOR = 2, HOSTSIM_READFIRST = 3, HOSTSIM_SHFL = 4 };
+enum { HOSTSIM_BALLOT = 1, HOSTSIM_SHFL_XOR = 2, HOSTSIM_READFIRST = 3, HOSTSIM_SHFL = 4, HOSTSIM_PERMUTE = 5, HOSTSIM_BPERMUTE = 6, HOSTSIM_JOIN = 7 };
 void hostsim_barrier_wait();                                                         // the running fiber waits for its block
 unsigned long long hostsim_wave_exchange(int kind, unsigned long long payload, int arg);  // ... for its wavefront; returns the lane's result
 void hostsim_run_block(unsigned int nthreads, unsigned int bx, unsigned int by, void (*call)(void *), void *ctx);
@@ -77,6 +78,10 @@ static inline int __shfl(int v, int src_lane) { return (int)(unsigned int)hostsi
 static inline unsigned long long __ballot(int p) { return hostsim_wave_exchange(HOSTSIM_BALLOT, p != 0, 0); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(unsigned int)hostsim_wave_exchange(HOSTSIM_READFIRST, (unsigned int)v, 0); }  // the first lane that is here
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+// ds_permute_b32 (push): lane i sends `data` to lane (addr / 4) % 64; every lane gets what was sent to it (0 if nothing was; the highest sender wins)
+static inline int __builtin_amdgcn_ds_permute(int addr, int data) { return (int)(unsigned int)hostsim_wave_exchange(HOSTSIM_PERMUTE, (unsigned int)data, (addr >> 2) & 63); }
+// ds_bpermute_b32 (pull): lane i reads `data` of lane (addr / 4) % 64 (0 when that lane is not here)
+static inline int __builtin_amdgcn_ds_bpermute(int addr, int data) { return (int)(unsigned int)hostsim_wave_exchange(HOSTSIM_BPERMUTE, (unsigned int)data, (addr >> 2) & 63); }
 // v_mbcnt_lo/hi: bits of `mask` below the calling lane (+ base)
 static inline unsigned int __builtin_amdgcn_mbcnt_lo(unsigned int mask, unsigned int base) {
     const unsigned int lane = hostsim_tid() & 63u;

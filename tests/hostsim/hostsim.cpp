@@ -160,8 +160,17 @@ void hostsim_run_block(unsigned int n, unsigned int bx, unsigned int by, void (*
             const unsigned int w1 = w0 + 64 < n ? w0 + 64 : n;
             unsigned long long here = 0;
             int kind = 0;
+            // HOSTSIM_JOIN is the reconvergence point of a divergent region (lanes that left the region early wait there for the others, as
+            // the device's exec mask makes them): it completes only when EVERY unfinished lane of the wavefront has arrived; while lanes are
+            // still inside the region, their wave operations complete among themselves and the joiners keep waiting.
+            unsigned int joiners = 0, unfinished = 0;
+            for (unsigned int i = w0; i < w1; i++) {
+                unfinished += fibers[i].state != DONE;
+                joiners += fibers[i].state == AT_WAVEOP && fibers[i].kind == HOSTSIM_JOIN;
+            }
+            const bool join_now = joiners && joiners == unfinished;
             for (unsigned int i = w0; i < w1; i++)
-                if (fibers[i].state == AT_WAVEOP) {
+                if (fibers[i].state == AT_WAVEOP && (fibers[i].kind != HOSTSIM_JOIN || join_now)) {
                     here |= 1ull << (i - w0);
                     if (kind && kind != fibers[i].kind) { std::fprintf(stderr, "hostsim: the lanes of a wavefront wait at different wave operations\n"); std::abort(); }
                     kind = fibers[i].kind;
@@ -184,6 +193,18 @@ void hostsim_run_block(unsigned int n, unsigned int bx, unsigned int by, void (*
                 case HOSTSIM_SHFL: {
                     const unsigned int lane = i - w0, pl = kind == HOSTSIM_SHFL_XOR ? (lane ^ (unsigned int)f.arg) & 63u : (unsigned int)f.arg & 63u;
                     f.result = (w0 + pl < w1 && (here >> pl & 1)) ? fibers[w0 + pl].payload : f.payload;
+                    break;
+                }
+                case HOSTSIM_JOIN: f.result = 0ull; break;
+                case HOSTSIM_BPERMUTE: {
+                    const unsigned int pl = (unsigned int)f.arg & 63u;
+                    f.result = (w0 + pl < w1 && (here >> pl & 1)) ? fibers[w0 + pl].payload : 0ull;
+                    break;
+                }
+                case HOSTSIM_PERMUTE: {
+                    f.result = 0ull;
+                    for (unsigned int j = w0; j < w1; j++)
+                        if ((here >> (j - w0) & 1) && ((unsigned int)fibers[j].arg & 63u) == i - w0) f.result = fibers[j].payload;
                     break;
                 }
                 default: std::fprintf(stderr, "hostsim: unknown wave operation %d\n", kind); std::abort();
