@@ -99,7 +99,7 @@ def test_baseline_config_stagewise_vs_reference_glsl(blue_noise, name, W, H, ste
 # that now differs by several units between neighbours; measured at frame 10 on MI355X: 0.0091 % of the specular texture, all proven)
 FLIP_LONG = dict(FLIP, **{"K2 temporal0": 1e-4, "K2 temporal1": 3e-4})
 # free-running divergence of the composed GI, frame by frame: bound = ~3x the fraction measured on MI355X (BASELINE.md "free-running")
-FREE_RUN_BOUND = float(os.environ.get("RFX_FREE_RUN_BOUND", "0.25"))
+FREE_RUN_BOUND = float(os.environ.get("RFX_FREE_RUN_BOUND", "0.025"))  # measured: frame 0 0.73 % (no history yet: six blur passes spread every K1 flip), later frames <= 0.03 %
 
 
 def test_configs4_options_16_frames_ages_and_free_running(blue_noise):
@@ -307,7 +307,9 @@ def test_config0_through_the_effect_no_denoise_pass(blue_noise):
             print(rt.line() + "  (%d of them: K1 inputs differ within the clamp footprint and the oracle on the implementation's input agrees)" % int(
                 (out_of_tolerance(got[j], want[j], False) & right_for_own_input).sum()))
             assert rt.unexplained == 0, rt.line()
-            assert rt.bad <= 5e-5 * rt.pixels + 10, rt.line()  # measured on MI355X: 13 of 2.07 M pixels (6e-6)
+            # K2 here consumes the implementation's OWN K1 output: where that differs from the reference's (this frame's K1 flips, bounded and proven
+            # above) K2 differs legitimately — measured 230 pixels for 306 K1 flips (a flip reaches its own pixel, rarely a neighbour's clamp box)
+            assert rt.bad <= 3 * int(k1_bad.sum()) + 10, rt.line()
     assert ctx.halo_violations() == 0
     ctx.close()
 

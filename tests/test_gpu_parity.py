@@ -24,11 +24,11 @@ class Bound(float):
         return o
 
 
-# HIP vs the C restatement on the synthetic dumps, strict metric; measured on MI355X (profiles/r04_parity/variant_twins.txt):
-# K1 <= 1.7e-4, K2 <= 2e-5, K3 <= 5e-5 (random-texel inputs of the variant tests: 2e-4), K4 <= 2e-5
-FLIP = dict(ssgi=Bound(5e-4, True), temporal=Bound(6e-5, False), denoise=Bound(6e-4, True), compose=Bound(6e-5, False))
-# K1 with an environment map: the equirect lookup (atan2 / acos -> a texel of the level the roughness picks) adds decisions; measured 8e-4
-FLIP_ENV = Bound(2.5e-3, True)
+# HIP vs the C restatement on the synthetic dumps, strict metric; measured on MI355X (profiles/r04_parity/variant_twins_measured.txt):
+# K1 <= 1.6e-4 (resolutionScale 0.25: 4.3e-4 of its 16x fewer pixels), K2 0, K3 0, K4 <= 8.7e-5 (mode "ssr") — bounds ~3x, +2 pixels
+FLIP = dict(ssgi=Bound(5e-4, True), temporal=Bound(3e-5, False), denoise=Bound(1.5e-4, True), compose=Bound(2.5e-4, False))
+# K1 with an environment map: the equirect lookup (atan2 / acos -> a texel of the level the roughness picks) adds decisions; measured 1.0e-3
+FLIP_ENV = Bound(3e-3, True)
 MEASURED = []  # (name, fraction) of every comparison of the session: printed at the end (conftest) for the bounds above
 
 
@@ -524,7 +524,7 @@ def test_traa_end_to_end_vs_oracle(half):
     dev = Context(W, H)
     a, b = run(dev), run(OracleRenderer(W, H))
     for fi in range(NF):
-        assert_close("traa effect f%d" % fi, a[fi], b[fi], 4e-3 * (fi + 1), half=False)  # free-running effects: an earlier flip stays in both histories
+        assert_close("traa effect f%d" % fi, a[fi], b[fi], 3e-4 * (fi + 1), half=False)  # free-running effects: an earlier flip stays in both histories
     # row tiles (the multi-GPU decomposition) reproduce the single context bit for bit
     from rfx_amd import tiling
     vmax = max(float(np.abs(f.velocity[..., 1].view(np.float32)).max()) for f in frames)
@@ -876,8 +876,9 @@ def test_resolution_scale_vs_oracle(blue_noise, rs):
     want = O.ssgi(f.depth, f.gbuffer, f.direct, comp, blue_noise, sp)
     ga, gb = O.unpack_ssgi(got)
     wa, wb = O.unpack_ssgi(want)
-    assert_close("rs%g ssgi.diffuse" % rs, ga, wa, FLIP["ssgi"])
-    assert_close("rs%g ssgi.specular" % rs, gb, wb, FLIP["ssgi"])
+    rs_bound = Bound(1.5e-3, True)  # a smaller target: the same handful of flips over 4-16x fewer pixels (measured 4.3e-4 at resolutionScale 0.25)
+    assert_close("rs%g ssgi.diffuse" % rs, ga, wa, rs_bound)
+    assert_close("rs%g ssgi.specular" % rs, gb, wb, rs_bound)
     assert (got == want).all(axis=-1).mean() > 0.99
     # K2 on the oracle's K1 texels
     full = np.zeros((H, W, 4), np.uint32)
