@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 16
+#define RFX_ABI_VERSION 17
 
 enum {
     RFX_OK = 0,
@@ -210,6 +210,17 @@ int rfx_set_row_window(rfx_ctx *, int y0, int y1);
  * Applies to every following draw; row-tiled contexts evaluate the whole frame's planes. */
 enum { RFX_UV_IDEAL = 0, RFX_UV_REFERENCE_GL = 1 };
 int rfx_set_uv_model(rfx_ctx *, int model);
+/* Draw folding (ABI 17; default ON).  The reference's Denoiser ends with two full-screen draws, the last PoissonDenoisePass draw into its
+ * target B and the DenoiserComposePass draw that reads it back (src/denoise/Denoiser.js:97-107, PoissonDenoisePass.js:146-147,
+ * DenoiserComposePass.js:133-134).  On a context that owns the WHOLE frame and draws on its own stream the library makes the two in ONE
+ * launch: rfx_poisson_denoise(later pass, writeToB, two textures) returns with its draw held; if the next call on the context is the
+ * rfx_compose that reads those targets (giSource 0, inputType 0, same rows) every lane composes its pixel from the two texels it has just
+ * stored, otherwise the held draw is launched first, whatever the call is — nothing can observe the order.  4K: 1.377 -> 1.340 ms per frame.
+ * What changes: the compose draw samples target B LINEAR at vUv, i.e. at the texel centre up to the rounding of vUv * size - 0.5 (a
+ * bilinear weight of 0 on about half the texels and up to 2.4e-4 at 4K, 6e-4 at 8K, on the rest); the folded draw takes the texel
+ * itself.  Measured at 4K on identical inputs: max |difference| 6.8e-4, no texel beyond 1e-3 (tests/test_gpu_parity.py).  enable = 0
+ * restores one launch per draw (exactly the reference's fetch); row-tiled contexts never fold. */
+int rfx_set_compose_fold(rfx_ctx *, int enable);
 
 /* ---- textures.  `row0`/`rows` are FRAME rows of the band being transferred; the band must lie
  * inside the rows the context holds: [max(0,tile_y0-halo), min(H,tile_y0+tile_rows+halo)).

@@ -15,6 +15,7 @@
 #include "rfx_device.h"
 #include "rfx_kernels.h"
 #include "k3_rotation_table.h"
+#include "k4_compose_texel.h"
 
 namespace {
 
@@ -69,7 +70,13 @@ RFX_DEV void k3_apply(CenterTexel &c, float l2w, float3 tl, float tapLuma, float
 // PITCH is a template parameter for that reason: LW = 64 + 2 Rx rounded up to 72 / 80 / 96 texels (Rx <= 4 / 8 / 16).
 
 // WHOLE: every view is the whole frame (a context that owns no row tile): rows need no rebasing and no halo accounting
-template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE>
+// FUSE (WHOLE, TC == 2, a later pass writing target B): the DenoiserComposePass draw that follows the Denoiser's last denoise draw
+// (src/denoise/Denoiser.js:97-107) is folded into this launch — every lane composes its own pixel from the two texels it has just stored
+// (rounded to the target's halfs first, as the compose draw would read them back) instead of a second launch re-reading depth, target B and
+// decoding the G-buffer texel again.  The compose draw samples target B LINEAR at vUv, i.e. at the texel's centre up to the rounding of
+// vUv * size (bilinear weights of ~1e-7 .. 2e-4 on the neighbours); the folded form takes the texel itself: the two differ by that weight
+// times the neighbours' difference, far inside the 1e-3 of the parity metric (tests hold folded == unfolded to 2e-4 relative).
+template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE, bool FUSE>
 RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     extern __shared__ float4 lds[];
     const int Rx = A.tile.Rx, Ry = A.tile.Ry, LW = A.tile.LW, LH = A.tile.LH;
@@ -129,7 +136,16 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     const int qy0 = ci - __mul24(y & 1, PITCH), qy1 = qy0 + PITCH;
     {
         const float fw = fabsf(s_depth[qx1] - s_depth[qx0]) + fabsf(s_depth[qy1] - s_depth[qy0]);
-        if (depth == 1.0f && fw == 0.0f) return;  // discard (:129-132): target keeps its contents
+        if (depth == 1.0f && fw == 0.0f) {  // discard (:129-132): target keeps its contents
+            if constexpr (FUSE) {  // ... and so does the compose draw's (DenoiserComposePass.js:61-64, the same test): mirror the kept texel
+                if (A.rgb_out) {
+                    const float4 keep = ((const float4 *)A.cout.ptr)[(size_t)y * d.W + x];
+                    float *r = A.rgb_out + ((size_t)y * d.W + x) * 3;
+                    r[0] = keep.x; r[1] = keep.y; r[2] = keep.z;
+                }
+            }
+            return;
+        }
     }
     const float4 gc = s_geom[ci];
     const float3 normal = make_float3(gc.x, gc.y, gc.z);
@@ -246,12 +262,25 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     }
 
     const size_t oi = (size_t)(unsigned int)(__mul24(WHOLE ? y : rfx_local_row(d, A.out0.row0, A.out0.rows, y), d.W) + x);
+    uint2 stored[TC];
 #pragma unroll
     for (int i = 0; i < TC; i++) {  // outputTexel :94-100
         const float inv = rfx_rcp(c[i].total);
         float3 o = make_float3(c[i].rgb.x * inv, c[i].rgb.y * inv, c[i].rgb.z * inv);
         o = make_float3(rfx_exp(o.x) - 1.0f, rfx_exp(o.y) - 1.0f, rfx_exp(o.z) - 1.0f);
-        ((uint2 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = rfx_store_half4(o.x, o.y, o.z, c[i].a, p.halfStoreRTZ != 0);
+        stored[i] = rfx_store_half4(o.x, o.y, o.z, c[i].a, p.halfStoreRTZ != 0);
+        ((uint2 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = stored[i];
+    }
+    if constexpr (FUSE) {  // the compose draw of this pixel (k4_compose.hip's body on the texels just stored: B0 = diffuse GI, B1 = specular GI)
+        static_assert(TC == 2 && WHOLE && !IN_TEMPORAL, "the folded compose draw reads both targets of a whole-frame later pass");
+        const float4 dgi = rfx_load_half4(stored[0]), sgi = rfx_load_half4(stored[1]);
+        const Material mat = rfx_get_material<true>(gbp[(unsigned int)(__mul24(y, d.W) + x)]);
+        const float4 o = k4_compose_texel(A.cp, u, v, depth, mat, make_float3(dgi.x, dgi.y, dgi.z), make_float3(sgi.x, sgi.y, sgi.z), make_float3(0.f, 0.f, 0.f));
+        ((float4 *)A.cout.ptr)[oi] = o;
+        if (A.rgb_out) {
+            float *r = A.rgb_out + oi * 3;
+            r[0] = o.x; r[1] = o.y; r[2] = o.z;
+        }
     }
 }
 
@@ -346,11 +375,11 @@ RFX_DEV void k3_generic_body(const K3Args &A, const FrameDims &d) {
     }
 }
 
-template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE>
+template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE, bool FUSE = false>
 __global__ __launch_bounds__(NT) void k3_tiled(K3Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-    k3_tiled_body<IN_TEMPORAL, TC, PITCH, WHOLE>(A, d);
+    k3_tiled_body<IN_TEMPORAL, TC, PITCH, WHOLE, FUSE>(A, d);
     rfx_flush_violations(d);
 }
 template <bool IN_TEMPORAL, int TC>
@@ -363,8 +392,11 @@ __global__ __launch_bounds__(256) void k3_generic(K3Args A) {
 
 }  // namespace
 
-hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream) {
+// `folded` (may be null): set to whether the launch also made the compose draw A.fuse_compose asks for — the tiled kernel on whole-frame
+// views, two textures, a later pass; otherwise the caller launches K4 itself
+hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
     K3Args A = A_in;
+    if (folded) *folded = false;
     const bool temporal = A.p.inputIsTemporal != 0;
     // apron of the tap footprint: anisotropic because the reference rotates in UV space
     const float aspect = A.dims.fW / A.dims.fH;
@@ -418,7 +450,24 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream) {
         else if (pitch == 80 + PAD) K3_TILED_W(T, C, 80 + PAD); \
         else K3_TILED_W(T, C, 96 + PAD);          \
     } while (0)
-        if (A.p.textureCount == 2) {
+        if (A.fuse_compose && whole && !temporal && A.p.textureCount == 2) {
+#define K3_FUSED(P)                                                                                                                      \
+    do {                                                                                                                                 \
+        static bool attr_set[64] = {false};                                                                                              \
+        int dev = 0;                                                                                                                     \
+        hipGetDevice(&dev);                                                                                                              \
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                                                    \
+            hipFuncSetAttribute((const void *)k3_tiled<false, 2, P, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                                              \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((k3_tiled<false, 2, P, true, true>), grid, block, lds, stream, A);                                            \
+    } while (0)
+            if (pitch == 72 + PAD) K3_FUSED(72 + PAD);
+            else if (pitch == 80 + PAD) K3_FUSED(80 + PAD);
+            else K3_FUSED(96 + PAD);
+#undef K3_FUSED
+            if (folded) *folded = true;
+        } else if (A.p.textureCount == 2) {
             if (temporal) K3_TILED_P(true, 2);
             else K3_TILED_P(false, 2);
         } else {

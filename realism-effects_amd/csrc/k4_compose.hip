@@ -2,8 +2,7 @@
 // Replaces `renderer.render` of src/denoise/pass/DenoiserComposePass.js:133-134; arithmetic from
 // the inline shader :36-86 and src/denoise/shader/denoiser_compose_functions.glsl:53-108.
 // Pure streaming kernel: 52 B/px (4 depth + 16 gbuffer + 2x8 GI in, 16 out).
-#include "rfx_brdf.h"
-#include "rfx_kernels.h"
+#include "k4_compose_texel.h"
 
 namespace {
 
@@ -12,8 +11,6 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = A.y0 + blockIdx.y * 4 + threadIdx.y;
     if (x >= d.W || y >= A.y1) return;
-    const float *C = A.p.camera.matrixWorld, *Vw = A.p.camera.matrixWorldInverse;
-    const float *P = A.p.camera.projectionMatrix, *Pi = A.p.camera.projectionMatrixInverse;
     const float u = rfx_frag_u(d.uv, x, y), v = rfx_frag_v(d.uv, y);
     const float *depthp = (const float *)A.depth.ptr;
     const float depth = depthp[rfx_xy_index(d, A.depth.row0, A.depth.rows, x, y)];
@@ -31,12 +28,6 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
         }
     }
     const Material mat = rfx_get_material<true>(((const uint4 *)A.gbuffer.ptr)[rfx_xy_index(d, A.gbuffer.row0, A.gbuffer.rows, x, y)]);
-    const float3 viewNormal = rfx_vec_mul_mat(C, mat.normal, 0.0f);  // :71 (not normalised)
-    const float n_ = A.p.camera.near_, f_ = A.p.camera.far_;
-    const float viewZ = -rfx_depth_to_view_z(depth, n_, f_, A.p.camera.isPerspective != 0);  // -getViewZ(depth) :73
-    const float clipW = P[2 * 4 + 3] * viewZ + P[3 * 4 + 3];
-    const float4 pp = rfx_mat_mul(Pi, ((u - 0.5f) * 2.0f) * clipW, ((v - 0.5f) * 2.0f) * clipW, ((viewZ - 0.5f) * 2.0f) * clipW, 1.0f * clipW);
-    const float3 viewDir = rfx_normalize(make_float3(pp.x, pp.y, -viewZ));
     // DenoiserComposePass.js:26-33: "diffuseSpecular" -> (textures[0], textures[1]); "specular" -> specularGi = textures[0],
     // diffuseGiTexture unbound (zeros) and the diffuse component comes from sceneTexture
     float4 dgi = make_float4(0.f, 0.f, 0.f, 0.f), sgi;
@@ -54,36 +45,12 @@ RFX_DEV void k4_compose_body(const K4Args &A, const FrameDims &d) {
     } else {
         sgi = rfx_fetch_h4_linear_fused<WHOLE>(A.gi0, d, u, v);
     }
-
-    // constructGlobalIllumination
-    const float roughness = mat.roughness * mat.roughness;
-    const float3 normal = rfx_vec_mul_mat(Vw, viewNormal, 0.0f);
-    const float3 vv = -viewDir;
-    float3 V = rfx_vec_mul_mat(Vw, vv, 0.0f);
-    float3 T, B;
-    rfx_onb(normal, T, B);
-    V = rfx_to_local(T, B, normal, V);
-    float3 H = rfx_sample_ggx_vndf(V, roughness, roughness, 0.25f, 0.25f);
-    if (H.z < 0.0f) H = -H;
-    float3 l = rfx_normalize(rfx_reflect(-V, H));
-    l = rfx_to_world(T, B, normal, l);
-    l = rfx_normalize(rfx_vec_mul_mat(C, l, 1.0f));  // vec4(l, 1.) quirk :81
-    if (rfx_dot(viewNormal, l) < 0.0f) l = -l;
-    const float3 h = rfx_normalize(vv + l);
-    const float VoH = fmaxf(1e-6f, rfx_dot(vv, h));
-    const float3 f0 = rfx_mix(make_float3(0.04f, 0.04f, 0.04f), mat.diffuse, mat.metalness);
-    const float3 F = rfx_f_schlick(f0, VoH);
-    const float om = 1.0f - mat.metalness;
-    float3 dc = make_float3(mat.diffuse.x * om * (1.0f - F.x) * dgi.x, mat.diffuse.y * om * (1.0f - F.y) * dgi.y, mat.diffuse.z * om * (1.0f - F.z) * dgi.z);
+    float3 scene = make_float3(0.f, 0.f, 0.f);
     if (A.p.inputType == 2) {  // denoiser_compose_functions.glsl:97-101: diffuseComponent = textureLod(sceneTexture, vUv, 0.).rgb
         const float4 sc = ((const float4 *)A.scene.ptr)[rfx_xy_index(d, A.scene.row0, A.scene.rows, x, y)];
-        dc = make_float3(sc.x, sc.y, sc.z);
+        scene = make_float3(sc.x, sc.y, sc.z);
     }
-    float4 o;
-    o.x = (dc.x + sgi.x * F.x) + mat.emissive.x;
-    o.y = (dc.y + sgi.y * F.y) + mat.emissive.y;
-    o.z = (dc.z + sgi.z * F.z) + mat.emissive.z;
-    o.w = 1.0f;
+    const float4 o = k4_compose_texel(A.p, u, v, depth, mat, make_float3(dgi.x, dgi.y, dgi.z), make_float3(sgi.x, sgi.y, sgi.z), scene);
     ((float4 *)A.out.ptr)[(size_t)rfx_local_row(d, A.out.row0, A.out.rows, y) * d.W + x] = o;
     if (A.rgb_out) {
         float *r = A.rgb_out + ((size_t)y * d.W + x) * 3;

@@ -12,7 +12,27 @@
 
 thread_local std::string g_create_err;
 
+// every entry point that takes a context: select its device, launch the draw the context may be holding (rfx_ctx.h k3_held)
+#define RFX_ENTER(c)                         \
+    do {                                     \
+        hipSetDevice((c)->device);           \
+        const int rc__ = rfx_internal_flush(c); \
+        if (rc__) return rc__;               \
+    } while (0)
+#ifndef RFX_FOLD_COMPOSE
+#define RFX_FOLD_COMPOSE 1  // build knob: 0 = never hold a denoise draw for its compose draw (A/B measurements)
+#endif
+
 extern "C" {
+
+unsigned int rfx_internal_folded_draws(const rfx_ctx *c) { return c ? c->folded_draws : 0u; }  // (tests: the fold really happened)
+
+int rfx_internal_flush(rfx_ctx *c) {
+    if (!c->k3_held) return RFX_OK;
+    c->k3_held = false;
+    HIPCHK(c, rfx_launch_k3(*c->k3_held_args, c->stream));
+    return RFX_OK;
+}
 
 int rfx_abi_version(void) { return RFX_ABI_VERSION; }
 
@@ -77,6 +97,8 @@ rfx_ctx *rfx_create(int device, int width, int height, int tile_y0, int tile_row
 void rfx_destroy(rfx_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
+    rfx_internal_flush(c);
+    delete c->k3_held_args;
     hipStreamSynchronize(c->stream);
     rfx_comm_release(c);
     // a staged copy may still be writing a back buffer: drain the upload stream before any buffer goes
@@ -126,7 +148,7 @@ int rfx_get_geometry(const rfx_ctx *c, int *width, int *height, int *tile_y0, in
 
 int rfx_set_stream(rfx_ctx *c, void *hip_stream) {
     if (!c) return RFX_EINVAL;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     // work already enqueued (uploads, the zero-fill of fresh render targets) must not race kernels on the new stream
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -135,6 +157,7 @@ int rfx_set_stream(rfx_ctx *c, void *hip_stream) {
 
 int rfx_set_row_window(rfx_ctx *c, int y0, int y1) {
     if (!c) return RFX_EINVAL;
+    RFX_ENTER(c);
     if (y1 <= y0) { c->win_y0 = 0; c->win_y1 = 0x7fffffff; }  // reset
     else { c->win_y0 = y0; c->win_y1 = y1; }
     return RFX_OK;
@@ -142,8 +165,16 @@ int rfx_set_row_window(rfx_ctx *c, int y0, int y1) {
 
 int rfx_set_uv_model(rfx_ctx *c, int model) {
     if (!c) return RFX_EINVAL;
+    RFX_ENTER(c);
     if (model != RFX_UV_IDEAL && model != RFX_UV_REFERENCE_GL) return fail(c, RFX_EINVAL, "rfx_set_uv_model: unknown model");
     c->uv_model = model;
+    return RFX_OK;
+}
+
+int rfx_set_compose_fold(rfx_ctx *c, int enable) {
+    if (!c) return RFX_EINVAL;
+    RFX_ENTER(c);
+    c->fold_compose = enable != 0;
     return RFX_OK;
 }
 
@@ -157,7 +188,7 @@ int rfx_tex_held_rows(const rfx_ctx *c, rfx_tex id, int *row0, int *rows) {
 static int ensure(rfx_ctx *c, int id) {
     Slot &s = c->slots[id];
     if (s.ptr) return RFX_OK;
-    hipSetDevice(c->device);
+    hipSetDevice(c->device);  // (not an entry point: rfx_compose allocates its target while the draw it folds in is still held)
     const size_t bytes = (size_t)s.rows * s.width * s.texel;
     hipError_t e = hipMalloc(&s.ptr, bytes);
     if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(texture)", e);
@@ -180,7 +211,7 @@ int rfx_upload(rfx_ctx *c, rfx_tex id, const void *host, int row0, int rows) {
     int rc = band_check(c, id, row0, rows);
     if (rc) return rc;
     if ((rc = ensure(c, id))) return rc;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     Slot &s = c->slots[id];
     const size_t pitch = (size_t)s.width * s.texel;
     HIPCHK(c, hipMemcpyAsync((char *)s.ptr + (size_t)(row0 - s.row0) * pitch, host, (size_t)rows * pitch, hipMemcpyHostToDevice, c->stream));
@@ -195,7 +226,7 @@ int rfx_download(rfx_ctx *c, rfx_tex id, void *host, int row0, int rows) {
     int rc = band_check(c, id, row0, rows);
     if (rc) return rc;
     if ((rc = ensure(c, id))) return rc;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     Slot &s = c->slots[id];
     const size_t pitch = (size_t)s.width * s.texel;
     HIPCHK(c, hipMemcpyAsync(host, (char *)s.ptr + (size_t)(row0 - s.row0) * pitch, (size_t)rows * pitch, hipMemcpyDeviceToHost, c->stream));
@@ -220,7 +251,7 @@ int rfx_stage_upload(rfx_ctx *c, rfx_tex id, const void *host, int row0, int row
     int rc = band_check(c, id, row0, rows);
     if (rc) return rc;
     if ((rc = ensure(c, id))) return rc;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     Slot &s = c->slots[id];
     if (!s.owned) return fail(c, RFX_ESTATE, "rfx_stage_upload: the slot is bound to an external buffer");
     const size_t pitch = (size_t)s.width * s.texel, bytes = (size_t)s.rows * pitch;
@@ -248,7 +279,7 @@ int rfx_stage_upload(rfx_ctx *c, rfx_tex id, const void *host, int row0, int row
 int rfx_stage_flip(rfx_ctx *c) {
     if (!c) return RFX_EINVAL;
     if (!c->upload_stream) return fail(c, RFX_ESTATE, "rfx_stage_flip: nothing staged");
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     // draws enqueued from now on wait for the staged copies; copies staged from now on wait for the draws enqueued so far
     HIPCHK(c, hipEventRecord(c->ev_staged, c->upload_stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_staged, 0));
@@ -278,7 +309,7 @@ int rfx_clear(rfx_ctx *c, rfx_tex id) {
     if (!c || id < 0 || id >= RFX_TEX_COUNT) return RFX_EINVAL;
     int rc = ensure(c, id);
     if (rc) return rc;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     Slot &s = c->slots[id];
     HIPCHK(c, hipMemsetAsync(s.ptr, 0, (size_t)s.rows * s.width * s.texel, c->stream));
     if (id == RFX_TEX_DEPTH) {
@@ -290,6 +321,8 @@ int rfx_clear(rfx_ctx *c, rfx_tex id) {
 
 void *rfx_tex_device_ptr(rfx_ctx *c, rfx_tex id) {
     if (!c || id < 0 || id >= RFX_TEX_COUNT) return nullptr;
+    hipSetDevice(c->device);
+    if (rfx_internal_flush(c)) return nullptr;  // (whoever takes an address may read or write the plane with work of its own)
     if (ensure(c, id)) return nullptr;
     // whoever takes the depth plane's address may write it with work this library cannot see (ordered against the draw stream only, as a
     // bound external buffer is): the pre-pass then stays in the draw stream
@@ -299,9 +332,9 @@ void *rfx_tex_device_ptr(rfx_ctx *c, rfx_tex id) {
 
 int rfx_bind_external(rfx_ctx *c, rfx_tex id, void *device_ptr) {
     if (!c || id < 0 || id >= RFX_TEX_COUNT || !device_ptr) return RFX_EINVAL;
+    RFX_ENTER(c);
     Slot &s = c->slots[id];
     if (s.owned && s.ptr) {  // launches that still use the old buffer finish first
-        hipSetDevice(c->device);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         hipFree(s.ptr);
     }
@@ -400,7 +433,7 @@ int rfx_pack_gbuffer(rfx_ctx *c, const rfx_aov_gbuffer *a, int row0, int rows) {
     int rc = band_check(c, RFX_TEX_GBUFFER, row0, rows);
     if (rc) return rc;
     if ((rc = ensure(c, RFX_TEX_GBUFFER))) return rc;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     const float *host[6] = {a->diffuse, a->normal, a->roughness, a->metalness, a->emissive, a->depth}, *dev[6];
     const int ch[6] = {4, 3, 1, 1, 3, 1};
     float *stage = nullptr;
@@ -420,7 +453,7 @@ int rfx_pack_velocity(rfx_ctx *c, const rfx_aov_velocity *a, int row0, int rows)
     int rc = band_check(c, RFX_TEX_VELOCITY, row0, rows);
     if (rc) return rc;
     if ((rc = ensure(c, RFX_TEX_VELOCITY))) return rc;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     const float *host[3] = {a->velocity, a->normal, a->depth}, *dev[3];
     const int ch[3] = {2, 3, 1};
     float *stage = nullptr;
@@ -436,7 +469,7 @@ int rfx_pack_velocity(rfx_ctx *c, const rfx_aov_velocity *a, int row0, int rows)
 
 int rfx_set_environment(rfx_ctx *c, const float *rgba, int width, int height, int halfFloatType, int halfStoreRTZ) {
     if (!c) return RFX_EINVAL;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     if (!rgba) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->env) hipFree(c->env);
@@ -497,7 +530,7 @@ int rfx_cube_to_equirect(rfx_ctx *c, const float *faces, int size, int generateM
     if (size < 1 || size > 8192 || width < 1 || height < 1 || width > 16384 || height > 16384)
         return fail(c, RFX_EINVAL, "rfx_cube_to_equirect: face size must be 1..8192, the target 1..16384 in each edge");
     if (generateMipmaps && (size & (size - 1))) return fail(c, RFX_EUNSUPPORTED, "rfx_cube_to_equirect: a mip chain needs a power-of-two face size");
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     int levels = 1;
     size_t nchain = (size_t)6 * size * size;
     if (generateMipmaps)
@@ -526,7 +559,7 @@ int rfx_set_environment_importance(rfx_ctx *c, const float *marginal, size_t mar
     if (!c->env) return fail(c, RFX_ESTATE, "rfx_set_environment_importance: no environment set");
     if (marginalCount != (size_t)c->env_h || conditionalCount != (size_t)c->env_w * c->env_h)
         return fail(c, RFX_EINVAL, "rfx_set_environment_importance: marginalWeights must hold height floats and conditionalWeights width*height");
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->env_marginal) hipFree(c->env_marginal);
     if (c->env_conditional) hipFree(c->env_conditional);
@@ -556,7 +589,7 @@ int rfx_download_environment(rfx_ctx *c, int level, float *rgba, int *levels) {
     if (!rgba) return RFX_OK;
     if (!c->env || level < 0 || level >= c->env_levels) return fail(c, RFX_EINVAL, "rfx_download_environment: no such level");
     const int w = (c->env_w >> level) > 0 ? c->env_w >> level : 1, h = (c->env_h >> level) > 0 ? c->env_h >> level : 1;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     HIPCHK(c, hipMemcpyAsync(rgba, c->env + c->env_off[level], (size_t)w * h * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RFX_OK;
@@ -570,7 +603,7 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
         return fail(c, RFX_ESTATE, "rfx_ssgi_march/trace/shade: importanceSampling needs useEnvMap and rfx_set_environment_importance");
     if (p->useEnvMap && !c->env) return fail(c, RFX_ESTATE, "rfx_ssgi_march/trace/shade: useEnvMap without rfx_set_environment");
     if (p->steps < 1 || p->refineSteps < 0) return fail(c, RFX_EINVAL, "rfx_ssgi_march/trace/shade: steps/refineSteps");
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     if (p->historySource < 0 || p->historySource > 3) return fail(c, RFX_EINVAL, "rfx_ssgi_march/trace/shade: historySource");
     if (p->historySource == 1 && (c->tile_y0 != 0 || c->tile_rows != c->H))
         return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_march/trace/shade: historySource TEMPORAL0 (denoiseMode \"temporal\") needs a whole-frame context: K1 gathers it anywhere on screen");
@@ -691,7 +724,7 @@ int rfx_internal_hit_rows_enqueue(rfx_ctx *c, int *rows_dev) {
     // the hand-over plane of a resolutionScale != 1 trace is indexed by the SMALLER target (and such a trace needs a whole-frame context, which
     // has no history to gather): the row reduction below reads it with the frame's pitch
     if (c->trace_scaled) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_hit_rows / rfx_gather_history_rows: the last rfx_ssgi_trace ran with resolutionScale != 1");
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     static const int preset[2] = {0x7fffffff, -1};
     HIPCHK(c, hipMemcpyAsync(rows_dev, preset, sizeof preset, hipMemcpyHostToDevice, c->stream));
     if (c->trace_y1 > c->trace_y0)
@@ -702,7 +735,7 @@ int rfx_internal_hit_rows_enqueue(rfx_ctx *c, int *rows_dev) {
 int rfx_internal_hit_mask_enqueue(rfx_ctx *c, int ranks) {
     if (!c->hits || !c->hits_traced) return fail(c, RFX_ESTATE, "rfx_gather_history_rows / rfx_ssgi_hit_mask: no rfx_ssgi_trace of this frame is waiting for its shade");
     if (c->trace_scaled) return fail(c, RFX_EUNSUPPORTED, "rfx_ssgi_hit_mask / rfx_gather_history_rows: the last rfx_ssgi_trace ran with resolutionScale != 1");
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     if (ranks < 1) ranks = 1;
     if (!c->hit_mask_dev || c->hit_mask_ranks < ranks) {
         if (c->hit_mask_dev) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->hit_mask_dev); hipHostFree(c->hit_mask_host); c->hit_mask_dev = nullptr; c->hit_mask_host = nullptr; }
@@ -731,7 +764,7 @@ int rfx_ssgi_hit_mask(rfx_ctx *c, unsigned int *row_mask, int rows) {
 
 int rfx_ssgi_hit_rows(rfx_ctx *c, int *row_lo, int *row_hi) {
     if (!c || !row_lo || !row_hi) return RFX_EINVAL;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     if (!c->hit_rows_dev) {  // sized for any communicator this context may get later: 2 + 2 * 64 ranks
         hipError_t e = hipMalloc((void **)&c->hit_rows_dev, sizeof(int) * 130);
         if (e == hipSuccess) e = hipHostMalloc((void **)&c->hit_rows_host, sizeof(int) * 128, hipHostMallocDefault);
@@ -756,7 +789,7 @@ int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
     if (!((p->inputType == 0 && p->textureCount == 2) || ((p->inputType == 1 || p->inputType == 2) && p->textureCount == 1)))
         return fail(c, RFX_EINVAL, "rfx_temporal_reproject: inputType/textureCount combination");
     if (p->historySource < 0 || p->historySource > 2) return fail(c, RFX_EINVAL, "rfx_temporal_reproject: historySource");
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     const int h0 = p->historySource == 0 ? RFX_TEX_DENOISE_B0 : (p->historySource == 1 ? RFX_TEX_FBCOPY_F16 : RFX_TEX_FBCOPY_F32);
     // with one texture the reference binds the same history to every index (TemporalReprojectPass.js:148-151)
     const int h1 = (p->historySource == 0 && p->textureCount == 2) ? RFX_TEX_DENOISE_B1 : h0;
@@ -802,7 +835,7 @@ int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
 int rfx_copy_framebuffer(rfx_ctx *c, rfx_tex dst) {
     if (!c) return RFX_EINVAL;
     if (dst != RFX_TEX_FBCOPY_F16 && dst != RFX_TEX_FBCOPY_F32) return fail(c, RFX_EINVAL, "rfx_copy_framebuffer: dst must be RFX_TEX_FBCOPY_F16 or _F32");
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     const int ids[] = {RFX_TEX_TEMPORAL0, (int)dst};
     int rc = need(c, ids, 2);
     if (rc) return rc;
@@ -815,7 +848,7 @@ int rfx_copy_framebuffer(rfx_ctx *c, rfx_tex dst) {
 int rfx_poisson_denoise(rfx_ctx *c, const rfx_denoise_params *p) {
     if (!c || !p) return RFX_EINVAL;
     if (p->textureCount != 1 && p->textureCount != 2) return fail(c, RFX_EINVAL, "rfx_poisson_denoise: textureCount");
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     const int in0 = p->inputIsTemporal ? RFX_TEX_TEMPORAL0 : (p->writeToB ? RFX_TEX_DENOISE_A0 : RFX_TEX_DENOISE_B0);
     const int in1 = p->inputIsTemporal ? RFX_TEX_TEMPORAL1 : (p->writeToB ? RFX_TEX_DENOISE_A1 : RFX_TEX_DENOISE_B1);
     const int out0 = p->writeToB ? RFX_TEX_DENOISE_B0 : RFX_TEX_DENOISE_A0;
@@ -835,6 +868,19 @@ int rfx_poisson_denoise(rfx_ctx *c, const rfx_denoise_params *p) {
     blue_noise_shift(p->blueNoiseIndex, &A.shift_x, &A.shift_y);
     A.out0 = wview(c, out0); A.out1 = wview(c, out1);
     A.p = *p;
+    A.fuse_compose = 0;
+    A.cout = TexViewW();
+    A.rgb_out = nullptr;
+    // The draw a Denoiser's loop ends with — a later pass into target B, both textures — on a whole-frame context drawing on the library's own
+    // stream (a host that brought its stream may order work of its own against what it has been told is enqueued) is held for the
+    // rfx_compose that follows it in the reference (rfx_ctx.h k3_held)
+    const bool whole_ctx = c->tile_y0 == 0 && c->tile_rows == c->H && A.y0 == 0 && A.y1 == c->H;
+    if (RFX_FOLD_COMPOSE && c->fold_compose && !p->inputIsTemporal && p->writeToB && p->textureCount == 2 && whole_ctx && c->stream == c->own_stream) {
+        if (!c->k3_held_args) c->k3_held_args = new K3Args;
+        *c->k3_held_args = A;
+        c->k3_held = true;
+        return RFX_OK;
+    }
     HIPCHK(c, rfx_launch_k3(A, c->stream));
     return RFX_OK;
 }
@@ -844,6 +890,12 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
     if (p->inputType != 0 && p->inputType != 2)
         return fail(c, RFX_EUNSUPPORTED, "rfx_compose: inputType diffuseSpecular (0) and specular (2) are built");
     hipSetDevice(c->device);
+    // a held denoise draw (rfx_ctx.h k3_held) whose targets this draw reads: both in one launch; any other combination launches it first
+    const bool fold = c->k3_held && p->inputType == 0 && p->giSource == 0;
+    if (!fold) {
+        const int frc = rfx_internal_flush(c);
+        if (frc) return frc;
+    }
     if (p->giSource != 0 && p->giSource != 1) return fail(c, RFX_EINVAL, "rfx_compose: giSource");
     const int g0 = p->giSource ? RFX_TEX_TEMPORAL0 : RFX_TEX_DENOISE_B0, g1 = p->giSource ? RFX_TEX_TEMPORAL1 : RFX_TEX_DENOISE_B1;
     const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, g0, g1, RFX_TEX_COMPOSE, RFX_TEX_DIRECT_LIGHT};
@@ -866,6 +918,22 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
         A.rgb_out = (float *)c->slots[RFX_TEX_COMPOSE_RGB].ptr;  // held whole, like COMPOSE: frame row y at y * W
     }
     A.p = *p;
+    if (fold) {
+        K3Args &K = *c->k3_held_args;
+        c->k3_held = false;
+        bool folded = false;
+        if (any && A.y0 == K.y0 && A.y1 == K.y1) {
+            K.fuse_compose = 1;
+            K.cp = *p;
+            K.cout = A.out;
+            K.rgb_out = A.rgb_out;
+        }
+        HIPCHK(c, rfx_launch_k3(K, c->stream, &folded));
+        if (folded) {
+            c->folded_draws++;
+            return RFX_OK;
+        }
+    }
     if (any) HIPCHK(c, rfx_launch_k4(A, c->stream));
     return RFX_OK;
 }
@@ -873,7 +941,7 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
 int rfx_final_compose(rfx_ctx *c, const rfx_final_params *p) {
     if (!c || !p) return RFX_EINVAL;
     if (p->fogMode < 0 || p->fogMode > 2) return fail(c, RFX_EINVAL, "rfx_final_compose: fogMode");
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     if (p->inputSource < 0 || p->inputSource > 2) return fail(c, RFX_EINVAL, "rfx_final_compose: inputSource");
     const int src = p->inputSource == 0 ? RFX_TEX_COMPOSE : (p->inputSource == 1 ? RFX_TEX_TEMPORAL0 : RFX_TEX_DENOISE_B0);
     const int ids[] = {RFX_TEX_DEPTH, src, RFX_TEX_DIRECT_LIGHT, RFX_TEX_FINAL};
@@ -891,20 +959,20 @@ int rfx_final_compose(rfx_ctx *c, const rfx_final_params *p) {
 
 int rfx_sync(rfx_ctx *c) {
     if (!c) return RFX_EINVAL;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return RFX_OK;
 }
 
 int rfx_time_begin(rfx_ctx *c) {
     if (!c) return RFX_EINVAL;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     return RFX_OK;
 }
 int rfx_time_end(rfx_ctx *c, float *elapsed_ms) {
     if (!c || !elapsed_ms) return RFX_EINVAL;
-    hipSetDevice(c->device);
+    RFX_ENTER(c);
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
@@ -915,6 +983,7 @@ unsigned int rfx_halo_violations(rfx_ctx *c) {
     unsigned int v = 0;
     if (!c) return 0;
     hipSetDevice(c->device);
+    rfx_internal_flush(c);
     hipStreamSynchronize(c->stream);
     hipMemcpy(&v, c->halo_violations, sizeof v, hipMemcpyDeviceToHost);
     return v;

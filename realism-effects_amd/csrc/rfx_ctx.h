@@ -67,8 +67,19 @@ struct rfx_ctx {
     hipEvent_t ev_staged = nullptr, ev_frame_done = nullptr;
     hipEvent_t ev_batch[2] = {nullptr, nullptr};  // the copies published by the last two flips (recorded on upload_stream)
     unsigned int flips = 0;
+    // The draw a Denoiser's denoise loop ends with (a later PoissonDenoisePass draw into target B; whole-frame context, the library's own
+    // stream) is HELD until the next call on the context: rfx_compose — the DenoiserComposePass draw that follows it in the reference,
+    // src/denoise/Denoiser.js:97-107 — then makes both draws in one launch (k3_denoise.hip FUSE); any other call launches the held draw
+    // first (rfx_internal_flush, at the top of every entry point), so nothing can observe the difference in order.
+    bool k3_held = false;
+    bool fold_compose = true;  // rfx_set_compose_fold
+    struct K3Args *k3_held_args = nullptr;
+    unsigned int folded_draws = 0;  // compose draws made inside a denoise launch so far
     std::string err;
 };
+// rfx_api.hip: launch the held draw, if any (every entry point that takes a context starts with it)
+extern "C" int rfx_internal_flush(rfx_ctx *c);
+extern "C" unsigned int rfx_internal_folded_draws(const rfx_ctx *c);  // (internal: not part of include/rfx.h)
 void rfx_comm_release(rfx_ctx *c);  // rfx_comm.hip: called by rfx_destroy
 // rfx_api.hip, for rfx_comm.hip: enqueue on the draw stream the reduction of the traced rays' history rows into rows_dev[0..1] (min, max)
 extern "C" int rfx_internal_hit_rows_enqueue(rfx_ctx *c, int *rows_dev);  // (internal: not part of include/rfx.h)

@@ -170,6 +170,11 @@ class Renderer {
 		if (m === undefined) throw new RangeError("setUvModel: \"ideal\" or \"reference_gl\"")
 		addon.setUvModel(this._h, m)
 	}
+	// whether the Denoiser's last denoise draw and the compose draw that follows it are made in one launch (rfx_set_compose_fold; the default on a
+	// whole-frame context).  false: one launch per draw, the reference's LINEAR fetch at vUv exactly
+	setComposeFold(enable) {
+		addon.setComposeFold(this._h, enable ? 1 : 0)
+	}
 	// the same draw in two launches (rfx_ssgi_trace / rfx_ssgi_shade): only the second reads last frame's composed GI
 	ssgiTrace(uniforms) {
 		addon.ssgiTrace(this._h, uniforms)

@@ -61,6 +61,7 @@ struct Fiber {
     hostsim_idx idx;
     int state, kind, arg;
     unsigned long long payload, result;
+    void *site;  // return address of the wave operation the fiber waits at (diagnostics)
     void *fake_stack;
 };
 thread_local Fiber *fibers = nullptr;
@@ -124,6 +125,7 @@ void hostsim_barrier_wait() {
     to_scheduler(false);
 }
 unsigned long long hostsim_wave_exchange(int kind, unsigned long long payload, int arg) {
+    cur->site = __builtin_return_address(0);
     Fiber *f = cur;
     f->state = AT_WAVEOP;
     f->kind = kind;
@@ -172,7 +174,14 @@ void hostsim_run_block(unsigned int n, unsigned int bx, unsigned int by, void (*
             for (unsigned int i = w0; i < w1; i++)
                 if (fibers[i].state == AT_WAVEOP && (fibers[i].kind != HOSTSIM_JOIN || join_now)) {
                     here |= 1ull << (i - w0);
-                    if (kind && kind != fibers[i].kind) { std::fprintf(stderr, "hostsim: the lanes of a wavefront wait at different wave operations\n"); std::abort(); }
+                    if (kind && kind != fibers[i].kind) {
+                        std::fprintf(stderr, "hostsim: the lanes of a wavefront wait at different wave operations (kinds per lane of the wavefront, . = not at one:");
+                        for (unsigned int j = w0; j < w1; j++) std::fprintf(stderr, " %c", fibers[j].state == AT_WAVEOP ? (char)('0' + fibers[j].kind) : fibers[j].state == DONE ? 'x' : '.');
+                        std::fprintf(stderr, ")\nsites (addr2line -f -i -e <lib> <offset>):");
+                        for (unsigned int j = w0; j < w1; j++) if (fibers[j].state == AT_WAVEOP) std::fprintf(stderr, " %u:%d:%p", j - w0, fibers[j].kind, fibers[j].site);
+                        std::fprintf(stderr, "\n");
+                        std::abort();
+                    }
                     kind = fibers[i].kind;
                 }
             if (!here) continue;

@@ -22,6 +22,7 @@ MOCK = textwrap.dedent('''
     class FakeCtx:
         def halo_violations(self): return 0
         def close(self): pass
+        def set_compose_fold(self, enable): pass
     kms = {"k1_ssgi_march": 0.61, "k2_temporal_reproject": 0.45, "k3_poisson_denoise_pass0": 0.24, "k3_poisson_denoise_pass1": 0.38, "k4_compose": 0.11}
     bench.build_case = lambda world, rank, lr, dev, d, one, W, H, tiles, *a, **k: dict(ctx=FakeCtx(), rows=tiles[rank][1], halo=0 if world == 1 else 12,
                                                                                        frame=None, fx=None, renderer=None)
@@ -32,7 +33,7 @@ MOCK = textwrap.dedent('''
             time.sleep(3600)
         return 0.0366, (0.0380 if k.get("cold") else None)
     bench.time_case = time_case
-    bench.kernel_times = lambda *a, **k: dict(kms)
+    bench.kernel_times = lambda *a, **k: (dict(kms), kms["k3_poisson_denoise_pass1"] + kms["k4_compose"])
     bench.cpu_baseline = lambda *a, **k: {"value": 10.4, "unit": "Mpixels/s", "cores": 32, "kind": "reference", "sample": "mock"}
     bench.main()
 ''') % ROOT

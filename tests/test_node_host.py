@@ -492,7 +492,7 @@ def test_cube_environment_js_and_python_hosts_issue_the_same_calls():
 def test_node_row_tiled_run_equals_single_process(tmp_path, ranks):
     """`run_dump.js --ranks N`: N Node processes, each driving its tile through the N-API addon, exchanging halo rows and the composed GI
     through the C ABI (rfx_comm_* / rfx_halo_exchange / rfx_allgather_history — under --hostsim over tests/hostsim/fakerccl.c), stitched by
-    the parent: the same bytes as one process rendering the whole frame."""
+    the parent: the same bytes as one process rendering the whole frame with one launch per draw."""
     from rfx_amd.dump import write_dump
     from rfx_amd.scene import synthetic_frame
     W, H = 160, 96
@@ -503,7 +503,8 @@ def test_node_row_tiled_run_equals_single_process(tmp_path, ranks):
         dirs.append(d)
     env = dict(os.environ, RFX_ONE_GPU="1")
     one, many = str(tmp_path / "one"), str(tmp_path / "many")
-    subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", one, "--steps", "12", "--refineSteps", "3"], text=True, env=env)
+    # (--composeFold false: the whole-frame process makes one launch per draw, as a row tile does — include/rfx.h rfx_set_compose_fold)
+    subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", one, "--steps", "12", "--refineSteps", "3", "--composeFold", "false"], text=True, env=env)
     res = subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", many, "--steps", "12", "--refineSteps", "3", "--ranks", str(ranks)],
                                   text=True, env=env, timeout=600)
     info = json.loads(res.strip().splitlines()[-1])
