@@ -315,82 +315,6 @@ RFX_DEV void k1_refine_packed(const MarchCtx &m, const FrameDims &d, Ray (&rays)
     K1_UNPACK(uv.x, rays[0].uv.x, rays[1].uv.x) K1_UNPACK(uv.y, rays[0].uv.y, rays[1].uv.y)
 #undef K1_UNPACK
 }
-#ifndef RFX_K1_COMPACT_MARCH
-#define RFX_K1_COMPACT_MARCH 0  // build knob: 1 = a wavefront whose live rays fit one per lane packs them and finishes the march in the one-slot form (k1_march_packed).  Same texels; MEASURED SLOWER at 4K in every form tried (K1 0.550-0.563 ms against 0.529-0.544, profiles/r04_k1/j_inwave_compaction.txt): not the default
-#endif
-#ifndef RFX_K1_COMPACT_AT
-#define RFX_K1_COMPACT_AT 0xffffffffu  // build knob: bit i set = the wavefront counts its live rays before step i (all steps, or a few chosen ones)
-#endif
-#ifndef RFX_K1_COMPACT_MIN_LEFT
-#define RFX_K1_COMPACT_MIN_LEFT 4  // build knob: steps that must be left for the packing (24 crossbar moves ~ one two-ray step) to pay
-#endif
-// One march step of ONE ray: k1_march_step's arithmetic for a single slot (the same operations in the same order on that ray's values)
-template <int PROJ, bool CS1>
-RFX_DEV void k1_march_step_one(const MarchCtx &m, const FrameDims &d, float3 &pos, const float3 dir, float2 &uv, float &live, float cs) {
-    if (CS1) {
-        pos = make_float3(__builtin_fmaf(dir.x, live, pos.x), __builtin_fmaf(dir.y, live, pos.y), __builtin_fmaf(dir.z, live, pos.z));
-    } else {
-        const float csr = cs * live;
-        pos = pos + dir * csr;
-    }
-    uv = k1_project<PROJ>(m, pos);
-    Tap tap;
-    {
-        const float cx = uv.x * d.fW, cy = uv.y * d.fH;
-        if (__builtin_amdgcn_ballot_w64(fmaxf(fabsf(cx), fabsf(cy)) >= 2147483648.0f) != 0) {
-            tap = k1_tap(m, d, uv);
-        } else {
-            tap = k1_tap_at(m, d, (int)__builtin_amdgcn_fmed3f(cx, 0.0f, (float)(d.W - 1)), (int)__builtin_amdgcn_fmed3f(cy, 0.0f, (float)(d.H - 1)));
-        }
-    }
-    const float2 mm = k1_cell_load(m.coarse, tap.cell);
-    const float h = pos.z;
-    const bool need = (live != 0.0f) & !((mm.y - h < 0.0f) | (mm.x - h >= m.thickness));
-    float z = 0.0f;
-    if (need) z = rfx_gather<float>(m.viewz, tap.idx);
-    const float diff = z - pos.z;
-    live = (need & (diff >= 0.0f) & (diff < m.thickness)) ? 0.0f : live;
-}
-// The rest of the march with ONE ray per lane (round 4).  Rays end at different steps — a third of the two-slot loop's lane-steps belong to
-// rays that have already hit, never started, or share a pixel with one that did (profiles/r03_experiments/k1_ray_statistics.txt) — and the
-// wavefront pays for both slots as long as either holds a live ray anywhere.  Once at most 63 of its 128 slots are live (all 64 lanes in
-// the loop), the live rays are packed into lanes 0 .. n-1 exactly as k1_refine_packed packs the rays that hit (ds_permute through the LDS
-// crossbar: no LDS memory, no barrier, nothing another wavefront waits for — the workgroup-wide compaction of round 3 bought no time
-// because its waves waited at barriers), marched to the end with the one-slot step — the same arithmetic per ray — and fetched back by
-// their owners.  `i` = the next step; `rb` = the pixel's random.b (cs(i) depends on it while i < 9).
-template <int PROJ>
-RFX_DEV void k1_march_packed(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2], float rb, int i, int split, unsigned long long l0, unsigned long long l1, int n0) {
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int rank0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(l0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)l0, 0u));
-    const int rank1 = n0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(l1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)l1, 0u));
-    const bool live0 = rays[0].live != 0.0f, live1 = rays[1].live != 0.0f;
-    const int dest0 = live0 ? rank0 : 63, dest1 = live1 ? rank1 : 63;  // (at most 63 live rays: no rank reaches lane 63)
-    const int n = n0 + __popcll(l1);
-    const bool from0 = lane < n0, mine = lane < n;
-    float3 pos, dir;
-#define K1_PACK(dst, field) { const float a = k1_push(dest0, rays[0].field), b = k1_push(dest1, rays[1].field); dst = from0 ? a : b; }
-    K1_PACK(pos.x, pos.x) K1_PACK(pos.y, pos.y) K1_PACK(pos.z, pos.z) K1_PACK(dir.x, dir.x) K1_PACK(dir.y, dir.y) K1_PACK(dir.z, dir.z)
-#undef K1_PACK
-    float prb = 0.0f;
-    if (i < split) {  // (wave-uniform) the steps before cs == 1 need the owner's random.b
-        const float a = k1_push(dest0, rb), b = k1_push(dest1, rb);
-        prb = from0 ? a : b;
-    }
-    float live = mine ? 1.0f : 0.0f;
-    float2 uv = make_float2(0.f, 0.f);
-    // (wave-uniform loops: all 64 lanes stay until no lane holds a live ray — they are all needed again for the moves back)
-    for (; i < split && __ballot(live != 0.0f) != 0; i++) {
-        const float t = (float)i + prb - 0.5f;
-        const float cs = 1.0f - rfx_exp2((t * t) * (-0.25f * 1.4426950408889634f));
-        k1_march_step_one<PROJ, false>(m, d, pos, dir, uv, live, cs);
-    }
-    for (; i < m.steps && __ballot(live != 0.0f) != 0; i++) k1_march_step_one<PROJ, true>(m, d, pos, dir, uv, live, 1.0f);
-    // every owner fetches the rays it sent (all lanes take part in the moves; the value is kept only where the slot's ray was sent)
-#define K1_UNPACK(val, f0, f1) { const float a = k1_pull(rank0, val), b = k1_pull(rank1, val); if (live0) f0 = a; if (live1) f1 = b; }
-    K1_UNPACK(pos.x, rays[0].pos.x, rays[1].pos.x) K1_UNPACK(pos.y, rays[0].pos.y, rays[1].pos.y) K1_UNPACK(pos.z, rays[0].pos.z, rays[1].pos.z)
-    K1_UNPACK(uv.x, rays[0].uv.x, rays[1].uv.x) K1_UNPACK(uv.y, rays[0].uv.y, rays[1].uv.y) K1_UNPACK(live, rays[0].live, rays[1].live)
-#undef K1_UNPACK
-}
 // RayMarch (:441-475) + BinarySearch (:477-503) for the pixel's TWO rays at once (slot 0 = optional diffuse ray,
 // slot 1 = specular ray), restructured for the SIMT machine without changing any per-ray arithmetic:
 //   * both rays advance in the same loop iteration (they share cs(i), and their taps are in flight together);
@@ -400,6 +324,11 @@ RFX_DEV void k1_march_packed(const MarchCtx &m, const FrameDims &d, Ray (&rays)[
 //   * cs(i) = 1 - exp(-t^2 / 4) with t = i + random.b - 0.5 >= i - 0.5 (:453-454): from i = 9 on, t >= 8.5 and exp(-t^2 / 4) <= 1.5e-8 <
 //     2^-25, so the subtraction rounds to exactly 1.0f — in the reference's fp32 as here — and `dir * cs` is `dir`: the second loop below
 //     evaluates no cs at all (no v_exp, no products), the same bits.
+// Two more forms of this loop were built and measured in round 4, both with the same texels and both SLOWER (profiles/r04_k1/j_inwave_compaction.txt,
+// k_occupancy_double_step.txt; the code: profiles/r04_k1/k1_march_experiments.patch): packing a wavefront's live rays one per lane through the LDS
+// crossbar once they fit (K1 0.550-0.563 against 0.529-0.544 ms), and marching two steps per iteration with the second speculated while the
+// first's fetches are in flight (0.549 against 0.535 ms).  At 8 wavefronts per SIMD the march is bound by instruction issue: whatever adds
+// instructions to remove idle lanes or round trips loses.
 template <int PROJ>
 RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2], float random_b) {
     const float scale = m.rayDistance / (float)m.steps;
@@ -411,37 +340,14 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
     }
     const int split = RFX_K1_CS1 ? min(m.steps, 9) : m.steps;
     int i = RFX_K1_ABLATE >= 3 ? m.steps : 1;
-    // A wavefront with all 64 lanes here (no background / out-of-frame lane left the fragment early) loops wave-uniformly — a lane without a
-    // live ray steps along by dir * 0, as a dead slot does — and leaves the two-slot form for k1_march_packed as soon as its live rays fit
-    // one per lane; any other wavefront keeps the per-lane loops.
-    const bool whole_wave = RFX_K1_COMPACT_MARCH && __ballot(1) == ~0ull;
-    bool packed = false;
-#define K1_LOOP_LIVE(rays) (whole_wave ? (__ballot(((rays)[0].live != 0.0f) | ((rays)[1].live != 0.0f)) != 0) : K1_ANY_LIVE(rays))
-#define K1_TRY_PACK()                                                                                                    \
-    if (whole_wave && m.steps - i >= RFX_K1_COMPACT_MIN_LEFT && ((RFX_K1_COMPACT_AT >> (i & 31)) & 1u)) {                \
-        const unsigned long long l0 = __ballot(rays[0].live != 0.0f), l1 = __ballot(rays[1].live != 0.0f);               \
-        const int n0 = __popcll(l0);                                                                                     \
-        if (n0 + __popcll(l1) <= 63) {                                                                                   \
-            k1_march_packed<PROJ>(m, d, rays, random_b, i, split, l0, l1, n0);                                          \
-            packed = true;                                                                                               \
-            break;                                                                                                       \
-        }                                                                                                                \
-    }
-    for (; i < split && K1_LOOP_LIVE(rays); i++) {
-        K1_TRY_PACK()
+    for (; i < split && K1_ANY_LIVE(rays); i++) {
         const float t = (float)i + random_b - 0.5f;
         // exp(-0.25 t^2) = exp2((-0.25 t^2) log2e): the scaling by -1/4 is exact, so it folds into the constant (one product instead of two,
         // the same bits)
         const float cs = 1.0f - rfx_exp2((t * t) * (-0.25f * 1.4426950408889634f));
         k1_march_step<PROJ, false>(m, d, rays, cs);
     }
-    if (!packed)
-        for (; i < m.steps && K1_LOOP_LIVE(rays); i++) {
-            K1_TRY_PACK()
-            k1_march_step<PROJ, true>(m, d, rays, 1.0f);
-        }
-#undef K1_TRY_PACK
-#undef K1_LOOP_LIVE
+    for (; i < m.steps && K1_ANY_LIVE(rays); i++) k1_march_step<PROJ, true>(m, d, rays, 1.0f);
 #pragma unroll
     for (int r = 0; r < 2; r++) rays[r].hit = started[r] & (rays[r].live == 0.0f);
     // (a wavefront none of whose rays hit — sky above the horizon, a wall facing away — has nothing to refine)
@@ -1019,7 +925,11 @@ hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
     // persistent: what the chip holds at once (4 workgroups of 8 waves per CU at <= 64 VGPRs; fewer fit with an environment map — the
     // surplus workgroups start late and find the counter exhausted), never more workgroups than there are tiles for their waves
     const int nbx = (A.out_w + 63) / 64, nby = (A.y1 - A.y0 + K1_TH - 1) / K1_TH;
-    const int want = (nbx * nby + K1_WAVES - 1) / K1_WAVES, fit = (A.n_cu > 0 ? A.n_cu : 256) * (32 / K1_WAVES);
+#ifndef RFX_K1_OCC
+#define RFX_K1_OCC 8  // measurement knob: wavefronts per SIMD the persistent grid is sized for.  8 = what the chip holds; measured at 4K 8 / 6 / 4 / 2: 0.542 / 0.561 / 0.641 / 0.958 ms
+                      // (profiles/r04_k1/k_occupancy_double_step.txt): at 8 the other waves hide nearly all of the march's latency
+#endif
+    const int want = (nbx * nby + K1_WAVES - 1) / K1_WAVES, fit = (A.n_cu > 0 ? A.n_cu : 256) * (4 * RFX_K1_OCC / K1_WAVES);
     dim3 block(64 * K1_WAVES), grid(want < fit ? want : fit);
     const float *P = A.p.camera.projectionMatrix;
     const bool persp = P[1] == 0.f && P[2] == 0.f && P[3] == 0.f && P[4] == 0.f && P[6] == 0.f && P[7] == 0.f && P[12] == 0.f && P[13] == 0.f &&
