@@ -53,8 +53,15 @@ BYTES_PER_PX = {"k1_ssgi_march": 68, "k2_temporal_reproject": 80, "k3_poisson_de
 
 
 # rocprofv3 kernel-name fragments of bench.py's kernel keys (profiles/*/pmc_hbm.csv)
-PMC_KERNEL = {"k1_ssgi_march": "false, 0>(K1Args)", "k2_temporal_reproject": "k2_temporal_reproject", "k3_poisson_denoise_pass0": "k3_tiled<true",
-              "k3_poisson_denoise_pass1": "k3_tiled<false", "k4_compose": "k4_compose"}
+# (every fragment of a tuple must occur in the name.  k3_tiled<IN_TEMPORAL, textures, LDS pitch, WHOLE, FUSE>: the launch that also makes the compose
+# draw — what a frame executes on a whole-frame context — ends in "true>(K3Args)")
+PMC_KERNEL = {"k1_ssgi_march": ("false, 0>(K1Args)",), "k2_temporal_reproject": ("k2_temporal_reproject",), "k3_poisson_denoise_pass0": ("k3_tiled<true",),
+              "k3_poisson_denoise_pass1": ("k3_tiled<false", "false>(K3Args)"), "k4_compose": ("k4_compose",),
+              "k3_pass1_plus_k4_folded": ("k3_tiled<false", "true>(K3Args)")}
+
+
+def _is_kernel(key, name):
+    return all(f in name for f in PMC_KERNEL[key])
 
 
 PROFILE_DIR = "profiles/r04_final"  # the committed rocprofv3 collection (tools/collect_profiles.sh) the counter-derived figures are read from
@@ -79,7 +86,7 @@ def pmc_traffic(kernel_key):
         return None
     vals = {}
     for r in csv.DictReader(open(path)):
-        if PMC_KERNEL[kernel_key] in r["kernel"]:
+        if _is_kernel(kernel_key, r["kernel"]):
             vals[r["counter"]] = float(r["mean_value_KB"])
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None
@@ -96,9 +103,9 @@ def issue_model():
         log("issue model not available: %r" % (e,))
         return None
     out = {}
-    for key, frag in PMC_KERNEL.items():
+    for key in PMC_KERNEL:
         for name, m in rows.items():
-            if frag in name:
+            if _is_kernel(key, name):
                 out[key] = {k: m[k] for k in ("valu_per_px", "predicted_issue_ms", "measured_ms", "issue_share_of_measured", "clock_GHz") if k in m}
     return out or None
 
@@ -493,7 +500,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "stream_copy_GBs": copy_gbs,
                          "frac_of_stream_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                          "traffic": pmc_traffic(dom) if (W1, rows) == (W4K, H4K) else None,
-                         "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 from %s/pmc_hbm.csv (rocprofv3 --pmc over the same kernels and arguments at 4K — tools/quick_time.py; this command's own FETCH_SIZE agrees to 0.1 %%, K2 2 %%: fetch_size_bench_command.csv; collected at git %s)" % (
+                         "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 from %s/pmc_hbm.csv (separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this bench command at 4K, tools/collect_profiles.sh; collected at git %s)" % (
                              PROFILE_DIR, prof.get("git_commit", "?")),
                          "algorithmic_bytes_per_launch": BYTES_PER_PX[dom] * px_tile, "avg_launch_ms": round(kms[dom], 4)},
             "halo_violations": viol,

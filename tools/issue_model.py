@@ -48,8 +48,9 @@ def _durations_us(profile_dir):
     return out
 
 
-def model(c, measured_us=None):
-    """c: counter name -> mean per launch.  Returns a dict, or None when the class counters are missing."""
+def model(c, measured_us=None, pixels=3840 * 2160, persistent=False):
+    """c: counter name -> mean per launch.  Returns a dict, or None when the class counters are missing.
+    persistent: the launch's wavefronts loop over tiles (K1 since round 4): instructions per pixel are counts / pixels, not counts / (64 x SQ_WAVES)."""
     need = ("SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32")
     if not all(k in c for k in need):
         return None
@@ -60,8 +61,9 @@ def model(c, measured_us=None):
     it = c.get("SQ_INSTS_VALU_INT32", 0.0)
     other = max(c["SQ_INSTS_VALU"] - fam - tr - cvt - it, 0.0)
     cycles_per_wave = (fam * RATE["fma_add_mul"] + tr * RATE["trans"] + cvt * RATE["cvt"] + it * RATE["int"] + other * RATE["other"]) / w
-    out = {"valu_per_px": round(c["SQ_INSTS_VALU"] / w, 1),
-           "per_px": {"fp32_add_mul_fma": round(fam / w, 1), "transcendental": round(tr / w, 1), "cvt": round(cvt / w, 1), "int32": round(it / w, 1), "other": round(other / w, 1)},
+    pw = pixels / 64.0 if persistent else w  # wave64 instructions per pixel = per (wavefront of 64 pixels)
+    out = {"valu_per_px": round(c["SQ_INSTS_VALU"] / pw, 1),
+           "per_px": {"fp32_add_mul_fma": round(fam / pw, 1), "transcendental": round(tr / pw, 1), "cvt": round(cvt / pw, 1), "int32": round(it / pw, 1), "other": round(other / pw, 1)},
            "issue_cycles_per_wave": round(cycles_per_wave, 0), "waves_per_simd": round(w / N_SIMD, 1)}
     if measured_us and "GRBM_GUI_ACTIVE" in c:
         clock_ghz = c["GRBM_GUI_ACTIVE"] / N_XCD / (measured_us * 1e3)
@@ -75,7 +77,7 @@ def table(profile_dir):
     cs, du = _counters(profile_dir), _durations_us(profile_dir)
     rows = {}
     for k, c in cs.items():
-        m = model(c, du.get(k))
+        m = model(c, du.get(k), persistent="k1_ssgi_march" in k)
         if m:
             rows[k] = m
     return rows
