@@ -1203,6 +1203,67 @@ def test_compose_folded_into_the_last_denoise_draw(blue_noise, size, uv_ideal, r
         assert np.array_equal(fo[3], fo[2][..., :3]) and np.array_equal(u[3], u[2][..., :3])
 
 
+@pytest.mark.parametrize("between", ["sync", "download", "row_window", "uv_model", "clear_other", "time_begin", "fold_off", "user_stream"])
+def test_any_call_between_the_two_draws_unfolds_them(blue_noise, between):
+    """The held denoise draw (rfx_ctx.h k3_held) is launched by WHATEVER the next call on the context is, unless that call is the compose draw
+    that reads its targets: nothing a host does between the two draws can observe the hold.  Every case must give the two-launch result bit
+    for bit and count no folded draw."""
+    import ctypes as C
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.scene import synthetic_frame
+
+    W, H = 192, 108
+    f = synthetic_frame(W, H, 1)
+    sp, tp, dp, cp = _params(abi, f, f.camera, 1.0, 12, 3)
+    rs = np.random.RandomState(3)
+    held = rs.rand(H, W, 4).astype(np.float32)
+    A = [(rs.rand(H, W, 4) * 2.0).astype(np.float16).view(np.uint16) for _ in range(2)]
+    dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 9, 0, 1
+
+    def run(mode):
+        ctx = Context(W, H)
+        ctx.lib.rfx_internal_folded_draws.restype = C.c_uint
+        ctx.lib.rfx_internal_folded_draws.argtypes = [C.c_void_p]
+        ctx.upload_frame(f)
+        ctx.upload(abi.TEX_COMPOSE, held)
+        ctx.upload(abi.TEX_DENOISE_A0, A[0])
+        ctx.upload(abi.TEX_DENOISE_A1, A[1])
+        if mode == "fold_off":
+            ctx.set_compose_fold(False)
+        if mode == "user_stream":
+            ctx.set_stream(0)  # handle 0 = back to the library's own stream (a real host stream never folds: rfx_api.hip)
+        ctx.poisson_denoise(dp)
+        if mode == "sync":
+            ctx.sync()
+        elif mode == "download":
+            ctx.download(abi.TEX_DEPTH)
+        elif mode == "row_window":
+            ctx.set_row_window(0, 0)
+        elif mode == "uv_model":
+            ctx.set_uv_model("reference_gl")
+        elif mode == "clear_other":
+            ctx.clear(abi.TEX_FINAL)
+        elif mode == "time_begin":
+            ctx.time_begin()
+        ctx.compose(cp)
+        n = ctx.lib.rfx_internal_folded_draws(ctx._h)
+        out = (ctx.download(abi.TEX_DENOISE_B0), ctx.download(abi.TEX_DENOISE_B1), ctx.download(abi.TEX_COMPOSE))
+        assert ctx.halo_violations() == 0
+        ctx.close()
+        return n, out
+
+    n_ref, ref = run("sync")
+    assert n_ref == 0
+    n, got = run(between)
+    if between == "user_stream":  # handle 0 selects the library's own stream: the fold is allowed there
+        assert n == 1 and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        return
+    assert n == 0, between
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b), between
+
+
 def test_folded_compose_on_a_4k_chain(blue_noise):
     """What the fold (see above) changes on BASELINE configs[2]: K1 -> K2 -> K3 -> K3 (+ K4) over two frames of the 4K synthetic orbit, the last two
     draws once as two launches and once as one.  Measured on MI355X: profiles/r04_parity/folded_compose_4k.txt; the bounds are ~3x that."""
