@@ -327,6 +327,7 @@ void *rfx_tex_device_ptr(rfx_ctx *c, rfx_tex id) {
     // whoever takes the depth plane's address may write it with work this library cannot see (ordered against the draw stream only, as a
     // bound external buffer is): the pre-pass then stays in the draw stream
     if (id == RFX_TEX_DEPTH) c->depth_external = true;
+    c->slots[id].exported = true;  // (a draw into this plane is never held for a later call: rfx_poisson_denoise)
     return c->slots[id].ptr;
 }
 
@@ -738,7 +739,13 @@ int rfx_internal_hit_mask_enqueue(rfx_ctx *c, int ranks) {
     RFX_ENTER(c);
     if (ranks < 1) ranks = 1;
     if (!c->hit_mask_dev || c->hit_mask_ranks < ranks) {
-        if (c->hit_mask_dev) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(c->hit_mask_dev); hipHostFree(c->hit_mask_host); c->hit_mask_dev = nullptr; c->hit_mask_host = nullptr; }
+        if (c->hit_mask_dev) {
+            // the packing kernels and the offset copy of an earlier rfx_gather_history_rows run on comm_stream and read these buffers (the row
+            // offsets live in the same allocation): both streams drain before they go
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->comm_stream) HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+            hipFree(c->hit_mask_dev); hipHostFree(c->hit_mask_host); c->hit_mask_dev = nullptr; c->hit_mask_host = nullptr;
+        }
         const size_t words = (size_t)(2 * ranks + 2) * c->H;  // [0, H) this tile's mask, [H, (n + 1) H) every rank's, then (n + 1) H row offsets
         hipError_t e = hipMalloc((void **)&c->hit_mask_dev, words * sizeof(unsigned int));
         if (e == hipSuccess) e = hipHostMalloc((void **)&c->hit_mask_host, words * sizeof(unsigned int), hipHostMallocDefault);
@@ -871,11 +878,16 @@ int rfx_poisson_denoise(rfx_ctx *c, const rfx_denoise_params *p) {
     A.fuse_compose = 0;
     A.cout = TexViewW();
     A.rgb_out = nullptr;
-    // The draw a Denoiser's loop ends with — a later pass into target B, both textures — on a whole-frame context drawing on the library's own
-    // stream (a host that brought its stream may order work of its own against what it has been told is enqueued) is held for the
-    // rfx_compose that follows it in the reference (rfx_ctx.h k3_held)
+    // OPT-IN (rfx_set_compose_fold; off by default).  The draw a Denoiser's loop ends with — a later pass into target B, both textures — on a
+    // whole-frame context drawing on the library's own stream is held for the rfx_compose that follows it in the reference (rfx_ctx.h
+    // k3_held).  Never when a plane either draw writes is visible outside the library — bound to a caller's buffer (rfx_bind_external) or its
+    // address handed out (rfx_tex_device_ptr): such a host may synchronise with the device by means of its own and must find the draw it
+    // was told is enqueued.
     const bool whole_ctx = c->tile_y0 == 0 && c->tile_rows == c->H && A.y0 == 0 && A.y1 == c->H;
-    if (RFX_FOLD_COMPOSE && c->fold_compose && !p->inputIsTemporal && p->writeToB && p->textureCount == 2 && whole_ctx && c->stream == c->own_stream) {
+    const auto is_private = [&](int id) { const Slot &s = c->slots[id]; return (s.owned || !s.ptr) && !s.exported; };
+    const bool targets_private = is_private(out0) && is_private(out1) && is_private(RFX_TEX_COMPOSE) && is_private(RFX_TEX_COMPOSE_RGB);
+    if (RFX_FOLD_COMPOSE && c->fold_compose && !p->inputIsTemporal && p->writeToB && p->textureCount == 2 && whole_ctx && c->stream == c->own_stream &&
+        targets_private) {
         if (!c->k3_held_args) c->k3_held_args = new K3Args;
         *c->k3_held_args = A;
         c->k3_held = true;

@@ -13,6 +13,7 @@ struct Slot {
     size_t texel = 0;
     int width = 0;
     bool uploaded = false;
+    bool exported = false;  // rfx_tex_device_ptr handed the plane's address out: work the library cannot see may read or write it
     // streaming dumps (rfx_stage_upload / rfx_stage_flip): the BACK buffer the next frame's plane is copied into while the draws read `ptr`
     void *back = nullptr;
     bool back_filled = false;
@@ -67,12 +68,14 @@ struct rfx_ctx {
     hipEvent_t ev_staged = nullptr, ev_frame_done = nullptr;
     hipEvent_t ev_batch[2] = {nullptr, nullptr};  // the copies published by the last two flips (recorded on upload_stream)
     unsigned int flips = 0;
-    // The draw a Denoiser's denoise loop ends with (a later PoissonDenoisePass draw into target B; whole-frame context, the library's own
-    // stream) is HELD until the next call on the context: rfx_compose — the DenoiserComposePass draw that follows it in the reference,
-    // src/denoise/Denoiser.js:97-107 — then makes both draws in one launch (k3_denoise.hip FUSE); any other call launches the held draw
-    // first (rfx_internal_flush, at the top of every entry point), so nothing can observe the difference in order.
+    // OPT-IN (rfx_set_compose_fold(ctx, 1); off by default since ABI 18): the draw a Denoiser's denoise loop ends with (a later
+    // PoissonDenoisePass draw into target B; whole-frame context, the library's own stream, targets the library owns and whose address it
+    // never handed out) is HELD until the next call on the context: rfx_compose — the DenoiserComposePass draw that follows it in the
+    // reference, src/denoise/Denoiser.js:97-107 — then makes both draws in one launch (k3_denoise.hip FUSE); any other call launches the
+    // held draw first (rfx_internal_flush, at the top of every entry point).  The folded compose reads the texel it has just stored instead
+    // of the reference's LINEAR fetch at vUv: an approximation (include/rfx.h), which is why it is not the default.
     bool k3_held = false;
-    bool fold_compose = true;  // rfx_set_compose_fold
+    bool fold_compose = false;  // rfx_set_compose_fold
     struct K3Args *k3_held_args = nullptr;
     unsigned int folded_draws = 0;  // compose draws made inside a denoise launch so far
     std::string err;

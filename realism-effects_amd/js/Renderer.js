@@ -170,8 +170,8 @@ class Renderer {
 		if (m === undefined) throw new RangeError("setUvModel: \"ideal\" or \"reference_gl\"")
 		addon.setUvModel(this._h, m)
 	}
-	// whether the Denoiser's last denoise draw and the compose draw that follows it are made in one launch (rfx_set_compose_fold; the default on a
-	// whole-frame context).  false: one launch per draw, the reference's LINEAR fetch at vUv exactly
+	// opt in to the Denoiser's last denoise draw and the compose draw that follows it being made in one launch on a whole-frame context
+	// (rfx_set_compose_fold: an approximation).  The default (false): one launch per draw, the reference's LINEAR fetch at vUv exactly
 	setComposeFold(enable) {
 		addon.setComposeFold(this._h, enable ? 1 : 0)
 	}

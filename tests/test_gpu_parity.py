@@ -1142,9 +1142,9 @@ def test_rgb_history_twin_matches_composed_gi(blue_noise):
 
 @pytest.mark.parametrize("size,uv_ideal,rgb", [((256, 144), False, 1), ((333, 77), False, 0), ((120, 200), True, 1), ((640, 360), False, 1)])
 def test_compose_folded_into_the_last_denoise_draw(blue_noise, size, uv_ideal, rgb):
-    """The library holds the Denoiser's last denoise draw (a later pass into target B, whole-frame context, own stream) and makes the compose
-    draw that follows it in the same launch (k3_denoise.hip FUSE, rfx_ctx.h k3_held).  Same calls with anything in between (here: rfx_sync)
-    make two launches.  Folded == unfolded: target B bit for bit; the composed texel up to the bilinear weights the compose draw's LINEAR
+    """Under rfx_set_compose_fold(ctx, 1) (opt-in since ABI 18) the library holds the Denoiser's last denoise draw (a later pass into target B,
+    whole-frame context, own stream) and makes the compose draw that follows it in the same launch (k3_denoise.hip FUSE, rfx_ctx.h k3_held).
+    Same calls with anything in between (here: rfx_sync), or without the opt-in, make two launches.  Folded == unfolded: target B bit for bit; the composed texel up to the bilinear weights the compose draw's LINEAR
     fetch at vUv puts on the neighbours of the texel the folded form reads — vUv * size - 0.5 is the texel's index only up to the rounding of
     vUv: weights of 0 on 40-60 % of the texels and up to 3e-5 (640 wide) / 2.4e-4 (4K) on the rest under the reference GL's vUv; here the
     inputs are white noise of amplitude 3, the worst case for it.  Discarded fragments keep the target's texel (and its RGB twin mirrors
@@ -1171,6 +1171,8 @@ def test_compose_folded_into_the_last_denoise_draw(blue_noise, size, uv_ideal, r
         ctx.lib.rfx_internal_folded_draws.argtypes = [C.c_void_p]
         if uv_ideal:
             ctx.set_uv_model("ideal")
+        if mode == "folded":
+            ctx.set_compose_fold(True)  # opt-in since ABI 18 (include/rfx.h rfx_set_compose_fold)
         ctx.upload_frame(f)
         ctx.upload(abi.TEX_COMPOSE, held)
         if rgb:
@@ -1203,11 +1205,14 @@ def test_compose_folded_into_the_last_denoise_draw(blue_noise, size, uv_ideal, r
         assert np.array_equal(fo[3], fo[2][..., :3]) and np.array_equal(u[3], u[2][..., :3])
 
 
-@pytest.mark.parametrize("between", ["sync", "download", "row_window", "uv_model", "clear_other", "time_begin", "fold_off", "user_stream"])
+@pytest.mark.parametrize("between", ["sync", "download", "row_window", "uv_model", "clear_other", "time_begin", "fold_off", "never_enabled", "exported_target",
+                                     "exported_compose", "external_target", "user_stream"])
 def test_any_call_between_the_two_draws_unfolds_them(blue_noise, between):
-    """The held denoise draw (rfx_ctx.h k3_held) is launched by WHATEVER the next call on the context is, unless that call is the compose draw
-    that reads its targets: nothing a host does between the two draws can observe the hold.  Every case must give the two-launch result bit
-    for bit and count no folded draw."""
+    """The held denoise draw (rfx_ctx.h k3_held; rfx_set_compose_fold(ctx, 1)) is launched by WHATEVER the next call on the context is, unless
+    that call is the compose draw that reads its targets: nothing a host does between the two draws can observe the hold.  And a draw is never
+    held at all without the opt-in (the default), nor when a plane either draw writes is visible outside the library — its address handed out
+    (rfx_tex_device_ptr) or a caller's buffer bound to it (rfx_bind_external): such a host may synchronise with the device by its own means
+    (ADVICE r04).  Every case must give the two-launch result bit for bit and count no folded draw."""
     import ctypes as C
     from rfx_amd import abi
     from rfx_amd.context import Context
@@ -1229,8 +1234,18 @@ def test_any_call_between_the_two_draws_unfolds_them(blue_noise, between):
         ctx.upload(abi.TEX_COMPOSE, held)
         ctx.upload(abi.TEX_DENOISE_A0, A[0])
         ctx.upload(abi.TEX_DENOISE_A1, A[1])
+        if mode != "never_enabled":
+            ctx.set_compose_fold(True)
         if mode == "fold_off":
             ctx.set_compose_fold(False)
+        if mode == "exported_target":
+            assert ctx.device_ptr(abi.TEX_DENOISE_B1)
+        if mode == "exported_compose":
+            assert ctx.device_ptr(abi.TEX_COMPOSE)
+        ext = None
+        if mode == "external_target":  # a caller's buffer behind target B0 (here: another context's plane of the same size)
+            ext = Context(W, H)
+            ctx.bind_external(abi.TEX_DENOISE_B0, ext.device_ptr(abi.TEX_DENOISE_B0))
         if mode == "user_stream":
             ctx.set_stream(0)  # handle 0 = back to the library's own stream (a real host stream never folds: rfx_api.hip)
         ctx.poisson_denoise(dp)
@@ -1251,6 +1266,8 @@ def test_any_call_between_the_two_draws_unfolds_them(blue_noise, between):
         out = (ctx.download(abi.TEX_DENOISE_B0), ctx.download(abi.TEX_DENOISE_B1), ctx.download(abi.TEX_COMPOSE))
         assert ctx.halo_violations() == 0
         ctx.close()
+        if ext is not None:
+            ext.close()
         return n, out
 
     n_ref, ref = run("sync")
@@ -1279,6 +1296,8 @@ def test_folded_compose_on_a_4k_chain(blue_noise):
         ctx = Context(W, H)
         ctx.lib.rfx_internal_folded_draws.restype = C.c_uint
         ctx.lib.rfx_internal_folded_draws.argtypes = [C.c_void_p]
+        if mode == "folded":
+            ctx.set_compose_fold(True)
         prev, keep = frames[0].camera, 0.0
         for fi, f in enumerate(frames):
             sp, tp, dp, cp = _params(abi, f, prev, keep)

@@ -107,6 +107,7 @@ for it in range(a.n):
                 for t, a_, b_ in ((0, abi.TEX_DENOISE_A0, abi.TEX_DENOISE_B0), (1, abi.TEX_DENOISE_A1, abi.TEX_DENOISE_B1)):
                     ctx.upload(a_, o["A"][t]); ctx.upload(b_, o["B"][t])
                 ctx.upload(abi.TEX_COMPOSE, o["hist"])
+                ctx.set_compose_fold(mode == "one")  # opt-in since ABI 18
                 ctx.poisson_denoise(dp)
                 if mode == "two":
                     ctx.sync()
