@@ -19,20 +19,10 @@
 
 namespace {
 
-#ifndef RFX_K3_TW
-#define RFX_K3_TW 64  // build knobs: pixels per workgroup tile (a wavefront is 64 consecutive pixels of a row either way)
-#endif
-#ifndef RFX_K3_TH
-#define RFX_K3_TH 8
-#endif
-constexpr int TW = RFX_K3_TW, TH = RFX_K3_TH;  // pixels per workgroup tile
-constexpr int NT = TW * TH;                    // threads per workgroup
-static_assert(TW % 64 == 0 && NT <= 1024, "a tile row is whole wavefronts; at most 16 wavefronts per workgroup");
+constexpr int TW = 64, TH = 8;  // pixels per workgroup tile
+constexpr int NT = TW * TH;     // 512 threads
 #ifndef RFX_K3_XCD_G
-#define RFX_K3_XCD_G 1  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major
-#endif
-#ifndef RFX_K3_LDS_MAX
-#define RFX_K3_LDS_MAX (80 * 1024)  // build knob: dynamic LDS a tiled launch may ask for (80 KiB: two workgroups per CU; 160 KiB is the CU's)
+#define RFX_K3_XCD_G 1  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major.  Measured at 4K (pass 0 / pass 1 ms): 0: 0.248/0.380, 1: 0.244/0.376, 2: 0.245/0.390, 4: 0.255/0.414, 8: 0.266/0.423, 16: 0.288/0.434
 #endif
 // The tile is staged with an apron of (Rx, Ry) texels.  The reference rotates the Poisson offsets in UV space
 // (`rm * (offset / resolution)`, poisson_denoise.frag:183-189), so on a W x H frame a tap lies within
@@ -141,7 +131,7 @@ RFX_DEV rfx_f2 k3_luma2(rfx_f2 r, rfx_f2 g, rfx_f2 b) {
 template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE, bool FUSE>
 RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     constexpr bool PAIR = RFX_K3_PAIRS && TC == 2;  // the pixel's two accumulators as float2 pairs (k3_apply_pair)
-    extern __shared__ float4 lds[];
+    float4 *lds = (float4 *)hostsim_lds;
     const int Rx = A.tile.Rx, Ry = A.tile.Ry, LW = A.tile.LW, LH = A.tile.LH;
     const int ntex = PITCH * LH;
     float4 *s_geom = lds;
@@ -556,10 +546,10 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
 #define RFX_K3_PAD 0  // build knob: extra texels per LDS row (bank-mapping experiments, profiles/r04_k3/)
 #endif
     constexpr int PAD = RFX_K3_PAD;
-    const int pitch = A.tile.LW <= TW + 8 ? TW + 8 + PAD : A.tile.LW <= TW + 10 ? TW + 10 + PAD : A.tile.LW <= TW + 12 ? TW + 12 + PAD : A.tile.LW <= TW + 16 ? TW + 16 + PAD : A.tile.LW <= TW + 32 ? TW + 32 + PAD : 0;
+    const int pitch = A.tile.LW <= 72 ? 72 + PAD : A.tile.LW <= 74 ? 74 + PAD : A.tile.LW <= 76 ? 76 + PAD : A.tile.LW <= 80 ? 80 + PAD : A.tile.LW <= 96 ? 96 + PAD : 0;
     const size_t lds = (size_t)pitch * A.tile.LH * (16 + 4 + 2 * (temporal ? 16 : 8));
-    // at least two workgroups per CU (160 KiB LDS) keep the staging of one tile under the arithmetic of another
-    const bool tiled = A.p.radius >= 0.0f && pitch != 0 && lds <= RFX_K3_LDS_MAX;
+    // two workgroups per CU (160 KiB LDS) keep the staging of one tile under the arithmetic of another
+    const bool tiled = A.p.radius >= 0.0f && pitch != 0 && lds <= 80 * 1024;
     // every view the whole frame (a context that owns no row tile): the kernels skip row rebasing and halo accounting
     const auto whole_view = [&](const void *ptr, int row0, int rows) { return ptr == nullptr || (row0 == 0 && rows == A.dims.H); };
     const bool whole = whole_view(A.depth.ptr, A.depth.row0, A.depth.rows) && whole_view(A.gbuffer.ptr, A.gbuffer.row0, A.gbuffer.rows) &&
@@ -574,7 +564,7 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
         int dev = 0;                                                                                                         \
         hipGetDevice(&dev);                                                                                                  \
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                                        \
-            hipFuncSetAttribute((const void *)k3_tiled<T, C, P, WH>, hipFuncAttributeMaxDynamicSharedMemorySize, RFX_K3_LDS_MAX); \
+            hipFuncSetAttribute((const void *)k3_tiled<T, C, P, WH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
             if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                                  \
         }                                                                                                                    \
         hipLaunchKernelGGL((k3_tiled<T, C, P, WH>), grid, block, lds, stream, A);                                            \
@@ -582,11 +572,11 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
 #define K3_TILED_W(T, C, P) do { if (whole) K3_TILED(T, C, P, true); else K3_TILED(T, C, P, false); } while (0)
 #define K3_TILED_P(T, C)                    \
     do {                                    \
-        if (pitch == TW + 8 + PAD) K3_TILED_W(T, C, TW + 8 + PAD); \
-        else if (pitch == TW + 10 + PAD) K3_TILED_W(T, C, TW + 10 + PAD); \
-        else if (pitch == TW + 12 + PAD) K3_TILED_W(T, C, TW + 12 + PAD); \
-        else if (pitch == TW + 16 + PAD) K3_TILED_W(T, C, TW + 16 + PAD); \
-        else K3_TILED_W(T, C, TW + 32 + PAD);          \
+        if (pitch == 72 + PAD) K3_TILED_W(T, C, 72 + PAD); \
+        else if (pitch == 74 + PAD) K3_TILED_W(T, C, 74 + PAD); \
+        else if (pitch == 76 + PAD) K3_TILED_W(T, C, 76 + PAD); \
+        else if (pitch == 80 + PAD) K3_TILED_W(T, C, 80 + PAD); \
+        else K3_TILED_W(T, C, 96 + PAD);          \
     } while (0)
         if (A.fuse_compose && whole && !temporal && A.p.textureCount == 2) {
 #define K3_FUSED(P)                                                                                                                      \
@@ -595,16 +585,16 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
         int dev = 0;                                                                                                                     \
         hipGetDevice(&dev);                                                                                                              \
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                                                    \
-            hipFuncSetAttribute((const void *)k3_tiled<false, 2, P, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RFX_K3_LDS_MAX); \
+            hipFuncSetAttribute((const void *)k3_tiled<false, 2, P, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
             if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                                              \
         }                                                                                                                                \
         hipLaunchKernelGGL((k3_tiled<false, 2, P, true, true>), grid, block, lds, stream, A);                                            \
     } while (0)
-            if (pitch == TW + 8 + PAD) K3_FUSED(TW + 8 + PAD);
-            else if (pitch == TW + 10 + PAD) K3_FUSED(TW + 10 + PAD);
-            else if (pitch == TW + 12 + PAD) K3_FUSED(TW + 12 + PAD);
-            else if (pitch == TW + 16 + PAD) K3_FUSED(TW + 16 + PAD);
-            else K3_FUSED(TW + 32 + PAD);
+            if (pitch == 72 + PAD) K3_FUSED(72 + PAD);
+            else if (pitch == 74 + PAD) K3_FUSED(74 + PAD);
+            else if (pitch == 76 + PAD) K3_FUSED(76 + PAD);
+            else if (pitch == 80 + PAD) K3_FUSED(80 + PAD);
+            else K3_FUSED(96 + PAD);
 #undef K3_FUSED
             if (folded) *folded = true;
         } else if (A.p.textureCount == 2) {

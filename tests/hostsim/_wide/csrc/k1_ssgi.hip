@@ -40,9 +40,6 @@ constexpr int K1_WAVES = 8;            // wavefronts per workgroup of the persis
 #ifndef RFX_K1_COUNTERS
 #define RFX_K1_COUNTERS 64  // build knob: tile queues of the persistent march kernel (power of two, <= 64)
 #endif
-#ifndef RFX_K1_XCD_G
-#define RFX_K1_XCD_G 0  // build knob: tile rows per XCD group of the queues' dealing (0 = launch order dealt round-robin); k1_ssgi_march
-#endif
 #ifndef RFX_K1_STATIC_TILES
 #define RFX_K1_STATIC_TILES 0  // build knob: 1 = no counters, wave w takes tiles w, w + nwaves, ... (A/B measurements)
 #endif
@@ -712,51 +709,30 @@ __global__ __launch_bounds__(64 * K1_WAVES) RFX_WAVES_PER_EU(ENV ? 1 : 8) void k
     FrameDims d = A.dims;
     d.viol = 0;
     const int lane = threadIdx.x & 63;
-    const unsigned int nbx = (unsigned int)(A.out_w + 63) / 64u, nby = (unsigned int)(A.y1 - A.y0 + K1_TH - 1) / (unsigned int)K1_TH, ntiles = nbx * nby;
-    // Every wavefront takes tiles from one of K1_COUNTERS device queues; workgroup b serves queue b % K1_COUNTERS (the same-address atomics of the
-    // whole chip are spread over K1_COUNTERS cache lines — one counter for all 8192 waves measured 0.81 ms for the launch, 7 ns per atomic being
-    // the whole difference to the non-persistent kernel).  The next tile's number is requested before this tile's work: the wavefront never waits
-    // for the atomic.  Which tiles a queue holds (k1_tile_of):
-    //   RFX_K1_XCD_G == 0: tiles in launch order dealt round-robin to the queues — every queue holds tiles of every image region, so the
-    //     queues drain together; but hardware workgroup b runs on XCD b % 8, so every XCD marches tiles from all over the frame and each of
-    //     the eight L2s ends up fetching the same view-Z and history lines (FETCH_SIZE 2.8x the algorithmic bytes, profiles/r04_final);
-    //   RFX_K1_XCD_G == G: the eight queues an XCD's workgroups serve share every 8th GROUP of G tile rows, walked row by row and dealt tile
-    //     by tile to the eight — the ~1000 wavefronts resident on an XCD then march one compact band of rows whose rays read neighbouring
-    //     texels, while groups of all image regions stay interleaved over the XCDs (a band per XCD measured slower: XCDs that own sky idle).
+    const unsigned int nbx = (unsigned int)(A.out_w + 63) / 64u, ntiles = nbx * ((unsigned int)(A.y1 - A.y0 + K1_TH - 1) / (unsigned int)K1_TH);
+    // Tiles in launch order, dealt round-robin to K1_COUNTERS queues; workgroup b serves queue b % K1_COUNTERS (hardware workgroup b runs on XCD
+    // b % 8: a queue's counter is bumped from one XCD's share of the waves, and the same-address atomics of the whole chip are spread over
+    // K1_COUNTERS cache lines — one counter for all 8192 waves measured 0.81 ms for the launch, 7 ns per atomic being the whole difference to the
+    // non-persistent kernel).  Every queue holds tiles of every image region, so the queues drain together.  The next tile's number is
+    // requested before this tile's work: the wavefront never waits for the atomic.
     const unsigned int nq = min((unsigned int)K1_COUNTERS, gridDim.x);  // (a small launch has fewer workgroups than queues: every queue needs a server)
     const unsigned int first = blockIdx.x % nq;
     unsigned int *counter = A.tile_counter + first * 32u;  // 128 bytes apart
-    const bool xcd_groups = RFX_K1_XCD_G > 0 && (nq & 7u) == 0u;
-    // n-th tile of this workgroup's queue -> (bx, by); false: the queue is exhausted
-    const auto k1_tile_of = [&](unsigned int n, unsigned int &bx, unsigned int &by) -> bool {
-        if (xcd_groups) {
-            const unsigned int xcd = first & 7u, sub = first >> 3, nsub = nq >> 3, per = (unsigned int)(RFX_K1_XCD_G > 0 ? RFX_K1_XCD_G : 1) * nbx;
-            const unsigned int m = n * nsub + sub, j = m / per, w = m - j * per, r = w / nbx;
-            by = (j * 8u + xcd) * (unsigned int)(RFX_K1_XCD_G > 0 ? RFX_K1_XCD_G : 1) + r;
-            bx = w - r * nbx;
-            if (by < nby) return true;
-            // the last group may be ragged: rows beyond the frame are skipped, later groups of this XCD do not exist
-            return false;
-        }
-        const unsigned int tile = n * nq + first;
-        by = tile / nbx;
-        bx = tile - by * nbx;
-        return tile < ntiles;
-    };
 #if RFX_K1_STATIC_TILES
     const unsigned int nwaves = gridDim.x * (unsigned int)K1_WAVES;
     unsigned int tile = blockIdx.x * (unsigned int)K1_WAVES + (threadIdx.x >> 6);
-    while (tile < ntiles) {
-        const unsigned int by = tile / nbx, bx = tile - by * nbx;
+#define K1_NEXT_TILE(t) ((t) + nwaves)
 #else
-    unsigned int n = 0;
-    if (lane == 0) n = atomicAdd(counter, 1u);
-    n = (unsigned int)__builtin_amdgcn_readfirstlane((int)n);
-    unsigned int bx, by;
-    while (k1_tile_of(n, bx, by)) {
+    unsigned int tile = 0;
+    if (lane == 0) tile = atomicAdd(counter, 1u);
+    tile = (unsigned int)__builtin_amdgcn_readfirstlane((int)tile) * nq + first;
+#endif
+    while (tile < ntiles) {
+#if !RFX_K1_STATIC_TILES
         unsigned int next = 0;
         if (lane == 0) next = atomicAdd(counter, 1u);
 #endif
+        const unsigned int by = tile / nbx, bx = tile - by * nbx;
         const int x = (int)bx * 64 + lane, y0 = A.y0 + (int)by * K1_TH;
 #pragma unroll 1
         for (int r = 0; r < K1_TH; r++) {
@@ -764,9 +740,9 @@ __global__ __launch_bounds__(64 * K1_WAVES) RFX_WAVES_PER_EU(ENV ? 1 : 8) void k
             RFX_WAVE_JOIN();  // background / out-of-frame lanes left the body early: the wavefront is whole again here
         }
 #if RFX_K1_STATIC_TILES
-        tile += nwaves;
+        tile = K1_NEXT_TILE(tile);
 #else
-        n = (unsigned int)__builtin_amdgcn_readfirstlane((int)next);
+        tile = (unsigned int)__builtin_amdgcn_readfirstlane((int)next) * nq + first;
 #endif
     }
     rfx_flush_violations(d);

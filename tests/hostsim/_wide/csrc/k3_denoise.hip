@@ -19,20 +19,10 @@
 
 namespace {
 
-#ifndef RFX_K3_TW
-#define RFX_K3_TW 64  // build knobs: pixels per workgroup tile (a wavefront is 64 consecutive pixels of a row either way)
-#endif
-#ifndef RFX_K3_TH
-#define RFX_K3_TH 8
-#endif
-constexpr int TW = RFX_K3_TW, TH = RFX_K3_TH;  // pixels per workgroup tile
-constexpr int NT = TW * TH;                    // threads per workgroup
-static_assert(TW % 64 == 0 && NT <= 1024, "a tile row is whole wavefronts; at most 16 wavefronts per workgroup");
+constexpr int TW = 64, TH = 8;  // pixels per workgroup tile
+constexpr int NT = TW * TH;     // 512 threads
 #ifndef RFX_K3_XCD_G
-#define RFX_K3_XCD_G 1  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major
-#endif
-#ifndef RFX_K3_LDS_MAX
-#define RFX_K3_LDS_MAX (80 * 1024)  // build knob: dynamic LDS a tiled launch may ask for (80 KiB: two workgroups per CU; 160 KiB is the CU's)
+#define RFX_K3_XCD_G 1  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major.  Measured at 4K (pass 0 / pass 1 ms): 0: 0.248/0.380, 1: 0.244/0.376, 2: 0.245/0.390, 4: 0.255/0.414, 8: 0.266/0.423, 16: 0.288/0.434
 #endif
 // The tile is staged with an apron of (Rx, Ry) texels.  The reference rotates the Poisson offsets in UV space
 // (`rm * (offset / resolution)`, poisson_denoise.frag:183-189), so on a W x H frame a tap lies within
@@ -50,24 +40,8 @@ struct CenterTexel {
     float total;
 };
 
-// ---- build knobs of round 5 (profiles/r05_k3/): both change the last bits of K3's output, not its arithmetic's meaning
-#ifndef RFX_K3_LOG2ACC
-#define RFX_K3_LOG2ACC 0  // 1 = the log-space colours are base-2 logarithms throughout (no `* ln 2` per tap and channel, exp2 at the end)
-#endif
-#ifndef RFX_K3_PAIRS
-#define RFX_K3_PAIRS 0    // 1 = the two textures' accumulators of a pixel laid out as float2 pairs (v_pk_fma / mul / add_f32 across the textures)
-#endif
-// The log-space colour `log(c + 1)` (poisson_denoise.frag:150,193) is carried as log2(c + 1) under RFX_K3_LOG2ACC: the weighted mean of
-// logarithms is linear in them, so the base only matters where the luminance of the log colour enters (k3_luma: lum is linear too,
-// lum(ln) = ln2 * lum(log2), and pow(x, 1/8) = exp2(log2(x) / 8) takes the factor as an added constant) and at the end (exp2 instead of exp).
-constexpr float K3_LN2 = 0.6931471805599453f;
-RFX_DEV float k3_logc(float x) { return RFX_K3_LOG2ACC ? rfx_log2(x) : rfx_log(x); }
-RFX_DEV float k3_unlog(float o) { return (RFX_K3_LOG2ACC ? rfx_exp2(o) : rfx_exp(o)) - 1.0f; }
-RFX_DEV float k3_luma(float3 a) {  // poisson_denoise.frag:28: pow(luminance(a), 1 / 8) of the LOG colour
-    if (RFX_K3_LOG2ACC) return rfx_exp2(__builtin_fmaf(0.125f, rfx_log2(rfx_lum(a)), 0.125f * -0.5287663729448977f));  // + log2(ln 2) / 8
-    return rfx_pow(rfx_lum(a), 0.125f);
-}
-RFX_DEV float3 k3_log3(float x, float y, float z) { return make_float3(k3_logc(x + 1.0f), k3_logc(y + 1.0f), k3_logc(z + 1.0f)); }
+RFX_DEV float k3_luma(float3 a) { return rfx_pow(rfx_lum(a), 0.125f); }  // poisson_denoise.frag:28
+RFX_DEV float3 k3_log3(float x, float y, float z) { return make_float3(rfx_log(x + 1.0f), rfx_log(y + 1.0f), rfx_log(z + 1.0f)); }
 
 // applyWeight poisson_denoise.frag:102-124 on an already log-transformed tap.  The bilateral weight arrives as its base-2
 // LOGARITHM `l2w`: the reference forms w = exp(-a) (getBasicNeighborWeight :52-78) [* exp(-g) for a specular texture], then
@@ -86,39 +60,6 @@ RFX_DEV void k3_apply_d(CenterTexel &c, float l2w, float disocclW, float3 tl, fl
 }
 RFX_DEV void k3_apply(CenterTexel &c, float l2w, float3 tl, float tapLuma, float lumaPhiL2) {
     k3_apply_d(c, l2w, rfx_exp2(0.1f * l2w), tl, tapLuma, lumaPhiL2);
-}
-// ... and for BOTH textures of a pixel at once (RFX_K3_PAIRS): lane .x of every pair is accumulator 0, .y accumulator 1.  The same operations
-// in the same order as k3_apply_d; what can be a packed fp32 instruction (v_pk_add / mul / fma_f32: 4.5 issue cycles for two results against
-// 2 x 2.7, profiles/r03_microbench) is written as one vector operation, the rest (|x|, min, exp2, the threshold select) per lane.
-typedef float rfx_f2 __attribute__((ext_vector_type(2)));
-struct CenterPair {
-    rfx_f2 r, g, b;   // log-space colour accumulators
-    rfx_f2 lumaPow, w, omw, total;  // omw = 1 - w (rfx_mix's first weight)
-};
-RFX_DEV rfx_f2 k3_f2(float a, float b) { rfx_f2 v; v.x = a; v.y = b; return v; }
-RFX_DEV void k3_apply_pair(CenterPair &c, rfx_f2 l2w, rfx_f2 disocclW, rfx_f2 tr, rfx_f2 tg, rfx_f2 tb, rfx_f2 tapLuma, float lumaPhiL2) {
-    const rfx_f2 d = c.lumaPow - tapLuma;
-    const rfx_f2 lumaDiff = k3_f2(fminf(fabsf(d.x), 0.5f), fminf(fabsf(d.y), 0.5f));
-    const rfx_f2 e = l2w - lumaDiff * lumaPhiL2;
-    const rfx_f2 wl = k3_f2(rfx_exp2(e.x), rfx_exp2(e.y));  // w * lumaFactor
-    rfx_f2 w = (wl * c.omw + disocclW * c.w) * c.w;         // rfx_mix(wl, disocclW, c.w) * c.w
-    w = k3_f2((w.x < 0.0001f) ? 0.0f : w.x, (w.y < 0.0001f) ? 0.0f : w.y);  // w *= step(0.0001, w)
-    c.r += tr * w;
-    c.g += tg * w;
-    c.b += tb * w;
-    c.total += w;
-}
-// log(c + 1) and pow(lum(.), 1/8) of a pair of colours (k3_log3 / k3_luma lane by lane)
-RFX_DEV rfx_f2 k3_logc2(rfx_f2 x) {
-    const rfx_f2 x1 = x + 1.0f;
-    const rfx_f2 l = k3_f2(rfx_log2(x1.x), rfx_log2(x1.y));
-    return RFX_K3_LOG2ACC ? l : l * K3_LN2;
-}
-RFX_DEV rfx_f2 k3_luma2(rfx_f2 r, rfx_f2 g, rfx_f2 b) {
-    const rfx_f2 lum = 0.2125f * r + 0.7154f * g + 0.0721f * b;
-    const rfx_f2 l = k3_f2(rfx_log2(lum.x), rfx_log2(lum.y));
-    const rfx_f2 e = RFX_K3_LOG2ACC ? 0.125f * l + (0.125f * -0.5287663729448977f) : 0.125f * l;
-    return k3_f2(rfx_exp2(e.x), rfx_exp2(e.y));
 }
 
 // dynamic LDS carve-up (all 16-byte aligned: the row pitch is a multiple of 8 texels), n = PITCH * LH texels:
@@ -140,8 +81,7 @@ RFX_DEV rfx_f2 k3_luma2(rfx_f2 r, rfx_f2 g, rfx_f2 b) {
 // times the neighbours' difference, far inside the 1e-3 of the parity metric (tests hold folded == unfolded to 2e-4 relative).
 template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE, bool FUSE>
 RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
-    constexpr bool PAIR = RFX_K3_PAIRS && TC == 2;  // the pixel's two accumulators as float2 pairs (k3_apply_pair)
-    extern __shared__ float4 lds[];
+    float4 *lds = (float4 *)hostsim_lds;
     const int Rx = A.tile.Rx, Ry = A.tile.Ry, LW = A.tile.LW, LH = A.tile.LH;
     const int ntex = PITCH * LH;
     float4 *s_geom = lds;
@@ -172,32 +112,16 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         const float3 n = rfx_unpack_normal(g.y);
         s_geom[li] = make_float4(n.x, n.y, n.z, rfx_decode_roughness(g.z));
         s_depth[li] = rfx_gather<float>(depthp, (unsigned int)(__mul24(rfx_view_row<WHOLE>(d, A.depth, gy), d.W) + gx));
-        if constexpr (PAIR && IN_TEMPORAL) {
-            // pass 0, two accumulators: the log-transformed texels the two ACCUMULATORS read (accumulator i reads texture ti(i), :137-165),
-            // interleaved — (x0, x1, y0, y1) (z0, z1, luma0, luma1) — so that a tap's two ds_read_b128 deliver float2 pairs in place
-            float3 l[2];
-            float lu[2];
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const TexView &src = p.isTextureSpecular[i] ? A.in1 : A.in0;
-                const float4 v = rfx_gather<float4>(src.ptr, (unsigned int)(__mul24(rfx_view_row<WHOLE>(d, src, gy), d.W) + gx));
-                l[i] = k3_log3(v.x, v.y, v.z);
-                lu[i] = k3_luma(l[i]);
-            }
-            s_in0[2 * li] = make_float4(l[0].x, l[1].x, l[0].y, l[1].y);
-            s_in0[2 * li + 1] = make_float4(l[0].z, l[1].z, lu[0], lu[1]);
-        } else {
-#pragma unroll
-            for (int t = 0; t < TC; t++) {
-                const TexView &src = t ? A.in1 : A.in0;
-                const unsigned int idx = (unsigned int)(__mul24(rfx_view_row<WHOLE>(d, src, gy), d.W) + gx);
-                if constexpr (IN_TEMPORAL) {
-                    const float4 v = rfx_gather<float4>(src.ptr, idx);
-                    const float3 l = k3_log3(v.x, v.y, v.z);
-                    s_in0[t * ntex + li] = make_float4(l.x, l.y, l.z, k3_luma(l));
-                } else {
-                    s_inN[t * ntex + li] = rfx_gather<uint2>(src.ptr, idx);
-                }
+        for (int t = 0; t < TC; t++) {
+            const TexView &src = t ? A.in1 : A.in0;
+            const unsigned int idx = (unsigned int)(__mul24(rfx_view_row<WHOLE>(d, src, gy), d.W) + gx);
+            if constexpr (IN_TEMPORAL) {
+                const float4 v = rfx_gather<float4>(src.ptr, idx);
+                const float3 l = k3_log3(v.x, v.y, v.z);
+                s_in0[t * ntex + li] = make_float4(l.x, l.y, l.z, k3_luma(l));
+            } else {
+                s_inN[t * ntex + li] = rfx_gather<uint2>(src.ptr, idx);
             }
         }
     }
@@ -300,19 +224,6 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     const float rf = p.radius * flatness;
     const float m00 = rf * co, m01 = rf * -sn, m10 = rf * sn, m11 = rf * co;  // mat2 rm = r*flatness*mat2(c,-s,s,c) :183
 
-    CenterPair cp2;
-    rfx_f2 l2spec2, dspec2;
-    if constexpr (PAIR) {
-        cp2.r = k3_f2(c[0].rgb.x, c[1].rgb.x); cp2.g = k3_f2(c[0].rgb.y, c[1].rgb.y); cp2.b = k3_f2(c[0].rgb.z, c[1].rgb.z);
-        cp2.lumaPow = k3_f2(c[0].lumaPow, c[1].lumaPow);
-        cp2.w = k3_f2(c[0].w, c[1].w);
-        cp2.omw = 1.0f - cp2.w;
-        cp2.total = k3_f2(c[0].total, c[1].total);
-        l2spec2 = k3_f2(l2spec_i[0], l2spec_i[1]);
-        dspec2 = k3_f2(dspec_i[0], dspec_i[1]);
-    }
-    const float4 *g_in01 = s_in0 + 2 * koff;  // (PAIR, pass 0: the interleaved pairs, two float4 per texel)
-
     // no unrolling: occupancy beats ILP here
 #pragma unroll 1
     for (int k = 0; k < 8; k++) {
@@ -336,32 +247,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         float l2basic = (-normalDiff * p.normalPhi - depthDiff * p.depthPhi - roughDiff * p.roughnessPhi) * K3_LOG2E;
         l2basic = (nd != 1.0f) ? l2basic : -__builtin_inff();
         const float dbasic = rfx_exp2(0.1f * l2basic);  // pow(basic weight, 0.1), shared by the textures
-        if constexpr (PAIR) {
-            rfx_f2 tr, tg, tb, tluma;
-            if constexpr (IN_TEMPORAL) {
-                const float4 a = g_in01[2 * ni], b = g_in01[2 * ni + 1];
-                tr = k3_f2(a.x, a.y); tg = k3_f2(a.z, a.w); tb = k3_f2(b.x, b.y); tluma = k3_f2(b.z, b.w);
-            } else {
-                const LinearCoord lx = rfx_linear_coord_fast(fx, xlo, wmh), ly = rfx_linear_coord_fast(fy, ylo, hmh);
-                const int li = __mul24(ly.i0, PITCH) + lx.i0;
-                const uint2 *q0 = g_inN[0] + li, *q1 = g_inN[1] + li;
-                // the sampler's bilinear blend (rfx_bilerp_half_rgb): x-lerps on the half texels per texture, the y-lerp on the pairs
-                const uint2 a00 = q0[0], a10 = q0[1], a01 = q0[PITCH], a11 = q0[PITCH + 1];
-                const uint2 b00 = q1[0], b10 = q1[1], b01 = q1[PITCH], b11 = q1[PITCH + 1];
-                const rfx_f2 r0 = k3_f2(rfx_half_lerp<0>(lx.w, a00.x, a10.x), rfx_half_lerp<0>(lx.w, b00.x, b10.x));
-                const rfx_f2 g0 = k3_f2(rfx_half_lerp<1>(lx.w, a00.x, a10.x), rfx_half_lerp<1>(lx.w, b00.x, b10.x));
-                const rfx_f2 b0 = k3_f2(rfx_half_lerp<0>(lx.w, a00.y, a10.y), rfx_half_lerp<0>(lx.w, b00.y, b10.y));
-                const rfx_f2 r1 = k3_f2(rfx_half_lerp<0>(lx.w, a01.x, a11.x), rfx_half_lerp<0>(lx.w, b01.x, b11.x));
-                const rfx_f2 g1 = k3_f2(rfx_half_lerp<1>(lx.w, a01.x, a11.x), rfx_half_lerp<1>(lx.w, b01.x, b11.x));
-                const rfx_f2 b1 = k3_f2(rfx_half_lerp<0>(lx.w, a01.y, a11.y), rfx_half_lerp<0>(lx.w, b01.y, b11.y));
-                const rfx_f2 wy = k3_f2(ly.w, ly.w);
-                tr = k3_logc2(__builtin_elementwise_fma(wy, r1 - r0, r0));
-                tg = k3_logc2(__builtin_elementwise_fma(wy, g1 - g0, g0));
-                tb = k3_logc2(__builtin_elementwise_fma(wy, b1 - b0, b0));
-                tluma = k3_luma2(tr, tg, tb);
-            }
-            k3_apply_pair(cp2, l2basic + l2spec2, dbasic * dspec2, tr, tg, tb, tluma, lumaPhiL2);
-        } else if constexpr (IN_TEMPORAL) {
+        if constexpr (IN_TEMPORAL) {
 #pragma unroll
             for (int i = 0; i < TC; i++) {
                 const float4 tl = g_in0[i][ni];
@@ -379,13 +265,6 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
             }
         }
     }
-    if constexpr (PAIR) {
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            c[i].rgb = make_float3(cp2.r[i], cp2.g[i], cp2.b[i]);
-            c[i].total = cp2.total[i];
-        }
-    }
 
     const size_t oi = (size_t)(unsigned int)(__mul24(WHOLE ? y : rfx_local_row(d, A.out0.row0, A.out0.rows, y), d.W) + x);
     uint2 stored[TC];
@@ -393,7 +272,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     for (int i = 0; i < TC; i++) {  // outputTexel :94-100
         const float inv = rfx_rcp(c[i].total);
         float3 o = make_float3(c[i].rgb.x * inv, c[i].rgb.y * inv, c[i].rgb.z * inv);
-        o = make_float3(k3_unlog(o.x), k3_unlog(o.y), k3_unlog(o.z));
+        o = make_float3(rfx_exp(o.x) - 1.0f, rfx_exp(o.y) - 1.0f, rfx_exp(o.z) - 1.0f);
         stored[i] = rfx_store_half4(o.x, o.y, o.z, c[i].a, p.halfStoreRTZ != 0);
         ((uint2 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = stored[i];
     }
@@ -496,7 +375,7 @@ RFX_DEV void k3_generic_body(const K3Args &A, const FrameDims &d) {
 #pragma unroll
     for (int i = 0; i < TC; i++) {
         float3 o = make_float3(c[i].rgb.x / c[i].total, c[i].rgb.y / c[i].total, c[i].rgb.z / c[i].total);
-        o = make_float3(k3_unlog(o.x), k3_unlog(o.y), k3_unlog(o.z));
+        o = make_float3(rfx_exp(o.x) - 1.0f, rfx_exp(o.y) - 1.0f, rfx_exp(o.z) - 1.0f);
         ((uint2 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = rfx_store_half4(o.x, o.y, o.z, c[i].a, p.halfStoreRTZ != 0);
     }
 }
@@ -556,10 +435,10 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
 #define RFX_K3_PAD 0  // build knob: extra texels per LDS row (bank-mapping experiments, profiles/r04_k3/)
 #endif
     constexpr int PAD = RFX_K3_PAD;
-    const int pitch = A.tile.LW <= TW + 8 ? TW + 8 + PAD : A.tile.LW <= TW + 10 ? TW + 10 + PAD : A.tile.LW <= TW + 12 ? TW + 12 + PAD : A.tile.LW <= TW + 16 ? TW + 16 + PAD : A.tile.LW <= TW + 32 ? TW + 32 + PAD : 0;
+    const int pitch = A.tile.LW <= 72 ? 72 + PAD : A.tile.LW <= 74 ? 74 + PAD : A.tile.LW <= 76 ? 76 + PAD : A.tile.LW <= 80 ? 80 + PAD : A.tile.LW <= 96 ? 96 + PAD : 0;
     const size_t lds = (size_t)pitch * A.tile.LH * (16 + 4 + 2 * (temporal ? 16 : 8));
-    // at least two workgroups per CU (160 KiB LDS) keep the staging of one tile under the arithmetic of another
-    const bool tiled = A.p.radius >= 0.0f && pitch != 0 && lds <= RFX_K3_LDS_MAX;
+    // two workgroups per CU (160 KiB LDS) keep the staging of one tile under the arithmetic of another
+    const bool tiled = A.p.radius >= 0.0f && pitch != 0 && lds <= 80 * 1024;
     // every view the whole frame (a context that owns no row tile): the kernels skip row rebasing and halo accounting
     const auto whole_view = [&](const void *ptr, int row0, int rows) { return ptr == nullptr || (row0 == 0 && rows == A.dims.H); };
     const bool whole = whole_view(A.depth.ptr, A.depth.row0, A.depth.rows) && whole_view(A.gbuffer.ptr, A.gbuffer.row0, A.gbuffer.rows) &&
@@ -574,7 +453,7 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
         int dev = 0;                                                                                                         \
         hipGetDevice(&dev);                                                                                                  \
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                                        \
-            hipFuncSetAttribute((const void *)k3_tiled<T, C, P, WH>, hipFuncAttributeMaxDynamicSharedMemorySize, RFX_K3_LDS_MAX); \
+            hipFuncSetAttribute((const void *)k3_tiled<T, C, P, WH>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
             if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                                  \
         }                                                                                                                    \
         hipLaunchKernelGGL((k3_tiled<T, C, P, WH>), grid, block, lds, stream, A);                                            \
@@ -582,11 +461,11 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
 #define K3_TILED_W(T, C, P) do { if (whole) K3_TILED(T, C, P, true); else K3_TILED(T, C, P, false); } while (0)
 #define K3_TILED_P(T, C)                    \
     do {                                    \
-        if (pitch == TW + 8 + PAD) K3_TILED_W(T, C, TW + 8 + PAD); \
-        else if (pitch == TW + 10 + PAD) K3_TILED_W(T, C, TW + 10 + PAD); \
-        else if (pitch == TW + 12 + PAD) K3_TILED_W(T, C, TW + 12 + PAD); \
-        else if (pitch == TW + 16 + PAD) K3_TILED_W(T, C, TW + 16 + PAD); \
-        else K3_TILED_W(T, C, TW + 32 + PAD);          \
+        if (pitch == 72 + PAD) K3_TILED_W(T, C, 72 + PAD); \
+        else if (pitch == 74 + PAD) K3_TILED_W(T, C, 74 + PAD); \
+        else if (pitch == 76 + PAD) K3_TILED_W(T, C, 76 + PAD); \
+        else if (pitch == 80 + PAD) K3_TILED_W(T, C, 80 + PAD); \
+        else K3_TILED_W(T, C, 96 + PAD);          \
     } while (0)
         if (A.fuse_compose && whole && !temporal && A.p.textureCount == 2) {
 #define K3_FUSED(P)                                                                                                                      \
@@ -595,16 +474,16 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
         int dev = 0;                                                                                                                     \
         hipGetDevice(&dev);                                                                                                              \
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                                                    \
-            hipFuncSetAttribute((const void *)k3_tiled<false, 2, P, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RFX_K3_LDS_MAX); \
+            hipFuncSetAttribute((const void *)k3_tiled<false, 2, P, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); \
             if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                                              \
         }                                                                                                                                \
         hipLaunchKernelGGL((k3_tiled<false, 2, P, true, true>), grid, block, lds, stream, A);                                            \
     } while (0)
-            if (pitch == TW + 8 + PAD) K3_FUSED(TW + 8 + PAD);
-            else if (pitch == TW + 10 + PAD) K3_FUSED(TW + 10 + PAD);
-            else if (pitch == TW + 12 + PAD) K3_FUSED(TW + 12 + PAD);
-            else if (pitch == TW + 16 + PAD) K3_FUSED(TW + 16 + PAD);
-            else K3_FUSED(TW + 32 + PAD);
+            if (pitch == 72 + PAD) K3_FUSED(72 + PAD);
+            else if (pitch == 74 + PAD) K3_FUSED(74 + PAD);
+            else if (pitch == 76 + PAD) K3_FUSED(76 + PAD);
+            else if (pitch == 80 + PAD) K3_FUSED(80 + PAD);
+            else K3_FUSED(96 + PAD);
 #undef K3_FUSED
             if (folded) *folded = true;
         } else if (A.p.textureCount == 2) {
