@@ -21,8 +21,11 @@ Timing: `--spinup` untimed frames first (default 200 = 0.3 s: the device sat idl
 milliseconds run below the sustained clock — with --steps 20 --warmup 5 alone the step measured 1.556 ms against 1.51 sustained), then the W
 untimed warm-up steps, then EXACTLY K timed steps between barriers and device synchronisation, max over ranks.  The line says `spinup_frames`.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (largest share of the step), its launches timed live with hipEvents
-on the stream the kernels run on, next to a device-to-device stream-copy rate measured in the same process; `issue_model` is, per kernel, the
+Prints ONE JSON line (rank 0).  `kernel_ms` are the per-draw durations INSIDE the frame loop (rfx_profile: hipEvents around every draw's
+launches on the stream they run on, over K more frames after the timed region — they sum to `ms_per_step`; K1's depth pre-pass runs on
+its own stream under the previous frame's later draws and is listed beside them); `roofline` is for the dominant kernel — K1, whose 68 B/px
+include the depth plane its pre-pass reads, so its duration there is march + pre-pass — next to a device-to-device stream-copy rate measured
+in the same process; `issue_model` is, per kernel, the
 absolute time its measured instruction mix costs to issue next to the time it took (rocprofv3 counters of this same command, committed under
 PROFILE_DIR; tools/issue_model.py) — the bound that actually binds; `ms_per_step_cold` is the same W + K protocol before the spin-up;
 `cpu_baseline` is the REFERENCE's own GLSL on Mesa llvmpipe on this box's host cores over the same frame (kind "reference"), with the C
@@ -64,6 +67,8 @@ def _is_kernel(key, name):
     return all(f in name for f in PMC_KERNEL[key])
 
 
+TRAFFIC_NOTE = ("fabric-side bytes per launch from %s/pmc_hbm.csv (separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this bench command at 4K, "
+                "tools/collect_profiles.sh; collected at git %s): (FETCH_SIZE x calibration + WRITE_SIZE) x 1024, calibration per kernel in pmc_traffic()")
 PROFILE_DIR = "profiles/r04_final"  # the committed rocprofv3 collection (tools/collect_profiles.sh) the counter-derived figures are read from
 
 
@@ -247,7 +252,7 @@ def verify_exchange(ctx, rank, world):
     return err
 
 
-def time_case(case, dist, n_steps, n_warmup, dev="cpu", spinup=0, cold=False):
+def time_case(case, dist, n_steps, n_warmup, dev="cpu", spinup=0, cold=False, first_frame=True):
     """W untimed steps, then exactly K timed steps between barriers + device synchronisation; max over ranks.
     `spinup`: untimed frames BEFORE the W warm-up steps — the device sat idle through ~20 s of dump generation and set-up, and the
     first tens of milliseconds after that run below the sustained clock (same frames, same work; measured with the driver's --steps 20
@@ -279,7 +284,8 @@ def time_case(case, dist, n_steps, n_warmup, dev="cpu", spinup=0, cold=False):
             dt = float(t.item())
         return dt
 
-    fx.update(renderer, None)  # first frame: uploads the dump (not timed), keepData = 0
+    if first_frame:
+        fx.update(renderer, None)  # first frame: uploads the dump (not timed), keepData = 0
     dt_cold = None
     if cold:  # the driver's own W + K protocol straight after the idle set-up phase, BEFORE any spin-up: reported beside the sustained figure
         for _ in range(n_warmup):
@@ -326,6 +332,24 @@ def kernel_times(case, iters):
     return kms, folded
 
 
+def kernel_times_in_frame(case, n_frames):
+    """Per-draw durations INSIDE the frame loop, as a frame executes them: rfx_profile brackets every draw's launches with hipEvents on the stream
+    they run on.  -> ({kernel key: ms per launch}, K1's depth pre-pass ms per frame — its own stream, under the previous frame's later draws)"""
+    ctx, renderer, fx = case["ctx"], case["renderer"], case["fx"]
+    for _ in range(3):
+        fx.update(renderer, None)
+    ctx.profile(True)
+    for _ in range(n_frames):
+        fx.update(renderer, None)
+    got = ctx.profile_read()
+    ctx.profile(False)
+    names = {"k1_ssgi_march": "k1_ssgi_march", "k2_temporal_reproject": "k2_temporal_reproject", "k3_poisson_denoise_pass0": "k3_poisson_denoise_pass0",
+             "k3_poisson_denoise_passN": "k3_poisson_denoise_pass1", "k4_compose": "k4_compose", "k3_passN_plus_k4_folded": "k3_pass1_plus_k4_folded"}
+    kms = {names[k]: ms / n for k, (ms, n) in got.items() if k in names}
+    pre = got.get("k1_prepass")
+    return kms, (pre[0] / pre[1] if pre else None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,10 +364,10 @@ def main():
     ap.add_argument("--cpu-port", action="store_true", help="(default since round 4) also time the C restatement (OpenMP) as a second, non-GL CPU line")
     ap.add_argument("--no-cpu-port", action="store_true", help="skip the C restatement's CPU line (~10 s)")
     ap.add_argument("--no-cold", action="store_true", help="skip the un-spun-up measurement (ms_per_step_cold)")
-    ap.add_argument("--checksum", action="store_true", help="add sha1 of the final whole-frame composed GI to the JSON line (tiled == single check; at N = 1 "
-                    "implies --no-compose-fold: a row tile makes one launch per draw, and the comparison is with the whole-frame context doing the same)")
-    ap.add_argument("--no-compose-fold", action="store_true", help="N = 1: one launch per draw (rfx_set_compose_fold(0)) instead of the last denoise draw and the compose "
-                    "draw in one launch")
+    ap.add_argument("--checksum", action="store_true", help="add sha1 of the final whole-frame composed GI to the JSON line (tiled == single check)")
+    ap.add_argument("--compose-fold", action="store_true", help="N = 1: time the OPT-IN one-launch form of the last denoise draw + the compose draw (rfx_set_compose_fold(1): "
+                    "an approximation, include/rfx.h) as the headline instead of reporting it beside it; never with --checksum")
+    ap.add_argument("--no-compose-fold", action="store_true", help="(the default since round 5; accepted for old command lines)")
     ap.add_argument("--exchange", choices=("c", "torch"), default="c", help="N > 1: exchanges through the C ABI's RCCL entry points (default) or torch.distributed")
     ap.add_argument("--extras-timeout", type=int, default=480, help="seconds the N > 1 extras (weak scaling, configs[4]) may take before the headline line is printed without them")
     ap.add_argument("--configs4-size", default="7680x4320", help="N > 1 extras: frame of the BASELINE configs[4] case (tests shrink it)")
@@ -417,8 +441,9 @@ def main():
     group, fallback_note = None, None
     try:
         case = build_case(world, rank, local_rank, dev, dist, one_gpu, W1, H1, tiles, 20, 5, 1, use_c=use_c)
-        if world == 1 and (args.no_compose_fold or args.checksum):
-            case["ctx"].set_compose_fold(False)
+        fold_headline = bool(world == 1 and args.compose_fold and not args.checksum)
+        if fold_headline:
+            case["ctx"].set_compose_fold(True)
     except RuntimeError as e:
         if not (use_c and "pre-flight" in str(e)):
             raise
@@ -453,7 +478,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         history = {"mode": mode, "MB_received_per_frame_max_over_ranks": round(float(t.item()) / 1e6, 3),
                    "whole_frame_allgather_MB": round((H1 - min(n for _, n in tiles)) * W1 * 12 / 1e6, 3)}
-    kms, pair_ms = kernel_times(case, max(5, min(args.steps, 20)))
+    kms_solo, _pair = kernel_times(case, max(5, min(args.steps, 20)))
+    kms, prepass_ms = kernel_times_in_frame(case, args.steps)
+    # the OPT-IN fold beside the headline (or the default beside it when the fold IS the headline): the same K timed frames, the other setting
+    other_ms = None
+    if world == 1 and not args.checksum:
+        ctx.set_compose_fold(not fold_headline)
+        other_ms = time_case(case, None, args.steps, args.warmup, dev, spinup=0, cold=False, first_frame=False)[0] / args.steps * 1e3
+        ctx.set_compose_fold(fold_headline)
     rows, halo = case["rows"], case["halo"]
     copy_gbs = stream_copy_gbs(dev) if (rank == 0 and not args.no_stream_copy) else None  # measured here, after the timed region
 
@@ -463,11 +495,18 @@ def main():
         if rank != 0:
             return
         px_tile = W1 * rows
-        dom = max(kms, key=kms.get)
-        achieved = BYTES_PER_PX[dom] * px_tile / (kms[dom] * 1e-3) / 1e9
-        chain_bytes = sum(BYTES_PER_PX[k] for k in kms)
+        # bytes per pixel of what a launch executes (the folded launch = later pass + compose)
+        bpp = dict(BYTES_PER_PX, k3_pass1_plus_k4_folded=BYTES_PER_PX["k3_poisson_denoise_pass1"] + BYTES_PER_PX["k4_compose"] - 36)
+        # K1's 68 B/px include the depth plane, which its PRE-PASS reads (k1_prepare + k1_pack_cells, own stream): its roofline duration is both
+        dur = dict(kms)
+        if prepass_ms is not None and "k1_ssgi_march" in dur:
+            dur["k1_ssgi_march"] += prepass_ms
+        dom = max(dur, key=dur.get)
+        achieved = bpp[dom] * px_tile / (dur[dom] * 1e-3) / 1e9
+        chain_bytes = sum(bpp[k] for k in kms)
         chain_ms = sum(kms.values())
-        ns_ms = chain_ms - kms["k4_compose"]  # the north-star quantity: K1 + K2 + 2 x K3 (268 B/px)
+        k4_ms = kms.get("k4_compose", 0.0)
+        ns_ms = chain_ms - k4_ms if "k4_compose" in kms else None  # the north-star quantity: K1 + K2 + 2 x K3 (268 B/px)
         ns_bytes = chain_bytes - BYTES_PER_PX["k4_compose"]
         prof = profile_meta()
         workload = ("configs[2]: %dx%d (%.2f Mpixel) on one GPU" % (W1, H1, W1 * H1 / 1e6) if world == 1 else
@@ -483,26 +522,32 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload + ", steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step",
                        "frame": "%dx%d" % (W1, H1), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz", "uv_model": "reference_gl",
-                       "compose_fold": bool(world == 1 and not (args.no_compose_fold or args.checksum)),
+                       "compose_fold": fold_headline,
                        "parallelism": "row-tiles x%d, RCCL halo send/recv after K2 and every K3 pass + composed GI (see history_exchange); exchange: %s" % (
                            world, case_exchange(use_c, one_gpu, args)) if world > 1 else "single GPU"},
+            # per-draw durations INSIDE the frame loop (rfx_profile: events around every draw on its stream, K more frames after the timed region)
             "kernel_ms": {k: round(v, 4) for k, v in kms.items()},
-            # the last denoise draw + the compose draw as a frame issues them: ONE launch on a whole-frame context (the library folds the compose
-            # draw into the denoise launch), two on a row tile
-            "k3_pass1_plus_k4_as_issued_ms": round(pair_ms, 4),
+            "k1_prepass_ms": round(prepass_ms, 4) if prepass_ms is not None else None,
+            # ... and every kernel timed on its own (back-to-back launches of the same entry point), as rounds 1-4 reported them
+            "kernel_ms_solo": {k: round(v, 4) for k, v in kms_solo.items()},
+            # the same K frames with the other setting of rfx_set_compose_fold (the OPT-IN one-launch form of the last denoise draw + the compose
+            # draw, an approximation: include/rfx.h; or, under --compose-fold, the default)
+            ("ms_per_step_default_two_launches" if fold_headline else "ms_per_step_compose_fold_opt_in"): round(other_ms, 4) if other_ms else None,
             "chain": {"algorithmic_bytes_per_px": chain_bytes, "sum_kernel_ms": round(chain_ms, 4),
                       "achieved_GBs": round(chain_bytes * px_tile / (chain_ms * 1e-3) / 1e9, 1),
                       "frac_of_peak": round(chain_bytes * px_tile / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            "north_star_chain": {"kernels": "K1+K2+2xK3", "algorithmic_bytes_per_px": ns_bytes, "sum_kernel_ms": round(ns_ms, 4),
-                                 "achieved_GBs": round(ns_bytes * px_tile / (ns_ms * 1e-3) / 1e9, 1),
-                                 "frac_of_peak": round(ns_bytes * px_tile / (ns_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "target_frac": 0.70},
+            "north_star_chain": ({"kernels": "K1+K2+2xK3", "algorithmic_bytes_per_px": ns_bytes, "sum_kernel_ms": round(ns_ms, 4),
+                                  "achieved_GBs": round(ns_bytes * px_tile / (ns_ms * 1e-3) / 1e9, 1),
+                                  "frac_of_peak": round(ns_bytes * px_tile / (ns_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "target_frac": 0.70} if ns_ms else None),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "stream_copy_GBs": copy_gbs,
                          "frac_of_stream_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                          "traffic": pmc_traffic(dom) if (W1, rows) == (W4K, H4K) else None,
-                         "traffic_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 from %s/pmc_hbm.csv (separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this bench command at 4K, tools/collect_profiles.sh; collected at git %s)" % (
-                             PROFILE_DIR, prof.get("git_commit", "?")),
-                         "algorithmic_bytes_per_launch": BYTES_PER_PX[dom] * px_tile, "avg_launch_ms": round(kms[dom], 4)},
+                         "traffic_note": TRAFFIC_NOTE % (PROFILE_DIR, prof.get("git_commit", "?")),
+                         "algorithmic_bytes_per_launch": bpp[dom] * px_tile, "avg_launch_ms": round(dur[dom], 4),
+                         "avg_launch_ms_note": ("in-frame duration, rfx_profile" + (
+                             ": march %.4f + depth pre-pass %.4f ms (the pre-pass reads the depth plane that is part of K1's 68 B/px; it runs on its own "
+                             "stream under the previous frame's later draws)" % (kms["k1_ssgi_march"], prepass_ms) if dom == "k1_ssgi_march" and prepass_ms is not None else ""))},
             "halo_violations": viol,
         }
         # what binds: instruction issue.  Per kernel, the ABSOLUTE time its measured dynamic instruction mix costs to issue
@@ -514,10 +559,10 @@ def main():
                 out["issue_model"] = dict(im, note="per kernel: predicted_issue_ms = sum(class count x measured issue cycles) x waves per SIMD / clock; measured_ms = the kernel's "
                                                    "average duration in the same rocprofv3 collection — %s/{pmc_sq_l2.csv, kernel_stats.csv, issue_model.txt} (collected at git %s)" % (
                                                        PROFILE_DIR, prof.get("git_commit", "?")))
-        out["kernel_ms_note"] = ("kernel_ms: every kernel timed on its own (hipEvents, back-to-back launches of the same kernel); inside a frame K1's depth pre-pass "
-                                 "(k1_prepare + k1_pack_cells, its own stream) runs under the previous frame's K2-K4, so a kernel trace of whole frames shows those "
-                                 "three a few percent longer and K1 shorter; and on one GPU a frame makes the last denoise draw and the compose draw in one launch "
-                                 "(k3_pass1_plus_k4_as_issued_ms, in a kernel trace k3_tiled<false, 2, 80, true, true>) — so sum_kernel_ms exceeds ms_per_step")
+        out["kernel_ms_note"] = ("kernel_ms: per-draw durations inside the frame loop (hipEvents around every draw's launches, rfx_profile) — they sum to ms_per_step up to the "
+                                 "events' own few microseconds; K1's depth pre-pass (k1_prepass_ms) runs on its own stream under the previous frame's K2-K4 and is not "
+                                 "in that sum.  kernel_ms_solo: every kernel timed on its own, back-to-back launches of one entry point (K1 then serialises with its own "
+                                 "pre-pass: longer than in a frame; K2-K4 run without a pre-pass beside them: shorter)")
         if world > 1:
             out["config"]["exchange_verified"] = bool(use_c)  # the C-ABI exchanges passed their pre-flight pattern check on every rank
             out["config"]["history_exchange"] = history

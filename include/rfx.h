@@ -382,6 +382,15 @@ unsigned int rfx_halo_violations(rfx_ctx *);
  * stream and return the mean milliseconds (used by bench.py for the roofline line). */
 int rfx_time_begin(rfx_ctx *);
 int rfx_time_end(rfx_ctx *, float *elapsed_ms);
+/* Per-draw device timing INSIDE a frame loop (ABI 18; bench.py's `kernel_ms` and `roofline`).  rfx_profile(ctx, 1) resets the sums and makes every
+ * draw entry point bracket the launches it makes with two hipEvents on the stream they run on (K1's depth pre-pass on its own stream, where it
+ * overlaps the previous frame's later draws); rfx_profile(ctx, 0) stops.  rfx_profile_read waits for the recorded events and returns, per kind,
+ * the summed milliseconds and the number of launches since the reset (arrays of RFX_PROF_COUNT entries; either may be NULL).  The events cost
+ * a few microseconds per draw: the frame's own time (`value`) is measured without them.  At most 8192 launches are recorded per reset. */
+enum { RFX_PROF_K1_PREPASS = 0, RFX_PROF_K1_MARCH, RFX_PROF_K2, RFX_PROF_K3_PASS0, RFX_PROF_K3_PASSN, RFX_PROF_K3_PASSN_PLUS_K4, RFX_PROF_K4, RFX_PROF_K5,
+       RFX_PROF_COUNT };
+int rfx_profile(rfx_ctx *, int enable);
+int rfx_profile_read(rfx_ctx *, float *ms_sum, int *launches);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,34 @@ thread_local std::string g_create_err;
         const int rc__ = rfx_internal_flush(c); \
         if (rc__) return rc__;               \
     } while (0)
+// rfx_profile: bracket the launches of one draw with two events on `stream` (no-ops unless profiling is on)
+static hipEvent_t prof_event(rfx_ctx *c) {
+    hipEvent_t e = nullptr;
+    if (!c->prof_free.empty()) { e = c->prof_free.back(); c->prof_free.pop_back(); return e; }
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
+static void prof_recycle(rfx_ctx *c) {
+    for (const rfx_ctx::ProfRec &r : c->prof_recs) { c->prof_free.push_back(r.a); c->prof_free.push_back(r.b); }
+    c->prof_recs.clear();
+}
+struct ProfScope {
+    rfx_ctx *c;
+    hipStream_t stream;
+    hipEvent_t a = nullptr, b = nullptr;
+    int kind;
+    ProfScope(rfx_ctx *c_, int kind_, hipStream_t s) : c(c_), stream(s), kind(kind_) {
+        if (!c->profiling || c->prof_recs.size() >= 8192) return;
+        a = prof_event(c); b = prof_event(c);
+        if (!a || !b) { if (a) c->prof_free.push_back(a); if (b) c->prof_free.push_back(b); a = b = nullptr; return; }
+        hipEventRecord(a, stream);
+    }
+    void set_kind(int k) { kind = k; }
+    ~ProfScope() {
+        if (!a) return;
+        hipEventRecord(b, stream);
+        c->prof_recs.push_back({kind, a, b});
+    }
+};
 #ifndef RFX_FOLD_COMPOSE
 #define RFX_FOLD_COMPOSE 1  // build knob: 0 = never hold a denoise draw for its compose draw (A/B measurements)
 #endif
@@ -30,6 +58,7 @@ unsigned int rfx_internal_folded_draws(const rfx_ctx *c) { return c ? c->folded_
 int rfx_internal_flush(rfx_ctx *c) {
     if (!c->k3_held) return RFX_OK;
     c->k3_held = false;
+    ProfScope prof(c, RFX_PROF_K3_PASSN, c->stream);
     HIPCHK(c, rfx_launch_k3(*c->k3_held_args, c->stream));
     return RFX_OK;
 }
@@ -128,6 +157,8 @@ void rfx_destroy(rfx_ctx *c) {
     if (c->env) hipFree(c->env);
     if (c->env_marginal) hipFree(c->env_marginal);
     if (c->env_conditional) hipFree(c->env_conditional);
+    prof_recycle(c);
+    for (hipEvent_t e : c->prof_free) hipEventDestroy(e);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -700,18 +731,25 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
 #define RFX_K1_PREP_STREAM 1  // build knob: 0 = the pre-pass in the draw stream (A/B measurements)
 #endif
         if (c->depth_external || !RFX_K1_PREP_STREAM) {
+            ProfScope prof(c, RFX_PROF_K1_PREPASS, c->stream);
             HIPCHK(c, rfx_launch_k1_prepare(A, c->stream));
         } else {
             if (c->depth_event_set) HIPCHK(c, hipStreamWaitEvent(c->prep_stream, c->ev_depth, 0));
             if (c->k1_event_set) HIPCHK(c, hipStreamWaitEvent(c->prep_stream, c->ev_k1_done, 0));
-            HIPCHK(c, rfx_launch_k1_prepare(A, c->prep_stream));
+            {
+                ProfScope prof(c, RFX_PROF_K1_PREPASS, c->prep_stream);
+                HIPCHK(c, rfx_launch_k1_prepare(A, c->prep_stream));
+            }
             HIPCHK(c, hipEventRecord(c->ev_prep_done, c->prep_stream));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_prep_done, 0));
         }
     }
     // the march kernel hands its tiles out from a counter: the pre-pass zeroes it; the shade stage has no pre-pass of its own
     if (any && stage == 2) HIPCHK(c, hipMemsetAsync(c->k1_tiles, 0, 64 * 128, c->stream));
-    if (any) HIPCHK(c, rfx_launch_k1(A, stage, c->stream));
+    if (any) {
+        ProfScope prof(c, RFX_PROF_K1_MARCH, c->stream);
+        HIPCHK(c, rfx_launch_k1(A, stage, c->stream));
+    }
     HIPCHK(c, hipEventRecord(c->ev_k1_done, c->stream));  // the next pre-pass overwrites what this launch reads
     c->k1_event_set = true;
     c->hits_traced = stage == 1;
@@ -835,6 +873,7 @@ int rfx_temporal_reproject(rfx_ctx *c, const rfx_temporal_params *p) {
             volatile float t3 = Pm[3 * 4 + row] * Vm[col * 4 + 3]; acc = acc + t3;
             A.prevPV[col * 4 + row] = acc;
         }
+    ProfScope prof(c, RFX_PROF_K2, c->stream);
     HIPCHK(c, rfx_launch_k2(A, c->stream));
     return RFX_OK;
 }
@@ -893,6 +932,7 @@ int rfx_poisson_denoise(rfx_ctx *c, const rfx_denoise_params *p) {
         c->k3_held = true;
         return RFX_OK;
     }
+    ProfScope prof(c, p->inputIsTemporal ? RFX_PROF_K3_PASS0 : RFX_PROF_K3_PASSN, c->stream);
     HIPCHK(c, rfx_launch_k3(A, c->stream));
     return RFX_OK;
 }
@@ -940,13 +980,20 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
             K.cout = A.out;
             K.rgb_out = A.rgb_out;
         }
-        HIPCHK(c, rfx_launch_k3(K, c->stream, &folded));
+        {
+            ProfScope prof(c, RFX_PROF_K3_PASSN, c->stream);
+            HIPCHK(c, rfx_launch_k3(K, c->stream, &folded));
+            if (folded) prof.set_kind(RFX_PROF_K3_PASSN_PLUS_K4);
+        }
         if (folded) {
             c->folded_draws++;
             return RFX_OK;
         }
     }
-    if (any) HIPCHK(c, rfx_launch_k4(A, c->stream));
+    if (any) {
+        ProfScope prof(c, RFX_PROF_K4, c->stream);
+        HIPCHK(c, rfx_launch_k4(A, c->stream));
+    }
     return RFX_OK;
 }
 
@@ -965,6 +1012,7 @@ int rfx_final_compose(rfx_ctx *c, const rfx_final_params *p) {
     A.depth = view(c, RFX_TEX_DEPTH); A.gi = view(c, src); A.scene = view(c, RFX_TEX_DIRECT_LIGHT);
     A.out = wview(c, RFX_TEX_FINAL);
     A.p = *p;
+    ProfScope prof(c, RFX_PROF_K5, c->stream);
     HIPCHK(c, rfx_launch_k5(A, c->stream));
     return RFX_OK;
 }
@@ -988,6 +1036,37 @@ int rfx_time_end(rfx_ctx *c, float *elapsed_ms) {
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
     HIPCHK(c, hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    return RFX_OK;
+}
+
+int rfx_profile(rfx_ctx *c, int enable) {
+    if (!c) return RFX_EINVAL;
+    RFX_ENTER(c);
+    if (enable) {  // events of an earlier run may still be pending: let them execute before they are recorded again
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->prep_stream) HIPCHK(c, hipStreamSynchronize(c->prep_stream));
+        prof_recycle(c);
+    }
+    c->profiling = enable != 0;
+    return RFX_OK;
+}
+int rfx_profile_read(rfx_ctx *c, float *ms_sum, int *launches) {
+    if (!c) return RFX_EINVAL;
+    RFX_ENTER(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->prep_stream) HIPCHK(c, hipStreamSynchronize(c->prep_stream));
+    float ms[RFX_PROF_COUNT] = {0};
+    int n[RFX_PROF_COUNT] = {0};
+    for (const rfx_ctx::ProfRec &r : c->prof_recs) {
+        float t = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.kind] += t;
+        n[r.kind]++;
+    }
+    for (int i = 0; i < RFX_PROF_COUNT; i++) {
+        if (ms_sum) ms_sum[i] = ms[i];
+        if (launches) launches[i] = n[i];
+    }
     return RFX_OK;
 }
 

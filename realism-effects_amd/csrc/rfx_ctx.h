@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 #include "../../include/rfx.h"
 
 struct Slot {
@@ -78,6 +79,11 @@ struct rfx_ctx {
     bool fold_compose = false;  // rfx_set_compose_fold
     struct K3Args *k3_held_args = nullptr;
     unsigned int folded_draws = 0;  // compose draws made inside a denoise launch so far
+    // rfx_profile: event pairs around the launches of every draw since the last reset (kind, start, stop), and the events free for re-use
+    struct ProfRec { int kind; hipEvent_t a, b; };
+    bool profiling = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_free;
     std::string err;
 };
 // rfx_api.hip: launch the held draw, if any (every entry point that takes a context starts with it)

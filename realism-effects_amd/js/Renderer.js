@@ -207,6 +207,13 @@ class Renderer {
 	haloViolations() {
 		return addon.haloViolations(this._h)
 	}
+	// per-draw device timing inside a frame loop (rfx_profile / rfx_profile_read): { ms: [...], launches: [...] } indexed by RFX_PROF_* of include/rfx.h
+	profile(enable) {
+		addon.profile(this._h, enable ? 1 : 0)
+	}
+	profileRead() {
+		return addon.profileRead(this._h)
+	}
 	timeBegin() {
 		addon.timeBegin(this._h)
 	}

@@ -695,11 +695,47 @@ static napi_value n_time_end(napi_env env, napi_callback_info info) {
     return out;
 }
 
+/* profile(ctx, enable) / profileRead(ctx) -> { ms: Float64Array(RFX_PROF_COUNT), launches: Int32Array-like array } (rfx_profile, rfx_profile_read) */
+static napi_value n_profile(napi_env env, napi_callback_info info) {
+    napi_value a[2];
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    int32_t on = 0;
+    NAPI_CALL(env, napi_get_value_int32(env, a[1], &on));
+    int rc = rfx_profile(c, on);
+    if (rc) return throw_rfx(env, c, "rfx_profile", rc);
+    return NULL;
+}
+static napi_value n_profile_read(napi_env env, napi_callback_info info) {
+    napi_value a[1], out, ms_arr, n_arr;
+    if (!get_args(env, info, 1, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    float ms[RFX_PROF_COUNT];
+    int n[RFX_PROF_COUNT];
+    int rc = rfx_profile_read(c, ms, n);
+    if (rc) return throw_rfx(env, c, "rfx_profile_read", rc);
+    NAPI_CALL(env, napi_create_object(env, &out));
+    NAPI_CALL(env, napi_create_array_with_length(env, RFX_PROF_COUNT, &ms_arr));
+    NAPI_CALL(env, napi_create_array_with_length(env, RFX_PROF_COUNT, &n_arr));
+    for (uint32_t i = 0; i < RFX_PROF_COUNT; i++) {
+        napi_value v;
+        NAPI_CALL(env, napi_create_double(env, ms[i], &v));
+        NAPI_CALL(env, napi_set_element(env, ms_arr, i, v));
+        NAPI_CALL(env, napi_create_int32(env, n[i], &v));
+        NAPI_CALL(env, napi_set_element(env, n_arr, i, v));
+    }
+    NAPI_CALL(env, napi_set_named_property(env, out, "ms", ms_arr));
+    NAPI_CALL(env, napi_set_named_property(env, out, "launches", n_arr));
+    return out;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
         {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"setEnvironmentImportance", n_set_environment_importance}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"ssgiTrace", n_ssgi_trace}, {"ssgiShade", n_ssgi_shade}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
-        {"sync", n_sync}, {"setRowWindow", n_set_row_window}, {"setUvModel", n_set_uv_model}, {"setComposeFold", n_set_compose_fold}, {"cubeToEquirect", n_cube_to_equirect}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end},
+        {"sync", n_sync}, {"setRowWindow", n_set_row_window}, {"setUvModel", n_set_uv_model}, {"setComposeFold", n_set_compose_fold}, {"cubeToEquirect", n_cube_to_equirect}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end}, {"profile", n_profile}, {"profileRead", n_profile_read},
         {"stageUpload", n_stage_upload}, {"stageFlip", n_stage_flip}, {"hostAlloc", n_host_alloc},
         {"splitRows", n_split_rows}, {"commUniqueId", n_comm_unique_id}, {"commInit", n_comm_init}, {"haloExchange", n_halo_exchange},
         {"allgatherHistory", n_allgather_history}, {"gatherHistoryRows", n_gather_history_rows}, {"commWait", n_comm_wait}, {"commDestroy", n_comm_destroy},

@@ -325,5 +325,17 @@ class Context:
         self._chk(self.lib.rfx_time_end(self._h, C.byref(ms)), "rfx_time_end")
         return ms.value
 
+
+    def profile(self, enable=True):
+        """Per-draw device timing inside a frame loop (include/rfx.h rfx_profile): True resets the sums and starts, False stops."""
+        self._chk(self.lib.rfx_profile(self._h, 1 if enable else 0), "rfx_profile")
+
+    def profile_read(self):
+        """-> {kind: (summed ms, launches)} since the last profile(True), for the kinds that launched (abi.PROF_KINDS)"""
+        n = len(abi.PROF_KINDS)
+        ms, cnt = (C.c_float * n)(), (C.c_int * n)()
+        self._chk(self.lib.rfx_profile_read(self._h, ms, cnt), "rfx_profile_read")
+        return {abi.PROF_KINDS[k]: (float(ms[k]), int(cnt[k])) for k in range(n) if cnt[k]}
+
     def halo_violations(self) -> int:
         return int(self.lib.rfx_halo_violations(self._h))

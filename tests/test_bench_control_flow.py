@@ -34,6 +34,7 @@ MOCK = textwrap.dedent('''
         return 0.0366, (0.0380 if k.get("cold") else None)
     bench.time_case = time_case
     bench.kernel_times = lambda *a, **k: (dict(kms), kms["k3_poisson_denoise_pass1"] + kms["k4_compose"])
+    bench.kernel_times_in_frame = lambda *a, **k: (dict(kms, k1_ssgi_march=0.55), 0.11)
     bench.cpu_baseline = lambda *a, **k: {"value": 10.4, "unit": "Mpixels/s", "cores": 32, "kind": "reference", "sample": "mock"}
     bench.main()
 ''') % ROOT
@@ -57,6 +58,10 @@ def test_bench_line_single_gpu():
     assert abs(j["ms_per_step_cold"] - 1.9) < 1e-6  # the W + K protocol before the spin-up, reported beside the sustained figure
     assert abs(j["value"] - 3840 * 2160 * 20 / 0.0366 / 1e6) < 0.01 and abs(j["ms_per_step"] - 1.83) < 1e-6
     assert j["roofline"]["bound"] == "hbm" and j["roofline"]["kernel"] == "k1_ssgi_march" and 0 < j["roofline"]["frac"] < 1
+    # the dominant kernel's duration is its in-frame launch PLUS its depth pre-pass (whose input is part of K1's algorithmic bytes)
+    assert abs(j["roofline"]["avg_launch_ms"] - 0.66) < 1e-6 and abs(j["kernel_ms"]["k1_ssgi_march"] - 0.55) < 1e-6 and abs(j["k1_prepass_ms"] - 0.11) < 1e-6
+    assert abs(j["roofline"]["achieved"] - 68 * 3840 * 2160 / 0.66e-3 / 1e9) < 0.1
+    assert j["config"]["compose_fold"] is False and abs(j["ms_per_step_compose_fold_opt_in"] - 1.83) < 1e-6  # the default is one launch per draw; the opt-in rides beside it
     assert j["cpu_baseline"]["kind"] == "reference" and j["config"]["workload"].startswith("configs[2]")
 
 

@@ -1332,6 +1332,52 @@ def test_folded_compose_on_a_4k_chain(blue_noise):
     assert n31 <= 3e-4 * W * H
 
 
+def test_per_draw_profile_counts_the_launches_of_a_frame(blue_noise):
+    """rfx_profile / rfx_profile_read (include/rfx.h): inside a frame loop every draw's launches are bracketed by events on the stream they run on —
+    three frames through SSGIEffect give 3 launches of each of K1's pre-pass, K1, K2, K3 pass 0, the later K3 pass and K4 (one launch per draw,
+    the default), none before the reset or after the stop; with the opt-in fold the last two draws are one launch of its own kind.  The
+    composed frames are the same bytes with and without the events."""
+    import types
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.effect import SSGIEffect
+    from rfx_amd.scene import synthetic_frame
+
+    W, H = 192, 108
+    f = synthetic_frame(W, H, 1)
+    f.static = True
+    outs = {}
+    for mode in ("plain", "profiled", "profiled+fold"):
+        ctx = Context(W, H)
+        if mode.endswith("fold"):
+            ctx.set_compose_fold(True)
+        scene = types.SimpleNamespace(frame=f)
+        fx = SSGIEffect(None, scene, f.camera, dict(width=W, height=H, steps=8, refineSteps=2, denoiseIterations=1), seeds=dict(ssgi=5, denoise=6))
+        fx.update(ctx, None)  # before the reset: not counted
+        if mode != "plain":
+            ctx.profile(True)
+        for _ in range(3):
+            fx.update(ctx, None)
+        if mode != "plain":
+            got = ctx.profile_read()
+            ctx.profile(False)
+            fx.update(ctx, None)  # after the stop: not counted
+            again = ctx.profile_read()
+            want = {"k1_prepass": 3, "k1_ssgi_march": 3, "k2_temporal_reproject": 3, "k3_poisson_denoise_pass0": 3}
+            want.update({"k3_passN_plus_k4_folded": 3} if mode.endswith("fold") else {"k3_poisson_denoise_passN": 3, "k4_compose": 3})
+            assert {k: n for k, (_ms, n) in got.items()} == want, got
+            assert all(ms >= 0.0 for ms, _n in got.values())
+            assert {k: n for k, (_ms, n) in again.items()} == want  # the sums stand until the next reset
+            ctx.profile(True)
+            assert ctx.profile_read() == {}
+        else:
+            fx.update(ctx, None)
+        outs[mode] = ctx.download(abi.TEX_COMPOSE)
+        assert ctx.halo_violations() == 0
+        ctx.close()
+    assert np.array_equal(outs["plain"], outs["profiled"])
+
+
 def test_row_windowed_draws_are_bit_identical(blue_noise):
     """rfx_set_row_window: a draw split into interior + two boundary strips (what a row tile does while its halo rows are still in
     flight) leaves exactly the texels the single launch leaves, for every kernel; an empty window draws nothing."""
