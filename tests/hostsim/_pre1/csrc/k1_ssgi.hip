@@ -222,76 +222,6 @@ RFX_DEV void k1_march_step(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         rays[r].live = (need[r] & (diff >= 0.0f) & (diff < m.thickness)) ? 0.0f : rays[r].live;  // a hit: the ray stops here
     }
 }
-#ifndef RFX_K1_PAIRS
-#define RFX_K1_PAIRS 1  // build knob: 1 = the march step's float arithmetic on (diffuse ray, specular ray) PAIRS — v_pk_fma / mul / add_f32, 4.5 issue cycles
-                        // for two results against 2 x 2.7 (profiles/r03_microbench); every lane operation is the IEEE one k1_march_step makes: same texels (sha1)
-#endif
-// The two rays of a pixel as structure-of-pairs: lane .x = slot 0 (optional diffuse ray), .y = slot 1 (specular ray)
-typedef float k1_f2 __attribute__((ext_vector_type(2)));
-struct RayPair {
-    k1_f2 px, py, pz, dx, dy, dz, u, v, live;
-};
-RFX_DEV k1_f2 k1_mk2(float a, float b) { k1_f2 r; r.x = a; r.y = b; return r; }
-// k1_march_step<PROJ, CS1> on a RayPair (PROJ_CENTRED / PROJ_PERSPECTIVE only: the general projection keeps the scalar form)
-template <int PROJ, bool CS1>
-RFX_DEV void k1_march_step_pair(const MarchCtx &m, const FrameDims &d, RayPair &R, float cs) {
-    static_assert(PROJ == PROJ_CENTRED || PROJ == PROJ_PERSPECTIVE, "pair form: perspective projections");
-    if (CS1) {  // pos + dir * live as one fma per coordinate (the product is exact)
-        R.px = __builtin_elementwise_fma(R.dx, R.live, R.px);
-        R.py = __builtin_elementwise_fma(R.dy, R.live, R.py);
-        R.pz = __builtin_elementwise_fma(R.dz, R.live, R.pz);
-    } else {
-        const k1_f2 csr = cs * R.live;
-        R.px = R.px + R.dx * csr;
-        R.py = R.py + R.dy * csr;
-        R.pz = R.pz + R.dz * csr;
-    }
-    {   // k1_project<PROJ>
-        k1_f2 qx, qy;
-        if (PROJ == PROJ_CENTRED) {
-            qx = m.P[0] * R.px;
-            qy = m.P[5] * R.py;
-        } else {
-            qx = m.P[0] * R.px + m.P[8] * R.pz;
-            qy = m.P[5] * R.py + m.P[9] * R.pz;
-        }
-        const k1_f2 pw = -R.pz;
-        const k1_f2 r = k1_mk2(rfx_rcp(pw.x), rfx_rcp(pw.y));
-        const k1_f2 q0 = qx * r, q1 = qy * r;  // k1_div: q = x * r; fma(fma(-w, q, x), r, q)
-        const k1_f2 dvx = __builtin_elementwise_fma(__builtin_elementwise_fma(-pw, q0, qx), r, q0);
-        const k1_f2 dvy = __builtin_elementwise_fma(__builtin_elementwise_fma(-pw, q1, qy), r, q1);
-        const k1_f2 half = k1_mk2(0.5f, 0.5f);
-        R.u = __builtin_elementwise_fma(dvx, half, half);
-        R.v = __builtin_elementwise_fma(dvy, half, half);
-    }
-    Tap tap[2];
-    {   // k1_taps
-        const k1_f2 cx = R.u * d.fW, cy = R.v * d.fH;
-        const float big = fmaxf(fmaxf(fabsf(cx.x), fabsf(cy.x)), fmaxf(fabsf(cx.y), fabsf(cy.y)));
-        if (__builtin_amdgcn_ballot_w64(big >= 2147483648.0f) != 0) {
-            tap[0] = k1_tap(m, d, make_float2(R.u.x, R.v.x));
-            tap[1] = k1_tap(m, d, make_float2(R.u.y, R.v.y));
-        } else {
-            const float wm1 = (float)(d.W - 1), hm1 = (float)(d.H - 1);
-            tap[0] = k1_tap_at(m, d, (int)__builtin_amdgcn_fmed3f(cx.x, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy.x, 0.0f, hm1));
-            tap[1] = k1_tap_at(m, d, (int)__builtin_amdgcn_fmed3f(cx.y, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy.y, 0.0f, hm1));
-        }
-    }
-    const float2 mm0 = k1_cell_load(m.coarse, tap[0].cell), mm1 = k1_cell_load(m.coarse, tap[1].cell);
-    // a hit needs 0 <= z - h < thickness: the cell rules it out when max - h < 0 or min - h >= thickness
-    const k1_f2 dmax = k1_mk2(mm0.y, mm1.y) - R.pz, dmin = k1_mk2(mm0.x, mm1.x) - R.pz;
-    const bool need0 = (R.live.x != 0.0f) & !((dmax.x < 0.0f) | (dmin.x >= m.thickness));
-    const bool need1 = (R.live.y != 0.0f) & !((dmax.y < 0.0f) | (dmin.y >= m.thickness));
-    k1_f2 z = k1_mk2(0.0f, 0.0f);
-    if (need0 | need1) {  // one exec region and one wait for both rays' exact texels (k1_march_step)
-        const unsigned int i0 = need0 ? tap[0].idx : tap[1].idx, i1 = need1 ? tap[1].idx : tap[0].idx;
-        z.x = rfx_gather<float>(m.viewz, i0);
-        z.y = rfx_gather<float>(m.viewz, i1);
-    }
-    const k1_f2 diff = z - R.pz;
-    R.live.x = (need0 & (diff.x >= 0.0f) & (diff.x < m.thickness)) ? 0.0f : R.live.x;  // a hit: the ray stops here
-    R.live.y = (need1 & (diff.y >= 0.0f) & (diff.y < m.thickness)) ? 0.0f : R.live.y;
-}
 // BinarySearch (:477-503) for the pixel's two rays in their two slots (rays that did not hit idle along): the form used when the wavefront's
 // hit rays do not fit one per lane
 template <int PROJ>
@@ -413,31 +343,6 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
     }
     const int split = RFX_K1_CS1 ? min(m.steps, 9) : m.steps;
     int i = RFX_K1_ABLATE >= 3 ? m.steps : 1;
-    if constexpr (RFX_K1_PAIRS && PROJ != PROJ_GENERAL && RFX_K1_MERGE_GATHERS && !RFX_K1_ABLATE) {
-        RayPair R;
-        R.px = k1_mk2(rays[0].pos.x, rays[1].pos.x); R.py = k1_mk2(rays[0].pos.y, rays[1].pos.y); R.pz = k1_mk2(rays[0].pos.z, rays[1].pos.z);
-        R.dx = k1_mk2(rays[0].dir.x, rays[1].dir.x); R.dy = k1_mk2(rays[0].dir.y, rays[1].dir.y); R.dz = k1_mk2(rays[0].dir.z, rays[1].dir.z);
-        R.u = k1_mk2(0.f, 0.f); R.v = k1_mk2(0.f, 0.f);
-        R.live = k1_mk2(rays[0].live, rays[1].live);
-#if RFX_K1_WAVE_LOOP
-#define K1_ANY_LIVE2(R) (__builtin_amdgcn_ballot_w64(((R).live.x != 0.0f) | ((R).live.y != 0.0f)) != 0)
-#else
-#define K1_ANY_LIVE2(R) (((R).live.x != 0.0f) | ((R).live.y != 0.0f))
-#endif
-        for (; i < split && K1_ANY_LIVE2(R); i++) {
-            const float t = (float)i + random_b - 0.5f;
-            const float cs = 1.0f - rfx_exp2((t * t) * (-0.25f * 1.4426950408889634f));  // (see the scalar loop below)
-            k1_march_step_pair<PROJ, false>(m, d, R, cs);
-        }
-        for (; i < m.steps && K1_ANY_LIVE2(R); i++) k1_march_step_pair<PROJ, true>(m, d, R, 1.0f);
-#undef K1_ANY_LIVE2
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            rays[r].pos = make_float3(R.px[r], R.py[r], R.pz[r]);
-            rays[r].uv = make_float2(R.u[r], R.v[r]);
-            rays[r].live = R.live[r];
-        }
-    } else {
     for (; i < split && K1_ANY_LIVE(rays); i++) {
         const float t = (float)i + random_b - 0.5f;
         // exp(-0.25 t^2) = exp2((-0.25 t^2) log2e): the scaling by -1/4 is exact, so it folds into the constant (one product instead of two,
@@ -446,7 +351,6 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         k1_march_step<PROJ, false>(m, d, rays, cs);
     }
     for (; i < m.steps && K1_ANY_LIVE(rays); i++) k1_march_step<PROJ, true>(m, d, rays, 1.0f);
-    }
 #pragma unroll
     for (int r = 0; r < 2; r++) rays[r].hit = started[r] & (rays[r].live == 0.0f);
     // (a wavefront none of whose rays hit — sky above the horizon, a wall facing away — has nothing to refine)

@@ -50,14 +50,12 @@ struct CenterTexel {
     float total;
 };
 
-// ---- two forms of the tap arithmetic adopted in round 5, each a build knob (0 = the round-4 form) so that they stay measurable: same
-// operations, other last bits (A/B at 4K, pass 0 / later pass: 0.205 / 0.274 ms -> base-2 0.206 / 0.265, pairs 0.202 / 0.256, both
-// 0.202 / 0.250; profiles/r05_k3/)
+// ---- build knobs of round 5 (profiles/r05_k3/): both change the last bits of K3's output, not its arithmetic's meaning
 #ifndef RFX_K3_LOG2ACC
-#define RFX_K3_LOG2ACC 1  // the log-space colours are base-2 logarithms throughout (no `* ln 2` per tap and channel, exp2 at the end)
+#define RFX_K3_LOG2ACC 0  // 1 = the log-space colours are base-2 logarithms throughout (no `* ln 2` per tap and channel, exp2 at the end)
 #endif
 #ifndef RFX_K3_PAIRS
-#define RFX_K3_PAIRS 1    // the two textures' accumulators of a pixel laid out as float2 pairs (v_pk_fma / mul / add_f32 across the textures)
+#define RFX_K3_PAIRS 0    // 1 = the two textures' accumulators of a pixel laid out as float2 pairs (v_pk_fma / mul / add_f32 across the textures)
 #endif
 // The log-space colour `log(c + 1)` (poisson_denoise.frag:150,193) is carried as log2(c + 1) under RFX_K3_LOG2ACC: the weighted mean of
 // logarithms is linear in them, so the base only matters where the luminance of the log colour enters (k3_luma: lum is linear too,
@@ -143,7 +141,7 @@ RFX_DEV rfx_f2 k3_luma2(rfx_f2 r, rfx_f2 g, rfx_f2 b) {
 template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE, bool FUSE>
 RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     constexpr bool PAIR = RFX_K3_PAIRS && TC == 2;  // the pixel's two accumulators as float2 pairs (k3_apply_pair)
-    extern __shared__ float4 lds[];
+    float4 *lds = (float4 *)hostsim_lds;
     const int Rx = A.tile.Rx, Ry = A.tile.Ry, LW = A.tile.LW, LH = A.tile.LH;
     const int ntex = PITCH * LH;
     float4 *s_geom = lds;
