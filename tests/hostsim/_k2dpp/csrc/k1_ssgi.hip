@@ -3,19 +3,22 @@
 // RayMarch :441-475, BinarySearch :477-503) in the MODE_SSGI / PERSPECTIVE_CAMERA /
 // no-env-map variant (the configs carry no env map).
 //
-// One pixel per lane; a wavefront is 64 consecutive pixels of one row (a 64 x K1_TH-pixel tile, K1_TH = 1): the G-buffer / direct-light /
-// output planes are read and written as coalesced 16 B/lane rows.  The march's depth taps are data-dependent gathers anywhere on screen; two
-// things keep them off the HBM / fabric path:
-//   * k1_prepare (one streaming pre-pass per draw) converts the depth plane to VIEW-SPACE Z once per texel (the same IEEE expression every tap
-//     would evaluate, ssgi_utils.frag:9) and reduces it to exact 16x16-texel (min, max) cells, which k1_pack_cells folds into a table of
-//     half-packed cells of at most 32 KiB (4K: 32-texel cells);
-//   * every tap first consults its cell: when the cell's range proves the texel cannot satisfy `0 <= z - hitPos.z < thickness` (RayMarch :463)
-//     — or fixes the sign BinarySearch tests (:493) — the exact texel is never fetched.  The decision is exact, not approximate: fp
-//     subtraction is monotonic, so the cell bounds bound the per-texel difference.
-// The march kernel is PERSISTENT: as many 8-wave workgroups as the chip holds at once are launched, each copies the (min, max) table into LDS
-// once (the only barrier), and every WAVEFRONT then takes tiles from one of 64 device queues until none is left — no workgroup waits for its
-// slowest wave, and a cell lookup (two per march step and ray, 64 unrelated addresses each) is an LDS read.  Which tiles a queue holds:
-// k1_ssgi_march.  Measurements: profiles/r04_k1, profiles/r05_k1; DESIGN.md §4.
+// One pixel per lane, 64x4-pixel workgroups: the G-buffer / direct-light / output planes are read and
+// written as coalesced 16 B/lane rows.  The march's depth taps are data-dependent gathers anywhere on
+// screen; two things keep them off the HBM/fabric path:
+//   * k1_prepare (one streaming pre-pass per draw) converts the depth plane to VIEW-SPACE Z once per texel
+//     (the same IEEE expression every tap would evaluate, ssgi_utils.frag:9) and reduces it to exact
+//     16x16-texel (min, max) cells, which k1_pack_cells folds into a table of half-packed cells small
+//     enough (<= 32 KiB; 4K: 32-texel cells) to stay resident in every CU's L1;
+//   * every tap first consults its cell: when the cell's range proves the texel cannot satisfy
+//     `0 <= z - hitPos.z < thickness` (RayMarch :463) — or fixes the sign BinarySearch tests (:493) — the
+//     exact texel is never fetched.  The decision is exact, not approximate: fp subtraction is monotonic,
+//     so the cell bounds bound the per-texel difference.
+// The march kernel is PERSISTENT (round 4): as many 8-wave workgroups as the chip holds at once are launched, each copies the (min, max)
+// table into LDS once, and every WAVEFRONT then takes 64x4-pixel tiles from a device counter until none is left — no barrier after the copy,
+// no workgroup waits for its slowest wave, and the cell lookups (two per march step and ray, 64 unrelated addresses each: ~30 cache lines
+// per instruction, which kept the CUs' L1 tag pipelines 80 % busy — the kernel's real bound in rounds 1-3, profiles/r04_k1/) become LDS reads.
+// Tiles are handed out in launch order (a band-per-XCD mapping measured slower: sky bands idle their XCD).
 #include "rfx_brdf.h"
 #include "rfx_kernels.h"
 
@@ -23,11 +26,13 @@ namespace {
 
 // The (min, max) view-Z table the march consults before touching a texel: one 4-byte cell = two halfs, min rounded
 // DOWN and max rounded UP, so a widened range can only reject fewer taps — the rejection tests stay exact.  The cell edge is
-// 2^cell_shift texels, chosen per frame size so that the whole table stays <= 32 KiB (rfx_api; 4K: 32-texel cells): every workgroup of the
-// march keeps its own copy in LDS.
+// 2^cell_shift texels, chosen per frame size so that the whole table stays <= 32 KiB (rfx_api; 4K: 32-texel cells): it then lives
+// in the CUs' L1 and a lookup costs what an LDS read costs.  Measured at 4K (same box, bit-identical output): 8-texel float2
+// cells (1 MiB) 0.789 ms, half cells 0.749, 16-texel 0.727, 32/64-texel 0.694-0.712; a per-workgroup LDS copy of the table
+// measured 0.700 — no better than the cached global lookup, so there is none.
 constexpr int BASE = 16;  // edge of the pre-pass's exact (float) cells, reduced to the final cells by k1_pack_cells
 #ifndef RFX_K1_TH
-#define RFX_K1_TH 1  // build knob: rows of 64 pixels per tile a wavefront takes from its queue
+#define RFX_K1_TH 1  // build knob: rows of 64 pixels per tile a wavefront takes from its queue (measured at 4K, 64 queues: 1: 0.620 ms, 2: 0.618, 4: 0.660)
 #endif
 constexpr int K1_TH = RFX_K1_TH;
 typedef uint32_t k1_cell_t;

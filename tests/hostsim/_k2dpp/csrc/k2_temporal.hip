@@ -15,11 +15,12 @@
 namespace {
 
 #ifndef RFX_K2_XCD_G
-#define RFX_K2_XCD_G 0  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major (measurements: profiles/HISTORY.md)
+#define RFX_K2_XCD_G 0  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major.  Measured at 4K: 0: 0.445 ms, 2: 0.450, 4: 0.461, 8: 0.489, 16: 0.500, 32: 0.517
 #endif
 #ifndef RFX_K2_TH
-#define RFX_K2_TH 8  // build knob: tile rows.  8 (eight waves per workgroup) stages 1.6 texels per pixel instead of 2.1 and, at this kernel's 70 VGPRs,
-                     // keeps 6 waves per SIMD resident (46 KB of LDS per workgroup) against 5 with 4 rows (measurements: profiles/r04_k2)
+#define RFX_K2_TH 8  // build knob: tile rows.  8 (eight waves per workgroup) stages 1.6 texels per pixel instead of 2.1 and, at the no-SLP build's 70 VGPRs, keeps
+                     // 6 waves per SIMD resident (46 KB of LDS per workgroup) against 5 with 4 rows: measured 0.325 against 0.353 ms at 4K (round 4; round 3's
+                     // 90-VGPR kernel was register-bound at 5 waves either way and measured 8 rows +0.6 %); 2 rows: 0.424 ms
 #endif
 constexpr int TW = 64, TH = RFX_K2_TH, AP = 2;    // tile, apron (neighbourhood radius <= 2)
 constexpr int LW = TW + 2 * AP, LH = TH + 2 * AP;  // 68 x 12 staged texels
@@ -100,9 +101,10 @@ RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &te
         S2[k] = (tc + 2.0f) * its[k];
     }
     const float sw0 = Wb[0] * Wa[1], sw1 = Wa[0] * Wb[1], sw2 = Wb[0] * Wb[1], sw3 = Wc[0] * Wb[1], sw4 = Wb[0] * Wc[1];
-    // A compiler barrier between the bilinear taps: left alone, the scheduler puts all 20 texels of the five taps in flight at once and the
-    // kernel needs ~20 more VGPRs (one wave per SIMD fewer); fenced after every second tap it fits its occupancy.  Same texels.
-    // (measurements and the ablation of the kernel's parts: profiles/HISTORY.md)
+    // A compiler barrier between the bilinear taps: left alone, the scheduler puts all 20 texels of the five taps in flight at once
+    // (40 VGPRs, 147 in total -> 3 waves/SIMD); fenced, the kernel fits 125 VGPRs -> 4 waves/SIMD: 0.48 -> 0.445 ms, same texels.
+    // (Ablation, same build: one tap instead of five 0.316 ms / 74 VGPRs, no history fetch 0.272, no neighbourhood AABB 0.467,
+    // staging + reprojection alone 0.176 — the five-tap fetch is 38 % of K2, by arithmetic and registers, not by its addresses.)
 #ifndef RFX_K2_FENCE
 #define RFX_K2_FENCE 2  // build knob: fence after every n-th tap, 0 = none
 #endif

@@ -82,6 +82,14 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 static inline int __builtin_amdgcn_ds_permute(int addr, int data) { return (int)(unsigned int)hostsim_wave_exchange(HOSTSIM_PERMUTE, (unsigned int)data, (addr >> 2) & 63); }
 // ds_bpermute_b32 (pull): lane i reads `data` of lane (addr / 4) % 64 (0 when that lane is not here)
 static inline int __builtin_amdgcn_ds_bpermute(int addr, int data) { return (int)(unsigned int)hostsim_wave_exchange(HOSTSIM_BPERMUTE, (unsigned int)data, (addr >> 2) & 63); }
+// v_mov_b32_dpp wave_shr:1 (0x138: lane i <- lane i - 1) / wave_shl:1 (0x130: lane i <- lane i + 1), bound_ctrl 0: the end lane keeps `old`
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int /*row_mask*/, int /*bank_mask*/, bool /*bound_ctrl*/) {
+    const int lane = (int)(hostsim_tid() & 63u);
+    const int from = ctrl == 0x138 ? lane - 1 : (ctrl == 0x130 ? lane + 1 : -1000);
+    if (from == -1000) { std::fprintf(stderr, "hostsim: DPP control 0x%x is not modelled\n", ctrl); std::abort(); }
+    const int got = (int)(unsigned int)hostsim_wave_exchange(HOSTSIM_SHFL, (unsigned int)src, (from + 64) & 63);  // (every lane takes part in the exchange)
+    return (from < 0 || from > 63) ? old : got;
+}
 // v_mbcnt_lo/hi: bits of `mask` below the calling lane (+ base)
 static inline unsigned int __builtin_amdgcn_mbcnt_lo(unsigned int mask, unsigned int base) {
     const unsigned int lane = hostsim_tid() & 63u;
