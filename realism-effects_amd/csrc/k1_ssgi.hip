@@ -218,7 +218,7 @@ RFX_DEV void k1_march_step(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
     }
 }
 #ifndef RFX_K1_PAIRS
-#define RFX_K1_PAIRS 1  // build knob: 1 = the march step's float arithmetic on (diffuse ray, specular ray) PAIRS — v_pk_fma / mul / add_f32, 4.5 issue cycles
+#define RFX_K1_PAIRS 0  // build knob (off: measured SLOWER, K1 0.530 -> 0.556 ms at 4K, profiles/r05_k1): 1 = the march step's float arithmetic on (diffuse ray, specular ray) PAIRS — v_pk_fma / mul / add_f32, 4.5 issue cycles
                         // for two results against 2 x 2.7 (profiles/r03_microbench); every lane operation is the IEEE one k1_march_step makes: same texels (sha1)
 #endif
 // The two rays of a pixel as structure-of-pairs: lane .x = slot 0 (optional diffuse ray), .y = slot 1 (specular ray)

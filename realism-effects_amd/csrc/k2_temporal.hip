@@ -8,7 +8,8 @@
 // texel, so the (2r+1)^2 neighbourhood AABB of both textures (up to 50 taps per pixel) and the 2x2-quad
 // derivatives read LDS instead of re-fetching and re-unpacking global texels.  The history taps
 // (5 bilinear taps x 2 textures at the reprojected uv) and the validation fetch stay global gathers:
-// their position is data dependent.
+// their position is data dependent.  (The AABB as column reductions exchanged between lanes with DPP wave shifts — 30 LDS reads per pixel instead
+// of 50, bit-identical — was built and measured in round 5: no faster, 13 % more VALU instructions; profiles/r05_k2/.)
 #include "rfx_device.h"
 #include "rfx_kernels.h"
 
@@ -24,11 +25,6 @@ namespace {
 constexpr int TW = 64, TH = RFX_K2_TH, AP = 2;    // tile, apron (neighbourhood radius <= 2)
 constexpr int LW = TW + 2 * AP, LH = TH + 2 * AP;  // 68 x 12 staged texels
 constexpr int NT = TW * TH;
-#ifndef RFX_K2_AABB_DPP
-#define RFX_K2_AABB_DPP 0  // build knob (experiment, profiles/r05_k2/): the neighbourhood AABB as a vertical reduction of the lane's own column (5 LDS reads per
-                           // texture instead of 25) and horizontal min / max over the wavefront's lanes with DPP wave shifts
-#endif
-constexpr int LWP = RFX_K2_AABB_DPP ? LW + 1 : LW;  // pitch of the staged input texels (DPP form: one more column, all NaN)
 
 struct VND {
     float vx, vy, depth;
@@ -148,63 +144,10 @@ RFX_DEV float4 k2_mask_unsampled(float4 t) {
 }
 
 struct Tile {
-    float4 tex[2][LH * LWP];  // unpacked input texels: [0] = diffuse (or the raw single texture), [1] = specular
+    float4 tex[2][LH * LW];  // unpacked input texels: [0] = diffuse (or the raw single texture), [1] = specular
     float4 vn[LH * LW];      // velocity texel: world normal.xyz, depth
     float2 vel[LH * LW];     // velocity.xy
 };
-
-#if RFX_K2_AABB_DPP
-// lane i <- lane i - 1 / lane i + 1 of the wavefront (v_mov_b32_dpp wave_shr:1 / wave_shl:1); the end lane, which has no such neighbour, keeps `fill`
-RFX_DEV float k2_shr1(float v, float fill) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false)); }
-RFX_DEV float k2_shl1(float v, float fill) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false)); }
-// The (2r + 1)^2 boxes of the raw neighbour texels around every pixel of a tile row (one wavefront = its 64 pixels), r = 2 and (NEED3) r = 1:
-// each lane reduces its OWN column over the 5 (3) rows — five LDS reads at immediate offsets of one address — and the wavefront reduces
-// horizontally with wave shifts.  The two columns either side of the row's 64 come from lanes 0 and 63 (every other lane reads the staged
-// all-NaN column there: v_min / v_max skip a NaN, as they skip the unsampled and the out-of-frame texels, which are staged as NaN too).
-template <bool NEED3>
-RFX_DEV void k2_aabb_dpp(const float4 *nt, int cit, int lane, float3 &b3mn, float3 &b3mx, float3 &b5mn, float3 &b5mx) {
-    const float qn = __builtin_nanf("");
-    const int nancol = cit - (lane + AP) + LW;  // this row's entry of the all-NaN column
-    const int e1 = lane == 0 ? cit - 1 : (lane == 63 ? cit + 1 : nancol), e2 = lane == 0 ? cit - 2 : (lane == 63 ? cit + 2 : nancol);
-    float v3n[3], v3x[3], v5n[3], v5x[3], a3n[3], a3x[3], a5n[3], a5x[3], c5n[3], c5x[3];
-#define K2_COL(base, o3n, o3x, o5n, o5x)                                                                                   \
-    {                                                                                                                      \
-        const float4 r0 = nt[(base) - 2 * LWP], r1 = nt[(base) - LWP], r2 = nt[(base)], r3 = nt[(base) + LWP], r4 = nt[(base) + 2 * LWP]; \
-        const float q0[3] = {r0.x, r0.y, r0.z}, q1[3] = {r1.x, r1.y, r1.z}, q2[3] = {r2.x, r2.y, r2.z}, q3[3] = {r3.x, r3.y, r3.z}, q4[3] = {r4.x, r4.y, r4.z}; \
-        _Pragma("unroll") for (int k = 0; k < 3; k++) {                                                                    \
-            o3n[k] = rfx_min3_raw(q1[k], q2[k], q3[k]);                                                                    \
-            o3x[k] = rfx_max3_raw(q1[k], q2[k], q3[k]);                                                                    \
-            o5n[k] = rfx_min3_raw(o3n[k], q0[k], q4[k]);                                                                   \
-            o5x[k] = rfx_max3_raw(o3x[k], q0[k], q4[k]);                                                                   \
-        }                                                                                                                  \
-    }
-    K2_COL(cit, v3n, v3x, v5n, v5x)
-    K2_COL(e1, a3n, a3x, a5n, a5x)
-    {
-        float d3n[3], d3x[3];
-        K2_COL(e2, d3n, d3x, c5n, c5x)
-    }
-#undef K2_COL
-    float o3n[3], o3x[3], o5n[3], o5x[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        if (NEED3) {  // columns x - 1 .. x + 1 of the three-row reductions
-            o3n[k] = rfx_min3_raw(rfx_min3_raw(v3n[k], k2_shr1(v3n[k], qn), k2_shl1(v3n[k], qn)), a3n[k], a3n[k]);
-            o3x[k] = rfx_max3_raw(rfx_max3_raw(v3x[k], k2_shr1(v3x[k], qn), k2_shl1(v3x[k], qn)), a3x[k], a3x[k]);
-        } else {
-            o3n[k] = qn;
-            o3x[k] = qn;
-        }
-        // columns x - 2 .. x + 2 of the five-row reductions: c = x - 1 .. x + 1 first (with the extra column next to the row's ends), then c's two neighbours
-        const float cn = rfx_min3_raw(rfx_min3_raw(v5n[k], k2_shr1(v5n[k], qn), k2_shl1(v5n[k], qn)), a5n[k], a5n[k]);
-        const float cx = rfx_max3_raw(rfx_max3_raw(v5x[k], k2_shr1(v5x[k], qn), k2_shl1(v5x[k], qn)), a5x[k], a5x[k]);
-        o5n[k] = rfx_min3_raw(rfx_min3_raw(cn, k2_shr1(cn, qn), k2_shl1(cn, qn)), a5n[k], c5n[k]);
-        o5x[k] = rfx_max3_raw(rfx_max3_raw(cx, k2_shr1(cx, qn), k2_shl1(cx, qn)), a5x[k], c5x[k]);
-    }
-    b3mn = make_float3(o3n[0], o3n[1], o3n[2]); b3mx = make_float3(o3x[0], o3x[1], o3x[2]);
-    b5mn = make_float3(o5n[0], o5n[1], o5n[2]); b5mx = make_float3(o5x[0], o5x[1], o5x[2]);
-}
-#endif
 
 template <int INPUT_TYPE, int TC, bool LOGT, bool HIST_F32, bool WHOLE>
 RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
@@ -216,23 +159,10 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
     const int tid = threadIdx.y * TW + threadIdx.x;
 
     // ---- stage tile + apron (out-of-frame texels are never addressed: CLAMP_TO_EDGE is applied first)
-    if (RFX_K2_AABB_DPP && tid < LH) {  // the all-NaN column: what a lane that needs no extra column reads instead
-        const float qn = __builtin_nanf("");
-        s.tex[0][tid * LWP + LW] = make_float4(qn, qn, qn, 0.0f);
-        if (INPUT_TYPE == 0) s.tex[1][tid * LWP + LW] = make_float4(qn, qn, qn, 0.0f);
-    }
     for (int i = tid; i < LW * LH; i += NT) {
         const int ly = i / LW, lx = i - ly * LW;
         const int gx = tx0 - AP + lx, gy = ty0 - AP + ly;
-        const int ti = ly * LWP + lx;  // (== i unless the input texels have their own pitch)
-        if (gx < 0 || gx >= d.W || gy < 0 || gy >= d.H || gy > A.y1 - 1 + AP) {
-            if (RFX_K2_AABB_DPP) {  // a position beyond the frame takes no part in any AABB (CLAMP_TO_EDGE only repeats a texel that is in it already): NaN
-                const float qn = __builtin_nanf("");
-                s.tex[0][ti] = make_float4(qn, qn, qn, 0.0f);
-                if (INPUT_TYPE == 0) s.tex[1][ti] = make_float4(qn, qn, qn, 0.0f);
-            }
-            continue;
-        }
+        if (gx < 0 || gx >= d.W || gy < 0 || gy >= d.H || gy > A.y1 - 1 + AP) continue;
         // the input texel this full-resolution position samples: itself, or — K1 drawn at resolutionScale < 1 — the NEAREST texel of the
         // smaller target at this pixel's vUv (whole-frame contexts only; the target is stored at the start of the slot, pitch in_w)
         uint4 t;
@@ -245,8 +175,8 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
         // a texel that was not sampled (`!(t.r >= 0.)`) takes no part in any neighbourhood AABB (reproject.frag:66) and its
         // colour is never read as a centre texel either: stage its rgb as quiet NaNs, which v_min/v_max skip, so the
         // 25-tap loops below need no per-tap test.  .a (roughness / ray length) is kept.
-        s.tex[0][ti] = k2_mask_unsampled(k2_unpack<INPUT_TYPE>(t, 0));
-        if (INPUT_TYPE == 0) s.tex[1][ti] = k2_mask_unsampled(k2_unpack<INPUT_TYPE>(t, 1));
+        s.tex[0][i] = k2_mask_unsampled(k2_unpack<INPUT_TYPE>(t, 0));
+        if (INPUT_TYPE == 0) s.tex[1][i] = k2_mask_unsampled(k2_unpack<INPUT_TYPE>(t, 1));
         const VND vd = k2_vnd(rfx_gather<uint4>(A.velocity.ptr, (unsigned int)(__mul24(rfx_view_row<WHOLE>(d, A.velocity, gy), d.W) + gx)));
         s.vn[i] = make_float4(vd.normal.x, vd.normal.y, vd.normal.z, vd.depth);
         s.vel[i] = make_float2(vd.vx, vd.vy);
@@ -254,10 +184,8 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
     __syncthreads();
 
     const int x = tx0 + threadIdx.x, y = ty0 + threadIdx.y;
-    // (the DPP form exchanges column reductions between ALL lanes of the wavefront: a lane that produces nothing stays until they are done)
-    bool alive = !(x >= d.W || y >= A.y1);
-    if (!RFX_K2_AABB_DPP && !alive) return;
-    const int cx = threadIdx.x + AP, cy = threadIdx.y + AP, ci = cy * LW + cx, cit = cy * LWP + cx;
+    if (x >= d.W || y >= A.y1) return;
+    const int cx = threadIdx.x + AP, cy = threadIdx.y + AP, ci = cy * LW + cx;
     const float u = rfx_frag_u(d.uv, x, y), v = rfx_frag_v(d.uv, y);
 
     const float4 cvn = s.vn[ci];
@@ -269,58 +197,49 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
     const float4 xa = s.vn[qx0], xb = s.vn[qx1], ya = s.vn[qy0], yb = s.vn[qy1];
     if (INPUT_TYPE != 1) {  // temporal_reproject.frag:188-193
         const float fw = fabsf(xb.w - xa.w) + fabsf(yb.w - ya.w);
-        if (depth == 1.0f && fw == 0.0f) {  // discard
-            if (!RFX_K2_AABB_DPP) return;
-            alive = false;
-        }
+        if (depth == 1.0f && fw == 0.0f) return;  // discard
     }
     const float3 fwn = make_float3(fabsf(xb.x - xa.x) + fabsf(yb.x - ya.x), fabsf(xb.y - xa.y) + fabsf(yb.y - ya.y), fabsf(xb.z - xa.z) + fabsf(yb.z - ya.z));
     const float curvature = rfx_length(fwn);  // getCurvature reproject.frag:265-269
 
     // getTexels + preprocessInput :124-145 happen per texture below (the centre texel is re-read from LDS there instead of being held in
     // registers across the disocclusion tests); only the two scalars getRoughnessRayLength needs are taken here
+    const float3 worldNormal = make_float3(cvn.x, cvn.y, cvn.z);
+    const float3 worldPos = k2_ss_to_ws(u, v, depth, p.camera.matrixWorld, p.camera.projectionMatrixInverse);
     float rayLength = 0.0f, roughness = 1.0f;  // getRoughnessRayLength :167-176
     if (INPUT_TYPE == 0) {
-        rayLength = s.tex[TC - 1][cit].w;
-        roughness = rfx_clamp(s.tex[0][cit].w, 0.0f, 1.0f);
+        rayLength = s.tex[TC - 1][ci].w;
+        roughness = rfx_clamp(s.tex[0][ci].w, 0.0f, 1.0f);
     } else if (INPUT_TYPE == 2) {
         float rl, ro;
-        rfx_unpack_half2(__float_as_uint(s.tex[0][cit].w), rl, ro);
+        rfx_unpack_half2(__float_as_uint(s.tex[0][ci].w), rl, ro);
         rayLength = rl;
         roughness = rfx_clamp(ro, 0.0f, 1.0f);
     }
-    float3 rd = make_float3(0.f, 0.f, 0.f), rs = rd;
-    float moveFactor = 0.0f;
-    size_t oi = 0;
-    if (alive) {  // (always, unless RFX_K2_AABB_DPP keeps lanes that produce nothing in the wavefront)
-        // getTexels + preprocessInput :124-145 happen per texture below (the centre texel is re-read from LDS there instead of being held in
-        // registers across the disocclusion tests); only the two scalars getRoughnessRayLength needs were taken above
-        const float3 worldNormal = make_float3(cvn.x, cvn.y, cvn.z);
-        const float3 worldPos = k2_ss_to_ws(u, v, depth, p.camera.matrixWorld, p.camera.projectionMatrixInverse);
-        const float n_ = p.camera.near_, f_ = p.camera.far_;
-        const float viewZ = p.camera.isPerspective ? fabsf((n_ * f_) * rfx_rcp((f_ - n_) * depth - f_)) : fabsf(depth * (n_ - f_) - n_);  // getViewZ reproject.frag:13-19
-        const float distFactor = 1.0f + rfx_rcp(viewZ + 1.0f);
+    const float n_ = p.camera.near_, f_ = p.camera.far_;
+    const float viewZ = p.camera.isPerspective ? fabsf((n_ * f_) * rfx_rcp((f_ - n_) * depth - f_)) : fabsf(depth * (n_ - f_) - n_);  // getViewZ reproject.frag:13-19
+    const float distFactor = 1.0f + rfx_rcp(viewZ + 1.0f);
 
-        // computeReprojectedUv :155-165
-        rd.x = u - cvel.x;
-        rd.y = v - cvel.y;
-        rd.z = k2_validate<WHOLE>(A, d, rd.x, rd.y, worldPos, worldNormal, distFactor);
-        rs = rd;
-        if (INPUT_TYPE != 1) {
-            if (!(curvature > 0.05f || rayLength < 0.01f)) {  // reprojectHitPoint reproject.frag:169-193
-                const float3 camPos = make_float3(p.camera.position[0], p.camera.position[1], p.camera.position[2]);
-                const float3 cameraRay = rfx_normalize(worldPos - camPos);
-                const float3 hp = camPos + cameraRay * rayLength;
-                const float4 r = rfx_mat_mul(A.prevPV, hp.x, hp.y, hp.z, 1.0f);
-                // IEEE divisions: this uv addresses a NEAREST fetch (the validation texel)
-                const float hu = (r.x / r.w) * 0.5f + 0.5f, hv = (r.y / r.w) * 0.5f + 0.5f;
-                const float conf = k2_validate<WHOLE>(A, d, hu, hv, worldPos, worldNormal, distFactor);
-                if (hu != -1.0f) rs = make_float3(hu, hv, conf);  // :161-163 falls back to the diffuse triple
-            }
+    // computeReprojectedUv :155-165
+    float3 rd, rs;
+    rd.x = u - cvel.x;
+    rd.y = v - cvel.y;
+    rd.z = k2_validate<WHOLE>(A, d, rd.x, rd.y, worldPos, worldNormal, distFactor);
+    rs = rd;
+    if (INPUT_TYPE != 1) {
+        if (!(curvature > 0.05f || rayLength < 0.01f)) {  // reprojectHitPoint reproject.frag:169-193
+            const float3 camPos = make_float3(p.camera.position[0], p.camera.position[1], p.camera.position[2]);
+            const float3 cameraRay = rfx_normalize(worldPos - camPos);
+            const float3 hp = camPos + cameraRay * rayLength;
+            const float4 r = rfx_mat_mul(A.prevPV, hp.x, hp.y, hp.z, 1.0f);
+            // IEEE divisions: this uv addresses a NEAREST fetch (the validation texel)
+            const float hu = (r.x / r.w) * 0.5f + 0.5f, hv = (r.y / r.w) * 0.5f + 0.5f;
+            const float conf = k2_validate<WHOLE>(A, d, hu, hv, worldPos, worldNormal, distFactor);
+            if (hu != -1.0f) rs = make_float3(hu, hv, conf);  // :161-163 falls back to the diffuse triple
         }
-        moveFactor = fminf((cvel.x * cvel.x + cvel.y * cvel.y) * 10000.0f, 1.0f);
-        oi = (size_t)(unsigned int)(__mul24(WHOLE ? y : rfx_local_row(d, A.out0.row0, A.out0.rows, y), d.W) + x);
     }
+    const float moveFactor = fminf((cvel.x * cvel.x + cvel.y * cvel.y) * 10000.0f, 1.0f);
+    const size_t oi = (size_t)(unsigned int)(__mul24(WHOLE ? y : rfx_local_row(d, A.out0.row0, A.out0.rows, y), d.W) + x);
 
     // neighbourhood columns with CLAMP_TO_EDGE, as LDS offsets
     int nxo[5];
@@ -334,20 +253,10 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
         // reproject() :83-122.  The 5 bilinear history fetches of THIS texture (sampleReprojectedTexture, reproject.frag:257-263)
         // are issued here, ahead of the LDS neighbourhood reduction that hides their latency; fetching both textures' taps
         // up front held 80 VGPRs of texels and capped the kernel at one workgroup per CU.
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (alive) acc = k2_bicubic<HIST_F32, WHOLE>(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
-        const float4 *nt = (INPUT_TYPE == 0 && spec) ? s.tex[1] : s.tex[0];
-#if RFX_K2_AABB_DPP
-        // getNeighborhoodAABB :53-81 without its centre: the 5x5 box of the raw neighbour texels and, where the radius can be 1 (a specular texture),
-        // the 3x3 one — every lane of the wavefront takes part (k2_aabb_dpp)
-        float3 b3mn, b3mx, b5mn, b5mx;
-        if (spec) k2_aabb_dpp<true>(nt, cit, (int)threadIdx.x, b3mn, b3mx, b5mn, b5mx);
-        else k2_aabb_dpp<false>(nt, cit, (int)threadIdx.x, b3mn, b3mx, b5mn, b5mx);
-        if (!alive) continue;
-#endif
+        const float4 acc = k2_bicubic<HIST_F32, WHOLE>(A, d, i ? A.hist1 : A.hist0, uvc.x, uvc.y);
         float3 accrgb = k2_to_log<LOGT>(make_float3(acc.x, acc.y, acc.z));
         float acca = acc.w;
-        const float4 inp = s.tex[i][cit];  // preprocessInput :124-128 (an unsampled texel was staged with NaN rgb: !(NaN >= 0))
+        const float4 inp = s.tex[i][ci];  // preprocessInput :124-128 (an unsampled texel was staged with NaN rgb: !(NaN >= 0))
         const bool sampled_i = inp.x >= 0.0f;
         float3 inrgb = k2_to_log<LOGT>(make_float3(fmaxf(inp.x, 0.0f), fmaxf(inp.y, 0.0f), fmaxf(inp.z, 0.0f)));
         if (!sampled_i) {
@@ -357,20 +266,15 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
             const int cr = (spec && roughness < 0.25f) ? 1 : 2;
             // clampNeighborhood reproject.frag:83-95 / getNeighborhoodAABB :53-81 (raw neighbour texels, centre included)
             const float3 ic = k2_from_log<LOGT>(inrgb);
-#if RFX_K2_AABB_DPP
-            float3 mni = make_float3(rfx_min_raw(ic.x, b3mn.x), rfx_min_raw(ic.y, b3mn.y), rfx_min_raw(ic.z, b3mn.z));
-            float3 mxi = make_float3(rfx_max_raw(ic.x, b3mx.x), rfx_max_raw(ic.y, b3mx.y), rfx_max_raw(ic.z, b3mx.z));
-            const float3 mno = b5mn, mxo = b5mx;  // (the 5x5 box contains the 3x3 one: joined below exactly as the ring is)
-            if (!spec) { mni = ic; mxi = ic; }
-#else
             // The 3x3 core is always inside the window; the outer ring only when the radius is 2.  min/max are order
             // independent, so the two sets are reduced separately (three-operand v_min3/v_max3) and joined by one select.
             const float qnan = __builtin_nanf("");
             float3 mni = ic, mxi = ic;
             float3 mno = make_float3(qnan, qnan, qnan), mxo = mno;
+            const float4 *nt = (INPUT_TYPE == 0 && spec) ? s.tex[1] : s.tex[0];
 #pragma unroll
             for (int oy = 0; oy < 5; oy++) {  // one row of five 12-byte LDS reads in flight at a time
-                const int nrow = __mul24(min(max(y + oy - 2, 0), d.H - 1) - ty0 + AP, LWP);  // CLAMP_TO_EDGE row, as an LDS offset
+                const int nrow = __mul24(min(max(y + oy - 2, 0), d.H - 1) - ty0 + AP, LW);  // CLAMP_TO_EDGE row, as an LDS offset
                 const float4 t0 = nt[nrow + nxo[0]], t1 = nt[nrow + nxo[1]], t2 = nt[nrow + nxo[2]], t3 = nt[nrow + nxo[3]], t4 = nt[nrow + nxo[4]];
 #define K2_RED3(acc_mn, acc_mx, a, b)                                                                                         \
     acc_mn = make_float3(rfx_min3_raw(acc_mn.x, a.x, b.x), rfx_min3_raw(acc_mn.y, a.y, b.y), rfx_min3_raw(acc_mn.z, a.z, b.z)); \
@@ -388,15 +292,14 @@ RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
                     K2_RED2(mno, mxo, t4);
                 }
             }
-#undef K2_RED3
-#undef K2_RED2
-#endif
             float3 mn, mx;
             {
                 const bool wide = cr == 2;
                 mn = make_float3(wide ? rfx_min_raw(mni.x, mno.x) : mni.x, wide ? rfx_min_raw(mni.y, mno.y) : mni.y, wide ? rfx_min_raw(mni.z, mno.z) : mni.z);
                 mx = make_float3(wide ? rfx_max_raw(mxi.x, mxo.x) : mxi.x, wide ? rfx_max_raw(mxi.y, mxo.y) : mxi.y, wide ? rfx_max_raw(mxi.z, mxo.z) : mxi.z);
             }
+#undef K2_RED3
+#undef K2_RED2
             mn = k2_to_log<LOGT>(mn);
             mx = k2_to_log<LOGT>(mx);
             const float3 clamped = make_float3(rfx_clamp(accrgb.x, mn.x, mx.x), rfx_clamp(accrgb.y, mn.y, mx.y), rfx_clamp(accrgb.z, mn.z, mx.z));
