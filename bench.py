@@ -60,16 +60,17 @@ BYTES_PER_PX = {"k1_ssgi_march": 68, "k2_temporal_reproject": 80, "k3_poisson_de
 # draw — what a frame executes on a whole-frame context — ends in "true>(K3Args)")
 PMC_KERNEL = {"k1_ssgi_march": ("false, 0>(K1Args)",), "k2_temporal_reproject": ("k2_temporal_reproject",), "k3_poisson_denoise_pass0": ("k3_tiled<true",),
               "k3_poisson_denoise_pass1": ("k3_tiled<false", "false>(K3Args)"), "k4_compose": ("k4_compose",),
-              "k3_pass1_plus_k4_folded": ("k3_tiled<false", "true>(K3Args)")}
+              "k3_pass1_plus_k4_folded": ("k3_tiled<false", "true>(K3Args)"), "k1_prepass": ("k1_prepare",)}
 
 
 def _is_kernel(key, name):
     return all(f in name for f in PMC_KERNEL[key])
 
 
-TRAFFIC_NOTE = ("fabric-side bytes per launch from %s/pmc_hbm.csv (separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this bench command at 4K, "
-                "tools/collect_profiles.sh; collected at git %s): (FETCH_SIZE x calibration + WRITE_SIZE) x 1024, calibration per kernel in pmc_traffic()")
-PROFILE_DIR = "profiles/r04_final"  # the committed rocprofv3 collection (tools/collect_profiles.sh) the counter-derived figures are read from
+TRAFFIC_NOTE = ("fabric-side bytes per launch (L2 misses: Infinity-Cache hits included) from %s/pmc_hbm.csv — separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+                "passes over this bench command at 4K, tools/collect_profiles.sh, collected at git %s; FETCH_SIZE calibrated on known request counts "
+                "(profiles/r05_microbench): see traffic_calibration")
+PROFILE_DIR = "profiles/r05_final"  # the committed rocprofv3 collection (tools/collect_profiles.sh) the counter-derived figures are read from
 
 
 def profile_meta():
@@ -80,22 +81,38 @@ def profile_meta():
         return {}
 
 
-def pmc_traffic(kernel_key):
-    """HBM-side bytes per launch of a kernel from the committed PMC summary of this same command
-    (PROFILE_DIR/pmc_hbm.csv: separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, values in KiB).
-    gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports half the bytes of wide coalesced reads -> x2.
-    Returns None when the summary is missing or was taken at another frame size."""
+# What FETCH_SIZE counts on this part (profiles/r05_microbench/: known request counts under rocprofv3 --pmc, kernel durations beside them): every
+# L2-to-fabric read request as 64 bytes.  Wide coalesced reads (4 or 16 B per lane over consecutive lanes: 1 GiB read once reports 512 MiB) travel
+# as 128-byte requests -> the counter shows HALF their bytes (the guide's x2); a 4-byte gather that misses travels as ONE 64-byte request (2^24
+# of them report 2^24 x 64 B and take 303 us = 3.5 TB/s; 128-byte requests would be 7.1 TB/s, above what the part sustains) -> the counter shows
+# its bytes.  So: traffic = streamed bytes + (FETCH_SIZE - streamed bytes / 2) + WRITE_SIZE, the kernel's STREAMED reads being known exactly
+# (every plane it reads once, row by row).  K1: view-Z 4 + depth 4 + G-buffer 16 + direct light 16 = 40 B/px streamed; its march taps and the
+# history fetch at the hit point are the gathers.  The LDS-tiled kernels read rows of their tile and apron (wide loads): x2 throughout — an upper
+# bound for K2, whose history taps are 8-byte gathers.
+STREAMED_READ_BPP = {"k1_ssgi_march": 40}
+
+
+def pmc_traffic(kernel_key, pixels=W4K * H4K):
+    """Fabric-side bytes per launch of a kernel from the committed PMC summary of this same command (PROFILE_DIR/pmc_hbm.csv: separate
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes, values in KiB), calibrated as above.  -> (bytes, how) or (None, None) when the
+    summary is missing."""
     import csv
     path = os.path.join(ROOT, PROFILE_DIR, "pmc_hbm.csv")
     if not os.path.exists(path):
-        return None
+        return None, None
     vals = {}
     for r in csv.DictReader(open(path)):
         if _is_kernel(kernel_key, r["kernel"]):
             vals[r["counter"]] = float(r["mean_value_KB"])
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None
-    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
+        return None, None
+    fetch, write = vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
+    if kernel_key in STREAMED_READ_BPP:
+        streamed = STREAMED_READ_BPP[kernel_key] * pixels
+        gathers = max(fetch - streamed / 2.0, 0.0)
+        return int(streamed + gathers + write), ("streamed reads %.0f MB (counted at half) + gather requests %.0f MB (64 B each, counted in full) + writes %.0f MB; "
+                                                 "the uniform x2 convention of rounds 2-4 would say %.0f MB" % (streamed / 1e6, gathers / 1e6, write / 1e6, (2 * fetch + write) / 1e6))
+    return int(2.0 * fetch + write), "2 x FETCH_SIZE + WRITE_SIZE (wide tile-row loads; an upper bound where the kernel also gathers)"
 
 
 def issue_model():
@@ -111,7 +128,8 @@ def issue_model():
     for key in PMC_KERNEL:
         for name, m in rows.items():
             if _is_kernel(key, name):
-                out[key] = {k: m[k] for k in ("valu_per_px", "predicted_issue_ms", "measured_ms", "issue_share_of_measured", "clock_GHz") if k in m}
+                out[key] = {k: m[k] for k in ("valu_per_px", "predicted_issue_ms", "measured_ms", "issue_share_of_measured", "clock_GHz", "rate_int", "rate_other",
+                                              "lds_busy_ms", "lds_busy_share_of_measured", "lds_conflict_share") if k in m}
     return out or None
 
 
@@ -542,7 +560,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "stream_copy_GBs": copy_gbs,
                          "frac_of_stream_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
-                         "traffic": pmc_traffic(dom) if (W1, rows) == (W4K, H4K) else None,
+                         "traffic": pmc_traffic(dom)[0] if (W1, rows) == (W4K, H4K) else None,
+                         "traffic_calibration": pmc_traffic(dom)[1] if (W1, rows) == (W4K, H4K) else None,
                          "traffic_note": TRAFFIC_NOTE % (PROFILE_DIR, prof.get("git_commit", "?")),
                          "algorithmic_bytes_per_launch": bpp[dom] * px_tile, "avg_launch_ms": round(dur[dom], 4),
                          "avg_launch_ms_note": ("in-frame duration, rfx_profile" + (
@@ -556,8 +575,11 @@ def main():
         if (W1, rows) == (W4K, H4K):
             im = issue_model()
             if im:
-                out["issue_model"] = dict(im, note="per kernel: predicted_issue_ms = sum(class count x measured issue cycles) x waves per SIMD / clock; measured_ms = the kernel's "
-                                                   "average duration in the same rocprofv3 collection — %s/{pmc_sq_l2.csv, kernel_stats.csv, issue_model.txt} (collected at git %s)" % (
+                out["issue_model"] = dict(im, note="per kernel: predicted_issue_ms = sum(class count x measured issue cycles) x waves per SIMD / clock, the classes the SQ "
+                                                   "counters do not name priced at the kernel's own ISA mix (rate_int / rate_other, tools/isa_mix.py); measured_ms = the kernel's "
+                                                   "average duration in the same rocprofv3 collection; lds_busy_ms = SQ_LDS_IDX_ACTIVE / 256 CUs / clock — "
+                                                   "%s/{pmc_sq_l2.csv, kernel_stats.csv, isa_other_mix.json, issue_model.txt} (collected at git %s).  A linear model: interleaved "
+                                                   "instruction streams issue up to ~25 %% below the sum of their isolated costs (valu_rates2.txt, k_mix_*)" % (
                                                        PROFILE_DIR, prof.get("git_commit", "?")))
         out["kernel_ms_note"] = ("kernel_ms: per-draw durations inside the frame loop (hipEvents around every draw's launches, rfx_profile) — they sum to ms_per_step up to the "
                                  "events' own few microseconds; K1's depth pre-pass (k1_prepass_ms) runs on its own stream under the previous frame's K2-K4 and is not "

@@ -165,7 +165,7 @@ RFX_DEV void k1_march_step(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         // straight-line: a stopped ray advances by dir * 0 (pos + (+-0) == pos) and re-derives the same uv — no exec-mask region per ray
-        // (measured 0.654 vs 0.666 ms at 4K, same texels).  `live` is the select as a product: cs * 1 == cs, cs * 0 == +0 (cs is in [0, 1]).
+        // (same texels).  `live` is the select as a product: cs * 1 == cs, cs * 0 == +0 (cs is in [0, 1]).
         if (CS1) {
             rays[r].pos = make_float3(__builtin_fmaf(rays[r].dir.x, rays[r].live, rays[r].pos.x), __builtin_fmaf(rays[r].dir.y, rays[r].live, rays[r].pos.y),
                                       __builtin_fmaf(rays[r].dir.z, rays[r].live, rays[r].pos.z));
@@ -195,10 +195,8 @@ RFX_DEV void k1_march_step(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
     float z[2] = {0.0f, 0.0f};
 #if RFX_K1_MERGE_GATHERS
     // ONE exec region and ONE wait for both rays' exact texels (a random 4-byte gather over a 33 MB plane each) instead of a region and a
-    // wait per ray.  A lane that needs only one of its two texels fetches that one twice (the same address: no extra cache line).  Measured
-    // 0.545 against 0.549 ms at 4K — the waits are not what the exact fetches cost; kept because it is not slower.  (Round 4 also put a second
-    // look in front of the fetch — the pre-pass's exact 16x16-texel (min, max), an L2-sized table: slower, 0.590 against 0.560 ms, as the
-    // extra hierarchy level of round 1 was.)
+    // wait per ray.  A lane that needs only one of its two texels fetches that one twice (the same address: no extra cache line).  Not
+    // faster than two regions — the waits are not what the exact fetches cost — and not slower (profiles/r04_k1).
     if (need[0] | need[1]) {
         const unsigned int i0 = need[0] ? tap[0].idx : tap[1].idx, i1 = need[1] ? tap[1].idx : tap[0].idx;
         z[0] = rfx_gather<float>(m.viewz, i0);
@@ -392,11 +390,9 @@ RFX_DEV void k1_refine_packed(const MarchCtx &m, const FrameDims &d, Ray (&rays)
 //   * cs(i) = 1 - exp(-t^2 / 4) with t = i + random.b - 0.5 >= i - 0.5 (:453-454): from i = 9 on, t >= 8.5 and exp(-t^2 / 4) <= 1.5e-8 <
 //     2^-25, so the subtraction rounds to exactly 1.0f — in the reference's fp32 as here — and `dir * cs` is `dir`: the second loop below
 //     evaluates no cs at all (no v_exp, no products), the same bits.
-// Two more forms of this loop were built and measured in round 4, both with the same texels and both SLOWER (profiles/r04_k1/j_inwave_compaction.txt,
-// k_occupancy_double_step.txt; the code: profiles/r04_k1/k1_march_experiments.patch): packing a wavefront's live rays one per lane through the LDS
-// crossbar once they fit (K1 0.550-0.563 against 0.529-0.544 ms), and marching two steps per iteration with the second speculated while the
-// first's fetches are in flight (0.549 against 0.535 ms).  At 8 wavefronts per SIMD the march is bound by instruction issue: whatever adds
-// instructions to remove idle lanes or round trips loses.
+// Other forms of this loop that were built and measured, all with the same texels and all slower (profiles/r04_k1, profiles/r05_k1): packing a
+// wavefront's live rays one per lane through the LDS crossbar once they fit, marching two steps per iteration with the second speculated
+// under the first's fetches, and the step's arithmetic on (ray 0, ray 1) float2 pairs (k1_march_step_pair, RFX_K1_PAIRS).
 template <int PROJ>
 RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2], float random_b) {
     const float scale = m.rayDistance / (float)m.steps;
@@ -805,8 +801,7 @@ __global__ __launch_bounds__(64 * K1_WAVES) RFX_WAVES_PER_EU(ENV ? 1 : 8) void k
     const int lane = threadIdx.x & 63;
     const unsigned int nbx = (unsigned int)(A.out_w + 63) / 64u, nby = (unsigned int)(A.y1 - A.y0 + K1_TH - 1) / (unsigned int)K1_TH, ntiles = nbx * nby;
     // Every wavefront takes tiles from one of K1_COUNTERS device queues; workgroup b serves queue b % K1_COUNTERS (the same-address atomics of the
-    // whole chip are spread over K1_COUNTERS cache lines — one counter for all 8192 waves measured 0.81 ms for the launch, 7 ns per atomic being
-    // the whole difference to the non-persistent kernel).  The next tile's number is requested before this tile's work: the wavefront never waits
+    // whole chip are spread over K1_COUNTERS cache lines: one counter for all 8192 waves costs the launch a third more time, profiles/r04_k1).  The next tile's number is requested before this tile's work: the wavefront never waits
     // for the atomic.  Which tiles a queue holds (k1_tile_of):
     //   RFX_K1_XCD_G == 0: tiles in launch order dealt round-robin to the queues — every queue holds tiles of every image region, so the
     //     queues drain together; but hardware workgroup b runs on XCD b % 8, so every XCD marches tiles from all over the frame and each of

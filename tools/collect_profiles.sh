@@ -17,6 +17,8 @@ json.dump({"profile": os.path.basename(sys.argv[1]), "git_commit": commit, "coll
            "command": "tools/collect_profiles.sh (3840x2160, steps 20/5, denoiseIterations 1; rocprofv3 --kernel-trace --stats of bench.py; one --pmc set per pass over the same bench.py command)"},
           open(os.path.join(sys.argv[1], "meta.json"), "w"))
 PY
+# the issue-rate microbenchmark (built here when the binary did not travel: hipcc is in the image)
+[ -x $ROOT/tools/microbench/bin/valu_rates2 ] || { mkdir -p $ROOT/tools/microbench/bin; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $ROOT/tools/microbench/valu_rates2.hip -o $ROOT/tools/microbench/bin/valu_rates2 2>/dev/null; }
 $ROOT/tools/microbench/bin/valu_rates2 > $OUT/valu_rates2.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 # the profiled command: the bench's own loop after its spin-up (--spinup 50: the device at its sustained clock, as in the line), 20 timed frames
@@ -61,6 +63,23 @@ with open(out + "/pmc_sq_l2.csv", "w") as fh:
             continue
         for k, v in sorted(acc[c].items()):
             w.writerow([k, c, len(v), "%.4g" % (sum(v) / len(v))])
+PY
+# the issue model, twice: the first pass yields every kernel's measured VALU instructions per pixel, which tools/isa_mix.py needs to weight the
+# kernel's loop blocks; the second prices "int" / "other" with that kernel's own mix (isa_other_mix.json)
+python $ROOT/tools/issue_model.py $OUT > $OUT/issue_model_flat_rates.txt 2>&1
+python - "$OUT" "$ROOT" <<'PY'
+import subprocess, sys
+sys.path.insert(0, sys.argv[2] + "/tools")
+import issue_model as IM
+rows = IM.table(sys.argv[1])
+args = []
+for frag, key in IM.MIX_KEY:
+    for name, m in rows.items():
+        if frag in name and "true>(K3Args)" not in name:  # (the folded launch is not the default path)
+            args.append("%s=%s" % (key, m["valu_per_px"]))
+            break
+subprocess.call([sys.executable, sys.argv[2] + "/tools/isa_mix.py", "--out", sys.argv[1] + "/isa_other_mix.json", "--valu-per-px"] + args,
+                stdout=open(sys.argv[1] + "/isa_other_mix.txt", "w"), stderr=subprocess.STDOUT)
 PY
 python $ROOT/tools/issue_model.py $OUT > $OUT/issue_model.txt 2>&1
 rm -rf $OUT/trace $OUT/pmc[0-9]* 
