@@ -146,7 +146,7 @@ RFX_DEV rfx_f2 k3_luma2(rfx_f2 r, rfx_f2 g, rfx_f2 b) {
 template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE, bool FUSE>
 RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     constexpr bool PAIR = RFX_K3_PAIRS && TC == 2;  // the pixel's two accumulators as float2 pairs (k3_apply_pair)
-    extern __shared__ float4 lds[];
+    float4 *lds = (float4 *)hostsim_lds;
     const int Rx = A.tile.Rx, Ry = A.tile.Ry, LW = A.tile.LW, LH = A.tile.LH;
     const int ntex = PITCH * LH;
     float4 *s_geom = lds;
