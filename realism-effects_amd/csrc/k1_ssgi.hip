@@ -789,6 +789,7 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d, const k1_ce
 }
 
 // (without an environment map the fragment fits 64 VGPRs = the hardware's 8 waves per SIMD; the bound keeps the register allocator there)
+// K1Args must stay the FIRST by-value parameter: RFX_KERNARGS_IN_LOOP re-reads it from offset 0 of the kernarg segment (rfx_device.h)
 template <int PROJ, bool ENV, bool MIS, int STAGE>
 __global__ __launch_bounds__(64 * K1_WAVES) RFX_WAVES_PER_EU(ENV ? 1 : 8) void k1_ssgi_march(K1Args A) {
     __shared__ k1_cell_t s_cells[K1_TABLE_CELLS];
@@ -1104,20 +1105,38 @@ hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
     // surplus workgroups start late and find the counter exhausted), never more workgroups than there are tiles for their waves
     const int nbx = (A.out_w + 63) / 64, nby = (A.y1 - A.y0 + K1_TH - 1) / K1_TH;
 #ifndef RFX_K1_OCC
-#define RFX_K1_OCC 8  // measurement knob: wavefronts per SIMD the persistent grid is sized for.  8 = what the chip holds; measured at 4K 8 / 6 / 4 / 2: 0.542 / 0.561 / 0.641 / 0.958 ms
-                      // (profiles/r04_k1/k_occupancy_double_step.txt): at 8 the other waves hide nearly all of the march's latency
+#define RFX_K1_OCC 8  // measurement knob: eighths of the chip's resident workgroups the persistent grid is sized for (8 = all; 6 / 4 / 2 are slower and read
+                      // less from the fabric: profiles/r04_k1/k_occupancy_double_step.txt, profiles/r05_k1/summary.txt)
 #endif
-    const int want = (nbx * nby + K1_WAVES - 1) / K1_WAVES, fit = (A.n_cu > 0 ? A.n_cu : 256) * (4 * RFX_K1_OCC / K1_WAVES);
-    dim3 block(64 * K1_WAVES), grid(want < fit ? want : fit);
+    const int want = (nbx * nby + K1_WAVES - 1) / K1_WAVES, n_cu = A.n_cu > 0 ? A.n_cu : 256;
+    dim3 block(64 * K1_WAVES), grid(1);
     const float *P = A.p.camera.projectionMatrix;
     const bool persp = P[1] == 0.f && P[2] == 0.f && P[3] == 0.f && P[4] == 0.f && P[6] == 0.f && P[7] == 0.f && P[12] == 0.f && P[13] == 0.f &&
                        P[15] == 0.f && P[11] == -1.f;
     const bool env = A.p.useEnvMap != 0, mis = env && A.p.importanceSampling != 0;
-#define K1_GO(P, E, M)                                                                                   \
-    do {                                                                                                 \
-        if (stage == 0) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 0>), grid, block, 0, stream, A);      \
-        else if (stage == 1) hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 1>), grid, block, 0, stream, A); \
-        else hipLaunchKernelGGL((k1_ssgi_march<P, E, M, 2>), grid, block, 0, stream, A);                 \
+    // the persistent grid: what the chip holds of THIS specialisation at once — the runtime's occupancy figure for its registers and static LDS
+    // (4 workgroups per CU at <= 64 VGPRs; fewer with an environment map), asked once per specialisation and device
+#define K1_GO_S(P, E, M, S)                                                                                                   \
+    do {                                                                                                                      \
+        static int per_cu[64] = {0};                                                                                          \
+        int dev = 0;                                                                                                          \
+        hipGetDevice(&dev);                                                                                                   \
+        int nb = (dev >= 0 && dev < 64) ? per_cu[dev] : 0;                                                                    \
+        if (nb <= 0) {                                                                                                        \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k1_ssgi_march<P, E, M, S>, 64 * K1_WAVES, 0) != hipSuccess || nb <= 0) \
+                nb = 32 / K1_WAVES;                                                                                           \
+            if (dev >= 0 && dev < 64) per_cu[dev] = nb;                                                                       \
+        }                                                                                                                     \
+        nb = nb * RFX_K1_OCC / 8;                                                                                             \
+        const int fit = n_cu * (nb > 0 ? nb : 1);                                                                             \
+        grid = dim3(want < fit ? want : fit);                                                                                 \
+        hipLaunchKernelGGL((k1_ssgi_march<P, E, M, S>), grid, block, 0, stream, A);                                           \
+    } while (0)
+#define K1_GO(P, E, M)                            \
+    do {                                          \
+        if (stage == 0) K1_GO_S(P, E, M, 0);      \
+        else if (stage == 1) K1_GO_S(P, E, M, 1); \
+        else K1_GO_S(P, E, M, 2);                 \
     } while (0)
     const bool centred = persp && P[8] == 0.f && P[9] == 0.f;
 #define K1_GO_P(PJ) do { if (mis) K1_GO(PJ, true, true); else if (env) K1_GO(PJ, true, false); else K1_GO(PJ, false, false); } while (0)
@@ -1126,5 +1145,6 @@ hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
     else K1_GO_P(PROJ_GENERAL);
 #undef K1_GO_P
 #undef K1_GO
+#undef K1_GO_S
     return hipGetLastError();
 }

@@ -204,6 +204,7 @@ static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 enum { hipDeviceAttributeMultiprocessorCount = 63 };
 static inline hipError_t hipDeviceGetAttribute(int *v, int, int) { *v = 2; return hipSuccess; }  // a small "chip": the persistent K1 grid is 8 workgroups
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 4; return hipSuccess; }  // (the persistent K1 grid: 4 workgroups per "CU")
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 16; return hipSuccess; }  // every "device" is this host: one rank per device index works
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
