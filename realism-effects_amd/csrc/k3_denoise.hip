@@ -337,8 +337,14 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     }
     const float4 *g_in01 = s_in0 + 2 * koff;  // (PAIR, pass 0: the interleaved pairs, two float4 per texel)
 
-    // no unrolling: occupancy beats ILP here
-#pragma unroll 1
+    // no unrolling by default: occupancy beats ILP here (build knobs: taps per loop iteration of pass 0 / of the later passes)
+#ifndef RFX_K3_UNROLL0
+#define RFX_K3_UNROLL0 1
+#endif
+#ifndef RFX_K3_UNROLLN
+#define RFX_K3_UNROLLN 1
+#endif
+#pragma clang loop unroll_count(IN_TEMPORAL ? RFX_K3_UNROLL0 : RFX_K3_UNROLLN)
     for (int k = 0; k < 8; k++) {
         const float ox = A.tap_ox[k], oy = A.tap_oy[k];  // POISSON[k] / resolution (:91-92,:189), divided once on the host
         // the tap's texture coordinate, every product and sum rounded on its own as in the GLSL (it addresses NEAREST fetches)

@@ -80,6 +80,8 @@ if only.startswith("K1") or not only:  # variants of the exact kernel must not c
     import hashlib
     ctx.ssgi_march(sp)
     print("ssgi sha1", hashlib.sha1(ctx.download(abi.TEX_SSGI).tobytes()).hexdigest()[:16])
-if not only:
+if not only or only.startswith("K3") or only.startswith("K2"):  # (a K2 / K3 variant: the same bits as the in-tree build?)
+    import hashlib
     for _, fn, _b in stages: fn()
+    print("temporal0 sha1", hashlib.sha1(ctx.download(abi.TEX_TEMPORAL0).tobytes()).hexdigest()[:16], "a0 sha1", hashlib.sha1(ctx.download(abi.TEX_DENOISE_A0).tobytes()).hexdigest()[:16])
     print("b0 sha1", hashlib.sha1(ctx.download(abi.TEX_DENOISE_B0).tobytes()).hexdigest()[:16], "compose sha1", hashlib.sha1(ctx.download(abi.TEX_COMPOSE).tobytes()).hexdigest()[:16])
