@@ -146,7 +146,7 @@ RFX_DEV rfx_f2 k3_luma2(rfx_f2 r, rfx_f2 g, rfx_f2 b) {
 template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE, bool FUSE>
 RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     constexpr bool PAIR = RFX_K3_PAIRS && TC == 2;  // the pixel's two accumulators as float2 pairs (k3_apply_pair)
-    extern __shared__ float4 lds[];
+    float4 *lds = (float4 *)hostsim_lds;
     const int Rx = A.tile.Rx, Ry = A.tile.Ry, LW = A.tile.LW, LH = A.tile.LH;
     const int ntex = PITCH * LH;
     float4 *s_geom = lds;
@@ -155,20 +155,6 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     uint4 *s_in2 = reinterpret_cast<uint4 *>(lds + ntex);         // ... and its interleaved form (K3_IL): both accumulators' texels of a position
     constexpr bool K3_IL = RFX_K3_INTERLEAVE != 0;
     float *s_depth = reinterpret_cast<float *>(lds + ntex) + (IN_TEMPORAL ? 8 : 4) * (size_t)ntex;
-    // Pass 0 with two accumulators: the first and last `skip` texels of the staged rectangle — the ends of its first and last row, corners no tap
-    // reaches (the taps lie in an ellipse, k3 launcher) — are not held: at 4K that is 4 of 1036 texels and the difference between two and three
-    // workgroups per CU (53 872 -> 53 744 B; the CU's 160 KiB are handed out in 1 280-byte granules, profiles/r05_microbench/lds_occupancy.txt).
-    // Same arrays under the same indices, moved down by `skip` texels, in the order depth | geometry | inputs: an index inside a shaved corner (only
-    // a tap coordinate that is not a finite number produces one: v_med3_f32 sends a NaN to the window's first texel, +inf to its last) falls
-    // into the 16-byte pad in front of the depth array, into the tail of the array before its own, or into the pad after the last — never
-    // outside the allocation.
-    const int skip = (PAIR && IN_TEMPORAL) ? A.tile.skip : 0;
-    if (PAIR && IN_TEMPORAL && skip > 0) {
-        const int nal = ntex - 2 * skip;  // a multiple of 4 (launcher)
-        s_depth = reinterpret_cast<float *>(lds) + 4 - skip;
-        s_geom = lds + 1 + nal / 4 - skip;
-        s_in0 = lds + 1 + nal / 4 + nal - 2 * skip;
-    }
     const rfx_denoise_params &p = A.p;
     const TileXY tile = rfx_xcd_tile<RFX_K3_XCD_G>((d.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH);
     if (!tile.valid) return;  // grid padding (uniform per workgroup, before any barrier)
@@ -184,7 +170,6 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         // rounding error of the product for these sizes (i < 2^16, LW < 2^8)
         const int ly = (int)(((float)i + 0.5f) * invLW), lx = i - __mul24(ly, LW);
         const int li = __mul24(ly, PITCH) + lx;
-        if (li < skip || li >= ntex - skip) continue;  // a shaved corner (pass 0 only; skip == 0 otherwise)
         const int uy = ty0 - Ry + ly;
         // rows beyond the apron of the last produced row are never addressed (the workgroup may overhang the launch's row range; a
         // row-tiled context does not hold them)
@@ -604,34 +589,13 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
     A.tile.Ry = RFX_K3_WIDE_APRON ? (int)ceilf(ry) + 1 : k3_apron(ry);
     A.tile.LW = TW + 2 * A.tile.Rx;
     A.tile.LH = TH + 2 * A.tile.Ry;
-    A.tile.skip = 0;
     // LDS row pitch: a compile-time constant of the tiled kernels (the footprint's second row is an immediate offset)
 #ifndef RFX_K3_PAD
 #define RFX_K3_PAD 0  // build knob: extra texels per LDS row (bank-mapping experiments, profiles/r04_k3/)
 #endif
     constexpr int PAD = RFX_K3_PAD;
     const int pitch = A.tile.LW <= TW + 8 ? TW + 8 + PAD : A.tile.LW <= TW + 10 ? TW + 10 + PAD : A.tile.LW <= TW + 12 ? TW + 12 + PAD : A.tile.LW <= TW + 16 ? TW + 16 + PAD : A.tile.LW <= TW + 32 ? TW + 32 + PAD : 0;
-    size_t lds = (size_t)pitch * A.tile.LH * (16 + 4 + 2 * (temporal ? 16 : 8));
-#ifndef RFX_K3_SHAVE
-#define RFX_K3_SHAVE 1  // build knob: 0 = pass 0 stages the whole rectangle (A/B measurements; same texels)
-#endif
-    if (RFX_K3_SHAVE && RFX_K3_PAIRS && temporal && A.p.textureCount == 2 && pitch == A.tile.LW && pitch != 0) {
-        // The corners of the staged rectangle no tap reaches: a tap's offset from its pixel, in pixels, lies in the ellipse (dx / rx)^2 + (dy / ry)^2 <= 1
-        // (the rotation acts in UV space, flatness <= 1, |POISSON[k]| <= 1), and the rectangle's first row is addressed only by the tile's first
-        // row of pixels with dy in [-Ry - 0.5, -Ry + 0.5): there |dx| <= rx * sqrt(1 - ((Ry - 0.5) / ry)^2), i.e. a NEAREST tap reaches at most X texels
-        // sideways and the first Rx - X texels of that row (and, mirrored, the last Rx - X of the last row) are never read.  Pass 0 only (the later
-        // passes' LINEAR footprints reach further and their LDS size is nowhere near a granule boundary).
-        const float t = ((float)A.tile.Ry - 0.5f - SLACK) / ry;
-        const int X = (int)floorf(0.5f + rx * sqrtf(fmaxf(0.0f, 1.0f - t * t)) + SLACK);
-        int skip = A.tile.Rx - X;
-        if (skip > 4) skip = 4;  // (the pad in front of the depth array holds four floats)
-        const int ntex = pitch * A.tile.LH;
-        while (skip > 0 && ((ntex - 2 * skip) & 3) != 0) skip--;  // the float4 arrays behind the depth array stay 16-byte aligned
-        if (skip > 0) {
-            A.tile.skip = skip;
-            lds = 16 + (size_t)(ntex - 2 * skip) * (4 + 16 + 32) + (size_t)skip * 32;  // pad | depth | geometry | interleaved inputs | pad
-        }
-    }
+    const size_t lds = (size_t)pitch * A.tile.LH * (16 + 4 + 2 * (temporal ? 16 : 8));
     // at least two workgroups per CU (160 KiB LDS) keep the staging of one tile under the arithmetic of another
     const bool tiled = A.p.radius >= 0.0f && pitch != 0 && lds <= RFX_K3_LDS_MAX;
     // every view the whole frame (a context that owns no row tile): the kernels skip row rebasing and halo accounting

@@ -63,7 +63,7 @@ struct K3Args {
     int shift_x, shift_y;
     TexViewW out0, out1;
     rfx_denoise_params p;
-    struct { int Rx, Ry, LW, LH, skip; } tile;  // filled by the launcher (skip: texels shaved off each end of the staged rectangle, k3_tiled_body)
+    struct { int Rx, Ry, LW, LH; } tile;  // filled by the launcher
     float tap_ox[8], tap_oy[8];           // POISSON[k] / resolution, filled by the launcher
     // the compose draw folded into this launch (rfx_api.hip: the context's deferred last denoise draw met its rfx_compose)
     int fuse_compose;

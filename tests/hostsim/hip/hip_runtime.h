@@ -132,6 +132,14 @@ static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / std::sqrt(x);
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_sinf(float rev) { return (float)std::sin((double)rev * 6.283185307179586476925); }
 static inline float __builtin_amdgcn_cosf(float rev) { return (float)std::cos((double)rev * 6.283185307179586476925); }
+static inline int __builtin_amdgcn_bitop3_b32(int a, int b, int c, unsigned int table) {  // v_bitop3_b32: bit i of the result = table[(a_i << 2) | (b_i << 1) | c_i]
+    unsigned int r = 0;
+    for (int i = 0; i < 32; i++) {
+        const unsigned int idx = ((((unsigned int)a >> i) & 1u) << 2) | ((((unsigned int)b >> i) & 1u) << 1) | (((unsigned int)c >> i) & 1u);
+        r |= ((table >> idx) & 1u) << i;
+    }
+    return (int)r;
+}
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
 typedef __fp16 hostsim_half2 __attribute__((ext_vector_type(2)));
 static inline unsigned short hostsim_f2h_rtz(float f) {  // v_cvt_pkrtz_f16_f32: truncate, finite overflow saturates at 65504
