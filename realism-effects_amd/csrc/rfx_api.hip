@@ -674,7 +674,8 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
     const int base = rfx_k1_base_cell();
     A.coarse_w = (c->W + base - 1) / base;
     A.coarse_h = (c->H + base - 1) / base;
-    // the march's table is kept L1-sized: double the cell edge until it is <= 32 KiB (4K: 32-texel cells, 31.9 KiB)
+    // the march's table lives in every workgroup's LDS (four workgroups per CU): the cell edge is doubled until it fits 36 KiB with its rows
+    // padded to a power of two (4K: 32-texel cells, 128 x 68 cells = 34 KiB)
     const int table_budget = RFX_K1_POW2 ? 36864 : 32768;
     for (A.cell_shift = 4;; A.cell_shift++) {
         A.cells_w = (c->W + (1 << A.cell_shift) - 1) >> A.cell_shift;

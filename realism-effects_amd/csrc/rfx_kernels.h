@@ -7,8 +7,9 @@
 // rows the host asks for, e.g. K1's +-2 rows that K2's neighbourhood clamp reads).
 
 #ifndef RFX_K1_POW2
-#define RFX_K1_POW2 0  // build knob: 1 = the march's (min, max) table has a power-of-two row pitch, so that a tap's LDS address is two shifts and a
-                       // v_bfi_b32 instead of two shifts, a 24-bit multiply-add and a shift (k1_tap_at); the table may then take 36 KiB instead of 32
+#define RFX_K1_POW2 1  // build knob: the march's (min, max) table has a power-of-two row pitch, so that a tap's LDS address is two shifts and one
+                       // v_bitop3_b32 (k1_tap_at); the table may then take 36 KiB instead of 32.  0 = rows of cells_w cells: two shifts, a 24-bit
+                       // multiply-add and a shift (A/B measurements; same texels)
 #endif
 struct K1Args {
     FrameDims dims;
