@@ -284,8 +284,10 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
         # of the unexplained pixels: how many does the implementation compute EXACTLY as the C restatement does (then the open question is
         # the reference GL against the restatement at that pixel — the proof's reach — not the kernel)
         r.unexplained_equal_to_restatement = 0
+        r.unexplained_at = []  # (y, x) of the unexplained pixels the oracle was re-run at
         if r.unexplained and "oracle_at_unexplained" in diag:  # (kept for the stage's other outputs: margins_of clears it)
             idx, obase, omargin = diag["oracle_at_unexplained"]
+            r.unexplained_at = [(int(y), int(x)) for y, x in idx]
             g, w = as_float(got), as_float(want)
             for k, (y, x) in enumerate(idx):
                 c = slice(0, g.shape[-1]) if obase.shape[-1] == g.shape[-1] else slice(0, 0)

@@ -168,12 +168,17 @@ def test_configs4_options_16_frames_stagewise_at_ages_1_6_11_16(blue_noise):
         # restatement disagree there.  Round 4 found one (frame 10, K1, pixel (584, 676): a refine tap 0.0074 texel from the boundary
         # between a surface at z = -8.6 and one at z = -14.3; the GL reads the other texel — 94 ulps of the coordinate, more than any
         # rounding model allows and more than the transcendentals' measured error can move; flipping that ONE sign test in the restatement
-        # reproduces the GL's texel bit for bit).  At most two such pixels in the sequence, none that differs from the restatement.
+        # reproduces the GL's texel bit for bit).  None that differs from the restatement; at 1920 x 1080 exactly that pixel and no other (at the dry-run sizes of the simulator: at most two).
         alike = getattr(r, "unexplained_equal_to_restatement", 0)
         assert r.unexplained - alike == 0, "%s: %d out-of-tolerance pixels the oracle cannot prove unstable, worst %s\n%s" % (r.name, r.unexplained, r.worst_unexplained, r.line())
         open_pixels += r.unexplained
+        # ... and the exception is PINNED: at 1920 x 1080 it is that one pixel of that one stage and frame — measured again at the round-5
+        # kernels (profiles/r05_parity/pytest_gpu_final.log) — not "any two pixels anywhere"
+        if r.unexplained and (W, H) == (1920, 1080):
+            assert r.name == "f10 K1 ssgi" and getattr(r, "unexplained_at", None) == [(584, 676)], "%s: open pixel(s) %s are not the documented one, f10 K1 ssgi (y 584, x 676)\n%s" % (
+                r.name, getattr(r, "unexplained_at", None), r.line())
     print("open pixels (unexplained, kernel == restatement bit for bit): %d" % open_pixels)
-    assert open_pixels <= 2
+    assert open_pixels <= (1 if (W, H) == (1920, 1080) else 2)
     for r in reports:
         kind = r.name.split(" ", 1)[1]
         bound = FLIP_LONG.get(kind, _bound(kind))
