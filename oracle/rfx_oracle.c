@@ -152,7 +152,13 @@ void rfxo_set_margin_plane(float *plane) { g_margin_plane = plane; }
  * whole 4K / 8K frames. */
 static const uint8_t *g_pixel_mask = NULL;
 void rfxo_set_pixel_mask(const uint8_t *mask) { g_pixel_mask = mask; }
-static inline void margin_note(float m) { if (m < g_margin) g_margin = m; }
+/* ... and the same minimum WITHOUT the texel-boundary reach of the march / refine taps (margin_tap below): a second optional plane, so that the tests can
+ * count the pixels whose only proof is that reach (the widened predicate is tracked, not just used) */
+static _Thread_local float g_margin_notap = 3.0e38f;
+static float *g_margin_notap_plane = NULL;
+void rfxo_set_margin_notap_plane(float *plane) { g_margin_notap_plane = plane; }
+static inline void margin_note(float m) { if (m < g_margin) g_margin = m; if (m < g_margin_notap) g_margin_notap = m; }
+static inline void margin_note_tap(float m) { if (m < g_margin) g_margin = m; }
 /* decision `a ? b` between two computed quantities; rel = relative perturbation either side can carry */
 static inline void margin_cmp(float a, float b, float rel) {
     float s = rel * fmaxf(fmaxf(fabsf(a), fabsf(b)), 1e-30f);
@@ -542,7 +548,7 @@ static void margin_tap(const k1_ctx *c, float u, float v, float h, int n_updates
             int n[2] = {idx[0], idx[1]};
             n[a] += side;
             if (dist >= slack || n[a] < 0 || n[a] > size[a] - 1) continue;
-            if (k1_tap_decides(c, k1_view_z(c, c->depth[(size_t)n[1] * c->W + n[0]]), h, kind) != here) margin_note(dist / fmaxf(slack, 1e-30f));
+            if (k1_tap_decides(c, k1_view_z(c, c->depth[(size_t)n[1] * c->W + n[0]]), h, kind) != here) margin_note_tap(dist / fmaxf(slack, 1e-30f));
         }
     }
 }
@@ -1118,9 +1124,10 @@ int rfxo_ssgi(int W, int H, int y0, int y1, const float *depth, const uint32_t *
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < oW; x++) {
             if (g_pixel_mask && !g_pixel_mask[(size_t)y * oW + x]) continue;
-            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; g_fetch_uv = 0.0f; pert_begin(x, y);
+            g_margin = 3.0e38f; g_margin_notap = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; g_fetch_uv = 0.0f; pert_begin(x, y);
             k1_pixel(&c, x, y, out + 4 * ((size_t)y * oW + x));
             if (g_margin_plane) g_margin_plane[(size_t)y * oW + x] = g_margin;
+            if (g_margin_notap_plane) g_margin_notap_plane[(size_t)y * oW + x] = g_margin_notap;
         }
     return 0;
 }
@@ -1357,9 +1364,10 @@ int rfxo_temporal(int W, int H, int y0, int y1, const uint32_t *ssgi, const uint
         for (int x = 0; x < W; x++) {
             size_t o = 4 * ((size_t)y * W + x);
             if (g_pixel_mask && !g_pixel_mask[(size_t)y * W + x]) continue;
-            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; g_fetch_uv = 0.0f; pert_begin(x, y);
+            g_margin = 3.0e38f; g_margin_notap = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; g_fetch_uv = 0.0f; pert_begin(x, y);
             k2_pixel(&c, x, y, out0 + o, out1 ? out1 + o : NULL);
             if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
+            if (g_margin_notap_plane) g_margin_notap_plane[(size_t)y * W + x] = g_margin_notap;
         }
     return 0;
 }
@@ -1475,9 +1483,10 @@ int rfxo_denoise(int W, int H, int y0, int y1, const float *depth, const uint32_
         for (int x = 0; x < W; x++) {
             size_t o = 4 * ((size_t)y * W + x);
             if (g_pixel_mask && !g_pixel_mask[(size_t)y * W + x]) continue;
-            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; g_fetch_uv = 0.0f; pert_begin(x, y);
+            g_margin = 3.0e38f; g_margin_notap = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; g_fetch_uv = 0.0f; pert_begin(x, y);
             k3_pixel(&c, x, y, out0 + o, out1 ? out1 + o : NULL);
             if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
+            if (g_margin_notap_plane) g_margin_notap_plane[(size_t)y * W + x] = g_margin_notap;
         }
     return 0;
 }
@@ -1496,8 +1505,9 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
     for (int y = y0; y < y1; y++)
         for (int x = 0; x < W; x++) {
             if (g_pixel_mask && !g_pixel_mask[(size_t)y * W + x]) continue;
-            g_margin = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; g_fetch_uv = 0.0f; pert_begin(x, y);
+            g_margin = 3.0e38f; g_margin_notap = 3.0e38f; g_fetch_rel = 0.0f; g_fetch_abs = 0.0f; g_fetch_uv = 0.0f; pert_begin(x, y);
             if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
+            if (g_margin_notap_plane) g_margin_notap_plane[(size_t)y * W + x] = g_margin_notap;
             float u = pert_uv(frag_u(x, y, W, H)), v = pert_uv(frag_v(y, W, H));
             float dep = fetch_r32f(depth, d, u, v);
             int qx0 = x & ~1, qx1 = x | 1, qy0 = y & ~1, qy1 = y | 1;
@@ -1555,6 +1565,7 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
             o[2] = diffuseC.z + specC.z + mat.emissive.z;
             o[3] = 1.0f;
             if (g_margin_plane) g_margin_plane[(size_t)y * W + x] = g_margin;
+            if (g_margin_notap_plane) g_margin_notap_plane[(size_t)y * W + x] = g_margin_notap;
         }
     return 0;
 }

@@ -46,13 +46,18 @@ class margins:
 
     def __init__(self, H, W):
         self.plane = np.full((H, W), 3.0e38, np.float32)
+        # the same minimum without the texel-boundary reach of K1's march / refine taps (rfx_oracle.c margin_tap): plane < 1 <= plane_notap marks a
+        # fragment whose only recorded instability is that reach
+        self.plane_notap = np.full((H, W), 3.0e38, np.float32)
 
     def __enter__(self):
         lib().rfxo_set_margin_plane(_p(self.plane))
+        lib().rfxo_set_margin_notap_plane(_p(self.plane_notap))
         return self
 
     def __exit__(self, *exc):
         lib().rfxo_set_margin_plane(None)
+        lib().rfxo_set_margin_notap_plane(None)
         return False
 
 

@@ -237,9 +237,13 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
             with O.margins(H, W) as mm:
                 base = picked(fn())
             unstable_sel |= mm.plane.reshape(-1)[sel] < 1.0
+            # ... of which: recorded ONLY by the texel-boundary reach of a march / refine tap (rfx_oracle.c margin_tap — the predicate round 4 widened)
+            tap_only_sel = unstable_sel & ~(mm.plane_notap.reshape(-1)[sel] < 1.0)
             for seed in range(1, n_perturb + 1):
                 with O.perturbation(seed):
-                    unstable_sel |= out_of_tolerance(picked(fn())[None], base[None], half, UNSTABLE_TOL_SCALE)[0]
+                    moved = out_of_tolerance(picked(fn())[None], base[None], half, UNSTABLE_TOL_SCALE)[0]
+                    unstable_sel |= moved
+                    tap_only_sel &= ~moved  # a perturbed re-evaluation moves it too: not "only" the reach
         # an out-of-tolerance pixel the first seeds did not move gets more draws (random signs per call: a flip that needs one particular
         # combination of signs is found with probability < 1 per seed) — only those few pixels are re-evaluated
         bad_sel = bad.reshape(-1)[sel]
@@ -256,6 +260,7 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
         unstable = np.zeros(H * W, bool)
         unstable[sel] = unstable_sel
         unstable = unstable.reshape(H, W)
+        diag["explained_only_by_tap_reach"] = int((tap_only_sel & bad.reshape(-1)[sel]).sum())
         left = bad & ~unstable
         if left.any():  # diagnostics for the test log: what the oracle itself computes at the pixels nobody could explain
             li = np.flatnonzero(left.reshape(-1))[:6]
@@ -296,8 +301,10 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
                 log("    unexplained (y %d, x %d) margin %.3g\n      impl   %s\n      ref    %s\n      oracle %s" % (
                     y, x, omargin[k], np.array2string(g[y - y0, x], precision=6), np.array2string(w[y - y0, x], precision=6),
                     np.array2string(obase[k], precision=6)))
+        #  how many of the explained out-of-tolerance pixels rest on the tap-reach margin alone: tracked per stage output, printed when not 0
+        r.explained_only_by_tap_reach = diag.get("explained_only_by_tap_reach", 0)
         reports.append(r)
-        log(r.line())
+        log(r.line() + ("   [%d of the explained only by a march / refine tap's texel-boundary reach]" % r.explained_only_by_tap_reach if r.explained_only_by_tap_reach else ""))
         return r
 
     for fi in range(frames):
