@@ -42,7 +42,7 @@ constexpr int K1_WAVES = 8;            // wavefronts per workgroup of the persis
 #define RFX_K1_STATIC_TILES 0  // build knob: 1 = no counters, wave w takes tiles w, w + nwaves, ... (A/B measurements)
 #endif
 constexpr int K1_COUNTERS = RFX_K1_COUNTERS;
-constexpr int K1_TABLE_CELLS = RFX_K1_POW2 ? 9216 : 8192;   // 32 KiB (36 with a power-of-two row pitch): rfx_api keeps the table within it for every frame size (cell edge doubled until it fits)
+constexpr int K1_TABLE_CELLS = 9216;   // 36 KiB: rfx_api keeps the table within it for every frame size (cell edge doubled until it fits)
 RFX_DEV uint32_t k1_half_toward(float v, bool up) {  // nearest half not below (up) / not above (!up) v
     uint32_t h = rfx_f2h_rne(v) & 0xffffu;
     const float f = rfx_h2f((unsigned short)h);
@@ -55,7 +55,7 @@ RFX_DEV uint32_t k1_half_toward(float v, bool up) {  // nearest half not below (
 }
 RFX_DEV k1_cell_t k1_cell_pack(float mn, float mx) { return k1_half_toward(mn, false) | (k1_half_toward(mx, true) << 16); }
 RFX_DEV float2 k1_cell_load(const k1_cell_t *t, unsigned int i) {  // t: the workgroup's LDS copy of the table; i: Tap::cell
-    const uint32_t v = RFX_K1_POW2 ? *(const k1_cell_t *)((const char *)t + i) : t[i];
+    const uint32_t v = *(const k1_cell_t *)((const char *)t + i);
     return make_float2(rfx_h2f((unsigned short)(v & 0xffffu)), rfx_h2f((unsigned short)(v >> 16)));
 }
 
@@ -64,7 +64,7 @@ struct MarchCtx {
     const float *viewz;        // full-frame view-space Z plane (k1_prepare)
     const k1_cell_t *coarse;   // (min, max) view Z per 2^cell_shift-texel cell: the LDS copy
     int coarse_w, cell_shift;  // cells per table row, log2 of the cell edge
-    unsigned int cell_xmask;   // RFX_K1_POW2: the bits of a cell's byte offset that come from the column, ((pitch - 1) << 2)
+    unsigned int cell_xmask;   // PROJ_TABLE_POW2: the bits of a cell's byte offset that come from the column, ((pitch - 1) << 2)
     int cell_xshift, cell_yshift;  // ... and the two shifts of k1_tap_at
     float rayDistance, thickness;
     int steps, refineSteps;
@@ -84,8 +84,14 @@ RFX_DEV float k1_div(float x, float w, float r) {
 // PROJ 2: additionally P[8] == P[9] == 0 (a centred frustum: every three.js PerspectiveCamera without a view offset) — the products
 // P8 z, P9 z are zeros and adding them changes at most the sign of a zero numerator, which the * 0.5 + 0.5 below erases.
 constexpr int PROJ_GENERAL = 0, PROJ_PERSPECTIVE = 1, PROJ_CENTRED = 2;
-template <int PROJ>
+// ... and, as bit 2 of the same template argument (it reaches every function of the march already), the layout of the (min, max) table:
+// PROJ_TABLE_POW2 = its rows are padded to a power of two (K1Args::cells_pow2; k1_tap_at).  A launch-time choice: no branch in the march.
+constexpr int PROJ_TABLE_POW2 = 4;
+constexpr int k1_proj_kind(int proj) { return proj & 3; }
+constexpr bool k1_table_pow2(int proj) { return (proj & PROJ_TABLE_POW2) != 0; }
+template <int PROJ_T>
 RFX_DEV float2 k1_project(const MarchCtx &m, float3 p) {
+    constexpr int PROJ = k1_proj_kind(PROJ_T);
     float px, py, pw;
     if (PROJ == PROJ_CENTRED) {
         px = m.P[0] * p.x;
@@ -107,38 +113,41 @@ RFX_DEV float2 k1_project(const MarchCtx &m, float3 p) {
 
 struct Tap {
     unsigned int idx;   // texel index into the view-Z plane (32-bit byte offsets from the wave-uniform base: the plane is < 4 GiB)
-    unsigned int cell;  // index into the (min, max) table (RFX_K1_POW2: the cell's byte offset)
+    unsigned int cell;  // the cell's byte offset in the (min, max) table
 };
+template <bool P2>
 RFX_DEV Tap k1_tap_at(const MarchCtx &m, const FrameDims &d, int xi, int yi) {
     Tap t;
     t.idx = (unsigned int)(__mul24(yi, d.W) + xi);  // rows and widths are < 2^23: the full-rate 24-bit multiply-add
-    if (RFX_K1_POW2) {
+    if (P2) {
         // the cell's BYTE offset ((yi >> s) << (k + 2)) | ((xi >> s) << 2) with a row pitch of 2^k cells, k >= s >= 2: the column bits are bits
         // 2 .. k+1 of xi >> (s - 2), everything above them bits k+2 .. of yi << (k + 2 - s) (whose low two bits are zero)
         const unsigned int a = (unsigned int)xi >> m.cell_xshift, b = (unsigned int)yi << m.cell_yshift;
         t.cell = (unsigned int)__builtin_amdgcn_bitop3_b32((int)a, (int)b, (int)m.cell_xmask, 0xE4);  // (a & mask) | (b & ~mask) as ONE v_bitop3_b32 (truth table 0xE4)
     } else {
-        t.cell = (unsigned int)(__mul24(yi >> m.cell_shift, m.coarse_w) + (xi >> m.cell_shift));
+        t.cell = (unsigned int)(__mul24(yi >> m.cell_shift, m.coarse_w) + (xi >> m.cell_shift)) << 2;
     }
     return t;
 }
+template <bool P2>
 RFX_DEV Tap k1_tap(const MarchCtx &m, const FrameDims &d, float2 uv) {
-    return k1_tap_at(m, d, rfx_nearest_idx(uv.x, d.fW, d.W), rfx_nearest_idx(uv.y, d.fH, d.H));
+    return k1_tap_at<P2>(m, d, rfx_nearest_idx(uv.x, d.fW, d.W), rfx_nearest_idx(uv.y, d.fH, d.H));
 }
 // The taps of both rays of a march step.  rfx_nearest_idx guards every coordinate against |u * size| >= 2^31 (texel 0 in the reference: x86
 // cvttss2si) with a compare and a select; a projected uv is that large only when a sample falls within ~1e-6 of the
 // camera plane, so the test is made ONCE per step for the whole wavefront (three v_max on the four coordinates, one compare) and the guarded
 // form runs in the wavefronts that need it.  v_med3_f32 sends a NaN to 0 as the guard does.  Same indices in every case.
+template <bool P2>
 RFX_DEV void k1_taps(const MarchCtx &m, const FrameDims &d, const float2 (&uv)[2], Tap (&tap)[2]) {
     const float cx0 = uv[0].x * d.fW, cy0 = uv[0].y * d.fH, cx1 = uv[1].x * d.fW, cy1 = uv[1].y * d.fH;
     const float big = fmaxf(fmaxf(fabsf(cx0), fabsf(cy0)), fmaxf(fabsf(cx1), fabsf(cy1)));
     if (__builtin_amdgcn_ballot_w64(big >= 2147483648.0f) != 0) {
-        tap[0] = k1_tap(m, d, uv[0]);
-        tap[1] = k1_tap(m, d, uv[1]);
+        tap[0] = k1_tap<P2>(m, d, uv[0]);
+        tap[1] = k1_tap<P2>(m, d, uv[1]);
     } else {
         const float wm1 = (float)(d.W - 1), hm1 = (float)(d.H - 1);
-        tap[0] = k1_tap_at(m, d, (int)__builtin_amdgcn_fmed3f(cx0, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy0, 0.0f, hm1));
-        tap[1] = k1_tap_at(m, d, (int)__builtin_amdgcn_fmed3f(cx1, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy1, 0.0f, hm1));
+        tap[0] = k1_tap_at<P2>(m, d, (int)__builtin_amdgcn_fmed3f(cx0, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy0, 0.0f, hm1));
+        tap[1] = k1_tap_at<P2>(m, d, (int)__builtin_amdgcn_fmed3f(cx1, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy1, 0.0f, hm1));
     }
 }
 struct Ray {
@@ -194,7 +203,7 @@ RFX_DEV void k1_march_step(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
     bool need[2];
     {
         const float2 uvs[2] = {rays[0].uv, rays[1].uv};
-        k1_taps(m, d, uvs, tap);
+        k1_taps<k1_table_pow2(PROJ)>(m, d, uvs, tap);
     }
 #pragma unroll
     for (int r = 0; r < 2; r++) mm[r] = RFX_K1_ABLATE >= 2 ? make_float2(__uint_as_float(tap[r].cell), rays[r].uv.x) : k1_cell_load(m.coarse, tap[r].cell);
@@ -252,7 +261,7 @@ RFX_DEV k1_f2 k1_mk2(float a, float b) { k1_f2 r; r.x = a; r.y = b; return r; }
 // k1_march_step<PROJ, CS1> on a RayPair (PROJ_CENTRED / PROJ_PERSPECTIVE only: the general projection keeps the scalar form)
 template <int PROJ, bool CS1>
 RFX_DEV void k1_march_step_pair(const MarchCtx &m, const FrameDims &d, RayPair &R, float cs) {
-    static_assert(PROJ == PROJ_CENTRED || PROJ == PROJ_PERSPECTIVE, "pair form: perspective projections");
+    static_assert(k1_proj_kind(PROJ) == PROJ_CENTRED || k1_proj_kind(PROJ) == PROJ_PERSPECTIVE, "pair form: perspective projections");
     if (CS1) {  // pos + dir * live as one fma per coordinate (the product is exact)
         R.px = __builtin_elementwise_fma(R.dx, R.live, R.px);
         R.py = __builtin_elementwise_fma(R.dy, R.live, R.py);
@@ -265,7 +274,7 @@ RFX_DEV void k1_march_step_pair(const MarchCtx &m, const FrameDims &d, RayPair &
     }
     {   // k1_project<PROJ>
         k1_f2 qx, qy;
-        if (PROJ == PROJ_CENTRED) {
+        if (k1_proj_kind(PROJ) == PROJ_CENTRED) {
             qx = m.P[0] * R.px;
             qy = m.P[5] * R.py;
         } else {
@@ -286,12 +295,12 @@ RFX_DEV void k1_march_step_pair(const MarchCtx &m, const FrameDims &d, RayPair &
         const k1_f2 cx = R.u * d.fW, cy = R.v * d.fH;
         const float big = fmaxf(fmaxf(fabsf(cx.x), fabsf(cy.x)), fmaxf(fabsf(cx.y), fabsf(cy.y)));
         if (__builtin_amdgcn_ballot_w64(big >= 2147483648.0f) != 0) {
-            tap[0] = k1_tap(m, d, make_float2(R.u.x, R.v.x));
-            tap[1] = k1_tap(m, d, make_float2(R.u.y, R.v.y));
+            tap[0] = k1_tap<k1_table_pow2(PROJ)>(m, d, make_float2(R.u.x, R.v.x));
+            tap[1] = k1_tap<k1_table_pow2(PROJ)>(m, d, make_float2(R.u.y, R.v.y));
         } else {
             const float wm1 = (float)(d.W - 1), hm1 = (float)(d.H - 1);
-            tap[0] = k1_tap_at(m, d, (int)__builtin_amdgcn_fmed3f(cx.x, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy.x, 0.0f, hm1));
-            tap[1] = k1_tap_at(m, d, (int)__builtin_amdgcn_fmed3f(cx.y, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy.y, 0.0f, hm1));
+            tap[0] = k1_tap_at<k1_table_pow2(PROJ)>(m, d, (int)__builtin_amdgcn_fmed3f(cx.x, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy.x, 0.0f, hm1));
+            tap[1] = k1_tap_at<k1_table_pow2(PROJ)>(m, d, (int)__builtin_amdgcn_fmed3f(cx.y, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy.y, 0.0f, hm1));
         }
     }
     const float2 mm0 = k1_cell_load(m.coarse, tap[0].cell), mm1 = k1_cell_load(m.coarse, tap[1].cell);
@@ -328,7 +337,7 @@ RFX_DEV void k1_refine_pairs(const MarchCtx &m, const FrameDims &d, Ray (&rays)[
         float2 mm[2];
         bool need[2], behind[2];
 #pragma unroll
-        for (int r = 0; r < 2; r++) tap[r] = k1_tap(m, d, rays[r].uv);
+        for (int r = 0; r < 2; r++) tap[r] = k1_tap<k1_table_pow2(PROJ)>(m, d, rays[r].uv);
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             need[r] = rays[r].hit;
@@ -386,7 +395,7 @@ RFX_DEV void k1_refine_packed(const MarchCtx &m, const FrameDims &d, Ray (&rays)
     float2 uv = make_float2(0.f, 0.f);
     for (int k = 0; k < m.refineSteps; k++) {
         if (mine) uv = k1_project<PROJ>(m, pos);
-        const Tap tap = k1_tap(m, d, uv);
+        const Tap tap = k1_tap<k1_table_pow2(PROJ)>(m, d, uv);
         const float2 mm = k1_cell_load(m.coarse, tap.cell);
         const float h = pos.z;
         const bool below = mm.y - h < 0.0f;             // diff < 0 everywhere in the cell
@@ -428,7 +437,7 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
     }
     const int split = RFX_K1_CS1 ? min(m.steps, 9) : m.steps;
     int i = RFX_K1_ABLATE >= 3 ? m.steps : 1;
-    if constexpr (RFX_K1_PAIRS && PROJ != PROJ_GENERAL && RFX_K1_MERGE_GATHERS && !RFX_K1_ABLATE) {
+    if constexpr (RFX_K1_PAIRS && k1_proj_kind(PROJ) != PROJ_GENERAL && RFX_K1_MERGE_GATHERS && !RFX_K1_ABLATE) {
         RayPair R;
         R.px = k1_mk2(rays[0].pos.x, rays[1].pos.x); R.py = k1_mk2(rays[0].pos.y, rays[1].pos.y); R.pz = k1_mk2(rays[0].pos.z, rays[1].pos.z);
         R.dx = k1_mk2(rays[0].dir.x, rays[1].dir.x); R.dy = k1_mk2(rays[0].dir.y, rays[1].dir.y); R.dz = k1_mk2(rays[0].dir.z, rays[1].dir.z);
@@ -685,7 +694,7 @@ RFX_DEV void k1_ssgi_march_body(const K1Args &A, const FrameDims &d, const k1_ce
     m.cell_shift = A.cell_shift;
     m.cell_xmask = (unsigned int)(A.cells_pitch - 1) << 2;
     m.cell_xshift = A.cell_shift - 2;
-    m.cell_yshift = A.cells_pitch_log2 + 2 - A.cell_shift;
+    m.cell_yshift = A.cells_pow2 ? A.cells_pitch_log2 + 2 - A.cell_shift : 0;
     m.rayDistance = p.rayDistance;
     m.thickness = p.thickness;
     m.steps = p.steps;
@@ -1167,9 +1176,12 @@ hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
     } while (0)
     const bool centred = persp && P[8] == 0.f && P[9] == 0.f;
 #define K1_GO_P(PJ) do { if (mis) K1_GO(PJ, true, true); else if (env) K1_GO(PJ, true, false); else K1_GO(PJ, false, false); } while (0)
-    if (centred) K1_GO_P(PROJ_CENTRED);
-    else if (persp) K1_GO_P(PROJ_PERSPECTIVE);
-    else K1_GO_P(PROJ_GENERAL);
+    // (the table's layout is a template argument too: PROJ_TABLE_POW2)
+#define K1_GO_T(PJ) do { if (A.cells_pow2) K1_GO_P((PJ) | PROJ_TABLE_POW2); else K1_GO_P(PJ); } while (0)
+    if (centred) K1_GO_T(PROJ_CENTRED);
+    else if (persp) K1_GO_T(PROJ_PERSPECTIVE);
+    else K1_GO_T(PROJ_GENERAL);
+#undef K1_GO_T
 #undef K1_GO_P
 #undef K1_GO
 #undef K1_GO_S

@@ -674,22 +674,36 @@ static int ssgi_draw(rfx_ctx *c, const rfx_ssgi_params *p, int stage) {
     const int base = rfx_k1_base_cell();
     A.coarse_w = (c->W + base - 1) / base;
     A.coarse_h = (c->H + base - 1) / base;
-    // the march's table lives in every workgroup's LDS (four workgroups per CU): the cell edge is doubled until it fits 36 KiB with its rows
-    // padded to a power of two (4K: 32-texel cells, 128 x 68 cells = 34 KiB)
-    const int table_budget = RFX_K1_POW2 ? 36864 : 32768;
-    for (A.cell_shift = 4;; A.cell_shift++) {
-        A.cells_w = (c->W + (1 << A.cell_shift) - 1) >> A.cell_shift;
-        A.cells_h = (c->H + (1 << A.cell_shift) - 1) >> A.cell_shift;
-        A.cells_pitch = A.cells_w;
-        A.cells_pitch_log2 = 0;
-        if (RFX_K1_POW2) {  // (at least 2^cell_shift cells per row: k1_tap_at's shifts are then left shifts)
-            A.cells_pitch_log2 = A.cell_shift;
-            while ((1 << A.cells_pitch_log2) < A.cells_w) A.cells_pitch_log2++;
-            A.cells_pitch = 1 << A.cells_pitch_log2;
+    // the march's table lives in every workgroup's LDS (four workgroups per CU): the cell edge is doubled until the table fits.  Two layouts
+    // (k1_tap_at): rows padded to a power of two, at least 2^cell_shift cells — a tap's LDS address is then two shifts and one v_bitop3_b32 — when
+    // that fits the 36 KiB at the SAME cell size as plain rows of cells_w cells would (4K: 32-texel cells, 128 x 68 cells = 34 KiB; every 16:9
+    // frame); plain rows otherwise (an ultrawide frame, a frame taller than 9216 rows: the padded table of such a frame holds at least H cells)
+    const int table_budget = 36864;
+    const auto k1_table = [&](int shift, bool pow2, int &cw, int &ch, int &pitch, int &pitch_log2) {
+        cw = (c->W + (1 << shift) - 1) >> shift;
+        ch = (c->H + (1 << shift) - 1) >> shift;
+        pitch = cw;
+        pitch_log2 = 0;
+        if (pow2) {
+            pitch_log2 = shift;  // (at least 2^cell_shift cells per row: the row term of k1_tap_at is then a LEFT shift by >= 2)
+            while ((1 << pitch_log2) < cw) pitch_log2++;
+            pitch = 1 << pitch_log2;
         }
-        A.cells_vec4 = (A.cells_pitch * A.cells_h + 3) / 4;
-        if ((size_t)A.cells_vec4 * 16 <= (size_t)table_budget || A.cell_shift >= 12) break;
+        return (size_t)((pitch * ch + 3) / 4) * 16;  // bytes, whole uint4s
+    };
+    A.cells_pow2 = 0;
+    for (A.cell_shift = 4;; A.cell_shift++) {
+        if (k1_table(A.cell_shift, false, A.cells_w, A.cells_h, A.cells_pitch, A.cells_pitch_log2) <= (size_t)table_budget || A.cell_shift >= 12) break;
     }
+    if (RFX_K1_POW2) {
+        int cw, ch, pitch, pl2;
+        if (k1_table(A.cell_shift, true, cw, ch, pitch, pl2) <= (size_t)table_budget) {
+            A.cells_pow2 = 1;
+            A.cells_pitch = pitch;
+            A.cells_pitch_log2 = pl2;
+        }
+    }
+    A.cells_vec4 = (A.cells_pitch * A.cells_h + 3) / 4;
     if (!c->viewz) {
         hipError_t e = hipMalloc((void **)&c->viewz, (size_t)c->W * c->H * sizeof(float));
         if (e == hipSuccess) e = hipMalloc((void **)&c->coarse, (size_t)A.coarse_w * A.coarse_h * sizeof(float2));

@@ -7,9 +7,9 @@
 // rows the host asks for, e.g. K1's +-2 rows that K2's neighbourhood clamp reads).
 
 #ifndef RFX_K1_POW2
-#define RFX_K1_POW2 1  // build knob: the march's (min, max) table has a power-of-two row pitch, so that a tap's LDS address is two shifts and one
-                       // v_bitop3_b32 (k1_tap_at); the table may then take 36 KiB instead of 32.  0 = rows of cells_w cells: two shifts, a 24-bit
-                       // multiply-add and a shift (A/B measurements; same texels)
+#define RFX_K1_POW2 1  // build knob: the march's (min, max) table gets a power-of-two row pitch where that costs no cell size, so that a tap's LDS address
+                       // is two shifts and one v_bitop3_b32 (k1_tap_at).  0 = always rows of cells_w cells: two shifts, a 24-bit multiply-add and a shift
+                       // (A/B measurements; same texels)
 #endif
 struct K1Args {
     FrameDims dims;
@@ -25,7 +25,8 @@ struct K1Args {
     int coarse_w, coarse_h;
     unsigned int *cells;  // the march's table: two halfs per 2^cell_shift-texel cell, padded to whole uint4s (k1_pack_cells)
     int cells_w, cells_h, cell_shift, cells_vec4;
-    int cells_pitch, cells_pitch_log2;  // cells per table row: cells_w, or (RFX_K1_POW2) the next power of two, at least 2^cell_shift — k1_tap_at
+    int cells_pitch, cells_pitch_log2;  // cells per table row: cells_w, or (cells_pow2) the next power of two, at least 2^cell_shift — k1_tap_at
+    int cells_pow2;                     // the table's rows are padded to a power of two (rfx_api: when that fits at the same cell size)
     // scene.environment: all mip levels as float4 texels, level l (max(w>>l,1) x max(h>>l,1)) at env + env_off[l]
     const float4 *env;
     int env_w, env_h, env_levels;

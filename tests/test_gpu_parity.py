@@ -120,6 +120,30 @@ def test_chain_stagewise_vs_oracle(blue_noise, size, steps, refine, missed):
     hip.close()
 
 
+def test_ssgi_on_a_frame_whose_cell_table_keeps_plain_rows(blue_noise):
+    """K1's (min, max) table has two layouts (rfx_api.hip, k1_tap_at): rows padded to a power of two where that fits its 36 KiB at the same cell
+    size (every 16:9 frame: the other tests), plain rows otherwise.  528 x 2400 is such a frame: 33 x 150 sixteen-texel cells fit, 64 x 150 do
+    not — the march then runs the kernels instantiated without PROJ_TABLE_POW2.  One frame of K1 against the oracle, every flip proven."""
+    from rfx_amd import abi
+    from rfx_amd.scene import synthetic_frame
+    import rfx_oracle as O
+    import stagewise as S
+
+    W, H = 528, 2400
+    assert ((W + 15) // 16) * ((H + 15) // 16) <= 9216 < 64 * ((H + 15) // 16)  # (plain rows fit, padded rows do not: the case this test is for)
+    hip, ora = S.HipStages(W, H, blue_noise), S.OracleStages(W, H, blue_noise)
+    comp = np.zeros((H, W, 4), np.float32)
+    h8 = lambda o: O.half_bits_to_float(np.ascontiguousarray(o).view(np.uint16))  # noqa: E731
+    f = synthetic_frame(W, H, 0)
+    sp, _, _, _ = _params(abi, f, f.camera, 0.0, 20, 5, 0)
+    hip.frame(f)
+    ora.frame(f)
+    sp.blueNoiseIndex = 1000
+    o = ora.ssgi(comp, sp)
+    assert_close("ssgi (plain-row table)", h8(hip.ssgi(comp, sp)), h8(o), FLIP["ssgi"], prove=lambda: h8(ora.ssgi(comp, sp)))
+    hip.close()
+
+
 class _LocalTiles:
     """N row-tile contexts on ONE device with host-staged halos: the single-process stand-in for
     rfx_amd.tiling.TiledRenderer (which needs one process per GPU).  Exercises the kernels' tile
