@@ -8,7 +8,7 @@
 // things keep them off the HBM / fabric path:
 //   * k1_prepare (one streaming pre-pass per draw) converts the depth plane to VIEW-SPACE Z once per texel (the same IEEE expression every tap
 //     would evaluate, ssgi_utils.frag:9) and reduces it to exact 16x16-texel (min, max) cells, which k1_pack_cells folds into a table of
-//     half-packed cells of at most 36 KiB with a power-of-two row pitch (4K: 32-texel cells, 128 x 68 = 34 KiB);
+//     half-packed cells of at most 36 KiB, its rows padded to a power of two where that fits (4K: 32-texel cells, 128 x 68 = 34 KiB);
 //   * every tap first consults its cell: when the cell's range proves the texel cannot satisfy `0 <= z - hitPos.z < thickness` (RayMarch :463)
 //     — or fixes the sign BinarySearch tests (:493) — the exact texel is never fetched.  The decision is exact, not approximate: fp
 //     subtraction is monotonic, so the cell bounds bound the per-texel difference.
@@ -23,7 +23,7 @@ namespace {
 
 // The (min, max) view-Z table the march consults before touching a texel: one 4-byte cell = two halfs, min rounded
 // DOWN and max rounded UP, so a widened range can only reject fewer taps — the rejection tests stay exact.  The cell edge is
-// 2^cell_shift texels, chosen per frame size so that the whole table, rows padded to a power of two, stays <= 36 KiB (rfx_api; 4K: 32-texel cells): every workgroup of the
+// 2^cell_shift texels, chosen per frame size so that the whole table stays <= 36 KiB (rfx_api, which also picks the row layout; 4K: 32-texel cells): every workgroup of the
 // march keeps its own copy in LDS.
 constexpr int BASE = 16;  // edge of the pre-pass's exact (float) cells, reduced to the final cells by k1_pack_cells
 #ifndef RFX_K1_TH
