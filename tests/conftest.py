@@ -13,7 +13,7 @@ for p in (os.path.join(ROOT, "realism-effects_amd"), os.path.join(ROOT, "oracle"
 HOSTSIM_NEEDS_HARDWARE = ("test_bench_multi_rank_flow_on_one_gpu",)
 # ... and the ones whose frame is too large for kernels executed thread by thread on the CPU (minutes per draw)
 HOSTSIM_TOO_LARGE = ("configs[4] 8K", "streamed_dumps_equal_uploaded_dumps[3840-2160") + (
-    () if os.environ.get("RFX_TEST_SEQ_SIZE") else ("16_frames_ages_and_free_running",))  # (1080p x 16 frames: 9 minutes on the simulator; RFX_TEST_SEQ_SIZE=160x90 runs its logic)
+    () if os.environ.get("RFX_TEST_SEQ_SIZE") else ("_16_frames",))  # (1080p x 16 frames: 9 minutes on the simulator; RFX_TEST_SEQ_SIZE=160x90 runs its logic)
 
 
 def hostsim_child_env(sim, build="_build"):

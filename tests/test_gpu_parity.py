@@ -120,17 +120,18 @@ def test_chain_stagewise_vs_oracle(blue_noise, size, steps, refine, missed):
     hip.close()
 
 
-def test_ssgi_on_a_frame_whose_cell_table_keeps_plain_rows(blue_noise):
+@pytest.mark.parametrize("W,H,padded_pitch", [(528, 2400, 64), (64, 9300, 16)])
+def test_ssgi_on_a_frame_whose_cell_table_keeps_plain_rows(blue_noise, W, H, padded_pitch):
     """K1's (min, max) table has two layouts (rfx_api.hip, k1_tap_at): rows padded to a power of two where that fits its 36 KiB at the same cell
     size (every 16:9 frame: the other tests), plain rows otherwise.  528 x 2400 is such a frame: 33 x 150 sixteen-texel cells fit, 64 x 150 do
-    not — the march then runs the kernels instantiated without PROJ_TABLE_POW2.  One frame of K1 against the oracle, every flip proven."""
+    not; so is anything taller than 9216 rows (a padded row holds at least 2^cell_shift cells: 16 x 582 for a 64 x 9300 strip) — the march then runs
+    the kernels instantiated without PROJ_TABLE_POW2.  One frame of K1 against the oracle, every flip proven."""
     from rfx_amd import abi
     from rfx_amd.scene import synthetic_frame
     import rfx_oracle as O
     import stagewise as S
 
-    W, H = 528, 2400
-    assert ((W + 15) // 16) * ((H + 15) // 16) <= 9216 < 64 * ((H + 15) // 16)  # (plain rows fit, padded rows do not: the case this test is for)
+    assert ((W + 15) // 16) * ((H + 15) // 16) <= 9216 < padded_pitch * ((H + 15) // 16)  # (plain rows fit, padded rows do not: the case this test is for)
     hip, ora = S.HipStages(W, H, blue_noise), S.OracleStages(W, H, blue_noise)
     comp = np.zeros((H, W, 4), np.float32)
     h8 = lambda o: O.half_bits_to_float(np.ascontiguousarray(o).view(np.uint16))  # noqa: E731
