@@ -99,9 +99,11 @@ static inline unsigned int __builtin_amdgcn_mbcnt_hi(unsigned int mask, unsigned
     const unsigned int lane = hostsim_tid() & 63u;
     return base + (lane > 32 ? (unsigned int)__builtin_popcount(mask & ((1u << (lane - 32)) - 1u)) : 0u);
 }
+extern size_t hostsim_last_shmem;  // dynamic shared memory the most recent launch asked for (tests read it: rfx_hostsim_last_dynamic_lds)
 template <class F>
 static void hostsim_launch(dim3 grid, dim3 block, size_t shmem, F body) {
     const long nblocks = (long)grid.x * grid.y * grid.z;
+    hostsim_last_shmem = shmem;
 #pragma omp parallel for schedule(dynamic, 4)
     for (long b = 0; b < nblocks; b++) {
         static thread_local unsigned char *lds = nullptr;

@@ -19,6 +19,8 @@ extern "C" void __sanitizer_finish_switch_fiber(void *fake_stack_save, const voi
 
 // bench.py asks the loaded library whether it is this simulator (no device to select, drain or profile then)
 extern "C" int rfx_hostsim_build(void) { return 1; }
+size_t hostsim_last_shmem = 0;
+extern "C" unsigned long long rfx_hostsim_last_dynamic_lds(void) { return (unsigned long long)hostsim_last_shmem; }
 
 thread_local hostsim_idx threadIdx, blockIdx, blockDim, gridDim;
 thread_local unsigned char *hostsim_lds = nullptr;

@@ -39,6 +39,47 @@ def test_differential_fuzz_of_the_kernels_against_the_oracle():
     assert "0 problems" in p.stdout.splitlines()[-1]
 
 
+@pytest.mark.skipif(not os.path.exists(CLANG) or shutil.which("make") is None, reason="no host clang++ / make")
+def test_k3_pass0_asks_for_an_lds_size_that_fits_three_times_into_a_cu():
+    """The launcher's own arithmetic, executed: on a 16:9 frame at radius 3 the first denoise pass of two textures must ask for no more dynamic LDS
+    than fits THREE times into a CU's 160 KiB handed out in 1 280-byte granules (measured: profiles/r05_microbench/lds_occupancy.txt) — 53 744 B since
+    the staged rectangle's unreachable corners are not held, 53 872 B (two workgroups per CU, pass 0 13 % slower) before.  The later passes: 43 776 B."""
+    sim = os.path.join(ROOT, "tests", "hostsim")
+    subprocess.check_call(["make", "-s", "-C", sim])
+    code = (
+        "import sys, ctypes\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "import numpy as np\n"
+        "from rfx_amd import abi\n"
+        "from rfx_amd.context import Context\n"
+        "from rfx_amd.scene import synthetic_frame\n"
+        "W, H = 256, 144\n"
+        "f = synthetic_frame(W, H, 0)\n"
+        "ctx = Context(W, H)\n"
+        "ctx.upload_frame(f)\n"
+        "ctx.upload(abi.TEX_TEMPORAL0, np.ones((H, W, 4), np.float32)); ctx.upload(abi.TEX_TEMPORAL1, np.ones((H, W, 4), np.float32))\n"
+        "dp = abi.DenoiseParams(radius=3, phi=0.5, lumaPhi=5, depthPhi=2, normalPhi=50, roughnessPhi=50, specularPhi=50, textureCount=2, blueNoiseIndex=5,\n"
+        "                       inputIsTemporal=1, writeToB=0, halfStoreRTZ=1)\n"
+        "dp.isTextureSpecular[:] = [0, 1]\n"
+        "lib = abi.load_library()\n"
+        "lib.rfx_hostsim_last_dynamic_lds.restype = ctypes.c_ulonglong\n"
+        "ctx.poisson_denoise(dp); ctx.sync(); a = lib.rfx_hostsim_last_dynamic_lds()\n"
+        "dp.inputIsTemporal, dp.writeToB = 0, 1\n"
+        "ctx.poisson_denoise(dp); ctx.sync(); b = lib.rfx_hostsim_last_dynamic_lds()\n"
+        "print(a, b)\n"
+    ) % (os.path.join(ROOT, "realism-effects_amd"), os.path.join(ROOT, "tests"))
+    from conftest import hostsim_child_env
+    env = dict(os.environ, **hostsim_child_env(sim))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    pass0, later = (int(v) for v in p.stdout.split()[-2:])
+    granule, cu = 1280, 160 * 1024
+    fits = lambda nbytes: cu // (-(-nbytes // granule) * granule)  # noqa: E731  workgroups of that LDS size per CU
+    assert pass0 == 16 + (74 * 14 - 4) * 52 + 64 == 53744 and fits(pass0) == 3, (pass0, fits(pass0))
+    assert later == 76 * 16 * 36 == 43776 and fits(later) == 3, (later, fits(later))
+    assert fits(74 * 14 * 52) == 2  # (what the whole rectangle would ask for)
+
+
 def test_comm_entry_points_without_a_loadable_rccl_report_unsupported():
     """rfx_comm.hip binds RCCL with dlopen at first use; a host without it must get RFX_EUNSUPPORTED from every exchange entry point, not a
     crash (round 2's loader built its message from two dlerror() calls: the second returns NULL -> std::string + nullptr).  The simulator
