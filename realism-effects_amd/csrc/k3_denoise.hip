@@ -32,7 +32,8 @@ static_assert(TW % 64 == 0 && NT <= 1024, "a tile row is whole wavefronts; at mo
 #define RFX_K3_XCD_G 1  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major
 #endif
 #ifndef RFX_K3_LDS_MAX
-#define RFX_K3_LDS_MAX (80 * 1024)  // build knob: dynamic LDS a tiled launch may ask for (80 KiB: two workgroups per CU; 160 KiB is the CU's)
+#define RFX_K3_LDS_MAX (80 * 1024)  // build knob: dynamic LDS a tiled launch may ask for (80 KiB: at least two workgroups per CU; the CU has 160 KiB, handed out in
+                                    // 1 280-byte granules: <= 53 760 B fit three times, <= 40 960 B four times — profiles/r05_microbench/lds_occupancy.txt)
 #endif
 // The tile is staged with an apron of (Rx, Ry) texels.  The reference rotates the Poisson offsets in UV space
 // (`rm * (offset / resolution)`, poisson_denoise.frag:183-189), so on a W x H frame a tap lies within
@@ -632,7 +633,7 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
             lds = 16 + (size_t)(ntex - 2 * skip) * (4 + 16 + 32) + (size_t)skip * 32;  // pad | depth | geometry | interleaved inputs | pad
         }
     }
-    // at least two workgroups per CU (160 KiB LDS) keep the staging of one tile under the arithmetic of another
+    // at least two workgroups per CU (160 KiB LDS) keep the staging of one tile under the arithmetic of another (4K: three of either pass kind)
     const bool tiled = A.p.radius >= 0.0f && pitch != 0 && lds <= RFX_K3_LDS_MAX;
     // every view the whole frame (a context that owns no row tile): the kernels skip row rebasing and halo accounting
     const auto whole_view = [&](const void *ptr, int row0, int rows) { return ptr == nullptr || (row0 == 0 && rows == A.dims.H); };
