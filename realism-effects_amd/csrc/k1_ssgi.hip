@@ -26,22 +26,10 @@ namespace {
 // 2^cell_shift texels, chosen per frame size so that the whole table stays <= 36 KiB (rfx_api, which also picks the row layout; 4K: 32-texel cells): every workgroup of the
 // march keeps its own copy in LDS.
 constexpr int BASE = 16;  // edge of the pre-pass's exact (float) cells, reduced to the final cells by k1_pack_cells
-#ifndef RFX_K1_TH
-#define RFX_K1_TH 1  // build knob: rows of 64 pixels per tile a wavefront takes from its queue
-#endif
-constexpr int K1_TH = RFX_K1_TH;
+constexpr int K1_TH = 1;               // rows of 64 pixels per tile a wavefront takes from its queue (2 / 4 measured slower: profiles/r04_k1)
 typedef uint32_t k1_cell_t;
 constexpr int K1_WAVES = 8;            // wavefronts per workgroup of the persistent march kernel
-#ifndef RFX_K1_COUNTERS
-#define RFX_K1_COUNTERS 64  // build knob: tile queues of the persistent march kernel (power of two, <= 64)
-#endif
-#ifndef RFX_K1_XCD_G
-#define RFX_K1_XCD_G 0  // build knob: tile rows per XCD group of the queues' dealing (0 = launch order dealt round-robin); k1_ssgi_march
-#endif
-#ifndef RFX_K1_STATIC_TILES
-#define RFX_K1_STATIC_TILES 0  // build knob: 1 = no counters, wave w takes tiles w, w + nwaves, ... (A/B measurements)
-#endif
-constexpr int K1_COUNTERS = RFX_K1_COUNTERS;
+constexpr int K1_COUNTERS = 64;        // tile queues of the persistent march kernel (one queue: +1/3 time; XCD-grouped or static dealing: slower — profiles/r04_k1, r05_k1)
 constexpr int K1_TABLE_CELLS = 9216;   // 36 KiB: rfx_api keeps the table within it for every frame size (cell edge doubled until it fits)
 RFX_DEV uint32_t k1_half_toward(float v, bool up) {  // nearest half not below (up) / not above (!up) v
     uint32_t h = rfx_f2h_rne(v) & 0xffffu;
@@ -156,29 +144,7 @@ struct Ray {
     float live;  // 1.0f while the ray marches, 0.0f once it has hit (or never existed): the step's scale factor, see k1_march_rays
     bool hit;
 };
-#ifndef RFX_K1_CS1
-#define RFX_K1_CS1 1  // build knob: 0 = evaluate cs(i) in every step (A/B measurements; same texels either way)
-#endif
-#ifndef RFX_K1_WAVE_LOOP
-#define RFX_K1_WAVE_LOOP 0  // build knob: 1 = the march loops are wave-uniform (every lane steps until no lane of the wavefront has a live ray), 0 = per lane
-#endif
-#if RFX_K1_WAVE_LOOP
-#define K1_ANY_LIVE(rays) (__builtin_amdgcn_ballot_w64(((rays)[0].live != 0.0f) | ((rays)[1].live != 0.0f)) != 0)
-#else
 #define K1_ANY_LIVE(rays) (((rays)[0].live != 0.0f) | ((rays)[1].live != 0.0f))
-#endif
-#ifndef RFX_K1_MERGE_GATHERS
-#define RFX_K1_MERGE_GATHERS 1  // build knob: both rays' exact-texel fetches of a step under one exec mask, one wait
-#endif
-#ifndef RFX_K1_ABLATE
-#define RFX_K1_ABLATE 0  // measurement knob (WRONG pixels): 1 = never fetch an exact texel, 2 = ... nor a cell, 3 = no march at all
-#endif
-#ifndef RFX_K1_HIT_IN_REGION
-#define RFX_K1_HIT_IN_REGION 1  // build knob: 0 = the hit tests of a march step are made outside the exact-texel exec region, in every step (A/B measurements; same texels)
-#endif
-#ifndef RFX_K1_GATHER_ALWAYS
-#define RFX_K1_GATHER_ALWAYS 0  // build knob: 1 = the exact texel is loaded in every step (texel 0 when the cell decides) instead of under an exec mask
-#endif
 // One march step of both rays.  CS1: the step's cs is exactly 1 (see below) — the position update is then pos + dir * live with an exact
 // product, i.e. ONE fma per coordinate with the same bits.
 template <int PROJ, bool CS1>
@@ -206,16 +172,17 @@ RFX_DEV void k1_march_step(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         k1_taps<k1_table_pow2(PROJ)>(m, d, uvs, tap);
     }
 #pragma unroll
-    for (int r = 0; r < 2; r++) mm[r] = RFX_K1_ABLATE >= 2 ? make_float2(__uint_as_float(tap[r].cell), rays[r].uv.x) : k1_cell_load(m.coarse, tap[r].cell);
+    for (int r = 0; r < 2; r++) mm[r] = k1_cell_load(m.coarse, tap[r].cell);
 #pragma unroll
     for (int r = 0; r < 2; r++) {  // (bitwise on purpose: no short-circuit branches in the loop)
         const float h = rays[r].pos.z;
         need[r] = (rays[r].live != 0.0f) & !((mm[r].y - h < 0.0f) | (mm[r].x - h >= m.thickness));
-        if (RFX_K1_ABLATE >= 1) need[r] = need[r] & (h == 12345.0f);
     }
-#if RFX_K1_HIT_IN_REGION && RFX_K1_MERGE_GATHERS && !RFX_K1_ABLATE
-    // ... and the hit tests inside the same exec region: a step in which no lane of the wavefront needs an exact texel (most steps of most
-    // wavefronts) executes neither the fetches nor the two rays' subtract / compare / compare / select
+    // ONE exec region and ONE wait for both rays' exact texels (a random 4-byte gather over a 33 MB plane each); a lane that needs only one of its
+    // two texels fetches that one twice (the same address: no extra cache line).  The hit tests live inside the same region: a step in which no
+    // lane of the wavefront needs an exact texel (most steps of most wavefronts) executes neither the fetches nor the two rays' subtract /
+    // compare / compare / select.  (Per-ray regions, tests outside the region, unconditional fetches and the step on (ray 0, ray 1) float2
+    // pairs were all built and measured, same texels, none faster: profiles/r04_k1, profiles/r05_k1, profiles/r06_cleanup.)
     if (need[0] | need[1]) {
         const unsigned int i0 = need[0] ? tap[0].idx : tap[1].idx, i1 = need[1] ? tap[1].idx : tap[0].idx;
         const float z0 = rfx_gather<float>(m.viewz, i0), z1 = rfx_gather<float>(m.viewz, i1);
@@ -223,100 +190,6 @@ RFX_DEV void k1_march_step(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         rays[0].live = (need[0] & (d0 >= 0.0f) & (d0 < m.thickness)) ? 0.0f : rays[0].live;  // a hit: the ray stops here
         rays[1].live = (need[1] & (d1 >= 0.0f) & (d1 < m.thickness)) ? 0.0f : rays[1].live;
     }
-    return;
-#endif
-    float z[2] = {0.0f, 0.0f};
-#if RFX_K1_MERGE_GATHERS
-    // ONE exec region and ONE wait for both rays' exact texels (a random 4-byte gather over a 33 MB plane each) instead of a region and a
-    // wait per ray.  A lane that needs only one of its two texels fetches that one twice (the same address: no extra cache line).  Not
-    // faster than two regions — the waits are not what the exact fetches cost — and not slower (profiles/r04_k1).
-    if (need[0] | need[1]) {
-        const unsigned int i0 = need[0] ? tap[0].idx : tap[1].idx, i1 = need[1] ? tap[1].idx : tap[0].idx;
-        z[0] = rfx_gather<float>(m.viewz, i0);
-        z[1] = rfx_gather<float>(m.viewz, i1);
-    }
-#else
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        if (RFX_K1_GATHER_ALWAYS) z[r] = rfx_gather<float>(m.viewz, need[r] ? tap[r].idx : 0u);
-        else z[r] = need[r] ? rfx_gather<float>(m.viewz, tap[r].idx) : 0.0f;
-    }
-#endif
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const float diff = z[r] - rays[r].pos.z;
-        rays[r].live = (need[r] & (diff >= 0.0f) & (diff < m.thickness)) ? 0.0f : rays[r].live;  // a hit: the ray stops here
-    }
-}
-#ifndef RFX_K1_PAIRS
-#define RFX_K1_PAIRS 0  // build knob (off: measured SLOWER, K1 0.530 -> 0.556 ms at 4K, profiles/r05_k1): 1 = the march step's float arithmetic on (diffuse ray, specular ray) PAIRS — v_pk_fma / mul / add_f32, 4.5 issue cycles
-                        // for two results against 2 x 2.7 (profiles/r03_microbench); every lane operation is the IEEE one k1_march_step makes: same texels (sha1)
-#endif
-// The two rays of a pixel as structure-of-pairs: lane .x = slot 0 (optional diffuse ray), .y = slot 1 (specular ray)
-typedef float k1_f2 __attribute__((ext_vector_type(2)));
-struct RayPair {
-    k1_f2 px, py, pz, dx, dy, dz, u, v, live;
-};
-RFX_DEV k1_f2 k1_mk2(float a, float b) { k1_f2 r; r.x = a; r.y = b; return r; }
-// k1_march_step<PROJ, CS1> on a RayPair (PROJ_CENTRED / PROJ_PERSPECTIVE only: the general projection keeps the scalar form)
-template <int PROJ, bool CS1>
-RFX_DEV void k1_march_step_pair(const MarchCtx &m, const FrameDims &d, RayPair &R, float cs) {
-    static_assert(k1_proj_kind(PROJ) == PROJ_CENTRED || k1_proj_kind(PROJ) == PROJ_PERSPECTIVE, "pair form: perspective projections");
-    if (CS1) {  // pos + dir * live as one fma per coordinate (the product is exact)
-        R.px = __builtin_elementwise_fma(R.dx, R.live, R.px);
-        R.py = __builtin_elementwise_fma(R.dy, R.live, R.py);
-        R.pz = __builtin_elementwise_fma(R.dz, R.live, R.pz);
-    } else {
-        const k1_f2 csr = cs * R.live;
-        R.px = R.px + R.dx * csr;
-        R.py = R.py + R.dy * csr;
-        R.pz = R.pz + R.dz * csr;
-    }
-    {   // k1_project<PROJ>
-        k1_f2 qx, qy;
-        if (k1_proj_kind(PROJ) == PROJ_CENTRED) {
-            qx = m.P[0] * R.px;
-            qy = m.P[5] * R.py;
-        } else {
-            qx = m.P[0] * R.px + m.P[8] * R.pz;
-            qy = m.P[5] * R.py + m.P[9] * R.pz;
-        }
-        const k1_f2 pw = -R.pz;
-        const k1_f2 r = k1_mk2(rfx_rcp(pw.x), rfx_rcp(pw.y));
-        const k1_f2 q0 = qx * r, q1 = qy * r;  // k1_div: q = x * r; fma(fma(-w, q, x), r, q)
-        const k1_f2 dvx = __builtin_elementwise_fma(__builtin_elementwise_fma(-pw, q0, qx), r, q0);
-        const k1_f2 dvy = __builtin_elementwise_fma(__builtin_elementwise_fma(-pw, q1, qy), r, q1);
-        const k1_f2 half = k1_mk2(0.5f, 0.5f);
-        R.u = __builtin_elementwise_fma(dvx, half, half);
-        R.v = __builtin_elementwise_fma(dvy, half, half);
-    }
-    Tap tap[2];
-    {   // k1_taps
-        const k1_f2 cx = R.u * d.fW, cy = R.v * d.fH;
-        const float big = fmaxf(fmaxf(fabsf(cx.x), fabsf(cy.x)), fmaxf(fabsf(cx.y), fabsf(cy.y)));
-        if (__builtin_amdgcn_ballot_w64(big >= 2147483648.0f) != 0) {
-            tap[0] = k1_tap<k1_table_pow2(PROJ)>(m, d, make_float2(R.u.x, R.v.x));
-            tap[1] = k1_tap<k1_table_pow2(PROJ)>(m, d, make_float2(R.u.y, R.v.y));
-        } else {
-            const float wm1 = (float)(d.W - 1), hm1 = (float)(d.H - 1);
-            tap[0] = k1_tap_at<k1_table_pow2(PROJ)>(m, d, (int)__builtin_amdgcn_fmed3f(cx.x, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy.x, 0.0f, hm1));
-            tap[1] = k1_tap_at<k1_table_pow2(PROJ)>(m, d, (int)__builtin_amdgcn_fmed3f(cx.y, 0.0f, wm1), (int)__builtin_amdgcn_fmed3f(cy.y, 0.0f, hm1));
-        }
-    }
-    const float2 mm0 = k1_cell_load(m.coarse, tap[0].cell), mm1 = k1_cell_load(m.coarse, tap[1].cell);
-    // a hit needs 0 <= z - h < thickness: the cell rules it out when max - h < 0 or min - h >= thickness
-    const k1_f2 dmax = k1_mk2(mm0.y, mm1.y) - R.pz, dmin = k1_mk2(mm0.x, mm1.x) - R.pz;
-    const bool need0 = (R.live.x != 0.0f) & !((dmax.x < 0.0f) | (dmin.x >= m.thickness));
-    const bool need1 = (R.live.y != 0.0f) & !((dmax.y < 0.0f) | (dmin.y >= m.thickness));
-    k1_f2 z = k1_mk2(0.0f, 0.0f);
-    if (need0 | need1) {  // one exec region and one wait for both rays' exact texels (k1_march_step)
-        const unsigned int i0 = need0 ? tap[0].idx : tap[1].idx, i1 = need1 ? tap[1].idx : tap[0].idx;
-        z.x = rfx_gather<float>(m.viewz, i0);
-        z.y = rfx_gather<float>(m.viewz, i1);
-    }
-    const k1_f2 diff = z - R.pz;
-    R.live.x = (need0 & (diff.x >= 0.0f) & (diff.x < m.thickness)) ? 0.0f : R.live.x;  // a hit: the ray stops here
-    R.live.y = (need1 & (diff.y >= 0.0f) & (diff.y < m.thickness)) ? 0.0f : R.live.y;
 }
 // BinarySearch (:477-503) for the pixel's two rays in their two slots (rays that did not hit idle along): the form used when the wavefront's
 // hit rays do not fit one per lane
@@ -368,9 +241,6 @@ RFX_DEV void k1_refine_pairs(const MarchCtx &m, const FrameDims &d, Ray (&rays)[
     for (int r = 0; r < 2; r++)
         if (rays[r].hit) rays[r].uv = k1_project<PROJ>(m, rays[r].pos);
 }
-#ifndef RFX_K1_COMPACT_REFINE
-#define RFX_K1_COMPACT_REFINE 1  // build knob: 0 = always refine in the two slots (A/B measurements; same texels)
-#endif
 // ... and ONE ray per lane: of the 128 ray slots of a wavefront typically 35-45 hold a ray that hit, and the five refinement steps cost a
 // fifth of K1's instructions with most lanes idle in both slots.  When all 64 lanes are here and at most 63 rays hit, the hit rays are
 // packed into lanes 0 .. n-1 (ds_permute: lane i sends slot r's position and direction to lane rank_r; a lane without that ray sends to lane
@@ -425,7 +295,7 @@ RFX_DEV void k1_refine_packed(const MarchCtx &m, const FrameDims &d, Ray (&rays)
 //     evaluates no cs at all (no v_exp, no products), the same bits.
 // Other forms of this loop that were built and measured, all with the same texels and all slower (profiles/r04_k1, profiles/r05_k1): packing a
 // wavefront's live rays one per lane through the LDS crossbar once they fit, marching two steps per iteration with the second speculated
-// under the first's fetches, and the step's arithmetic on (ray 0, ray 1) float2 pairs (k1_march_step_pair, RFX_K1_PAIRS).
+// under the first's fetches, and the step's arithmetic on (ray 0, ray 1) float2 pairs (profiles/r06_cleanup/k1_rejected_variants.patch).
 template <int PROJ>
 RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2], float random_b) {
     const float scale = m.rayDistance / (float)m.steps;
@@ -435,33 +305,8 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         rays[r].dir = rays[r].dir * scale;
         rays[r].uv = make_float2(0.f, 0.f);
     }
-    const int split = RFX_K1_CS1 ? min(m.steps, 9) : m.steps;
-    int i = RFX_K1_ABLATE >= 3 ? m.steps : 1;
-    if constexpr (RFX_K1_PAIRS && k1_proj_kind(PROJ) != PROJ_GENERAL && RFX_K1_MERGE_GATHERS && !RFX_K1_ABLATE) {
-        RayPair R;
-        R.px = k1_mk2(rays[0].pos.x, rays[1].pos.x); R.py = k1_mk2(rays[0].pos.y, rays[1].pos.y); R.pz = k1_mk2(rays[0].pos.z, rays[1].pos.z);
-        R.dx = k1_mk2(rays[0].dir.x, rays[1].dir.x); R.dy = k1_mk2(rays[0].dir.y, rays[1].dir.y); R.dz = k1_mk2(rays[0].dir.z, rays[1].dir.z);
-        R.u = k1_mk2(0.f, 0.f); R.v = k1_mk2(0.f, 0.f);
-        R.live = k1_mk2(rays[0].live, rays[1].live);
-#if RFX_K1_WAVE_LOOP
-#define K1_ANY_LIVE2(R) (__builtin_amdgcn_ballot_w64(((R).live.x != 0.0f) | ((R).live.y != 0.0f)) != 0)
-#else
-#define K1_ANY_LIVE2(R) (((R).live.x != 0.0f) | ((R).live.y != 0.0f))
-#endif
-        for (; i < split && K1_ANY_LIVE2(R); i++) {
-            const float t = (float)i + random_b - 0.5f;
-            const float cs = 1.0f - rfx_exp2((t * t) * (-0.25f * 1.4426950408889634f));  // (see the scalar loop below)
-            k1_march_step_pair<PROJ, false>(m, d, R, cs);
-        }
-        for (; i < m.steps && K1_ANY_LIVE2(R); i++) k1_march_step_pair<PROJ, true>(m, d, R, 1.0f);
-#undef K1_ANY_LIVE2
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            rays[r].pos = make_float3(R.px[r], R.py[r], R.pz[r]);
-            rays[r].uv = make_float2(R.u[r], R.v[r]);
-            rays[r].live = R.live[r];
-        }
-    } else {
+    const int split = min(m.steps, 9);
+    int i = 1;
     for (; i < split && K1_ANY_LIVE(rays); i++) {
         const float t = (float)i + random_b - 0.5f;
         // exp(-0.25 t^2) = exp2((-0.25 t^2) log2e): the scaling by -1/4 is exact, so it folds into the constant (one product instead of two,
@@ -470,7 +315,6 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         k1_march_step<PROJ, false>(m, d, rays, cs);
     }
     for (; i < m.steps && K1_ANY_LIVE(rays); i++) k1_march_step<PROJ, true>(m, d, rays, 1.0f);
-    }
 #pragma unroll
     for (int r = 0; r < 2; r++) rays[r].hit = started[r] & (rays[r].live == 0.0f);
     // (a wavefront none of whose rays hit — sky above the horizon, a wall facing away — has nothing to refine)
@@ -478,7 +322,7 @@ RFX_DEV void k1_march_rays(const MarchCtx &m, const FrameDims &d, Ray (&rays)[2]
         const unsigned long long h0 = __ballot(rays[0].hit), h1 = __ballot(rays[1].hit);
         const int n0 = __popcll(h0), n1 = __popcll(h1);
         if (n0 + n1 == 0) {
-        } else if (RFX_K1_COMPACT_REFINE && n0 + n1 <= 63 && __ballot(1) == ~0ull) {
+        } else if (n0 + n1 <= 63 && __ballot(1) == ~0ull) {
             k1_refine_packed<PROJ>(m, d, rays, h0, h1, n0, n1);
         } else {
             k1_refine_pairs<PROJ>(m, d, rays);
@@ -838,40 +682,21 @@ __global__ __launch_bounds__(64 * K1_WAVES) RFX_WAVES_PER_EU(ENV ? 1 : 8) void k
     const int lane = threadIdx.x & 63;
     const unsigned int nbx = (unsigned int)(A.out_w + 63) / 64u, nby = (unsigned int)(A.y1 - A.y0 + K1_TH - 1) / (unsigned int)K1_TH, ntiles = nbx * nby;
     // Every wavefront takes tiles from one of K1_COUNTERS device queues; workgroup b serves queue b % K1_COUNTERS (the same-address atomics of the
-    // whole chip are spread over K1_COUNTERS cache lines: one counter for all 8192 waves costs the launch a third more time, profiles/r04_k1).  The next tile's number is requested before this tile's work: the wavefront never waits
-    // for the atomic.  Which tiles a queue holds (k1_tile_of):
-    //   RFX_K1_XCD_G == 0: tiles in launch order dealt round-robin to the queues — every queue holds tiles of every image region, so the
-    //     queues drain together; but hardware workgroup b runs on XCD b % 8, so every XCD marches tiles from all over the frame and each of
-    //     the eight L2s ends up fetching the same view-Z and history lines (FETCH_SIZE 2.8x the algorithmic bytes, profiles/r04_final);
-    //   RFX_K1_XCD_G == G: the eight queues an XCD's workgroups serve share every 8th GROUP of G tile rows, walked row by row and dealt tile
-    //     by tile to the eight — the ~1000 wavefronts resident on an XCD then march one compact band of rows whose rays read neighbouring
-    //     texels, while groups of all image regions stay interleaved over the XCDs (a band per XCD measured slower: XCDs that own sky idle).
+    // whole chip are spread over K1_COUNTERS cache lines: one counter for all 8192 waves costs the launch a third more time, profiles/r04_k1).  The
+    // next tile's number is requested before this tile's work: the wavefront never waits for the atomic.  A queue holds the tiles n * nq + first in
+    // launch order — tiles of every image region, so the queues drain together.  (Dealing compact row bands to the queues an XCD serves, or a band per
+    // XCD, or static tiles without counters, all measured slower: the fabric reads follow the wavefronts in flight, not the XCD a tile lands on —
+    // profiles/r05_k1/summary.txt; the code: profiles/r06_cleanup/k1_rejected_variants.patch.)
     const unsigned int nq = min((unsigned int)K1_COUNTERS, gridDim.x);  // (a small launch has fewer workgroups than queues: every queue needs a server)
     const unsigned int first = blockIdx.x % nq;
     unsigned int *counter = A.tile_counter + first * 32u;  // 128 bytes apart
-    const bool xcd_groups = RFX_K1_XCD_G > 0 && (nq & 7u) == 0u;
     // n-th tile of this workgroup's queue -> (bx, by); false: the queue is exhausted
     const auto k1_tile_of = [&](unsigned int n, unsigned int &bx, unsigned int &by) -> bool {
-        if (xcd_groups) {
-            const unsigned int xcd = first & 7u, sub = first >> 3, nsub = nq >> 3, per = (unsigned int)(RFX_K1_XCD_G > 0 ? RFX_K1_XCD_G : 1) * nbx;
-            const unsigned int m = n * nsub + sub, j = m / per, w = m - j * per, r = w / nbx;
-            by = (j * 8u + xcd) * (unsigned int)(RFX_K1_XCD_G > 0 ? RFX_K1_XCD_G : 1) + r;
-            bx = w - r * nbx;
-            if (by < nby) return true;
-            // the last group may be ragged: rows beyond the frame are skipped, later groups of this XCD do not exist
-            return false;
-        }
         const unsigned int tile = n * nq + first;
         by = tile / nbx;
         bx = tile - by * nbx;
         return tile < ntiles;
     };
-#if RFX_K1_STATIC_TILES
-    const unsigned int nwaves = gridDim.x * (unsigned int)K1_WAVES;
-    unsigned int tile = blockIdx.x * (unsigned int)K1_WAVES + (threadIdx.x >> 6);
-    while (tile < ntiles) {
-        const unsigned int by = tile / nbx, bx = tile - by * nbx;
-#else
     unsigned int n = 0;
     if (lane == 0) n = atomicAdd(counter, 1u);
     n = (unsigned int)__builtin_amdgcn_readfirstlane((int)n);
@@ -879,18 +704,13 @@ __global__ __launch_bounds__(64 * K1_WAVES) RFX_WAVES_PER_EU(ENV ? 1 : 8) void k
     while (k1_tile_of(n, bx, by)) {
         unsigned int next = 0;
         if (lane == 0) next = atomicAdd(counter, 1u);
-#endif
         const int x = (int)bx * 64 + lane, y0 = A.y0 + (int)by * K1_TH;
 #pragma unroll 1
         for (int r = 0; r < K1_TH; r++) {
             k1_ssgi_march_body<PROJ, ENV, MIS, STAGE>(RFX_KERNARGS_IN_LOOP(A), d, s_cells, x, y0 + r);
             RFX_WAVE_JOIN();  // background / out-of-frame lanes left the body early: the wavefront is whole again here
         }
-#if RFX_K1_STATIC_TILES
-        tile += nwaves;
-#else
         n = (unsigned int)__builtin_amdgcn_readfirstlane((int)next);
-#endif
     }
     rfx_flush_violations(d);
 }
@@ -1009,46 +829,6 @@ __global__ __launch_bounds__(256) void k1_prepare(const float *depth, float *vie
     if ((threadIdx.x & (BASE / VEC - 1)) == 0 && cx < base_w) base[(size_t)cy * base_w + cx] = make_float2(mn, mx);
 }
 
-#ifndef RFX_K1_PREPASS_V1
-#define RFX_K1_PREPASS_V1 0  // build knob: 1 = the pre-pass of rounds 1-4 (one texel per thread, LDS reduction) for A/B measurements; same planes
-#endif
-#if RFX_K1_PREPASS_V1
-__global__ __launch_bounds__(64 * BASE) void k1_prepare_v1(const float *depth, float *viewz, float2 *base, int W, int H, int base_w, float nearMulFar,
-                                                           float farMinusNear, float cameraFar, float nearMinusFar, float cameraNear, int perspective) {
-    constexpr int CPR = 64 / BASE;  // cells per block row
-    __shared__ float s_min[BASE][CPR], s_max[BASE][CPR];
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * BASE + threadIdx.y;
-    float z = 0.0f;
-    const bool in = x < W && y < H;
-    if (in) {
-        const float dpt = depth[(size_t)y * W + x];
-        z = perspective ? nearMulFar / (farMinusNear * dpt - cameraFar) : dpt * nearMinusFar - cameraNear;
-        viewz[(size_t)y * W + x] = z;
-    }
-    float mn = in ? z : INFINITY, mx = in ? z : -INFINITY;
-#pragma unroll
-    for (int o = 1; o < BASE; o <<= 1) {
-        mn = fminf(mn, __shfl_xor(mn, o));
-        mx = fmaxf(mx, __shfl_xor(mx, o));
-    }
-    if ((threadIdx.x & (BASE - 1)) == 0) {
-        s_min[threadIdx.y][threadIdx.x / BASE] = mn;
-        s_max[threadIdx.y][threadIdx.x / BASE] = mx;
-    }
-    __syncthreads();
-    if (threadIdx.y == 0 && threadIdx.x < CPR) {
-        float a = s_min[0][threadIdx.x], b = s_max[0][threadIdx.x];
-#pragma unroll
-        for (int r = 1; r < BASE; r++) {
-            a = fminf(a, s_min[r][threadIdx.x]);
-            b = fmaxf(b, s_max[r][threadIdx.x]);
-        }
-        const int cx = blockIdx.x * CPR + threadIdx.x;
-        if (cx < base_w) base[(size_t)blockIdx.y * base_w + cx] = make_float2(a, b);
-    }
-}
-#endif
-
 // ... and the march's table: cell (cx, cy) of edge BASE << up = the (min, max) of its (1 << up)^2 base cells, packed to two halfs
 __global__ __launch_bounds__(256) void k1_pack_cells(const float2 *base, int base_w, int base_h, k1_cell_t *cells, int cells_w, int cells_h, int cells_pitch, int up,
                                                      int cells_padded, unsigned int *tile_counter) {
@@ -1117,17 +897,12 @@ hipError_t rfx_launch_k1_prepare(const K1Args &A, hipStream_t stream) {
     // 16-byte loads when every row starts 16-byte aligned (the planes come from hipMalloc: the pitch decides)
     const int W = A.dims.W, H = A.dims.H;
     const dim3 block(64, 4);
-#if RFX_K1_PREPASS_V1
-    hipLaunchKernelGGL(k1_prepare_v1, dim3((W + 63) / 64, (H + BASE - 1) / BASE), dim3(64, BASE), 0, stream, (const float *)A.depth.ptr, A.viewz, A.coarse, W, H, A.coarse_w, A.nearMulFar,
-                       A.farMinusNear, A.p.camera.far_, A.nearMinusFar, A.p.camera.near_, A.p.camera.isPerspective);
-#else
     if (W % 4 == 0 && ((uintptr_t)A.depth.ptr & 15u) == 0 && ((uintptr_t)A.viewz & 15u) == 0)  // (a caller's depth buffer may sit at any address)
         hipLaunchKernelGGL(k1_prepare<4>, dim3((W + 255) / 256, ((H + BASE - 1) / BASE + 3) / 4), block, 0, stream, (const float *)A.depth.ptr, A.viewz, A.coarse, W, H, A.coarse_w,
                            A.nearMulFar, A.farMinusNear, A.p.camera.far_, A.nearMinusFar, A.p.camera.near_, A.p.camera.isPerspective);
     else
         hipLaunchKernelGGL(k1_prepare<1>, dim3((W + 63) / 64, ((H + BASE - 1) / BASE + 3) / 4), block, 0, stream, (const float *)A.depth.ptr, A.viewz, A.coarse, W, H, A.coarse_w,
                            A.nearMulFar, A.farMinusNear, A.p.camera.far_, A.nearMinusFar, A.p.camera.near_, A.p.camera.isPerspective);
-#endif
     int up = 0;
     while ((BASE << up) < (1 << A.cell_shift)) up++;
     const int padded = A.cells_vec4 * 4;
@@ -1140,10 +915,6 @@ hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
     // persistent: what the chip holds at once (4 workgroups of 8 waves per CU at <= 64 VGPRs; fewer fit with an environment map — the
     // surplus workgroups start late and find the counter exhausted), never more workgroups than there are tiles for their waves
     const int nbx = (A.out_w + 63) / 64, nby = (A.y1 - A.y0 + K1_TH - 1) / K1_TH;
-#ifndef RFX_K1_OCC
-#define RFX_K1_OCC 8  // measurement knob: eighths of the chip's resident workgroups the persistent grid is sized for (8 = all; 6 / 4 / 2 are slower and read
-                      // less from the fabric: profiles/r04_k1/k_occupancy_double_step.txt, profiles/r05_k1/summary.txt)
-#endif
     const int want = (nbx * nby + K1_WAVES - 1) / K1_WAVES, n_cu = A.n_cu > 0 ? A.n_cu : 256;
     dim3 block(64 * K1_WAVES), grid(1);
     const float *P = A.p.camera.projectionMatrix;
@@ -1163,7 +934,6 @@ hipError_t rfx_launch_k1(const K1Args &A, int stage, hipStream_t stream) {
                 nb = 32 / K1_WAVES;                                                                                           \
             if (dev >= 0 && dev < 64) per_cu[dev] = nb;                                                                       \
         }                                                                                                                     \
-        nb = nb * RFX_K1_OCC / 8;                                                                                             \
         const int fit = n_cu * (nb > 0 ? nb : 1);                                                                             \
         grid = dim3(want < fit ? want : fit);                                                                                 \
         hipLaunchKernelGGL((k1_ssgi_march<P, E, M, S>), grid, block, 0, stream, A);                                           \

@@ -8,21 +8,21 @@
 // texel, so the (2r+1)^2 neighbourhood AABB of both textures (up to 50 taps per pixel) and the 2x2-quad
 // derivatives read LDS instead of re-fetching and re-unpacking global texels.  The history taps
 // (5 bilinear taps x 2 textures at the reprojected uv) and the validation fetch stay global gathers:
-// their position is data dependent.  (The AABB as column reductions exchanged between lanes with DPP wave shifts — 30 LDS reads per pixel instead
+// their position is data dependent.  A tap's y-lerp and the weighted sum of the five taps are written on (r, g) / (b, a) float2 PAIRS (k2_f2:
+// v_pk_add / mul / fma_f32, 4.5 issue cycles for two results against 2 x 2.7; the x-lerps read halfs in place and stay scalar): every lane
+// operation is the IEEE one of the scalar form and this file is compiled without contraction — the same bits (sha1 of both targets at 4K),
+// K2 0.324 -> 0.314 ms (profiles/r06_k2/; the bicubic weights as an (u, v) pair and the log-space colours as (r, g) + b on top of it: 80 VGPRs, no
+// faster).  (The AABB as column reductions exchanged between lanes with DPP wave shifts — 30 LDS reads per pixel instead
 // of 50, bit-identical — was built and measured in round 5: no faster, 13 % more VALU instructions; profiles/r05_k2/.)
 #include "rfx_device.h"
 #include "rfx_kernels.h"
 
 namespace {
 
-#ifndef RFX_K2_XCD_G
-#define RFX_K2_XCD_G 0  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major (measurements: profiles/HISTORY.md)
-#endif
-#ifndef RFX_K2_TH
-#define RFX_K2_TH 8  // build knob: tile rows.  8 (eight waves per workgroup) stages 1.6 texels per pixel instead of 2.1 and, at this kernel's 70 VGPRs,
-                     // keeps 6 waves per SIMD resident (46 KB of LDS per workgroup) against 5 with 4 rows (measurements: profiles/r04_k2)
-#endif
-constexpr int TW = 64, TH = RFX_K2_TH, AP = 2;    // tile, apron (neighbourhood radius <= 2)
+constexpr int K2_XCD_G = 0;  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major (measurements: profiles/HISTORY.md)
+// 8 tile rows (eight waves per workgroup) stage 1.6 texels per pixel instead of 2.1 and keep 6 waves per SIMD resident (46 KB of LDS per workgroup)
+// against 5 with 4 rows (measurements: profiles/r04_k2)
+constexpr int TW = 64, TH = 8, AP = 2;             // tile, apron (neighbourhood radius <= 2)
 constexpr int LW = TW + 2 * AP, LH = TH + 2 * AP;  // 68 x 12 staged texels
 constexpr int NT = TW * TH;
 
@@ -63,12 +63,40 @@ RFX_DEV float k2_validate(const K2Args &A, const FrameDims &d, float ru, float r
     return rfx_pow(conf, A.p.confidencePower);
 }
 
+typedef float k2_f2 __attribute__((ext_vector_type(2)));
+RFX_DEV k2_f2 k2_mk2(float a, float b) { k2_f2 r; r.x = a; r.y = b; return r; }
+struct k2_rgba { k2_f2 rg, ba; };
+
 // BiCubicCatmullRom5Tap reproject.frag:212-255 — five hardware-bilinear taps of the RGBA16F (or RGBA32F) history
-// (RGBA16F: the sampler's lerps fused, on the half texels themselves — rfx_fetch_h4_linear_fused; what the oracle GL does)
+// (RGBA16F: the sampler's lerps fused, on the half texels themselves; what the oracle GL does — rfx_fetch_h4_linear_fused's arithmetic with the
+// y-lerp of the four channels as two packed fmas)
 template <bool HIST_F32, bool WHOLE>
-RFX_DEV float4 k2_history_tap(const TexView &tex, const FrameDims &d, float u, float v) {
-    if constexpr (HIST_F32) return rfx_fetch_f4_linear(tex, d, u, v);
-    else return rfx_fetch_h4_linear_fused<WHOLE>(tex, d, u, v);
+RFX_DEV k2_rgba k2_history_tap(const TexView &t, const FrameDims &d, float u, float v) {
+    k2_rgba r;
+    if constexpr (HIST_F32) {
+        const float4 c = rfx_fetch_f4_linear(t, d, u, v);
+        r.rg = k2_mk2(c.x, c.y);
+        r.ba = k2_mk2(c.z, c.w);
+    } else {
+        float cx, cy;
+        {
+#pragma clang fp contract(off)
+            cx = u * d.fW;
+            cy = v * d.fH;
+        }
+        const LinearCoord lx = rfx_linear_coord_fast(cx, d.fW - 0.5f), ly = rfx_linear_coord_fast(cy, d.fH - 0.5f);
+        const int x1 = min(lx.i0 + 1, d.W - 1), y1 = min(ly.i0 + 1, d.H - 1);
+        const unsigned int r0 = (unsigned int)__mul24(rfx_view_row<WHOLE>(d, t, ly.i0), d.W), r1 = (unsigned int)__mul24(rfx_view_row<WHOLE>(d, t, y1), d.W);
+        const uint2 t00 = rfx_gather<uint2>(t.ptr, r0 + lx.i0), t10 = rfx_gather<uint2>(t.ptr, r0 + x1);
+        const uint2 t01 = rfx_gather<uint2>(t.ptr, r1 + lx.i0), t11 = rfx_gather<uint2>(t.ptr, r1 + x1);
+        const float wx = lx.w;
+        const k2_f2 rg0 = k2_mk2(rfx_half_lerp<0>(wx, t00.x, t10.x), rfx_half_lerp<1>(wx, t00.x, t10.x)), ba0 = k2_mk2(rfx_half_lerp<0>(wx, t00.y, t10.y), rfx_half_lerp<1>(wx, t00.y, t10.y));
+        const k2_f2 rg1 = k2_mk2(rfx_half_lerp<0>(wx, t01.x, t11.x), rfx_half_lerp<1>(wx, t01.x, t11.x)), ba1 = k2_mk2(rfx_half_lerp<0>(wx, t01.y, t11.y), rfx_half_lerp<1>(wx, t01.y, t11.y));
+        const k2_f2 wy = k2_mk2(ly.w, ly.w);
+        r.rg = __builtin_elementwise_fma(wy, rg1 - rg0, rg0);
+        r.ba = __builtin_elementwise_fma(wy, ba1 - ba0, ba0);
+    }
+    return r;
 }
 template <bool HIST_F32, bool WHOLE>
 RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &tex, float pu, float pv) {
@@ -99,27 +127,17 @@ RFX_DEV float4 k2_bicubic(const K2Args &A, const FrameDims &d, const TexView &te
     // A compiler barrier between the bilinear taps: left alone, the scheduler puts all 20 texels of the five taps in flight at once and the
     // kernel needs ~20 more VGPRs (one wave per SIMD fewer); fenced after every second tap it fits its occupancy.  Same texels.
     // (measurements and the ablation of the kernel's parts: profiles/HISTORY.md)
-#ifndef RFX_K2_FENCE
-#define RFX_K2_FENCE 2  // build knob: fence after every n-th tap, 0 = none
-#endif
-#define K2_TAP_FENCE(k) do { if (RFX_K2_FENCE && ((k) % RFX_K2_FENCE) == 0) asm volatile("" ::: "memory"); } while (0)  // after every 2nd tap (1, 2, 3 compile alike)
-    const float4 Ct = k2_history_tap<HIST_F32, WHOLE>(tex, d, S1[0], S0[1]);
-    K2_TAP_FENCE(1);
-    const float4 Cl = k2_history_tap<HIST_F32, WHOLE>(tex, d, S0[0], S1[1]);
-    K2_TAP_FENCE(2);
-    const float4 Cc = k2_history_tap<HIST_F32, WHOLE>(tex, d, S1[0], S1[1]);
-    K2_TAP_FENCE(3);
-    const float4 Cr = k2_history_tap<HIST_F32, WHOLE>(tex, d, S2[0], S1[1]);
-    K2_TAP_FENCE(4);
-    const float4 Cb = k2_history_tap<HIST_F32, WHOLE>(tex, d, S1[0], S2[1]);
-#undef K2_TAP_FENCE
+    const k2_rgba Ct = k2_history_tap<HIST_F32, WHOLE>(tex, d, S1[0], S0[1]);
+    const k2_rgba Cl = k2_history_tap<HIST_F32, WHOLE>(tex, d, S0[0], S1[1]);
+    asm volatile("" ::: "memory");
+    const k2_rgba Cc = k2_history_tap<HIST_F32, WHOLE>(tex, d, S1[0], S1[1]);
+    const k2_rgba Cr = k2_history_tap<HIST_F32, WHOLE>(tex, d, S2[0], S1[1]);
+    asm volatile("" ::: "memory");
+    const k2_rgba Cb = k2_history_tap<HIST_F32, WHOLE>(tex, d, S1[0], S2[1]);
     const float wm = rfx_rcp_rn((((sw0 + sw1) + sw2) + sw3) + sw4);  // 1. / sum, sum ~ 1
-    float4 r;
-    r.x = fmaxf(((((Ct.x * sw0 + Cl.x * sw1) + Cc.x * sw2) + Cr.x * sw3) + Cb.x * sw4) * wm, 0.0f);
-    r.y = fmaxf(((((Ct.y * sw0 + Cl.y * sw1) + Cc.y * sw2) + Cr.y * sw3) + Cb.y * sw4) * wm, 0.0f);
-    r.z = fmaxf(((((Ct.z * sw0 + Cl.z * sw1) + Cc.z * sw2) + Cr.z * sw3) + Cb.z * sw4) * wm, 0.0f);
-    r.w = fmaxf(((((Ct.w * sw0 + Cl.w * sw1) + Cc.w * sw2) + Cr.w * sw3) + Cb.w * sw4) * wm, 0.0f);
-    return r;
+    const k2_f2 rg = ((((Ct.rg * sw0 + Cl.rg * sw1) + Cc.rg * sw2) + Cr.rg * sw3) + Cb.rg * sw4) * wm;
+    const k2_f2 ba = ((((Ct.ba * sw0 + Cl.ba * sw1) + Cc.ba * sw2) + Cr.ba * sw3) + Cb.ba * sw4) * wm;
+    return make_float4(fmaxf(rg.x, 0.0f), fmaxf(rg.y, 0.0f), fmaxf(ba.x, 0.0f), fmaxf(ba.y, 0.0f));
 }
 
 template <bool LOGT>
@@ -153,7 +171,7 @@ template <int INPUT_TYPE, int TC, bool LOGT, bool HIST_F32, bool WHOLE>
 RFX_DEV void k2_body(const K2Args &A, const FrameDims &d) {
     __shared__ Tile s;
     const rfx_temporal_params &p = A.p;
-    const TileXY tile = rfx_xcd_tile<RFX_K2_XCD_G>((d.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH);
+    const TileXY tile = rfx_xcd_tile<K2_XCD_G>((d.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH);
     if (!tile.valid) return;  // grid padding (uniform per workgroup, before the barrier)
     const int tx0 = tile.bx * TW, ty0 = A.y0 + tile.by * TH;
     const int tid = threadIdx.y * TW + threadIdx.x;
@@ -366,7 +384,7 @@ hipError_t rfx_launch_copy_fb(const FrameDims &d, int y0, int y1, TexView src, T
 }
 
 hipError_t rfx_launch_k2(const K2Args &A, hipStream_t stream) {
-    dim3 block(TW, TH), grid(rfx_xcd_grid(RFX_K2_XCD_G, (A.dims.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH));
+    dim3 block(TW, TH), grid(rfx_xcd_grid(K2_XCD_G, (A.dims.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH));
     const bool lt = A.p.logTransform != 0;
     // every view is the whole frame (a context that owns no row tile): no row rebasing, no halo accounting in the kernel
     const auto whole_view = [&](const void *ptr, int row0, int rows) { return ptr == nullptr || (row0 == 0 && rows == A.dims.H); };
