@@ -56,11 +56,9 @@ BYTES_PER_PX = {"k1_ssgi_march": 68, "k2_temporal_reproject": 80, "k3_poisson_de
 
 
 # rocprofv3 kernel-name fragments of bench.py's kernel keys (profiles/*/pmc_hbm.csv)
-# (every fragment of a tuple must occur in the name.  k3_tiled<IN_TEMPORAL, textures, LDS pitch, WHOLE, FUSE>: the launch that also makes the compose
-# draw — what a frame executes on a whole-frame context — ends in "true>(K3Args)")
+# (every fragment of a tuple must occur in the name; k3_tiled<IN_TEMPORAL, textures, LDS pitch, WHOLE>)
 PMC_KERNEL = {"k1_ssgi_march": ("false, 0>(K1Args)",), "k2_temporal_reproject": ("k2_temporal_reproject",), "k3_poisson_denoise_pass0": ("k3_tiled<true",),
-              "k3_poisson_denoise_pass1": ("k3_tiled<false", "false>(K3Args)"), "k4_compose": ("k4_compose",),
-              "k3_pass1_plus_k4_folded": ("k3_tiled<false", "true>(K3Args)"), "k1_prepass": ("k1_prepare",)}
+              "k3_poisson_denoise_pass1": ("k3_tiled<false",), "k4_compose": ("k4_compose",), "k1_prepass": ("k1_prepare",)}
 
 
 def _is_kernel(key, name):
@@ -335,19 +333,8 @@ def kernel_times(case, iters):
         for _ in range(iters):
             fn()
         kms[name] = ctx.time_end() / iters
-    # On a whole-frame context the library makes the last denoise draw and the compose draw that follows it in ONE launch (rfx_ctx.h k3_held,
-    # k3_denoise.hip FUSE): that is what a frame executes.  The loops above call one entry point repeatedly, which launches each draw on its
-    # own; here the pair as a frame issues it.
-    def pair():
-        k3(1)
-        ctx.compose(cp)
-    pair()
-    ctx.time_begin()
-    for _ in range(iters):
-        pair()
-    folded = ctx.time_end() / iters
     ctx.sync()
-    return kms, folded
+    return kms
 
 
 def kernel_times_in_frame(case, n_frames):
@@ -362,7 +349,7 @@ def kernel_times_in_frame(case, n_frames):
     got = ctx.profile_read()
     ctx.profile(False)
     names = {"k1_ssgi_march": "k1_ssgi_march", "k2_temporal_reproject": "k2_temporal_reproject", "k3_poisson_denoise_pass0": "k3_poisson_denoise_pass0",
-             "k3_poisson_denoise_passN": "k3_poisson_denoise_pass1", "k4_compose": "k4_compose", "k3_passN_plus_k4_folded": "k3_pass1_plus_k4_folded"}
+             "k3_poisson_denoise_passN": "k3_poisson_denoise_pass1", "k4_compose": "k4_compose"}
     kms = {names[k]: ms / n for k, (ms, n) in got.items() if k in names}
     pre = got.get("k1_prepass")
     return kms, (pre[0] / pre[1] if pre else None)
@@ -383,9 +370,7 @@ def main():
     ap.add_argument("--no-cpu-port", action="store_true", help="skip the C restatement's CPU line (~10 s)")
     ap.add_argument("--no-cold", action="store_true", help="skip the un-spun-up measurement (ms_per_step_cold)")
     ap.add_argument("--checksum", action="store_true", help="add sha1 of the final whole-frame composed GI to the JSON line (tiled == single check)")
-    ap.add_argument("--compose-fold", action="store_true", help="N = 1: time the OPT-IN one-launch form of the last denoise draw + the compose draw (rfx_set_compose_fold(1): "
-                    "an approximation, include/rfx.h) as the headline instead of reporting it beside it; never with --checksum")
-    ap.add_argument("--no-compose-fold", action="store_true", help="(the default since round 5; accepted for old command lines)")
+    ap.add_argument("--no-compose-fold", action="store_true", help="(accepted for old command lines: the compose fold left the library in ABI 19)")
     ap.add_argument("--exchange", choices=("c", "torch"), default="c", help="N > 1: exchanges through the C ABI's RCCL entry points (default) or torch.distributed")
     ap.add_argument("--extras-timeout", type=int, default=480, help="seconds the N > 1 extras (weak scaling, configs[4]) may take before the headline line is printed without them")
     ap.add_argument("--configs4-size", default="7680x4320", help="N > 1 extras: frame of the BASELINE configs[4] case (tests shrink it)")
@@ -459,9 +444,6 @@ def main():
     group, fallback_note = None, None
     try:
         case = build_case(world, rank, local_rank, dev, dist, one_gpu, W1, H1, tiles, 20, 5, 1, use_c=use_c)
-        fold_headline = bool(world == 1 and args.compose_fold and not args.checksum)
-        if fold_headline:
-            case["ctx"].set_compose_fold(True)
     except RuntimeError as e:
         if not (use_c and "pre-flight" in str(e)):
             raise
@@ -496,14 +478,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         history = {"mode": mode, "MB_received_per_frame_max_over_ranks": round(float(t.item()) / 1e6, 3),
                    "whole_frame_allgather_MB": round((H1 - min(n for _, n in tiles)) * W1 * 12 / 1e6, 3)}
-    kms_solo, _pair = kernel_times(case, max(5, min(args.steps, 20)))
+    kms_solo = kernel_times(case, max(5, min(args.steps, 20)))
     kms, prepass_ms = kernel_times_in_frame(case, args.steps)
-    # the OPT-IN fold beside the headline (or the default beside it when the fold IS the headline): the same K timed frames, the other setting
-    other_ms = None
-    if world == 1 and not args.checksum:
-        ctx.set_compose_fold(not fold_headline)
-        other_ms = time_case(case, None, args.steps, args.warmup, dev, spinup=0, cold=False, first_frame=False)[0] / args.steps * 1e3
-        ctx.set_compose_fold(fold_headline)
     rows, halo = case["rows"], case["halo"]
     copy_gbs = stream_copy_gbs(dev) if (rank == 0 and not args.no_stream_copy) else None  # measured here, after the timed region
 
@@ -513,8 +489,7 @@ def main():
         if rank != 0:
             return
         px_tile = W1 * rows
-        # bytes per pixel of what a launch executes (the folded launch = later pass + compose)
-        bpp = dict(BYTES_PER_PX, k3_pass1_plus_k4_folded=BYTES_PER_PX["k3_poisson_denoise_pass1"] + BYTES_PER_PX["k4_compose"] - 36)
+        bpp = BYTES_PER_PX
         # K1's 68 B/px include the depth plane, which its PRE-PASS reads (k1_prepare + k1_pack_cells, own stream): its roofline duration is both
         dur = dict(kms)
         if prepass_ms is not None and "k1_ssgi_march" in dur:
@@ -540,7 +515,6 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload + ", steps=20 refineSteps=5 denoiseIterations=1, K1+K2+2xK3+K4 per step",
                        "frame": "%dx%d" % (W1, H1), "tile_rows": rows, "halo_rows": halo, "direct_light": True, "half_store": "rtz", "uv_model": "reference_gl",
-                       "compose_fold": fold_headline,
                        "parallelism": "row-tiles x%d, RCCL halo send/recv after K2 and every K3 pass + composed GI (see history_exchange); exchange: %s" % (
                            world, case_exchange(use_c, one_gpu, args)) if world > 1 else "single GPU"},
             # per-draw durations INSIDE the frame loop (rfx_profile: events around every draw on its stream, K more frames after the timed region)
@@ -548,9 +522,6 @@ def main():
             "k1_prepass_ms": round(prepass_ms, 4) if prepass_ms is not None else None,
             # ... and every kernel timed on its own (back-to-back launches of the same entry point), as rounds 1-4 reported them
             "kernel_ms_solo": {k: round(v, 4) for k, v in kms_solo.items()},
-            # the same K frames with the other setting of rfx_set_compose_fold (the OPT-IN one-launch form of the last denoise draw + the compose
-            # draw, an approximation: include/rfx.h; or, under --compose-fold, the default)
-            ("ms_per_step_default_two_launches" if fold_headline else "ms_per_step_compose_fold_opt_in"): round(other_ms, 4) if other_ms else None,
             "chain": {"algorithmic_bytes_per_px": chain_bytes, "sum_kernel_ms": round(chain_ms, 4),
                       "achieved_GBs": round(chain_bytes * px_tile / (chain_ms * 1e-3) / 1e9, 1),
                       "frac_of_peak": round(chain_bytes * px_tile / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},

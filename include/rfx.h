@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define RFX_ABI_VERSION 18
+#define RFX_ABI_VERSION 19
 
 enum {
     RFX_OK = 0,
@@ -210,20 +210,10 @@ int rfx_set_row_window(rfx_ctx *, int y0, int y1);
  * Applies to every following draw; row-tiled contexts evaluate the whole frame's planes. */
 enum { RFX_UV_IDEAL = 0, RFX_UV_REFERENCE_GL = 1 };
 int rfx_set_uv_model(rfx_ctx *, int model);
-/* Draw folding (ABI 17; OPT-IN since ABI 18: off unless enabled).  The reference's Denoiser ends with two full-screen draws, the last
- * PoissonDenoisePass draw into its target B and the DenoiserComposePass draw that reads it back (src/denoise/Denoiser.js:97-107,
- * PoissonDenoisePass.js:146-147, DenoiserComposePass.js:133-134).  With enable = 1, on a context that owns the WHOLE frame, draws on its own
- * stream and has never exposed the planes the two draws write (rfx_bind_external / rfx_tex_device_ptr on DENOISE_B0 / B1, COMPOSE,
- * COMPOSE_RGB), the library makes the two in ONE launch: rfx_poisson_denoise(later pass, writeToB, two textures) returns RFX_OK with its
- * draw HELD — nothing is enqueued yet, and a launch error of the held draw surfaces from the call that launches it; if the next call on the
- * context is the rfx_compose that reads those targets (giSource 0, inputType 0, same rows) every lane composes its pixel from the two texels
- * it has just stored, otherwise the held draw is launched first, whatever the call is.  4K: 1.377 -> 1.340 ms per frame.
- * It is an APPROXIMATION, which is why it is not the default: the compose draw samples target B LINEAR at vUv, i.e. at the texel centre up
- * to the rounding of vUv * size - 0.5 (a bilinear weight of 0 on about half the texels and up to 2.4e-4 at 4K, 6e-4 at 8K, on the rest); the
- * folded draw takes the texel itself.  Measured at 4K on identical inputs: max |difference| to the unfolded draw 6.8e-4, no texel beyond 1e-3;
- * against the reference GLSL itself: tests/test_gpu_baseline_configs.py (the folded pair as one more stage of the stage-wise comparison;
- * BASELINE.md carries the numbers).  The default (0) is one launch per draw, exactly the reference's fetch; row-tiled contexts never fold. */
-int rfx_set_compose_fold(rfx_ctx *, int enable);
+/* (ABI 17-18 had rfx_set_compose_fold: the compose draw made inside the last denoise launch from the texel just stored — an approximation of
+ * the reference's LINEAR fetch.  Removed in ABI 19: an exact fold needs a second launch for the tile-edge pixels and saves at most 0.008 ms of
+ * a 1.25 ms 4K frame before its LDS exchange is paid for (profiles/r06_k4/exact_fold_bounds.txt), and the library keeps ONE parity contract:
+ * one launch per draw, exactly the reference's fetches.) */
 
 /* ---- textures.  `row0`/`rows` are FRAME rows of the band being transferred; the band must lie
  * inside the rows the context holds: [max(0,tile_y0-halo), min(H,tile_y0+tile_rows+halo)).
@@ -307,9 +297,7 @@ int rfx_temporal_reproject(rfx_ctx *, const rfx_temporal_params *);
  * `dst` is RFX_TEX_FBCOPY_F16 (source texels must be half-representable, i.e. drawn with targetHalf = 1: the copy is then
  * exact, as in the reference where both sides have the same type) or RFX_TEX_FBCOPY_F32. */
 int rfx_copy_framebuffer(rfx_ctx *, rfx_tex dst);
-/* One PoissonDenoisePass draw.  Enqueued when the call returns — except under rfx_set_compose_fold(ctx, 1), where the draw a Denoiser's loop
- * ends with (later pass, writeToB, two textures, whole-frame context, own stream, private targets) is HELD for the rfx_compose that follows;
- * see rfx_set_compose_fold for the deferred-launch contract. */
+/* One PoissonDenoisePass draw. */
 int rfx_poisson_denoise(rfx_ctx *, const rfx_denoise_params *);
 int rfx_compose(rfx_ctx *, const rfx_compose_params *);
 /* The effect's mainImage (src/ssgi/shader/ssgi_compose.frag:20-45), which postprocessing's EffectPass runs after
@@ -387,7 +375,7 @@ int rfx_time_end(rfx_ctx *, float *elapsed_ms);
  * overlaps the previous frame's later draws); rfx_profile(ctx, 0) stops.  rfx_profile_read waits for the recorded events and returns, per kind,
  * the summed milliseconds and the number of launches since the reset (arrays of RFX_PROF_COUNT entries; either may be NULL).  The events cost
  * a few microseconds per draw: the frame's own time (`value`) is measured without them.  At most 8192 launches are recorded per reset. */
-enum { RFX_PROF_K1_PREPASS = 0, RFX_PROF_K1_MARCH, RFX_PROF_K2, RFX_PROF_K3_PASS0, RFX_PROF_K3_PASSN, RFX_PROF_K3_PASSN_PLUS_K4, RFX_PROF_K4, RFX_PROF_K5,
+enum { RFX_PROF_K1_PREPASS = 0, RFX_PROF_K1_MARCH, RFX_PROF_K2, RFX_PROF_K3_PASS0, RFX_PROF_K3_PASSN, RFX_PROF_K4, RFX_PROF_K5,
        RFX_PROF_COUNT };
 int rfx_profile(rfx_ctx *, int enable);
 int rfx_profile_read(rfx_ctx *, float *ms_sum, int *launches);

@@ -15,26 +15,15 @@
 #include "rfx_device.h"
 #include "rfx_kernels.h"
 #include "k3_rotation_table.h"
-#include "k4_compose_texel.h"
 
 namespace {
 
-#ifndef RFX_K3_TW
-#define RFX_K3_TW 64  // build knobs: pixels per workgroup tile (a wavefront is 64 consecutive pixels of a row either way)
-#endif
-#ifndef RFX_K3_TH
-#define RFX_K3_TH 8
-#endif
-constexpr int TW = RFX_K3_TW, TH = RFX_K3_TH;  // pixels per workgroup tile
+constexpr int TW = 64, TH = 8;                 // pixels per workgroup tile (64 x 16, 128 x 8, 64 x 7 measured slower: profiles/r05_k3)
 constexpr int NT = TW * TH;                    // threads per workgroup
 static_assert(TW % 64 == 0 && NT <= 1024, "a tile row is whole wavefronts; at most 16 wavefronts per workgroup");
-#ifndef RFX_K3_XCD_G
-#define RFX_K3_XCD_G 1  // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major
-#endif
-#ifndef RFX_K3_LDS_MAX
-#define RFX_K3_LDS_MAX (80 * 1024)  // build knob: dynamic LDS a tiled launch may ask for (80 KiB: at least two workgroups per CU; the CU has 160 KiB, handed out in
-                                    // 1 280-byte granules: <= 53 760 B fit three times, <= 40 960 B four times — profiles/r05_microbench/lds_occupancy.txt)
-#endif
+constexpr int K3_XCD_G = 1;                    // tile rows per XCD group (rfx_xcd_tile); 0 = plain row-major
+constexpr int K3_LDS_MAX = 80 * 1024;          // dynamic LDS a tiled launch may ask for (80 KiB: at least two workgroups per CU; the CU has 160 KiB, handed out in
+                                               // 1 280-byte granules: <= 53 760 B fit three times, <= 40 960 B four times — profiles/r05_microbench/lds_occupancy.txt)
 // The tile is staged with an apron of (Rx, Ry) texels.  The reference rotates the Poisson offsets in UV space
 // (`rm * (offset / resolution)`, poisson_denoise.frag:183-189), so on a W x H frame a tap lies within
 // r = radius * max(1, W/H) pixels horizontally and radius * max(1, H/W) vertically of the pixel centre — NOT in a circle of
@@ -51,27 +40,15 @@ struct CenterTexel {
     float total;
 };
 
-// ---- two forms of the tap arithmetic adopted in round 5, each a build knob (0 = the round-4 form) so that they stay measurable: same
-// operations, other last bits (A/B at 4K, pass 0 / later pass: 0.205 / 0.274 ms -> base-2 0.206 / 0.265, pairs 0.202 / 0.256, both
-// 0.202 / 0.250; profiles/r05_k3/)
-#ifndef RFX_K3_LOG2ACC
-#define RFX_K3_LOG2ACC 1  // the log-space colours are base-2 logarithms throughout (no `* ln 2` per tap and channel, exp2 at the end)
-#endif
-#ifndef RFX_K3_INTERLEAVE
-#define RFX_K3_INTERLEAVE 1  // with RFX_K3_PAIRS: the later passes stage the two accumulators' RGBA16F texels interleaved, one ds_read_b128 per footprint position
-#endif
-#ifndef RFX_K3_PAIRS
-#define RFX_K3_PAIRS 1    // the two textures' accumulators of a pixel laid out as float2 pairs (v_pk_fma / mul / add_f32 across the textures)
-#endif
-// The log-space colour `log(c + 1)` (poisson_denoise.frag:150,193) is carried as log2(c + 1) under RFX_K3_LOG2ACC: the weighted mean of
-// logarithms is linear in them, so the base only matters where the luminance of the log colour enters (k3_luma: lum is linear too,
-// lum(ln) = ln2 * lum(log2), and pow(x, 1/8) = exp2(log2(x) / 8) takes the factor as an added constant) and at the end (exp2 instead of exp).
-constexpr float K3_LN2 = 0.6931471805599453f;
-RFX_DEV float k3_logc(float x) { return RFX_K3_LOG2ACC ? rfx_log2(x) : rfx_log(x); }
-RFX_DEV float k3_unlog(float o) { return (RFX_K3_LOG2ACC ? rfx_exp2(o) : rfx_exp(o)) - 1.0f; }
+// ---- the tap arithmetic of round 5 (the round-4 forms — natural logarithms, scalar accumulators, separate RGBA16F planes — and their A/B at 4K,
+// pass 0 / later pass 0.205 / 0.274 ms -> 0.202 / 0.250: profiles/r05_k3/, code in profiles/r06_cleanup/k3_rejected_variants.patch).
+// The log-space colour `log(c + 1)` (poisson_denoise.frag:150,193) is carried as log2(c + 1): the weighted mean of logarithms is linear in
+// them, so the base only matters where the luminance of the log colour enters (k3_luma: lum is linear too, lum(ln) = ln2 * lum(log2), and
+// pow(x, 1/8) = exp2(log2(x) / 8) takes the factor as an added constant) and at the end (exp2 instead of exp): no `* ln 2` per tap and channel.
+RFX_DEV float k3_logc(float x) { return rfx_log2(x); }
+RFX_DEV float k3_unlog(float o) { return rfx_exp2(o) - 1.0f; }
 RFX_DEV float k3_luma(float3 a) {  // poisson_denoise.frag:28: pow(luminance(a), 1 / 8) of the LOG colour
-    if (RFX_K3_LOG2ACC) return rfx_exp2(__builtin_fmaf(0.125f, rfx_log2(rfx_lum(a)), 0.125f * -0.5287663729448977f));  // + log2(ln 2) / 8
-    return rfx_pow(rfx_lum(a), 0.125f);
+    return rfx_exp2(__builtin_fmaf(0.125f, rfx_log2(rfx_lum(a)), 0.125f * -0.5287663729448977f));  // + log2(ln 2) / 8
 }
 RFX_DEV float3 k3_log3(float x, float y, float z) { return make_float3(k3_logc(x + 1.0f), k3_logc(y + 1.0f), k3_logc(z + 1.0f)); }
 
@@ -93,7 +70,7 @@ RFX_DEV void k3_apply_d(CenterTexel &c, float l2w, float disocclW, float3 tl, fl
 RFX_DEV void k3_apply(CenterTexel &c, float l2w, float3 tl, float tapLuma, float lumaPhiL2) {
     k3_apply_d(c, l2w, rfx_exp2(0.1f * l2w), tl, tapLuma, lumaPhiL2);
 }
-// ... and for BOTH textures of a pixel at once (RFX_K3_PAIRS): lane .x of every pair is accumulator 0, .y accumulator 1.  The same operations
+// ... and for BOTH textures of a pixel at once (TC == 2): lane .x of every pair is accumulator 0, .y accumulator 1.  The same operations
 // in the same order as k3_apply_d; what can be a packed fp32 instruction (v_pk_add / mul / fma_f32: 4.5 issue cycles for two results against
 // 2 x 2.7, profiles/r03_microbench) is written as one vector operation, the rest (|x|, min, exp2, the threshold select) per lane.
 typedef float rfx_f2 __attribute__((ext_vector_type(2)));
@@ -117,13 +94,12 @@ RFX_DEV void k3_apply_pair(CenterPair &c, rfx_f2 l2w, rfx_f2 disocclW, rfx_f2 tr
 // log(c + 1) and pow(lum(.), 1/8) of a pair of colours (k3_log3 / k3_luma lane by lane)
 RFX_DEV rfx_f2 k3_logc2(rfx_f2 x) {
     const rfx_f2 x1 = x + 1.0f;
-    const rfx_f2 l = k3_f2(rfx_log2(x1.x), rfx_log2(x1.y));
-    return RFX_K3_LOG2ACC ? l : l * K3_LN2;
+    return k3_f2(rfx_log2(x1.x), rfx_log2(x1.y));
 }
 RFX_DEV rfx_f2 k3_luma2(rfx_f2 r, rfx_f2 g, rfx_f2 b) {
     const rfx_f2 lum = 0.2125f * r + 0.7154f * g + 0.0721f * b;
     const rfx_f2 l = k3_f2(rfx_log2(lum.x), rfx_log2(lum.y));
-    const rfx_f2 e = RFX_K3_LOG2ACC ? 0.125f * l + (0.125f * -0.5287663729448977f) : 0.125f * l;
+    const rfx_f2 e = 0.125f * l + (0.125f * -0.5287663729448977f);
     return k3_f2(rfx_exp2(e.x), rfx_exp2(e.y));
 }
 
@@ -138,23 +114,16 @@ RFX_DEV rfx_f2 k3_luma2(rfx_f2 r, rfx_f2 g, rfx_f2 b) {
 // PITCH is a template parameter for that reason: LW = 64 + 2 Rx rounded up to 72 / 74 / 76 / 80 / 96 texels (Rx <= 4 / 5 / 6 / 8 / 16).
 
 // WHOLE: every view is the whole frame (a context that owns no row tile): rows need no rebasing and no halo accounting
-// FUSE (WHOLE, TC == 2, a later pass writing target B): the DenoiserComposePass draw that follows the Denoiser's last denoise draw
-// (src/denoise/Denoiser.js:97-107) is folded into this launch — every lane composes its own pixel from the two texels it has just stored
-// (rounded to the target's halfs first, as the compose draw would read them back) instead of a second launch re-reading depth, target B and
-// decoding the G-buffer texel again.  The compose draw samples target B LINEAR at vUv, i.e. at the texel's centre up to the rounding of
-// vUv * size (bilinear weights of ~1e-7 .. 2e-4 on the neighbours); the folded form takes the texel itself: the two differ by that weight
-// times the neighbours' difference, far inside the 1e-3 of the parity metric (tests hold folded == unfolded to 2e-4 relative).
-template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE, bool FUSE>
+template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE>
 RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
-    constexpr bool PAIR = RFX_K3_PAIRS && TC == 2;  // the pixel's two accumulators as float2 pairs (k3_apply_pair)
+    constexpr bool PAIR = TC == 2;  // the pixel's two accumulators as float2 pairs (k3_apply_pair)
     extern __shared__ float4 lds[];
     const int Rx = A.tile.Rx, Ry = A.tile.Ry, LW = A.tile.LW, LH = A.tile.LH;
     const int ntex = PITCH * LH;
     float4 *s_geom = lds;
     float4 *s_in0 = lds + ntex;                                   // pass 0 view
     uint2 *s_inN = reinterpret_cast<uint2 *>(lds + ntex);         // pass >= 1 view
-    uint4 *s_in2 = reinterpret_cast<uint4 *>(lds + ntex);         // ... and its interleaved form (K3_IL): both accumulators' texels of a position
-    constexpr bool K3_IL = RFX_K3_INTERLEAVE != 0;
+    uint4 *s_in2 = reinterpret_cast<uint4 *>(lds + ntex);         // ... and its interleaved form (two accumulators): both accumulators' texels of a position
     float *s_depth = reinterpret_cast<float *>(lds + ntex) + (IN_TEMPORAL ? 8 : 4) * (size_t)ntex;
     // Pass 0 with two accumulators: the first and last `skip` texels of the staged rectangle — the ends of its first and last row, corners no tap
     // reaches (the taps lie in an ellipse, k3 launcher) — are not held: at 4K that is 4 of 1036 texels and the difference between two and three
@@ -171,7 +140,14 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
         s_in0 = lds + 1 + nal / 4 + nal - 2 * skip;
     }
     const rfx_denoise_params &p = A.p;
-    const TileXY tile = rfx_xcd_tile<RFX_K3_XCD_G>((d.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH);
+    if (PAIR && IN_TEMPORAL && skip > 0) {
+        // ... and the two pads hold zeros, not what the previous workgroup left in LDS: a frame with a NaN / inf depth or normal stays deterministic
+        const int t = threadIdx.y * TW + threadIdx.x, nal = ntex - 2 * skip;
+        float *f = reinterpret_cast<float *>(lds);
+        if (t < 4) f[t] = 0.0f;
+        if (t < 8 * skip) f[4 + nal * 13 + t] = 0.0f;  // behind depth (1) + geometry (4) + interleaved inputs (8 floats per texel)
+    }
+    const TileXY tile = rfx_xcd_tile<K3_XCD_G>((d.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH);
     if (!tile.valid) return;  // grid padding (uniform per workgroup, before any barrier)
     const int tx0 = tile.bx * TW, ty0 = A.y0 + tile.by * TH;
     const int tid = threadIdx.y * TW + threadIdx.x;
@@ -209,7 +185,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
             }
             s_in0[2 * li] = make_float4(l[0].x, l[1].x, l[0].y, l[1].y);
             s_in0[2 * li + 1] = make_float4(l[0].z, l[1].z, lu[0], lu[1]);
-        } else if constexpr (PAIR && K3_IL) {
+        } else if constexpr (PAIR) {
             // later pass, two accumulators: the raw RGBA16F texels the two accumulators read side by side, 16 bytes per position — a bilinear
             // footprint is four aligned ds_read_b128 (7.1 LDS cycles each on this part) instead of four ds_read2_b64 per texture pair (9.0 each)
             uint2 t2[2];
@@ -249,13 +225,6 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     {
         const float fw = fabsf(s_depth[qx1] - s_depth[qx0]) + fabsf(s_depth[qy1] - s_depth[qy0]);
         if (depth == 1.0f && fw == 0.0f) {  // discard (:129-132): target keeps its contents
-            if constexpr (FUSE) {  // ... and so does the compose draw's (DenoiserComposePass.js:61-64, the same test): mirror the kept texel
-                if (A.rgb_out) {
-                    const float4 keep = ((const float4 *)A.cout.ptr)[(size_t)y * d.W + x];
-                    float *r = A.rgb_out + ((size_t)y * d.W + x) * 3;
-                    r[0] = keep.x; r[1] = keep.y; r[2] = keep.z;
-                }
-            }
             return;
         }
     }
@@ -315,7 +284,7 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
                 fy = v * d.fH;
             }
             const LinearCoord lx = rfx_linear_coord_fast(fx, xlo, wmh), ly = rfx_linear_coord_fast(fy, ylo, hmh);
-            if constexpr (PAIR && K3_IL) {
+            if constexpr (PAIR) {
                 const uint4 *q = s_in2 + koff + (__mul24(ly.i0, PITCH) + lx.i0);
                 const uint4 p00 = q[0], p10 = q[1], p01 = q[PITCH], p11 = q[PITCH + 1];
                 t = i ? rfx_bilerp_half_rgba(make_uint2(p00.z, p00.w), make_uint2(p10.z, p10.w), make_uint2(p01.z, p01.w), make_uint2(p11.z, p11.w), lx.w, ly.w)
@@ -353,14 +322,8 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     }
     const float4 *g_in01 = s_in0 + 2 * koff;  // (PAIR, pass 0: the interleaved pairs, two float4 per texel)
 
-    // no unrolling by default: occupancy beats ILP here (build knobs: taps per loop iteration of pass 0 / of the later passes)
-#ifndef RFX_K3_UNROLL0
-#define RFX_K3_UNROLL0 1
-#endif
-#ifndef RFX_K3_UNROLLN
-#define RFX_K3_UNROLLN 1
-#endif
-#pragma clang loop unroll_count(IN_TEMPORAL ? RFX_K3_UNROLL0 : RFX_K3_UNROLLN)
+    // no unrolling: occupancy beats ILP here (2 / 4 / 8 taps per iteration: static issue cost -9 .. -19 %, measured +-1 %, profiles/r05_k3)
+#pragma clang loop unroll_count(1)
     for (int k = 0; k < 8; k++) {
         const float ox = A.tap_ox[k], oy = A.tap_oy[k];  // POISSON[k] / resolution (:91-92,:189), divided once on the host
         // the tap's texture coordinate, every product and sum rounded on its own as in the GLSL (it addresses NEAREST fetches)
@@ -391,17 +354,10 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
                 const LinearCoord lx = rfx_linear_coord_fast(fx, xlo, wmh), ly = rfx_linear_coord_fast(fy, ylo, hmh);
                 const int li = __mul24(ly.i0, PITCH) + lx.i0;
                 // the sampler's bilinear blend (rfx_bilerp_half_rgb): x-lerps on the half texels per texture, the y-lerp on the pairs
-                uint2 a00, a10, a01, a11, b00, b10, b01, b11;
-                if constexpr (K3_IL) {
-                    const uint4 *q = s_in2 + koff + li;
-                    const uint4 p00 = q[0], p10 = q[1], p01 = q[PITCH], p11 = q[PITCH + 1];
-                    a00 = make_uint2(p00.x, p00.y); a10 = make_uint2(p10.x, p10.y); a01 = make_uint2(p01.x, p01.y); a11 = make_uint2(p11.x, p11.y);
-                    b00 = make_uint2(p00.z, p00.w); b10 = make_uint2(p10.z, p10.w); b01 = make_uint2(p01.z, p01.w); b11 = make_uint2(p11.z, p11.w);
-                } else {
-                    const uint2 *q0 = g_inN[0] + li, *q1 = g_inN[1] + li;
-                    a00 = q0[0]; a10 = q0[1]; a01 = q0[PITCH]; a11 = q0[PITCH + 1];
-                    b00 = q1[0]; b10 = q1[1]; b01 = q1[PITCH]; b11 = q1[PITCH + 1];
-                }
+                const uint4 *q = s_in2 + koff + li;
+                const uint4 p00 = q[0], p10 = q[1], p01 = q[PITCH], p11 = q[PITCH + 1];
+                const uint2 a00 = make_uint2(p00.x, p00.y), a10 = make_uint2(p10.x, p10.y), a01 = make_uint2(p01.x, p01.y), a11 = make_uint2(p11.x, p11.y);
+                const uint2 b00 = make_uint2(p00.z, p00.w), b10 = make_uint2(p10.z, p10.w), b01 = make_uint2(p01.z, p01.w), b11 = make_uint2(p11.z, p11.w);
                 const rfx_f2 r0 = k3_f2(rfx_half_lerp<0>(lx.w, a00.x, a10.x), rfx_half_lerp<0>(lx.w, b00.x, b10.x));
                 const rfx_f2 g0 = k3_f2(rfx_half_lerp<1>(lx.w, a00.x, a10.x), rfx_half_lerp<1>(lx.w, b00.x, b10.x));
                 const rfx_f2 b0 = k3_f2(rfx_half_lerp<0>(lx.w, a00.y, a10.y), rfx_half_lerp<0>(lx.w, b00.y, b10.y));
@@ -442,25 +398,12 @@ RFX_DEV void k3_tiled_body(const K3Args &A, const FrameDims &d) {
     }
 
     const size_t oi = (size_t)(unsigned int)(__mul24(WHOLE ? y : rfx_local_row(d, A.out0.row0, A.out0.rows, y), d.W) + x);
-    uint2 stored[TC];
 #pragma unroll
     for (int i = 0; i < TC; i++) {  // outputTexel :94-100
         const float inv = rfx_rcp(c[i].total);
         float3 o = make_float3(c[i].rgb.x * inv, c[i].rgb.y * inv, c[i].rgb.z * inv);
         o = make_float3(k3_unlog(o.x), k3_unlog(o.y), k3_unlog(o.z));
-        stored[i] = rfx_store_half4(o.x, o.y, o.z, c[i].a, p.halfStoreRTZ != 0);
-        ((uint2 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = stored[i];
-    }
-    if constexpr (FUSE) {  // the compose draw of this pixel (k4_compose.hip's body on the texels just stored: B0 = diffuse GI, B1 = specular GI)
-        static_assert(TC == 2 && WHOLE && !IN_TEMPORAL, "the folded compose draw reads both targets of a whole-frame later pass");
-        const float4 dgi = rfx_load_half4(stored[0]), sgi = rfx_load_half4(stored[1]);
-        const Material mat = rfx_get_material<true>(gbp[(unsigned int)(__mul24(y, d.W) + x)]);
-        const float4 o = k4_compose_texel(A.cp, u, v, depth, mat, make_float3(dgi.x, dgi.y, dgi.z), make_float3(sgi.x, sgi.y, sgi.z), make_float3(0.f, 0.f, 0.f));
-        ((float4 *)A.cout.ptr)[oi] = o;
-        if (A.rgb_out) {
-            float *r = A.rgb_out + oi * 3;
-            r[0] = o.x; r[1] = o.y; r[2] = o.z;
-        }
+        ((uint2 *)(i ? A.out1.ptr : A.out0.ptr))[oi] = rfx_store_half4(o.x, o.y, o.z, c[i].a, p.halfStoreRTZ != 0);
     }
 }
 
@@ -555,11 +498,11 @@ RFX_DEV void k3_generic_body(const K3Args &A, const FrameDims &d) {
     }
 }
 
-template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE, bool FUSE = false>
+template <bool IN_TEMPORAL, int TC, int PITCH, bool WHOLE>
 __global__ __launch_bounds__(NT) void k3_tiled(K3Args A) {
     FrameDims d = A.dims;
     d.viol = 0;
-    k3_tiled_body<IN_TEMPORAL, TC, PITCH, WHOLE, FUSE>(A, d);
+    k3_tiled_body<IN_TEMPORAL, TC, PITCH, WHOLE>(A, d);
     rfx_flush_violations(d);
 }
 template <bool IN_TEMPORAL, int TC>
@@ -572,11 +515,8 @@ __global__ __launch_bounds__(256) void k3_generic(K3Args A) {
 
 }  // namespace
 
-// `folded` (may be null): set to whether the launch also made the compose draw A.fuse_compose asks for — the tiled kernel on whole-frame
-// views, two textures, a later pass; otherwise the caller launches K4 itself
-hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
+hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream) {
     K3Args A = A_in;
-    if (folded) *folded = false;
     const bool temporal = A.p.inputIsTemporal != 0;
     // apron of the tap footprint: anisotropic because the reference rotates in UV space
     const float aspect = A.dims.fW / A.dims.fH;
@@ -598,25 +538,16 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
         const int a = temporal ? (int)floorf(r + 0.5f + SLACK) : (int)floorf(r + SLACK) + 1;
         return a < 1 ? 1 : a;
     };
-#ifndef RFX_K3_WIDE_APRON
-#define RFX_K3_WIDE_APRON 0  // build knob: 1 = the apron of rounds 2-4, ceil(r) + 1 for every pass (A/B measurements; same texels)
-#endif
-    A.tile.Rx = RFX_K3_WIDE_APRON ? (int)ceilf(rx) + 1 : k3_apron(rx);
-    A.tile.Ry = RFX_K3_WIDE_APRON ? (int)ceilf(ry) + 1 : k3_apron(ry);
+    A.tile.Rx = k3_apron(rx);
+    A.tile.Ry = k3_apron(ry);
     A.tile.LW = TW + 2 * A.tile.Rx;
     A.tile.LH = TH + 2 * A.tile.Ry;
     A.tile.skip = 0;
-    // LDS row pitch: a compile-time constant of the tiled kernels (the footprint's second row is an immediate offset)
-#ifndef RFX_K3_PAD
-#define RFX_K3_PAD 0  // build knob: extra texels per LDS row (bank-mapping experiments, profiles/r04_k3/)
-#endif
-    constexpr int PAD = RFX_K3_PAD;
-    const int pitch = A.tile.LW <= TW + 8 ? TW + 8 + PAD : A.tile.LW <= TW + 10 ? TW + 10 + PAD : A.tile.LW <= TW + 12 ? TW + 12 + PAD : A.tile.LW <= TW + 16 ? TW + 16 + PAD : A.tile.LW <= TW + 32 ? TW + 32 + PAD : 0;
+    // LDS row pitch: a compile-time constant of the tiled kernels (the footprint's second row is an immediate offset; padding it by 1 / 2 / 4 texels
+    // moves neither the time nor the bank-conflict share: the conflicts are collisions of per-pixel-rotated taps, profiles/r04_k3)
+    const int pitch = A.tile.LW <= TW + 8 ? TW + 8 : A.tile.LW <= TW + 10 ? TW + 10 : A.tile.LW <= TW + 12 ? TW + 12 : A.tile.LW <= TW + 16 ? TW + 16 : A.tile.LW <= TW + 32 ? TW + 32 : 0;
     size_t lds = (size_t)pitch * A.tile.LH * (16 + 4 + 2 * (temporal ? 16 : 8));
-#ifndef RFX_K3_SHAVE
-#define RFX_K3_SHAVE 1  // build knob: 0 = pass 0 stages the whole rectangle (A/B measurements; same texels)
-#endif
-    if (RFX_K3_SHAVE && RFX_K3_PAIRS && temporal && A.p.textureCount == 2 && pitch == A.tile.LW && pitch != 0) {
+    if (temporal && A.p.textureCount == 2 && pitch == A.tile.LW && pitch != 0) {
         // The corners of the staged rectangle no tap reaches: a tap's offset from its pixel, in pixels, lies in the ellipse (dx / rx)^2 + (dy / ry)^2 <= 1
         // (the rotation acts in UV space, flatness <= 1, |POISSON[k]| <= 1), and the rectangle's first row is addressed only by the tile's first
         // row of pixels with dy in [-Ry - 0.5, -Ry + 0.5): there |dx| <= rx * sqrt(1 - ((Ry - 0.5) / ry)^2), i.e. a NEAREST tap reaches at most X texels
@@ -634,14 +565,14 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
         }
     }
     // at least two workgroups per CU (160 KiB LDS) keep the staging of one tile under the arithmetic of another (4K: three of either pass kind)
-    const bool tiled = A.p.radius >= 0.0f && pitch != 0 && lds <= RFX_K3_LDS_MAX;
+    const bool tiled = A.p.radius >= 0.0f && pitch != 0 && lds <= (size_t)K3_LDS_MAX;
     // every view the whole frame (a context that owns no row tile): the kernels skip row rebasing and halo accounting
     const auto whole_view = [&](const void *ptr, int row0, int rows) { return ptr == nullptr || (row0 == 0 && rows == A.dims.H); };
     const bool whole = whole_view(A.depth.ptr, A.depth.row0, A.depth.rows) && whole_view(A.gbuffer.ptr, A.gbuffer.row0, A.gbuffer.rows) &&
                        whole_view(A.in0.ptr, A.in0.row0, A.in0.rows) && whole_view(A.in1.ptr, A.in1.row0, A.in1.rows) &&
                        whole_view(A.out0.ptr, A.out0.row0, A.out0.rows) && whole_view(A.out1.ptr, A.out1.row0, A.out1.rows);
     if (tiled) {
-        dim3 block(TW, TH), grid(rfx_xcd_grid(RFX_K3_XCD_G, (A.dims.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH));
+        dim3 block(TW, TH), grid(rfx_xcd_grid(K3_XCD_G, (A.dims.W + TW - 1) / TW, (A.y1 - A.y0 + TH - 1) / TH));
         // the attribute is per device (a process may hold contexts on several): remembered per device ordinal
 #define K3_TILED(T, C, P, WH)                                                                                                \
     do {                                                                                                                     \
@@ -649,7 +580,7 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
         int dev = 0;                                                                                                         \
         hipGetDevice(&dev);                                                                                                  \
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                                        \
-            hipFuncSetAttribute((const void *)k3_tiled<T, C, P, WH>, hipFuncAttributeMaxDynamicSharedMemorySize, RFX_K3_LDS_MAX); \
+            hipFuncSetAttribute((const void *)k3_tiled<T, C, P, WH>, hipFuncAttributeMaxDynamicSharedMemorySize, K3_LDS_MAX); \
             if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                                  \
         }                                                                                                                    \
         hipLaunchKernelGGL((k3_tiled<T, C, P, WH>), grid, block, lds, stream, A);                                            \
@@ -657,32 +588,13 @@ hipError_t rfx_launch_k3(const K3Args &A_in, hipStream_t stream, bool *folded) {
 #define K3_TILED_W(T, C, P) do { if (whole) K3_TILED(T, C, P, true); else K3_TILED(T, C, P, false); } while (0)
 #define K3_TILED_P(T, C)                    \
     do {                                    \
-        if (pitch == TW + 8 + PAD) K3_TILED_W(T, C, TW + 8 + PAD); \
-        else if (pitch == TW + 10 + PAD) K3_TILED_W(T, C, TW + 10 + PAD); \
-        else if (pitch == TW + 12 + PAD) K3_TILED_W(T, C, TW + 12 + PAD); \
-        else if (pitch == TW + 16 + PAD) K3_TILED_W(T, C, TW + 16 + PAD); \
-        else K3_TILED_W(T, C, TW + 32 + PAD);          \
+        if (pitch == TW + 8) K3_TILED_W(T, C, TW + 8); \
+        else if (pitch == TW + 10) K3_TILED_W(T, C, TW + 10); \
+        else if (pitch == TW + 12) K3_TILED_W(T, C, TW + 12); \
+        else if (pitch == TW + 16) K3_TILED_W(T, C, TW + 16); \
+        else K3_TILED_W(T, C, TW + 32);          \
     } while (0)
-        if (A.fuse_compose && whole && !temporal && A.p.textureCount == 2) {
-#define K3_FUSED(P)                                                                                                                      \
-    do {                                                                                                                                 \
-        static bool attr_set[64] = {false};                                                                                              \
-        int dev = 0;                                                                                                                     \
-        hipGetDevice(&dev);                                                                                                              \
-        if (dev < 0 || dev >= 64 || !attr_set[dev]) {                                                                                    \
-            hipFuncSetAttribute((const void *)k3_tiled<false, 2, P, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RFX_K3_LDS_MAX); \
-            if (dev >= 0 && dev < 64) attr_set[dev] = true;                                                                              \
-        }                                                                                                                                \
-        hipLaunchKernelGGL((k3_tiled<false, 2, P, true, true>), grid, block, lds, stream, A);                                            \
-    } while (0)
-            if (pitch == TW + 8 + PAD) K3_FUSED(TW + 8 + PAD);
-            else if (pitch == TW + 10 + PAD) K3_FUSED(TW + 10 + PAD);
-            else if (pitch == TW + 12 + PAD) K3_FUSED(TW + 12 + PAD);
-            else if (pitch == TW + 16 + PAD) K3_FUSED(TW + 16 + PAD);
-            else K3_FUSED(TW + 32 + PAD);
-#undef K3_FUSED
-            if (folded) *folded = true;
-        } else if (A.p.textureCount == 2) {
+        if (A.p.textureCount == 2) {
             if (temporal) K3_TILED_P(true, 2);
             else K3_TILED_P(false, 2);
         } else {

@@ -12,13 +12,8 @@
 
 thread_local std::string g_create_err;
 
-// every entry point that takes a context: select its device, launch the draw the context may be holding (rfx_ctx.h k3_held)
-#define RFX_ENTER(c)                         \
-    do {                                     \
-        hipSetDevice((c)->device);           \
-        const int rc__ = rfx_internal_flush(c); \
-        if (rc__) return rc__;               \
-    } while (0)
+// every entry point that takes a context: select its device
+#define RFX_ENTER(c) hipSetDevice((c)->device)
 // rfx_profile: bracket the launches of one draw with two events on `stream` (no-ops unless profiling is on)
 static hipEvent_t prof_event(rfx_ctx *c) {
     hipEvent_t e = nullptr;
@@ -47,21 +42,8 @@ struct ProfScope {
         c->prof_recs.push_back({kind, a, b});
     }
 };
-#ifndef RFX_FOLD_COMPOSE
-#define RFX_FOLD_COMPOSE 1  // build knob: 0 = never hold a denoise draw for its compose draw (A/B measurements)
-#endif
 
 extern "C" {
-
-unsigned int rfx_internal_folded_draws(const rfx_ctx *c) { return c ? c->folded_draws : 0u; }  // (tests: the fold really happened)
-
-int rfx_internal_flush(rfx_ctx *c) {
-    if (!c->k3_held) return RFX_OK;
-    c->k3_held = false;
-    ProfScope prof(c, RFX_PROF_K3_PASSN, c->stream);
-    HIPCHK(c, rfx_launch_k3(*c->k3_held_args, c->stream));
-    return RFX_OK;
-}
 
 int rfx_abi_version(void) { return RFX_ABI_VERSION; }
 
@@ -126,8 +108,6 @@ rfx_ctx *rfx_create(int device, int width, int height, int tile_y0, int tile_row
 void rfx_destroy(rfx_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
-    rfx_internal_flush(c);
-    delete c->k3_held_args;
     hipStreamSynchronize(c->stream);
     rfx_comm_release(c);
     // a staged copy may still be writing a back buffer: drain the upload stream before any buffer goes
@@ -202,13 +182,6 @@ int rfx_set_uv_model(rfx_ctx *c, int model) {
     return RFX_OK;
 }
 
-int rfx_set_compose_fold(rfx_ctx *c, int enable) {
-    if (!c) return RFX_EINVAL;
-    RFX_ENTER(c);
-    c->fold_compose = enable != 0;
-    return RFX_OK;
-}
-
 int rfx_tex_held_rows(const rfx_ctx *c, rfx_tex id, int *row0, int *rows) {
     if (!c || id < 0 || id >= RFX_TEX_COUNT) return RFX_EINVAL;
     if (row0) *row0 = c->slots[id].row0;
@@ -219,7 +192,6 @@ int rfx_tex_held_rows(const rfx_ctx *c, rfx_tex id, int *row0, int *rows) {
 static int ensure(rfx_ctx *c, int id) {
     Slot &s = c->slots[id];
     if (s.ptr) return RFX_OK;
-    hipSetDevice(c->device);  // (not an entry point: rfx_compose allocates its target while the draw it folds in is still held)
     const size_t bytes = (size_t)s.rows * s.width * s.texel;
     hipError_t e = hipMalloc(&s.ptr, bytes);
     if (e != hipSuccess) return fail(c, RFX_ENOMEM, "hipMalloc(texture)", e);
@@ -353,12 +325,10 @@ int rfx_clear(rfx_ctx *c, rfx_tex id) {
 void *rfx_tex_device_ptr(rfx_ctx *c, rfx_tex id) {
     if (!c || id < 0 || id >= RFX_TEX_COUNT) return nullptr;
     hipSetDevice(c->device);
-    if (rfx_internal_flush(c)) return nullptr;  // (whoever takes an address may read or write the plane with work of its own)
     if (ensure(c, id)) return nullptr;
     // whoever takes the depth plane's address may write it with work this library cannot see (ordered against the draw stream only, as a
     // bound external buffer is): the pre-pass then stays in the draw stream
     if (id == RFX_TEX_DEPTH) c->depth_external = true;
-    c->slots[id].exported = true;  // (a draw into this plane is never held for a later call: rfx_poisson_denoise)
     return c->slots[id].ptr;
 }
 
@@ -936,24 +906,6 @@ int rfx_poisson_denoise(rfx_ctx *c, const rfx_denoise_params *p) {
     blue_noise_shift(p->blueNoiseIndex, &A.shift_x, &A.shift_y);
     A.out0 = wview(c, out0); A.out1 = wview(c, out1);
     A.p = *p;
-    A.fuse_compose = 0;
-    A.cout = TexViewW();
-    A.rgb_out = nullptr;
-    // OPT-IN (rfx_set_compose_fold; off by default).  The draw a Denoiser's loop ends with — a later pass into target B, both textures — on a
-    // whole-frame context drawing on the library's own stream is held for the rfx_compose that follows it in the reference (rfx_ctx.h
-    // k3_held).  Never when a plane either draw writes is visible outside the library — bound to a caller's buffer (rfx_bind_external) or its
-    // address handed out (rfx_tex_device_ptr): such a host may synchronise with the device by means of its own and must find the draw it
-    // was told is enqueued.
-    const bool whole_ctx = c->tile_y0 == 0 && c->tile_rows == c->H && A.y0 == 0 && A.y1 == c->H;
-    const auto is_private = [&](int id) { const Slot &s = c->slots[id]; return (s.owned || !s.ptr) && !s.exported; };
-    const bool targets_private = is_private(out0) && is_private(out1) && is_private(RFX_TEX_COMPOSE) && is_private(RFX_TEX_COMPOSE_RGB);
-    if (RFX_FOLD_COMPOSE && c->fold_compose && !p->inputIsTemporal && p->writeToB && p->textureCount == 2 && whole_ctx && c->stream == c->own_stream &&
-        targets_private) {
-        if (!c->k3_held_args) c->k3_held_args = new K3Args;
-        *c->k3_held_args = A;
-        c->k3_held = true;
-        return RFX_OK;
-    }
     ProfScope prof(c, p->inputIsTemporal ? RFX_PROF_K3_PASS0 : RFX_PROF_K3_PASSN, c->stream);
     HIPCHK(c, rfx_launch_k3(A, c->stream));
     return RFX_OK;
@@ -963,13 +915,7 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
     if (!c || !p) return RFX_EINVAL;
     if (p->inputType != 0 && p->inputType != 2)
         return fail(c, RFX_EUNSUPPORTED, "rfx_compose: inputType diffuseSpecular (0) and specular (2) are built");
-    hipSetDevice(c->device);
-    // a held denoise draw (rfx_ctx.h k3_held) whose targets this draw reads: both in one launch; any other combination launches it first
-    const bool fold = c->k3_held && p->inputType == 0 && p->giSource == 0;
-    if (!fold) {
-        const int frc = rfx_internal_flush(c);
-        if (frc) return frc;
-    }
+    RFX_ENTER(c);
     if (p->giSource != 0 && p->giSource != 1) return fail(c, RFX_EINVAL, "rfx_compose: giSource");
     const int g0 = p->giSource ? RFX_TEX_TEMPORAL0 : RFX_TEX_DENOISE_B0, g1 = p->giSource ? RFX_TEX_TEMPORAL1 : RFX_TEX_DENOISE_B1;
     const int ids[] = {RFX_TEX_DEPTH, RFX_TEX_GBUFFER, g0, g1, RFX_TEX_COMPOSE, RFX_TEX_DIRECT_LIGHT};
@@ -992,26 +938,6 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
         A.rgb_out = (float *)c->slots[RFX_TEX_COMPOSE_RGB].ptr;  // held whole, like COMPOSE: frame row y at y * W
     }
     A.p = *p;
-    if (fold) {
-        K3Args &K = *c->k3_held_args;
-        c->k3_held = false;
-        bool folded = false;
-        if (any && A.y0 == K.y0 && A.y1 == K.y1) {
-            K.fuse_compose = 1;
-            K.cp = *p;
-            K.cout = A.out;
-            K.rgb_out = A.rgb_out;
-        }
-        {
-            ProfScope prof(c, RFX_PROF_K3_PASSN, c->stream);
-            HIPCHK(c, rfx_launch_k3(K, c->stream, &folded));
-            if (folded) prof.set_kind(RFX_PROF_K3_PASSN_PLUS_K4);
-        }
-        if (folded) {
-            c->folded_draws++;
-            return RFX_OK;
-        }
-    }
     if (any) {
         ProfScope prof(c, RFX_PROF_K4, c->stream);
         HIPCHK(c, rfx_launch_k4(A, c->stream));
@@ -1096,7 +1022,6 @@ unsigned int rfx_halo_violations(rfx_ctx *c) {
     unsigned int v = 0;
     if (!c) return 0;
     hipSetDevice(c->device);
-    rfx_internal_flush(c);
     hipStreamSynchronize(c->stream);
     hipMemcpy(&v, c->halo_violations, sizeof v, hipMemcpyDeviceToHost);
     return v;

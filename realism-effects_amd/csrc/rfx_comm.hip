@@ -89,7 +89,6 @@ int nccl_fail(rfx_ctx *c, const char *what, NcclResult rc) {
 // an EARLIER exchange while a later one is still in flight would need one event per exchange; the protocols here never do.)
 int comm_begin(rfx_ctx *c) {
     hipSetDevice(c->device);
-    if (const int frc = rfx_internal_flush(c)) return frc;  // "the draws so far" include a held one (rfx_ctx.h k3_held)
     hipError_t e = hipEventRecord(c->ev_draws, c->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->comm_stream, c->ev_draws, 0);
     return e == hipSuccess ? RFX_OK : fail(c, RFX_EDEVICE, "rfx_comm: ordering the exchange stream after the draws", e);
@@ -426,7 +425,6 @@ int rfx_comm_wait(rfx_ctx *c) {
     if (!c) return RFX_EINVAL;
     if (!c->comm_pending) return RFX_OK;
     hipSetDevice(c->device);
-    if (const int frc = rfx_internal_flush(c)) return frc;
     hipError_t e = hipStreamWaitEvent(c->stream, c->ev_comm, 0);
     if (e != hipSuccess) return fail(c, RFX_EDEVICE, "rfx_comm_wait: hipStreamWaitEvent", e);
     c->comm_pending = false;

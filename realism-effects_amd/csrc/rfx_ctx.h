@@ -14,7 +14,6 @@ struct Slot {
     size_t texel = 0;
     int width = 0;
     bool uploaded = false;
-    bool exported = false;  // rfx_tex_device_ptr handed the plane's address out: work the library cannot see may read or write it
     // streaming dumps (rfx_stage_upload / rfx_stage_flip): the BACK buffer the next frame's plane is copied into while the draws read `ptr`
     void *back = nullptr;
     bool back_filled = false;
@@ -69,16 +68,6 @@ struct rfx_ctx {
     hipEvent_t ev_staged = nullptr, ev_frame_done = nullptr;
     hipEvent_t ev_batch[2] = {nullptr, nullptr};  // the copies published by the last two flips (recorded on upload_stream)
     unsigned int flips = 0;
-    // OPT-IN (rfx_set_compose_fold(ctx, 1); off by default since ABI 18): the draw a Denoiser's denoise loop ends with (a later
-    // PoissonDenoisePass draw into target B; whole-frame context, the library's own stream, targets the library owns and whose address it
-    // never handed out) is HELD until the next call on the context: rfx_compose — the DenoiserComposePass draw that follows it in the
-    // reference, src/denoise/Denoiser.js:97-107 — then makes both draws in one launch (k3_denoise.hip FUSE); any other call launches the
-    // held draw first (rfx_internal_flush, at the top of every entry point).  The folded compose reads the texel it has just stored instead
-    // of the reference's LINEAR fetch at vUv: an approximation (include/rfx.h), which is why it is not the default.
-    bool k3_held = false;
-    bool fold_compose = false;  // rfx_set_compose_fold
-    struct K3Args *k3_held_args = nullptr;
-    unsigned int folded_draws = 0;  // compose draws made inside a denoise launch so far
     // rfx_profile: event pairs around the launches of every draw since the last reset (kind, start, stop), and the events free for re-use
     struct ProfRec { int kind; hipEvent_t a, b; };
     bool profiling = false;
@@ -86,9 +75,6 @@ struct rfx_ctx {
     std::vector<hipEvent_t> prof_free;
     std::string err;
 };
-// rfx_api.hip: launch the held draw, if any (every entry point that takes a context starts with it)
-extern "C" int rfx_internal_flush(rfx_ctx *c);
-extern "C" unsigned int rfx_internal_folded_draws(const rfx_ctx *c);  // (internal: not part of include/rfx.h)
 void rfx_comm_release(rfx_ctx *c);  // rfx_comm.hip: called by rfx_destroy
 // rfx_api.hip, for rfx_comm.hip: enqueue on the draw stream the reduction of the traced rays' history rows into rows_dev[0..1] (min, max)
 extern "C" int rfx_internal_hit_rows_enqueue(rfx_ctx *c, int *rows_dev);  // (internal: not part of include/rfx.h)

@@ -67,11 +67,6 @@ struct K3Args {
     rfx_denoise_params p;
     struct { int Rx, Ry, LW, LH, skip; } tile;  // filled by the launcher (skip: texels shaved off each end of the staged rectangle, k3_tiled_body)
     float tap_ox[8], tap_oy[8];           // POISSON[k] / resolution, filled by the launcher
-    // the compose draw folded into this launch (rfx_api.hip: the context's deferred last denoise draw met its rfx_compose)
-    int fuse_compose;
-    rfx_compose_params cp;
-    TexViewW cout;   // RFX_TEX_COMPOSE (whole frame)
-    float *rgb_out;  // RFX_TEX_COMPOSE_RGB or null
 };
 
 struct K4Args {
@@ -108,7 +103,7 @@ hipError_t rfx_launch_k1_hit_rows(const FrameDims &, int y0, int y1, TexView dep
 // mask[row] |= 1 << column block (32 blocks across the frame) for every history texel the shade stage of the traced rays of rows [y0, y1) will read (H words, zeroed)
 hipError_t rfx_launch_k1_hit_mask(const FrameDims &, int y0, int y1, TexView depth, TexViewW out, const float4 *hits, bool allow_missed, unsigned int *mask, hipStream_t);
 hipError_t rfx_launch_k2(const K2Args &, hipStream_t);
-hipError_t rfx_launch_k3(const K3Args &, hipStream_t, bool *folded = nullptr);
+hipError_t rfx_launch_k3(const K3Args &, hipStream_t);
 hipError_t rfx_launch_k4(const K4Args &, hipStream_t);
 // rows [y0, y1) of an RGBA32F plane -> the same rows of an RGBA16F (to_half) or RGBA32F plane
 hipError_t rfx_launch_copy_fb(const FrameDims &, int y0, int y1, TexView src, TexViewW dst, bool to_half, hipStream_t);

@@ -170,11 +170,6 @@ class Renderer {
 		if (m === undefined) throw new RangeError("setUvModel: \"ideal\" or \"reference_gl\"")
 		addon.setUvModel(this._h, m)
 	}
-	// opt in to the Denoiser's last denoise draw and the compose draw that follows it being made in one launch on a whole-frame context
-	// (rfx_set_compose_fold: an approximation).  The default (false): one launch per draw, the reference's LINEAR fetch at vUv exactly
-	setComposeFold(enable) {
-		addon.setComposeFold(this._h, enable ? 1 : 0)
-	}
 	// the same draw in two launches (rfx_ssgi_trace / rfx_ssgi_shade): only the second reads last frame's composed GI
 	ssgiTrace(uniforms) {
 		addon.ssgiTrace(this._h, uniforms)

@@ -132,9 +132,6 @@ if (tiled) {
 } else renderer = new rfx.Renderer(first.width, first.height)
 // --uvModel '"reference_gl"': every fragment sees the vUv the reference GL's rasteriser interpolates (rfx_set_uv_model) instead of (i + 0.5) / n
 if (opt.uvModel) (renderer.inner || renderer).setUvModel(opt.uvModel)
-// --composeFold true: a whole-frame renderer makes the Denoiser's last denoise draw and the compose draw in one launch (rfx_set_compose_fold(1), an
-// approximation a row tile never makes); the default, one launch per draw, is the setting under which `--ranks N` and one process write the same bytes
-if (opt.composeFold !== undefined && !renderer.inner) renderer.setComposeFold(opt.composeFold === true)
 if (opt.traa) {
 	const half = opt.traa === "half"
 	const traa = new rfx.TRAAEffect(scene, camera, new rfx.VelocityDepthNormalPass(scene, camera), { fullAccumulate: true }, true)

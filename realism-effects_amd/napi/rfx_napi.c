@@ -455,18 +455,6 @@ static napi_value n_set_uv_model(napi_env env, napi_callback_info info) {
     return NULL;
 }
 
-/* setComposeFold(ctx, enable): rfx_set_compose_fold */
-static napi_value n_set_compose_fold(napi_env env, napi_callback_info info) {
-    napi_value a[2];
-    int32_t on;
-    if (!get_args(env, info, 2, a)) return NULL;
-    rfx_ctx *c = get_ctx(env, a[0]);
-    if (!c || !get_int(env, a[1], &on)) return NULL;
-    int rc = rfx_set_compose_fold(c, on);
-    if (rc) return throw_rfx(env, c, "rfx_set_compose_fold", rc);
-    return NULL;
-}
-
 /* ---- row-tiled runs (rfx.h "row-tiled runs"): one Node process per GPU */
 /* splitRows(height, nranks, rank) -> [tile_y0, tile_rows] */
 static napi_value n_split_rows(napi_env env, napi_callback_info info) {
@@ -735,7 +723,7 @@ static napi_value init(napi_env env, napi_value exports) {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"abiVersion", n_abi_version}, {"create", n_create}, {"heldRows", n_held_rows}, {"upload", n_upload}, {"download", n_download},
         {"clear", n_clear}, {"setEnvironment", n_set_environment}, {"setEnvironmentImportance", n_set_environment_importance}, {"packGBuffer", n_pack_gbuffer}, {"packVelocity", n_pack_velocity}, {"ssgiMarch", n_ssgi}, {"ssgiTrace", n_ssgi_trace}, {"ssgiShade", n_ssgi_shade}, {"temporalReproject", n_temporal}, {"copyFramebuffer", n_copy_framebuffer}, {"poissonDenoise", n_denoise}, {"compose", n_compose}, {"finalCompose", n_final},
-        {"sync", n_sync}, {"setRowWindow", n_set_row_window}, {"setUvModel", n_set_uv_model}, {"setComposeFold", n_set_compose_fold}, {"cubeToEquirect", n_cube_to_equirect}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end}, {"profile", n_profile}, {"profileRead", n_profile_read},
+        {"sync", n_sync}, {"setRowWindow", n_set_row_window}, {"setUvModel", n_set_uv_model}, {"cubeToEquirect", n_cube_to_equirect}, {"haloViolations", n_halo_violations}, {"timeBegin", n_time_begin}, {"timeEnd", n_time_end}, {"profile", n_profile}, {"profileRead", n_profile_read},
         {"stageUpload", n_stage_upload}, {"stageFlip", n_stage_flip}, {"hostAlloc", n_host_alloc},
         {"splitRows", n_split_rows}, {"commUniqueId", n_comm_unique_id}, {"commInit", n_comm_init}, {"haloExchange", n_halo_exchange},
         {"allgatherHistory", n_allgather_history}, {"gatherHistoryRows", n_gather_history_rows}, {"commWait", n_comm_wait}, {"commDestroy", n_comm_destroy},

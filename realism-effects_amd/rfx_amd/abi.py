@@ -13,9 +13,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "..", "csrc", "librfx_hip.so")
 
-RFX_ABI_VERSION = 18
+RFX_ABI_VERSION = 19
 # rfx_profile_read's kinds (include/rfx.h RFX_PROF_*)
-PROF_KINDS = ("k1_prepass", "k1_ssgi_march", "k2_temporal_reproject", "k3_poisson_denoise_pass0", "k3_poisson_denoise_passN", "k3_passN_plus_k4_folded", "k4_compose", "k5_final_compose")
+PROF_KINDS = ("k1_prepass", "k1_ssgi_march", "k2_temporal_reproject", "k3_poisson_denoise_pass0", "k3_poisson_denoise_passN", "k4_compose", "k5_final_compose")
 RFX_UV_IDEAL, RFX_UV_REFERENCE_GL = 0, 1  # rfx_set_uv_model
 RFX_OK, RFX_EINVAL, RFX_ENOMEM, RFX_EDEVICE, RFX_ESTATE, RFX_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 
@@ -96,7 +96,7 @@ class FinalParams(C.Structure):
 
 EXPORTS = [
     "rfx_abi_version", "rfx_create", "rfx_destroy", "rfx_last_error", "rfx_get_geometry", "rfx_set_stream", "rfx_tex_texel_bytes", "rfx_tex_held_rows",
-    "rfx_upload", "rfx_download", "rfx_clear", "rfx_tex_device_ptr", "rfx_bind_external", "rfx_pack_gbuffer", "rfx_pack_velocity", "rfx_set_environment", "rfx_set_environment_importance", "rfx_download_environment", "rfx_cube_to_equirect", "rfx_set_row_window", "rfx_set_uv_model", "rfx_set_compose_fold", "rfx_ssgi_march", "rfx_ssgi_trace", "rfx_ssgi_shade", "rfx_temporal_reproject",
+    "rfx_upload", "rfx_download", "rfx_clear", "rfx_tex_device_ptr", "rfx_bind_external", "rfx_pack_gbuffer", "rfx_pack_velocity", "rfx_set_environment", "rfx_set_environment_importance", "rfx_download_environment", "rfx_cube_to_equirect", "rfx_set_row_window", "rfx_set_uv_model", "rfx_ssgi_march", "rfx_ssgi_trace", "rfx_ssgi_shade", "rfx_temporal_reproject",
     "rfx_copy_framebuffer", "rfx_poisson_denoise", "rfx_compose", "rfx_final_compose", "rfx_sync", "rfx_halo_violations", "rfx_time_begin", "rfx_time_end", "rfx_profile", "rfx_profile_read",
     "rfx_host_alloc", "rfx_host_free", "rfx_stage_upload", "rfx_stage_flip", "rfx_split_rows", "rfx_comm_unique_id", "rfx_comm_init", "rfx_comm_destroy", "rfx_halo_exchange", "rfx_allgather_history", "rfx_gather_history_rows", "rfx_ssgi_hit_rows", "rfx_ssgi_hit_mask", "rfx_comm_wait",
 ]
@@ -154,7 +154,6 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rfx_download_environment.argtypes = [vp, i, vp, C.POINTER(i)]
     lib.rfx_set_row_window.argtypes = [vp, C.c_int, C.c_int]
     lib.rfx_set_uv_model.argtypes = [vp, C.c_int]
-    lib.rfx_set_compose_fold.argtypes = [vp, C.c_int]
     lib.rfx_cube_to_equirect.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_int]
     lib.rfx_ssgi_march.argtypes = [vp, C.POINTER(SsgiParams)]
     lib.rfx_ssgi_trace.argtypes = [vp, C.POINTER(SsgiParams)]

@@ -228,13 +228,6 @@ class Context:
         m = {"ideal": abi.RFX_UV_IDEAL, "reference_gl": abi.RFX_UV_REFERENCE_GL}.get(model, model)
         self._chk(self.lib.rfx_set_uv_model(self._h, int(m)), "rfx_set_uv_model")
 
-    def set_compose_fold(self, enable=True):
-        """Opt in to the library making the Denoiser's last denoise draw and the compose draw that follows it in one launch on a whole-frame
-        context (include/rfx.h rfx_set_compose_fold: an approximation, -2.75 % frame time at 4K).  The default (False): one launch per
-        draw, the reference's LINEAR fetch at vUv exactly."""
-        self._chk(self.lib.rfx_set_compose_fold(self._h, 1 if enable else 0), "rfx_set_compose_fold")
-
-    # -- the four draws (+ the framebuffer copy)
     def ssgi_march(self, p: abi.SsgiParams):
         self._chk(self.lib.rfx_ssgi_march(self._h, C.byref(p)), "rfx_ssgi_march")
 

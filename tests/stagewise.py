@@ -118,24 +118,6 @@ class HipStages:
         c.compose(cp)
         return c.download(abi.TEX_COMPOSE)
 
-    def denoise_compose_folded(self, ins, outs_init, dp, comp_init, cp):
-        """the Denoiser's last denoise draw and the compose draw AS ONE LAUNCH (rfx_set_compose_fold(ctx, 1), opt-in): -> ([B0, B1], composed)"""
-        import ctypes as C
-        c = self.ctx
-        c.lib.rfx_internal_folded_draws.restype = C.c_uint
-        c.lib.rfx_internal_folded_draws.argtypes = [C.c_void_p]
-        assert dp.writeToB and not dp.inputIsTemporal
-        c.upload(abi.TEX_DENOISE_A0, ins[0]); c.upload(abi.TEX_DENOISE_A1, ins[1])
-        c.upload(abi.TEX_DENOISE_B0, outs_init[0]); c.upload(abi.TEX_DENOISE_B1, outs_init[1])
-        c.upload(abi.TEX_COMPOSE, comp_init)
-        n0 = c.lib.rfx_internal_folded_draws(c._h)
-        c.set_compose_fold(True)
-        c.poisson_denoise(dp)
-        c.compose(cp)
-        c.set_compose_fold(False)
-        assert c.lib.rfx_internal_folded_draws(c._h) == n0 + 1, "the pair was not folded into one launch"
-        return [c.download(abi.TEX_DENOISE_B0), c.download(abi.TEX_DENOISE_B1)], c.download(abi.TEX_COMPOSE)
-
     def close(self):
         assert self.ctx.halo_violations() == 0
         self.ctx.close()
@@ -169,26 +151,21 @@ def _h(t):  # RGBA16F target read back as float32 -> the half bit patterns (exac
 
 
 def run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start=1000, denoise_start=2000, shader_dir=None, log=print,
-        with_margins=True, n_perturb=6, sample_every=64, extra_perturb=96, compare_from=0, uv_model="reference_gl", rows=None, compare_only=None,
-        fold_stage=False):
+        with_margins=True, n_perturb=6, sample_every=64, extra_perturb=96, compare_from=0, uv_model="reference_gl", rows=None, compare_only=None):
     """Returns the list of parity.Report (one per stage output and frame).  frame_fn(i) -> dump frame i (rfx_amd.scene Frame).
     uv_model "reference_gl" (the default of the library and of this harness): the implementation (rfx_set_uv_model / rfxo_set_uv_model)
     evaluates the reference GL's own vUv planes, and the proving oracle then carries no vUv uncertainty at all; "ideal": (i + 0.5) / n on the
     implementation's side, the vUv uncertainty in the proofs.
     rows (y0, y1): every draw still covers the whole frame on both sides, but only that band of rows is compared and proven — what makes an
     8K frame affordable in the default suite (the numpy side of a whole 33 Mpixel stage output costs minutes).
-    compare_only: a set of frame numbers — the other frames only advance the reference chain (a long sequence compared at a few ages).
-    fold_stage: one more report per frame, "K4 compose (folded)": the implementation's OPT-IN one-launch form of the last denoise draw + the
-    compose draw (rfx_set_compose_fold) against the reference's K4 output.  Its inputs are the last denoise draw's, so the composed texel is
-    compared where the implementation's target B is bit-identical to the reference's over the compose draw's bilinear footprint (elsewhere the
-    two K4s do not see identical inputs: those pixels are excluded and their share is printed)."""
+    compare_only: a set of frame numbers — the other frames only advance the reference chain (a long sequence compared at a few ages)."""
     with O.uv_model({"ideal": "ideal", "reference_gl": "reference"}[uv_model]):
         return _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start, denoise_start, shader_dir, log,
-                    with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model, rows, compare_only, fold_stage)
+                    with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model, rows, compare_only)
 
 
 def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start, denoise_start, shader_dir, log,
-         with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model, rows=None, compare_only=None, fold_stage=False):
+         with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model, rows=None, compare_only=None):
     import chain
     y0, y1 = (0, H) if rows is None else (max(0, int(rows[0])), min(H, int(rows[1])))
     ref = chain.GLRefChain(W, H, blue, shader_dir=shader_dir, steps=steps, refineSteps=refine, denoiseIterations=iterations)
@@ -364,8 +341,6 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
             _one_denoise_pass(ref, f.camera, pi, idx[pi])
             RO = [_h(t) for t in (ref.t_A if horizontal else ref.t_B)]
             dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = idx[pi], int(pi == 0), int(not horizontal)
-            if pi == 2 * iterations - 1:  # the draw the Denoiser's loop ends with: kept for the folded stage below
-                last_pass = (ins, outs_init, type(dp).from_buffer_copy(bytes(dp)), RO)
             IO = impl.denoise(ins, outs_init, dp)
             m = margins_of(lambda: ora.denoise(ins, outs_init, dp), True, bad_of(IO, RO, True))
             for j in range(2):
@@ -377,24 +352,6 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
         RC = np.ascontiguousarray(ref.t_compose.read())
         IC = impl.compose(Bc, comp_prev, cp)
         check(tag + "K4 compose", IC, RC, margins_of(lambda: ora.compose(Bc, comp_prev, cp), False, bad_of(IC, RC, False)), half=False)
-        # ---- the same two draws as ONE launch (opt-in fold): against the reference's K4 output, where K4's inputs are identical
-        if fold_stage and iterations >= 1 and hasattr(impl, "denoise_compose_folded"):
-            l_ins, l_init, l_dp, l_RO = last_pass
-            IBf, ICf = impl.denoise_compose_folded(l_ins, l_init, l_dp, comp_prev, cp)
-            differs = np.zeros((H, W), bool)
-            for g, w in zip(IBf, l_RO):
-                differs |= (np.ascontiguousarray(g).view(np.uint16).reshape(H, W, 4) != np.ascontiguousarray(w).view(np.uint16).reshape(H, W, 4)).any(axis=-1)
-            near = differs.copy()  # the compose draw's LINEAR fetch reaches the eight neighbours at most
-            near[1:] |= differs[:-1]; near[:-1] |= differs[1:]
-            near[:, 1:] |= near[:, :-1].copy(); near[:, :-1] |= near[:, 1:].copy()
-            bad = bad_of(ICf, RC, False) & ~near
-            m, at_risk = margins_of(lambda: ora.compose(Bc, comp_prev, cp), False, bad)
-            r = strict(tag + "K4 compose (folded)", ICf[y0:y1], RC[y0:y1], explainable=None if m is None else m[y0:y1], half=False, ignore=near[y0:y1])
-            r.at_risk = at_risk
-            r.compared_fraction = 1.0 - float(near[y0:y1].mean())
-            r.unexplained_equal_to_restatement = 0
-            reports.append(r)
-            log(r.line() + "   [compared on %.2f %% of the band: where target B == the reference's bit for bit over the fetch footprint]" % (100 * r.compared_fraction))
     impl.close()
     return reports
 

@@ -22,7 +22,6 @@ MOCK = textwrap.dedent('''
     class FakeCtx:
         def halo_violations(self): return 0
         def close(self): pass
-        def set_compose_fold(self, enable): pass
     kms = {"k1_ssgi_march": 0.61, "k2_temporal_reproject": 0.45, "k3_poisson_denoise_pass0": 0.24, "k3_poisson_denoise_pass1": 0.38, "k4_compose": 0.11}
     bench.build_case = lambda world, rank, lr, dev, d, one, W, H, tiles, *a, **k: dict(ctx=FakeCtx(), rows=tiles[rank][1], halo=0 if world == 1 else 12,
                                                                                        frame=None, fx=None, renderer=None)
@@ -33,7 +32,7 @@ MOCK = textwrap.dedent('''
             time.sleep(3600)
         return 0.0366, (0.0380 if k.get("cold") else None)
     bench.time_case = time_case
-    bench.kernel_times = lambda *a, **k: (dict(kms), kms["k3_poisson_denoise_pass1"] + kms["k4_compose"])
+    bench.kernel_times = lambda *a, **k: dict(kms)
     bench.kernel_times_in_frame = lambda *a, **k: (dict(kms, k1_ssgi_march=0.55), 0.11)
     bench.cpu_baseline = lambda *a, **k: {"value": 10.4, "unit": "Mpixels/s", "cores": 32, "kind": "reference", "sample": "mock"}
     bench.main()
@@ -61,7 +60,7 @@ def test_bench_line_single_gpu():
     # the dominant kernel's duration is its in-frame launch PLUS its depth pre-pass (whose input is part of K1's algorithmic bytes)
     assert abs(j["roofline"]["avg_launch_ms"] - 0.66) < 1e-6 and abs(j["kernel_ms"]["k1_ssgi_march"] - 0.55) < 1e-6 and abs(j["k1_prepass_ms"] - 0.11) < 1e-6
     assert abs(j["roofline"]["achieved"] - 68 * 3840 * 2160 / 0.66e-3 / 1e9) < 0.1
-    assert j["config"]["compose_fold"] is False and abs(j["ms_per_step_compose_fold_opt_in"] - 1.83) < 1e-6  # the default is one launch per draw; the opt-in rides beside it
+    assert "compose_fold" not in j["config"]  # one launch per draw is the only path since ABI 19
     assert j["cpu_baseline"]["kind"] == "reference" and j["config"]["workload"].startswith("configs[2]")
 
 

@@ -247,7 +247,6 @@ def test_row_tiled_chain_is_bit_identical_to_single_context(ntiles):
             fx.update(renderer, None)
 
     single = Context(W, H)
-    single.set_compose_fold(False)  # a row tile makes one launch per draw: the comparison is with the whole-frame context doing the same (include/rfx.h rfx_set_compose_fold)
     run(single)
     tiled = _LocalTiles(W, H, ntiles, halo)
     run(tiled)
@@ -1165,203 +1164,10 @@ def test_rgb_history_twin_matches_composed_gi(blue_noise):
     ctx.close()
 
 
-@pytest.mark.parametrize("size,uv_ideal,rgb", [((256, 144), False, 1), ((333, 77), False, 0), ((120, 200), True, 1), ((640, 360), False, 1)])
-def test_compose_folded_into_the_last_denoise_draw(blue_noise, size, uv_ideal, rgb):
-    """Under rfx_set_compose_fold(ctx, 1) (opt-in since ABI 18) the library holds the Denoiser's last denoise draw (a later pass into target B,
-    whole-frame context, own stream) and makes the compose draw that follows it in the same launch (k3_denoise.hip FUSE, rfx_ctx.h k3_held).
-    Same calls with anything in between (here: rfx_sync), or without the opt-in, make two launches.  Folded == unfolded: target B bit for bit; the composed texel up to the bilinear weights the compose draw's LINEAR
-    fetch at vUv puts on the neighbours of the texel the folded form reads — vUv * size - 0.5 is the texel's index only up to the rounding of
-    vUv: weights of 0 on 40-60 % of the texels and up to 3e-5 (640 wide) / 2.4e-4 (4K) on the rest under the reference GL's vUv; here the
-    inputs are white noise of amplitude 3, the worst case for it.  Discarded fragments keep the target's texel (and its RGB twin mirrors
-    it) either way.  (The 4K figure on a real chain: test_folded_compose_on_a_4k_chain.)"""
-    import ctypes as C
-    from rfx_amd import abi
-    from rfx_amd.context import Context
-    from rfx_amd.scene import synthetic_frame
-
-    W, H = size
-    f = synthetic_frame(W, H, 1)
-    assert (f.depth == 1.0).mean() > 0.02  # there IS background: both draws discard there
-    sp, tp, dp, cp = _params(abi, f, f.camera, 1.0, 12, 3)
-    rs = np.random.RandomState(11)
-    held = rs.rand(H, W, 4).astype(np.float32)
-    A = [(rs.rand(H, W, 4) * 3.0).astype(np.float16).view(np.uint16) for _ in range(2)]
-    Bold = [rs.rand(H, W, 4).astype(np.float16).view(np.uint16) for _ in range(2)]
-    dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 7, 0, 1
-    cp.writeHistoryRGB = rgb
-    out = {}
-    for mode in ("unfolded", "folded"):
-        ctx = Context(W, H)
-        ctx.lib.rfx_internal_folded_draws.restype = C.c_uint
-        ctx.lib.rfx_internal_folded_draws.argtypes = [C.c_void_p]
-        if uv_ideal:
-            ctx.set_uv_model("ideal")
-        if mode == "folded":
-            ctx.set_compose_fold(True)  # opt-in since ABI 18 (include/rfx.h rfx_set_compose_fold)
-        ctx.upload_frame(f)
-        ctx.upload(abi.TEX_COMPOSE, held)
-        if rgb:
-            ctx.upload(abi.TEX_COMPOSE_RGB, np.ascontiguousarray(held[..., :3]))
-        for t, a, b in ((0, abi.TEX_DENOISE_A0, abi.TEX_DENOISE_B0), (1, abi.TEX_DENOISE_A1, abi.TEX_DENOISE_B1)):
-            ctx.upload(a, A[t])
-            ctx.upload(b, Bold[t])
-        ctx.poisson_denoise(dp)
-        if mode == "unfolded":
-            ctx.sync()
-        ctx.compose(cp)
-        assert ctx.lib.rfx_internal_folded_draws(ctx._h) == (1 if mode == "folded" else 0)
-        out[mode] = [ctx.download(abi.TEX_DENOISE_B0), ctx.download(abi.TEX_DENOISE_B1), ctx.download(abi.TEX_COMPOSE)] + (
-            [ctx.download(abi.TEX_COMPOSE_RGB)] if rgb else [])
-        # a second pair: the held state is per draw, not sticky
-        ctx.poisson_denoise(dp)
-        assert np.array_equal(ctx.download(abi.TEX_DENOISE_B0), out[mode][0])  # (the download launched the held draw)
-        ctx.compose(cp)
-        assert ctx.lib.rfx_internal_folded_draws(ctx._h) == (1 if mode == "folded" else 0)
-        assert ctx.halo_violations() == 0
-        ctx.close()
-    u, fo = out["unfolded"], out["folded"]
-    assert np.array_equal(u[0], fo[0]) and np.array_equal(u[1], fo[1])
-    disc = np.all(u[2] == held, axis=-1)
-    assert disc.mean() > 0.02 and np.array_equal(u[2][disc], fo[2][disc])
-    err = np.abs(u[2] - fo[2]).max()
-    print("folded vs unfolded compose %dx%d: max |diff| %.3g (values up to %.3g)" % (W, H, err, np.abs(u[2]).max()))
-    assert np.allclose(fo[2], u[2], rtol=2e-5, atol=1.5e-4)
-    if rgb:
-        assert np.array_equal(fo[3], fo[2][..., :3]) and np.array_equal(u[3], u[2][..., :3])
-
-
-@pytest.mark.parametrize("between", ["sync", "download", "row_window", "uv_model", "clear_other", "time_begin", "fold_off", "never_enabled", "exported_target",
-                                     "exported_compose", "external_target", "user_stream"])
-def test_any_call_between_the_two_draws_unfolds_them(blue_noise, between):
-    """The held denoise draw (rfx_ctx.h k3_held; rfx_set_compose_fold(ctx, 1)) is launched by WHATEVER the next call on the context is, unless
-    that call is the compose draw that reads its targets: nothing a host does between the two draws can observe the hold.  And a draw is never
-    held at all without the opt-in (the default), nor when a plane either draw writes is visible outside the library — its address handed out
-    (rfx_tex_device_ptr) or a caller's buffer bound to it (rfx_bind_external): such a host may synchronise with the device by its own means
-    (ADVICE r04).  Every case must give the two-launch result bit for bit and count no folded draw."""
-    import ctypes as C
-    from rfx_amd import abi
-    from rfx_amd.context import Context
-    from rfx_amd.scene import synthetic_frame
-
-    W, H = 192, 108
-    f = synthetic_frame(W, H, 1)
-    sp, tp, dp, cp = _params(abi, f, f.camera, 1.0, 12, 3)
-    rs = np.random.RandomState(3)
-    held = rs.rand(H, W, 4).astype(np.float32)
-    A = [(rs.rand(H, W, 4) * 2.0).astype(np.float16).view(np.uint16) for _ in range(2)]
-    dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 9, 0, 1
-
-    def run(mode):
-        ctx = Context(W, H)
-        ctx.lib.rfx_internal_folded_draws.restype = C.c_uint
-        ctx.lib.rfx_internal_folded_draws.argtypes = [C.c_void_p]
-        ctx.upload_frame(f)
-        ctx.upload(abi.TEX_COMPOSE, held)
-        ctx.upload(abi.TEX_DENOISE_A0, A[0])
-        ctx.upload(abi.TEX_DENOISE_A1, A[1])
-        if mode != "never_enabled":
-            ctx.set_compose_fold(True)
-        if mode == "fold_off":
-            ctx.set_compose_fold(False)
-        if mode == "exported_target":
-            assert ctx.device_ptr(abi.TEX_DENOISE_B1)
-        if mode == "exported_compose":
-            assert ctx.device_ptr(abi.TEX_COMPOSE)
-        ext = None
-        if mode == "external_target":  # a caller's buffer behind target B0 (here: another context's plane of the same size)
-            ext = Context(W, H)
-            ctx.bind_external(abi.TEX_DENOISE_B0, ext.device_ptr(abi.TEX_DENOISE_B0))
-        if mode == "user_stream":
-            ctx.set_stream(0)  # handle 0 = back to the library's own stream (a real host stream never folds: rfx_api.hip)
-        ctx.poisson_denoise(dp)
-        if mode == "sync":
-            ctx.sync()
-        elif mode == "download":
-            ctx.download(abi.TEX_DEPTH)
-        elif mode == "row_window":
-            ctx.set_row_window(0, 0)
-        elif mode == "uv_model":
-            ctx.set_uv_model("reference_gl")
-        elif mode == "clear_other":
-            ctx.clear(abi.TEX_FINAL)
-        elif mode == "time_begin":
-            ctx.time_begin()
-        ctx.compose(cp)
-        n = ctx.lib.rfx_internal_folded_draws(ctx._h)
-        out = (ctx.download(abi.TEX_DENOISE_B0), ctx.download(abi.TEX_DENOISE_B1), ctx.download(abi.TEX_COMPOSE))
-        assert ctx.halo_violations() == 0
-        ctx.close()
-        if ext is not None:
-            ext.close()
-        return n, out
-
-    n_ref, ref = run("sync")
-    assert n_ref == 0
-    n, got = run(between)
-    if between == "user_stream":  # handle 0 selects the library's own stream: the fold is allowed there
-        assert n == 1 and np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
-        return
-    assert n == 0, between
-    for a, b in zip(got, ref):
-        assert np.array_equal(a, b), between
-
-
-def test_folded_compose_on_a_4k_chain(blue_noise):
-    """What the fold (see above) changes on BASELINE configs[2]: K1 -> K2 -> K3 -> K3 (+ K4) over two frames of the 4K synthetic orbit, the last two
-    draws once as two launches and once as one.  Measured on MI355X: profiles/r04_parity/folded_compose_4k.txt; the bounds are ~3x that."""
-    import ctypes as C
-    from rfx_amd import abi
-    from rfx_amd.context import Context
-    from rfx_amd.scene import synthetic_frame
-
-    W, H = 3840, 2160
-    out = {}
-    frames = [synthetic_frame(W, H, i) for i in range(2)]
-    for mode in ("unfolded", "folded"):
-        ctx = Context(W, H)
-        ctx.lib.rfx_internal_folded_draws.restype = C.c_uint
-        ctx.lib.rfx_internal_folded_draws.argtypes = [C.c_void_p]
-        if mode == "folded":
-            ctx.set_compose_fold(True)
-        prev, keep = frames[0].camera, 0.0
-        for fi, f in enumerate(frames):
-            sp, tp, dp, cp = _params(abi, f, prev, keep)
-            ctx.upload_frame(f)
-            sp.blueNoiseIndex = 40 + fi
-            ctx.ssgi_march(sp)
-            ctx.temporal_reproject(tp)
-            dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 50 + 2 * fi, 1, 0
-            ctx.poisson_denoise(dp)
-            dp.blueNoiseIndex, dp.inputIsTemporal, dp.writeToB = 51 + 2 * fi, 0, 1
-            ctx.poisson_denoise(dp)
-            if mode == "unfolded":
-                ctx.sync()
-            ctx.compose(cp)
-            prev, keep = f.camera, 1.0
-            if fi == 0:
-                out[mode + "0"] = ctx.download(abi.TEX_COMPOSE)
-        assert ctx.lib.rfx_internal_folded_draws(ctx._h) == (2 if mode == "folded" else 0)
-        out[mode] = ctx.download(abi.TEX_COMPOSE)
-        ctx.close()
-    # frame 0: the same inputs on both sides -> the fold's own deviation
-    d0 = np.abs(out["folded0"][..., :3] - out["unfolded0"][..., :3])
-    n3 = int((d0.max(axis=-1) > 1e-3).sum())
-    rel = d0 / np.maximum(np.abs(out["unfolded0"][..., :3]), 1e-3)
-    print("fold at 4K, frame 0 (identical inputs): max |diff| %.3g, max relative %.3g, texels beyond 1e-3: %d of %d; composed values up to %.3g"
-          % (d0.max(), rel.max(), n3, W * H, np.abs(out["unfolded0"]).max()))
-    # frame 1: the deviation after it went through the next frame's K1 history fetch, K2 and K3 (free-running)
-    d1 = np.abs(out["folded"][..., :3] - out["unfolded"][..., :3])
-    n31 = int((d1.max(axis=-1) > 1e-3).sum())
-    print("fold at 4K, frame 1 (free-running): max |diff| %.3g, texels beyond 1e-3: %d (%.4f %%)" % (d1.max(), n31, 100.0 * n31 / (W * H)))
-    assert d0.max() < 3e-3 and n3 <= 30
-    assert n31 <= 3e-4 * W * H
-
-
 def test_per_draw_profile_counts_the_launches_of_a_frame(blue_noise):
     """rfx_profile / rfx_profile_read (include/rfx.h): inside a frame loop every draw's launches are bracketed by events on the stream they run on —
     three frames through SSGIEffect give 3 launches of each of K1's pre-pass, K1, K2, K3 pass 0, the later K3 pass and K4 (one launch per draw,
-    the default), none before the reset or after the stop; with the opt-in fold the last two draws are one launch of its own kind.  The
-    composed frames are the same bytes with and without the events."""
+    the reference's own sequence), none before the reset or after the stop.  The composed frames are the same bytes with and without the events."""
     import types
     from rfx_amd import abi
     from rfx_amd.context import Context
@@ -1372,10 +1178,8 @@ def test_per_draw_profile_counts_the_launches_of_a_frame(blue_noise):
     f = synthetic_frame(W, H, 1)
     f.static = True
     outs = {}
-    for mode in ("plain", "profiled", "profiled+fold"):
+    for mode in ("plain", "profiled"):
         ctx = Context(W, H)
-        if mode.endswith("fold"):
-            ctx.set_compose_fold(True)
         scene = types.SimpleNamespace(frame=f)
         fx = SSGIEffect(None, scene, f.camera, dict(width=W, height=H, steps=8, refineSteps=2, denoiseIterations=1), seeds=dict(ssgi=5, denoise=6))
         fx.update(ctx, None)  # before the reset: not counted
@@ -1388,8 +1192,7 @@ def test_per_draw_profile_counts_the_launches_of_a_frame(blue_noise):
             ctx.profile(False)
             fx.update(ctx, None)  # after the stop: not counted
             again = ctx.profile_read()
-            want = {"k1_prepass": 3, "k1_ssgi_march": 3, "k2_temporal_reproject": 3, "k3_poisson_denoise_pass0": 3}
-            want.update({"k3_passN_plus_k4_folded": 3} if mode.endswith("fold") else {"k3_poisson_denoise_passN": 3, "k4_compose": 3})
+            want = {"k1_prepass": 3, "k1_ssgi_march": 3, "k2_temporal_reproject": 3, "k3_poisson_denoise_pass0": 3, "k3_poisson_denoise_passN": 3, "k4_compose": 3}
             assert {k: n for k, (_ms, n) in got.items()} == want, got
             assert all(ms >= 0.0 for ms, _n in got.values())
             assert {k: n for k, (_ms, n) in again.items()} == want  # the sums stand until the next reset

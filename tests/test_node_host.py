@@ -503,8 +503,7 @@ def test_node_row_tiled_run_equals_single_process(tmp_path, ranks):
         dirs.append(d)
     env = dict(os.environ, RFX_ONE_GPU="1")
     one, many = str(tmp_path / "one"), str(tmp_path / "many")
-    # (--composeFold false: the whole-frame process makes one launch per draw, as a row tile does — include/rfx.h rfx_set_compose_fold)
-    subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", one, "--steps", "12", "--refineSteps", "3", "--composeFold", "false"], text=True, env=env)
+    subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", one, "--steps", "12", "--refineSteps", "3"], text=True, env=env)
     res = subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", many, "--steps", "12", "--refineSteps", "3", "--ranks", str(ranks)],
                                   text=True, env=env, timeout=600)
     info = json.loads(res.strip().splitlines()[-1])

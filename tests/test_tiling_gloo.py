@@ -350,7 +350,6 @@ def test_tiled_kernels_are_bit_identical_to_one_context(tmp_path, world):
     mp.spawn(_kernel_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
     ref = Context(W, H)
-    ref.set_compose_fold(False)  # row tiles make one launch per draw (include/rfx.h rfx_set_compose_fold)
     _chain(ref, types.SimpleNamespace(frame=None), frames[0].camera, frames)
     for rank in range(world):
         z = np.load(os.path.join(str(tmp_path), "k%d.npz" % rank))
@@ -384,7 +383,6 @@ def test_tiled_kernels_with_c_abi_exchanges_are_bit_identical_to_one_context(tmp
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
     frames = [synthetic_frame(W, H, i) for i in range(FRAMES)]
     ref = Context(W, H)
-    ref.set_compose_fold(False)  # row tiles make one launch per draw (include/rfx.h rfx_set_compose_fold)
     _chain(ref, types.SimpleNamespace(frame=None), frames[0].camera, frames)
     for rank in range(world):
         z = np.load(os.path.join(str(tmp_path), "c%d.npz" % rank))

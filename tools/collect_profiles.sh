@@ -75,7 +75,7 @@ rows = IM.table(sys.argv[1])
 args = []
 for frag, key in IM.MIX_KEY:
     for name, m in rows.items():
-        if frag in name and "true>(K3Args)" not in name:  # (the folded launch is not the default path)
+        if frag in name:
             args.append("%s=%s" % (key, m["valu_per_px"]))
             break
 subprocess.call([sys.executable, sys.argv[2] + "/tools/isa_mix.py", "--out", sys.argv[1] + "/isa_other_mix.json", "--valu-per-px"] + args,

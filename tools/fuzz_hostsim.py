@@ -99,28 +99,6 @@ for it in range(a.n):
                 if frac > lim + 2.0 / (W * H):
                     fails += 1
                     print("MISMATCH %s frame %d: %.3f%% of pixels (in-tolerance max %.2e)  cfg %s" % (name, o["fi"], 100 * frac, mx, cfg), flush=True)
-            # the last denoise draw + the compose draw as a frame issues them on a whole-frame context: ONE launch (rfx_ctx.h k3_held) — against
-            # the same two calls with a sync in between (two launches): target B bit for bit, the composed texel up to the bilinear weights the
-            # compose draw's LINEAR fetch at vUv puts on the texel's neighbours (<= ~W * 2^-22)
-            pair = {}
-            for mode in ("two", "one"):
-                for t, a_, b_ in ((0, abi.TEX_DENOISE_A0, abi.TEX_DENOISE_B0), (1, abi.TEX_DENOISE_A1, abi.TEX_DENOISE_B1)):
-                    ctx.upload(a_, o["A"][t]); ctx.upload(b_, o["B"][t])
-                ctx.upload(abi.TEX_COMPOSE, o["hist"])
-                ctx.set_compose_fold(mode == "one")  # opt-in since ABI 18
-                ctx.poisson_denoise(dp)
-                if mode == "two":
-                    ctx.sync()
-                ctx.compose(o["cp"])
-                pair[mode] = (ctx.download(abi.TEX_DENOISE_B0), ctx.download(abi.TEX_DENOISE_B1), ctx.download(abi.TEX_COMPOSE))
-            nchecks += 1
-            same_b = np.array_equal(pair["one"][0], pair["two"][0]) and np.array_equal(pair["one"][1], pair["two"][1])
-            cu, cf = pair["two"][2][..., :3], pair["one"][2][..., :3]
-            tol = max(W, H) * 2.0 ** -21 * float(np.abs(cu).max()) + 1e-6
-            if not same_b or not np.all(np.abs(cf - cu) <= tol):
-                fails += 1
-                print("MISMATCH folded compose frame %d: target B %s, composed max |diff| %.3g (tolerance %.3g)  cfg %s" % (
-                    o["fi"], "equal" if same_b else "DIFFERS", float(np.abs(cf - cu).max()), tol, cfg), flush=True)
         assert ctx.halo_violations() == 0, "halo violations"
         ctx.close()
         # ... and cut into row tiles (ragged, as thin as the halo allows): every tile's own rows, each stage fed the oracle's whole-frame

@@ -26,8 +26,8 @@ RATE_FAST, RATE_GEN, RATE_PK, RATE_TRANS, RATE_CND_COLD = 2.7, 4.2, 4.55, 8.3, 2
 KERNELS = {  # key -> (source, mangled-name fragment, contraction flag)
     "k1_ssgi_march": ("k1_ssgi.hip", "k1_ssgi_marchILi6ELb0ELb0ELi0E", "off"),  # PROJ_CENTRED | PROJ_TABLE_POW2: the 16:9 frames' specialisation
     "k2_temporal_reproject": ("k2_temporal.hip", "k2_temporal_reprojectILi0ELi2ELb1ELb0ELb1E", "off"),
-    "k3_poisson_denoise_pass0": ("k3_denoise.hip", "k3_tiledILb1ELi2ELi74ELb1ELb0E", "fast-honor-pragmas"),
-    "k3_poisson_denoise_pass1": ("k3_denoise.hip", "k3_tiledILb0ELi2ELi76ELb1ELb0E", "fast-honor-pragmas"),
+    "k3_poisson_denoise_pass0": ("k3_denoise.hip", "k3_tiledILb1ELi2ELi74ELb1EEE", "fast-honor-pragmas"),
+    "k3_poisson_denoise_pass1": ("k3_denoise.hip", "k3_tiledILb0ELi2ELi76ELb1EEE", "fast-honor-pragmas"),
     "k4_compose": ("k4_compose.hip", "k4_composeILb1E", "fast-honor-pragmas"),
 }
 
