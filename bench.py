@@ -205,7 +205,7 @@ def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, 
             dist.broadcast_object_list(box, src=0)
             uid = box[0]
             # the exchanges behind the C ABI: RCCL Send/Recv + all-gather on the context's own exchange stream (rfx.h "row-tiled runs")
-            renderer = tiling.CommTiledRenderer(ctx, rank, world, uid, history_gather=HISTORY_GATHER[0])
+            renderer = tiling.CommTiledRenderer(ctx, rank, world, uid, history_gather="all" if HISTORY_GATHER[0] == "peer" else HISTORY_GATHER[0])
             exchange = "C ABI: rfx_halo_exchange / rfx_allgather_history (RCCL, own stream, overlapped)"
             bad = [verify_exchange(ctx, rank, world)]
             flags = [None] * world
@@ -220,8 +220,17 @@ def build_case(world, rank, local_rank, dev, dist, one_gpu, W, H, tiles, steps, 
             torch.cuda.set_stream(stream)
             ctx.set_stream(stream.cuda_stream)
             ctx.uses_torch_stream = not one_gpu  # gloo stages device tensors through the host: drain the stream around every exchange there
-            renderer = tiling.TiledRenderer(ctx, tiling.bind_torch_buffers(ctx, dev), rank, world, group=group)
+            # (the peer pull reads the library's own RGB twin through IPC mappings: not bound to a torch tensor then)
+            texs = tiling.EXCHANGED if HISTORY_GATHER[0] == "peer" else None
+            renderer = tiling.TiledRenderer(ctx, tiling.bind_torch_buffers(ctx, dev, texs=texs), rank, world, group=group)
             exchange = "torch.distributed (%s)" % ("gloo, one-GPU functional mode" if one_gpu else "nccl = RCCL")
+        if HISTORY_GATHER[0] == "peer":
+            def all_gather_object(obj):
+                out = [None] * world
+                dist.all_gather_object(out, obj, group=group)
+                return out
+            renderer.use_peer_history(all_gather_object)
+            exchange += "; composed GI: rfx_peer_gather_history (peer loads through IPC mappings, device-driven)"
     # static: the same dump every step, uploaded once before the timed region (the metric is quoted with inputs resident in HBM)
     frame = types.SimpleNamespace(depth=depth_full, gbuffer=band.gbuffer, velocity=band.velocity, direct=band.direct, camera=band.camera, static=True)
     scene = types.SimpleNamespace(frame=frame)
@@ -375,8 +384,12 @@ def main():
     ap.add_argument("--extras-timeout", type=int, default=480, help="seconds the N > 1 extras (weak scaling, configs[4]) may take before the headline line is printed without them")
     ap.add_argument("--configs4-size", default="7680x4320", help="N > 1 extras: frame of the BASELINE configs[4] case (tests shrink it)")
     ap.add_argument("--no-extras", action="store_true", help="N > 1: only the headline case (skip the weak-scaling and configs[4] extras)")
-    ap.add_argument("--history-gather", choices=("all", "bounded"), default="all",
-                    help="N > 1: the composed GI as a whole-frame all-gather under the next frame's trace (default), or only the rows the traced rays read, between trace and shade (rfx_gather_history_rows)")
+    ap.add_argument("--no-kernel-loops", action="store_true", help="skip kernel_ms_solo (back-to-back launches of one entry point): a profile taken over this command then "
+                    "holds in-frame launches only (tools/collect_profiles.sh)")
+    ap.add_argument("--no-configs4", action="store_true", help="N = 1: skip the BASELINE configs[4] extra (8K, steps 40, six K3 draws: ~1-2 min of host-side dump generation)")
+    ap.add_argument("--history-gather", choices=("all", "bounded", "peer"), default="all",
+                    help="N > 1: the composed GI as a whole-frame all-gather under the next frame's trace (default); only the column blocks the traced rays read, between trace and "
+                         "shade, as packed RCCL messages (bounded: rfx_gather_history_rows) or pulled by the consumer's own kernel through IPC mappings (peer: rfx_peer_gather_history)")
     args = ap.parse_args()
     HISTORY_GATHER[0] = args.history_gather
 
@@ -462,7 +475,7 @@ def main():
     if args.checksum:  # before the per-kernel timing below re-runs kernels on this rank's tile only
         import hashlib
         renderer = case["renderer"]
-        if getattr(renderer, "history_gather", "all") == "bounded":  # the ranks hold only the rows their own rays needed: complete the frame
+        if getattr(renderer, "history_gather", "all") in ("bounded", "peer"):  # the ranks hold only the rows their own rays needed: complete the frame
             renderer.gather_whole_history()
         # .rgb of the whole composed frame: what a tiled run gathers (RFX_TEX_COMPOSE_RGB) and what the next frame's K1 reads
         rgb = ctx.download(abi.TEX_COMPOSE_RGB) if getattr(renderer, "gather_history_rgb", False) else ctx.download(abi.TEX_COMPOSE)[..., :3]
@@ -473,17 +486,43 @@ def main():
     if world > 1:
         got = getattr(case["renderer"], "history_bytes_received", None)
         mode = getattr(case["renderer"], "history_gather", "all")
-        mine = float(np.mean(got[-args.steps:])) if (mode == "bounded" and got) else float((H1 - case["rows"]) * W1 * 12)
+        mine = float(np.mean(got[-args.steps:])) if (mode in ("bounded", "peer") and got) else float((H1 - case["rows"]) * W1 * 12)
         t = torch.tensor([mine], dtype=torch.float64, device=ctl_device(dist, dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         history = {"mode": mode, "MB_received_per_frame_max_over_ranks": round(float(t.item()) / 1e6, 3),
                    "whole_frame_allgather_MB": round((H1 - min(n for _, n in tiles)) * W1 * 12 / 1e6, 3)}
-    kms_solo = kernel_times(case, max(5, min(args.steps, 20)))
+    kms_solo = {} if args.no_kernel_loops else kernel_times(case, max(5, min(args.steps, 20)))
     kms, prepass_ms = kernel_times_in_frame(case, args.steps)
     rows, halo = case["rows"], case["halo"]
     copy_gbs = stream_copy_gbs(dev) if (rank == 0 and not args.no_stream_copy) else None  # measured here, after the timed region
 
     extras = {}
+    if world == 1 and not args.no_configs4 and not args.checksum and (W1, H1) == (W4K, H4K):
+        # BASELINE configs[4] on this one GPU, beside the headline: 8K, steps 40, denoiseIterations 3 (six K3 draws), 16 frames — the configuration
+        # north_star assigns to eight GPUs, and the one whose dominant kernel is NOT the 4K line's (five of its nine launches are K3's later pass)
+        try:
+            W8, H8 = (int(v) for v in args.configs4_size.split("x"))
+            c4 = build_case(1, 0, local_rank, dev, None, one_gpu, W8, H8, [(0, H8)], 40, 5, 3)
+            d4, _ = time_case(c4, None, 16, 2, dev, spinup=0, cold=False)
+            k4ms, pre4 = kernel_times_in_frame(c4, 16)
+            px8 = W8 * H8
+            per_frame = {"k1_ssgi_march": 1, "k2_temporal_reproject": 1, "k3_poisson_denoise_pass0": 1, "k3_poisson_denoise_pass1": 5, "k4_compose": 1}
+            frame_bytes = sum(BYTES_PER_PX[k] * n for k, n in per_frame.items())  # 68 + 80 + 68 + 5 x 52 + 52 = 528 B/px
+            sum_ms = sum(k4ms.get(k, 0.0) * n for k, n in per_frame.items())
+            extras["configs4_8k"] = {
+                "workload": "configs[4]: %dx%d (%.1f Mpixel) steps=40 refineSteps=5 denoiseIterations=3, K1+K2+6xK3+K4 per frame, 16 frames, one GPU" % (W8, H8, px8 / 1e6),
+                "ms_per_frame": round(d4 / 16 * 1e3, 4), "value": round(px8 * 16 / d4 / 1e6, 2), "unit": "Mpixels/s",
+                "kernel_ms_per_launch": {k: round(v, 4) for k, v in k4ms.items()}, "launches_per_frame": per_frame,
+                "k1_prepass_ms": round(pre4, 4) if pre4 is not None else None,
+                "roofline_frac_per_kernel": {k: round(BYTES_PER_PX[k] * px8 / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) for k, v in k4ms.items() if k in BYTES_PER_PX and v > 0},
+                "dominant_kernel_by_frame_time": max(per_frame, key=lambda k: k4ms.get(k, 0.0) * per_frame[k]),
+                "chain": {"algorithmic_bytes_per_px": frame_bytes, "sum_kernel_ms": round(sum_ms, 4),
+                          "frac_of_peak": round(frame_bytes * px8 / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sum_ms else None},
+                "halo_violations": c4["ctx"].halo_violations()}
+            c4["ctx"].close()
+            del c4
+        except Exception as e:  # noqa: BLE001  the headline is measured: report it, and what stopped the extra
+            extras["configs4_8k"] = {"error": repr(e)[:300]}
 
     def emit():
         if rank != 0:

@@ -352,6 +352,24 @@ int rfx_allgather_history(rfx_ctx *, rfx_tex id, void *ncclComm);
  * transfers are asynchronous like the other exchanges (rfx_comm_wait before rfx_ssgi_shade).  `bytes_received` (may be NULL): what this
  * rank receives this frame.  A host uses EITHER this or rfx_allgather_history after K4. */
 int rfx_gather_history_rows(rfx_ctx *, rfx_tex id, void *ncclComm, size_t *bytes_received);
+/* The DEVICE-DRIVEN form of the bounded gather (ABI 19; csrc/rfx_peer.hip): no RCCL, no host wait, no packing.  xGMI lets a kernel load a
+ * peer GPU's memory, so every rank exports the plane once (rfx_peer_export: RFX_PEER_BLOB_BYTES bytes holding HIP IPC handles of the plane and
+ * of a small flag block; the host moves the N blobs to every rank by any means it has — they are plain bytes) and opens its peers'
+ * (rfx_peer_open: `blobs` = the N blobs in rank order; the context's tile must be rfx_split_rows(height, nranks, rank)).  Then, per frame,
+ * BETWEEN rfx_ssgi_trace and rfx_ssgi_shade and on EVERY rank, rfx_peer_gather_history enqueues on the exchange stream: a flag barrier through
+ * the peers' mapped flag blocks ("every rank's compose draw of the previous frame has executed"), ONE kernel that walks this rank's own row
+ * mask (rfx_ssgi_hit_mask's, already on the device) and copies the column blocks its rays will read straight out of their owners' planes, and
+ * a second barrier ("every rank has pulled") that the next rfx_compose — which overwrites those rows — is ordered after.  The shade is ordered
+ * after the pull by rfx_comm_wait, like the other exchanges.  Bit-identical to the all-gather form.  Nothing waits on the host:
+ * `bytes_pulled_previous_call` (may be NULL) reports what the PREVIOUS call's kernel moved, and a peer that never reached a barrier (~2 s)
+ * surfaces as RFX_EDEVICE from the next call instead of hanging the device.  The plane must be the library's own (not rfx_bind_external).
+ * Contexts of one process (one per device, peer access enabled by the host) are recognised by the blob's process id and use each other's
+ * addresses directly.  A host uses ONE of rfx_allgather_history / rfx_gather_history_rows / rfx_peer_gather_history. */
+#define RFX_PEER_BLOB_BYTES 192
+int rfx_peer_export(rfx_ctx *, rfx_tex id, void *blob);
+int rfx_peer_open(rfx_ctx *, rfx_tex id, const void *blobs, int rank, int nranks);
+int rfx_peer_gather_history(rfx_ctx *, rfx_tex id, size_t *bytes_pulled_previous_call);
+int rfx_peer_close(rfx_ctx *);
 /* The reduction on its own (any context, no communicator): after rfx_ssgi_trace, the inclusive range of history rows the shade of the
  * traced rows will read; row_hi < row_lo when it reads none.  Blocks until the trace has finished. */
 int rfx_ssgi_hit_rows(rfx_ctx *, int *row_lo, int *row_hi);

@@ -17,7 +17,7 @@ obj)
 link)
   lib=$2; shift 2
   objs=""
-  for o in rfx_api rfx_comm k0_import k1_ssgi k2_temporal k3_denoise k4_compose; do
+  for o in rfx_api rfx_comm rfx_peer k0_import k1_ssgi k2_temporal k3_denoise k4_compose; do
     r=$o.o
     for kv in "$@"; do [ "${kv%%=*}" = "$o" ] && r=variants/${kv#*=}.o; done
     objs="$objs $r"

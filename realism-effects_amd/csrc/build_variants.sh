@@ -14,7 +14,7 @@ for spec in "$@"; do
   (
     /opt/rocm/bin/hipcc $F $defs -c $stem.hip -o variants/${stem}_$name.o 2>/dev/null
     objs=""
-    for o in rfx_api rfx_comm k0_import k1_ssgi k2_temporal k3_denoise k4_compose; do
+    for o in rfx_api rfx_comm rfx_peer k0_import k1_ssgi k2_temporal k3_denoise k4_compose; do
       if [ $o = $stem ]; then objs="$objs variants/${stem}_$name.o"; else objs="$objs $o.o"; fi
     done
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o variants/librfx_${stem}_$name.so $objs 2>/dev/null

@@ -32,13 +32,12 @@ struct ProfScope {
     ProfScope(rfx_ctx *c_, int kind_, hipStream_t s) : c(c_), stream(s), kind(kind_) {
         if (!c->profiling || c->prof_recs.size() >= 8192) return;
         a = prof_event(c); b = prof_event(c);
-        if (!a || !b) { if (a) c->prof_free.push_back(a); if (b) c->prof_free.push_back(b); a = b = nullptr; return; }
-        hipEventRecord(a, stream);
+        if (!a || !b || hipEventRecord(a, stream) != hipSuccess) drop();  // (a capturing user stream refuses the record: the draw is simply not timed)
     }
-    void set_kind(int k) { kind = k; }
+    void drop() { if (a) c->prof_free.push_back(a); if (b) c->prof_free.push_back(b); a = b = nullptr; }
     ~ProfScope() {
         if (!a) return;
-        hipEventRecord(b, stream);
+        if (hipEventRecord(b, stream) != hipSuccess) { drop(); return; }  // never a half-recorded pair in prof_recs
         c->prof_recs.push_back({kind, a, b});
     }
 };
@@ -109,6 +108,7 @@ void rfx_destroy(rfx_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    rfx_peer_release(c);
     rfx_comm_release(c);
     // a staged copy may still be writing a back buffer: drain the upload stream before any buffer goes
     if (c->upload_stream) { hipStreamSynchronize(c->upload_stream); hipStreamDestroy(c->upload_stream); }
@@ -938,6 +938,10 @@ int rfx_compose(rfx_ctx *c, const rfx_compose_params *p) {
         A.rgb_out = (float *)c->slots[RFX_TEX_COMPOSE_RGB].ptr;  // held whole, like COMPOSE: frame row y at y * W
     }
     A.p = *p;
+    if (c->peer_release_pending) {  // rfx_peer_gather_history: this draw overwrites rows a peer's kernel may still be pulling
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_peer_release, 0));
+        c->peer_release_pending = false;
+    }
     if (any) {
         ProfScope prof(c, RFX_PROF_K4, c->stream);
         HIPCHK(c, rfx_launch_k4(A, c->stream));
@@ -1001,13 +1005,16 @@ int rfx_profile(rfx_ctx *c, int enable) {
 int rfx_profile_read(rfx_ctx *c, float *ms_sum, int *launches) {
     if (!c) return RFX_EINVAL;
     RFX_ENTER(c);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->prep_stream) HIPCHK(c, hipStreamSynchronize(c->prep_stream));
+    // every pair is waited for on its own: the draws may have been enqueued on a stream that is no longer the current one (rfx_set_stream between
+    // the draws and this call), which a synchronisation of today's streams would not cover; a pair that cannot be read is skipped, not fatal
     float ms[RFX_PROF_COUNT] = {0};
     int n[RFX_PROF_COUNT] = {0};
     for (const rfx_ctx::ProfRec &r : c->prof_recs) {
         float t = 0.0f;
-        HIPCHK(c, hipEventElapsedTime(&t, r.a, r.b));
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) {
+            (void)hipGetLastError();
+            continue;
+        }
         ms[r.kind] += t;
         n[r.kind]++;
     }

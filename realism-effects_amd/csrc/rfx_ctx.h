@@ -68,6 +68,16 @@ struct rfx_ctx {
     hipEvent_t ev_staged = nullptr, ev_frame_done = nullptr;
     hipEvent_t ev_batch[2] = {nullptr, nullptr};  // the copies published by the last two flips (recorded on upload_stream)
     unsigned int flips = 0;
+    // the peer-load history gather (rfx_peer.hip): this rank's flag block (fine-grained), the device table of every rank's plane and flag block
+    // ([0, n) planes, [n, 2 n) flag blocks), what the last call's kernels reported ([0] status bits, [1] texels pulled), the mappings to close
+    unsigned long long *peer_flags = nullptr;
+    void **peer_table_dev = nullptr;
+    unsigned long long *peer_status_dev = nullptr, *peer_status_host = nullptr;
+    std::vector<void *> peer_mapped;
+    hipEvent_t ev_peer_release = nullptr;  // recorded after the "every rank has pulled" barrier: the next compose draw waits for it
+    bool peer_release_pending = false;
+    int peer_n = 0, peer_rank = 0, peer_tex = -1;
+    unsigned long long peer_epoch = 0;
     // rfx_profile: event pairs around the launches of every draw since the last reset (kind, start, stop), and the events free for re-use
     struct ProfRec { int kind; hipEvent_t a, b; };
     bool profiling = false;
@@ -76,6 +86,7 @@ struct rfx_ctx {
     std::string err;
 };
 void rfx_comm_release(rfx_ctx *c);  // rfx_comm.hip: called by rfx_destroy
+void rfx_peer_release(rfx_ctx *c);  // rfx_peer.hip: called by rfx_destroy (before rfx_comm_release: it drains the exchange stream)
 // rfx_api.hip, for rfx_comm.hip: enqueue on the draw stream the reduction of the traced rays' history rows into rows_dev[0..1] (min, max)
 extern "C" int rfx_internal_hit_rows_enqueue(rfx_ctx *c, int *rows_dev);  // (internal: not part of include/rfx.h)
 // ... and of the traced rays' row masks into the first H words of c->hit_mask_dev (allocated here for `ranks` gathered copies)

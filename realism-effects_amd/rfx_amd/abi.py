@@ -14,6 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "..", "csrc", "librfx_hip.so")
 
 RFX_ABI_VERSION = 19
+PEER_BLOB_BYTES = 192  # include/rfx.h RFX_PEER_BLOB_BYTES
 # rfx_profile_read's kinds (include/rfx.h RFX_PROF_*)
 PROF_KINDS = ("k1_prepass", "k1_ssgi_march", "k2_temporal_reproject", "k3_poisson_denoise_pass0", "k3_poisson_denoise_passN", "k4_compose", "k5_final_compose")
 RFX_UV_IDEAL, RFX_UV_REFERENCE_GL = 0, 1  # rfx_set_uv_model
@@ -98,7 +99,7 @@ EXPORTS = [
     "rfx_abi_version", "rfx_create", "rfx_destroy", "rfx_last_error", "rfx_get_geometry", "rfx_set_stream", "rfx_tex_texel_bytes", "rfx_tex_held_rows",
     "rfx_upload", "rfx_download", "rfx_clear", "rfx_tex_device_ptr", "rfx_bind_external", "rfx_pack_gbuffer", "rfx_pack_velocity", "rfx_set_environment", "rfx_set_environment_importance", "rfx_download_environment", "rfx_cube_to_equirect", "rfx_set_row_window", "rfx_set_uv_model", "rfx_ssgi_march", "rfx_ssgi_trace", "rfx_ssgi_shade", "rfx_temporal_reproject",
     "rfx_copy_framebuffer", "rfx_poisson_denoise", "rfx_compose", "rfx_final_compose", "rfx_sync", "rfx_halo_violations", "rfx_time_begin", "rfx_time_end", "rfx_profile", "rfx_profile_read",
-    "rfx_host_alloc", "rfx_host_free", "rfx_stage_upload", "rfx_stage_flip", "rfx_split_rows", "rfx_comm_unique_id", "rfx_comm_init", "rfx_comm_destroy", "rfx_halo_exchange", "rfx_allgather_history", "rfx_gather_history_rows", "rfx_ssgi_hit_rows", "rfx_ssgi_hit_mask", "rfx_comm_wait",
+    "rfx_host_alloc", "rfx_host_free", "rfx_stage_upload", "rfx_stage_flip", "rfx_split_rows", "rfx_comm_unique_id", "rfx_comm_init", "rfx_comm_destroy", "rfx_halo_exchange", "rfx_allgather_history", "rfx_gather_history_rows", "rfx_peer_export", "rfx_peer_open", "rfx_peer_gather_history", "rfx_peer_close", "rfx_ssgi_hit_rows", "rfx_ssgi_hit_mask", "rfx_comm_wait",
 ]
 
 _lib = None
@@ -183,6 +184,10 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.rfx_halo_exchange.argtypes = [vp, i, vp, i, i]
     lib.rfx_allgather_history.argtypes = [vp, i, vp]
     lib.rfx_gather_history_rows.argtypes = [vp, i, vp, C.POINTER(C.c_size_t)]
+    lib.rfx_peer_export.argtypes = [vp, i, vp]
+    lib.rfx_peer_open.argtypes = [vp, i, vp, i, i]
+    lib.rfx_peer_gather_history.argtypes = [vp, i, C.POINTER(C.c_size_t)]
+    lib.rfx_peer_close.argtypes = [vp]
     lib.rfx_ssgi_hit_rows.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     lib.rfx_ssgi_hit_mask.argtypes = [vp, C.POINTER(C.c_uint32), i]
     lib.rfx_comm_wait.argtypes = [vp]

@@ -307,6 +307,29 @@ class Context:
         self._chk(self.lib.rfx_gather_history_rows(self._h, tex, None, C.byref(n)), "rfx_gather_history_rows")
         return int(n.value)
 
+    # -- the device-driven history gather (rfx_peer_*: peer loads through IPC mappings, no RCCL)
+    def peer_export(self, tex: int) -> bytes:
+        """rfx_peer_export: the blob (IPC handles of the plane and of this rank's flag block) every other rank needs"""
+        b = C.create_string_buffer(abi.PEER_BLOB_BYTES)
+        self._chk(self.lib.rfx_peer_export(self._h, tex, b), "rfx_peer_export")
+        return b.raw
+
+    def peer_open(self, tex: int, blobs, rank: int, nranks: int):
+        """rfx_peer_open: `blobs` = every rank's peer_export() in rank order"""
+        raw = b"".join(blobs)
+        assert len(raw) == nranks * abi.PEER_BLOB_BYTES
+        self._chk(self.lib.rfx_peer_open(self._h, tex, raw, rank, nranks), "rfx_peer_open")
+
+    def peer_gather_history(self, tex: int) -> int:
+        """rfx_peer_gather_history (between ssgi_trace and ssgi_shade, on every rank): this rank's kernel pulls the column blocks its rays will
+        read out of their owners' planes.  Returns the bytes the PREVIOUS call's kernel moved (nothing waits on the host)."""
+        n = C.c_size_t(0)
+        self._chk(self.lib.rfx_peer_gather_history(self._h, tex, C.byref(n)), "rfx_peer_gather_history")
+        return int(n.value)
+
+    def peer_close(self):
+        self._chk(self.lib.rfx_peer_close(self._h), "rfx_peer_close")
+
     def comm_wait(self):
         self._chk(self.lib.rfx_comm_wait(self._h), "rfx_comm_wait")
 

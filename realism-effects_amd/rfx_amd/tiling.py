@@ -116,15 +116,50 @@ class TiledRenderer:
         self.overlap_history_gather = world > 1 and hasattr(inner, "ssgi_trace")
         # K1 reads only .rgb of the composed GI: when the RGB twin is bound, K4 keeps it and IT is gathered (12 B/px instead of 16)
         self.gather_history_rgb = world > 1 and abi.TEX_COMPOSE_RGB in tensors
+        self.history_gather = "all"
+        self.history_bytes_received = []  # per frame, "bounded" / "peer" modes (what "all" receives: the other tiles, every frame)
+
+    def use_peer_history(self, all_gather_object):
+        """Switch the composed-GI exchange to the DEVICE-DRIVEN pull (include/rfx.h rfx_peer_*): between a frame's trace and its shade this
+        rank's own kernel loads the column blocks its rays will read straight out of their owners' planes, through IPC mappings — no
+        collective, no host wait.  The RGB twin must be the library's own plane (not bound to a torch tensor).
+        `all_gather_object(obj) -> [every rank's obj in rank order]`: how the ranks' export blobs travel, once (any host channel)."""
+        if self.world == 1:
+            return
+        if not self.overlap_history_gather:
+            raise RuntimeError("use_peer_history: the tile renderer must split K1 into ssgi_trace / ssgi_shade (the pull sits between them)")
+        tex = abi.TEX_COMPOSE_RGB
+        blobs = all_gather_object(self.inner.peer_export(tex))
+        self.inner.peer_open(tex, blobs, self.rank, self.world)
+        self.gather_history_rgb = True
+        self.history_gather = "peer"
+        self._all_gather_object = all_gather_object
+
+    def _peer_before_shade(self):
+        self.finish_pending()
+        self.history_bytes_received.append(self.inner.peer_gather_history(abi.TEX_COMPOSE_RGB))
+        self.inner.comm_wait()  # orders the shade after the pull (stream order: nothing waits on the host)
+
+    def gather_whole_history(self):
+        """every rank's rows of the composed GI on every rank, now (a host that wants the whole frame on one rank — bench.py's checksum)"""
+        if self.world > 1 and self.history_gather == "peer":
+            tex = abi.TEX_COMPOSE_RGB
+            self.inner.sync()
+            parts = self._all_gather_object(np.ascontiguousarray(self.inner.download(tex)[self.tile_y0:self.tile_y0 + self.tile_rows]))
+            self.inner.upload(tex, np.concatenate(parts, axis=0))
 
     def __getattr__(self, name):  # everything else (upload, the four draws, ...) goes to the tile's renderer
         return getattr(self.inner, name)
 
     # anything that reads the whole composed GI, or hands control back to the caller, first lets the all-gather land
     def before_ssgi_shade(self):
+        if self.history_gather == "peer":
+            return self._peer_before_shade()
         self.finish_pending()
 
     def ssgi_march(self, p):
+        if self.world > 1 and self.history_gather == "peer":
+            raise RuntimeError("history_gather \"peer\": K1 must run as ssgi_trace / ssgi_shade (the pull sits between them)")
         self.finish_pending()
         return self.inner.ssgi_march(p)
 
@@ -236,8 +271,8 @@ class TiledRenderer:
             self.finish_halo()
 
     def allgather_compose(self):
-        if self.world == 1:
-            return
+        if self.world == 1 or self.history_gather == "peer":
+            return  # peer: the column blocks are pulled on demand, in before_ssgi_shade
         dist = self._dist
         full = self.tensors[abi.TEX_COMPOSE_RGB if self.gather_history_rgb else abi.TEX_COMPOSE]  # whole frame
         mine = full[self.tile_y0:self.tile_y0 + self.tile_rows]
@@ -289,7 +324,6 @@ class CommTiledRenderer(TiledRenderer):
         ctx.comm_init(unique_id, rank, world)
         self._comm_pending = False
         self.history_gather = history_gather if (world > 1 and self.overlap_history_gather) else "all"
-        self.history_bytes_received = []  # per frame, "bounded" mode (what "all" receives: the other tiles, every frame)
 
     def exchange(self, texs):
         if self.world == 1 or self.halo == 0:
@@ -307,24 +341,28 @@ class CommTiledRenderer(TiledRenderer):
         return abi.TEX_COMPOSE_RGB if self.gather_history_rgb else abi.TEX_COMPOSE
 
     def allgather_compose(self):
-        if self.world == 1 or self.history_gather == "bounded":
-            return  # bounded: the rows travel on demand, in before_ssgi_shade
+        if self.world == 1 or self.history_gather in ("bounded", "peer"):
+            return  # bounded / peer: the rows travel on demand, in before_ssgi_shade
         self.inner.allgather_history(self._history_tex())
         self._pending = [True]
 
     def before_ssgi_shade(self):
+        if self.world > 1 and self.history_gather == "peer":
+            return self._peer_before_shade()
         if self.world > 1 and self.history_gather == "bounded":
             self.history_bytes_received.append(self.inner.gather_history_rows(self._history_tex()))
             self._pending = [True]
         self.finish_pending()
 
     def ssgi_march(self, p):
-        if self.world > 1 and self.history_gather == "bounded":
+        if self.world > 1 and self.history_gather in ("bounded", "peer"):
             raise RuntimeError("CommTiledRenderer(history_gather=\"bounded\"): K1 must run as ssgi_trace / ssgi_shade (the gather sits between them)")
         return super().ssgi_march(p)
 
     def gather_whole_history(self):
         """every rank's rows of the composed GI to every rank, now (a host that wants the whole frame on one rank — bench.py's checksum)"""
+        if self.world > 1 and self.history_gather == "peer":
+            return TiledRenderer.gather_whole_history(self)
         if self.world > 1:
             self.inner.allgather_history(self._history_tex())
             self._pending = [True]

@@ -16,6 +16,16 @@ HOSTSIM_TOO_LARGE = ("configs[4] 8K", "streamed_dumps_equal_uploaded_dumps[3840-
     () if os.environ.get("RFX_TEST_SEQ_SIZE") else ("_16_frames",))  # (1080p x 16 frames: 9 minutes on the simulator; RFX_TEST_SEQ_SIZE=160x90 runs its logic)
 
 
+# `-m "gpu and quick"`: the mid-round check — one BASELINE configuration against the reference GLSL, the 4K band, one variant of every widened
+# row, the hosts and the exchanges; measured on MI355X: see tools/gpu_runs (the full `-m gpu` suite stays the round's last word)
+QUICK = ("stagewise_vs_reference_glsl[configs[1]-", "full_size_4k_band", "chain_stagewise_vs_oracle[size2", "env_map_vs_oracle[0.5", "env_map_importance_sampling_vs_oracle",
+         "ssr_mode_chain", "single_texture_variants", "traa_end_to_end_vs_oracle[True", "denoise_modes_vs_oracle[full_temporal", "final_compose_vs_oracle",
+         "resolution_scale_vs_oracle[0.5", "import_attribute_planes", "orthographic_camera", "cube_to_equirect", "node_host_drives", "per_draw_profile",
+         "row_windowed_draws", "row_tiled_chain_is_bit_identical_to_single_context[2", "trace_plus_shade_is_bit_identical_to_march[plain", "hit_rows_bound",
+         "comm_entry_points_on_a_single_rank_ring", "multi_rank_flow_on_one_gpu[2-540-peer", "rgb_history_twin", "nan_texels",
+         "tiled_kernels_with_c_abi_exchanges", "config0_through_the_effect")
+
+
 def hostsim_child_env(sim, build="_build"):
     """Environment of a python child process that must load the host simulator: tests/hostsim/inject/sitecustomize.py (found through
     PYTHONPATH at interpreter start) calls rfx_amd.abi.set_library_path(RFX_TEST_LIB)."""
@@ -35,6 +45,7 @@ def pytest_addoption(parser):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference + llvmpipe (build container only)")
+    config.addinivalue_line("markers", "quick: the few-minute subset of the gpu tests (-m \"gpu and quick\"; the list: QUICK in tests/conftest.py)")
     if config.getoption("--hostsim"):
         import subprocess
         sim = os.path.join(ROOT, "tests", "hostsim")
@@ -58,6 +69,9 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
+    for it in items:
+        if it.get_closest_marker("gpu") and any(n in it.nodeid for n in QUICK):
+            it.add_marker(pytest.mark.quick)
     if not config.getoption("--hostsim"):
         return
     skip = pytest.mark.skip(reason="--hostsim: needs the device (RCCL / torch.cuda)")

@@ -190,6 +190,12 @@ using std::min;
 static inline int min(int a, unsigned int b) { return a < (int)b ? a : (int)b; }
 static inline unsigned int atomicAdd(unsigned int *p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned int atomicOr(unsigned int *p, unsigned int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+// rfx_peer.hip's flag barrier (never launched here: hipIpcGetMemHandle below refuses, so rfx_peer_export does)
+#define __HIP_MEMORY_SCOPE_SYSTEM 0
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
+static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline int atomicMin(int *p, int v) {  // (idempotent: safe under the replay of a block's passes)
     int old = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (v < old && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
@@ -208,6 +214,12 @@ typedef struct hostsim_event *hipEvent_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
 enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum { hipErrorNotSupported = 801, hipDeviceMallocFinegrained = 1, hipIpcMemLazyEnablePeerAccess = 1 };
+struct hipIpcMemHandle_t { char reserved[64]; };
+// no second address space to map: the peer-load exchange (rfx_peer.hip) reports RFX_EUNSUPPORTED on the simulator
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *, void *) { return hipErrorNotSupported; }
+static inline hipError_t hipIpcOpenMemHandle(void **, hipIpcMemHandle_t, unsigned int) { return hipErrorNotSupported; }
+static inline hipError_t hipIpcCloseMemHandle(void *) { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "hostsim"; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
@@ -218,6 +230,7 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, co
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 16; return hipSuccess; }  // every "device" is this host: one rank per device index works
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipExtMallocWithFlags(void **p, size_t n, unsigned int) { *p = std::aligned_alloc(256, (n + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned int = 0) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { std::memmove(d, s, n); return hipSuccess; }

@@ -219,6 +219,7 @@ def test_configs4_free_running_16_frames(blue_noise, W, H):
         ref.denoise(f.camera, idx)
         ref.compose(f.camera)
         fg = f.depth != 1.0
+        assert fg.any(), "frame %d of the sequence has no foreground pixel: the statistics below are over the foreground" % fi
         got, want = ctx.download(abi.TEX_COMPOSE), np.ascontiguousarray(ref.t_compose.read())
         bad = out_of_tolerance(got, want, False)
         with np.errstate(invalid="ignore"):

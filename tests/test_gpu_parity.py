@@ -846,28 +846,37 @@ def test_comm_entry_points_on_a_single_rank_ring(blue_noise):
     ctx.close()
 
 
-def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("ranks,height,history", [(2, 540, "all"), (2, 540, "peer"), (3, 544, "peer")])
+def test_bench_multi_rank_flow_on_one_gpu(tmp_path, ranks, height, history):
     """bench.py's N>1 path end to end — torch.distributed.run, per-rank band dumps, halo Send/Recv after K2 and every K3 pass, the
-    composed-GI all-gather, max-over-ranks timing — with two ranks sharing this GPU over gloo (RCCL refuses two ranks on one device;
+    composed-GI exchange, max-over-ranks timing — with the ranks sharing this GPU over gloo (RCCL refuses two ranks on one device;
     only the transport differs from the multi-GPU run).  The final whole-frame composed GI must be bit-identical to the single-rank
-    run of the same frame."""
+    run of the same frame.  history "all": the whole-frame all-gather; "peer": the device-driven pull (rfx_peer_gather_history) — every
+    rank's kernel loads the column blocks its rays read out of the OTHER PROCESSES' planes through HIP IPC mappings, ordered by flag
+    barriers in mapped memory; N processes on one device map each other's allocations exactly as N devices would (544 rows over three
+    ranks: a ragged last tile)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RFX_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
-    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--checksum", "--no-extras", "--spinup", "0"]
-    p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                         "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--width", "960", "--height", "540"] + common,
+    common = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--checksum", "--no-extras", "--spinup", "0"]
+    p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                         "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", str(ranks), "--width", "960", "--height", str(height),
+                         "--history-gather", history] + common,
                         env=env, text=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p2.returncode == 0, p2.stderr[-3000:]
     two = p2.stdout
     j2 = json.loads([l for l in two.splitlines() if l.startswith("{")][-1])
     # N > 1 is BASELINE configs[3]'s shape: THE SAME frame cut into N row tiles (strong scaling)
-    assert j2["n_gpus"] == 2 and j2["halo_violations"] == 0 and j2["value"] > 0 and j2["scaling"] == "strong"
+    assert j2["n_gpus"] == ranks and j2["halo_violations"] == 0 and j2["value"] > 0 and j2["scaling"] == "strong"
     W, H = [int(x) for x in j2["config"]["frame"].split("x")]
-    assert (W, H) == (960, 540) and H == j2["frame_rows"] == 2 * j2["config"]["tile_rows"]
+    assert (W, H) == (960, height) and H == j2["frame_rows"]
+    hx = j2["config"]["history_exchange"]
+    assert hx["mode"] == history
+    if history == "peer":  # the pull moves only what the rays read: less than the other tiles' rows, more than nothing
+        assert 0 < hx["MB_received_per_frame_max_over_ranks"] < hx["whole_frame_allgather_MB"], hx
     one = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--width", str(W), "--height", str(H)] + common, env=env, text=True,
                                   stderr=subprocess.DEVNULL, timeout=600)
     j1 = json.loads([l for l in one.splitlines() if l.startswith("{")][-1])

@@ -22,7 +22,7 @@ PY
 $ROOT/tools/microbench/bin/valu_rates2 > $OUT/valu_rates2.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 # the profiled command: the bench's own loop after its spin-up (--spinup 50: the device at its sustained clock, as in the line), 20 timed frames
-BENCH="python $ROOT/bench.py --steps 20 --warmup 2 --spinup 50 --no-cpu-baseline --no-stream-copy --no-cold"
+BENCH="python $ROOT/bench.py --steps 20 --warmup 2 --spinup 50 --no-cpu-baseline --no-stream-copy --no-cold --no-kernel-loops --no-configs4"
 # 1. the bench line itself (un-profiled, with the CPU baselines)
 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
 # 2. kernel trace + stats
