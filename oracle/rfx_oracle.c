@@ -1494,6 +1494,10 @@ int rfxo_denoise(int W, int H, int y0, int y1, const float *depth, const uint32_
 /* ==================================================================== K4: DenoiserComposePass */
 /* gi0/gi1: K3 target B ([0] = diffuse, [1] = specular; inputType "specular": gi0 is the specular GI, gi1 unused);
  * scene: the composer's input buffer (sceneTexture), only read when inputType == TYPE_SPECULAR */
+/* diagnostic (tools/k4_error_tail.py): when set, every composed pixel writes (|v + l| before the half vector's normalisation :90, VoH, |reflect(-V, H)|
+ * before ITS normalisation :77, dot(viewNormal, l) before the sign test :87) into this W x H x 4 plane */
+static float *g_compose_probe = NULL;
+void rfxo_set_compose_probe(float *plane) { g_compose_probe = plane; }
 int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_t *gbuffer, const void *gi0v, const void *gi1v,
                  const float *scene, const rfx_compose_params *p, float *out) {
     const uint16_t *gi0 = (const uint16_t *)gi0v, *gi1 = (const uint16_t *)gi1v; /* giSource 0: RGBA16F linear; 1: RGBA32F nearest (K2's targets) */
@@ -1543,13 +1547,19 @@ int rfxo_compose(int W, int H, int y0, int y1, const float *depth, const uint32_
             margin_note(fabsf(Hh.z) / MARGIN_REL_SHORT);
             if (Hh.z < 0.0f) Hh = neg3(Hh);
             v3 I = neg3(V);
-            v3 l = normalize3(sub3(I, mul3(Hh, 2.0f * dot3(Hh, I))));
+            const v3 refl = sub3(I, mul3(Hh, 2.0f * dot3(Hh, I)));
+            v3 l = normalize3(refl);
             l = add3(add3(mul3(T, l.x), mul3(B, l.y)), mul3(N, l.z));
             l = normalize3(v4_mul_mat_xyz(C, l, 1.0f)); /* vec4(l, 1.) quirk :81 */
             margin_note(fabsf(dot3(viewNormal, l)) / (MARGIN_REL_SHORT * fmaxf(length3(viewNormal), 1e-30f)));
+            const float nl = dot3(viewNormal, l);
             if (dot3(viewNormal, l) < 0.0f) l = neg3(l);
             v3 h = normalize3(add3(vv, l));
             float VoH = fmaxf(1e-6f, dot3(vv, h)); /* EPSILON from <common> */
+            if (g_compose_probe) {
+                float *q = g_compose_probe + 4 * ((size_t)y * W + x);
+                q[0] = length3(add3(vv, l)); q[1] = VoH; q[2] = length3(refl); q[3] = nl;
+            }
             v3 f0 = mix3(V3(0.04f, 0.04f, 0.04f), mat.diffuse, mat.metalness);
             v3 F = f_schlick3(f0, VoH);
             float om = 1.0f - mat.metalness;
