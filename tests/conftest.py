@@ -22,7 +22,7 @@ QUICK = ("stagewise_vs_reference_glsl[configs[1]-", "full_size_4k_band", "chain_
          "ssr_mode_chain", "single_texture_variants", "traa_end_to_end_vs_oracle[True", "denoise_modes_vs_oracle[full_temporal", "final_compose_vs_oracle",
          "resolution_scale_vs_oracle[0.5", "import_attribute_planes", "orthographic_camera", "cube_to_equirect", "node_host_drives", "per_draw_profile",
          "row_windowed_draws", "row_tiled_chain_is_bit_identical_to_single_context[2", "trace_plus_shade_is_bit_identical_to_march[plain", "hit_rows_bound",
-         "comm_entry_points_on_a_single_rank_ring", "multi_rank_flow_on_one_gpu[2-540-peer", "rgb_history_twin", "nan_texels",
+         "comm_entry_points_on_a_single_rank_ring", "multi_rank_flow_on_one_gpu[2-540-peer", "peer_history_gather_between", "rgb_history_twin", "nan_texels",
          "tiled_kernels_with_c_abi_exchanges", "config0_through_the_effect")
 
 

@@ -8,6 +8,8 @@ adjacent binary16 numbers, or — fp32 outputs — within 1e-5 relative.  Out-of
 fraction measured on MI355X (BOUND below) and, wherever the test can re-run the oracle stage (`prove=`), every one of them must be PROVEN
 unstable by the oracle (stagewise.prove_flips: a decision margin < 1, or the output moves under primitives perturbed within the reference
 GL's measured error): `unexplained == 0`."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1272,6 +1274,78 @@ def test_smoke_fallback_against_the_oracle_proves_every_flip(blue_noise):
     for r in reports:
         assert r.unexplained == 0, r.line()
         assert r.bad <= 0.002 * r.pixels + 3, r.line()
+
+
+def test_peer_history_gather_between_two_contexts_of_one_process(blue_noise):
+    """rfx_peer_* with both ranks in ONE process (include/rfx.h: contexts of one process are recognised by the blob's process id and use each
+    other's addresses directly): two tile contexts on this device, each plane filled with its owner's value; after the trace,
+    rfx_peer_gather_history on both — the barrier kernels of the two exchange streams meet on the device while the host has long returned — and
+    each context holds, of the OTHER tile's rows, exactly the column blocks its own row mask names, everything else untouched.  State errors:
+    gather before open, open before export, a second open."""
+    from rfx_amd import abi
+    from rfx_amd.context import Context, RfxError
+    from rfx_amd.scene import synthetic_frame
+
+    if os.environ.get("RFX_HOSTSIM") == "1":
+        c = Context(64, 32, tile_y0=0, tile_rows=16, halo_rows=4)
+        with pytest.raises(RfxError, match="hipIpcGetMemHandle"):  # no second address space on the simulator: the mode reports itself unsupported
+            c.peer_export(abi.TEX_COMPOSE_RGB)
+        c.close()
+        return
+    W, H = 224, 126
+    f = synthetic_frame(W, H, 1)
+    tiles = Context.split_rows(H, 2, 0), Context.split_rows(H, 2, 1)
+    ctxs = [Context(W, H, tile_y0=y0, tile_rows=rows, halo_rows=8) for (y0, rows) in tiles]
+    with pytest.raises(RfxError, match="rfx_peer_export"):
+        ctxs[0].peer_gather_history(abi.TEX_COMPOSE_RGB)
+    with pytest.raises(RfxError, match="rfx_peer_export"):
+        ctxs[0].peer_open(abi.TEX_COMPOSE_RGB, [b"\0" * abi.PEER_BLOB_BYTES] * 2, 0, 2)
+    blobs = [c.peer_export(abi.TEX_COMPOSE_RGB) for c in ctxs]
+    for r, c in enumerate(ctxs):
+        c.peer_open(abi.TEX_COMPOSE_RGB, blobs, r, 2)
+    with pytest.raises(RfxError, match="already open"):
+        ctxs[0].peer_open(abi.TEX_COMPOSE_RGB, blobs, 0, 2)
+    sp, _, _, _ = _params(abi, f, f.prev_camera, 1.0)
+    sp.blueNoiseIndex, sp.historySource = 4242, 3  # K1 reads the RGB twin
+    masks = []
+    for r, c in enumerate(ctxs):
+        c.upload_frame(f)
+        plane = np.full((H, W, 3), -1.0, np.float32)  # -1: "not mine, not pulled"
+        y0, rows = tiles[r]
+        plane[y0:y0 + rows] = float(r + 1)
+        c.upload(abi.TEX_COMPOSE_RGB, plane)
+    for c in ctxs:
+        c.ssgi_trace(sp)
+        masks.append(c.ssgi_hit_mask())
+    for c in ctxs:  # every rank issues the call; neither waits on the host
+        c.ssgi_trace(sp)
+        assert c.peer_gather_history(abi.TEX_COMPOSE_RGB) == 0  # (what the PREVIOUS call pulled: there was none)
+    pulled = []
+    for r, c in enumerate(ctxs):
+        c.comm_wait()
+        c.sync()
+        got = c.download(abi.TEX_COMPOSE_RGB)
+        oy0, orows = tiles[1 - r]
+        blocks = (np.arange(W, dtype=np.int64) * 32) // W
+        needed = ((masks[r][:, None] >> blocks[None, :].astype(np.uint32)) & 1).astype(bool)
+        want = np.full((H, W, 3), -1.0, np.float32)
+        y0, rows = tiles[r]
+        want[y0:y0 + rows] = float(r + 1)
+        other = np.zeros((H, W), bool)
+        other[oy0:oy0 + orows] = True
+        want[needed & other] = float(2 - r)
+        assert np.array_equal(got, want), "rank %d: %d texels differ" % (r, int((got != want).any(-1).sum()))
+        pulled.append(int((needed & other).sum()))
+    assert sum(pulled) > 0  # (vacuous otherwise: the synthetic frame's reflections cross the tile boundary)
+    for r, c in enumerate(ctxs):  # the next call reports the previous one's bytes, and that no peer missed a barrier
+        c.ssgi_trace(sp)
+        assert c.peer_gather_history(abi.TEX_COMPOSE_RGB) == pulled[r] * 12
+    for c in ctxs:
+        c.comm_wait()
+        c.sync()
+        assert c.halo_violations() == 0
+        c.peer_close()
+        c.close()
 
 
 @pytest.mark.parametrize("missed", [0, 1])

@@ -17,7 +17,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 @pytest.mark.skipif(not os.path.exists(CLANG) or shutil.which("make") is None, reason="no host clang++ / make")
 def test_gpu_tests_subset_passes_under_host_simulation():
     sel = ("cube or chain_stagewise_vs_oracle or row_tiled_chain_is_bit_identical or denoise_variants or traa_end_to_end or ssgi_trace_plus_shade "
-           "or row_windowed_draws or per_draw_profile or reference_vuv_model_on_device or resolution_scale or node_host_drives or streamed_dumps or tiled_kernels or node_row_tiled_run or single_rank_ring or node_cube_environment")
+           "or row_windowed_draws or per_draw_profile or peer_history_gather_between or reference_vuv_model_on_device or resolution_scale or node_host_drives or streamed_dumps or tiled_kernels or node_row_tiled_run or single_rank_ring or node_cube_environment")
     p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_zz_gpu_cube_environment.py", "tests/test_gpu_parity.py", "tests/test_gpu_baseline_configs.py", "tests/test_node_host.py", "tests/test_tiling_gloo.py",
                         "-m", "gpu", "--hostsim", "-q", "-x", "-k", sel, "-p", "no:cacheprovider"], cwd=ROOT, capture_output=True, text=True, timeout=1500)
     tail = "\n".join((p.stdout + p.stderr).splitlines()[-25:])
