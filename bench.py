@@ -68,7 +68,7 @@ def _is_kernel(key, name):
 TRAFFIC_NOTE = ("fabric-side bytes per launch (L2 misses: Infinity-Cache hits included) from %s/pmc_hbm.csv — separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
                 "passes over this bench command at 4K, tools/collect_profiles.sh, collected at git %s; FETCH_SIZE calibrated on known request counts "
                 "(profiles/r05_microbench): see traffic_calibration")
-PROFILE_DIR = "profiles/r05_final"  # the committed rocprofv3 collection (tools/collect_profiles.sh) the counter-derived figures are read from
+PROFILE_DIR = "profiles/r06_final"  # the committed rocprofv3 collection (tools/collect_profiles.sh) the counter-derived figures are read from
 
 
 def profile_meta():
