@@ -30,6 +30,10 @@
  *     `halo_rows` rows above and below (clipped to the frame) for the gathers
  *     (SURVEY.md §8e).  Row indices in every call are FRAME rows.
  *   - device buffers are owned by the library unless bound with rfx_bind_external().
+ *   - threading: a context is driven by ONE host thread at a time (the reference drives its passes from the JS main thread); different contexts
+ *     may be driven from different threads.  The only state the library shares between contexts are per-device caches of launch constants
+ *     (the occupancy figure K1's persistent grid is sized with, the dynamic-LDS attribute of K3's kernels) and the RCCL binding: two threads that
+ *     first use a kernel specialisation at the same moment both compute and store the SAME value — an unsynchronised but idempotent write.
  */
 #ifndef RFX_H
 #define RFX_H
