@@ -107,6 +107,31 @@ void rfxo_frag_uv(int model, int W, int H, float *out) {
         for (int x = 0; x < W; x++) { out[((size_t)y * W + x) * 2] = frag_u(x, y, W, H); out[((size_t)y * W + x) * 2 + 1] = frag_v(y, W, H); }
     g_uv_model = keep;
 }
+/* The reference GL's OWN exp, bit for bit (diagnostic mode, rfxo_set_gl_exp(1); default off).  llvmpipe (Mesa 23.2 gallivm, lp_bld_arit.c — a
+ * dependency of the reference's execution here that is not under /root/reference; its published algorithm, restated): exp2(x) clamps x to
+ * [-126.99999, 128], splits it into floor and fraction, builds 2^floor from exponent bits and 2^fraction from a degree-5 polynomial evaluated as
+ * even(f^2) + f * odd(f^2) with fused multiply-adds; exp(x) = exp2(x * log2 e).  oracle/glref/probes/probe_exp_restatement.py holds the restatement
+ * equal to the GL on 65 536 inputs, and shows how the march's `cs = 1. - exp(-0.25 * pow(t, 2.))` (ssgi.frag:453-454) reaches it after the GLSL
+ * compiler's algebraic pass: exp2(RN(t * RN(t * c))), c = -0.25 * log2 e — equal on 6 x 4096 inputs.  The GL's cs is up to 2.6e-6 (relative) from the
+ * true value at the first step; the product and the default oracle use the true exp (the GLSL's meaning), this mode is for root-causing a pixel. */
+static int g_gl_exp = 0;
+void rfxo_set_gl_exp(int on) { g_gl_exp = on; }
+static inline float gl_exp2(float x) {
+    x = fminf(128.0f, x);
+    x = fmaxf(-126.99999f, x);
+    const float ip = floorf(x), fp = x - ip, x2 = fp * fp;
+    const float even = fmaf(x2, fmaf(x2, 0.00898934009049466391101f, 0.240153617044375388211f), 1.0f);
+    const float odd = fmaf(x2, fmaf(x2, 0.00187757667519147912699f, 0.0558263180532956664775f), 0.693153073200168932794f);
+    const float poly = fmaf(odd, fp, even);
+    union { uint32_t u; float f; } sc;
+    sc.u = (uint32_t)((int32_t)ip + 127) << 23;
+    return sc.f * poly;
+}
+/* 1. - exp(-0.25 * pow(t, 2.)) as the reference GL evaluates it */
+static inline float gl_march_cs(float t) {
+    const float c = -0.25f * 1.4426950408889634074f;
+    return 1.0f - gl_exp2(t * (t * c));
+}
 /* function-like macros are not re-expanded inside their own expansion: (expf)(x) is libm's */
 #define expf(x) pert_rel((expf)(x))
 #define logf(x) pert_rel((logf)(x))
@@ -577,7 +602,7 @@ static void k1_ray_march(const k1_ctx *c, v3 *dir, v3 *hitPos, float random_b, f
     *u = 0.0f; *v = 0.0f;
     for (int i = 1; i < c->p->steps; i++) {
         float m = (float)i + random_b - 0.5f;
-        float cs = 1.0f - expf(-0.25f * (m * m));
+        float cs = g_gl_exp ? gl_march_cs(m) : 1.0f - expf(-0.25f * (m * m));
         *hitPos = add3(*hitPos, mul3(*dir, cs));
         k1_project(c, *hitPos, u, v);
         float z = k1_view_z(c, fetch_r32f(c->depth, d, *u, *v));
