@@ -107,7 +107,7 @@ void rfxo_frag_uv(int model, int W, int H, float *out) {
         for (int x = 0; x < W; x++) { out[((size_t)y * W + x) * 2] = frag_u(x, y, W, H); out[((size_t)y * W + x) * 2 + 1] = frag_v(y, W, H); }
     g_uv_model = keep;
 }
-/* The reference GL's OWN exp, bit for bit (diagnostic mode, rfxo_set_gl_exp(1); default off).  llvmpipe (Mesa 23.2 gallivm, lp_bld_arit.c — a
+/* The reference GL's OWN exp, sin and cos, bit for bit (diagnostic mode, rfxo_set_gl_exp(1); default off).  llvmpipe (Mesa 23.2 gallivm, lp_bld_arit.c — a
  * dependency of the reference's execution here that is not under /root/reference; its published algorithm, restated): exp2(x) clamps x to
  * [-126.99999, 128], splits it into floor and fraction, builds 2^floor from exponent bits and 2^fraction from a degree-5 polynomial evaluated as
  * even(f^2) + f * odd(f^2) with fused multiply-adds; exp(x) = exp2(x * log2 e).  oracle/glref/probes/probe_exp_restatement.py holds the restatement
@@ -132,6 +132,32 @@ static inline float gl_march_cs(float t) {
     const float c = -0.25f * 1.4426950408889634074f;
     return 1.0f - gl_exp2(t * (t * c));
 }
+/* ... and its sin / cos (lp_build_sin_or_cos: the Cephes / sse_mathfun single-precision sincos — |x| * 4/pi truncated to the next even octant, the
+ * three-constant "extended precision" argument reduction with fused multiply-adds, one of two degree-3 polynomials in z = x^2 selected by the octant, the
+ * sign from the octant and the argument): the restatement equals the GL on 8 x 4096 inputs over [-6.3, 6.3] (tools/open_pixel.py's header has the probe). */
+static inline float gl_sincos(float a, int want_cos) {
+    union { float f; uint32_t u; int32_t i; } av, r;
+    av.f = a;
+    const float x = fabsf(a);
+    const float y = x * 1.27323954473516f;
+    const int32_t j = (int32_t)y, jadd = j + 1, jand = jadd & ~1;
+    const float y2 = (float)jand;
+    const int32_t e2 = want_cos ? jand - 2 : jand;
+    const uint32_t sign = want_cos ? ((uint32_t)(4 & ~e2) << 29) : ((av.u ^ ((uint32_t)jadd << 29)) & 0x80000000u);
+    const float x1 = fmaf(y2, -0.78515625f, x), x2 = fmaf(y2, -2.4187564849853515625e-4f, x1), x3 = fmaf(y2, -3.77489497744594108e-8f, x2);
+    const float z = x3 * x3;
+    float res;
+    if ((e2 & 2) == 0) {
+        const float q = fmaf(fmaf(z, -1.9515295891E-4f, 8.3321608736E-3f), z, -1.6666654611E-1f) * z;
+        res = fmaf(q, x3, x3);
+    } else {
+        const float c = (fmaf(fmaf(z, 2.443315711809948E-005f, -1.388731625493765E-003f), z, 4.166664568298827E-002f) * z) * z;
+        res = (c - z * 0.5f) + 1.0f;
+    }
+    r.f = res;
+    r.u ^= sign;
+    return r.f;
+}
 /* function-like macros are not re-expanded inside their own expansion: (expf)(x) is libm's */
 #define expf(x) pert_rel((expf)(x))
 #define logf(x) pert_rel((logf)(x))
@@ -139,8 +165,8 @@ static inline float gl_march_cs(float t) {
 #define sqrtf(x) pert_sqrt((sqrtf)(x))
 #define exp2f(x) pert_rel((exp2f)(x))
 #define log2f(x) pert_rel((log2f)(x))
-#define sinf(x) pert_ang((sinf)(x))
-#define cosf(x) pert_ang((cosf)(x))
+#define sinf(x) (g_gl_exp ? gl_sincos((x), 0) : pert_ang((sinf)(x)))
+#define cosf(x) (g_gl_exp ? gl_sincos((x), 1) : pert_ang((cosf)(x)))
 #define atan2f(y, x) pert_ang((atan2f)(y, x))
 
 /* ------------------------------------------------------------------ small vector helpers */
@@ -486,6 +512,19 @@ static inline float eval_disney_specular(float roughness, float NoH, float NoV, 
     return D * G / (4.0f * NoL * NoV);
 }
 /* SampleGGXVNDF :153-170 */
+/* diagnostic (tools/open_pixel_trace.py): the march of ONE pixel's specular ray, value by value.  rfxo_set_trace(x, y, buf, n): while pixel (x, y) is
+ * evaluated, every TRACE(tag, a, b, c, d) appends (tag, a, b, c, d) to buf (n floats); tags: 0 viewPos+viewZ, 1 specular ray + random.b, 2 final hit position,
+ * 3 view normal + roughness^2, 20-25 inside SampleGGXVNDF (random.rg + t1 t2; q k s Vh.z; Nh; H; l local; T1), 10+i march step i (position, cs), 110+i its tap (u, v, z - h), 200+k refine step k (position), 300+k its tap. */
+static int g_trace_x = -1, g_trace_y = -1, g_trace_n = 0, g_trace_cap = 0, g_trace_on = 0, g_trace_spec = 0;
+static float *g_trace_buf = NULL;
+void rfxo_set_trace(int x, int y, float *buf, int cap) { g_trace_x = x; g_trace_y = y; g_trace_buf = buf; g_trace_cap = cap; g_trace_n = 0; }
+int rfxo_trace_count(void) { return g_trace_n; }
+static inline void TRACE(int tag, float a, float b, float c, float d) {
+    if (!g_trace_on || !g_trace_buf || g_trace_n + 5 > g_trace_cap) return;
+    float *q = g_trace_buf + g_trace_n;
+    q[0] = (float)tag; q[1] = a; q[2] = b; q[3] = c; q[4] = d;
+    g_trace_n += 5;
+}
 static inline v3 sample_ggx_vndf(v3 V, float ax, float ay, float r1, float r2) {
     v3 Vh = normalize3(V3(ax * V.x, ay * V.y, V.z));
     float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
@@ -507,8 +546,16 @@ static inline v3 sample_ggx_vndf(v3 V, float ax, float ay, float r1, float r2) {
         const float dq = 6e-7f; /* ~5 ulps of the O(1) terms */
         float dk = q > dq ? dq / (2.0f * (sqrtf)(q)) : (sqrtf)(dq);
         g_unc_dir = 2.0f * dk + 4e-7f;
+        /* ... and a second one (round 6, the root cause of the 16-frame sequence's "open pixel", tools/open_pixel_trace.py): T1 = (-Vh.y, Vh.x, 0) *
+         * inversesqrt(lensq) is the DIRECTION of Vh's tangential part.  When the view vector is almost the normal (V local ~ (1e-3, 4e-4, 1)) that part is
+         * the small difference of O(1) products in ToLocal's dot(V, T), dot(V, B): one ulp of those (6e-8 — a fused against an unfused multiply-add, the
+         * order of a three-term sum) is a relative 1e-4 of it, T1 turns by that, and the sampling disk — hence H, l and the whole ray — turns with
+         * it by r * t1 error.  Measured at the open pixel: V local y -3.5566e-4 (restatement) against -3.5569e-4 (reference GL), T1 off by 2.2e-5,
+         * the ray direction by 2.1e-5, the refine tap by 0.0074 texel across a silhouette. */
+        if (lensq > 0.0f) g_unc_dir += r * 1.2e-7f / (sqrtf)(lensq);
     }
     v3 Nh = add3(add3(mul3(T1, t1), mul3(T2, t2)), mul3(Vh, k));
+    TRACE(20, r1, r2, t1, t2); TRACE(21, q, k, s, Vh.z); TRACE(22, Nh.x, Nh.y, Nh.z, 0.0f); TRACE(25, T1.x, T1.y, T1.z, 0.0f);
     return normalize3(V3(ax * Nh.x, ay * Nh.y, fmaxf(0.0f, Nh.z)));
 }
 static inline void onb(v3 N, v3 *T, v3 *B) { /* :172-176 */
@@ -586,6 +633,7 @@ static void k1_binary_search(const k1_ctx *c, v3 *dir, v3 *hitPos, float *u, flo
         k1_project(c, *hitPos, u, v);
         float z = k1_view_z(c, fetch_r32f(c->depth, d, *u, *v));
         float diff = z - hitPos->z;
+        if (g_trace_spec) { TRACE(200 + i, hitPos->x, hitPos->y, hitPos->z, 0.0f); TRACE(300 + i, *u, *v, diff, z); }
         margin_cmp(z, hitPos->z, MARGIN_REL_MARCH); /* :493 sign of diff */
         margin_tap(c, *u, *v, hitPos->z, n_updates + i + 1, 1);
         *dir = mul3(*dir, 0.5f);
@@ -607,6 +655,7 @@ static void k1_ray_march(const k1_ctx *c, v3 *dir, v3 *hitPos, float random_b, f
         k1_project(c, *hitPos, u, v);
         float z = k1_view_z(c, fetch_r32f(c->depth, d, *u, *v));
         float diff = z - hitPos->z;
+        if (g_trace_spec) { TRACE(10 + i, hitPos->x, hitPos->y, hitPos->z, cs); TRACE(110 + i, *u, *v, diff, z); }
         margin_cmp(z, hitPos->z, MARGIN_REL_MARCH);                                   /* :463 diff >= 0 */
         margin_cmp(z - c->p->thickness, hitPos->z, MARGIN_REL_MARCH);                 /* :463 diff < thickness */
         margin_tap(c, *u, *v, hitPos->z, i, 0);
@@ -781,13 +830,16 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
     V = V3(dot3(V, T), dot3(V, B), dot3(V, N)); /* ToLocal */
     v3 f0 = mix3(V3(0.04f, 0.04f, 0.04f), mat.diffuse, mat.metalness);
     v4 random = blue_noise(c->blue, x, y, p->blueNoiseIndex, u, v, (dims){c->outW, c->outH}); /* `resolution` = the render target's size */
+    g_trace_on = (x == g_trace_x && y == g_trace_y);
     v3 Hh = sample_ggx_vndf(V, roughnessSq, roughnessSq, random.x, random.y);
+    TRACE(23, Hh.x, Hh.y, Hh.z, 0.0f); TRACE(26, V.x, V.y, V.z, 0.0f);
     margin_note(fabsf(Hh.z) / MARGIN_REL_SHORT); /* |H| = 1 */
     if (Hh.z < 0.0f) Hh = neg3(Hh);
     /* reflect(-V, H) = I - 2*dot(N,I)*N with I=-V */
     v3 I = neg3(V);
     float dNI = dot3(Hh, I);
     v3 l = normalize3(sub3(I, mul3(Hh, 2.0f * dNI)));
+    TRACE(24, l.x, l.y, l.z, dNI);
     l = add3(add3(mul3(T, l.x), mul3(B, l.y)), mul3(N, l.z)); /* ToWorld */
     l = normalize3(v4_mul_mat_xyz(C, l, 0.0f));
     float NoL, NoH, LoH, VoH;
@@ -862,6 +914,18 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
         diffuseGI = gi; /* mix(0, gi, 1/1) */
     }
     l = specularRay; /* :246-265 */
+    /* proofs only: a direction whose conditioning (sample_ggx_vndf) leaves it uncertain by more than a few ulps is moved by that uncertainty, so that the
+     * perturbed re-evaluations re-take every march and refine decision of the ray under it (well-conditioned rays — 4e-7 — are left alone: moving every
+     * ray by an ulp would put every tap near a texel boundary at risk) */
+    if (g_pert_seed && g_pert_state && !isEnvSample && unc_spec > 2e-6f) {
+        const float a = unc_spec - 4e-7f;
+        l = normalize3(V3(l.x + pert_sign() * a, l.y + pert_sign() * a, l.z + pert_sign() * a));
+    }
+    g_trace_on = (x == g_trace_x && y == g_trace_y);
+    g_trace_spec = g_trace_on;
+    TRACE(0, viewPos.x, viewPos.y, viewPos.z, viewZ);
+    TRACE(1, specularRay.x, specularRay.y, specularRay.z, random.z);
+    TRACE(3, viewNormal.x, viewNormal.y, viewNormal.z, roughnessSq);
     g_unc_dir = isEnvSample ? 4e-7f : unc_spec;
     calc_angles(l, vv, n, &NoL, &NoH, &LoH, &VoH);
     {
@@ -872,6 +936,9 @@ static void k1_pixel(const k1_ctx *c, int x, int y, uint32_t *out) {
         else gi = V3(gi.x / pdf, gi.y / pdf, gi.z / pdf);
         gi = V3(gi.x / emsPdf, gi.y / emsPdf, gi.z / emsPdf);
         specularGI = gi;
+        TRACE(2, hitPos.x, hitPos.y, hitPos.z, 0.0f);
+        g_trace_spec = 0;
+        g_trace_on = 0;
     }
     v3 specularHitPos = hitPos;
     if (p->useDirectLight) { /* :267-272 */
