@@ -1,7 +1,6 @@
 // k4_compose_texel.h — the arithmetic of DenoiserComposePass's fragment for ONE texel whose inputs are at hand: the inline shader
 // src/denoise/pass/DenoiserComposePass.js:66-85 and constructGlobalIllumination, src/denoise/shader/denoiser_compose_functions.glsl:53-108.
-// Shared by K4 (k4_compose.hip: one launch per draw) and by the last K3 launch when the library folds the compose draw into it
-// (k3_denoise.hip, FUSE): the same function in two translation units compiled with the same flags.
+// Used by K4 (k4_compose.hip).  (Rounds 4-5 also compiled it into the last K3 launch, the compose fold that left the library in round 6: DESIGN.md §4 K4.)
 #pragma once
 #include "rfx_brdf.h"
 #include "rfx_kernels.h"

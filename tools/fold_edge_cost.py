@@ -8,6 +8,8 @@ which would add an LDS exchange and a barrier to it — and the compose draw ove
 launch, which has to walk every fourth row pair and the strided columns.
 
     python tools/fold_edge_cost.py [W H]
+
+(Run in round 6 against ABI 18, which still had the inexact fold: profiles/r06_k4/exact_fold_bounds.txt.  On ABI 19 the folded-pair line prints nan.)
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
