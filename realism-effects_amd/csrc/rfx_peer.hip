@@ -220,7 +220,8 @@ int rfx_peer_gather_history(rfx_ctx *c, rfx_tex id, size_t *bytes_pulled_previou
     unsigned int *status = (unsigned int *)c->peer_status_dev;
     unsigned long long *pulled = c->peer_status_dev + 1;
     HIPCHK(c, hipMemsetAsync(pulled, 0, sizeof(unsigned long long), c->comm_stream));
-    hipLaunchKernelGGL(peer_barrier, dim3(1), dim3(64), 0, c->comm_stream, flags, me, n, ++c->peer_epoch, status);  // every rank has composed
+    const unsigned long long composed = ++c->peer_epoch, pulled_everywhere = ++c->peer_epoch;
+    hipLaunchKernelGGL(peer_barrier, dim3(1), dim3(64), 0, c->comm_stream, flags, me, n, composed, status);  // every rank has composed
     int base = 0;
     rfx_split_rows(H, n, 0, nullptr, &base);
     hipLaunchKernelGGL(peer_pull, dim3((W + 63) / 64, (H + 3) / 4), dim3(64, 4), 0, c->comm_stream, (float *)s.ptr, (float *const *)c->peer_table_dev, c->hit_mask_dev, W, H, base, n, me, fpt,
@@ -231,7 +232,7 @@ int rfx_peer_gather_history(rfx_ctx *c, rfx_tex id, size_t *bytes_pulled_previou
     HIPCHK(c, hipEventRecord(c->ev_comm, c->comm_stream));
     c->comm_pending = true;
     // ... the next compose draw needs every rank to have pulled (rfx_compose waits for this event)
-    hipLaunchKernelGGL(peer_barrier, dim3(1), dim3(64), 0, c->comm_stream, flags, me, n, ++c->peer_epoch, status);
+    hipLaunchKernelGGL(peer_barrier, dim3(1), dim3(64), 0, c->comm_stream, flags, me, n, pulled_everywhere, status);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev_peer_release, c->comm_stream));
     c->peer_release_pending = true;

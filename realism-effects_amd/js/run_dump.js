@@ -13,6 +13,8 @@
 // With --ranks N (N > 1): the frame is cut into N row tiles, ONE NODE PROCESS PER GPU (this process spawns them: rank r drives
 // device r), which exchange halo rows and the composed GI over RCCL through the C ABI (js/tiling.js); rank 0 creates the
 // ncclUniqueId and hands it over through a file.  The parent stitches the tiles: the outputs are bit-identical to a --ranks 1 run.
+// --historyGather '"all"' (default) | '"bounded"' | '"peer"': how next frame's K1 gets the composed GI of the other tiles (js/tiling.js); "peer"
+// moves no collective at all — each rank's kernel loads what its rays read through HIP IPC mappings (the blobs travel through files too).
 const fs = require("fs")
 const path = require("path")
 const rfx = require("./index")
@@ -39,6 +41,7 @@ if (opt.ranks > 1 && opt.rank === undefined) {
 	const idFile = path.join(idDir, "nccl_id")
 	const cleanup = () => {
 		try { fs.unlinkSync(idFile) } catch (e) { /* never written */ }
+		for (let r = 0; r < opt.ranks; r++) try { fs.unlinkSync(idFile + ".peer" + r) } catch (e) { /* not that mode */ }
 		try { fs.rmdirSync(idDir) } catch (e) { /* not empty: leave it */ }
 	}
 	const kids = []
@@ -71,7 +74,8 @@ if (opt.ranks > 1 && opt.rank === undefined) {
 	})
 	return
 }
-const tiled = opt.ranks > 1 ? { rank: opt.rank, ranks: opt.ranks, idFile: opt.idFile } : null
+const tiled = opt.ranks > 1 ? { rank: opt.rank, ranks: opt.ranks, idFile: opt.idFile, historyGather: opt.historyGather || "all" } : null
+delete opt.historyGather
 delete opt.ranks
 delete opt.rank
 delete opt.idFile
@@ -115,20 +119,33 @@ if (tiled) {
 		for (let i = 1; i < v.length; i += 4) if (Math.abs(v[i]) > vmax) vmax = Math.abs(v[i])
 	}
 	const halo = rfx.requiredHalo(opt.radius === undefined ? 3 : opt.radius, vmax, first.height, first.width)
+	const waitFor = (file, what) => {
+		const t0 = Date.now()
+		while (!fs.existsSync(file)) {
+			if (Date.now() - t0 > 120000) throw new Error("rank " + tiled.rank + ": no " + what)
+			Atomics.wait(new Int32Array(new SharedArrayBuffer(4)), 0, 0, 20)
+		}
+		return fs.readFileSync(file)
+	}
 	let id
 	if (tiled.rank === 0) {
 		id = rfx.commUniqueId()
 		fs.writeFileSync(tiled.idFile + ".tmp", id)
 		fs.renameSync(tiled.idFile + ".tmp", tiled.idFile)
 	} else {
-		const t0 = Date.now()
-		while (!fs.existsSync(tiled.idFile)) {
-			if (Date.now() - t0 > 120000) throw new Error("rank " + tiled.rank + ": no ncclUniqueId from rank 0")
-			Atomics.wait(new Int32Array(new SharedArrayBuffer(4)), 0, 0, 20)
-		}
-		id = fs.readFileSync(tiled.idFile)
+		id = waitFor(tiled.idFile, "ncclUniqueId from rank 0")
 	}
-	renderer = new rfx.TiledRenderer(first.width, first.height, tiled.rank, tiled.ranks, halo, id, { device: process.env.RFX_ONE_GPU === "1" ? 0 : tiled.rank })
+	renderer = new rfx.TiledRenderer(first.width, first.height, tiled.rank, tiled.ranks, halo, id,
+		{ device: process.env.RFX_ONE_GPU === "1" ? 0 : tiled.rank, historyGather: tiled.historyGather === "peer" ? "all" : tiled.historyGather })
+	// --historyGather '"peer"': the ranks' export blobs (192 plain bytes each) travel once, through files next to the id file
+	if (tiled.historyGather === "peer")
+		renderer.usePeerHistory(blob => {
+			fs.writeFileSync(tiled.idFile + ".peer" + tiled.rank + ".tmp", blob)
+			fs.renameSync(tiled.idFile + ".peer" + tiled.rank + ".tmp", tiled.idFile + ".peer" + tiled.rank)
+			const all = []
+			for (let r = 0; r < tiled.ranks; r++) all.push(waitFor(tiled.idFile + ".peer" + r, "peer blob of rank " + r))
+			return all
+		})
 } else renderer = new rfx.Renderer(first.width, first.height)
 // --uvModel '"reference_gl"': every fragment sees the vUv the reference GL's rasteriser interpolates (rfx_set_uv_model) instead of (i + 0.5) / n
 if (opt.uvModel) (renderer.inner || renderer).setUvModel(opt.uvModel)

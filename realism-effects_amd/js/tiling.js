@@ -8,7 +8,9 @@
 //   the composed GI                  : next frame's K1 gathers it anywhere on screen, but only its SHADING half reads it, so K1 runs as
 //                                      ssgiTrace / ssgiShade: historyGather "all" (default) all-gathers .rgb (RFX_TEX_COMPOSE_RGB)
 //                                      after K4 and waits between the two halves; "bounded" moves, between the two, exactly the rows
-//                                      the traced rays will read, from their owners (rfx_gather_history_rows)
+//                                      the traced rays will read, from their owners (rfx_gather_history_rows); "peer" (usePeerHistory)
+//                                      has this rank's own kernel load those column blocks out of the owners' planes through HIP IPC
+//                                      mappings (rfx_peer_*): no collective, no host wait
 const addon = require("../napi/rfx_napi.node")
 const { Renderer, TEX } = require("./Renderer")
 
@@ -37,6 +39,10 @@ class TiledRenderer {
 			haloExchange: (tex, up, down) => addon.haloExchange(this.inner._h, tex, up, down),
 			allgatherHistory: tex => addon.allgatherHistory(this.inner._h, tex),
 			gatherHistoryRows: tex => addon.gatherHistoryRows(this.inner._h, tex),
+			peerExport: tex => addon.peerExport(this.inner._h, tex),
+			peerOpen: (tex, blobs, rank, nranks) => addon.peerOpen(this.inner._h, tex, blobs, rank, nranks),
+			peerGatherHistory: tex => addon.peerGatherHistory(this.inner._h, tex),
+			peerClose: () => addon.peerClose(this.inner._h),
 			commWait: () => addon.commWait(this.inner._h)
 		}
 		this.width = width
@@ -51,7 +57,7 @@ class TiledRenderer {
 		// trace and its shade only the rows of the composed GI that the tiles' rays will read travel (rfx_gather_history_rows) — fewer
 		// bytes (scene dependent: 67-71 % at N = 4 / 8 on the synthetic orbit at 4K), but on the critical path (rfx_amd/tiling.py).
 		this.historyGather = nranks > 1 ? (options.historyGather || "all") : "all"
-		if (this.historyGather !== "bounded" && this.historyGather !== "all") throw new RangeError("historyGather: \"bounded\" or \"all\"")
+		if (this.historyGather !== "bounded" && this.historyGather !== "all") throw new RangeError("historyGather: \"bounded\" or \"all\" (\"peer\": usePeerHistory)")
 		this.historyBytesReceived = []
 		this._haloPending = false
 		this._gatherPending = false
@@ -70,6 +76,15 @@ class TiledRenderer {
 	}
 	_down() {
 		return this.rank > 0 ? this.rank - 1 : -1
+	}
+	// Switch the composed-GI exchange to the device-driven pull (include/rfx.h rfx_peer_*; rfx_amd/tiling.py use_peer_history).
+	// `allGather(Buffer) -> [every rank's Buffer, in rank order]`: how the ranks' export blobs travel, once, by any channel the host has
+	usePeerHistory(allGather) {
+		if (this.nranks === 1) return
+		const blobs = allGather(this._comm.peerExport(TEX.COMPOSE_RGB))
+		if (!Array.isArray(blobs) || blobs.length !== this.nranks) throw new RangeError("usePeerHistory: allGather returns one blob per rank, in rank order")
+		this._comm.peerOpen(TEX.COMPOSE_RGB, Buffer.concat(blobs), this.rank, this.nranks)
+		this.historyGather = "peer"
 	}
 	exchange(texs) {
 		if (this.nranks === 1 || this.haloRows === 0) return
@@ -104,9 +119,13 @@ class TiledRenderer {
 			this._gatherPending = true
 		}
 		this.commWait()
+		if (this.nranks > 1 && this.historyGather === "peer") {
+			this.historyBytesReceived.push(this._comm.peerGatherHistory(TEX.COMPOSE_RGB)) // (what the previous frame's pull moved)
+			this._comm.commWait() // orders the shade after the pull (stream order: nothing waits on the host)
+		}
 	}
 	ssgiMarch(u) {
-		if (this.nranks > 1 && this.historyGather === "bounded") throw new Error("TiledRenderer (historyGather \"bounded\"): K1 must run as ssgiTrace / ssgiShade")
+		if (this.nranks > 1 && this.historyGather !== "all") throw new Error("TiledRenderer (historyGather \"" + this.historyGather + "\"): K1 must run as ssgiTrace / ssgiShade")
 		this.commWait()
 		this.inner.ssgiMarch(u)
 	}

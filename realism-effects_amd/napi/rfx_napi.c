@@ -538,6 +538,76 @@ static napi_value n_gather_history_rows(napi_env env, napi_callback_info info) {
     napi_create_double(env, (double)got, &out);
     return out;
 }
+/* The device-driven history gather (include/rfx.h rfx_peer_*: the consumer's own kernel loads the column blocks its rays read out of the
+ * peers' planes through HIP IPC mappings).  peerExport(ctx, tex) -> Buffer of RFX_PEER_BLOB_BYTES; peerOpen(ctx, tex, Buffer of nranks blobs in
+ * rank order, rank, nranks); peerGatherHistory(ctx, tex) -> bytes the PREVIOUS call pulled; peerClose(ctx) */
+static napi_value n_peer_export(napi_env env, napi_callback_info info) {
+    napi_value a[2], buf;
+    int32_t tex;
+    char blob[RFX_PEER_BLOB_BYTES];
+    void *data = NULL;
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[1], &tex)) return NULL;
+    int rc = rfx_peer_export(c, (rfx_tex)tex, blob);
+    if (rc) return throw_rfx(env, c, "rfx_peer_export", rc);
+    NAPI_CALL(env, napi_create_buffer_copy(env, sizeof blob, blob, &data, &buf));
+    return buf;
+}
+static napi_value n_peer_open(napi_env env, napi_callback_info info) {
+    napi_value a[5];
+    int32_t tex, rank, n;
+    void *data = NULL;
+    size_t len = 0;
+    if (!get_args(env, info, 5, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[1], &tex) || !get_int(env, a[3], &rank) || !get_int(env, a[4], &n)) return NULL;
+    if (n < 1 || napi_get_buffer_info(env, a[2], &data, &len) != napi_ok || len != (size_t)n * RFX_PEER_BLOB_BYTES) {
+        napi_throw_type_error(env, NULL, "peerOpen: the blobs are one Buffer of nranks * RFX_PEER_BLOB_BYTES bytes, in rank order");
+        return NULL;
+    }
+    int rc = rfx_peer_open(c, (rfx_tex)tex, data, rank, n);
+    if (rc) return throw_rfx(env, c, "rfx_peer_open", rc);
+    return NULL;
+}
+static napi_value n_peer_gather_history(napi_env env, napi_callback_info info) {
+    napi_value a[2], out;
+    int32_t tex;
+    size_t got = 0;
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c || !get_int(env, a[1], &tex)) return NULL;
+    int rc = rfx_peer_gather_history(c, (rfx_tex)tex, &got);
+    if (rc) return throw_rfx(env, c, "rfx_peer_gather_history", rc);
+    napi_create_double(env, (double)got, &out);
+    return out;
+}
+static napi_value n_peer_close(napi_env env, napi_callback_info info) {
+    napi_value a[1];
+    if (!get_args(env, info, 1, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    int rc = rfx_peer_close(c);
+    if (rc) return throw_rfx(env, c, "rfx_peer_close", rc);
+    return NULL;
+}
+/* ssgiHitMask(ctx, Uint32Array of frame-height entries): rfx_ssgi_hit_mask (after ssgiTrace; blocks until the trace has finished) */
+static napi_value n_ssgi_hit_mask(napi_env env, napi_callback_info info) {
+    napi_value a[2], ab;
+    napi_typedarray_type type;
+    size_t len = 0, off = 0;
+    void *data = NULL;
+    if (!get_args(env, info, 2, a)) return NULL;
+    rfx_ctx *c = get_ctx(env, a[0]);
+    if (!c) return NULL;
+    if (napi_get_typedarray_info(env, a[1], &type, &len, &data, &ab, &off) != napi_ok || type != napi_uint32_array) {
+        napi_throw_type_error(env, NULL, "ssgiHitMask: a Uint32Array with one entry per frame row");
+        return NULL;
+    }
+    int rc = rfx_ssgi_hit_mask(c, (unsigned int *)data, (int)len);
+    if (rc) return throw_rfx(env, c, "rfx_ssgi_hit_mask", rc);
+    return NULL;
+}
 /* commWait(ctx) / commDestroy(ctx) */
 static napi_value n_comm_wait(napi_env env, napi_callback_info info) {
     napi_value a[1];
@@ -727,6 +797,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"stageUpload", n_stage_upload}, {"stageFlip", n_stage_flip}, {"hostAlloc", n_host_alloc},
         {"splitRows", n_split_rows}, {"commUniqueId", n_comm_unique_id}, {"commInit", n_comm_init}, {"haloExchange", n_halo_exchange},
         {"allgatherHistory", n_allgather_history}, {"gatherHistoryRows", n_gather_history_rows}, {"commWait", n_comm_wait}, {"commDestroy", n_comm_destroy},
+        {"peerExport", n_peer_export}, {"peerOpen", n_peer_open}, {"peerGatherHistory", n_peer_gather_history}, {"peerClose", n_peer_close}, {"ssgiHitMask", n_ssgi_hit_mask},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; i++) {
         napi_value f;

@@ -1281,17 +1281,29 @@ def test_peer_history_gather_between_two_contexts_of_one_process(blue_noise):
     other's addresses directly): two tile contexts on this device, each plane filled with its owner's value; after the trace,
     rfx_peer_gather_history on both — the barrier kernels of the two exchange streams meet on the device while the host has long returned — and
     each context holds, of the OTHER tile's rows, exactly the column blocks its own row mask names, everything else untouched.  State errors:
-    gather before open, open before export, a second open."""
+    gather before open, open before export, a second open.  One host thread per context issues the calls (on the device one thread could issue
+    both — launches return at once; on the simulator a launch RUNS on the calling thread, so the two barrier kernels need two threads to meet)."""
+    import threading
     from rfx_amd import abi
     from rfx_amd.context import Context, RfxError
     from rfx_amd.scene import synthetic_frame
 
-    if os.environ.get("RFX_HOSTSIM") == "1":
-        c = Context(64, 32, tile_y0=0, tile_rows=16, halo_rows=4)
-        with pytest.raises(RfxError, match="hipIpcGetMemHandle"):  # no second address space on the simulator: the mode reports itself unsupported
-            c.peer_export(abi.TEX_COMPOSE_RGB)
-        c.close()
-        return
+    def on_both(fn):  # fn(rank) on one thread per context; the results in rank order
+        out, errs = [None, None], []
+
+        def run(r):
+            try:
+                out[r] = fn(r)
+            except BaseException as e:  # noqa: BLE001 (re-raised below)
+                errs.append(e)
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+        return out
     W, H = 224, 126
     f = synthetic_frame(W, H, 1)
     tiles = Context.split_rows(H, 2, 0), Context.split_rows(H, 2, 1)
@@ -1305,6 +1317,16 @@ def test_peer_history_gather_between_two_contexts_of_one_process(blue_noise):
         c.peer_open(abi.TEX_COMPOSE_RGB, blobs, r, 2)
     with pytest.raises(RfxError, match="already open"):
         ctxs[0].peer_open(abi.TEX_COMPOSE_RGB, blobs, 0, 2)
+    # a blob of ANOTHER process is mapped through its IPC handles: one that names no allocation is refused, with the call that refused it
+    y0, rows = tiles[1]
+    other = Context(W, H, tile_y0=y0, tile_rows=rows, halo_rows=8)
+    mine = bytearray(other.peer_export(abi.TEX_COMPOSE_RGB))
+    foreign = bytearray(blobs[0])
+    foreign[8:16] = (int.from_bytes(foreign[8:16], "little") + 1).to_bytes(8, "little")  # the exporter's process id
+    foreign[40:] = bytes(len(foreign) - 40)  # ... and no handles
+    with pytest.raises(RfxError, match="hipIpcOpenMemHandle"):
+        other.peer_open(abi.TEX_COMPOSE_RGB, [bytes(foreign), bytes(mine)], 1, 2)
+    other.close()
     sp, _, _, _ = _params(abi, f, f.prev_camera, 1.0)
     sp.blueNoiseIndex, sp.historySource = 4242, 3  # K1 reads the RGB twin
     masks = []
@@ -1317,9 +1339,10 @@ def test_peer_history_gather_between_two_contexts_of_one_process(blue_noise):
     for c in ctxs:
         c.ssgi_trace(sp)
         masks.append(c.ssgi_hit_mask())
-    for c in ctxs:  # every rank issues the call; neither waits on the host
-        c.ssgi_trace(sp)
-        assert c.peer_gather_history(abi.TEX_COMPOSE_RGB) == 0  # (what the PREVIOUS call pulled: there was none)
+    def first_pull(r):  # every rank issues the call; neither waits on the host
+        ctxs[r].ssgi_trace(sp)
+        return ctxs[r].peer_gather_history(abi.TEX_COMPOSE_RGB)
+    assert on_both(first_pull) == [0, 0]  # (what the PREVIOUS call pulled: there was none)
     pulled = []
     for r, c in enumerate(ctxs):
         c.comm_wait()
@@ -1337,9 +1360,7 @@ def test_peer_history_gather_between_two_contexts_of_one_process(blue_noise):
         assert np.array_equal(got, want), "rank %d: %d texels differ" % (r, int((got != want).any(-1).sum()))
         pulled.append(int((needed & other).sum()))
     assert sum(pulled) > 0  # (vacuous otherwise: the synthetic frame's reflections cross the tile boundary)
-    for r, c in enumerate(ctxs):  # the next call reports the previous one's bytes, and that no peer missed a barrier
-        c.ssgi_trace(sp)
-        assert c.peer_gather_history(abi.TEX_COMPOSE_RGB) == pulled[r] * 12
+    assert on_both(first_pull) == [p * 12 for p in pulled]  # the next call reports the previous one's bytes, and that no peer missed a barrier
     for c in ctxs:
         c.comm_wait()
         c.sync()

@@ -309,11 +309,16 @@ const inner = {
   compose(u) { calls.push(["compose", u.writeHistoryRGB]) }, sync() { calls.push(["sync"]) }
 }
 const comm = { haloExchange(tex, up, down) { calls.push(["halo", tex, up, down]) }, allgatherHistory(tex) { calls.push(["gather", tex]) },
-  gatherHistoryRows(tex) { calls.push(["gather_rows", tex]); return 0 }, commWait() { calls.push(["wait"]) } }
+  gatherHistoryRows(tex) { calls.push(["gather_rows", tex]); return 0 }, commWait() { calls.push(["wait"]) },
+  peerExport(tex) { calls.push(["peer_export", tex]); return Buffer.alloc(192, 1 + rank) }, peerOpen(tex, blobs, r, n) { calls.push(["peer_open", tex, Array.from(blobs.filter((_, i) => i % 192 === 0)), r, n]) },
+  peerGatherHistory(tex) { calls.push(["peer_gather", tex]); return 0 } }
+let rank = 0
 const out = {}
-for (const rn of [[0, 3, "bounded"], [1, 3, "bounded"], [2, 3, "bounded"], [0, 1, "bounded"], [1, 3, "all"]]) {
+for (const rn of [[0, 3, "bounded"], [1, 3, "bounded"], [2, 3, "bounded"], [0, 1, "bounded"], [1, 3, "all"], [0, 3, "peer"], [2, 3, "peer"], [0, 1, "peer"]]) {
   calls.length = 0
-  const r = new TiledRenderer(96, 66, rn[0], rn[1], 6, null, { inner, comm, historyGather: rn[2] })
+  rank = rn[0]
+  const r = new TiledRenderer(96, 66, rn[0], rn[1], 6, null, { inner, comm, historyGather: rn[2] === "peer" ? "all" : rn[2] })
+  if (rn[2] === "peer") r.usePeerHistory(b => Array.from({ length: rn[1] }, (_, q) => (q === rn[0] ? b : Buffer.alloc(192, 1 + q))))
   const e = new fx.SSGIEffect(null, { frame: {} }, cam, { width: 96, height: 66 }, { ssgi: 10, denoise: 20 })
   e.update(r, null); e.update(r, null); r.sync()
   out[rn.join("/")] = { calls: calls.slice(), tile: [r.tileY0, r.tileRows], exchanges: r.exchangeCount }
@@ -326,7 +331,7 @@ def test_node_tiled_renderer_call_sequence_equals_python(tmp_path):
     """js/tiling.js TiledRenderer (the Node multi-process host's exchange protocol over the C ABI's RCCL entry points) against
     rfx_amd.tiling.CommTiledRenderer, both on recording stand-ins for the tile renderer and the exchange layer: the same draws, windows
     (interior first, then the boundary strips), halo exchanges, gathers and waits, in the same order, for a bottom, a middle and a top
-    rank of three and for a single rank."""
+    rank of three and for a single rank — in the three forms of the composed-GI exchange ("all", "bounded", "peer")."""
     from rfx_amd import tiling
     from rfx_amd.scene import synthetic_frame
     f = synthetic_frame(32, 16, 0)
@@ -339,7 +344,7 @@ def test_node_tiled_renderer_call_sequence_equals_python(tmp_path):
 
     class RecCtx:
         def __init__(self, rank, world):
-            self.W, self.H = W, H
+            self.W, self.H, self.rank = W, H, rank
             self.tile_y0, self.tile_rows = tiling.split_rows(H, world)[rank]
             self.halo = halo if world > 1 else 0
             self.calls = []
@@ -384,15 +389,28 @@ def test_node_tiled_renderer_call_sequence_equals_python(tmp_path):
             self.calls.append(["gather_rows", tex])
             return 0
 
+        def peer_export(self, tex):
+            self.calls.append(["peer_export", tex])
+            return bytes([1 + self.rank]) * 192
+
+        def peer_open(self, tex, blobs, rank, world):
+            self.calls.append(["peer_open", tex, [b[0] for b in blobs], rank, world])
+
+        def peer_gather_history(self, tex):
+            self.calls.append(["peer_gather", tex])
+            return 0
+
         def comm_wait(self):
             self.calls.append(["wait"])
 
         def sync(self):
             self.calls.append(["sync"])
 
-    for rank, world, mode in ((0, 3, "bounded"), (1, 3, "bounded"), (2, 3, "bounded"), (0, 1, "bounded"), (1, 3, "all")):
+    for rank, world, mode in ((0, 3, "bounded"), (1, 3, "bounded"), (2, 3, "bounded"), (0, 1, "bounded"), (1, 3, "all"), (0, 3, "peer"), (2, 3, "peer"), (0, 1, "peer")):
         ctx = RecCtx(rank, world)
-        r = tiling.CommTiledRenderer(ctx, rank, world, b"\0" * 128, history_gather=mode)
+        r = tiling.CommTiledRenderer(ctx, rank, world, b"\0" * 128, history_gather="all" if mode == "peer" else mode)
+        if mode == "peer":  # the device-driven pull (rfx_peer_*): the blobs travel once, then one call between trace and shade, no collective
+            r.use_peer_history(lambda b: [b if q == rank else bytes([1 + q]) * 192 for q in range(world)])
         scene = types.SimpleNamespace(frame=types.SimpleNamespace(depth=np.zeros((0, W), np.float32), gbuffer=np.zeros((0, W, 4), np.uint32),
                                                                   velocity=np.zeros((0, W, 4), np.uint32), direct=np.zeros((0, W, 4), np.float32),
                                                                   camera=f.camera, aov=None))
@@ -404,7 +422,7 @@ def test_node_tiled_renderer_call_sequence_equals_python(tmp_path):
         assert got["tile"] == [ctx.tile_y0, ctx.tile_rows]
         if world > 1:  # the composed GI travels either between trace and shade (bounded) or after K4 (all), never both
             kinds = {c[0] for c in ctx.calls}
-            assert ("gather_rows" in kinds) == (mode == "bounded") and ("gather" in kinds) == (mode == "all"), kinds
+            assert ("gather_rows" in kinds) == (mode == "bounded") and ("gather" in kinds) == (mode == "all") and ("peer_gather" in kinds) == (mode == "peer"), kinds
         assert got["calls"] == json.loads(json.dumps(ctx.calls)), (rank, world, got["calls"][:12], ctx.calls[:12])
         assert got["exchanges"] == r.exchange_count
 
@@ -510,6 +528,114 @@ def test_node_row_tiled_run_equals_single_process(tmp_path, ranks):
     assert info["ranks"] == ranks and info["haloViolations"] == 0 and info["frames"] == 3
     for name in ("final", "compose", "denoise_b0", "denoise_b1", "temporal0", "ssgi"):
         a, b = open(os.path.join(one, name + ".bin"), "rb").read(), open(os.path.join(many, name + ".bin"), "rb").read()
+        assert a == b, name
+
+
+PEER_WORKERS = r"""
+"use strict"
+// Two row tiles of one frame, one worker thread each, both on device 0: js/tiling.js TiledRenderer with historyGather "peer" (the real
+// N-API rfx_peer_* calls: the two contexts' barrier and pull kernels meet on the device), and a TEST exchange layer for the halo rows —
+// host copies between the two threads in lock step — because two RCCL ranks cannot share one GPU.
+const { Worker, isMainThread, workerData } = require("worker_threads")
+const fs = require("fs"), path = require("path")
+const N = 2
+if (isMainThread) {
+  const [JS, dumps, out, opt] = [process.argv[2], JSON.parse(process.argv[3]), process.argv[4], JSON.parse(process.argv[5])]
+  const shared = { ctl: new SharedArrayBuffer(16), blobs: new SharedArrayBuffer(192 * N), rows: new SharedArrayBuffer(N * 2 * (1 << 20)) }
+  let left = N
+  const info = []
+  for (let rank = 0; rank < N; rank++)
+    new Worker(__filename, { workerData: Object.assign({ JS, dumps, out, opt, rank }, shared) })
+      .on("message", m => (info[rank] = m)).on("error", e => { console.error(e); process.exit(1) })
+      .on("exit", code => { if (code) process.exit(code); if (!--left) console.log(JSON.stringify(info)) })
+} else {
+  const { JS, dumps, out, opt, rank } = workerData
+  const rfx = require(JS + "/index")
+  const addon = require(JS + "/../napi/rfx_napi.node")
+  const ctl = new Int32Array(workerData.ctl)
+  const barrier = () => {
+    const g = Atomics.load(ctl, 1)
+    if (Atomics.add(ctl, 0, 1) === N - 1) { Atomics.store(ctl, 0, 0); Atomics.add(ctl, 1, 1); Atomics.notify(ctl, 1) }
+    else { const t0 = Date.now(); while (Atomics.load(ctl, 1) === g) { Atomics.wait(ctl, 1, g, 200); if (Date.now() - t0 > 60000) throw new Error("rank " + rank + ": the other tile never arrived") } }
+  }
+  const slot = (r, k) => new Uint8Array(workerData.rows, (r * 2 + k) * (1 << 20), 1 << 20)
+  let R
+  const put = (k, a) => { const b = new Uint8Array(a.buffer, a.byteOffset, a.byteLength); slot(rank, k).set(b); return a }
+  const get = (r, k, like) => { const b = new Uint8Array(like.byteLength); b.set(slot(r, k).subarray(0, like.byteLength)); return new like.constructor(b.buffer) }
+  const comm = {
+    haloExchange(tex, up, down) {
+      const y0 = R.tileY0, y1 = y0 + R.tileRows, h = R.haloRows
+      let top, bottom
+      if (up >= 0) top = put(0, R.inner.download(tex, y1 - h, h))
+      if (down >= 0) bottom = put(1, R.inner.download(tex, y0, h))
+      barrier()
+      if (up >= 0) R.inner.upload(tex, get(up, 1, top), y1, h)
+      if (down >= 0) R.inner.upload(tex, get(down, 0, bottom), y0 - h, h)
+      barrier()
+    },
+    allgatherHistory() { throw new Error("not in this mode") }, gatherHistoryRows() { throw new Error("not in this mode") },
+    commWait: () => addon.commWait(R.inner._h),
+    peerExport: tex => addon.peerExport(R.inner._h, tex), peerOpen: (tex, blobs, r, n) => addon.peerOpen(R.inner._h, tex, blobs, r, n),
+    peerGatherHistory: tex => addon.peerGatherHistory(R.inner._h, tex), peerClose: () => addon.peerClose(R.inner._h)
+  }
+  const first = rfx.readDump(dumps[0])
+  R = new rfx.TiledRenderer(first.width, first.height, rank, N, opt.halo, null, { comm, device: 0 })
+  R.usePeerHistory(blob => {
+    new Uint8Array(workerData.blobs, 192 * rank, 192).set(blob)
+    barrier()
+    return Array.from({ length: N }, (_, q) => Buffer.from(new Uint8Array(workerData.blobs, 192 * q, 192)))
+  })
+  const scene = { frame: first }, camera = Object.assign({}, first.camera)
+  const effect = new rfx.SSGIEffect(null, scene, camera, { width: first.width, height: first.height, steps: opt.steps, refineSteps: opt.refineSteps }, { ssgi: 11, denoise: 22 }, true)
+  for (const d of dumps) {
+    const f = d === dumps[0] ? first : rfx.readDump(d)
+    scene.frame = f
+    Object.assign(camera, f.camera)
+    effect.update(R, null)
+  }
+  R.sync()
+  effect.mainImage(R)
+  for (const [name, tex] of [["final", rfx.TEX.FINAL], ["compose", rfx.TEX.COMPOSE], ["denoise_b0", rfx.TEX.DENOISE_B0], ["temporal0", rfx.TEX.TEMPORAL0], ["ssgi", rfx.TEX.SSGI]]) {
+    const a = R.download(tex, R.tileY0, R.tileRows)
+    fs.writeFileSync(path.join(out, name + ".rank" + rank + ".bin"), Buffer.from(a.buffer, a.byteOffset, a.byteLength))
+  }
+  const pulled = R.historyBytesReceived.slice() // (each call reports what the call before it pulled)
+  barrier() // neither plane is unmapped while the other tile may still read it
+  require("worker_threads").parentPort.postMessage({ rank, pulled, haloViolations: R.haloViolations(), exchanges: R.exchangeCount, mode: R.historyGather })
+}
+"""
+
+
+@pytest.mark.gpu
+def test_node_peer_history_gather_between_two_tiles_on_one_gpu(tmp_path):
+    """js/tiling.js with historyGather "peer" ON THE DEVICE: two row tiles of one frame driven by two worker threads of one Node process
+    through the N-API addon (peerExport / peerOpen / peerGatherHistory — rfx_peer_*, the consumer's own kernel pulling the column blocks its
+    rays read out of the other tile's plane, the flag barriers of the two contexts meeting on the device), the halo rows moved by a TEST
+    exchange layer (host copies in lock step — two RCCL ranks cannot share a GPU, which is why run_dump.js --ranks runs under --hostsim
+    only): every output of three frames equals the bytes of one process rendering the whole frame, and something was pulled.  Also under
+    --hostsim (contexts of one process use each other's addresses: no mapping needed; a launch runs on the calling thread, so the two
+    workers' barrier kernels meet like the device's)."""
+    from rfx_amd.dump import write_dump
+    from rfx_amd.scene import synthetic_frame
+    W, H = 160, 96
+    dirs = []
+    for i in range(3):
+        d = str(tmp_path / ("dump%d" % i))
+        write_dump(d, synthetic_frame(W, H, i))
+        dirs.append(d)
+    one, many = str(tmp_path / "one"), str(tmp_path / "many")
+    os.makedirs(many)
+    subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", one, "--steps", "12", "--refineSteps", "3"], text=True)
+    script = str(tmp_path / "peer_workers.js")
+    open(script, "w").write(PEER_WORKERS)
+    res = subprocess.check_output([node, script, JS, json.dumps(dirs), many, json.dumps(dict(halo=12, steps=12, refineSteps=3))], text=True, timeout=300)
+    info = json.loads(res.strip().splitlines()[-1])
+    assert [i["rank"] for i in info] == [0, 1] and all(i["mode"] == "peer" and i["haloViolations"] == 0 for i in info), info
+    assert all(len(i["pulled"]) == 3 and i["pulled"][0] == 0 for i in info), info  # one report per frame, each of the call before
+    assert sum(sum(i["pulled"]) for i in info) > 0, info  # (vacuous otherwise: reflections cross the tile boundary in this scene)
+    for name in ("final", "compose", "denoise_b0", "temporal0", "ssgi"):
+        a = open(os.path.join(one, name + ".bin"), "rb").read()
+        b = b"".join(open(os.path.join(many, "%s.rank%d.bin" % (name, r)), "rb").read() for r in range(2))
         assert a == b, name
 
 
