@@ -368,7 +368,10 @@ int rfx_gather_history_rows(rfx_ctx *, rfx_tex id, void *ncclComm, size_t *bytes
  * `bytes_pulled_previous_call` (may be NULL) reports what the PREVIOUS call's kernel moved, and a peer that never reached a barrier (~2 s)
  * surfaces as RFX_EDEVICE from the next call instead of hanging the device.  The plane must be the library's own (not rfx_bind_external).
  * Contexts of one process (one per device, peer access enabled by the host) are recognised by the blob's process id and use each other's
- * addresses directly.  A host uses ONE of rfx_allgather_history / rfx_gather_history_rows / rfx_peer_gather_history. */
+ * addresses directly.  (Several contexts of one process on ONE device — a test set-up — work too, as long as their exchange streams sit on
+ * different hardware queues: the barrier kernels of the ranks must be resident together, and the HIP runtime multiplexes a process's streams
+ * onto GPU_MAX_HW_QUEUES (4) queues per device; with more streams than queues two barrier kernels can queue behind each other, and the call
+ * after the bounded poll reports RFX_EDEVICE.  Set GPU_MAX_HW_QUEUES >= 4 x the contexts before the first HIP call.)  A host uses ONE of rfx_allgather_history / rfx_gather_history_rows / rfx_peer_gather_history. */
 #define RFX_PEER_BLOB_BYTES 192
 int rfx_peer_export(rfx_ctx *, rfx_tex id, void *blob);
 int rfx_peer_open(rfx_ctx *, rfx_tex id, const void *blobs, int rank, int nranks);

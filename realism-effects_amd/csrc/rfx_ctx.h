@@ -106,8 +106,10 @@ static inline size_t texel_bytes(int id) {
 
 static inline int fail(rfx_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
     char buf[512];
-    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-    else snprintf(buf, sizeof buf, "%s", what);
+    if (e != hipSuccess) {
+        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        (void)hipGetLastError();  // reported here: not again by the next launch check of this thread (HIP keeps the last error until it is read)
+    } else snprintf(buf, sizeof buf, "%s", what);
     if (c) c->err = buf;
     else g_create_err = buf;
     return code;

@@ -206,7 +206,7 @@ int rfx_peer_gather_history(rfx_ctx *c, rfx_tex id, size_t *bytes_pulled_previou
     const int n = c->peer_n, me = c->peer_rank, H = c->H, W = c->W, fpt = (int)(s.texel / sizeof(float));
     // what the PREVIOUS call's kernels reported (its copy has long executed): a peer that never arrived, and the texels pulled
     if (c->peer_epoch > 0) {
-        if (c->peer_status_host[0] & 1u) return fail(c, RFX_EDEVICE, "rfx_peer_gather_history: a peer did not reach the previous call's barrier (every rank must issue the call once per frame)");
+        if (c->peer_status_host[0] & 1u) return fail(c, RFX_EDEVICE, "rfx_peer_gather_history: a peer did not reach the previous call's barrier (every rank must issue the call once per frame; contexts of one process on ONE device: include/rfx.h on GPU_MAX_HW_QUEUES)");
         if (bytes_pulled_previous_call) *bytes_pulled_previous_call = (size_t)c->peer_status_host[1] * s.texel;
     }
     // this tile's row mask, on the draw stream (a bit per column block of every frame row this tile's rays read)

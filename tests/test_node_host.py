@@ -628,7 +628,9 @@ def test_node_peer_history_gather_between_two_tiles_on_one_gpu(tmp_path):
     subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", one, "--steps", "12", "--refineSteps", "3"], text=True)
     script = str(tmp_path / "peer_workers.js")
     open(script, "w").write(PEER_WORKERS)
-    res = subprocess.check_output([node, script, JS, json.dumps(dirs), many, json.dumps(dict(halo=12, steps=12, refineSteps=3))], text=True, timeout=300)
+    # two contexts of one process on ONE device: their exchange streams on different hardware queues (include/rfx.h rfx_peer_*)
+    res = subprocess.check_output([node, script, JS, json.dumps(dirs), many, json.dumps(dict(halo=12, steps=12, refineSteps=3))], text=True, timeout=300,
+                                  env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
     info = json.loads(res.strip().splitlines()[-1])
     assert [i["rank"] for i in info] == [0, 1] and all(i["mode"] == "peer" and i["haloViolations"] == 0 for i in info), info
     assert all(len(i["pulled"]) == 3 and i["pulled"][0] == 0 for i in info), info  # one report per frame, each of the call before

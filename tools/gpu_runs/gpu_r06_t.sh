@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, call T: the Node host's peer mode on the device (two tiles, two worker threads of one Node process, js/tiling.js usePeerHistory),
+# round 6, call T (re-run as V after the fixes: sticky HIP error cleared in fail(), the one-device tests ask for 16 hardware queues):
 # the one-process peer test in its threaded form, the N-process flows, and the quick subset after rfx_peer.hip's host-side change
 # (the two barrier epochs are named before the launches: same launches, same arguments).
 set -x
