@@ -40,6 +40,24 @@ def test_differential_fuzz_of_the_kernels_against_the_oracle():
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG) or shutil.which("make") is None, reason="no host clang++ / make")
+def test_differential_fuzz_of_the_variants_in_lock_step_with_the_oracle():
+    """tools/fuzz_effects.py: random SSGIEffect / SSREffect options (mode, denoiseMode, iterations, radius, the phi's, resolutionScale ...), frame
+    sizes, cameras, environments and fog — the effect drives the simulated kernels and the C restatement in lock step, every draw on identical
+    inputs (60 cases here; 500 plain, 120 under AddressSanitizer and 600 on the device were clean when this was written) — and its self-test:
+    with one parameter of the LIBRARY's draw perturbed the same limits must flag K1, K2 and K3."""
+    sim = os.path.join(ROOT, "tests", "hostsim")
+    subprocess.check_call(["make", "-s", "-C", sim])
+    from conftest import hostsim_child_env
+    env = dict(os.environ, **hostsim_child_env(sim))
+    tool = [sys.executable, os.path.join(ROOT, "tools", "fuzz_effects.py"), "--lib", os.path.join(sim, "_build", "librfx_hostsim.so")]
+    p = subprocess.run(tool + ["--n", "60", "--seed", "5"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert " 0 problems" in p.stdout.splitlines()[-1]
+    p = subprocess.run(tool + ["--n", "12", "--seed", "5", "--self-test"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0 and "self-test" in p.stdout.splitlines()[-1], (p.stdout + p.stderr)[-3000:]
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG) or shutil.which("make") is None, reason="no host clang++ / make")
 def test_k3_pass0_asks_for_an_lds_size_that_fits_three_times_into_a_cu():
     """The launcher's own arithmetic, executed: on a 16:9 frame at radius 3 the first denoise pass of two textures must ask for no more dynamic LDS
     than fits THREE times into a CU's 160 KiB handed out in 1 280-byte granules (measured: profiles/r05_microbench/lds_occupancy.txt) — 53 744 B since

@@ -4,6 +4,10 @@ on the same inputs.  Both sides use libm-grade primitives, so they agree to a ha
 than a fraction of a percent of its pixels is a logic bug (apron, halo, launch shape, an option the kernel and the oracle read differently).
 
     make -C tests/hostsim && python tools/fuzz_hostsim.py --lib tests/hostsim/_build/librfx_hostsim.so [--n 200] [--seed 1]
+
+--device: the same cases against the PRODUCT library on an MI355X (the kernels as compiled for gfx950 at the odd sizes no test pins: 1-pixel
+frames, portrait, tiles as thin as the halo; the device's v_exp / v_log / v_rcp against libm flip a few more pixels than the simulator does —
+same limits, a fraction of a percent plus two pixels).
 """
 import argparse
 import os
@@ -24,11 +28,12 @@ from rfx_amd.scene import synthetic_frame  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=100)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--device", action="store_true", help="run against librfx_hip.so on the GPU instead of the simulator")
 ap.add_argument("--lib", default=None, help="tests/hostsim/_build/librfx_hostsim.so (not needed in a child of pytest --hostsim)")
 a = ap.parse_args()
 if a.lib:
     abi.set_library_path(a.lib)
-assert hasattr(abi.load_library(), "rfx_hostsim_build"), "run with --lib tests/hostsim/_build/librfx_hostsim.so (or under pytest --hostsim's child environment)"
+assert a.device != hasattr(abi.load_library(), "rfx_hostsim_build"), "run with --device on a GPU box, or with --lib tests/hostsim/_build/librfx_hostsim.so (or under pytest --hostsim's child environment)"
 rng = np.random.RandomState(a.seed)
 blue = load_blue_noise_table()
 fails = nchecks = 0
