@@ -238,7 +238,8 @@ def assemble_final(fog_mode=0, perspective=True) -> str:
 def write_assembled(outdir: str, **kw):
     """Build products for the GPU box (no /root/reference there): oracle/_ref/shaders/*.frag."""
     os.makedirs(outdir, exist_ok=True)
-    for name, src in (("ssgi_20_5", assemble_ssgi(20, 5)), ("ssgi_8_2", assemble_ssgi(8, 2)), ("ssgi_40_5", assemble_ssgi(40, 5)),
+    more = tuple(("ssgi_%d_%d" % sr, assemble_ssgi(*sr)) for sr in ((1, 0), (3, 1), (12, 3), (17, 6), (24, 0)))  # tools/fuzz_vs_reference_gl.py --device
+    for name, src in more + (("ssgi_20_5", assemble_ssgi(20, 5)), ("ssgi_8_2", assemble_ssgi(8, 2)), ("ssgi_40_5", assemble_ssgi(40, 5)),
                       ("temporal", assemble_temporal()), ("denoise", assemble_denoise()), ("compose", assemble_compose()),
                       ("ssgi_ssr_20_5", assemble_ssgi(20, 5, 1)), ("temporal_ssr", assemble_temporal(texture_count=1, input_type=2, reproject_specular=True, neighborhood_clamp=True)),
                       ("denoise_ssr", assemble_denoise(texture_count=1, is_texture_specular=(True, True))), ("compose_ssr", assemble_compose(input_type=2)),

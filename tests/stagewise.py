@@ -151,24 +151,29 @@ def _h(t):  # RGBA16F target read back as float32 -> the half bit patterns (exac
 
 
 def run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start=1000, denoise_start=2000, shader_dir=None, log=print,
-        with_margins=True, n_perturb=6, sample_every=64, extra_perturb=96, compare_from=0, uv_model="reference_gl", rows=None, compare_only=None):
+        with_margins=True, n_perturb=6, sample_every=64, extra_perturb=96, compare_from=0, uv_model="reference_gl", rows=None, compare_only=None, options=None):
     """Returns the list of parity.Report (one per stage output and frame).  frame_fn(i) -> dump frame i (rfx_amd.scene Frame).
     uv_model "reference_gl" (the default of the library and of this harness): the implementation (rfx_set_uv_model / rfxo_set_uv_model)
     evaluates the reference GL's own vUv planes, and the proving oracle then carries no vUv uncertainty at all; "ideal": (i + 0.5) / n on the
     implementation's side, the vUv uncertainty in the proofs.
     rows (y0, y1): every draw still covers the whole frame on both sides, but only that band of rows is compared and proven — what makes an
     8K frame affordable in the default suite (the numpy side of a whole 33 Mpixel stage output costs minutes).
-    compare_only: a set of frame numbers — the other frames only advance the reference chain (a long sequence compared at a few ages)."""
+    compare_only: a set of frame numbers — the other frames only advance the reference chain (a long sequence compared at a few ages).
+    options: SSGIEffect options other than the defaults, set on the reference chain AND in the implementation's uniform blocks — any of
+    distance, thickness, missedRays, radius, phi, lumaPhi, depthPhi, normalPhi, roughnessPhi, specularPhi (tools/fuzz_oracle_vs_gl.py)."""
     with O.uv_model({"ideal": "ideal", "reference_gl": "reference"}[uv_model]):
         return _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start, denoise_start, shader_dir, log,
-                    with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model, rows, compare_only)
+                    with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model, rows, compare_only, options)
 
 
 def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi_start, denoise_start, shader_dir, log,
-         with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model, rows=None, compare_only=None):
+         with_margins, n_perturb, sample_every, extra_perturb, compare_from, uv_model, rows=None, compare_only=None, options=None):
     import chain
+    options = dict(options or {})
+    unknown = set(options) - {"distance", "thickness", "missedRays", "radius", "phi", "lumaPhi", "depthPhi", "normalPhi", "roughnessPhi", "specularPhi"}
+    assert not unknown, unknown
     y0, y1 = (0, H) if rows is None else (max(0, int(rows[0])), min(H, int(rows[1])))
-    ref = chain.GLRefChain(W, H, blue, shader_dir=shader_dir, steps=steps, refineSteps=refine, denoiseIterations=iterations)
+    ref = chain.GLRefChain(W, H, blue, shader_dir=shader_dir, steps=steps, refineSteps=refine, denoiseIterations=iterations, **options)
     impl = impl_cls(W, H, blue)
     if hasattr(impl, "set_uv_model"):
         impl.set_uv_model(uv_model)
@@ -291,6 +296,11 @@ def _run(impl_cls, W, H, steps, refine, iterations, frames, blue, frame_fn, ssgi
         if ora is not None:
             ora.frame(f)
         sp, tp, dp, cp = stage_params(f.camera, prev_cam or f.camera, keep, steps, refine)
+        for k, v in options.items():
+            if k in ("distance", "thickness", "missedRays"):
+                setattr(sp, {"distance": "rayDistance", "thickness": "thickness", "missedRays": "missedRays"}[k], v)
+            else:
+                setattr(dp, k, v)
         tag = "f%d " % fi
         if fi < compare_from or (compare_only is not None and fi not in compare_only):  # only advance the reference chain (its state after frame fi is what frame fi + 1 is compared on)
             si = (ssgi_start + si + 1) % M31

@@ -1,4 +1,5 @@
 """CPU: the strict parity metric and the oracle's two flip-proof mechanisms (tests/parity.py, oracle/rfx_oracle.c)."""
+import os
 import numpy as np
 import pytest
 
@@ -138,3 +139,20 @@ def test_stagewise_under_the_reference_vuv_only_k1_can_flip(blue_noise):
         if " K3 " in r.name or " K4 " in r.name:  # K2 keeps its own discontinuities (disocclusion tests on reprojected positions)
             assert r.bad == 0 and r.linf_abs <= 1e-3, r.line()
     assert sum(r.bad for r in reports) <= 1e-3 * W * H * 3
+
+
+def test_restatement_against_the_reference_glsl_at_random_sizes_and_options():
+    """tools/fuzz_vs_reference_gl.py: the C restatement against the reference's own GLSL on llvmpipe at random frame sizes (odd, tiny, portrait),
+    step counts, denoise iterations and option values (distance, thickness, missedRays, radius, the phi's), both vUv models — nothing unexplained
+    (24 cases here; 300 cases / 11.3 M pixels were clean when this was written, and 300 against the KERNELS on an MI355X:
+    profiles/r06_parity/) — and its self-test: with one uniform of the restatement perturbed per stage the proofs must NOT explain the
+    difference away on any of K1 / K2 / K3."""
+    import subprocess
+    import sys
+    _glref_or_skip()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = [sys.executable, os.path.join(root, "tools", "fuzz_vs_reference_gl.py")]
+    p = subprocess.run(tool + ["--n", "24", "--seed", "21"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and " 0 unexplained; 0 errors" in p.stdout.splitlines()[-1], (p.stdout + p.stderr)[-3000:]
+    p = subprocess.run(tool + ["--n", "8", "--seed", "21", "--self-test"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "self-test" in p.stdout.splitlines()[-1], (p.stdout + p.stderr)[-3000:]
