@@ -783,12 +783,16 @@ static inline void calc_angles(v3 l, v3 v, v3 n, float *NoL, float *NoH, float *
  * conditionalWeights env_w x env_h read at (blueNoise.y, v); the pixel is whatever ivec2(vUv * resolution) makes of it = (px, py) */
 static inline void k1_cdf_uv(const k1_ctx *c, int px, int py, float *u, float *v) {
     dims dres = {c->outW, c->outH};
-    {   /* A quad partner that is a background texel (main() returned at :109-113) or lies outside the target never ran the blue-noise fetch:
-         * on the oracle's GL its `random` still holds the zero initialisation, so it contributes the table entry of (0, 0) to the quad's
-         * derivatives (GLSL leaves derivatives after a non-uniform return undefined; measured on llvmpipe, reproduced) */
+    {   /* A quad partner that is a background texel (main() returned at :109-113) never ran the blue-noise fetch: on the oracle's GL its
+         * `random` still holds the zero initialisation, so it contributes the table entry of (0, 0) to the quad's derivatives (GLSL leaves
+         * derivatives after a non-uniform return undefined; measured on llvmpipe, reproduced).  A partner OUTSIDE the target (the last
+         * column / row of an odd-sized one) is a helper invocation like any other: it runs the fragment on its extrapolated vUv — the depth
+         * fetch clamps to the edge texel, the blue-noise pixel is ivec2(vUv * resolution) = (px, py) beyond the target.  (Until round 6 it
+         * was modelled like a background partner; tools/fuzz_variants_vs_reference_gl.py --only-envmis on odd sizes: 651 unexplained
+         * pixels of the last column before, none after.) */
         dims d = {c->W, c->H};
         float pu = frag_u(px, py, c->outW, c->outH), pv = frag_v(py, c->outW, c->outH);
-        if (px >= c->outW || py >= c->outH || fetch_r32f(c->depth, d, pu, pv) == 1.0f) {
+        if (fetch_r32f(c->depth, d, pu, pv) == 1.0f) {
             *v = c->marginal[0];
             *u = c->conditional[(size_t)nearest_idx(*v, c->env_h) * c->env_w + 0];
             return;

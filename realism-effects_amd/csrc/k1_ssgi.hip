@@ -417,16 +417,16 @@ RFX_DEV float3 k1_env_color(const K1Args &A, float3 l, float roughness, bool isD
 // ---- importanceSampling (ssgi.frag:197-216, sampleEquirectProbability ssgi_utils.frag:210-225)
 // uv of the environment texel the pixel's blue-noise pair selects through the two inverse-CDF tables: marginalWeights is an env_h x 1 NEAREST
 // texture read at (blueNoise.x, 0), conditionalWeights an env_w x env_h one read at (blueNoise.y, v)
-// A pixel that is background (main() returned before the blue-noise fetch, ssgi.frag:109-113) or outside the target takes part in its quad's
-// derivatives with `random` = 0, its zero initialisation: GLSL leaves derivatives after a non-uniform return undefined, this is what the
-// oracle's GL does (measured).
+// A pixel that is background (main() returned before the blue-noise fetch, ssgi.frag:109-113) takes part in its quad's derivatives with
+// `random` = 0, its zero initialisation: GLSL leaves derivatives after a non-uniform return undefined, this is what the oracle's GL does
+// (measured).  A quad partner OUTSIDE the target (the last column / row of an odd-sized one) is a helper invocation that runs the fragment on its
+// extrapolated vUv: the depth fetch clamps to the edge texel, its blue-noise pixel is (px, py) beyond the target (round 6: the reference GLSL at
+// random odd sizes, tools/fuzz_variants_vs_reference_gl.py).
 RFX_DEV float2 k1_cdf_uv(const K1Args &A, const FrameDims &d, int px, int py) {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (px < A.out_w && py < A.out_h) {
-        const int sx = rfx_nearest_idx(rfx_frag_u(A.out_uv, px, py), d.fW, d.W), sy = rfx_nearest_idx(rfx_frag_v(A.out_uv, py), d.fH, d.H);
-        if (((const float *)A.depth.ptr)[rfx_xy_index(d, A.depth.row0, A.depth.rows, sx, sy)] != 1.0f)
-            r = rfx_blue_noise((const uchar4 *)A.blue, px, py, A.shift_x, A.shift_y);
-    }
+    const int sx = rfx_nearest_idx(rfx_frag_u(A.out_uv, px, py), d.fW, d.W), sy = rfx_nearest_idx(rfx_frag_v(A.out_uv, py), d.fH, d.H);
+    if (((const float *)A.depth.ptr)[rfx_xy_index(d, A.depth.row0, A.depth.rows, sx, sy)] != 1.0f)
+        r = rfx_blue_noise((const uchar4 *)A.blue, px, py, A.shift_x, A.shift_y);
     const float v = A.env_marginal[rfx_nearest_idx(r.x, (float)A.env_h, A.env_h)];
     const float u = A.env_conditional[rfx_nearest_idx(v, (float)A.env_h, A.env_h) * A.env_w + rfx_nearest_idx(r.y, (float)A.env_w, A.env_w)];
     return make_float2(u, v);

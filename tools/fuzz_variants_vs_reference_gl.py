@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""The VARIANTS of the path against the reference's own GLSL, strict metric with proofs, at random sizes: the effect host (rfx_amd.effect
+SSGIEffect / SSREffect with random mode, denoiseMode, denoise iterations, resolutionScale, perspective / orthographic camera, environment with and
+without importance sampling, fog) drives the C restatement, and the reference chain on llvmpipe (oracle/glref GLRefChain, assembled from the
+reference's sources with the same options) performs the same draws IN LOCK STEP: before every draw the restatement's textures are set to the
+reference chain's (identical inputs), after it the written target is compared under tests/parity.py `strict` (absolute 1e-3 / adjacent
+binary16) and every out-of-tolerance pixel must be proven by the oracle (decision margin or conditioning: tests/stagewise.py prove_flips).
+tools/fuzz_vs_reference_gl.py does this for the default chain (and for the kernels on the device); the committed goldens pin the variants at
+one size each; this pins them at sizes and step counts nobody chose.
+
+    python tools/fuzz_variants_vs_reference_gl.py [--n 60] [--seed 1]        # the restatement; build container (reads the shaders from /root/reference)
+    python tools/fuzz_variants_vs_reference_gl.py --device [--n 60]          # the KERNELS against the reference chain, the restatement proving; on
+                                                                             # the GPU box from oracle/_ref/shaders (the variants `make -C oracle ref` assembled)
+
+TEST INFRASTRUCTURE."""
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (os.path.join(ROOT, "realism-effects_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "glref"), os.path.join(ROOT, "tests"),
+           os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, _p)
+import rfx_oracle as O  # noqa: E402
+import chain  # noqa: E402
+import stagewise as S  # noqa: E402
+from oracle_renderer import OracleRenderer  # noqa: E402
+from parity import out_of_tolerance, strict  # noqa: E402
+from test_oracle_vs_golden import ssr_unpack  # noqa: E402
+from rfx_amd import abi, effect  # noqa: E402
+from rfx_amd.scene import synthetic_environment, synthetic_frame  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=60)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--frames", type=int, default=2)
+ap.add_argument("--device", action="store_true", help="the implementation compared with the reference chain is librfx_hip.so on the GPU (or whatever "
+                "library rfx_amd.abi loads: the simulator under its test environment); the restatement still makes the proofs")
+ap.add_argument("--prebuilt", action="store_true", help="use oracle/_ref/shaders even where /root/reference exists (what the GPU box does)")
+ap.add_argument("--only-envmis", action="store_true", help="every case: mode ssgi, perspective, environment with importance sampling, odd frame sizes "
+                "(the implicit-lod fetch whose quad partners lie outside an odd-sized target)")
+ap.add_argument("--verbose", action="store_true", help="print both sides' values at the worst unexplained pixel of a stage output")
+ap.add_argument("--self-test", action="store_true", help="hand the RESTATEMENT a perturbed uniform per stage (K1 thickness x 0.5, K2 confidencePower x 2, "
+                "K3 depthPhi x 2): unexplained pixels must appear on all three kernels")
+a = ap.parse_args()
+os.environ.setdefault("LP_NUM_THREADS", str(os.cpu_count() or 8))
+have_src = os.path.isdir(chain.REFERENCE_SRC) and not a.prebuilt
+assert have_src or a.device, "needs the reference's shader sources (the build container)"
+SYNCED = [t for t in abi.TEX_FORMAT if t not in (abi.TEX_BLUE_NOISE,)]
+
+
+def h8(t):
+    return O.half_bits_to_float(np.ascontiguousarray(t).view(np.uint16))
+
+
+def _half_bits(tex):  # an RGBA16F GL target read back as float32 -> the half bit patterns (exactly representable)
+    return np.ascontiguousarray(tex.read().astype(np.float16).view(np.uint16))
+
+
+class GLLockstep(OracleRenderer):
+    """The renderer the effect sees = the restatement; every draw is also made on the reference chain, on whose textures both sides start."""
+
+    def __init__(self, W, H, c, report, dev=None):
+        super().__init__(W, H)
+        self.c, self.report, self.dev = c, report, dev
+        self.f = None
+        self.pass_i = 0
+
+    # --device: the library sees every upload and, before every draw, the same pulled state
+    def upload(self, tex, array, row0=None, rows=None):
+        super().upload(tex, array, row0, rows)
+        if self.dev is not None:
+            self.dev.upload(tex, array, row0, rows)
+
+    def set_environment(self, rgba, half_float_type=True, half_store_rtz=True):
+        super().set_environment(rgba, half_float_type=half_float_type, half_store_rtz=half_store_rtz)
+        if self.dev is not None:
+            self.dev.set_environment(rgba, half_float_type=half_float_type, half_store_rtz=half_store_rtz)
+
+    def set_environment_importance(self, marginal, conditional, total_sum):
+        super().set_environment_importance(marginal, conditional, total_sum)
+        if self.dev is not None:
+            self.dev.set_environment_importance(marginal, conditional, total_sum)
+
+    def begin_frame(self, f):
+        self.f, self.pass_i = f, 0
+        self.c.upload_frame(f)
+
+    # ---- reference chain -> restatement: the state every draw starts from
+    def _pull(self):
+        c, t = self.c, self.tex
+        k1 = np.ascontiguousarray(c.t_ssgi.read()).view(np.uint32)
+        t[abi.TEX_SSGI].reshape(-1)[:k1.size] = k1.reshape(-1)
+        for j in range(c.tc):
+            t[abi.TEX_TEMPORAL0 + j][...] = c.t_temporal[j].read()
+            t[(abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1)[j]][...] = _half_bits(c.t_A[j])
+            t[(abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1)[j]][...] = _half_bits(c.t_B[j])
+        t[abi.TEX_COMPOSE][...] = c.t_compose.read()
+        if c.t_fb is not None:
+            t[abi.TEX_FBCOPY_F32][...] = c.t_fb.read()
+
+    def _check(self, name, texs, draw, wants, views, halfs, ddraw=None):
+        """draw(): the restatement's draw (from the pulled state); wants[i]: the reference chain's target i; views[i]: texture -> (h, w, C) floats;
+        ddraw(dev): the same draw on the library (--device: ITS targets are compared, the restatement proves)"""
+        snap = {t: self.tex[t].copy() for t in texs}
+        if self.dev is not None:
+            for t in SYNCED:
+                self.dev.upload(t, self.tex[t])
+            ddraw(self.dev)
+            dev_outs = [self.dev.download(t) for t in texs]
+
+        def fn():
+            for t in texs:
+                self.tex[t][...] = snap[t]
+            draw()
+            return [self.tex[t].copy() for t in texs]
+        outs = fn() if self.dev is None else dev_outs
+        for i, t in enumerate(texs):
+            got, want = views[i](outs[i]), views[i](wants[i])
+            bad = out_of_tolerance(got, want, halfs[i])
+            proven = S.prove_flips(fn, lambda o, i=i: views[i](o[i]), bad, halfs[i], n_perturb=8, extra_perturb=96) if bad.any() else None
+            r = strict("%s.%d" % (name, i), got, want, explainable=proven, half=halfs[i])
+            if r.unexplained and a.verbose:
+                y, x = r.worst_unexplained[:2]
+                print("    %s (y %d, x %d)\n      restatement %s\n      reference   %s" % (r.name, y, x, np.array2string(got[y, x], precision=6), np.array2string(want[y, x], precision=6)))
+                one = np.zeros(got.shape[:2], bool)
+                one[y, x] = True
+                with O.pixel_mask(one):
+                    with O.margins(*one.shape) as mm:
+                        base = views[i](fn()[i])[y, x]
+                    dev = 0.0
+                    for seed in range(1, 257):
+                        with O.perturbation(seed):
+                            dev = max(dev, float(np.abs(views[i](fn()[i])[y, x] - base).max()))
+                print("      decision margin %.3g; largest move of the restatement's value under 256 perturbations of its primitives: %.3g (tolerance 1e-3, proof threshold 5e-4)" % (mm.plane[y, x], dev))
+            self.report(r)
+
+    # ---- the draws
+    def ssgi_march(self, p):
+        self._pull()
+        c = self.c
+        assert p.steps == c.o["steps"] and p.refineSteps == c.o["refineSteps"] and abs(p.rayDistance - c.o["distance"]) < 1e-6
+        c.ssgi(self.f.camera, p.blueNoiseIndex)
+        oW, oH = c.ssgi_size
+        want = np.zeros_like(self.tex[abi.TEX_SSGI])
+        k1 = np.ascontiguousarray(c.t_ssgi.read()).view(np.uint32)
+        want.reshape(-1)[:k1.size] = k1.reshape(-1)
+        cut = lambda t: np.ascontiguousarray(t).reshape(-1)[:oH * oW * 4].reshape(oH, oW, 4)  # noqa: E731
+        q = mutate(p, "thickness", 0.5)
+        if p.mode == 1:  # raw rgb floats + two halfs
+            self._check("K1rgb", [abi.TEX_SSGI], lambda: OracleRenderer.ssgi_march(self, q), [want], [lambda t: ssr_unpack(cut(t))[..., :3]], [False], lambda d: d.ssgi_march(p))
+            self._check("K1hl", [abi.TEX_SSGI], lambda: OracleRenderer.ssgi_march(self, q), [want], [lambda t: ssr_unpack(cut(t))[..., 3:]], [True], lambda d: d.ssgi_march(p))
+        else:
+            self._check("K1", [abi.TEX_SSGI], lambda: OracleRenderer.ssgi_march(self, q), [want], [lambda t: h8(cut(t))], [True], lambda d: d.ssgi_march(p))
+
+    def temporal_reproject(self, p):
+        self._pull()
+        c = self.c
+        assert p.textureCount == c.tc and not p.fullAccumulate and p.maxBlend == 1.0 and abs(p.neighborhoodClampIntensity - 0.5) < 1e-6
+        assert abs(p.keepData - c.keep_data) < 1e-6, (p.keepData, c.keep_data)
+        c.temporal(self.f.camera, camera_moved=True)
+        texs = [abi.TEX_TEMPORAL0, abi.TEX_TEMPORAL1][:c.tc]
+        q = mutate(p, "confidencePower", 2.0)
+        self._check("K2", texs, lambda: OracleRenderer.temporal_reproject(self, q), [c.t_temporal[j].read() for j in range(c.tc)], [lambda t: t] * c.tc, [False] * c.tc,
+                    lambda d: d.temporal_reproject(p))
+
+    def copy_framebuffer(self, dst):
+        self._pull()  # (the reference chain made its copy inside temporal(): TemporalReprojectPass.js:197-201)
+        assert dst == abi.TEX_FBCOPY_F32
+        before = self.c.t_fb.read()
+        OracleRenderer.copy_framebuffer(self, dst)
+        assert np.array_equal(self.tex[dst].view(np.uint32), np.ascontiguousarray(before).view(np.uint32)), "framebuffer copy"
+        if self.dev is not None:
+            self.dev.upload(abi.TEX_TEMPORAL0, self.tex[abi.TEX_TEMPORAL0])
+            self.dev.copy_framebuffer(dst)
+            assert np.array_equal(self.dev.download(dst).view(np.uint32), np.ascontiguousarray(before).view(np.uint32)), "framebuffer copy (library)"
+
+    def poisson_denoise(self, p):
+        self._pull()
+        c, i = self.c, self.pass_i
+        self.pass_i += 1
+        assert c.has_denoise and p.textureCount == c.tc and bool(p.inputIsTemporal) == (i == 0) and bool(p.writeToB) == (i % 2 == 1)
+        assert all(abs(getattr(p, k) - c.o[k]) < 1e-6 for k in ("radius", "phi", "lumaPhi", "depthPhi", "normalPhi", "roughnessPhi", "specularPhi"))
+        g, cam = c.p_denoise, self.f.camera
+        g.sampler("depthTexture", c.t_depth)
+        g.sampler("gBufferTexture", c.t_gbuffer)
+        g.sampler("blueNoiseTexture", c.t_blue)
+        for k in ("radius", "phi", "lumaPhi", "depthPhi", "normalPhi", "roughnessPhi", "specularPhi"):
+            g.set(k, float(c.o[k]))
+        for k, v in (("projectionMatrix", cam.projectionMatrix), ("projectionMatrixInverse", cam.projectionMatrixInverse), ("cameraMatrixWorld", cam.matrixWorld),
+                     ("viewMatrix", cam.matrixWorldInverse)):
+            g.set(k, v)
+        g.set("resolution", [float(c.W), float(c.H)])
+        g.set("blueNoiseSize", [128.0, 128.0])
+        src = c.t_temporal if i == 0 else (c.t_B if i % 2 == 0 else c.t_A)  # PoissonDenoisePass.js:135-149
+        dst = c.t_A if i % 2 == 0 else c.t_B
+        g.sampler("inputTexture", src[0])
+        if c.tc == 2:
+            g.sampler("inputTexture2", src[1])
+        g.set("blueNoiseIndex", int(p.blueNoiseIndex))
+        g.draw(dst[:c.tc])
+        texs = ([abi.TEX_DENOISE_B0, abi.TEX_DENOISE_B1] if p.writeToB else [abi.TEX_DENOISE_A0, abi.TEX_DENOISE_A1])[:c.tc]
+        q = mutate(p, "depthPhi", 2.0)
+        self._check("K3p%d" % min(i, 1), texs, lambda: OracleRenderer.poisson_denoise(self, q), [_half_bits(d) for d in dst[:c.tc]], [h8] * c.tc, [True] * c.tc,
+                    lambda d: d.poisson_denoise(p))
+
+    def compose(self, p):
+        self._pull()
+        self.c.compose(self.f.camera)
+        self._check("K4", [abi.TEX_COMPOSE], lambda: OracleRenderer.compose(self, p), [self.c.t_compose.read()], [lambda t: t], [False], lambda d: d.compose(p))
+
+    def final_compose(self, p):
+        self._pull()
+        want = chain.chain_final(self.c, self.f, fog_mode=int(p.fogMode), fog_color=tuple(float(x) for x in p.fogColor), fog_near=float(p.fogNear),
+                                 fog_far=float(p.fogFar), fog_density=float(p.fogDensity))
+        self._check("final", [abi.TEX_FINAL], lambda: OracleRenderer.final_compose(self, p), [want], [lambda t: t], [False], lambda d: d.final_compose(p))
+
+
+def mutate(p, field, k):
+    if not a.self_test:
+        return p
+    q = type(p).from_buffer_copy(p)
+    setattr(q, field, getattr(q, field) * k)
+    return q
+
+
+from make_golden import reference_importance  # noqa: E402  (the worker's CDF pass as the reference's JS computes it)
+
+PREBUILT = [(20, 5), (8, 2), (40, 5), (1, 0), (3, 1), (12, 3), (17, 6), (24, 0)]
+SHADERS = os.path.join(ROOT, "oracle", "_ref", "shaders")
+blue = np.fromfile(os.path.join(ROOT, "realism-effects_amd", "data", "blue_noise_128_rgba8.bin"), np.uint8).reshape(128, 128, 4)
+rng = np.random.RandomState(a.seed)
+tot = dict(cases=0, outputs=0, pixels=0, bad=0, explained=0, unexplained=0, errors=0)
+caught, kinds = {}, {}
+t0 = time.time()
+for it in range(a.n):
+    rs = float(rng.choice([1, 1, 1, 0.5, 0.25]))
+    W = int(rng.choice([rng.randint(2, 40), rng.randint(40, 160), 64, 65, 127]))
+    H = int(rng.choice([rng.randint(2, 24), rng.randint(24, 100), 8, 9, 72]))
+    if (W * rs) % 1 or (H * rs) % 1:
+        rs = 1.0
+    mode = str(rng.choice(["ssgi", "ssgi", "ssr"]))
+    dm = str(rng.choice(["full", "full_temporal", "denoised", "temporal"]))
+    ortho = float(rng.choice([0, 0, 3.2])) if mode == "ssgi" else 0.0  # (the reference chain assembles its ssr programs for the perspective camera)
+    envkind = str(rng.choice(["none", "none", "env", "envmis"])) if (mode == "ssgi" and not ortho) else "none"
+    fog = int(rng.choice([0, 0, 1, 2]))
+    uv = str(rng.choice(["ideal", "reference_gl"]))
+    if a.only_envmis:
+        mode, ortho, envkind, rs, W, H = "ssgi", 0.0, "envmis", 1.0, W | 1, H | 1
+    if not have_src:  # the GPU box: what `make -C oracle ref` assembled — perspective programs, missedRays false; ssr / env / envmis at steps 20 / 5
+        ortho = 0.0
+    opt = dict(mode=mode, denoiseMode=dm, denoiseIterations=int(rng.choice([1, 1, 2])), steps=int(rng.randint(1, 25)), refineSteps=int(rng.randint(0, 7)),
+               distance=float(rng.choice([0.5, 3.0, 10.0, 40.0])), thickness=float(rng.choice([0.1, 1.0, 10.0])), missedRays=bool(rng.randint(2)),
+               radius=float(rng.choice([1.0, 3.0, 3.0, 5.0])), phi=float(rng.choice([0.1, 0.5, 2.0])), lumaPhi=float(rng.choice([0.5, 5.0, 20.0])),
+               depthPhi=float(rng.choice([0.5, 2.0, 10.0])), normalPhi=float(rng.choice([5.0, 50.0])), roughnessPhi=float(rng.choice([1.0, 50.0])),
+               specularPhi=float(rng.choice([1.0, 50.0])), envBlur=float(rng.choice([0.0, 0.1, 0.5, 1.0])), resolutionScale=rs,
+               importanceSampling=envkind == "envmis")
+    if not have_src:
+        opt["missedRays"] = False
+        opt["steps"], opt["refineSteps"] = (20, 5) if (mode == "ssr" or envkind != "none") else PREBUILT[rng.randint(len(PREBUILT))]
+    cfg = dict(W=W, H=H, ortho=ortho, env=envkind, fog=fog, uv=uv, **opt)
+    kind = "%s/%s%s%s%s" % (mode, dm, "/ortho" if ortho else "", "/" + envkind if envkind != "none" else "", "/rs%g" % rs if rs != 1 else "")
+    kinds[kind] = kinds.get(kind, 0) + 1
+
+    def report(r):
+        tot["outputs"] += 1
+        tot["pixels"] += r.pixels
+        tot["bad"] += r.bad
+        tot["explained"] += r.explained
+        tot["unexplained"] += r.unexplained
+        if r.unexplained:
+            caught[r.name[:2]] = caught.get(r.name[:2], 0) + r.unexplained
+            if not a.self_test:
+                print("UNEXPLAINED %s: %d of %d out-of-tolerance pixels, worst %s  cfg %s" % (r.name, r.unexplained, r.bad, r.worst_unexplained, cfg), flush=True)
+    try:
+        kw = dict(ortho_half_height=ortho) if ortho else {}
+        frames = [synthetic_frame(W, H, i, **kw) for i in range(a.frames)]
+        env = synthetic_environment(64, 32) if envkind != "none" else None
+        importance = reference_importance(np.ascontiguousarray(env, np.float32).astype(np.float16).astype(np.float32)) if envkind == "envmis" else None
+        gopt = {k: v for k, v in opt.items() if k != "importanceSampling"}
+        c = chain.GLRefChain(W, H, blue, shader_dir=None if have_src else SHADERS, environment=env, importance=importance, orthographic=bool(ortho), **gopt)
+        scene = types.SimpleNamespace(frame=frames[0])
+        if env is not None:
+            scene.environment = dict(data=env, type=effect.HalfFloatType)
+        if fog == 1:
+            scene.fog = types.SimpleNamespace(color=(0.3, 0.5, 0.7), near=1.0, far=6.0)
+        elif fog == 2:
+            scene.fog = types.SimpleNamespace(color=(0.6, 0.5, 0.4), density=0.15, isFogExp2=True)
+        cam = types.SimpleNamespace(**vars(frames[0].camera))
+        dev = None
+        if a.device:
+            from rfx_amd.context import Context
+            dev = Context(W, H)
+            dev.set_uv_model(uv)
+        R = GLLockstep(W, H, c, report, dev)
+        with O.uv_model({"ideal": "ideal", "reference_gl": "reference"}[uv]):
+            fx = effect.SSGIEffect(None, scene, cam, dict(width=W, height=H, **opt), seeds=dict(ssgi=10 + it, denoise=500 + it), half_store_rtz=True)
+            for f in frames:
+                scene.frame = f
+                for k, v in vars(f.camera).items():
+                    setattr(cam, k, v)
+                R.begin_frame(f)
+                fx.update(R, None)
+                fx.mainImage(R)
+        tot["cases"] += 1
+        if dev is not None:
+            assert dev.halo_violations() == 0
+            dev.close()
+    except Exception as e:  # noqa: BLE001
+        tot["errors"] += 1
+        import traceback
+        print("ERROR %r cfg %s\n%s" % (e, cfg, traceback.format_exc(limit=4)), flush=True)
+    if (it + 1) % 10 == 0:
+        print("... %d / %d cases, %d unexplained, %d errors, %.0f s" % (it + 1, a.n, tot["unexplained"], tot["errors"], time.time() - t0), flush=True)
+print("variants drawn: " + ", ".join("%s x%d" % kv for kv in sorted(kinds.items())))
+print("%(cases)d cases, %(outputs)d stage outputs, %(pixels)d pixels compared: %(bad)d outside the strict tolerance, %(explained)d proven (discontinuity / "
+      "conditioning), %(unexplained)d unexplained; %(errors)d errors" % tot)
+if a.self_test:
+    print("self-test: unexplained pixels per kernel with the restatement's uniform perturbed: %s" % caught)
+    sys.exit(0 if all(caught.get(k, 0) > 0 for k in ("K1", "K2", "K3")) and not tot["errors"] else 1)
+sys.exit(1 if tot["unexplained"] or tot["errors"] else 0)
