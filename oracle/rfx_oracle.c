@@ -708,6 +708,13 @@ static v3 k1_env_color(const k1_ctx *c, v3 l, float roughness, int isDiffuseSamp
     /* equirectDirectionToUv ssgi_utils.frag:64-74 */
     float u = atan2f(dir.z, dir.x) / (2.0f * M_PIf), v = mesa_acos(dir.y) / M_PIf;
     u += 0.5f; v = 1.0f - v;
+    /* The equirect u is undefined at the poles: a direction whose components are known to +-unc has u known to +-unc / (2 pi rho) of the
+     * map's width, rho = |(dir.x, dir.z)|.  A cosine-hemisphere sample with blue-noise byte 0 IS the surface normal — straight up over a floor —
+     * and its u is then the atan2 of two rounding residues of the view -> world transform: two implementations with ulp-accurate
+     * inversesqrt agree on nothing there, and the deeper levels of the chain (envBlur) do differ along their top row.  Unstable when that
+     * uncertainty exceeds 1e-3 texel of level 0.  (Round 6: the kernels against the reference chain over the variants, 1 pixel in 4000 at
+     * envBlur 0.5; tools/diag/env_device_vs_oracle.py.) */
+    margin_note((sqrtf)(dir.x * dir.x + dir.z * dir.z) * (2.0f * M_PIf) * 1e-3f / (g_unc_dir * (float)c->env_w));
     v3 col = k1_env_trilinear(c, u, v, mip);
     const float maxEnvLum = isEnvSample ? 100.0f : 25.0f; /* :328-340 */
     float envLum = lum(col);

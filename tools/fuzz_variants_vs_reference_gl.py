@@ -228,7 +228,8 @@ def mutate(p, field, k):
     return q
 
 
-from make_golden import reference_importance  # noqa: E402  (the worker's CDF pass as the reference's JS computes it)
+if have_src:
+    from make_golden import reference_importance  # noqa: E402  (the worker's CDF pass as the reference's JS computes it)
 
 PREBUILT = [(20, 5), (8, 2), (40, 5), (1, 0), (3, 1), (12, 3), (17, 6), (24, 0)]
 SHADERS = os.path.join(ROOT, "oracle", "_ref", "shaders")
@@ -280,7 +281,15 @@ for it in range(a.n):
         kw = dict(ortho_half_height=ortho) if ortho else {}
         frames = [synthetic_frame(W, H, i, **kw) for i in range(a.frames)]
         env = synthetic_environment(64, 32) if envkind != "none" else None
-        importance = reference_importance(np.ascontiguousarray(env, np.float32).astype(np.float16).astype(np.float32)) if envkind == "envmis" else None
+        importance = None
+        if envkind == "envmis":  # what the reference's worker computes from the half-float map's texels: its own JS restated (tests/golden/make_golden.py,
+            # reads the reference's source), or — on the GPU box — the host's tables, which the goldens pin against exactly that
+            texels = np.ascontiguousarray(env, np.float32).astype(np.float16).astype(np.float32)
+            if have_src:
+                importance = reference_importance(texels)
+            else:
+                from rfx_amd.envmap import build_importance
+                importance = build_importance(texels, False)
         gopt = {k: v for k, v in opt.items() if k != "importanceSampling"}
         c = chain.GLRefChain(W, H, blue, shader_dir=None if have_src else SHADERS, environment=env, importance=importance, orthographic=bool(ortho), **gopt)
         scene = types.SimpleNamespace(frame=frames[0])
