@@ -33,6 +33,28 @@ ap.add_argument("--self-test", action="store_true", help="hand the RESTATEMENT a
                 "x 2): the proofs must NOT explain that away — unexplained pixels on all three kernels, or the metric proves too much")
 a = ap.parse_args()
 os.environ.setdefault("LP_NUM_THREADS", str(os.cpu_count() or 8))
+CHUNK = 400  # the GL harness keeps every program it compiled (oracle/glref/glref.c: 2048 slots, 4 per case): larger batches run as child processes
+if a.n > CHUNK and not a.self_test:
+    import re
+    import subprocess
+    tot = dict(cases=0, outputs=0, pixels=0, bad=0, explained=0, unexplained=0, errors=0)
+    for k in range((a.n + CHUNK - 1) // CHUNK):
+        n = min(CHUNK, a.n - k * CHUNK)
+        argv = [sys.executable, os.path.abspath(__file__), "--n", str(n), "--seed", str(a.seed * 1000 + k), "--frames", str(a.frames)]
+        argv += [f for f, on in (("--device", a.device), ("--prebuilt", a.prebuilt)) if on]
+        out = subprocess.run(argv, capture_output=True, text=True).stdout
+        sys.stdout.write("".join(l + "\n" for l in out.splitlines() if l.startswith(("UNEXPLAINED", "ERROR"))))
+        m = re.search(r"(\d+) cases, (\d+) stage outputs, (\d+) pixels compared: (\d+) outside the strict tolerance, (\d+) proven .*?, (\d+) unexplained; (\d+) errors", out)
+        if not m:
+            tot["errors"] += n
+            print("chunk %d: no summary line\n%s" % (k, out[-2000:]), flush=True)
+            continue
+        for key, v in zip(("cases", "outputs", "pixels", "bad", "explained", "unexplained", "errors"), m.groups()):
+            tot[key] += int(v)
+        print("... chunk %d (seed %d): %s" % (k, a.seed * 1000 + k, m.group(0)), flush=True)
+    print("%(cases)d cases, %(outputs)d stage outputs, %(pixels)d pixels compared: %(bad)d outside the strict tolerance, %(explained)d proven (discontinuity / "
+          "conditioning), %(unexplained)d unexplained; %(errors)d errors" % tot)
+    sys.exit(1 if tot["unexplained"] or tot["errors"] else 0)
 blue = load_blue_noise_table()
 
 
