@@ -66,3 +66,14 @@ def test_fuzz_kernels_against_the_reference_chain_over_the_variants():
     assert " 0 unexplained; 0 errors" in last, last
     last = _run("fuzz_variants_vs_reference_gl.py", "--device", "--n", "12", "--seed", "105", "--only-envmis")
     assert " 0 unexplained; 0 errors" in last, last
+
+
+@pytest.mark.gpu
+def test_fuzz_cube_conversion_and_packers():
+    """tools/fuzz_aux_vs_reference_gl.py --device: rfx_cube_to_equirect at random face sizes (odd ones, with and without the chain) and the importer's
+    packers at random frame sizes — against the reference GLSL where its sources are, against the restatement on the GPU box (which the same tool
+    holds against the reference GLSL in the build container: tests/test_parity_metric.py)."""
+    if os.path.isdir("/root/reference/src"):
+        _gl_or_skip()
+    last = _run("fuzz_aux_vs_reference_gl.py", "--device", "--n", "80", "--seed", "106")
+    assert last.endswith(" 0 problems"), last

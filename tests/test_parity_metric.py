@@ -177,3 +177,17 @@ def test_variants_against_the_reference_glsl_in_lock_step_at_random_sizes():
         assert p.returncode == 0 and " 0 unexplained; 0 errors" in p.stdout, (extra, (p.stdout + p.stderr)[-3000:])
     p = subprocess.run(tool + ["--n", "8", "--seed", "4", "--self-test"], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "self-test" in p.stdout.splitlines()[-1], (p.stdout + p.stderr)[-3000:]
+
+
+def test_cube_conversion_and_packers_against_the_reference_glsl_at_random_sizes():
+    """tools/fuzz_aux_vs_reference_gl.py: the restatement's CubeToEquirectEnvPass (random face sizes, odd ones too, with / without the chain) and
+    packers (random frame sizes and scenes, HDR emissive) against the reference GLSL on llvmpipe — every equirect texel inside the fp32 rule, the
+    packed words bit for bit."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("assembles the two programs from the reference's sources")
+    _glref_or_skip()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_aux_vs_reference_gl.py"), "--n", "80", "--seed", "31"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and p.stdout.splitlines()[-1].endswith(" 0 problems"), (p.stdout + p.stderr)[-3000:]

@@ -242,6 +242,40 @@ class GLLockstep(OracleRenderer):
         self._check("final", [abi.TEX_FINAL], lambda: OracleRenderer.final_compose(self, p), [want], [lambda t: t], [False], lambda d: d.final_compose(p))
 
 
+class GLTraaLockstep(GLLockstep):
+    """TRAAEffect: K2 alone on the composer's input buffer, its own framebuffer copy as history (oracle/glref GLRefTRAA)."""
+
+    def _pull(self):
+        c, t = self.c, self.tex
+        if c.half:
+            t[abi.TEX_FBCOPY_F16][...] = _half_bits(c.t_fb)
+        else:
+            t[abi.TEX_FBCOPY_F32][...] = c.t_fb.read()
+        t[abi.TEX_TEMPORAL0][...] = c.t_out.read()
+
+    def temporal_reproject(self, p):
+        self._pull()
+        c = self.c
+        assert p.textureCount == 1 and not p.fullAccumulate and abs(p.maxBlend - 0.9) < 1e-6 and p.neighborhoodClampIntensity == 1.0 and p.keepData == 1.0
+        assert bool(p.targetHalf) == bool(c.half) and p.historySource == (1 if c.half else 2)
+        want = c.render(self.f.camera, camera_moved=True)
+        q = mutate(p, "confidencePower", 2.0)
+        self._check("K2traa", [abi.TEX_TEMPORAL0], lambda: OracleRenderer.temporal_reproject(self, q), [want], [lambda t: t], [bool(c.half)],
+                    lambda d: d.temporal_reproject(p))
+
+    def copy_framebuffer(self, dst):
+        c = self.c
+        assert dst == (abi.TEX_FBCOPY_F16 if c.half else abi.TEX_FBCOPY_F32)
+        self.tex[abi.TEX_TEMPORAL0][...] = c.t_out.read()
+        want = _half_bits(c.t_fb) if c.half else np.ascontiguousarray(c.t_fb.read())
+        OracleRenderer.copy_framebuffer(self, dst)
+        assert np.array_equal(np.ascontiguousarray(self.tex[dst]).view(np.uint8), want.view(np.uint8)), "framebuffer copy"
+        if self.dev is not None:
+            self.dev.upload(abi.TEX_TEMPORAL0, self.tex[abi.TEX_TEMPORAL0])
+            self.dev.copy_framebuffer(dst)
+            assert np.array_equal(np.ascontiguousarray(self.dev.download(dst)).view(np.uint8), want.view(np.uint8)), "framebuffer copy (library)"
+
+
 def mutate(p, field, k):
     if not a.self_test:
         return p
@@ -272,6 +306,9 @@ for it in range(a.n):
     envkind = str(rng.choice(["none", "none", "env", "envmis"])) if (mode == "ssgi" and not ortho) else "none"
     fog = int(rng.choice([0, 0, 1, 2]))
     uv = str(rng.choice(["ideal", "reference_gl"]))
+    traa = str(rng.choice(["no", "no", "no", "no", "no", "half", "float"]))
+    if a.only_envmis:
+        traa = "no"
     if a.only_envmis:
         mode, ortho, envkind, rs, W, H = "ssgi", 0.0, "envmis", 1.0, W | 1, H | 1
     if not have_src:  # the GPU box: what `make -C oracle ref` assembled — perspective programs, missedRays false; ssr / env / envmis at steps 20 / 5
@@ -286,7 +323,9 @@ for it in range(a.n):
         opt["missedRays"] = False
         opt["steps"], opt["refineSteps"] = (20, 5) if (mode == "ssr" or envkind != "none") else PREBUILT[rng.randint(len(PREBUILT))]
     cfg = dict(W=W, H=H, ortho=ortho, env=envkind, fog=fog, uv=uv, **opt)
-    kind = "%s/%s%s%s%s" % (mode, dm, "/ortho" if ortho else "", "/" + envkind if envkind != "none" else "", "/rs%g" % rs if rs != 1 else "")
+    if traa != "no":
+        cfg = dict(W=W, H=H, uv=uv, traa=traa)
+    kind = "traa/" + traa if traa != "no" else "%s/%s%s%s%s" % (mode, dm, "/ortho" if ortho else "", "/" + envkind if envkind != "none" else "", "/rs%g" % rs if rs != 1 else "")
     kinds[kind] = kinds.get(kind, 0) + 1
 
     def report(r):
@@ -300,8 +339,31 @@ for it in range(a.n):
             if not a.self_test:
                 print("UNEXPLAINED %s: %d of %d out-of-tolerance pixels, worst %s  cfg %s" % (r.name, r.unexplained, r.bad, r.worst_unexplained, cfg), flush=True)
     try:
-        kw = dict(ortho_half_height=ortho) if ortho else {}
-        frames = [synthetic_frame(W, H, i, **kw) for i in range(a.frames)]
+        kw = dict(ortho_half_height=ortho) if (ortho and traa == "no") else {}
+        frames = [synthetic_frame(W, H, i, **kw) for i in range(a.frames + (1 if traa != "no" else 0))]
+        if traa != "no":
+            dev = None
+            if a.device:
+                from rfx_amd.context import Context
+                dev = Context(W, H)
+                dev.set_uv_model(uv)
+            c = chain.GLRefTRAA(W, H, half=traa == "half", shader_dir=None if have_src else SHADERS)
+            scene = types.SimpleNamespace(frame=frames[0])
+            cam = types.SimpleNamespace(**vars(frames[0].camera))
+            R = GLTraaLockstep(W, H, c, report, dev)
+            with O.uv_model({"ideal": "ideal", "reference_gl": "reference"}[uv]):
+                tx = effect.TRAAEffect(scene, cam, effect.VelocityDepthNormalPass(scene, cam), dict(fullAccumulate=True), half_store_rtz=True)
+                for f in frames:
+                    scene.frame = f
+                    for k, v in vars(f.camera).items():
+                        setattr(cam, k, v)
+                    R.begin_frame(f)
+                    tx.update(R, dict(texture=dict(type=effect.HalfFloatType if traa == "half" else effect.FloatType), width=W, height=H, data=f.direct))
+            tot["cases"] += 1
+            if dev is not None:
+                assert dev.halo_violations() == 0
+                dev.close()
+            raise StopIteration
         env = synthetic_environment(64, 32) if envkind != "none" else None
         importance = None
         if envkind == "envmis":  # what the reference's worker computes from the half-float map's texels: its own JS restated (tests/golden/make_golden.py,
@@ -341,6 +403,8 @@ for it in range(a.n):
         if dev is not None:
             assert dev.halo_violations() == 0
             dev.close()
+    except StopIteration:  # (a TRAAEffect case: done above)
+        pass
     except Exception as e:  # noqa: BLE001
         tot["errors"] += 1
         import traceback
