@@ -1501,3 +1501,42 @@ def test_denoise_with_nan_texels_stays_inside_its_tile(blue_noise):
         for j in range(2):
             g, w = O.half_bits_to_float(got[j])[clean][None], O.half_bits_to_float(want[j])[clean][None]
             assert_close("%s%d (pixels away from the NaN texels)" % (name, j), g, w, FLIP["denoise"])
+
+
+@pytest.mark.gpu
+def test_row_tiled_env_importance_sampling_at_an_odd_size_is_bit_identical():
+    """K1 with scene.environment and importance sampling on an ODD-sized frame (the implicit-lod fetch whose quad partners lie beyond the last column
+    and row: round 6), cut into 2 and 3 row tiles: every tile's rows equal the whole context's, bit for bit, no halo violation — the partner rows
+    a tile needs beyond its own are the depth plane's, which every tile holds whole."""
+    from rfx_amd import abi
+    from rfx_amd.context import Context
+    from rfx_amd.envmap import build_importance
+    from rfx_amd.scene import synthetic_environment, synthetic_frame
+
+    W, H = 65, 37
+    env = synthetic_environment(64, 32)
+    imp = build_importance(env.astype(np.float16).astype(np.float32), False)
+    f = synthetic_frame(W, H, 1)
+    comp = np.random.RandomState(1).rand(H, W, 4).astype(np.float32)
+    sp, _, _, _ = _params(abi, f, f.camera, 1.0, 12, 3)
+    sp.useEnvMap, sp.importanceSampling, sp.envBlur, sp.blueNoiseIndex = 1, 1, 0.5, 77
+
+    def run(ctx):
+        ctx.set_environment(env, half_float_type=True, half_store_rtz=True)
+        ctx.set_environment_importance(*imp)
+        ctx.upload_frame(f)
+        ctx.upload(abi.TEX_COMPOSE, comp)
+        ctx.ssgi_march(sp)
+    whole = Context(W, H)
+    run(whole)
+    ref = whole.download(abi.TEX_SSGI)
+    whole.close()
+    assert (ref[:, -1] != 0).any()
+    for n in (2, 3):
+        for r in range(n):
+            y0, rows = Context.split_rows(H, n, r)
+            c = Context(W, H, tile_y0=y0, tile_rows=rows, halo_rows=4)
+            run(c)
+            assert np.array_equal(c.download(abi.TEX_SSGI, y0, rows), ref[y0:y0 + rows]), (n, r)
+            assert c.halo_violations() == 0
+            c.close()
