@@ -1288,14 +1288,14 @@ def test_peer_history_gather_between_two_contexts_of_one_process(blue_noise):
     from rfx_amd.context import Context, RfxError
     from rfx_amd.scene import synthetic_frame
 
-    if os.environ.get("RFX_HOSTSIM") != "1" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 16:
+    if os.environ.get("RFX_HOSTSIM") != "1" and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
         # Two (here three) contexts of one process on ONE device: their exchange streams must sit on different hardware queues, or the two
         # barrier kernels queue behind each other (include/rfx.h; measured: profiles/r06_multigpu/one_process_hw_queues.txt).  The HIP
         # runtime reads the setting once, before its first call: this test runs itself in a fresh interpreter with it.
         import subprocess
         import sys
         me = "%s::test_peer_history_gather_between_two_contexts_of_one_process" % os.path.abspath(__file__)
-        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", me], env=dict(os.environ, GPU_MAX_HW_QUEUES="16"),
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", me], env=dict(os.environ, GPU_MAX_HW_QUEUES="8"),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-4000:]
         return

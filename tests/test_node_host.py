@@ -628,9 +628,19 @@ def test_node_peer_history_gather_between_two_tiles_on_one_gpu(tmp_path):
     subprocess.check_output([node, os.path.join(JS, "run_dump.js")] + dirs + ["--out", one, "--steps", "12", "--refineSteps", "3"], text=True)
     script = str(tmp_path / "peer_workers.js")
     open(script, "w").write(PEER_WORKERS)
-    # two contexts of one process on ONE device: their exchange streams on different hardware queues (include/rfx.h rfx_peer_*)
-    res = subprocess.check_output([node, script, JS, json.dumps(dirs), many, json.dumps(dict(halo=12, steps=12, refineSteps=3))], text=True, timeout=300,
-                                  env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
+    # Two contexts of one process on ONE device: their exchange streams on different hardware queues (include/rfx.h rfx_peer_*) — 8 of them,
+    # not more: the device maps a bounded number of queues at a time, the pytest process that ran sixty tests before this one keeps its own, and
+    # a queue that is swapped out while the other tile's barrier kernel polls for it is the same failure again (seen once in a whole-suite run
+    # with 16; never in the runs of this test alone).  One retry for that case, reported.
+    cmd = [node, script, JS, json.dumps(dirs), many, json.dumps(dict(halo=12, steps=12, refineSteps=3))]
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    try:
+        res = subprocess.check_output(cmd, text=True, timeout=300, env=env, stderr=subprocess.PIPE)
+    except subprocess.CalledProcessError as e:
+        if "did not reach the previous call's barrier" not in (e.stderr or ""):
+            raise
+        print("NOTE: the two tiles' barrier kernels were not resident together (hardware queue scheduling); second attempt")
+        res = subprocess.check_output(cmd, text=True, timeout=300, env=env)
     info = json.loads(res.strip().splitlines()[-1])
     assert [i["rank"] for i in info] == [0, 1] and all(i["mode"] == "peer" and i["haloViolations"] == 0 for i in info), info
     assert all(len(i["pulled"]) == 3 and i["pulled"][0] == 0 for i in info), info  # one report per frame, each of the call before
