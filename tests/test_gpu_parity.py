@@ -1295,8 +1295,13 @@ def test_peer_history_gather_between_two_contexts_of_one_process(blue_noise):
         import subprocess
         import sys
         me = "%s::test_peer_history_gather_between_two_contexts_of_one_process" % os.path.abspath(__file__)
-        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", me], env=dict(os.environ, GPU_MAX_HW_QUEUES="8"),
-                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        for attempt in (1, 2):  # (one retry, reported, when the two barrier kernels were not resident together: hardware queue scheduling of a
+            # device that other processes — the pytest process itself — hold queues on; test_node_host.py has the same provision)
+            r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", me], env=dict(os.environ, GPU_MAX_HW_QUEUES="8"),
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+            if r.returncode == 0 or attempt == 2 or "did not reach the previous call's barrier" not in r.stdout:
+                break
+            print("NOTE: the two contexts' barrier kernels were not resident together (hardware queue scheduling); second attempt")
         assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-4000:]
         return
 
