@@ -281,8 +281,9 @@ int rfx_download_environment(rfx_ctx *, int level, float *rgba, int *levels);
  * FloatType render target as readRenderTargetPixels returns it: row 0 = bottom) — the DataTexture the effect then treats like any
  * equirectangular environment: hand it to rfx_set_environment(…, halfFloatType = 0) and build the importance tables from it.
  * generateMipmaps = 0: the cube is sampled LINEAR, seamless, at level 0 (minFilter LinearFilter: HDRCubeTextureLoader's set-up);
- * 1: three's CubeTexture default, LinearMipmapLinearFilter over the chain glGenerateMipmap builds (size a power of two), with the
- * implicit level of detail of `textureCube` (the pass minifies near the face edges: levels 0-2 take part). */
+ * 1: three's CubeTexture default, LinearMipmapLinearFilter over the chain glGenerateMipmap builds (any size since round 6: an odd level is
+ * reduced by the GL's bilinear blit, an even one by the 2x2 average it degenerates to), with the implicit level of detail of `textureCube`
+ * (the pass minifies near the face edges: levels 0-2 take part). */
 int rfx_cube_to_equirect(rfx_ctx *, const float *faces_rgba, int size, int generateMipmaps, float *equirect_rgba, int width, int height);
 
 /* ---- the four draws (+ the framebuffer copy and the effect's own fragment) */

@@ -1131,7 +1131,6 @@ static inline void cube_pass_direction(int x, int y, int W, int H, float *d) {
  * mipmaps = 0: the cube has level 0 only (minFilter LinearFilter); 1: LinearMipmapLinearFilter over the generated chain (S a power of two) */
 int rfxo_cube_to_equirect(const float *faces, int S, int mipmaps, int W, int H, float *out) {
     if (!faces || !out || S < 1 || W < 1 || H < 1) return -1;
-    if (mipmaps && (S & (S - 1))) return -1;
     const float *lv[16] = {faces};
     float *owned[16] = {0};
     int sizes[16] = {S}, levels = 1;
@@ -1139,7 +1138,20 @@ int rfxo_cube_to_equirect(const float *faces, int S, int mipmaps, int W, int H, 
         int s0 = sizes[levels - 1], s1 = s0 >> 1;
         float *dst = (float *)malloc((size_t)6 * s1 * s1 * 4 * sizeof(float));
         const float *src = lv[levels - 1];
-        for (int f = 0; f < 6; f++)
+        /* glGenerateMipmap on the oracle's GL is a LINEAR blit of every face on its own: a target texel fetches the source level at its centre,
+         * CLAMP_TO_EDGE, no neighbouring face.  From an even size that is the 2x2 average below (weights exactly one half); from an ODD size
+         * (faces that are not a power of two: 31 -> 15 -> 7 -> 3 -> 1, 12 -> 6 -> 3 -> 1) the general bilinear tap.  Round 6, measured:
+         * tools/fuzz_aux_vs_reference_gl.py, every equirect texel of faces 1..48 inside the fp32 rule. */
+        for (int f = 0; f < 6 && (s0 & 1); f++) {
+            dims d0 = {s0, s0};
+            for (int y = 0; y < s1; y++)
+                for (int x = 0; x < s1; x++) {
+                    v4 c = fetch_f4_linear(src + ((size_t)f * s0 * s0) * 4, d0, ((float)x + 0.5f) / (float)s1, ((float)y + 0.5f) / (float)s1);
+                    float *o = dst + 4 * (((size_t)f * s1 + y) * s1 + x);
+                    o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+                }
+        }
+        for (int f = 0; f < 6 && !(s0 & 1); f++)
             for (int y = 0; y < s1; y++)
                 for (int x = 0; x < s1; x++)
                     for (int k = 0; k < 4; k++) {

@@ -226,6 +226,16 @@ __global__ __launch_bounds__(256) void k0_cube_mip(const float4 *src, float4 *ds
     if (i >= 6 * s1 * s1) return;
     const int f = i / (s1 * s1), r = i - f * s1 * s1, y = r / s1, x = r - y * s1;
     const float4 *q = src + (size_t)f * s0 * s0;
+    if (s0 & 1) {  // a level of odd size (a face that is not a power of two): the GL's LINEAR blit of the face at the target texel's centre, CLAMP_TO_EDGE
+        int x0, x1, y0, y1;
+        float wx, wy;
+        rfx_linear_coord(((float)x + 0.5f) / (float)s1, (float)s0, s0, x0, x1, wx);
+        rfx_linear_coord(((float)y + 0.5f) / (float)s1, (float)s0, s0, y0, y1, wy);
+        const float4 t00 = q[(size_t)y0 * s0 + x0], t10 = q[(size_t)y0 * s0 + x1], t01 = q[(size_t)y1 * s0 + x0], t11 = q[(size_t)y1 * s0 + x1];
+        dst[i] = make_float4(rfx_lerp(wy, rfx_lerp(wx, t00.x, t10.x), rfx_lerp(wx, t01.x, t11.x)), rfx_lerp(wy, rfx_lerp(wx, t00.y, t10.y), rfx_lerp(wx, t01.y, t11.y)),
+                             rfx_lerp(wy, rfx_lerp(wx, t00.z, t10.z), rfx_lerp(wx, t01.z, t11.z)), rfx_lerp(wy, rfx_lerp(wx, t00.w, t10.w), rfx_lerp(wx, t01.w, t11.w)));
+        return;
+    }
     const float4 a = q[(size_t)(2 * y) * s0 + 2 * x], b = q[(size_t)(2 * y) * s0 + 2 * x + 1];
     const float4 c = q[(size_t)(2 * y + 1) * s0 + 2 * x], e = q[(size_t)(2 * y + 1) * s0 + 2 * x + 1];
     float4 o;
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(256) void k0_cube_mip(const float4 *src, float4 *ds
 
 }  // namespace
 
-// `chain` holds level 0 (6 * size * size texels) and room for the further levels (levels > 1: size a power of two), built here
+// `chain` holds level 0 (6 * size * size texels) and room for the further levels (size >> l, at least 1), built here
 hipError_t rfx_launch_cube_to_equirect(float4 *chain, int size, int levels, float4 *out, int W, int H, const UvPlanes &uv, hipStream_t stream) {
     K0Cube A;
     A.chain = chain; A.S = size; A.levels = levels; A.out = out; A.W = W; A.H = H; A.uv = uv;

@@ -531,7 +531,6 @@ int rfx_cube_to_equirect(rfx_ctx *c, const float *faces, int size, int generateM
     if (!c || !faces || !equirect) return RFX_EINVAL;
     if (size < 1 || size > 8192 || width < 1 || height < 1 || width > 16384 || height > 16384)
         return fail(c, RFX_EINVAL, "rfx_cube_to_equirect: face size must be 1..8192, the target 1..16384 in each edge");
-    if (generateMipmaps && (size & (size - 1))) return fail(c, RFX_EUNSUPPORTED, "rfx_cube_to_equirect: a mip chain needs a power-of-two face size");
     RFX_ENTER(c);
     int levels = 1;
     size_t nchain = (size_t)6 * size * size;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The two side draws of the path at random sizes against the reference's own GLSL on llvmpipe (oracle/glref):
-  * CubeToEquirectEnvPass (scene.environment as a CubeTexture): random face sizes (odd ones too), with and without the mip chain, at the pass's own
+  * CubeToEquirectEnvPass (scene.environment as a CubeTexture): random face sizes (odd ones too), with and without the mip chain (which for a face that is not a power of two goes through odd-sized levels), at the pass's own
     target size — every texel inside the fp32 rule of tests/parity.py (|a - b| <= 1e-3 or <= 1e-5 |b|);
   * the raster passes' packers (packGBuffer / packNormal) as the importer of attribute planes: random frame sizes and scenes, HDR emissive
     values sprinkled in — bit for bit on covered texels (the emissive word of BLACK-emissive texels apart: encodeRGBE8 takes log2(0), and what
@@ -60,7 +60,7 @@ for it in range(a.n):
     try:
         if it % 2 == 0:  # ---- cube -> equirect
             S = int(rng.choice([rng.randint(1, 9), rng.randint(9, 49), 16, 31, 32, 33]))
-            mip = bool(rng.randint(2)) and not (S & (S - 1))  # (the library builds glGenerateMipmap's chain for power-of-two faces only: include/rfx.h)
+            mip = bool(rng.randint(2))
             faces = cube_faces(S, 100 + it)
             import math
             W, H = (chain.cube_equirect_size(S) if have_src else (int(2 ** math.ceil(math.log2(2 * S * 3 ** 0.5))), int(2 ** math.ceil(math.log2(S * 3 ** 0.5)))))
